@@ -1,0 +1,300 @@
+/*
+ * serf_sim.h — C ABI of the MI355X bulk SWIM/Serf gossip simulator.
+ *
+ * This is the drop-in boundary for the hot path of al8n/serf (serf-core 0.5.1):
+ * Lamport-clocked broadcast / rebroadcast, the join/leave-intent state machine, the user-event
+ * and query de-duplication rings and the retransmit-limited piggyback queues — executed for all N
+ * simulated nodes per gossip tick on the GPU.  One call acts on every simulated node (bulk form).
+ *
+ * The reference has no FFI today (it is 100 % Rust, `#![forbid(unsafe_code)]`,
+ * serf-core/src/lib.rs:3).  The entry points below are what a Rust `extern "C"` block for this path
+ * would bind (see INTEGRATION.md for the binding).  Each entry point cites the reference interface
+ * it replaces.  All pointers are plain host pointers unless the name says `dev`; sizes are element
+ * counts unless they say bytes.  Return value: 0 = ok, < 0 = SIM_E* code.  A handle is
+ * single-threaded (the host serialises calls; parallelism is the GPU's).
+ *
+ * Both the HIP product library (serf_amd/csrc, exported with the prefix `sim_`) and the CPU oracle
+ * (oracle/, exported with the prefix `osim_`, TEST INFRASTRUCTURE ONLY) implement exactly this
+ * interface; only POD layouts and constants are shared through this header, never code.
+ */
+#ifndef SERF_SIM_H
+#define SERF_SIM_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ constants */
+
+#define SIM_ABI_VERSION 1u
+
+#define SIM_P 4u  /* piggyback records per gossip packet (64-byte packet)             */
+#define SIM_Q 16u /* retransmit-queue slots per node (all four queues share the pool) */
+#define SIM_C 6u  /* keys per de-dup ring bucket (32-byte bucket)                     */
+#define SIM_MAX_FANOUT 4u
+#define SIM_MAX_CONF 4u /* suspicion confirmers remembered per (observer, subject)   */
+
+/* error codes (serf-core/src/error.rs:64-81 maps its enum onto these for the bulk path) */
+#define SIM_OK 0
+#define SIM_EINVAL -1    /* bad argument / bad config                                  */
+#define SIM_ENOMEM -2    /* host or device allocation failed                           */
+#define SIM_EDEVICE -3   /* HIP runtime error (no GPU, launch failure)                 */
+#define SIM_ENOSLOT -4   /* no free view slot for a new active subject                 */
+#define SIM_ESTATE -5    /* call not valid in the node's SerfState (api.rs:422-437)    */
+#define SIM_ERANGE -6    /* output buffer too small                                    */
+#define SIM_ETOOBIG -7   /* user event / query larger than the configured limit        */
+
+/* MemberStatus — serf-core/src/types/member.rs:54-87 (same numeric values). */
+enum sim_member_status {
+  SIM_STATUS_NONE = 0,
+  SIM_STATUS_ALIVE = 1,
+  SIM_STATUS_LEAVING = 2,
+  SIM_STATUS_LEFT = 3,
+  SIM_STATUS_FAILED = 4
+};
+
+/* SerfState — serf-core/src/serf.rs:80-89. */
+enum sim_serf_state { SIM_SERF_ALIVE = 0, SIM_SERF_LEAVING = 1, SIM_SERF_LEFT = 2, SIM_SERF_SHUTDOWN = 3 };
+
+/* memberlist node state (memberlist-core 0.8.1, not vendored). */
+enum sim_swim_state { SIM_SWIM_ALIVE = 0, SIM_SWIM_SUSPECT = 1, SIM_SWIM_DEAD = 2, SIM_SWIM_LEFT = 3 };
+
+/* MemberEventType — serf-core/src/event.rs:263-279, plus user/query events (event.rs:367-378). */
+enum sim_event_type {
+  SIM_EV_JOIN = 0,
+  SIM_EV_LEAVE = 1,
+  SIM_EV_FAILED = 2,
+  SIM_EV_UPDATE = 3,
+  SIM_EV_REAP = 4,
+  SIM_EV_USER = 5,
+  SIM_EV_QUERY = 6
+};
+
+/* Piggyback record kinds.  1-4 are serf messages (serf-core/src/types/message.rs:17-28),
+ * 5-7 are memberlist's own state broadcasts (App. B.4). */
+enum sim_kind {
+  SIM_K_EMPTY = 0,
+  SIM_K_JOIN = 1,    /* JoinMessage{ltime,id}         types/join.rs:18-38            */
+  SIM_K_LEAVE = 2,   /* LeaveMessage{ltime,id,prune}  types/leave.rs:21-44           */
+  SIM_K_EVENT = 3,   /* UserEventMessage              types/user_event/message.rs:15 */
+  SIM_K_QUERY = 4,   /* QueryMessage (dedup fields)   types/query.rs:17-28           */
+  SIM_K_ALIVE = 5,
+  SIM_K_SUSPECT = 6,
+  SIM_K_DEAD = 7
+};
+
+/* record flags (4 bits) */
+#define SIM_F_PRUNE 1u        /* LeaveMessage.prune                       */
+#define SIM_F_NO_BROADCAST 1u /* QueryFlag::NO_BROADCAST (types/query.rs) */
+#define SIM_F_ACK 2u          /* QueryFlag::ACK                           */
+#define SIM_F_CC 1u           /* UserEventMessage.cc (coalesce)           */
+
+/*
+ * 16-byte piggyback record — the unit carried in packets and held in queues.
+ *   key : subject node id (JOIN/LEAVE/ALIVE/SUSPECT/DEAD), event key (EVENT) or query id (QUERY)
+ *   val : Lamport time (JOIN/LEAVE/EVENT/QUERY), incarnation (ALIVE),
+ *         incarnation | from << 32 (SUSPECT/DEAD)
+ *   meta: [31:30] class  [29:24] transmits  [23:18] 63-len64  [17:8] 1023-seq  [7:4] kind  [3:0] flags
+ * Comparing `meta` as an unsigned integer yields TransmitLimitedQueue's drain order
+ * (class asc, transmits asc, length desc, id desc — App. B.1); an empty slot is meta = 0xFFFFFFFF.
+ * On the wire class/transmits/seq are zero (SIM_META_WIRE_MASK).
+ */
+typedef struct sim_record {
+  uint32_t key;
+  uint32_t meta;
+  uint64_t val;
+} sim_record;
+
+#define SIM_META_EMPTY 0xFFFFFFFFu
+#define SIM_META_WIRE_MASK 0x00FC00FFu /* len, kind, flags */
+#define SIM_META_KIND(m) (((m) >> 4) & 0xFu)
+#define SIM_META_FLAGS(m) ((m)&0xFu)
+#define SIM_META_TRANSMITS(m) (((m) >> 24) & 0x3Fu)
+#define SIM_META_SEQ(m) (1023u - (((m) >> 8) & 0x3FFu))
+#define SIM_META_LEN64(m) (63u - (((m) >> 18) & 0x3Fu))
+
+/* 64-byte gossip packet: SIM_P records, empty records have meta == 0 on the wire. */
+typedef struct sim_packet {
+  sim_record rec[SIM_P];
+} sim_packet;
+
+/*
+ * 32-byte per-(observer, subject-slot) view entry.
+ *   bits: [0] known  [3:1] MemberStatus  [5:4] swim state  [7:6] buffered intent (0 none,1 join,2 leave)
+ *         [10:8] nconf  [31:11] stamp (tick, 21 bits: suspicion start / intent wall time / leave time)
+ *   ltime: status_time when known, buffered intent ltime otherwise (base.rs:1835-1866)
+ */
+typedef struct sim_view {
+  uint64_t ltime;
+  uint32_t inc;
+  uint32_t bits;
+  uint32_t conf[SIM_MAX_CONF];
+} sim_view;
+
+#define SIM_VB_KNOWN 1u
+#define SIM_VB_STATUS(b) (((b) >> 1) & 7u)
+#define SIM_VB_SWIM(b) (((b) >> 4) & 3u)
+#define SIM_VB_INTENT(b) (((b) >> 6) & 3u)
+#define SIM_VB_NCONF(b) (((b) >> 8) & 7u)
+#define SIM_VB_STAMP(b) ((b) >> 11)
+
+/* 32-byte de-dup ring bucket (event ring: base.rs:783-813, query ring: base.rs:1025-1042).
+ * keys[0] == 0 means "bucket absent" (None). */
+typedef struct sim_bucket {
+  uint64_t ltime;
+  uint32_t keys[SIM_C];
+} sim_bucket;
+
+/* 80-byte per-node row: the node's own (non-view) state.  serf.rs:133-169 (`SerfCore`): three
+ * Lamport clocks, EventCore/QueryCore min_time, SerfState; plus memberlist's incarnation. */
+typedef struct sim_row {
+  uint64_t clock, event_clock, query_clock; /* types/clock.rs:124; all start at 1     */
+  uint64_t event_min, query_min;            /* EventCore.min_time / QueryCore.min_time */
+  uint32_t flags;                           /* SIM_RF_*                                */
+  uint32_t inc;                             /* own incarnation (memberlist)            */
+  uint32_t n_known, n_failed, n_left;       /* |members.states|, |failed|, |left|      */
+  uint32_t next_seq;                        /* next TransmitLimitedQueue id            */
+  uint32_t overflow;                        /* records dropped by the Q bound          */
+  uint32_t susp_next;                       /* earliest suspicion deadline (tick), 0 = none */
+  uint32_t awareness;                       /* memberlist health score                 */
+  uint32_t probe_pending;                   /* subject awaiting a slot for suspect(), +1 */
+} sim_row;
+
+#define SIM_RF_UP 1u
+#define SIM_RF_STATE(f) (((f) >> 1) & 3u) /* enum sim_serf_state */
+#define SIM_RF_WATCHED 8u
+
+/* ------------------------------------------------------------------ configuration */
+
+typedef struct sim_config {
+  uint32_t struct_size;       /* sizeof(sim_config), for ABI checking                           */
+  uint32_t n_nodes;           /* N: simulated nodes, ids 0..N-1 (cluster-wide)                  */
+  uint32_t vshards;           /* V >= 1 virtual shards (N % V == 0, (N/V) % V == 0)             */
+  uint32_t shard_rank;        /* this process's shard when shard_count > 1                      */
+  uint32_t shard_count;       /* 1 (all V shards local) or V (one shard per process/GPU)        */
+  uint32_t fanout;            /* gossip_nodes: 3 = lan(), 4 = wan()   (1..SIM_MAX_FANOUT)       */
+  uint32_t view_slots;        /* A: active-subject slots; 0 or >= N => dense (slot == subject)  */
+  uint32_t event_ring;        /* event_buffer_size (options.rs:516), default 512                */
+  uint32_t query_ring;        /* query_buffer_size (options.rs:517), default 512                */
+  uint32_t retransmit_mult;   /* memberlist retransmit_mult, lan() = 4                          */
+  uint32_t probe_interval;    /* ticks per probe (lan: 1 s / 200 ms = 5); 0 = SWIM layer off    */
+  uint32_t suspicion_mult;    /* lan 4                                                          */
+  uint32_t suspicion_max_mult;/* lan 6                                                          */
+  uint32_t indirect_checks;   /* lan 3                                                          */
+  uint32_t loss_u32;          /* packet loss probability * 2^32 (0 = lossless)                  */
+  uint32_t intent_timeout;    /* recent_intent_timeout in ticks (options.rs:515), 0 = never     */
+  uint32_t leave_delay;       /* broadcast_timeout + leave_propagate_delay in ticks             */
+  uint32_t flags;             /* SIM_CF_*                                                       */
+  uint64_t seed;              /* master seed; default 0x5EEDC0DE5E4F0001                        */
+} sim_config;
+
+#define SIM_CF_BASELINE_JOINED 1u /* all nodes known+Alive at status_time 1, clock 2 (config 2-5) */
+#define SIM_DEFAULT_SEED 0x5EEDC0DE5E4F0001ull
+
+/* Stats — mirrors serf-core/src/serf/api.rs:586-602 (`Stats`) for one simulated node. */
+typedef struct sim_stats {
+  uint32_t members, failed, left;
+  uint32_t health_score;
+  uint64_t member_time, event_time, query_time; /* the three Lamport clocks          */
+  uint32_t intent_queue, event_queue, query_queue, swim_queue; /* queue depths       */
+  uint32_t serf_state;                          /* enum sim_serf_state               */
+  uint32_t up;                                  /* ground truth: process running     */
+  uint32_t incarnation;
+  uint32_t queue_overflow;                      /* records dropped by the Q bound    */
+} sim_stats;
+
+/* Event record surfaced for watched nodes (event.rs:325-378). */
+typedef struct sim_event {
+  uint32_t tick;
+  uint32_t observer;
+  uint32_t type;  /* enum sim_event_type                          */
+  uint32_t key;   /* subject id / event key / query id            */
+  uint64_t ltime; /* Lamport time of the message, 0 for member events from SWIM */
+} sim_event;
+
+typedef struct sim_handle sim_handle;
+
+/* Scheduled operation kinds for sim_inject. */
+enum sim_op {
+  SIM_OP_USER_EVENT = 1, /* a = event key (!= 0), b = encoded length in bytes     api.rs:241  */
+  SIM_OP_QUERY = 2,      /* a = query id (!= 0),  b = flags                       api.rs:304  */
+  SIM_OP_LEAVE = 3,      /* graceful leave of `node`                              api.rs:422  */
+  SIM_OP_JOIN = 4,       /* (re)join: a = peer                                    api.rs:318  */
+  SIM_OP_FORCE_LEAVE = 5,/* a = subject, b = prune                                api.rs:505  */
+  SIM_OP_CRASH = 6,      /* ground truth: process stops (tests `shutdown()` a node, event.rs:112) */
+  SIM_OP_REVIVE = 7,     /* ground truth: process resumes with its old state                   */
+  SIM_OP_LEAVE_FINISH = 8/* internal: memberlist.leave + state = Left (api.rs:462-497)         */
+};
+
+/* ------------------------------------------------------------------ entry points */
+
+/* Serf::new / new_in (api.rs:25, base.rs:62-344): allocate all N nodes' state in HBM.
+ * Clocks start at 1 (base.rs:198-205).  Fails with SIM_EDEVICE when no HIP device is usable. */
+int sim_create(const sim_config* cfg, sim_handle** out);
+/* Serf::shutdown (api.rs:525). */
+int sim_destroy(sim_handle* h);
+/* Use an existing HIP stream (e.g. torch's current stream) for all launches; NULL = default. */
+int sim_set_stream(sim_handle* h, void* hip_stream);
+
+/* Serf::join (api.rs:318) / Serf::leave (api.rs:422) / remove_failed_node(_prune) (api.rs:505,
+ * base.rs:452-480) / user_event (api.rs:241) / query (api.rs:304, base.rs:875) — applied at the
+ * start of the next tick, in call order. */
+int sim_join(sim_handle* h, uint32_t node, uint32_t peer);
+int sim_leave(sim_handle* h, uint32_t node);
+int sim_force_leave(sim_handle* h, uint32_t node, uint32_t subject, int prune);
+int sim_user_event(sim_handle* h, uint32_t node, uint32_t event_key, uint32_t encoded_len, int coalesce);
+int sim_query(sim_handle* h, uint32_t node, uint32_t query_id, uint32_t flags);
+/* Churn / packet-loss / kill / revive schedule: run `op` on `node` at the start of tick `tick`
+ * (reference analogue: MessageDropper delegate.rs:42-45 and tests that shutdown() a node). */
+int sim_inject(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, uint32_t b);
+
+/* The hot loop: n_ticks gossip intervals for every node.  Replaces, per node and tick:
+ * SerfDelegate::notify_message (delegate.rs:157-315), the handlers it dispatches to
+ * (base.rs:750-837, 972-1073, 1338-1373, 1442-1572), SerfDelegate::broadcast_messages
+ * (delegate.rs:317-384) and memberlist's TransmitLimitedQueue / gossip fan-out (App. B.1-B.2).
+ * Asynchronous on the handle's stream; sim_sync waits. */
+int sim_step(sim_handle* h, uint32_t n_ticks);
+int sim_sync(sim_handle* h);
+int sim_tick(const sim_handle* h, uint64_t* tick);
+
+/* Serf::members (api.rs:136) as seen by `observer`: out_status[s] = MemberStatus of subject s,
+ * out_ltime[s] = status_time.  cap must be >= N. */
+int sim_members(sim_handle* h, uint32_t observer, uint8_t* out_status, uint64_t* out_ltime, uint32_t cap);
+/* Serf::stats (api.rs:150-183). */
+int sim_stats_get(sim_handle* h, uint32_t node, sim_stats* out);
+/* Event stream (EventSubscriber, event.rs:430-491) for watched observers. */
+int sim_watch(sim_handle* h, uint32_t observer);
+int sim_drain_events(sim_handle* h, sim_event* out, uint32_t cap, uint32_t* n);
+
+/* Bit-exact comparison support.  The digest is 8 x u64: one order-independent 64-bit sum
+ * (sum over elements of mix64(index, value)) per state array:
+ * [0] rows [1] queues [2] inbox [3] view [4] event ring [5] query ring [6] ops/aux [7] reserved */
+int sim_state_digest(sim_handle* h, uint64_t out[8]);
+/* Raw dump of one state array of the local shard (host buffer).  which = enum sim_array.
+ * Call with buf == NULL to get the size in *bytes. */
+enum sim_array { SIM_ARR_ROWS = 0, SIM_ARR_QUEUE = 1, SIM_ARR_INBOX = 2, SIM_ARR_VIEW = 3,
+                 SIM_ARR_ERING = 4, SIM_ARR_QRING = 5, SIM_ARR_SLOTMAP = 6 };
+int sim_dump_state(sim_handle* h, uint32_t which, void* buf, size_t cap_bytes, size_t* bytes);
+
+/* Rumor convergence: number of up nodes that have applied the message (kind,key,ltime) and
+ * number of up nodes (rounds-to-99 % = first tick with seen >= 0.99 * up). */
+int sim_convergence(sim_handle* h, uint32_t kind, uint32_t key, uint64_t ltime,
+                    uint64_t* seen, uint64_t* up);
+
+/* Sharded mode (shard_count == V > 1): the tick kernel writes outgoing packets into `send` and
+ * reads incoming ones from `recv`, both DEVICE buffers of sim_exchange_bytes() bytes laid out as
+ * [V destinations][fanout][N/V/V packets].  The caller (serf_amd.shard, RCCL all_to_all_single)
+ * moves send -> recv between sim_step(h,1) calls. */
+int sim_exchange_bytes(const sim_handle* h, size_t* bytes);
+int sim_bind_exchange(sim_handle* h, void* send_dev, void* recv_dev);
+
+uint32_t sim_abi_version(void);
+const char* sim_backend_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SERF_SIM_H */

@@ -1,0 +1,249 @@
+"""ctypes binding of the C ABI declared in include/serf_sim.h.
+
+The binding is generic over (shared-library path, symbol prefix): the product library
+``serf_amd/csrc/libserf_sim.so`` exports ``sim_*``; a test may bind any other implementation of
+the same ABI (the CPU oracle exports ``osim_*``) by passing its own path — nothing in this package
+knows where such a library lives.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+P, Q, CKEYS, MAX_FANOUT = 4, 16, 6, 4
+DEFAULT_SEED = 0x5EEDC0DE5E4F0001
+
+OK, EINVAL, ENOMEM, EDEVICE, ENOSLOT, ESTATE, ERANGE, ETOOBIG = 0, -1, -2, -3, -4, -5, -6, -7
+_ERR = {EINVAL: "SIM_EINVAL", ENOMEM: "SIM_ENOMEM", EDEVICE: "SIM_EDEVICE", ENOSLOT: "SIM_ENOSLOT",
+        ESTATE: "SIM_ESTATE", ERANGE: "SIM_ERANGE", ETOOBIG: "SIM_ETOOBIG"}
+
+# enum sim_member_status (types/member.rs:54-87)
+STATUS_NONE, STATUS_ALIVE, STATUS_LEAVING, STATUS_LEFT, STATUS_FAILED = 0, 1, 2, 3, 4
+# enum sim_kind
+K_JOIN, K_LEAVE, K_EVENT, K_QUERY, K_ALIVE, K_SUSPECT, K_DEAD = 1, 2, 3, 4, 5, 6, 7
+# enum sim_op
+OP_USER_EVENT, OP_QUERY, OP_LEAVE, OP_JOIN, OP_FORCE_LEAVE, OP_CRASH, OP_REVIVE, OP_LEAVE_FINISH = 1, 2, 3, 4, 5, 6, 7, 8
+# enum sim_array
+ARR_ROWS, ARR_QUEUE, ARR_INBOX, ARR_VIEW, ARR_ERING, ARR_QRING, ARR_SLOTMAP = range(7)
+CF_BASELINE_JOINED = 1
+F_NO_BROADCAST = 1
+
+
+class SimError(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__(f"{what}: {_ERR.get(code, code)}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "struct_size", "n_nodes", "vshards", "shard_rank", "shard_count", "fanout", "view_slots",
+        "event_ring", "query_ring", "retransmit_mult", "probe_interval", "suspicion_mult",
+        "suspicion_max_mult", "indirect_checks", "loss_u32", "intent_timeout", "leave_delay",
+        "flags")] + [("seed", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("members", C.c_uint32), ("failed", C.c_uint32), ("left", C.c_uint32),
+                ("health_score", C.c_uint32), ("member_time", C.c_uint64),
+                ("event_time", C.c_uint64), ("query_time", C.c_uint64),
+                ("intent_queue", C.c_uint32), ("event_queue", C.c_uint32),
+                ("query_queue", C.c_uint32), ("swim_queue", C.c_uint32),
+                ("serf_state", C.c_uint32), ("up", C.c_uint32), ("incarnation", C.c_uint32),
+                ("queue_overflow", C.c_uint32)]
+
+
+class Event(C.Structure):
+    _fields_ = [("tick", C.c_uint32), ("observer", C.c_uint32), ("type", C.c_uint32),
+                ("key", C.c_uint32), ("ltime", C.c_uint64)]
+
+
+ROW_DTYPE = np.dtype([("clock", "<u8"), ("event_clock", "<u8"), ("query_clock", "<u8"),
+                      ("event_min", "<u8"), ("query_min", "<u8"), ("flags", "<u4"), ("inc", "<u4"),
+                      ("n_known", "<u4"), ("n_failed", "<u4"), ("n_left", "<u4"),
+                      ("next_seq", "<u4"), ("overflow", "<u4"), ("susp_next", "<u4"),
+                      ("awareness", "<u4"), ("probe_pending", "<u4")])
+REC_DTYPE = np.dtype([("key", "<u4"), ("meta", "<u4"), ("val", "<u8")])
+VIEW_DTYPE = np.dtype([("ltime", "<u8"), ("inc", "<u4"), ("bits", "<u4"), ("conf", "<u4", (4,))])
+BUCKET_DTYPE = np.dtype([("ltime", "<u8"), ("keys", "<u4", (CKEYS,))])
+_ARR_DTYPE = {ARR_ROWS: ROW_DTYPE, ARR_QUEUE: REC_DTYPE, ARR_INBOX: REC_DTYPE, ARR_VIEW: VIEW_DTYPE,
+              ARR_ERING: BUCKET_DTYPE, ARR_QRING: BUCKET_DTYPE, ARR_SLOTMAP: np.dtype("<u4")}
+
+# every symbol include/serf_sim.h declares (without prefix)
+ABI_SYMBOLS = ("create", "destroy", "set_stream", "join", "leave", "force_leave", "user_event",
+               "query", "inject", "step", "sync", "tick", "members", "stats_get", "watch",
+               "drain_events", "state_digest", "dump_state", "convergence", "exchange_bytes",
+               "bind_exchange", "abi_version", "backend_name")
+
+
+def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, view_slots=0,
+                event_ring=512, query_ring=512, retransmit_mult=4, probe_interval=0,
+                suspicion_mult=4, suspicion_max_mult=6, indirect_checks=3, loss=0.0,
+                intent_timeout=0, leave_delay=30, flags=CF_BASELINE_JOINED, seed=DEFAULT_SEED):
+    cfg = Config()
+    cfg.struct_size = C.sizeof(Config)
+    cfg.n_nodes, cfg.vshards, cfg.shard_rank, cfg.shard_count = n_nodes, vshards, shard_rank, shard_count
+    cfg.fanout, cfg.view_slots, cfg.event_ring, cfg.query_ring = fanout, view_slots, event_ring, query_ring
+    cfg.retransmit_mult, cfg.probe_interval = retransmit_mult, probe_interval
+    cfg.suspicion_mult, cfg.suspicion_max_mult, cfg.indirect_checks = suspicion_mult, suspicion_max_mult, indirect_checks
+    cfg.loss_u32 = min(0xFFFFFFFF, int(round(loss * 2 ** 32)))
+    cfg.intent_timeout, cfg.leave_delay, cfg.flags, cfg.seed = intent_timeout, leave_delay, flags, seed
+    return cfg
+
+
+class SimLib:
+    """One loaded implementation of the ABI."""
+
+    def __init__(self, path, prefix="sim_"):
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                f"{path} is missing — build it first (python -c 'import __graft_entry__ as g; g.build()')")
+        self.path, self.prefix = path, prefix
+        self.dll = C.CDLL(path)
+        self.f = {}
+        H, u32, u64, vp = C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p
+        sig = {
+            "create": (C.c_int, [C.POINTER(Config), C.POINTER(H)]),
+            "destroy": (C.c_int, [H]),
+            "set_stream": (C.c_int, [H, vp]),
+            "join": (C.c_int, [H, u32, u32]),
+            "leave": (C.c_int, [H, u32]),
+            "force_leave": (C.c_int, [H, u32, u32, C.c_int]),
+            "user_event": (C.c_int, [H, u32, u32, u32, C.c_int]),
+            "query": (C.c_int, [H, u32, u32, u32]),
+            "inject": (C.c_int, [H, u64, u32, u32, u32, u32]),
+            "step": (C.c_int, [H, u32]),
+            "sync": (C.c_int, [H]),
+            "tick": (C.c_int, [H, C.POINTER(u64)]),
+            "members": (C.c_int, [H, u32, vp, vp, u32]),
+            "stats_get": (C.c_int, [H, u32, C.POINTER(Stats)]),
+            "watch": (C.c_int, [H, u32]),
+            "drain_events": (C.c_int, [H, C.POINTER(Event), u32, C.POINTER(u32)]),
+            "state_digest": (C.c_int, [H, C.POINTER(u64 * 8)]),
+            "dump_state": (C.c_int, [H, u32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+            "convergence": (C.c_int, [H, u32, u32, u64, C.POINTER(u64), C.POINTER(u64)]),
+            "exchange_bytes": (C.c_int, [H, C.POINTER(C.c_size_t)]),
+            "bind_exchange": (C.c_int, [H, vp, vp]),
+            "abi_version": (u32, []),
+            "backend_name": (C.c_char_p, []),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(self.dll, prefix + name)  # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+            self.f[name] = fn
+
+    def backend_name(self):
+        return self.f["backend_name"]().decode()
+
+    def abi_version(self):
+        return self.f["abi_version"]()
+
+
+class Sim:
+    """A simulated cluster behind the C ABI; method names follow ``Serf`` (serf/api.rs)."""
+
+    def __init__(self, lib: SimLib, cfg: Config):
+        self.lib, self.cfg = lib, cfg
+        self.h = C.c_void_p()
+        rc = lib.f["create"](C.byref(cfg), C.byref(self.h))
+        if rc:
+            self.h = None
+            raise SimError(rc, "sim_create")
+        self.n = cfg.n_nodes
+
+    def _ck(self, rc, what):
+        if rc < 0:
+            raise SimError(rc, what)
+        return rc
+
+    def close(self):
+        if self.h:
+            self.lib.f["destroy"](self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- Serf API (api.rs) ----
+    def join(self, node, peer=0):
+        self._ck(self.lib.f["join"](self.h, node, peer), "sim_join")
+
+    def leave(self, node):
+        self._ck(self.lib.f["leave"](self.h, node), "sim_leave")
+
+    def remove_failed_node(self, node, subject, prune=False):
+        self._ck(self.lib.f["force_leave"](self.h, node, subject, int(prune)), "sim_force_leave")
+
+    def user_event(self, node, key, encoded_len=32, coalesce=False):
+        self._ck(self.lib.f["user_event"](self.h, node, key, encoded_len, int(coalesce)), "sim_user_event")
+
+    def query(self, node, query_id, flags=0):
+        self._ck(self.lib.f["query"](self.h, node, query_id, flags), "sim_query")
+
+    def inject(self, tick, op, node, a=0, b=0):
+        self._ck(self.lib.f["inject"](self.h, tick, op, node, a, b), "sim_inject")
+
+    def set_stream(self, stream_ptr):
+        self._ck(self.lib.f["set_stream"](self.h, C.c_void_p(stream_ptr)), "sim_set_stream")
+
+    def step(self, n=1):
+        self._ck(self.lib.f["step"](self.h, n), "sim_step")
+
+    def sync(self):
+        self._ck(self.lib.f["sync"](self.h), "sim_sync")
+
+    @property
+    def tick(self):
+        t = C.c_uint64()
+        self._ck(self.lib.f["tick"](self.h, C.byref(t)), "sim_tick")
+        return t.value
+
+    def members(self, observer):
+        st = np.zeros(self.n, np.uint8)
+        lt = np.zeros(self.n, np.uint64)
+        self._ck(self.lib.f["members"](self.h, observer, st.ctypes.data, lt.ctypes.data, self.n), "sim_members")
+        return st, lt
+
+    def stats(self, node):
+        s = Stats()
+        self._ck(self.lib.f["stats_get"](self.h, node, C.byref(s)), "sim_stats_get")
+        return s
+
+    def watch(self, observer):
+        self._ck(self.lib.f["watch"](self.h, observer), "sim_watch")
+
+    def drain_events(self, cap=65536):
+        buf = (Event * cap)()
+        n = C.c_uint32()
+        self._ck(self.lib.f["drain_events"](self.h, buf, cap, C.byref(n)), "sim_drain_events")
+        return [(e.tick, e.observer, e.type, e.key, e.ltime) for e in buf[:n.value]]
+
+    def digest(self):
+        d = (C.c_uint64 * 8)()
+        self._ck(self.lib.f["state_digest"](self.h, C.byref(d)), "sim_state_digest")
+        return tuple(int(x) for x in d)
+
+    def dump(self, which):
+        n = C.c_size_t()
+        self._ck(self.lib.f["dump_state"](self.h, which, None, 0, C.byref(n)), "sim_dump_state")
+        buf = np.zeros(n.value, np.uint8)
+        self._ck(self.lib.f["dump_state"](self.h, which, buf.ctypes.data, n.value, C.byref(n)), "sim_dump_state")
+        return buf.view(_ARR_DTYPE[which])
+
+    def convergence(self, kind, key, ltime):
+        seen, up = C.c_uint64(), C.c_uint64()
+        self._ck(self.lib.f["convergence"](self.h, kind, key, ltime, C.byref(seen), C.byref(up)), "sim_convergence")
+        return seen.value, up.value
+
+    def exchange_bytes(self):
+        n = C.c_size_t()
+        self._ck(self.lib.f["exchange_bytes"](self.h, C.byref(n)), "sim_exchange_bytes")
+        return n.value
+
+    def bind_exchange(self, send_ptr, recv_ptr):
+        self._ck(self.lib.f["bind_exchange"](self.h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr)), "sim_bind_exchange")
