@@ -1,0 +1,115 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs — bit-exact, every state array, every tick."""
+import numpy as np
+import pytest
+
+from serf_amd import _ffi
+from tests import _scenario as sc
+
+pytestmark = pytest.mark.gpu
+
+
+def pair(oracle, hiplib, n, **kw):
+    cfg = _ffi.make_config(n, **kw)
+    return _ffi.Sim(hiplib, cfg), _ffi.Sim(oracle, _ffi.make_config(n, **kw))
+
+
+def test_backend_is_hip(hiplib):
+    assert hiplib.backend_name() == "hip-gfx950"
+    assert hiplib.abi_version() == 1
+
+
+@pytest.mark.parametrize("n,fanout,dense", [(128, 3, True), (100, 3, True), (257, 4, False), (1024, 4, False), (2, 3, True), (1, 3, True), (5, 4, True)])
+def test_full_state_every_tick_small(oracle, hiplib, n, fanout, dense):
+    # config 1 shape (128 nodes, fan-out 3) and ragged sizes; every array compared after every tick
+    kw = dict(fanout=fanout, view_slots=0 if dense else 64, event_ring=16, query_ring=8, leave_delay=6)
+    g, o = pair(oracle, hiplib, n, **kw)
+    ops = sc.schedule(n, 60, rate=0.6, seed=n * 7 + fanout, max_member_subjects=min(n // 2, 40))
+    sc.apply_schedule(g, ops)
+    sc.apply_schedule(o, ops)
+    for t in range(90):
+        g.step(1)
+        o.step(1)
+        assert g.digest() == o.digest(), f"digest differs after tick {t}"
+        if t % 10 == 0 or t < 5:
+            sc.assert_same_state(g, o, f"n={n} tick {t}")
+    sc.assert_same_state(g, o, f"n={n} final")
+
+
+def test_packet_loss_and_overload(oracle, hiplib):
+    # 5 % packet loss and an injection rate above the protocol's capacity => queue overflow paths
+    g, o = pair(oracle, hiplib, 512, fanout=3, view_slots=128, event_ring=8, query_ring=8, loss=0.05)
+    ops = sc.schedule(512, 40, rate=3.0, seed=99, max_member_subjects=100)
+    sc.apply_schedule(g, ops)
+    sc.apply_schedule(o, ops)
+    for t in range(80):
+        g.step(1)
+        o.step(1)
+        assert g.digest() == o.digest(), f"digest differs after tick {t}"
+    sc.assert_same_state(g, o, "loss+overload final")
+    assert o.dump(_ffi.ARR_ROWS)["overflow"].sum() > 0, "scenario should exercise the overflow path"
+
+
+def test_seq_renormalisation(oracle, hiplib):
+    # > 1023 queue ids on one node forces the id renumbering path
+    g, o = pair(oracle, hiplib, 64, fanout=3, event_ring=2048)
+    for t in range(1100):
+        for s in (g, o):
+            s.inject(t, _ffi.OP_USER_EVENT, 3, t + 1, 32)
+    for t in range(0, 1120, 16):
+        g.step(16)
+        o.step(16)
+        assert g.digest() == o.digest(), f"digest differs after tick {t + 16}"
+    sc.assert_same_state(g, o, "renorm final")
+
+
+def test_config2_64k_bit_exact(oracle, hiplib):
+    # BASELINE config 2: 64 Ki nodes, fan-out 3, bit-exact vs CPU replay, >= 256 ticks
+    n = 65536
+    g, o = pair(oracle, hiplib, n, fanout=3, view_slots=128, event_ring=64, query_ring=64)
+    ops = sc.schedule(n, 200, rate=0.5, seed=2, max_member_subjects=100)
+    sc.apply_schedule(g, ops)
+    sc.apply_schedule(o, ops)
+    for t in range(0, 256, 8):
+        g.step(8)
+        o.step(8)
+        assert g.digest() == o.digest(), f"digest differs after tick {t + 8}"
+    for node in (0, 1, 4097, n - 1):
+        a, b = g.stats(node), o.stats(node)
+        for f, _ in _ffi.Stats._fields_:
+            assert getattr(a, f) == getattr(b, f), (node, f)
+        sa, la = g.members(node)
+        sb, lb = o.members(node)
+        assert (sa == sb).all() and (la == lb).all()
+    k0 = next(op for op in ops if op[1] == _ffi.OP_USER_EVENT)
+    assert g.convergence(_ffi.K_EVENT, k0[3], 1) == o.convergence(_ffi.K_EVENT, k0[3], 1)
+
+
+def test_config3_1m_properties(hiplib):
+    # BASELINE config 3 size (1 Mi nodes, fan-out 4): size-independent properties
+    n = 1 << 20
+    g = _ffi.Sim(hiplib, _ffi.make_config(n, fanout=4, view_slots=64, event_ring=64, query_ring=64))
+    g.user_event(12345, 777, 64)
+    g.leave(4242)
+    seen_prev = 0
+    for t in range(24):
+        g.step(1)
+        seen, up = g.convergence(_ffi.K_EVENT, 777, 1)
+        assert seen >= seen_prev, "a rumor never un-spreads"
+        seen_prev = seen
+    assert up == n
+    assert seen == n, "lossless epidemic reaches every node"
+    seen, up = g.convergence(_ffi.K_LEAVE, 4242, 2)
+    assert seen == up
+    st, lt = g.members(0)
+    assert st[4242] == _ffi.STATUS_LEAVING and lt[4242] == 2
+    assert (np.delete(st, 4242) == _ffi.STATUS_ALIVE).all()
+    rows = g.dump(_ffi.ARR_ROWS)
+    assert rows["clock"].min() == 3 and rows["event_clock"].min() == 2  # everyone witnessed both
+    # idempotence: the queues drain and the state stops changing
+    g.step(40)
+    d1 = g.digest()
+    g.step(5)
+    d2 = g.digest()
+    assert d1[:2] == d2[:2] and d1[3:] == d2[3:]
+    assert g.dump(_ffi.ARR_QUEUE)["meta"].min() == 0xFFFFFFFF
