@@ -1,0 +1,147 @@
+#!/usr/bin/env python
+"""bench.py — member-ticks/sec of the bulk SWIM/Serf gossip hot path on MI355X.
+
+A "step" is one gossip tick of every simulated node.  N=1: BASELINE.json configs[2]
+(1 Mi nodes, fan-out 4, HBM-roofline report).  N>1: one shard of 1 Mi nodes per GPU (weak
+scaling), one RCCL all_to_all_single per tick.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# SURVEY.md §8d algorithmic bytes per member-tick (v0 layout): 2R + 2QE + 2fPE + 4(f+2)
+def b_tick_v0(f):
+    return 2 * 64 + 2 * 16 * 16 + 2 * f * 4 * 16 + 4 * (f + 2)
+
+
+def cpu_baseline(fanout, seconds_budget=20.0):
+    """The CPU oracle ("port") on a bounded sample of the same workload, rank 0 only."""
+    from serf_amd import _ffi
+    from tests import _scenario as sc
+    from tests._oracle import load_oracle
+
+    lib = load_oracle()
+    n, ticks = 1 << 18, 24
+    sim = _ffi.Sim(lib, _ffi.make_config(n, fanout=fanout, view_slots=64, event_ring=64, query_ring=64))
+    sc.apply_schedule(sim, sc.schedule(n, ticks, rate=0.5, seed=11, max_member_subjects=32))
+    sim.step(4)  # warm-up (page faults, rumors in flight)
+    t0 = time.perf_counter()
+    done = 0
+    while done < ticks and time.perf_counter() - t0 < seconds_budget:
+        sim.step(4)
+        done += 4
+    dt = time.perf_counter() - t0
+    cores = lib.dll.osim_t_threads()
+    sim.close()
+    return {"value": n * done / dt, "unit": "member-ticks/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n} nodes x {done} ticks, fan-out {fanout}, same rumor mix, view_slots=64 rings=64 (CPU oracle, OpenMP)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=60)
+    ap.add_argument("--nodes-per-gpu", type=int, default=1 << 20)
+    ap.add_argument("--fanout", type=int, default=4)
+    ap.add_argument("--view-slots", type=int, default=1024)
+    ap.add_argument("--ring", type=int, default=512)
+    ap.add_argument("--rate", type=float, default=0.5, help="rumors injected per tick (cluster-wide)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import serf_amd
+    from serf_amd import _ffi
+    from serf_amd.shard import ShardedSim
+    from tests import _scenario as sc
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    n_total = args.nodes_per_gpu * world
+    lib = serf_amd.load()
+    kw = dict(fanout=args.fanout, view_slots=args.view_slots, event_ring=args.ring, query_ring=args.ring)
+    total_ticks = args.steps + args.warmup
+    ops = sc.schedule(n_total, total_ticks, rate=args.rate, seed=3, max_member_subjects=args.view_slots // 2)
+    if world > 1:
+        sim = ShardedSim(lib, n_total, dev, **kw)
+        step, inject = sim.step, sim.inject
+    else:
+        sim = _ffi.Sim(lib, _ffi.make_config(n_total, **kw))
+        sim.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        step, inject = sim.step, sim.inject
+    for t, op, node, a, b in ops:
+        inject(t, op, node, a, b)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step(args.warmup)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    step(args.steps)
+    ev1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+
+    if rank == 0:
+        value = n_total * args.steps / dt
+        bt = b_tick_v0(args.fanout)
+        # dominant kernel = tick_kernel: one launch per tick; HIP-event time over the timed region
+        kern_s = ev_ms / 1e3 / args.steps
+        achieved = args.nodes_per_gpu * bt / kern_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "member-ticks/sec", "value": value, "unit": "member-ticks/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": f"{n_total} nodes ({args.nodes_per_gpu}/GPU), fan-out {args.fanout}, "
+                                   f"{args.rate} rumors/tick (events/queries/leaves/force-leaves/crashes), "
+                                   f"view_slots {args.view_slots}, rings {args.ring} — BASELINE configs[2]",
+                       "parallelism": f"node-id range shards x{world}, 1 all_to_all_single/tick" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "kernel": "tick_kernel", "kernel_ms": kern_s * 1e3, "b_tick_bytes": bt},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.fanout)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

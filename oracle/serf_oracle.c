@@ -23,8 +23,38 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define API(name) osim_##name
+
+/* Worker threads for the node loop: min(online CPUs, cgroup CPU quota), overridable with
+ * ORACLE_THREADS.  (GPU boxes expose 256 CPUs under a 16-CPU quota; one OpenMP thread per visible
+ * CPU would spend its life in contended barriers.) */
+static int g_threads = 0;
+static int oracle_threads(void) {
+  if (g_threads) return g_threads;
+  int n = 1;
+#ifdef _OPENMP
+  n = omp_get_num_procs();
+#endif
+  FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r");
+  if (f) {
+    long long q = 0, per = 0;
+    if (fscanf(f, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) {
+      int lim = (int)((q + per - 1) / per);
+      if (lim >= 1 && lim < n) n = lim;
+    }
+    fclose(f);
+  }
+  const char* e = getenv("ORACLE_THREADS");
+  if (e && atoi(e) > 0) n = atoi(e);
+  if (n < 1) n = 1;
+  g_threads = n;
+  return n;
+}
+int osim_t_threads(void) { return oracle_threads(); }
 
 /* =====================================================================================
  * Counter-based PRNG and the per-tick fan-out permutation (DESIGN.md SIMSPEC §2).  The reference
@@ -681,7 +711,8 @@ static void step_one(osim* s) {
   if (s->n_watched) {
     for (uint32_t l = 0; l < s->Nl; ++l) tick_node(s, &p, l);
   } else {
-#pragma omp parallel for schedule(static)
+    int nt = oracle_threads();
+#pragma omp parallel for schedule(static) num_threads(nt) if (s->Nl >= 4096)
     for (uint32_t l = 0; l < s->Nl; ++l) tick_node(s, &p, l);
   }
   s->prev = p;
@@ -907,7 +938,8 @@ static inline uint64_t dig(uint64_t w, uint64_t idx) { return mix64(w ^ (idx * 0
 static uint64_t dig_words(const void* p, size_t n_words) {
   const uint64_t* w = (const uint64_t*)p;
   uint64_t acc = 0;
-#pragma omp parallel for reduction(+ : acc) schedule(static)
+  int nt = oracle_threads();
+#pragma omp parallel for reduction(+ : acc) schedule(static) num_threads(nt) if (n_words >= (1u << 16))
   for (size_t i = 0; i < n_words; ++i) acc += dig(w[i], (uint64_t)i);
   return acc;
 }
