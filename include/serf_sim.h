@@ -29,13 +29,15 @@ extern "C" {
 
 /* ------------------------------------------------------------------ constants */
 
-#define SIM_ABI_VERSION 1u
+#define SIM_ABI_VERSION 2u
 
 #define SIM_P 4u  /* piggyback records per gossip packet (64-byte packet)             */
 #define SIM_Q 16u /* retransmit-queue slots per node (all four queues share the pool) */
 #define SIM_C 6u  /* keys per de-dup ring bucket (32-byte bucket)                     */
 #define SIM_MAX_FANOUT 4u
-#define SIM_MAX_CONF 4u /* suspicion confirmers remembered per (observer, subject)   */
+#define SIM_MAX_CONF 4u /* conf[0] = node that started the suspicion, conf[1..3] = confirmers (k <= 3) */
+#define SIM_S 4u        /* suspicion timers a node can track at once                   */
+#define SIM_MAX_AWARENESS 7u /* memberlist awareness_max_multiplier - 1 (lan: 8)      */
 
 /* error codes (serf-core/src/error.rs:64-81 maps its enum onto these for the bulk path) */
 #define SIM_OK 0
@@ -148,8 +150,9 @@ typedef struct sim_bucket {
   uint32_t keys[SIM_C];
 } sim_bucket;
 
-/* 80-byte per-node row: the node's own (non-view) state.  serf.rs:133-169 (`SerfCore`): three
- * Lamport clocks, EventCore/QueryCore min_time, SerfState; plus memberlist's incarnation. */
+/* 96-byte per-node row: the node's own (non-view) state.  serf.rs:133-169 (`SerfCore`): three
+ * Lamport clocks, EventCore/QueryCore min_time, SerfState; plus memberlist's incarnation,
+ * awareness and the suspicion timers it is running (memberlist-core). */
 typedef struct sim_row {
   uint64_t clock, event_clock, query_clock; /* types/clock.rs:124; all start at 1     */
   uint64_t event_min, query_min;            /* EventCore.min_time / QueryCore.min_time */
@@ -160,7 +163,8 @@ typedef struct sim_row {
   uint32_t overflow;                        /* records dropped by the Q bound          */
   uint32_t susp_next;                       /* earliest suspicion deadline (tick), 0 = none */
   uint32_t awareness;                       /* memberlist health score                 */
-  uint32_t probe_pending;                   /* subject awaiting a slot for suspect(), +1 */
+  uint32_t probe_pending;                   /* reserved (0)                            */
+  uint32_t susp[SIM_S];                     /* view slot + 1 of each running suspicion timer, 0 = free */
 } sim_row;
 
 #define SIM_RF_UP 1u

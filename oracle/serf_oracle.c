@@ -23,6 +23,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -68,6 +69,8 @@ static inline uint64_t mix64(uint64_t z) {
   return z ^ (z >> 31);
 }
 enum { STREAM_PERM = 1, STREAM_OFF = 2, STREAM_ROT = 3, STREAM_LOSS = 4, STREAM_PROBE = 5 };
+/* sub-draws of the per-(tick, prober) probe stream */
+enum { PD_TARGET = 0, PD_PING = 1, PD_ACK = 2, PD_RELAY0 = 3 /* + 5*j: relay, 4 legs */ };
 static inline uint64_t rng_base(uint64_t seed, uint64_t stream, uint64_t a) {
   return mix64(mix64(seed ^ (stream * 0xD6E8FEB86659FD93ull)) ^ a);
 }
@@ -80,7 +83,7 @@ typedef struct tickp {
   uint32_t M, nbits, mask, shift, feff, V, blk;
   uint32_t mul[3], add[3], imul[3];
   uint32_t off[SIM_MAX_FANOUT], rot[SIM_MAX_FANOUT];
-  uint64_t loss_base;
+  uint64_t loss_base, probe_base;
   uint32_t loss_u32;
 } tickp;
 
@@ -126,6 +129,7 @@ static void tickp_make(tickp* p, const sim_config* c, uint64_t tick) {
     p->rot[k] = (uint32_t)(rng4(c->seed, STREAM_ROT, tick, k) % (uint64_t)p->V);
   }
   p->loss_base = rng_base(c->seed, STREAM_LOSS, tick);
+  p->probe_base = rng_base(c->seed, STREAM_PROBE, tick);
   p->loss_u32 = c->loss_u32;
 }
 
@@ -173,7 +177,6 @@ static inline int pkt_lost(const tickp* p, uint32_t gid, uint32_t k) {
  * ===================================================================================== */
 #define NOSLOT 0xFFFFFFFFu
 #define STAMP_MASK 0x1FFFFFu
-#define MAX_PEND (2 * SIM_MAX_FANOUT * SIM_P + 4)
 
 typedef struct sim_opent {
   uint64_t tick;
@@ -202,6 +205,13 @@ struct sim_handle {
   sim_event* events;
   size_t n_events, cap_events;
   uint32_t n_watched;
+  /* memberlist layer (App. B): ground-truth liveness of ALL N nodes (replicated on every shard:
+   * it only changes through the replicated op schedule), suspicion parameters */
+  uint32_t* upmap;      /* [ceil(N/32)] bit i = node i's process is running */
+  uint32_t swim;        /* probe_interval > 0 */
+  uint32_t k_conf;      /* confirmations that shrink a suspicion timer (B.5) */
+  uint32_t T[SIM_MAX_CONF]; /* timeout in ticks after c confirmations */
+  const tickp* tp;      /* parameters of the tick being executed */
 };
 typedef struct sim_handle osim;
 
@@ -233,8 +243,8 @@ typedef struct nctx {
   uint32_t l;   /* local node index */
   uint32_t gid; /* global node id   */
   sim_row* row;
-  sim_record pend[MAX_PEND];
-  uint32_t n_pend;
+  sim_record* q; /* this node's Q queue slots, sorted by meta */
+  int mute;      /* push-pull merge: handlers run but nothing is queued (delegate.rs:427-554) */
 } nctx;
 
 static inline sim_view* view_at(osim* s, uint32_t l, uint32_t subject) {
@@ -272,12 +282,78 @@ static inline uint32_t wire_meta(uint32_t kind, uint32_t flags, uint32_t len_byt
   if (len64 > 63u) len64 = 63u;
   return ((63u - len64) << 18) | ((kind & 15u) << 4) | (flags & 15u);
 }
-static inline void pend_push(nctx* c, uint32_t key, uint32_t wmeta, uint64_t val) {
-  if (c->n_pend >= MAX_PEND) return;
-  sim_record* r = &c->pend[c->n_pend++];
-  r->key = key;
-  r->meta = wmeta & SIM_META_WIRE_MASK;
-  r->val = val;
+/* =====================================================================================
+ * TransmitLimitedQueue (memberlist-core, App. B.1) in its bounded, pooled form.
+ * The Q slots of a node are kept sorted by `meta` (= drain order); empties last.
+ * ===================================================================================== */
+static int rec_cmp(const void* a, const void* b) {
+  uint32_t x = ((const sim_record*)a)->meta, y = ((const sim_record*)b)->meta;
+  return x < y ? -1 : x > y;
+}
+static inline void rec_clear(sim_record* r) {
+  r->key = 0;
+  r->meta = SIM_META_EMPTY;
+  r->val = 0;
+}
+static void queue_renorm(sim_row* row, sim_record* q) {
+  /* seq := rank by age (older = smaller); next_seq := count */
+  uint32_t seqs[SIM_Q], n = 0;
+  for (uint32_t i = 0; i < SIM_Q; ++i)
+    if (q[i].meta != SIM_META_EMPTY) seqs[n++] = SIM_META_SEQ(q[i].meta);
+  for (uint32_t i = 0; i < SIM_Q; ++i) {
+    if (q[i].meta == SIM_META_EMPTY) continue;
+    uint32_t sq = SIM_META_SEQ(q[i].meta), rank = 0;
+    for (uint32_t j = 0; j < n; ++j) rank += (seqs[j] < sq);
+    q[i].meta = (q[i].meta & ~(0x3FFu << 8)) | ((1023u - rank) << 8);
+  }
+  row->next_seq = n;
+  qsort(q, SIM_Q, sizeof(sim_record), rec_cmp);
+}
+/* queue_broadcast (B.1), one record at a time in arrival order: the record gets the next id; a
+ * memberlist (class 0) broadcast first invalidates queued class-0 broadcasts about the same node;
+ * when all Q slots are taken the entry that drains last (largest meta, possibly the newcomer)
+ * is dropped and counted in `overflow` (model bound: the reference queue is unbounded between
+ * QueueChecker runs, base.rs:683-740). */
+static void q_push(nctx* c, uint32_t key, uint32_t wmeta, uint64_t val) {
+  if (c->mute) return;
+  sim_row* row = c->row;
+  sim_record* q = c->q;
+  uint32_t kind = SIM_META_KIND(wmeta), cls = kind_class(kind);
+  uint32_t seq = row->next_seq++;
+  sim_record r;
+  r.key = key;
+  r.meta = (cls << 30) | (wmeta & SIM_META_WIRE_MASK) | ((1023u - seq) << 8);
+  r.val = val;
+  if (cls == 0) {
+    int hit = 0;
+    for (uint32_t i = 0; i < SIM_Q; ++i)
+      if (q[i].meta != SIM_META_EMPTY && (q[i].meta >> 30) == 0 && q[i].key == key) { rec_clear(&q[i]); hit = 1; }
+    if (hit) qsort(q, SIM_Q, sizeof(sim_record), rec_cmp);
+  }
+  if (q[SIM_Q - 1].meta != SIM_META_EMPTY) { /* full */
+    row->overflow++;
+    if (r.meta > q[SIM_Q - 1].meta) return; /* the newcomer drains last: it is the one dropped */
+  }
+  uint32_t i = SIM_Q - 1;
+  while (i > 0 && q[i - 1].meta > r.meta) { q[i] = q[i - 1]; --i; }
+  q[i] = r;
+}
+/* get_broadcasts for one packet (B.1 with a record-count budget of SIM_P): the first P entries
+ * in drain order; transmits+1; drop at the retransmit limit; re-insert. */
+static void queue_emit(sim_row* row, sim_record* q, uint32_t limit, sim_packet* out) {
+  (void)row;
+  memset(out, 0, sizeof *out);
+  for (uint32_t p = 0; p < SIM_P; ++p) {
+    sim_record* r = &q[p];
+    if (r->meta == SIM_META_EMPTY) break;
+    out->rec[p].key = r->key;
+    out->rec[p].meta = r->meta & SIM_META_WIRE_MASK;
+    out->rec[p].val = r->val;
+    uint32_t t = SIM_META_TRANSMITS(r->meta) + 1;
+    if (t >= limit) rec_clear(r);
+    else r->meta = (r->meta & ~(0x3Fu << 24)) | (t << 24);
+  }
+  qsort(q, SIM_Q, sizeof(sim_record), rec_cmp);
 }
 
 /* ---- intent buffer: base.rs:1820-1866 ---- */
@@ -332,7 +408,7 @@ static int handle_join_intent(nctx* c, uint32_t subject, uint64_t ltime) {
 static void broadcast_join(nctx* c, uint64_t ltime) {
   lc_witness(&c->row->clock, ltime);                         /* base.rs:384 */
   handle_join_intent(c, c->gid, ltime);                      /* base.rs:387 */
-  pend_push(c, c->gid, wire_meta(SIM_K_JOIN, 0, 16), ltime); /* base.rs:389-391 */
+  q_push(c, c->gid, wire_meta(SIM_K_JOIN, 0, 16), ltime); /* base.rs:389-391 */
 }
 
 /* handle_prune: base.rs:1628-1653.  The Leaving-state sleep (broadcast_timeout +
@@ -477,6 +553,182 @@ static int handle_query(nctx* c, uint32_t id, uint64_t ltime, uint32_t flags) {
   return (flags & SIM_F_NO_BROADCAST) ? 0 : 1; /* base.rs:1062-1073 */
 }
 
+/* =====================================================================================
+ * memberlist-core 0.8.1 SWIM layer (NOT in /root/reference — restated from SURVEY.md App. B.2-B.5;
+ * "parity unpinned").  The serf-side exits are the reference's own EventDelegate hooks:
+ * notify_join -> handle_node_join (delegate.rs:565-569, base.rs:1206-1334) and
+ * notify_leave -> handle_node_leave (delegate.rs:571-575, base.rs:1375-1440).
+ * Record formats: ALIVE {key = node, val = incarnation}; SUSPECT / DEAD {key = node,
+ * val = incarnation | from << 32}.
+ * ===================================================================================== */
+static inline uint32_t vb_set_swim(uint32_t b, uint32_t w) { return (b & ~(3u << 4)) | ((w & 3u) << 4); }
+static inline uint32_t vb_set_nconf(uint32_t b, uint32_t n) { return (b & ~(7u << 8)) | ((n & 7u) << 8); }
+static inline int up_of(const osim* s, uint32_t gid) { return (s->upmap[gid >> 5] >> (gid & 31)) & 1u; }
+static inline void up_set(osim* s, uint32_t gid, int up) {
+  if (up) s->upmap[gid >> 5] |= 1u << (gid & 31);
+  else s->upmap[gid >> 5] &= ~(1u << (gid & 31));
+}
+static inline void aw_delta(sim_row* row, int d) { /* awareness (Lifeguard health score), B.3 */
+  int a = (int)row->awareness + d;
+  row->awareness = a < 0 ? 0u : a > (int)SIM_MAX_AWARENESS ? SIM_MAX_AWARENESS : (uint32_t)a;
+}
+/* suspicion timer bookkeeping: row->susp[] lists the view slots (+1) this node runs a timer for;
+ * row->susp_next is the earliest deadline (absolute tick, 0 = none) */
+static void susp_forget(nctx* c, uint32_t slot) {
+  for (uint32_t j = 0; j < SIM_S; ++j)
+    if (c->row->susp[j] == slot + 1) c->row->susp[j] = 0;
+}
+static void susp_track(nctx* c, uint32_t slot, uint32_t deadline) {
+  sim_row* row = c->row;
+  uint32_t j = 0;
+  while (j < SIM_S && row->susp[j]) ++j;
+  if (j == SIM_S) { row->overflow++; return; } /* model bound: the timer is not tracked (B.5) */
+  row->susp[j] = slot + 1;
+  if (!row->susp_next || deadline < row->susp_next) row->susp_next = deadline;
+}
+/* refute (memberlist state.go `refute`): bump the incarnation past the accusation, gossip alive */
+static void swim_refute(nctx* c, uint32_t accused_inc) {
+  uint32_t inc = c->row->inc + 1;
+  if (accused_inc >= inc) inc = accused_inc + 1;
+  c->row->inc = inc;
+  sim_view* e = view_at(c->s, c->l, c->gid);
+  if (e) e->inc = inc;
+  aw_delta(c->row, +1);
+  q_push(c, c->gid, wire_meta(SIM_K_ALIVE, 0, 64), inc);
+}
+/* aliveNode (B.4) */
+static void swim_alive(nctx* c, uint32_t subject, uint32_t inc, uint32_t wmeta) {
+  sim_view* e = view_at(c->s, c->l, subject);
+  if (!e) return; /* model bound: subject without a view slot */
+  if (subject == c->gid) {
+    if (inc <= c->row->inc) return; /* our own message, or older */
+    swim_refute(c, inc);            /* somebody claims a newer incarnation of us */
+    return;
+  }
+  if (!(e->bits & SIM_VB_KNOWN)) { /* new member: notify_join */
+    e->inc = inc;
+    e->bits = vb_set_swim(e->bits, SIM_SWIM_ALIVE);
+    handle_node_join(c, subject);
+    e->inc = inc; /* handle_node_join rebuilt `bits`; the swim state Alive == 0 survives */
+    q_push(c, subject, wmeta, inc);
+    return;
+  }
+  if (inc <= e->inc) return;
+  uint32_t old = SIM_VB_SWIM(e->bits);
+  if (old == SIM_SWIM_SUSPECT) susp_forget(c, c->s->slot_of[subject]);
+  e->inc = inc;
+  e->bits = vb_set_nconf(vb_set_swim(e->bits, SIM_SWIM_ALIVE), 0);
+  q_push(c, subject, wmeta, inc);
+  if (old == SIM_SWIM_DEAD || old == SIM_SWIM_LEFT) handle_node_join(c, subject);
+}
+/* suspectNode (B.4) + suspicion.Confirm (B.5) */
+static void swim_suspect(nctx* c, uint32_t subject, uint32_t inc, uint32_t from, uint32_t wmeta) {
+  osim* s = c->s;
+  sim_view* e = view_at(s, c->l, subject);
+  if (!e || !(e->bits & SIM_VB_KNOWN)) return;
+  if (inc < e->inc) return;
+  uint64_t val = (uint64_t)inc | ((uint64_t)from << 32);
+  if (SIM_VB_SWIM(e->bits) == SIM_SWIM_SUSPECT) { /* a timer exists: try to confirm */
+    uint32_t n = SIM_VB_NCONF(e->bits);
+    if (n >= s->k_conf) return;
+    for (uint32_t i = 0; i <= n; ++i)
+      if (e->conf[i] == from) return;
+    e->conf[n + 1] = from;
+    e->bits = vb_set_nconf(e->bits, n + 1);
+    uint32_t deadline = (uint32_t)s->tick - (((uint32_t)s->tick - SIM_VB_STAMP(e->bits)) & STAMP_MASK) + s->T[n + 1];
+    if (c->row->susp_next && deadline < c->row->susp_next) c->row->susp_next = deadline;
+    q_push(c, subject, wmeta, val);
+    return;
+  }
+  if (SIM_VB_SWIM(e->bits) != SIM_SWIM_ALIVE) return;
+  if (subject == c->gid) { swim_refute(c, inc); return; }
+  q_push(c, subject, wmeta, val);
+  e->inc = inc;
+  e->bits = vb_set_stamp(vb_set_nconf(vb_set_swim(e->bits, SIM_SWIM_SUSPECT), 0), (uint32_t)s->tick & STAMP_MASK);
+  e->conf[0] = from;
+  e->conf[1] = e->conf[2] = e->conf[3] = 0;
+  susp_track(c, s->slot_of[subject], (uint32_t)s->tick + s->T[0]);
+}
+/* deadNode (B.4) */
+static void swim_dead(nctx* c, uint32_t subject, uint32_t inc, uint32_t from, uint32_t wmeta) {
+  osim* s = c->s;
+  sim_view* e = view_at(s, c->l, subject);
+  if (!e || !(e->bits & SIM_VB_KNOWN)) return;
+  if (inc < e->inc) return;
+  uint32_t old = SIM_VB_SWIM(e->bits);
+  if (old == SIM_SWIM_SUSPECT) { /* cancel the timer */
+    susp_forget(c, s->slot_of[subject]);
+    e->bits = vb_set_nconf(e->bits, 0);
+  }
+  if (old == SIM_SWIM_DEAD || old == SIM_SWIM_LEFT) return;
+  if (subject == c->gid && SIM_RF_STATE(c->row->flags) != SIM_SERF_LEAVING &&
+      SIM_RF_STATE(c->row->flags) != SIM_SERF_LEFT) { /* not leaving: refute */
+    swim_refute(c, inc);
+    return;
+  }
+  q_push(c, subject, wmeta, (uint64_t)inc | ((uint64_t)from << 32));
+  e->inc = inc;
+  e->bits = vb_set_swim(e->bits, from == subject ? SIM_SWIM_LEFT : SIM_SWIM_DEAD);
+  handle_node_leave(c, subject); /* notify_leave */
+}
+/* suspicion timers (B.5): fire -> deadNode(inc, from = self) */
+static void swim_timers(nctx* c) {
+  osim* s = c->s;
+  sim_row* row = c->row;
+  uint32_t now = (uint32_t)s->tick;
+  if (!row->susp_next || now < row->susp_next) return;
+  uint32_t next = 0;
+  for (uint32_t j = 0; j < SIM_S; ++j) {
+    uint32_t a = row->susp[j];
+    if (!a) continue;
+    sim_view* e = &s->view[(size_t)(a - 1) * s->Nl + c->l];
+    if (SIM_VB_SWIM(e->bits) != SIM_SWIM_SUSPECT) { row->susp[j] = 0; continue; }
+    uint32_t age = (now - SIM_VB_STAMP(e->bits)) & STAMP_MASK;
+    uint32_t T = s->T[SIM_VB_NCONF(e->bits)];
+    if (age >= T) {
+      swim_dead(c, s->subject_of[a - 1], e->inc, c->gid, wire_meta(SIM_K_DEAD, 0, 32)); /* clears susp[j] */
+    } else {
+      uint32_t deadline = now - age + T;
+      if (!next || deadline < next) next = deadline;
+    }
+  }
+  row->susp_next = next;
+}
+/* probe (B.3): one target per probe interval, direct ping + `indirect_checks` relays; a failed
+ * probe makes this node suspect the target.  All draws come from the per-(tick, prober) stream. */
+static inline uint64_t probe_draw(const tickp* p, uint32_t gid, uint32_t j) {
+  return mix64(p->probe_base ^ ((uint64_t)gid * 32u + j));
+}
+static inline int leg_lost(const tickp* p, uint32_t gid, uint32_t j) {
+  return p->loss_u32 && (uint32_t)(probe_draw(p, gid, j) >> 32) < p->loss_u32;
+}
+static void swim_probe(nctx* c, const tickp* p) {
+  osim* s = c->s;
+  uint32_t PI = s->cfg.probe_interval;
+  if (s->N < 2 || ((uint32_t)s->tick + c->gid) % PI) return;
+  uint32_t t = (uint32_t)(probe_draw(p, c->gid, PD_TARGET) % (uint64_t)(s->N - 1));
+  if (t >= c->gid) ++t; /* uniform over the other N-1 nodes */
+  sim_view* e = view_at(s, c->l, t);
+  const sim_view* ev = e ? e : &s->base[t];
+  if (!(ev->bits & SIM_VB_KNOWN)) return;                                    /* not a member (yet) */
+  uint32_t sw = SIM_VB_SWIM(ev->bits);
+  if (sw == SIM_SWIM_DEAD || sw == SIM_SWIM_LEFT) return;                    /* probe skips dead nodes */
+  int ok = 0;
+  if (up_of(s, t)) {
+    ok = !leg_lost(p, c->gid, PD_PING) && !leg_lost(p, c->gid, PD_ACK);
+    for (uint32_t j = 0; !ok && j < s->cfg.indirect_checks && j < 4; ++j) {
+      uint32_t r = (uint32_t)(probe_draw(p, c->gid, PD_RELAY0 + 5 * j) % (uint64_t)s->N);
+      if (r == c->gid || r == t || !up_of(s, r)) continue;
+      ok = !leg_lost(p, c->gid, PD_RELAY0 + 5 * j + 1) && !leg_lost(p, c->gid, PD_RELAY0 + 5 * j + 2) &&
+           !leg_lost(p, c->gid, PD_RELAY0 + 5 * j + 3) && !leg_lost(p, c->gid, PD_RELAY0 + 5 * j + 4);
+    }
+  }
+  if (ok) { aw_delta(c->row, -1); return; }
+  aw_delta(c->row, +1);
+  if (!e) { c->row->overflow++; return; } /* model bound: no view slot to hold the suspicion */
+  swim_suspect(c, t, e->inc, c->gid, wire_meta(SIM_K_SUSPECT, 0, 32));
+}
+
 /* SerfDelegate::notify_message dispatch: delegate.rs:183-300 */
 static void dispatch_record(nctx* c, const sim_record* r) {
   uint32_t kind = SIM_META_KIND(r->meta), flags = SIM_META_FLAGS(r->meta);
@@ -486,96 +738,17 @@ static void dispatch_record(nctx* c, const sim_record* r) {
     case SIM_K_JOIN: rb = handle_join_intent(c, r->key, r->val); break;                         /* delegate.rs:205-216 */
     case SIM_K_EVENT: rb = handle_user_event(c, r->key, r->val); break;                         /* delegate.rs:217-228 */
     case SIM_K_QUERY: rb = handle_query(c, r->key, r->val, flags); break;                       /* delegate.rs:229-256 */
+    /* memberlist's own broadcasts never reach the serf delegate; they are handled below it */
+    case SIM_K_ALIVE: if (c->s->swim) swim_alive(c, r->key, (uint32_t)r->val, r->meta); return;
+    case SIM_K_SUSPECT: if (c->s->swim) swim_suspect(c, r->key, (uint32_t)r->val, (uint32_t)(r->val >> 32), r->meta); return;
+    case SIM_K_DEAD: if (c->s->swim) swim_dead(c, r->key, (uint32_t)r->val, (uint32_t)(r->val >> 32), r->meta); return;
     default: return;
   }
   if (rb) { /* delegate.rs:294-300: re-queue the ORIGINAL message unchanged */
     /* the refute join (if any) was pushed by the handler before we get here; the original
      * message is appended after it — but a refuted leave is never rebroadcast, so order is moot */
-    pend_push(c, r->key, r->meta, r->val);
+    q_push(c, r->key, r->meta, r->val);
   }
-}
-
-/* =====================================================================================
- * TransmitLimitedQueue (memberlist-core, App. B.1) in its bounded, pooled form.
- * The Q slots of a node are kept sorted by `meta` (= drain order); empties last.
- * ===================================================================================== */
-static int rec_cmp(const void* a, const void* b) {
-  uint32_t x = ((const sim_record*)a)->meta, y = ((const sim_record*)b)->meta;
-  return x < y ? -1 : x > y;
-}
-static inline void rec_clear(sim_record* r) {
-  r->key = 0;
-  r->meta = SIM_META_EMPTY;
-  r->val = 0;
-}
-static void queue_renorm(sim_row* row, sim_record* q) {
-  /* seq := rank by age (older = smaller); next_seq := count */
-  uint32_t seqs[SIM_Q], n = 0;
-  for (uint32_t i = 0; i < SIM_Q; ++i)
-    if (q[i].meta != SIM_META_EMPTY) seqs[n++] = SIM_META_SEQ(q[i].meta);
-  for (uint32_t i = 0; i < SIM_Q; ++i) {
-    if (q[i].meta == SIM_META_EMPTY) continue;
-    uint32_t sq = SIM_META_SEQ(q[i].meta), rank = 0;
-    for (uint32_t j = 0; j < n; ++j) rank += (seqs[j] < sq);
-    q[i].meta = (q[i].meta & ~(0x3FFu << 8)) | ((1023u - rank) << 8);
-  }
-  row->next_seq = n;
-  qsort(q, SIM_Q, sizeof(sim_record), rec_cmp);
-}
-/* queue_broadcast for every pending record, in arrival order (B.1): pool = old ∪ new; a
- * memberlist (class 0) broadcast invalidates older class-0 broadcasts about the same node;
- * keep the best Q by drain order, count the rest as overflow. */
-static void queue_enqueue(nctx* c, sim_record* q) {
-  sim_row* row = c->row;
-  if (!c->n_pend) return;
-  sim_record pool[SIM_Q + MAX_PEND];
-  uint32_t n = 0;
-  for (uint32_t i = 0; i < SIM_Q; ++i)
-    if (q[i].meta != SIM_META_EMPTY) pool[n++] = q[i];
-  for (uint32_t i = 0; i < c->n_pend; ++i) {
-    sim_record r = c->pend[i];
-    uint32_t kind = SIM_META_KIND(r.meta);
-    uint32_t seq = row->next_seq++;
-    r.meta = (kind_class(kind) << 30) | (r.meta & SIM_META_WIRE_MASK) | ((1023u - seq) << 8);
-    pool[n++] = r;
-  }
-  /* invalidation among class-0 entries with the same key: keep the newest */
-  for (uint32_t i = 0; i < n; ++i) {
-    if ((pool[i].meta >> 30) != 0 || pool[i].meta == SIM_META_EMPTY) continue;
-    for (uint32_t j = 0; j < n; ++j) {
-      if (j == i || pool[j].meta == SIM_META_EMPTY || (pool[j].meta >> 30) != 0) continue;
-      if (pool[j].key == pool[i].key && SIM_META_SEQ(pool[j].meta) > SIM_META_SEQ(pool[i].meta)) {
-        rec_clear(&pool[i]);
-        break;
-      }
-    }
-  }
-  qsort(pool, n, sizeof(sim_record), rec_cmp);
-  uint32_t valid = 0;
-  while (valid < n && pool[valid].meta != SIM_META_EMPTY) ++valid;
-  for (uint32_t i = 0; i < SIM_Q; ++i) {
-    if (i < valid) q[i] = pool[i];
-    else rec_clear(&q[i]);
-  }
-  if (valid > SIM_Q) row->overflow += valid - SIM_Q;
-  c->n_pend = 0;
-}
-/* get_broadcasts for one packet (B.1 with a record-count budget of SIM_P): the first P entries
- * in drain order; transmits+1; drop at the retransmit limit; re-insert. */
-static void queue_emit(sim_row* row, sim_record* q, uint32_t limit, sim_packet* out) {
-  (void)row;
-  memset(out, 0, sizeof *out);
-  for (uint32_t p = 0; p < SIM_P; ++p) {
-    sim_record* r = &q[p];
-    if (r->meta == SIM_META_EMPTY) break;
-    out->rec[p].key = r->key;
-    out->rec[p].meta = r->meta & SIM_META_WIRE_MASK;
-    out->rec[p].val = r->val;
-    uint32_t t = SIM_META_TRANSMITS(r->meta) + 1;
-    if (t >= limit) rec_clear(r);
-    else r->meta = (r->meta & ~(0x3Fu << 24)) | (t << 24);
-  }
-  qsort(q, SIM_Q, sizeof(sim_record), rec_cmp);
 }
 
 /* =====================================================================================
@@ -586,11 +759,15 @@ static void nctx_init(nctx* c, osim* s, uint32_t l) {
   c->l = l;
   c->gid = s->shard0 + l;
   c->row = &s->rows[l];
-  c->n_pend = 0;
+  c->q = &s->queue[(size_t)l * SIM_Q];
+  c->mute = 0;
 }
 static int has_alive_members(const osim* s) { return s->N > 1; } /* base.rs:346-359, bulk form */
 
 static void apply_op(osim* s, const sim_opent* op) {
+  /* ground-truth liveness is replicated on every shard (probes read it, B.3) */
+  if (op->op == SIM_OP_CRASH) up_set(s, op->node, 0);
+  if (op->op == SIM_OP_REVIVE || op->op == SIM_OP_JOIN) up_set(s, op->node, 1);
   if (op->node < s->shard0 || op->node >= s->shard0 + s->Nl) return; /* another shard's node */
   uint32_t l = op->node - s->shard0;
   nctx c;
@@ -604,14 +781,14 @@ static void apply_op(osim* s, const sim_opent* op) {
       uint64_t lt = row->event_clock;               /* api.rs:264 */
       row->event_clock++;                           /* api.rs:285 */
       handle_user_event(&c, op->a, lt);             /* api.rs:288 */
-      pend_push(&c, op->a, wire_meta(SIM_K_EVENT, 0, op->b), lt); /* api.rs:290-297 */
+      q_push(&c, op->a, wire_meta(SIM_K_EVENT, 0, op->b), lt); /* api.rs:290-297 */
       break;
     }
     case SIM_OP_QUERY: { /* base.rs:875-940 */
       if (!(row->flags & SIM_RF_UP)) break;
       uint64_t lt = row->query_clock;               /* base.rs:904 */
       handle_query(&c, op->a, lt, op->b);           /* base.rs:932 */
-      pend_push(&c, op->a, wire_meta(SIM_K_QUERY, op->b, 32), lt); /* base.rs:935-942 */
+      q_push(&c, op->a, wire_meta(SIM_K_QUERY, op->b, 32), lt); /* base.rs:935-942 */
       break;
     }
     case SIM_OP_LEAVE: { /* api.rs:422-460 */
@@ -622,19 +799,28 @@ static void apply_op(osim* s, const sim_opent* op) {
       uint64_t lt = row->clock;                     /* api.rs:444 */
       row->clock++;                                 /* api.rs:449 */
       handle_leave_intent(&c, c.gid, lt, 0);        /* api.rs:452 */
-      if (has_alive_members(s)) pend_push(&c, c.gid, wire_meta(SIM_K_LEAVE, 0, 16), lt); /* api.rs:456-460 */
+      if (has_alive_members(s)) q_push(&c, c.gid, wire_meta(SIM_K_LEAVE, 0, 16), lt); /* api.rs:456-460 */
       break;
     }
-    case SIM_OP_LEAVE_FINISH: { /* api.rs:474-497: memberlist.leave, then state = Left */
+    case SIM_OP_LEAVE_FINISH: { /* api.rs:474-497: memberlist.leave (gossips dead{self, from = self}),
+                                   then state = Left; the process stays up until SIM_OP_CRASH (shutdown) */
       uint32_t st = SIM_RF_STATE(row->flags);
-      if (st != SIM_SERF_LEAVING) break;
+      if (st != SIM_SERF_LEAVING || !(row->flags & SIM_RF_UP)) break;
+      if (s->swim) swim_dead(&c, c.gid, row->inc, c.gid, wire_meta(SIM_K_DEAD, 0, 32));
       row->flags = (row->flags & ~(3u << 1)) | (SIM_SERF_LEFT << 1);
-      row->flags &= ~SIM_RF_UP;
       break;
     }
-    case SIM_OP_JOIN: { /* api.rs:318-364: (memberlist.join,) broadcast_join(clock.time()) */
+    case SIM_OP_JOIN: { /* api.rs:318-364: memberlist.join, broadcast_join(clock.time()) */
       row->flags |= SIM_RF_UP;
       row->flags = (row->flags & ~(3u << 1)) | (SIM_SERF_ALIVE << 1);
+      if (s->swim) { /* a (re)joining node announces itself with an incarnation above what it is accused of */
+        sim_view* e = view_at(s, l, c.gid);
+        uint32_t old = e ? SIM_VB_SWIM(e->bits) : SIM_SWIM_ALIVE;
+        if (e) e->bits = vb_set_nconf(vb_set_swim(e->bits, SIM_SWIM_ALIVE), 0);
+        swim_refute(&c, e ? e->inc : row->inc);
+        aw_delta(row, -1); /* not an accusation: undo refute's health penalty */
+        if (old == SIM_SWIM_DEAD || old == SIM_SWIM_LEFT) handle_node_join(&c, c.gid); /* aliveNode(self) at start-up */
+      }
       broadcast_join(&c, row->clock);               /* api.rs:342 */
       break;
     }
@@ -643,14 +829,14 @@ static void apply_op(osim* s, const sim_opent* op) {
       uint64_t lt = row->clock;                     /* base.rs:456-460 */
       handle_leave_intent(&c, op->a, lt, (int)op->b); /* base.rs:463 */
       if (has_alive_members(s))                     /* base.rs:466 */
-        pend_push(&c, op->a, wire_meta(SIM_K_LEAVE, op->b ? SIM_F_PRUNE : 0, 16), lt);
+        q_push(&c, op->a, wire_meta(SIM_K_LEAVE, op->b ? SIM_F_PRUNE : 0, 16), lt);
       break;
     }
     case SIM_OP_CRASH: row->flags &= ~SIM_RF_UP; break;
     case SIM_OP_REVIVE: row->flags |= SIM_RF_UP; break;
     default: break;
   }
-  queue_enqueue(&c, q);
+  (void)q;
 }
 
 /* =====================================================================================
@@ -684,7 +870,10 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
           if (SIM_META_KIND(pk->rec[r].meta) != SIM_K_EMPTY) dispatch_record(&c, &pk->rec[r]);
       }
     }
-    queue_enqueue(&c, q);
+    if (s->swim) {
+      swim_timers(&c);
+      swim_probe(&c, p);
+    }
     uint32_t limit = s->cfg.retransmit_mult * digits10(row->n_known); /* B.1, serf.rs:123-131 */
     for (uint32_t k = 0; k < p->feff; ++k) queue_emit(row, q, limit, &out[k]);
   }
@@ -725,6 +914,34 @@ static void step_one(osim* s) {
 uint32_t API(abi_version)(void) { return SIM_ABI_VERSION; }
 const char* API(backend_name)(void) { return "cpu-oracle"; }
 
+/* Suspicion parameters (memberlist suspicion.go / util.go, App. B.5), in ticks:
+ *   k   = suspicion_mult - 2 independent confirmations wanted (0 when the cluster is too small),
+ *   min = suspicion_mult * floor(1000 * max(1, log10(max(1, N)))) * probe_interval / 1000,
+ *   max = suspicion_max_mult * min,
+ *   T[c] = max(min, floor(max - ln(c+1)/ln(k+1) * (max - min)))   (T[0] = min when k = 0). */
+static void swim_params(const sim_config* c, uint32_t* swim, uint32_t* k_out, uint32_t T[SIM_MAX_CONF]) {
+  *swim = c->probe_interval > 0;
+  uint32_t k = c->suspicion_mult >= 2 ? c->suspicion_mult - 2 : 0;
+  if (k > SIM_MAX_CONF - 1) k = SIM_MAX_CONF - 1; /* model bound: conf[] holds the starter + 3 confirmers */
+  if (c->n_nodes < 2 || c->n_nodes - 2 < k) k = 0;
+  double scale = log10(c->n_nodes > 1 ? (double)c->n_nodes : 1.0);
+  if (scale < 1.0) scale = 1.0;
+  uint64_t mn = (uint64_t)c->suspicion_mult * (uint64_t)floor(scale * 1000.0) * c->probe_interval / 1000u;
+  if (mn < 1) mn = 1;
+  uint64_t mx = (uint64_t)c->suspicion_max_mult * mn;
+  if (mx < mn) mx = mn;
+  for (uint32_t i = 0; i < SIM_MAX_CONF; ++i) {
+    double t = (double)mn;
+    if (k >= 1 && i <= k) {
+      double frac = log((double)i + 1.0) / log((double)k + 1.0);
+      t = floor((double)mx - frac * (double)(mx - mn));
+      if (t < (double)mn) t = (double)mn;
+    }
+    T[i] = t > 2000000.0 ? 2000000u : (uint32_t)t; /* stays below the 21-bit stamp horizon */
+  }
+  *k_out = k;
+}
+
 static int cfg_check(const sim_config* c) {
   if (!c || c->struct_size != sizeof(sim_config)) return SIM_EINVAL;
   if (c->n_nodes < 1 || c->vshards < 1 || c->n_nodes % c->vshards) return SIM_EINVAL;
@@ -743,7 +960,7 @@ int API(destroy)(osim* s) {
   free(s->rows); free(s->queue); free(s->inbox[0]); free(s->inbox[1]);
   if (s->own_x) { free(s->xsend); free(s->xrecv); }
   free(s->view); free(s->ering); free(s->qring); free(s->slot_of); free(s->subject_of);
-  free(s->base); free(s->ops); free(s->events); free(s);
+  free(s->base); free(s->ops); free(s->events); free(s->upmap); free(s);
   return SIM_OK;
 }
 
@@ -778,7 +995,10 @@ int API(create)(const sim_config* cfg, osim** out) {
   s->slot_of = (uint32_t*)malloc((size_t)s->N * sizeof(uint32_t));
   s->subject_of = (uint32_t*)malloc((size_t)s->A * sizeof(uint32_t));
   s->base = (sim_view*)calloc(s->N, sizeof(sim_view));
-  if (!s->rows || !s->queue || !s->view || !s->ering || !s->qring || !s->slot_of ||
+  s->upmap = (uint32_t*)malloc(((size_t)s->N + 31) / 32 * sizeof(uint32_t));
+  if (s->upmap) memset(s->upmap, 0xFF, ((size_t)s->N + 31) / 32 * sizeof(uint32_t));
+  swim_params(cfg, &s->swim, &s->k_conf, s->T);
+  if (!s->upmap || !s->rows || !s->queue || !s->view || !s->ering || !s->qring || !s->slot_of ||
       !s->subject_of || !s->base || (cfg->shard_count > 1 ? (!s->xsend || !s->xrecv)
                                                           : (!s->inbox[0] || !s->inbox[1]))) {
     API(destroy)(s);
@@ -843,7 +1063,7 @@ int API(inject)(osim* s, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, 
     case SIM_OP_QUERY: if (!a) return SIM_EINVAL; break;
     case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: rc = ensure_slot(s, node); break;
     case SIM_OP_FORCE_LEAVE: rc = ensure_slot(s, a); break;
-    case SIM_OP_CRASH: case SIM_OP_REVIVE: break;
+    case SIM_OP_CRASH: case SIM_OP_REVIVE: if (s->swim) rc = ensure_slot(s, node); break;
     default: return SIM_EINVAL;
   }
   if (rc) return rc;
@@ -863,9 +1083,13 @@ int API(inject)(osim* s, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, 
 int API(join)(osim* s, uint32_t node, uint32_t peer) { return API(inject)(s, s ? s->tick : 0, SIM_OP_JOIN, node, peer, 0); }
 int API(leave)(osim* s, uint32_t node) {
   if (!s) return SIM_EINVAL;
+  /* api.rs:422-499: leave intent now; memberlist.leave after broadcast_timeout; the caller's
+   * shutdown() (api.rs:525) after leave_propagate_delay — both modelled as leave_delay ticks */
   int rc = API(inject)(s, s->tick, SIM_OP_LEAVE, node, 0, 0);
   if (rc) return rc;
-  return API(inject)(s, s->tick + s->cfg.leave_delay + 1, SIM_OP_LEAVE_FINISH, node, 0, 0);
+  rc = API(inject)(s, s->tick + s->cfg.leave_delay + 1, SIM_OP_LEAVE_FINISH, node, 0, 0);
+  if (rc) return rc;
+  return API(inject)(s, s->tick + 2 * s->cfg.leave_delay + 2, SIM_OP_CRASH, node, 0, 0);
 }
 int API(force_leave)(osim* s, uint32_t node, uint32_t subject, int prune) {
   return API(inject)(s, s ? s->tick : 0, SIM_OP_FORCE_LEAVE, node, subject, prune ? 1u : 0u);
@@ -958,6 +1182,11 @@ int API(state_digest)(osim* s, uint64_t out[8]) {
   {
     uint64_t acc = 0;
     for (uint32_t i = 0; i < s->N; ++i) acc += dig((uint64_t)s->slot_of[i], (uint64_t)i);
+    for (uint32_t i = 0; i < (s->N + 31) / 32; ++i) {
+      uint32_t w = s->upmap[i];
+      if (i == s->N / 32 && (s->N & 31)) w &= (1u << (s->N & 31)) - 1u; /* bits past N are not state */
+      acc += dig((uint64_t)w, (uint64_t)s->N + i);
+    }
     out[6] = acc;
   }
   return SIM_OK;
@@ -1034,10 +1263,7 @@ int API(bind_exchange)(osim* s, void* send, void* recv) {
   if (!(s) || (node) < (s)->shard0 || (node) >= (s)->shard0 + (s)->Nl) return SIM_EINVAL; \
   nctx c;                                                                          \
   nctx_init(&c, (s), (node) - (s)->shard0)
-static int t_finish(nctx* c) { /* queue what the handler asked to rebroadcast */
-  queue_enqueue(c, &c->s->queue[(size_t)c->l * SIM_Q]);
-  return 0;
-}
+static int t_finish(nctx* c) { (void)c; return 0; } /* rebroadcasts are queued as they happen */
 int osim_t_clock_get(osim* s, uint32_t node, uint32_t which, uint64_t* t) {
   TCTX(s, node);
   *t = which == 0 ? c.row->clock : which == 1 ? c.row->event_clock : c.row->query_clock;
@@ -1097,33 +1323,64 @@ int osim_t_upsert_intent(osim* s, uint32_t node, uint32_t subject, uint32_t ty, 
 int osim_t_join_intent(osim* s, uint32_t node, uint32_t subject, uint64_t ltime) {
   TCTX(s, node);
   int rb = handle_join_intent(&c, subject, ltime);
-  if (rb) pend_push(&c, subject, wire_meta(SIM_K_JOIN, 0, 16), ltime);
+  if (rb) q_push(&c, subject, wire_meta(SIM_K_JOIN, 0, 16), ltime);
   t_finish(&c);
   return rb;
 }
 int osim_t_leave_intent(osim* s, uint32_t node, uint32_t subject, uint64_t ltime, int prune) {
   TCTX(s, node);
   int rb = handle_leave_intent(&c, subject, ltime, prune);
-  if (rb) pend_push(&c, subject, wire_meta(SIM_K_LEAVE, prune ? SIM_F_PRUNE : 0, 16), ltime);
+  if (rb) q_push(&c, subject, wire_meta(SIM_K_LEAVE, prune ? SIM_F_PRUNE : 0, 16), ltime);
   t_finish(&c);
   return rb;
 }
 int osim_t_user_event(osim* s, uint32_t node, uint32_t key, uint64_t ltime) {
   TCTX(s, node);
   int rb = handle_user_event(&c, key, ltime);
-  if (rb) pend_push(&c, key, wire_meta(SIM_K_EVENT, 0, 32), ltime);
+  if (rb) q_push(&c, key, wire_meta(SIM_K_EVENT, 0, 32), ltime);
   t_finish(&c);
   return rb;
 }
 int osim_t_query(osim* s, uint32_t node, uint32_t id, uint64_t ltime, uint32_t flags) {
   TCTX(s, node);
   int rb = handle_query(&c, id, ltime, flags);
-  if (rb) pend_push(&c, id, wire_meta(SIM_K_QUERY, flags, 32), ltime);
+  if (rb) q_push(&c, id, wire_meta(SIM_K_QUERY, flags, 32), ltime);
   t_finish(&c);
   return rb;
 }
 int osim_t_notify_join(osim* s, uint32_t node, uint32_t subject) { TCTX(s, node); handle_node_join(&c, subject); return SIM_OK; }
 int osim_t_notify_leave(osim* s, uint32_t node, uint32_t subject) { TCTX(s, node); handle_node_leave(&c, subject); return SIM_OK; }
+
+/* memberlist handler hooks (App. B.4): the tick loop's own functions, one call = one message */
+int osim_t_swim_alive(osim* s, uint32_t node, uint32_t subject, uint32_t inc) {
+  TCTX(s, node);
+  swim_alive(&c, subject, inc, wire_meta(SIM_K_ALIVE, 0, 64));
+  return SIM_OK;
+}
+int osim_t_swim_suspect(osim* s, uint32_t node, uint32_t subject, uint32_t inc, uint32_t from) {
+  TCTX(s, node);
+  swim_suspect(&c, subject, inc, from, wire_meta(SIM_K_SUSPECT, 0, 32));
+  return SIM_OK;
+}
+int osim_t_swim_dead(osim* s, uint32_t node, uint32_t subject, uint32_t inc, uint32_t from) {
+  TCTX(s, node);
+  swim_dead(&c, subject, inc, from, wire_meta(SIM_K_DEAD, 0, 32));
+  return SIM_OK;
+}
+int osim_t_swim_timers(osim* s, uint32_t node) { TCTX(s, node); swim_timers(&c); return SIM_OK; }
+int osim_t_swim_params(osim* s, uint32_t* k, uint32_t* T) {
+  if (!s) return SIM_EINVAL;
+  *k = s->k_conf;
+  for (uint32_t i = 0; i < SIM_MAX_CONF; ++i) T[i] = s->T[i];
+  return SIM_OK;
+}
+int osim_t_view_get(osim* s, uint32_t node, uint32_t subject, sim_view* out) {
+  TCTX(s, node);
+  sim_view* e = view_at(s, c.l, subject);
+  if (!e) return SIM_ENOSLOT;
+  *out = *e;
+  return SIM_OK;
+}
 
 /* Reaper::run body: base.rs:521-581 (reap! on failed with reconnect_timeout, on left with
  * tombstone_timeout, then reap_intents base.rs:1820-1822); `now` and timeouts in ticks. */
@@ -1163,6 +1420,7 @@ int osim_t_merge_remote_state(osim* s, uint32_t node, uint64_t ltime, uint64_t e
                               const uint64_t* ev_ltime, const uint32_t* ev_key, uint32_t n_ev,
                               int is_join, int event_join_ignore) {
   TCTX(s, node);
+  c.mute = 1; /* merge does not rebroadcast */
   if (ltime > 0) lc_witness(&c.row->clock, ltime - 1);              /* delegate.rs:466-468 */
   if (event_ltime > 0) lc_witness(&c.row->event_clock, event_ltime - 1); /* delegate.rs:469-474 */
   if (query_ltime > 0) lc_witness(&c.row->query_clock, query_ltime - 1); /* delegate.rs:475-480 */
@@ -1178,7 +1436,6 @@ int osim_t_merge_remote_state(osim* s, uint32_t node, uint64_t ltime, uint64_t e
   }
   if (is_join && event_join_ignore && event_ltime > c.row->event_min) c.row->event_min = event_ltime; /* delegate.rs:531-537 */
   for (uint32_t i = 0; i < n_ev; ++i) handle_user_event(&c, ev_key[i], ev_ltime[i]); /* delegate.rs:540-552 */
-  c.n_pend = 0; /* merge does not rebroadcast */
   return SIM_OK;
 }
 

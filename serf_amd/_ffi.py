@@ -27,6 +27,8 @@ K_JOIN, K_LEAVE, K_EVENT, K_QUERY, K_ALIVE, K_SUSPECT, K_DEAD = 1, 2, 3, 4, 5, 6
 OP_USER_EVENT, OP_QUERY, OP_LEAVE, OP_JOIN, OP_FORCE_LEAVE, OP_CRASH, OP_REVIVE, OP_LEAVE_FINISH = 1, 2, 3, 4, 5, 6, 7, 8
 # enum sim_array
 ARR_ROWS, ARR_QUEUE, ARR_INBOX, ARR_VIEW, ARR_ERING, ARR_QRING, ARR_SLOTMAP = range(7)
+# enum sim_swim_state (memberlist node state)
+SWIM_ALIVE, SWIM_SUSPECT, SWIM_DEAD, SWIM_LEFT = 0, 1, 2, 3
 CF_BASELINE_JOINED = 1
 F_NO_BROADCAST = 1
 
@@ -64,7 +66,7 @@ ROW_DTYPE = np.dtype([("clock", "<u8"), ("event_clock", "<u8"), ("query_clock", 
                       ("event_min", "<u8"), ("query_min", "<u8"), ("flags", "<u4"), ("inc", "<u4"),
                       ("n_known", "<u4"), ("n_failed", "<u4"), ("n_left", "<u4"),
                       ("next_seq", "<u4"), ("overflow", "<u4"), ("susp_next", "<u4"),
-                      ("awareness", "<u4"), ("probe_pending", "<u4")])
+                      ("awareness", "<u4"), ("probe_pending", "<u4"), ("susp", "<u4", (4,))])
 REC_DTYPE = np.dtype([("key", "<u4"), ("meta", "<u4"), ("val", "<u8")])
 VIEW_DTYPE = np.dtype([("ltime", "<u8"), ("inc", "<u4"), ("bits", "<u4"), ("conf", "<u4", (4,))])
 BUCKET_DTYPE = np.dtype([("ltime", "<u8"), ("keys", "<u4", (CKEYS,))])

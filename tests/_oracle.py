@@ -42,6 +42,12 @@ def load_oracle():
         "queue_max": (u64, [u64, u64, u64]),
         "merge_remote_state": (C.c_int, [H, u32, u64, u64, u64, P32, P64, u32, P32, u32, P64, P32, u32, C.c_int, C.c_int]),
         "targets": (C.c_int, [H, u64, u32, P32]),
+        "swim_alive": (C.c_int, [H, u32, u32, u32]),
+        "swim_suspect": (C.c_int, [H, u32, u32, u32, u32]),
+        "swim_dead": (C.c_int, [H, u32, u32, u32, u32]),
+        "swim_timers": (C.c_int, [H, u32]),
+        "swim_params": (C.c_int, [H, P32, P32]),
+        "view_get": (C.c_int, [H, u32, u32, C.c_void_p]),
     }
     lib.t = {}
     for name, (res, args) in hooks.items():
@@ -108,6 +114,33 @@ class Node:
 
     def reap(self, now, reconnect_timeout, tombstone_timeout, intent_timeout):
         assert self.t["reap"](self.sim.h, self.node, now, reconnect_timeout, tombstone_timeout, intent_timeout) == 0
+
+    # ---- memberlist layer ----
+    def alive(self, subject, inc):
+        assert self.t["swim_alive"](self.sim.h, self.node, subject, inc) == 0
+
+    def suspect(self, subject, inc, frm):
+        assert self.t["swim_suspect"](self.sim.h, self.node, subject, inc, frm) == 0
+
+    def dead(self, subject, inc, frm):
+        assert self.t["swim_dead"](self.sim.h, self.node, subject, inc, frm) == 0
+
+    def run_timers(self):
+        assert self.t["swim_timers"](self.sim.h, self.node) == 0
+
+    def view(self, subject):
+        """(swim state, incarnation, nconf, MemberStatus, known) of `subject` as seen by this node."""
+        import numpy as np
+        buf = np.zeros(1, _ffi.VIEW_DTYPE)
+        assert self.t["view_get"](self.sim.h, self.node, subject, buf.ctypes.data) == 0
+        b = int(buf["bits"][0])
+        return {"swim": (b >> 4) & 3, "inc": int(buf["inc"][0]), "nconf": (b >> 8) & 7,
+                "status": (b >> 1) & 7, "known": b & 1, "stamp": b >> 11,
+                "ltime": int(buf["ltime"][0]), "conf": [int(x) for x in buf["conf"][0]]}
+
+    def queue_kinds(self):
+        q = self.sim.dump(_ffi.ARR_QUEUE).reshape(-1, _ffi.Q)[self.node]
+        return [int((m >> 4) & 15) for m in q["meta"] if m != 0xFFFFFFFF]
 
     def member(self, subject):
         st, lt = self.sim.members(self.node)

@@ -1,0 +1,297 @@
+"""memberlist layer of the oracle: handler rules one message at a time, then
+whole-cluster scenarios that restate the reference's timing-dependent event-sequence tests
+(serf-core/src/serf/base/tests/serf/event.rs:88-130 crash => Join,Failed; :174-232 graceful =>
+Join,Leave) as deterministic tick-model runs.
+
+memberlist-core 0.8.1 is not under /root/reference, so these tests pin the oracle to the published
+SWIM/Lifeguard rules as restated in App. B ("parity unpinned"); the serf-side exits they reach
+(handle_node_join / handle_node_leave, base.rs:1206-1440) are pinned by tests/test_oracle_kat.py.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from serf_amd import _ffi
+from tests._oracle import Node
+
+ALIVE, LEAVING, LEFT, FAILED, NONE = _ffi.STATUS_ALIVE, _ffi.STATUS_LEAVING, _ffi.STATUS_LEFT, _ffi.STATUS_FAILED, _ffi.STATUS_NONE
+SW_ALIVE, SW_SUSPECT, SW_DEAD, SW_LEFT = _ffi.SWIM_ALIVE, _ffi.SWIM_SUSPECT, _ffi.SWIM_DEAD, _ffi.SWIM_LEFT
+EV_JOIN, EV_LEAVE, EV_FAILED = 0, 1, 2
+
+
+def cluster(oracle, n=8, **kw):
+    kw.setdefault("probe_interval", 5)
+    sim = _ffi.Sim(oracle, _ffi.make_config(n, **kw))
+    return sim, Node(oracle, sim, 0)
+
+
+def params(oracle, sim):
+    k = C.c_uint32()
+    T = (C.c_uint32 * 4)()
+    assert oracle.t["swim_params"](sim.h, C.byref(k), T) == 0
+    return k.value, list(T)
+
+
+# ------------------------------------------------------------------------------------------------
+# suspicion timeout table (App. B.5 gives the LAN values in ticks)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,tmin", [(128, 42), (65536, 96), (1 << 20, 120)])
+def test_suspicion_timeouts_lan(oracle, n, tmin):
+    sim, _ = cluster(oracle, n, view_slots=4, event_ring=1, query_ring=1)
+    k, T = params(oracle, sim)
+    assert k == 2                      # suspicion_mult 4 - 2
+    assert T[0] == 6 * tmin            # starts at max = suspicion_max_timeout_mult * min
+    assert T[2] == tmin                # k confirmations drive it down to min
+    assert tmin < T[1] < 6 * tmin
+    # ln(2)/ln(3) of the way down, floored
+    assert T[1] == int(np.floor(6 * tmin - np.log(2.0) / np.log(3.0) * (5 * tmin)))
+
+
+def test_small_cluster_has_no_confirmations(oracle):
+    sim, _ = cluster(oracle, 3)
+    k, T = params(oracle, sim)
+    assert k == 0 and T[0] == 4 * 1 * 5  # min = mult * max(1, log10 n) * probe_interval
+
+
+# ------------------------------------------------------------------------------------------------
+# aliveNode / suspectNode / deadNode, one message at a time (App. B.4)
+# ------------------------------------------------------------------------------------------------
+def test_alive_rules(oracle):
+    sim, s1 = cluster(oracle)
+    assert s1.view(3)["inc"] == 0
+    s1.alive(3, 0)                      # inc <= current: ignored, nothing queued
+    assert s1.queue_kinds() == []
+    s1.alive(3, 2)                      # newer incarnation: adopt + rebroadcast
+    v = s1.view(3)
+    assert (v["inc"], v["swim"]) == (2, SW_ALIVE)
+    assert s1.queue_kinds() == [_ffi.K_ALIVE]
+    s1.alive(3, 1)                      # stale again
+    assert s1.view(3)["inc"] == 2
+
+
+def test_suspect_confirm_and_timer(oracle):
+    sim, s1 = cluster(oracle, 128)
+    k, T = params(oracle, sim)
+    oracle.t["set_tick"](sim.h, 100)
+    s1.suspect(9, 0, 5)                 # node 5 accuses node 9
+    v = s1.view(9)
+    assert (v["swim"], v["nconf"], v["conf"][0], v["stamp"]) == (SW_SUSPECT, 0, 5, 100)
+    assert v["status"] == ALIVE         # serf only hears about it when the node is declared dead
+    row = sim.dump(_ffi.ARR_ROWS)[0]
+    assert row["susp_next"] == 100 + T[0] and list(row["susp"]).count(0) == 3
+    assert s1.queue_kinds() == [_ffi.K_SUSPECT]
+    s1.suspect(9, 0, 5)                 # same accuser again: not a confirmation
+    assert s1.view(9)["nconf"] == 0
+    s1.suspect(9, 0, 6)                 # independent confirmation 1
+    s1.suspect(9, 0, 7)                 # independent confirmation 2 (= k)
+    s1.suspect(9, 0, 8)                 # beyond k: ignored
+    v = s1.view(9)
+    assert v["nconf"] == 2 and v["conf"][:3] == [5, 6, 7]
+    assert sim.dump(_ffi.ARR_ROWS)[0]["susp_next"] == 100 + T[2]
+    # timer: not yet at T[2]-1, fires at T[2]
+    oracle.t["set_tick"](sim.h, 100 + T[2] - 1)
+    s1.run_timers()
+    assert s1.view(9)["swim"] == SW_SUSPECT
+    oracle.t["set_tick"](sim.h, 100 + T[2])
+    s1.run_timers()
+    v = s1.view(9)
+    assert (v["swim"], v["status"]) == (SW_DEAD, FAILED)      # notify_leave: Alive -> Failed (base.rs:1394)
+    row = sim.dump(_ffi.ARR_ROWS)[0]
+    assert row["n_failed"] == 1 and row["susp_next"] == 0 and not any(row["susp"])
+    assert _ffi.K_DEAD in s1.queue_kinds()
+
+
+def test_suspect_stale_and_non_alive_ignored(oracle):
+    sim, s1 = cluster(oracle)
+    s1.alive(3, 4)
+    s1.suspect(3, 3, 5)                 # older incarnation
+    assert s1.view(3)["swim"] == SW_ALIVE
+    s1.dead(3, 4, 5)
+    s1.suspect(3, 4, 6)                 # already dead
+    assert s1.view(3)["swim"] == SW_DEAD
+
+
+def test_refute_suspect_and_dead_about_self(oracle):
+    sim, s1 = cluster(oracle)
+    s1.suspect(0, 0, 5)                 # somebody suspects us: refute with inc = max(own+1, accused+1)
+    row = sim.dump(_ffi.ARR_ROWS)[0]
+    assert row["inc"] == 1 and row["awareness"] == 1
+    assert s1.view(0)["swim"] == SW_ALIVE and s1.view(0)["inc"] == 1
+    assert s1.queue_kinds() == [_ffi.K_ALIVE]
+    s1.dead(0, 7, 5)                    # accused at a higher incarnation
+    assert sim.dump(_ffi.ARR_ROWS)[0]["inc"] == 8
+    assert s1.view(0)["status"] == ALIVE
+
+
+def test_dead_from_self_is_left(oracle):
+    sim, s1 = cluster(oracle)
+    s1.set_member(3, LEAVING, 5)
+    s1.dead(3, 0, 3)                    # from == subject: a graceful leave (memberlist.leave)
+    v = s1.view(3)
+    assert (v["swim"], v["status"]) == (SW_LEFT, LEFT)       # Leaving -> Left (base.rs:1384)
+    s1.dead(4, 0, 2)                    # declared dead by somebody else
+    v = s1.view(4)
+    assert (v["swim"], v["status"]) == (SW_DEAD, FAILED)
+    row = sim.dump(_ffi.ARR_ROWS)[0]
+    assert (row["n_left"], row["n_failed"]) == (1, 1)
+    s1.dead(4, 0, 6)                    # already dead: no second notify_leave
+    assert sim.dump(_ffi.ARR_ROWS)[0]["n_failed"] == 1
+
+
+def test_alive_after_dead_rejoins(oracle):
+    sim, s1 = cluster(oracle)
+    s1.dead(4, 0, 2)
+    s1.alive(4, 0)                      # same incarnation: a dead node stays dead
+    assert s1.view(4)["swim"] == SW_DEAD
+    s1.alive(4, 1)                      # refutation arrives: notify_join => Alive again (base.rs:1234-1274)
+    v = s1.view(4)
+    assert (v["swim"], v["status"], v["inc"]) == (SW_ALIVE, ALIVE, 1)
+    assert sim.dump(_ffi.ARR_ROWS)[0]["n_failed"] == 0
+
+
+def test_alive_cancels_suspicion(oracle):
+    sim, s1 = cluster(oracle, 128)
+    s1.suspect(9, 0, 5)
+    s1.alive(9, 1)
+    v = s1.view(9)
+    assert (v["swim"], v["nconf"]) == (SW_ALIVE, 0)
+    assert not any(sim.dump(_ffi.ARR_ROWS)[0]["susp"])
+
+
+def test_class0_broadcast_invalidates_older_one_about_same_node(oracle):
+    # memberlist's broadcasts are named by node: a newer one replaces the queued older one (App. B.1)
+    sim, s1 = cluster(oracle, 128)
+    s1.suspect(9, 0, 5)
+    s1.suspect(10, 0, 5)
+    s1.dead(9, 0, 5)
+    assert sorted(s1.queue_kinds()) == [_ffi.K_SUSPECT, _ffi.K_DEAD]
+    q = sim.dump(_ffi.ARR_QUEUE).reshape(-1, _ffi.Q)[0]
+    keys = {int(k): int((m >> 4) & 15) for k, m in zip(q["key"], q["meta"]) if m != 0xFFFFFFFF}
+    assert keys == {9: _ffi.K_DEAD, 10: _ffi.K_SUSPECT}
+
+
+def test_unknown_member_learned_through_alive(oracle):
+    # not pre-joined: only self is known; an alive message makes memberlist call notify_join,
+    # which applies buffered intents (join.rs:267-347 join_pending_intents)
+    sim, s1 = cluster(oracle, 8, flags=0)
+    assert s1.member(3) == (NONE, 0)
+    s1.join_intent(3, 5)
+    s1.leave_intent(3, 6)
+    s1.alive(3, 0)
+    assert s1.member(3) == (LEAVING, 6)
+    assert sim.stats(0).members == 2
+
+
+# ------------------------------------------------------------------------------------------------
+# whole-cluster scenarios
+# ------------------------------------------------------------------------------------------------
+def run_until(sim, pred, max_ticks, step=1):
+    for _ in range(0, max_ticks, step):
+        sim.step(step)
+        if pred():
+            return sim.tick
+    return None
+
+
+def statuses_of(sim, subject, observers):
+    return [int(sim.members(o)[0][subject]) for o in observers]
+
+
+def test_crash_is_detected_and_declared_failed(oracle):
+    # event.rs:88-130 (serf_events_failed): a node that stops is reported Failed by everybody else
+    n, victim = 128, 77
+    sim, _ = cluster(oracle, n, fanout=3)
+    k, T = params(oracle, sim)
+    sim.watch(3)
+    sim.inject(2, _ffi.OP_CRASH, victim)
+    others = [o for o in range(n) if o != victim]
+    t_done = run_until(sim, lambda: all(s == FAILED for s in statuses_of(sim, victim, others)), 6 * T[0])
+    assert t_done is not None, "crash never detected"
+    assert t_done >= T[2], "nobody may declare a node dead before the minimum suspicion timeout"
+    ev = [e for e in sim.drain_events() if e[3] == victim]
+    assert [e[2] for e in ev] == [EV_FAILED] and ev[0][1] == 3
+    for o in (0, 3, 100):
+        st = sim.stats(o)
+        assert (st.failed, st.left, st.members) == (1, 0, n)
+    # the suspicion machinery is idle again and the rumours have drained
+    sim.step(80)
+    rows = sim.dump(_ffi.ARR_ROWS)
+    up = rows["flags"] & 1
+    assert not rows["susp"][up == 1].any() and not rows["susp_next"][up == 1].any()
+    assert (sim.dump(_ffi.ARR_QUEUE)["meta"].reshape(n, -1)[up == 1] == 0xFFFFFFFF).all()
+
+
+def test_revive_in_time_refutes_the_suspicion(oracle):
+    n, victim = 128, 5
+    sim, _ = cluster(oracle, n, fanout=3)
+    k, T = params(oracle, sim)
+    sim.inject(1, _ffi.OP_CRASH, victim)
+    sim.inject(1 + T[2] // 2, _ffi.OP_REVIVE, victim)   # back before anybody's timer can fire
+    seen_suspect = False
+    for _ in range(T[0] + 60):
+        sim.step(1)
+        if not seen_suspect:
+            v = sim.dump(_ffi.ARR_VIEW).reshape(n, n)[victim]   # dense: view[subject][observer]
+            seen_suspect = bool((((v["bits"] >> 4) & 3) == SW_SUSPECT).any())
+    assert seen_suspect, "the outage should have been noticed"
+    rows = sim.dump(_ffi.ARR_ROWS)
+    v = sim.dump(_ffi.ARR_VIEW).reshape(n, n)[victim]
+    if rows["inc"][victim] > 0:      # it heard the accusation and refuted
+        assert (((v["bits"] >> 4) & 3) == SW_ALIVE).all()
+        assert (v["inc"] == rows["inc"][victim]).all()
+    assert all(s == ALIVE for s in statuses_of(sim, victim, range(0, n, 7)))
+    assert rows["n_failed"].sum() == 0
+
+
+def test_graceful_leave_is_left_not_failed(oracle):
+    # event.rs:174-232 (serf_events_leave): Leave intent, then memberlist.leave => Left everywhere
+    n, leaver = 64, 9
+    sim, _ = cluster(oracle, n, fanout=3, leave_delay=10)
+    sim.watch(2)
+    sim.step(1)
+    sim.leave(leaver)
+    sim.step(10)
+    assert all(s == LEAVING for s in statuses_of(sim, leaver, (0, 2, 33, 63)))
+    sim.step(25)
+    assert all(s == LEFT for s in statuses_of(sim, leaver, [o for o in range(n) if o != leaver]))
+    ev = [e for e in sim.drain_events() if e[3] == leaver]
+    assert [e[2] for e in ev] == [EV_LEAVE]
+    sim.step(200)                       # the process is gone now; nobody ever calls it Failed
+    assert sim.stats(leaver).up == 0
+    st = sim.stats(2)
+    assert (st.failed, st.left) == (0, 1)
+
+
+def test_leave_then_rejoin(oracle):
+    # event.rs:257-402 leave -> rejoin -> leave keeps Join/Leave ordering and the intent queues drain
+    n, node = 64, 11
+    sim, _ = cluster(oracle, n, fanout=3, leave_delay=8)
+    sim.watch(0)
+    sim.step(1)
+    sim.leave(node)
+    sim.step(40)
+    assert statuses_of(sim, node, (0, 5)) == [LEFT, LEFT]
+    sim.join(node)
+    sim.step(40)
+    assert statuses_of(sim, node, (0, 5, 63)) == [ALIVE] * 3
+    assert sim.stats(node).incarnation >= 1
+    sim.leave(node)
+    sim.step(40)
+    assert statuses_of(sim, node, (0, 5, 63)) == [LEFT] * 3
+    ev = [e[2] for e in sim.drain_events() if e[3] == node]
+    assert ev == [EV_LEAVE, EV_JOIN, EV_LEAVE]
+    sim.step(60)
+    assert sim.stats(0).intent_queue == 0 and sim.stats(0).swim_queue == 0
+
+
+def test_packet_loss_causes_refuted_false_suspicions(oracle):
+    # heavy loss: probes fail although the target is up; the accused refute by bumping their incarnation
+    n = 64
+    sim, _ = cluster(oracle, n, fanout=3, loss=0.35, indirect_checks=1)
+    sim.step(400)
+    rows = sim.dump(_ffi.ARR_ROWS)
+    assert rows["inc"].max() >= 1, "35 % loss with one indirect check must produce false suspicions"
+    assert rows["awareness"].max() >= 1
+    v = sim.dump(_ffi.ARR_VIEW).reshape(n, n)
+    assert (v["inc"].max(axis=1) <= rows["inc"]).all(), "nobody knows a higher incarnation than the owner's"
