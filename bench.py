@@ -19,7 +19,7 @@ def b_tick_v0(f):
     return 2 * 64 + 2 * 16 * 16 + 2 * f * 4 * 16 + 4 * (f + 2)
 
 
-def cpu_baseline(fanout, seconds_budget=20.0):
+def cpu_baseline(fanout, probe_interval, seconds_budget=20.0):
     """The CPU oracle ("port") on a bounded sample of the same workload, rank 0 only."""
     from serf_amd import _ffi
     from tests import _scenario as sc
@@ -27,7 +27,8 @@ def cpu_baseline(fanout, seconds_budget=20.0):
 
     lib = load_oracle()
     n, ticks = 1 << 18, 24
-    sim = _ffi.Sim(lib, _ffi.make_config(n, fanout=fanout, view_slots=64, event_ring=64, query_ring=64))
+    sim = _ffi.Sim(lib, _ffi.make_config(n, fanout=fanout, view_slots=64, event_ring=64, query_ring=64,
+                                         probe_interval=probe_interval))
     sc.apply_schedule(sim, sc.schedule(n, ticks, rate=0.5, seed=11, max_member_subjects=32))
     sim.step(4)  # warm-up (page faults, rumors in flight)
     t0 = time.perf_counter()
@@ -52,6 +53,7 @@ def main():
     ap.add_argument("--view-slots", type=int, default=1024)
     ap.add_argument("--ring", type=int, default=512)
     ap.add_argument("--rate", type=float, default=0.5, help="rumors injected per tick (cluster-wide)")
+    ap.add_argument("--probe-interval", type=int, default=5, help="memberlist probe interval in ticks (0 = SWIM layer off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -77,7 +79,8 @@ def main():
 
     n_total = args.nodes_per_gpu * world
     lib = serf_amd.load()
-    kw = dict(fanout=args.fanout, view_slots=args.view_slots, event_ring=args.ring, query_ring=args.ring)
+    kw = dict(fanout=args.fanout, view_slots=args.view_slots, event_ring=args.ring, query_ring=args.ring,
+              probe_interval=args.probe_interval)
     total_ticks = args.steps + args.warmup
     ops = sc.schedule(n_total, total_ticks, rate=args.rate, seed=3, max_member_subjects=args.view_slots // 2)
     if world > 1:
@@ -130,14 +133,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{n_total} nodes ({args.nodes_per_gpu}/GPU), fan-out {args.fanout}, "
                                    f"{args.rate} rumors/tick (events/queries/leaves/force-leaves/crashes), "
-                                   f"view_slots {args.view_slots}, rings {args.ring} — BASELINE configs[2]",
+                                   f"view_slots {args.view_slots}, rings {args.ring}, probe interval {args.probe_interval} ticks — BASELINE configs[2]",
                        "parallelism": f"node-id range shards x{world}, 1 all_to_all_single/tick" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": "tick_kernel", "kernel_ms": kern_s * 1e3, "b_tick_bytes": bt},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.fanout)
+            out["cpu_baseline"] = cpu_baseline(args.fanout, args.probe_interval)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

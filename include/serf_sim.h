@@ -170,6 +170,7 @@ typedef struct sim_row {
 #define SIM_RF_UP 1u
 #define SIM_RF_STATE(f) (((f) >> 1) & 3u) /* enum sim_serf_state */
 #define SIM_RF_WATCHED 8u
+#define SIM_RF_MINTIME 16u /* event_min or query_min is non-zero (snapshot restore / join-ignore) */
 
 /* ------------------------------------------------------------------ configuration */
 

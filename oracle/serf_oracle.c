@@ -1147,8 +1147,26 @@ int API(watch)(osim* s, uint32_t obs) {
   s->rows[obs - s->shard0].flags |= SIM_RF_WATCHED;
   return SIM_OK;
 }
+static int ev_cmp(const void* a, const void* b) { /* canonical order of the log: (tick, observer), stable */
+  const sim_event *x = (const sim_event*)a, *y = (const sim_event*)b;
+  if (x->tick != y->tick) return x->tick < y->tick ? -1 : 1;
+  if (x->observer != y->observer) return x->observer < y->observer ? -1 : 1;
+  return x < y ? -1 : x > y; /* same node: program order (qsort on the original array positions) */
+}
 int API(drain_events)(osim* s, sim_event* out, uint32_t cap, uint32_t* n) {
   if (!s || !n) return SIM_EINVAL;
+  if (s->n_events > 1) { /* insertion sort keeps it stable without relying on qsort's address trick */
+    for (size_t i = 1; i < s->n_events; ++i) {
+      sim_event e = s->events[i];
+      size_t j = i;
+      while (j > 0 && (s->events[j - 1].tick > e.tick ||
+                       (s->events[j - 1].tick == e.tick && s->events[j - 1].observer > e.observer))) {
+        s->events[j] = s->events[j - 1];
+        --j;
+      }
+      s->events[j] = e;
+    }
+  }
   uint32_t m = (uint32_t)(s->n_events < cap ? s->n_events : cap);
   if (out) memcpy(out, s->events, m * sizeof(sim_event));
   memmove(s->events, s->events + m, (s->n_events - m) * sizeof(sim_event));
@@ -1306,6 +1324,7 @@ int osim_t_set_serf_state(osim* s, uint32_t node, uint32_t st) {
 int osim_t_set_min_time(osim* s, uint32_t node, uint32_t which, uint64_t t) {
   TCTX(s, node);
   if (which == 1) c.row->event_min = t; else c.row->query_min = t;
+  if (c.row->event_min || c.row->query_min) c.row->flags |= SIM_RF_MINTIME; else c.row->flags &= ~SIM_RF_MINTIME;
   return SIM_OK;
 }
 int osim_t_recent_intent(osim* s, uint32_t node, uint32_t subject, uint32_t ty, uint64_t* ltime) {
@@ -1434,7 +1453,10 @@ int osim_t_merge_remote_state(osim* s, uint32_t node, uint64_t ltime, uint64_t e
     if (is_left) continue;
     handle_join_intent(&c, subj[j], st_ltime[j]);
   }
-  if (is_join && event_join_ignore && event_ltime > c.row->event_min) c.row->event_min = event_ltime; /* delegate.rs:531-537 */
+  if (is_join && event_join_ignore && event_ltime > c.row->event_min) { /* delegate.rs:531-537 */
+    c.row->event_min = event_ltime;
+    c.row->flags |= SIM_RF_MINTIME;
+  }
   for (uint32_t i = 0; i < n_ev; ++i) handle_user_event(&c, ev_key[i], ev_ltime[i]); /* delegate.rs:540-552 */
   return SIM_OK;
 }

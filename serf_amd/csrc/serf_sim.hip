@@ -1,17 +1,22 @@
 // serf_sim.hip — MI355X (gfx950) implementation of include/serf_sim.h.
 //
-// One simulated node per lane.  Per gossip tick each lane
-//   1. streams its own row (3 Lamport clocks, state bits) and its retransmit queue (16 x 16 B,
-//      SoA [slot][node] so a wave's loads are 1 KiB contiguous) out of HBM,
-//   2. reads the fan-out packets addressed to it (inbox[k][node], 64 B each, coalesced),
+// One simulated node per lane, one fused kernel per gossip tick.  Per tick each lane
+//   1. streams its packed row (three 16-byte groups: the 3 Lamport clocks, SerfState bits and
+//      counters, queue bookkeeping; a fourth group with the memberlist fields when the SWIM layer
+//      is on) and the 16 sort keys of its TransmitLimitedQueue out of HBM,
+//   2. reads the fan-out packets addressed to it (inbox[k][node], 64 B each), four records at a
+//      time, first issuing the four independent de-dup lookups of a packet (slot map -> view
+//      column entry, or event/query ring bucket) and only then running the handlers in arrival
+//      order, so a packet costs two memory round trips instead of eight,
 //   3. runs every piggyback record through the serf-core handlers (Lamport witness, join/leave
-//      intent vs. status_time, user-event / query de-dup rings) against its column of the
-//      slot-major view table (view[slot][node]) — the rebroadcast decision of
-//      serf-core/src/serf/delegate.rs:157-315 and serf/base.rs:750-1572,
-//   4. keeps its TransmitLimitedQueue sorted in registers (static-index insertion / merge
-//      networks, no scratch), drains `fanout` packets of SIM_P records from it
+//      intent vs. status_time, user-event / query de-dup rings: serf-core/src/serf/delegate.rs:
+//      157-315, serf/base.rs:750-1572) and memberlist's alive/suspect/dead rules below them,
+//   4. advances its suspicion timers and, every probe interval, probes one peer,
+//   5. keeps the queue as 16 sort keys in registers — (class, transmits, length, id, slot) packed
+//      in 32 bits, sorted by min/max networks — while the 16-byte records themselves never move
+//      (slot-stable payload array), drains `fanout` packets of SIM_P records
 //      (delegate.rs:317-384, memberlist-core App. B.1) and
-//   5. pushes each packet into the inbox cell of the peer chosen by this tick's fixed-point-free
+//   6. pushes each packet into the inbox cell of the peer chosen by this tick's fixed-point-free
 //      pseudo-random bijection — exactly one writer per cell, so no atomics and no ordering
 //      ambiguity (DESIGN.md SIMSPEC).
 // Integer / byte work only: the roofline is HBM bandwidth, there is nothing for MFMA to do.
@@ -21,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -34,6 +40,7 @@ typedef uint64_t u64;
 #define NOSLOT 0xFFFFFFFFu
 #define STAMP_MASK 0x1FFFFFu
 #define BLOCK 256
+#define KEMPTY 0xFFFFFFFFu  // empty sort key
 
 // ------------------------------------------------------------------------------------------------
 // hashing / permutation (same arithmetic as the spec; host and device)
@@ -45,6 +52,7 @@ __host__ __device__ static inline u64 mix64(u64 z) {
   return z ^ (z >> 31);
 }
 enum { STREAM_PERM = 1, STREAM_OFF = 2, STREAM_ROT = 3, STREAM_LOSS = 4, STREAM_PROBE = 5 };
+enum { PD_TARGET = 0, PD_PING = 1, PD_ACK = 2, PD_RELAY0 = 3 };
 static inline u64 rng_base(u64 seed, u64 stream, u64 a) {
   return mix64(mix64(seed ^ (stream * 0xD6E8FEB86659FD93ull)) ^ a);
 }
@@ -52,7 +60,7 @@ static inline u64 rng4(u64 seed, u64 stream, u64 a, u64 b) { return mix64(rng_ba
 
 struct TickP {  // per-tick parameters, passed by value (lands in SGPRs)
   u64 tick;
-  u64 loss_base;
+  u64 loss_base, probe_base;
   u32 M, mask, shift, feff, V, blk, loss_u32, first;  // first: tick 0 has no inbox yet
   u32 mul[3], add[3], imul[3];
   u32 off[SIM_MAX_FANOUT], rot[SIM_MAX_FANOUT];
@@ -95,6 +103,7 @@ static void tickp_make(TickP* p, const sim_config* c, u64 tick) {
     p->rot[k] = (u32)(rng4(c->seed, STREAM_ROT, tick, k) % (u64)p->V);
   }
   p->loss_base = rng_base(c->seed, STREAM_LOSS, tick);
+  p->probe_base = rng_base(c->seed, STREAM_PROBE, tick);
   p->loss_u32 = c->loss_u32;
   p->first = (tick == 0);
 }
@@ -125,23 +134,34 @@ __device__ static inline u32 sigma_inv(const TickP& p, u32 y) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// device state
+// device state (data layout in HBM: DESIGN.md §3)
 // ------------------------------------------------------------------------------------------------
 struct Dev {
-  // rows, SoA
-  u64 *clock, *eclock, *qclock, *emin, *qmin;
-  u32 *flags, *inc, *nknown, *nfailed, *nleft, *seqcnt, *overflow, *suspnext, *awareness, *probepend;
-  uint4* queue;     // [Q][Nl]
-  uint4* inbox[2];  // [f][Nl] packets of 4 x uint4 (local mode)
+  // row groups, one uint4 per node each
+  uint4* R0;  // {clock.lo, clock.hi, event_clock.lo, event_clock.hi}
+  uint4* R1;  // {query_clock.lo, query_clock.hi, flags, n_known}
+  uint4* R2;  // {n_failed, n_left, next_seq | used-slot mask << 16, overflow}
+  uint4* R3;  // {incarnation, susp_next, awareness, probe_pending}      (memberlist layer)
+  uint4* R4;  // susp[4]: view slot + 1 of each running suspicion timer   (memberlist layer)
+  uint4* R5;  // {event_min.lo, event_min.hi, query_min.lo, query_min.hi} (read when SIM_RF_MINTIME)
+  uint4* qkeys;  // [4][Nl]  the 16 sort keys of a node's queue, ascending, 4 per uint4
+  uint4* qpay;   // [Q][Nl]  slot-stable wire records {key, wire meta, val.lo, val.hi}
+  uint4* inbox[2];       // [f][Nl] packets of 4 x uint4 (local mode)
   uint4 *xsend, *xrecv;  // sharded mode: [V][f][blk] packets
-  uint4* view;      // [A][Nl] entries of 2 x uint4
-  uint4* ering;     // [Bev][Nl] buckets of 2 x uint4
-  uint4* qring;     // [Bq][Nl]
+  uint4* view;   // [A][Nl] entries of 2 x uint4 {ltime.lo, ltime.hi, inc, bits}{conf[4]}
+  uint4* ering;  // [Bev][Nl] buckets of 2 x uint4 {ltime.lo, ltime.hi, k0, k1}{k2..k5}
+  uint4* qring;  // [Bq][Nl]
   u32* slot_of;     // [N]
+  u32* subject_of;  // [A]
+  u32* upmap;       // [ceil(N/32)] ground-truth liveness of every node (all shards)
+  sim_event* events;
+  u32* ev_count;
+  u32 ev_cap;
   u32 N, Nl, M, V, A, Bev, Bq, f, shard0, shard_rank, sharded, retransmit_mult;
+  u32 bev_mask, bq_mask;  // B - 1 when B is a power of two (> 1), else 0
+  u32 swim, PI, kconf, ic, T[SIM_MAX_CONF];
 };
 
-// seqcnt packs next_seq (low 16) and the number of valid queue entries (high 16)
 __device__ static inline u32 digits10(u32 n) {
   u32 d = 0;
   d += n >= 1u; d += n >= 10u; d += n >= 100u; d += n >= 1000u; d += n >= 10000u;
@@ -150,13 +170,25 @@ __device__ static inline u32 digits10(u32 n) {
   return d;
 }
 
+// A queue entry's sort key: [27:26] class [25:20] transmits [19:14] 63-len [13:4] 1023-seq [3:0] slot.
+// Ascending order of the key is TransmitLimitedQueue's drain order (App. B.1); the canonical
+// `meta` of include/serf_sim.h is (key >> 4) << 8 | (wire meta & 0xFF).
 struct Node {  // one node's state in registers
   u64 clock, eclock, qclock;
-  u32 flags, nknown, nfailed, nleft, next_seq, overflow, sc0;
-  uint4 q[SIM_Q];  // {key, meta, val.lo, val.hi}, sorted by meta; empty = meta 0xFFFFFFFF
+  u32 flags, nknown, nfailed, nleft, next_seq, used, overflow;
+  u32 inc, susp_next, awareness, ppend;
+  u32 sk[SIM_Q];
+};
+struct Orig {  // what was loaded, to store only what changed
+  uint4 r0, r1, r2, r3;
+  u32 cnt;
 };
 
-#define QEMPTY make_uint4(0u, SIM_META_EMPTY, 0u, 0u)
+struct Ctx {
+  const Dev& d;
+  u32 l, gid;
+  u32 tick;  // low 32 bits of the tick
+};
 
 __device__ static inline u32 kind_class(u32 kind) {
   return (kind == SIM_K_JOIN || kind == SIM_K_LEAVE) ? 1u : kind == SIM_K_QUERY ? 2u : kind == SIM_K_EVENT ? 3u : 0u;
@@ -167,140 +199,183 @@ __host__ __device__ static inline u32 wire_meta(u32 kind, u32 flags, u32 len_byt
   return ((63u - len64) << 18) | ((kind & 15u) << 4) | (flags & 15u);
 }
 
-// queue_broadcast (memberlist TransmitLimitedQueue, App. B.1): sorted insertion with a fresh id;
-// the entry that falls off the end of the Q-slot pool is counted as overflow.
-__device__ static inline void q_insert(Node& n, u32 key, u32 wmeta, u64 val) {
-  u32 kind = (wmeta >> 4) & 15u;
-  u32 seq = n.next_seq++;
-  u32 meta = (kind_class(kind) << 30) | (wmeta & SIM_META_WIRE_MASK) | ((1023u - seq) << 8);
-  uint4 rec = make_uint4(key, meta, (u32)val, (u32)(val >> 32));
-  if (n.q[SIM_Q - 1].y != SIM_META_EMPTY || meta > n.q[SIM_Q - 1].y) {
-    // pool full (or the newcomer ranks last of a full pool): one record is dropped
-    if (n.q[SIM_Q - 1].y != SIM_META_EMPTY) n.overflow++;
-  }
+// ---- row / queue load-store -------------------------------------------------------------------
+__device__ static inline void node_load(const Dev& d, u32 l, Node& n, Orig& o) {
+  o.r0 = d.R0[l]; o.r1 = d.R1[l]; o.r2 = d.R2[l];
+  o.r3 = d.swim ? d.R3[l] : make_uint4(0, 0, 0, 0);
+  n.clock = (u64)o.r0.x | ((u64)o.r0.y << 32);
+  n.eclock = (u64)o.r0.z | ((u64)o.r0.w << 32);
+  n.qclock = (u64)o.r1.x | ((u64)o.r1.y << 32);
+  n.flags = o.r1.z; n.nknown = o.r1.w;
+  n.nfailed = o.r2.x; n.nleft = o.r2.y; n.next_seq = o.r2.z & 0xFFFFu; n.used = o.r2.z >> 16; n.overflow = o.r2.w;
+  n.inc = o.r3.x; n.susp_next = o.r3.y; n.awareness = o.r3.z; n.ppend = o.r3.w;
+  o.cnt = __popc(n.used);
 #pragma unroll
-  for (int i = SIM_Q - 1; i >= 1; --i) {
-    bool below = n.q[i - 1].y > meta;  // predecessor sorts after the newcomer => shift it right
-    bool here = !below && n.q[i].y > meta;
-    uint4 v = below ? n.q[i - 1] : (here ? rec : n.q[i]);
-    n.q[i] = v;
+  for (int g = 0; g < 4; ++g) {
+    uint4 k = (o.cnt > (u32)(4 * g)) ? d.qkeys[(size_t)g * d.Nl + l] : make_uint4(KEMPTY, KEMPTY, KEMPTY, KEMPTY);
+    n.sk[4 * g] = k.x; n.sk[4 * g + 1] = k.y; n.sk[4 * g + 2] = k.z; n.sk[4 * g + 3] = k.w;
   }
-  if (n.q[0].y > meta) n.q[0] = rec;
+}
+__device__ static inline bool ne4(const uint4& a, const uint4& b) { return a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w; }
+__device__ static inline void node_store(const Dev& d, u32 l, const Node& n, const Orig& o) {
+  uint4 r0 = make_uint4((u32)n.clock, (u32)(n.clock >> 32), (u32)n.eclock, (u32)(n.eclock >> 32));
+  uint4 r1 = make_uint4((u32)n.qclock, (u32)(n.qclock >> 32), n.flags, n.nknown);
+  uint4 r2 = make_uint4(n.nfailed, n.nleft, (n.next_seq & 0xFFFFu) | (n.used << 16), n.overflow);
+  uint4 r3 = make_uint4(n.inc, n.susp_next, n.awareness, n.ppend);
+  if (ne4(r0, o.r0)) d.R0[l] = r0;
+  if (ne4(r1, o.r1)) d.R1[l] = r1;
+  if (ne4(r2, o.r2)) d.R2[l] = r2;
+  if (d.swim && ne4(r3, o.r3)) d.R3[l] = r3;
+  u32 cnt = max(o.cnt, (u32)__popc(n.used));
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    if (cnt > (u32)(4 * g)) d.qkeys[(size_t)g * d.Nl + l] = make_uint4(n.sk[4 * g], n.sk[4 * g + 1], n.sk[4 * g + 2], n.sk[4 * g + 3]);
 }
 
-// compare-and-swap on the drain key
-__device__ static inline void cas(uint4& a, uint4& b) {
-  bool sw = a.y > b.y;
-  uint4 lo = sw ? b : a, hi = sw ? a : b;
+// ---- TransmitLimitedQueue on sort keys ----------------------------------------------------------
+__device__ static inline void cas32(u32& a, u32& b) {
+  u32 lo = min(a, b), hi = max(a, b);
   a = lo;
   b = hi;
 }
-
-// get_broadcasts for one packet: the first SIM_P entries in drain order, transmits+1, drop at the
-// retransmit limit, then restore the sorted order (4-sort + bitonic merge, static indices only).
-__device__ static inline void q_emit(Node& n, u32 limit, uint4 (&pk)[SIM_P]) {
+// queue_broadcast (memberlist TransmitLimitedQueue, App. B.1): fresh id, a class-0 broadcast
+// invalidates the queued class-0 broadcast about the same node, the entry that drains last falls
+// off a full pool (counted as overflow); the record goes to the lowest free payload slot.
+__device__ static void q_insert(const Ctx& c, Node& n, u32 key, u32 wmeta, u64 val) {
+  const Dev& d = c.d;
+  u32 kind = (wmeta >> 4) & 15u, cls = kind_class(kind);
+  u32 seq = n.next_seq++;
+  u32 k32 = (cls << 26) | (((wmeta >> 18) & 63u) << 14) | ((1023u - seq) << 4);
+  if (cls == 0 && n.used) {
+    u32 pos = SIM_Q, slot = 0;
 #pragma unroll
-  for (int p = 0; p < (int)SIM_P; ++p) {
-    uint4 e = n.q[p];
-    bool valid = e.y != SIM_META_EMPTY;
-    pk[p] = valid ? make_uint4(e.x, e.y & SIM_META_WIRE_MASK, e.z, e.w) : make_uint4(0, 0, 0, 0);
-    u32 t = ((e.y >> 24) & 0x3Fu) + 1u;
-    bool drop = t >= limit;
-    uint4 bumped = make_uint4(e.x, (e.y & ~(0x3Fu << 24)) | (t << 24), e.z, e.w);
-    n.q[p] = valid ? (drop ? QEMPTY : bumped) : e;
+    for (int i = 0; i < (int)SIM_Q; ++i) {
+      u32 k = n.sk[i];
+      if (k != KEMPTY && (k >> 26) == 0) {
+        u32 sl = k & 15u;
+        if (d.qpay[(size_t)sl * d.Nl + c.l].x == key) { pos = i; slot = sl; }
+      }
+    }
+    if (pos < SIM_Q) {
+      n.used &= ~(1u << slot);
+#pragma unroll
+      for (int i = 0; i < (int)SIM_Q - 1; ++i) n.sk[i] = ((u32)i >= pos) ? n.sk[i + 1] : n.sk[i];
+      n.sk[SIM_Q - 1] = KEMPTY;
+    }
   }
-  // sort the 4 touched entries
-  cas(n.q[0], n.q[1]); cas(n.q[2], n.q[3]); cas(n.q[0], n.q[2]); cas(n.q[1], n.q[3]); cas(n.q[1], n.q[2]);
-  // bitonic sequence: q[4..15] ascending followed by the 4 touched entries descending
-  uint4 s[SIM_Q];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) s[i] = n.q[i + 4];
-  s[12] = n.q[3]; s[13] = n.q[2]; s[14] = n.q[1]; s[15] = n.q[0];
-#pragma unroll
-  for (int d = 8; d >= 1; d >>= 1) {
-#pragma unroll
-    for (int i = 0; i < SIM_Q; ++i)
-      if ((i & d) == 0) cas(s[i], s[i + d]);
+  if (n.sk[SIM_Q - 1] != KEMPTY) {  // pool full
+    n.overflow++;
+    if (k32 > n.sk[SIM_Q - 1]) return;  // the newcomer drains last: it is the one dropped
+    n.used &= ~(1u << (n.sk[SIM_Q - 1] & 15u));
+    n.sk[SIM_Q - 1] = KEMPTY;
   }
+  u32 slot = (u32)__ffs((int)(~n.used & 0xFFFFu)) - 1u;
+  n.used |= 1u << slot;
+  k32 |= slot;
+  d.qpay[(size_t)slot * d.Nl + c.l] = make_uint4(key, wmeta & SIM_META_WIRE_MASK, (u32)val, (u32)(val >> 32));
 #pragma unroll
-  for (int i = 0; i < SIM_Q; ++i) n.q[i] = s[i];
+  for (int i = SIM_Q - 1; i >= 1; --i) {
+    bool below = n.sk[i - 1] > k32;  // predecessor sorts after the newcomer => shift it right
+    bool here = !below && n.sk[i] > k32;
+    n.sk[i] = below ? n.sk[i - 1] : (here ? k32 : n.sk[i]);
+  }
+  if (n.sk[0] > k32) n.sk[0] = k32;
 }
 
-// rare: renumber the queue ids when the 10-bit id space is nearly used up
+// get_broadcasts for one packet: the first SIM_P entries in drain order, transmits+1, drop at the
+// retransmit limit, then restore the sorted order (4-sort + bitonic merge on 32-bit keys).
+// Returns the payload slots of the emitted entries, 0xFF where there is none.
+__device__ static inline u32 q_round(Node& n, u32 limit) {
+  u32 a[SIM_P], slots = 0;
+#pragma unroll
+  for (int p = 0; p < (int)SIM_P; ++p) {
+    u32 k = n.sk[p];
+    bool valid = k != KEMPTY;
+    u32 t = ((k >> 20) & 63u) + 1u;
+    bool drop = t >= limit;
+    slots |= (valid ? (k & 15u) : 0xFFu) << (8 * p);
+    if (valid && drop) n.used &= ~(1u << (k & 15u));
+    a[p] = valid ? (drop ? KEMPTY : k + (1u << 20)) : k;
+  }
+  cas32(a[0], a[1]); cas32(a[2], a[3]); cas32(a[0], a[2]); cas32(a[1], a[3]); cas32(a[1], a[2]);
+  u32 s[SIM_Q];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = n.sk[i + 4];
+  s[12] = a[3]; s[13] = a[2]; s[14] = a[1]; s[15] = a[0];
+#pragma unroll
+  for (int dd = 8; dd >= 1; dd >>= 1) {
+#pragma unroll
+    for (int i = 0; i < (int)SIM_Q; ++i)
+      if ((i & dd) == 0) cas32(s[i], s[i + dd]);
+  }
+#pragma unroll
+  for (int i = 0; i < (int)SIM_Q; ++i) n.sk[i] = s[i];
+  return slots;
+}
+
+// rare: renumber the queue ids when the 10-bit id space is nearly used up (order-preserving)
 __device__ static void q_renorm(Node& n) {
-  u32 cnt = 0;
-  uint4 o[SIM_Q];
+  u32 o[SIM_Q], cnt = 0;
 #pragma unroll
-  for (int i = 0; i < SIM_Q; ++i) o[i] = n.q[i];
+  for (int i = 0; i < (int)SIM_Q; ++i) o[i] = n.sk[i];
 #pragma unroll
-  for (int i = 0; i < SIM_Q; ++i) {
-    bool vi = o[i].y != SIM_META_EMPTY;
-    u32 si = SIM_META_SEQ(o[i].y), rank = 0;
+  for (int i = 0; i < (int)SIM_Q; ++i) {
+    if (o[i] == KEMPTY) continue;
+    u32 fi = (o[i] >> 4) & 0x3FFu, rank = 0;  // field = 1023 - seq: larger field = older
 #pragma unroll
-    for (int j = 0; j < SIM_Q; ++j) rank += (o[j].y != SIM_META_EMPTY && SIM_META_SEQ(o[j].y) < si) ? 1u : 0u;
-    if (vi) {
-      n.q[i].y = (o[i].y & ~(0x3FFu << 8)) | ((1023u - rank) << 8);
-      cnt++;
-    }
+    for (int j = 0; j < (int)SIM_Q; ++j) rank += (o[j] != KEMPTY && ((o[j] >> 4) & 0x3FFu) > fi) ? 1u : 0u;
+    n.sk[i] = (o[i] & ~(0x3FFu << 4)) | ((1023u - rank) << 4);
+    cnt++;
   }
   n.next_seq = cnt;
 }
 
-// ---- row / queue load-store -------------------------------------------------------------------
-__device__ static inline void node_load(const Dev& d, u32 l, Node& n) {
-  n.clock = d.clock[l]; n.eclock = d.eclock[l]; n.qclock = d.qclock[l];
-  n.flags = d.flags[l]; n.nknown = d.nknown[l]; n.nfailed = d.nfailed[l]; n.nleft = d.nleft[l];
-  n.overflow = d.overflow[l];
-  u32 sc = d.seqcnt[l];
-  n.sc0 = sc;
-  n.next_seq = sc & 0xFFFFu;
-  u32 cnt = sc >> 16;
-#pragma unroll
-  for (int i = 0; i < SIM_Q; ++i) n.q[i] = ((u32)i < cnt) ? d.queue[(size_t)i * d.Nl + l] : QEMPTY;
-}
-__device__ static inline void node_store(const Dev& d, u32 l, const Node& n, const Node& o) {
-  if (n.clock != o.clock) d.clock[l] = n.clock;
-  if (n.eclock != o.eclock) d.eclock[l] = n.eclock;
-  if (n.qclock != o.qclock) d.qclock[l] = n.qclock;
-  if (n.flags != o.flags) d.flags[l] = n.flags;
-  if (n.nknown != o.nknown) d.nknown[l] = n.nknown;
-  if (n.nfailed != o.nfailed) d.nfailed[l] = n.nfailed;
-  if (n.nleft != o.nleft) d.nleft[l] = n.nleft;
-  if (n.overflow != o.overflow) d.overflow[l] = n.overflow;
-  u32 cnt = 0;
-#pragma unroll
-  for (int i = 0; i < SIM_Q; ++i) {
-    cnt += n.q[i].y != SIM_META_EMPTY;
-    uint4 a = n.q[i], b = o.q[i];
-    if (a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w) d.queue[(size_t)i * d.Nl + l] = a;
-  }
-  u32 sc = (n.next_seq & 0xFFFFu) | (cnt << 16);
-  if (sc != o.sc0) d.seqcnt[l] = sc;
-}
-
-// ---- handlers ----------------------------------------------------------------------------------
-struct Ctx {
-  const Dev& d;
-  u32 l, gid;
-  u32 stamp;  // tick & STAMP_MASK
-};
-
-__device__ static inline void witness(u64& c, u64 t) {  // types/clock.rs:155-172
-  if (t >= c) c = t + 1;
+// ---- view / ring access -------------------------------------------------------------------------
+__device__ static inline u32 vb_make(u32 known, u32 status, u32 swim, u32 intent, u32 nconf, u32 stamp) {
+  return (known & 1u) | ((status & 7u) << 1) | ((swim & 3u) << 4) | ((intent & 3u) << 6) | ((nconf & 7u) << 8) | (stamp << 11);
 }
 __device__ static inline u32 vb_set_status(u32 b, u32 s) { return (b & ~(7u << 1)) | ((s & 7u) << 1); }
+__device__ static inline u32 vb_set_swim(u32 b, u32 w) { return (b & ~(3u << 4)) | ((w & 3u) << 4); }
 __device__ static inline u32 vb_set_intent(u32 b, u32 t) { return (b & ~(3u << 6)) | ((t & 3u) << 6); }
+__device__ static inline u32 vb_set_nconf(u32 b, u32 k) { return (b & ~(7u << 8)) | ((k & 7u) << 8); }
 __device__ static inline u32 vb_set_stamp(u32 b, u32 st) { return (b & 0x7FFu) | (st << 11); }
+#define E_LTIME(e) ((u64)(e).x | ((u64)(e).y << 32))
+#define E_SET_LTIME(e, t) ((e).x = (u32)(t), (e).y = (u32)((t) >> 32))
 
+__device__ static inline uint4* view_slot_ptr(const Ctx& c, u32 a) { return c.d.view + ((size_t)a * c.d.Nl + c.l) * 2; }
 __device__ static inline uint4* view_ptr(const Ctx& c, u32 subject) {
   if (subject >= c.d.N) return nullptr;
   u32 a = c.d.slot_of[subject];
   if (a == NOSLOT) return nullptr;
-  return c.d.view + ((size_t)a * c.d.Nl + c.l) * 2;
+  return view_slot_ptr(c, a);
 }
-#define E_LTIME(e) ((u64)(e).x | ((u64)(e).y << 32))
-#define E_SET_LTIME(e, t) ((e).x = (u32)(t), (e).y = (u32)((t) >> 32))
+__device__ static inline u32 ring_idx(u64 lt, u32 B, u32 mask) {
+  if (mask) return (u32)lt & mask;
+  return (lt >> 32) ? (u32)(lt % B) : ((u32)lt % B);
+}
+__device__ static inline uint4* ering_ptr(const Ctx& c, u64 lt) {
+  return c.d.ering + ((size_t)ring_idx(lt, c.d.Bev, c.d.bev_mask) * c.d.Nl + c.l) * 2;
+}
+__device__ static inline uint4* qring_ptr(const Ctx& c, u64 lt) {
+  return c.d.qring + ((size_t)ring_idx(lt, c.d.Bq, c.d.bq_mask) * c.d.Nl + c.l) * 2;
+}
 
+// Event stream of watched observers (event.rs:325-378); appended in program order per node, the
+// host orders the log by (tick, observer).
+__device__ static inline void emit_event(const Ctx& c, const Node& n, u32 type, u32 key, u64 ltime) {
+  if (!(n.flags & SIM_RF_WATCHED)) return;
+  u32 i = atomicAdd(c.d.ev_count, 1u);
+  if (i < c.d.ev_cap) {
+    sim_event e;
+    e.tick = c.tick; e.observer = c.gid; e.type = type; e.key = key; e.ltime = ltime;
+    c.d.events[i] = e;
+  }
+}
+
+// ---- serf-core handlers --------------------------------------------------------------------------
+__device__ static inline void witness(u64& c, u64 t) {  // types/clock.rs:155-172
+  if (t >= c) c = t + 1;
+}
 // upsert_intent: base.rs:1835-1866
 __device__ static inline bool upsert_intent(uint4& e, u32 ty, u64 ltime, u32 stamp) {
   if (SIM_VB_INTENT(e.w)) {
@@ -316,52 +391,51 @@ __device__ static inline bool upsert_intent(uint4& e, u32 ty, u64 ltime, u32 sta
   return true;
 }
 // erase_node!: base.rs:499-518
-__device__ static inline void erase_member(Node& n, uint4* p, const uint4& e) {
+__device__ static inline void erase_member(const Ctx& c, Node& n, uint4* p, const uint4& e, u32 subject) {
   u32 st = SIM_VB_STATUS(e.w);
   if (st == SIM_STATUS_FAILED && n.nfailed) n.nfailed--;
   if (st == SIM_STATUS_LEFT && n.nleft) n.nleft--;
   p[0] = make_uint4(0, 0, 0, 0);
   p[1] = make_uint4(0, 0, 0, 0);
   if (n.nknown) n.nknown--;
+  emit_event(c, n, SIM_EV_REAP, subject, 0);
 }
-// handle_node_join_intent: base.rs:1338-1373
-__device__ static bool handle_join_intent(const Ctx& c, Node& n, u32 subject, u64 ltime) {
+// handle_node_join_intent: base.rs:1338-1373.  (p, e) = the subject's view entry, e preloaded.
+__device__ static bool handle_join_intent(const Ctx& c, Node& n, u32 subject, u64 ltime, uint4* p, uint4 e, bool& dirty) {
   witness(n.clock, ltime);
-  uint4* p = view_ptr(c, subject);
   if (!p) return false;
-  uint4 e = p[0];
   if (e.w & SIM_VB_KNOWN) {
     if (ltime <= E_LTIME(e)) return false;
     E_SET_LTIME(e, ltime);
     if (SIM_VB_STATUS(e.w) == SIM_STATUS_LEAVING) e.w = vb_set_status(e.w, SIM_STATUS_ALIVE);
     p[0] = e;
+    dirty = true;
     return true;
   }
-  bool rb = upsert_intent(e, 1, ltime, c.stamp);
-  if (rb) p[0] = e;
+  bool rb = upsert_intent(e, 1, ltime, c.tick & STAMP_MASK);
+  if (rb) { p[0] = e; dirty = true; }
   return rb;
 }
 // broadcast_join: base.rs:381-397
-__device__ static void broadcast_join(const Ctx& c, Node& n, u64 ltime) {
+__device__ static void broadcast_join(const Ctx& c, Node& n, u64 ltime, bool& dirty) {
   witness(n.clock, ltime);
-  handle_join_intent(c, n, c.gid, ltime);
-  q_insert(n, c.gid, wire_meta(SIM_K_JOIN, 0, 16), ltime);
+  uint4* p = view_ptr(c, c.gid);
+  handle_join_intent(c, n, c.gid, ltime, p, p ? p[0] : make_uint4(0, 0, 0, 0), dirty);
+  q_insert(c, n, c.gid, wire_meta(SIM_K_JOIN, 0, 16), ltime);
 }
 // handle_node_leave_intent: base.rs:1442-1572
-__device__ static bool handle_leave_intent(const Ctx& c, Node& n, u32 subject, u64 ltime, bool prune) {
+__device__ static bool handle_leave_intent(const Ctx& c, Node& n, u32 subject, u64 ltime, bool prune, uint4* p, uint4 e, bool& dirty) {
   u32 state = SIM_RF_STATE(n.flags);
   witness(n.clock, ltime);
-  uint4* p = view_ptr(c, subject);
   if (!p) return false;
-  uint4 e = p[0];
   if (!(e.w & SIM_VB_KNOWN)) {
-    bool rb = upsert_intent(e, 2, ltime, c.stamp);
-    if (rb) p[0] = e;
+    bool rb = upsert_intent(e, 2, ltime, c.tick & STAMP_MASK);
+    if (rb) { p[0] = e; dirty = true; }
     return rb;
   }
   if (ltime <= E_LTIME(e)) return false;
   if (subject == c.gid && state == SIM_SERF_ALIVE) {  // refute: base.rs:1470-1480
-    broadcast_join(c, n, n.clock);
+    broadcast_join(c, n, n.clock, dirty);
     return false;
   }
   E_SET_LTIME(e, ltime);
@@ -376,107 +450,325 @@ __device__ static bool handle_leave_intent(const Ctx& c, Node& n, u32 subject, u
     e.w = vb_set_status(e.w, SIM_STATUS_LEFT);
     if (n.nfailed) n.nfailed--;
     n.nleft++;
+    emit_event(c, n, SIM_EV_LEAVE, subject, 0);
   } else {
     e.w = vb_set_status(e.w, SIM_STATUS_LEAVING);
   }
-  if (prune && rb) erase_member(n, p, e);  // handle_prune: base.rs:1628-1653
+  dirty = true;
+  if (prune && rb) erase_member(c, n, p, e, subject);  // handle_prune: base.rs:1628-1653
   else p[0] = e;
   return rb;
 }
-// handle_user_event: base.rs:750-837 (quirk U1 kept)
-__device__ static bool handle_user_event(const Ctx& c, Node& n, u32 key, u64 ltime) {
+// handle_node_join (memberlist notify_join): base.rs:1206-1334; works on the entry in registers
+__device__ static void node_join_e(const Ctx& c, Node& n, uint4& e, u32 subject) {
+  if (e.w & SIM_VB_KNOWN) {
+    u32 old = SIM_VB_STATUS(e.w);
+    e.w = vb_set_stamp(vb_set_status(e.w, SIM_STATUS_ALIVE), 0);
+    if (old == SIM_STATUS_FAILED && n.nfailed) n.nfailed--;
+    if (old == SIM_STATUS_LEFT && n.nleft) n.nleft--;
+  } else {
+    u32 status = SIM_STATUS_ALIVE, it = SIM_VB_INTENT(e.w);
+    u64 lt = 0;
+    if (it == 1) lt = E_LTIME(e);
+    if (it == 2) { lt = E_LTIME(e); status = SIM_STATUS_LEAVING; }
+    E_SET_LTIME(e, lt);
+    e.w = vb_make(1, status, SIM_VB_SWIM(e.w), 0, 0, 0);
+    n.nknown++;
+  }
+  emit_event(c, n, SIM_EV_JOIN, subject, 0);
+}
+// handle_node_leave (memberlist notify_leave): base.rs:1375-1440
+__device__ static void node_leave_e(const Ctx& c, Node& n, uint4& e, u32 subject) {
+  if (!(e.w & SIM_VB_KNOWN)) return;
+  u32 st = SIM_VB_STATUS(e.w), stamp = c.tick & STAMP_MASK;
+  if (st == SIM_STATUS_LEAVING) {
+    e.w = vb_set_stamp(vb_set_status(e.w, SIM_STATUS_LEFT), stamp);
+    n.nleft++;
+    emit_event(c, n, SIM_EV_LEAVE, subject, 0);
+  } else if (st == SIM_STATUS_ALIVE) {
+    e.w = vb_set_stamp(vb_set_status(e.w, SIM_STATUS_FAILED), stamp);
+    n.nfailed++;
+    emit_event(c, n, SIM_EV_FAILED, subject, 0);
+  }
+}
+__device__ static inline bool bucket_add(uint4* p, uint4& b0, u32 key, bool same_lt, bool check_lt, Node& n, bool& seen) {
+  // returns true when the key was added; `seen` when it was already there (subject to ltime for queries)
+  seen = false;
+  bool m = !check_lt || same_lt;
+  if (m && (b0.z == key || b0.w == key)) { seen = true; return false; }
+  if (b0.w == 0) { b0.w = key; p[0] = b0; return true; }
+  uint4 b1 = p[1];
+  if (m && (b1.x == key || b1.y == key || b1.z == key || b1.w == key)) { seen = true; return false; }
+  if (b1.x == 0) b1.x = key;
+  else if (b1.y == 0) b1.y = key;
+  else if (b1.z == 0) b1.z = key;
+  else if (b1.w == 0) b1.w = key;
+  else { n.overflow++; return false; }  // model bound: bucket full => treated as seen
+  p[1] = b1;
+  return true;
+}
+// handle_user_event: base.rs:750-837 (quirk U1 kept).  (p, b0) = ring bucket of ltime, preloaded.
+__device__ static bool handle_user_event(const Ctx& c, Node& n, u32 key, u64 ltime, uint4* p, uint4 b0, bool& dirty) {
   witness(n.eclock, ltime);
-  if (ltime < c.d.emin[c.l]) return false;
+  if (n.flags & SIM_RF_MINTIME) {
+    uint4 mn = c.d.R5[c.l];
+    if (ltime < ((u64)mn.x | ((u64)mn.y << 32))) return false;
+  }
   u64 B = c.d.Bev, cur = n.eclock;
   if (cur > B && ltime < cur - B) return false;
-  u32 idx = (u32)(ltime % B);
-  uint4* p = c.d.ering + ((size_t)idx * c.d.Nl + c.l) * 2;
-  uint4 b0 = p[0];
   if (b0.z) {  // bucket present: keys[0] != 0
-    uint4 b1 = p[1];
-    u32 k[SIM_C] = {b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    u32 cnt = 0;
-    bool dup = false;
-#pragma unroll
-    for (int i = 0; i < (int)SIM_C; ++i) {
-      dup |= (k[i] == key);  // key != 0, so empty slots never match
-      cnt += k[i] != 0;
-    }
-    if (dup) return false;
-    if (cnt == SIM_C) { n.overflow++; return false; }
-    if (cnt == 1) b0.w = key;
-    else if (cnt == 2) b1.x = key;
-    else if (cnt == 3) b1.y = key;
-    else if (cnt == 4) b1.z = key;
-    else b1.w = key;
-    if (cnt == 1) p[0] = b0; else p[1] = b1;
+    bool seen;
+    if (!bucket_add(p, b0, key, false, false, n, seen)) return false;
   } else {
     p[0] = make_uint4((u32)ltime, (u32)(ltime >> 32), key, 0);
   }
+  dirty = true;
+  emit_event(c, n, SIM_EV_USER, key, ltime);
   return true;
 }
 // handle_query, de-dup part: base.rs:972-1073 (quirks Q1, Q2 kept)
-__device__ static bool handle_query(const Ctx& c, Node& n, u32 id, u64 ltime, u32 flags) {
+__device__ static bool handle_query(const Ctx& c, Node& n, u32 id, u64 ltime, u32 flags, uint4* p, uint4 b0, bool& dirty) {
   witness(n.qclock, ltime);
-  if (ltime < c.d.qmin[c.l]) return false;
+  if (n.flags & SIM_RF_MINTIME) {
+    uint4 mn = c.d.R5[c.l];
+    if (ltime < ((u64)mn.z | ((u64)mn.w << 32))) return false;
+  }
   u64 cur = n.qclock, qt = c.d.Bq;
   if (cur > qt && qt < cur - qt) return false;
-  u32 idx = (u32)(ltime % qt);
-  uint4* p = c.d.qring + ((size_t)idx * c.d.Nl + c.l) * 2;
-  uint4 b0 = p[0];
   if (b0.z) {
-    uint4 b1 = p[1];
-    u32 k[SIM_C] = {b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    bool same = (E_LTIME(b0) == ltime);
-    u32 cnt = 0;
-    bool dup = false;
-#pragma unroll
-    for (int i = 0; i < (int)SIM_C; ++i) {
-      dup |= (same && k[i] == id);
-      cnt += k[i] != 0;
-    }
-    if (dup) return false;
-    if (cnt == SIM_C) { n.overflow++; return false; }
-    if (cnt == 1) b0.w = id;
-    else if (cnt == 2) b1.x = id;
-    else if (cnt == 3) b1.y = id;
-    else if (cnt == 4) b1.z = id;
-    else b1.w = id;
-    if (cnt == 1) p[0] = b0; else p[1] = b1;
+    bool seen;
+    if (!bucket_add(p, b0, id, E_LTIME(b0) == ltime, true, n, seen)) return false;
   } else {
     p[0] = make_uint4((u32)ltime, (u32)(ltime >> 32), id, 0);
   }
+  dirty = true;
+  emit_event(c, n, SIM_EV_QUERY, id, ltime);
   return !(flags & SIM_F_NO_BROADCAST);
 }
-// SerfDelegate::notify_message: delegate.rs:183-300
-__device__ static inline void dispatch(const Ctx& c, Node& n, const uint4& r) {
+
+// ---- memberlist SWIM layer (oracle/serf_oracle.c swim_*) ------------------
+__device__ static inline void aw_delta(Node& n, int dlt) {
+  int a = (int)n.awareness + dlt;
+  n.awareness = a < 0 ? 0u : a > (int)SIM_MAX_AWARENESS ? SIM_MAX_AWARENESS : (u32)a;
+}
+__device__ static inline void susp_forget(const Ctx& c, u32 slot) {
+  uint4 s = c.d.R4[c.l], t = s;
+  if (t.x == slot + 1) t.x = 0;
+  if (t.y == slot + 1) t.y = 0;
+  if (t.z == slot + 1) t.z = 0;
+  if (t.w == slot + 1) t.w = 0;
+  if (ne4(s, t)) c.d.R4[c.l] = t;
+}
+__device__ static inline void susp_track(const Ctx& c, Node& n, u32 slot, u32 deadline) {
+  uint4 s = c.d.R4[c.l];
+  if (s.x == 0) s.x = slot + 1;
+  else if (s.y == 0) s.y = slot + 1;
+  else if (s.z == 0) s.z = slot + 1;
+  else if (s.w == 0) s.w = slot + 1;
+  else { n.overflow++; return; }  // model bound: the timer is not tracked
+  c.d.R4[c.l] = s;
+  if (!n.susp_next || deadline < n.susp_next) n.susp_next = deadline;
+}
+__device__ static void swim_refute(const Ctx& c, Node& n, u32 accused_inc) {
+  u32 inc = n.inc + 1;
+  if (accused_inc >= inc) inc = accused_inc + 1;
+  n.inc = inc;
+  uint4* p = view_ptr(c, c.gid);
+  if (p) { uint4 e = p[0]; e.z = inc; p[0] = e; }
+  aw_delta(n, +1);
+  q_insert(c, n, c.gid, wire_meta(SIM_K_ALIVE, 0, 64), inc);
+}
+__device__ static void swim_alive(const Ctx& c, Node& n, u32 subject, u32 inc, u32 wmeta, uint4* p, uint4 e, bool& dirty) {
+  if (!p) return;
+  if (subject == c.gid) {
+    if (inc <= n.inc) return;
+    dirty = true;
+    swim_refute(c, n, inc);
+    return;
+  }
+  if (!(e.w & SIM_VB_KNOWN)) {  // new member: notify_join
+    e.w = vb_set_swim(e.w, SIM_SWIM_ALIVE);
+    node_join_e(c, n, e, subject);
+    e.z = inc;
+    p[0] = e;
+    dirty = true;
+    q_insert(c, n, subject, wmeta, inc);
+    return;
+  }
+  if (inc <= e.z) return;
+  u32 old = SIM_VB_SWIM(e.w);
+  if (old == SIM_SWIM_SUSPECT) susp_forget(c, c.d.slot_of[subject]);
+  e.z = inc;
+  e.w = vb_set_nconf(vb_set_swim(e.w, SIM_SWIM_ALIVE), 0);
+  q_insert(c, n, subject, wmeta, inc);
+  if (old == SIM_SWIM_DEAD || old == SIM_SWIM_LEFT) node_join_e(c, n, e, subject);
+  p[0] = e;
+  dirty = true;
+}
+__device__ static void swim_suspect(const Ctx& c, Node& n, u32 subject, u32 inc, u32 from, u32 wmeta, uint4* p, uint4 e, bool& dirty) {
+  const Dev& d = c.d;
+  if (!p || !(e.w & SIM_VB_KNOWN)) return;
+  if (inc < e.z) return;
+  u64 val = (u64)inc | ((u64)from << 32);
+  if (SIM_VB_SWIM(e.w) == SIM_SWIM_SUSPECT) {  // a timer exists: try to confirm
+    u32 k = SIM_VB_NCONF(e.w);
+    if (k >= d.kconf) return;
+    uint4 cf = p[1];
+    if (cf.x == from) return;
+    if (k >= 1 && cf.y == from) return;
+    if (k >= 2 && cf.z == from) return;
+    if (k >= 3 && cf.w == from) return;
+    if (k == 0) cf.y = from;
+    else if (k == 1) cf.z = from;
+    else cf.w = from;
+    p[1] = cf;
+    e.w = vb_set_nconf(e.w, k + 1);
+    p[0] = e;
+    dirty = true;
+    u32 deadline = c.tick - ((c.tick - SIM_VB_STAMP(e.w)) & STAMP_MASK) + d.T[k + 1];
+    if (n.susp_next && deadline < n.susp_next) n.susp_next = deadline;
+    q_insert(c, n, subject, wmeta, val);
+    return;
+  }
+  if (SIM_VB_SWIM(e.w) != SIM_SWIM_ALIVE) return;
+  if (subject == c.gid) { dirty = true; swim_refute(c, n, inc); return; }
+  q_insert(c, n, subject, wmeta, val);
+  e.z = inc;
+  e.w = vb_set_stamp(vb_set_nconf(vb_set_swim(e.w, SIM_SWIM_SUSPECT), 0), c.tick & STAMP_MASK);
+  p[0] = e;
+  p[1] = make_uint4(from, 0, 0, 0);
+  dirty = true;
+  susp_track(c, n, d.slot_of[subject], c.tick + d.T[0]);
+}
+__device__ static void swim_dead(const Ctx& c, Node& n, u32 subject, u32 inc, u32 from, u32 wmeta, uint4* p, uint4 e, bool& dirty) {
+  if (!p || !(e.w & SIM_VB_KNOWN)) return;
+  if (inc < e.z) return;
+  u32 old = SIM_VB_SWIM(e.w);
+  if (old == SIM_SWIM_SUSPECT) {  // cancel the timer
+    susp_forget(c, c.d.slot_of[subject]);
+    e.w = vb_set_nconf(e.w, 0);
+    p[0] = e;
+    dirty = true;
+  }
+  if (old == SIM_SWIM_DEAD || old == SIM_SWIM_LEFT) return;
+  u32 st = SIM_RF_STATE(n.flags);
+  if (subject == c.gid && st != SIM_SERF_LEAVING && st != SIM_SERF_LEFT) {  // not leaving: refute
+    dirty = true;
+    swim_refute(c, n, inc);
+    return;
+  }
+  q_insert(c, n, subject, wmeta, (u64)inc | ((u64)from << 32));
+  e.z = inc;
+  e.w = vb_set_swim(e.w, from == subject ? SIM_SWIM_LEFT : SIM_SWIM_DEAD);
+  node_leave_e(c, n, e, subject);  // notify_leave
+  p[0] = e;
+  dirty = true;
+}
+// suspicion timers (B.5): fire -> deadNode(inc, from = self)
+__device__ static void swim_timers(const Ctx& c, Node& n) {
+  const Dev& d = c.d;
+  u32 now = c.tick;
+  if (!n.susp_next || now < n.susp_next) return;
+  u32 next = 0;
+  bool dirty = false;
+  for (u32 j = 0; j < SIM_S; ++j) {
+    uint4 s4 = d.R4[c.l];  // reloaded: swim_dead's susp_forget rewrites it
+    u32 a = j == 0 ? s4.x : j == 1 ? s4.y : j == 2 ? s4.z : s4.w;
+    if (!a) continue;
+    uint4* p = view_slot_ptr(c, a - 1);
+    uint4 e = p[0];
+    if (SIM_VB_SWIM(e.w) != SIM_SWIM_SUSPECT) {
+      if (j == 0) s4.x = 0; else if (j == 1) s4.y = 0; else if (j == 2) s4.z = 0; else s4.w = 0;
+      d.R4[c.l] = s4;
+      continue;
+    }
+    u32 age = (now - SIM_VB_STAMP(e.w)) & STAMP_MASK;
+    u32 T = d.T[SIM_VB_NCONF(e.w)];
+    if (age >= T) {
+      swim_dead(c, n, d.subject_of[a - 1], e.z, c.gid, wire_meta(SIM_K_DEAD, 0, 32), p, e, dirty);
+    } else {
+      u32 deadline = now - age + T;
+      if (!next || deadline < next) next = deadline;
+    }
+  }
+  n.susp_next = next;
+}
+// probe (B.3)
+__device__ static inline u64 probe_draw(const TickP& tp, u32 gid, u32 j) { return mix64(tp.probe_base ^ ((u64)gid * 32u + j)); }
+__device__ static inline bool leg_lost(const TickP& tp, u32 gid, u32 j) {
+  return tp.loss_u32 && (u32)(probe_draw(tp, gid, j) >> 32) < tp.loss_u32;
+}
+__device__ static inline bool up_of(const Dev& d, u32 gid) { return (d.upmap[gid >> 5] >> (gid & 31)) & 1u; }
+__device__ static void swim_probe(const Ctx& c, Node& n, const TickP& tp, const uint4* base) {
+  const Dev& d = c.d;
+  if (d.N < 2 || (c.tick + c.gid) % d.PI) return;
+  u32 t = (u32)(probe_draw(tp, c.gid, PD_TARGET) % (u64)(d.N - 1));
+  if (t >= c.gid) ++t;
+  uint4* p = view_ptr(c, t);
+  uint4 e = p ? p[0] : base[(size_t)t * 2];
+  if (!(e.w & SIM_VB_KNOWN)) return;
+  u32 sw = SIM_VB_SWIM(e.w);
+  if (sw == SIM_SWIM_DEAD || sw == SIM_SWIM_LEFT) return;
+  bool ok = false;
+  if (up_of(d, t)) {
+    ok = !leg_lost(tp, c.gid, PD_PING) && !leg_lost(tp, c.gid, PD_ACK);
+    for (u32 j = 0; !ok && j < d.ic && j < 4; ++j) {
+      u32 r = (u32)(probe_draw(tp, c.gid, PD_RELAY0 + 5 * j) % (u64)d.N);
+      if (r == c.gid || r == t || !up_of(d, r)) continue;
+      ok = !leg_lost(tp, c.gid, PD_RELAY0 + 5 * j + 1) && !leg_lost(tp, c.gid, PD_RELAY0 + 5 * j + 2) &&
+           !leg_lost(tp, c.gid, PD_RELAY0 + 5 * j + 3) && !leg_lost(tp, c.gid, PD_RELAY0 + 5 * j + 4);
+    }
+  }
+  if (ok) { aw_delta(n, -1); return; }
+  aw_delta(n, +1);
+  if (!p) { n.overflow++; return; }  // model bound: no view slot to hold the suspicion
+  bool dirty = false;
+  swim_suspect(c, n, t, e.z, c.gid, wire_meta(SIM_K_SUSPECT, 0, 32), p, e, dirty);
+}
+
+// ---- SerfDelegate::notify_message: delegate.rs:183-300 -----------------------------------------------
+__device__ static inline bool member_kind(u32 kind) {
+  return kind == SIM_K_JOIN || kind == SIM_K_LEAVE || kind >= SIM_K_ALIVE;
+}
+// address of the state a record is checked against (null: nothing to look at)
+__device__ static inline uint4* lookup_ptr(const Ctx& c, u32 kind, u32 key, u64 val, u32 slot) {
+  if (kind == SIM_K_EVENT) return ering_ptr(c, val);
+  if (kind == SIM_K_QUERY) return qring_ptr(c, val);
+  if (kind == SIM_K_EMPTY || slot == NOSLOT) return nullptr;
+  return view_slot_ptr(c, slot);
+}
+__device__ static void dispatch(const Ctx& c, Node& n, const uint4& r, uint4* p, const uint4& e, bool& dirty) {
   u32 kind = SIM_META_KIND(r.y), flags = SIM_META_FLAGS(r.y);
   u64 val = (u64)r.z | ((u64)r.w << 32);
   bool rb = false;
-  if (kind == SIM_K_LEAVE) rb = handle_leave_intent(c, n, r.x, val, flags & SIM_F_PRUNE);
-  else if (kind == SIM_K_JOIN) rb = handle_join_intent(c, n, r.x, val);
-  else if (kind == SIM_K_EVENT) rb = handle_user_event(c, n, r.x, val);
-  else if (kind == SIM_K_QUERY) rb = handle_query(c, n, r.x, val, flags);
-  if (rb) q_insert(n, r.x, r.y, val);  // re-queue the original message unchanged
+  if (kind == SIM_K_EVENT) rb = handle_user_event(c, n, r.x, val, p, e, dirty);
+  else if (kind == SIM_K_QUERY) rb = handle_query(c, n, r.x, val, flags, p, e, dirty);
+  else if (kind == SIM_K_JOIN) rb = handle_join_intent(c, n, r.x, val, p, e, dirty);
+  else if (kind == SIM_K_LEAVE) rb = handle_leave_intent(c, n, r.x, val, flags & SIM_F_PRUNE, p, e, dirty);
+  else if (c.d.swim) {  // memberlist's own broadcasts are handled below the serf delegate
+    if (kind == SIM_K_ALIVE) swim_alive(c, n, r.x, r.z, r.y, p, e, dirty);
+    else if (kind == SIM_K_SUSPECT) swim_suspect(c, n, r.x, r.z, r.w, r.y, p, e, dirty);
+    else if (kind == SIM_K_DEAD) swim_dead(c, n, r.x, r.z, r.w, r.y, p, e, dirty);
+  }
+  if (rb) q_insert(c, n, r.x, r.y, val);  // re-queue the original message unchanged (delegate.rs:294-300)
 }
 
 // ------------------------------------------------------------------------------------------------
 // the tick kernel
 // ------------------------------------------------------------------------------------------------
 template <bool SHARDED>
-__global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur) {
+__global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, const uint4* base) {
   u32 l = blockIdx.x * BLOCK + threadIdx.x;
   if (l >= d.Nl) return;
   u32 gid = d.shard0 + l;
   u32 g = gid / tp.M, ll = gid - g * tp.M;
-  Ctx c{d, l, gid, (u32)tp.tick & STAMP_MASK};
-  u32 flags0 = d.flags[l];
-  bool up = flags0 & SIM_RF_UP;
-  Node n, o;
-  uint4 zero = make_uint4(0, 0, 0, 0);
+  Ctx c{d, l, gid, (u32)tp.tick};
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+  Node n;
+  Orig o;
+  node_load(d, l, n, o);
+  bool up = n.flags & SIM_RF_UP;
   if (up) {
-    node_load(d, l, n);
-    o = n;
     if (n.next_seq > 1023u - 64u) q_renorm(n);
     if (!tp.first) {
       for (u32 k = 0; k < d.f; ++k) {
@@ -488,12 +780,43 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur) {
         } else {
           cell = d.inbox[cur] + ((size_t)k * d.Nl + l) * 4;
         }
-        uint4 r0 = cell[0], r1 = cell[1], r2 = cell[2], r3 = cell[3];
-        for (u32 p = 0; p < SIM_P; ++p) {
-          uint4 r = p == 0 ? r0 : p == 1 ? r1 : p == 2 ? r2 : r3;
-          if (SIM_META_KIND(r.y) != SIM_K_EMPTY) dispatch(c, n, r);
+        uint4 r[SIM_P];
+#pragma unroll
+        for (int p = 0; p < (int)SIM_P; ++p) r[p] = cell[p];
+        // wave-uniform early out: nobody in this wave received anything in packet k
+        bool any = false;
+#pragma unroll
+        for (int p = 0; p < (int)SIM_P; ++p) any |= SIM_META_KIND(r[p].y) != SIM_K_EMPTY;
+        if (!__any(any)) continue;
+        // phase A: the four lookups of this packet, independent of each other
+        u32 sl[SIM_P];
+#pragma unroll
+        for (int p = 0; p < (int)SIM_P; ++p) {
+          u32 kind = SIM_META_KIND(r[p].y);
+          sl[p] = (member_kind(kind) && r[p].x < d.N) ? d.slot_of[r[p].x] : NOSLOT;
+        }
+        uint4* ptr[SIM_P];
+        uint4 e0[SIM_P];
+#pragma unroll
+        for (int p = 0; p < (int)SIM_P; ++p) {
+          ptr[p] = lookup_ptr(c, SIM_META_KIND(r[p].y), r[p].x, (u64)r[p].z | ((u64)r[p].w << 32), sl[p]);
+          e0[p] = ptr[p] ? ptr[p][0] : zero;
+        }
+        // phase B: the handlers, in arrival order; an entry is re-read if an earlier record of
+        // this packet changed anything (rare: most records are duplicates)
+        bool dirty = false;
+#pragma unroll
+        for (int p = 0; p < (int)SIM_P; ++p) {
+          if (SIM_META_KIND(r[p].y) == SIM_K_EMPTY) continue;
+          uint4 e = e0[p];
+          if (dirty && ptr[p]) e = ptr[p][0];
+          dispatch(c, n, r[p], ptr[p], e, dirty);
         }
       }
+    }
+    if (d.swim) {
+      swim_timers(c, n);
+      swim_probe(c, n, tp, base);
     }
   }
   u32 limit = up ? d.retransmit_mult * digits10(n.nknown) : 0;
@@ -501,9 +824,15 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur) {
   for (u32 k = 0; k < tp.feff; ++k) {
     uint4 pk[SIM_P] = {zero, zero, zero, zero};
     if (up) {
-      q_emit(n, limit, pk);
-      if (tp.loss_u32 && (u32)(mix64(tp.loss_base ^ ((u64)gid * 4u + k)) >> 32) < tp.loss_u32)
-        pk[0] = pk[1] = pk[2] = pk[3] = zero;
+      u32 slots = q_round(n, limit);
+      bool lost = tp.loss_u32 && (u32)(mix64(tp.loss_base ^ ((u64)gid * 4u + k)) >> 32) < tp.loss_u32;
+      if (!lost) {
+#pragma unroll
+        for (int p = 0; p < (int)SIM_P; ++p) {
+          u32 s = (slots >> (8 * p)) & 0xFFu;
+          if (s != 0xFFu) pk[p] = d.qpay[(size_t)s * d.Nl + l];
+        }
+      }
     }
     u32 y = sx + tp.off[k];
     if (y >= tp.M) y -= tp.M;
@@ -525,33 +854,42 @@ struct OpBatch {
   u32 n;
   u32 op[8], node[8], a[8], b[8];
 };
+__device__ static inline void up_set(const Dev& d, u32 gid, bool up) {
+  u32 w = d.upmap[gid >> 5];
+  d.upmap[gid >> 5] = up ? (w | (1u << (gid & 31))) : (w & ~(1u << (gid & 31)));
+}
 __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive) {
   if (threadIdx.x || blockIdx.x) return;
   for (u32 i = 0; i < ob.n; ++i) {
-    u32 gid = ob.node[i];
+    u32 gid = ob.node[i], op = ob.op[i];
+    // ground-truth liveness is replicated on every shard (probes read it)
+    if (op == SIM_OP_CRASH) up_set(d, gid, false);
+    if (op == SIM_OP_REVIVE || op == SIM_OP_JOIN) up_set(d, gid, true);
     if (gid < d.shard0 || gid >= d.shard0 + d.Nl) continue;
     u32 l = gid - d.shard0;
-    Ctx c{d, l, gid, (u32)tick & STAMP_MASK};
-    Node n, o;
-    node_load(d, l, n);
-    o = n;
+    Ctx c{d, l, gid, (u32)tick};
+    Node n;
+    Orig o;
+    node_load(d, l, n, o);
     if (n.next_seq > 1023u - 64u) q_renorm(n);
-    bool up = n.flags & SIM_RF_UP;
+    bool up = n.flags & SIM_RF_UP, dirty = false;
     u32 a = ob.a[i], b = ob.b[i];
-    switch (ob.op[i]) {
+    switch (op) {
       case SIM_OP_USER_EVENT:  // api.rs:241-299
         if (up) {
           u64 lt = n.eclock;
           n.eclock++;
-          handle_user_event(c, n, a, lt);
-          q_insert(n, a, wire_meta(SIM_K_EVENT, 0, b), lt);
+          uint4* p = ering_ptr(c, lt);
+          handle_user_event(c, n, a, lt, p, p[0], dirty);
+          q_insert(c, n, a, wire_meta(SIM_K_EVENT, 0, b), lt);
         }
         break;
       case SIM_OP_QUERY:  // base.rs:875-942
         if (up) {
           u64 lt = n.qclock;
-          handle_query(c, n, a, lt, b);
-          q_insert(n, a, wire_meta(SIM_K_QUERY, b, 32), lt);
+          uint4* p = qring_ptr(c, lt);
+          handle_query(c, n, a, lt, b, p, p[0], dirty);
+          q_insert(c, n, a, wire_meta(SIM_K_QUERY, b, 32), lt);
         }
         break;
       case SIM_OP_LEAVE:  // api.rs:422-460
@@ -559,26 +897,49 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive) {
           n.flags = (n.flags & ~(3u << 1)) | (SIM_SERF_LEAVING << 1);
           u64 lt = n.clock;
           n.clock++;
-          handle_leave_intent(c, n, gid, lt, false);
-          if (has_alive) q_insert(n, gid, wire_meta(SIM_K_LEAVE, 0, 16), lt);
+          uint4* p = view_ptr(c, gid);
+          handle_leave_intent(c, n, gid, lt, false, p, p ? p[0] : make_uint4(0, 0, 0, 0), dirty);
+          if (has_alive) q_insert(c, n, gid, wire_meta(SIM_K_LEAVE, 0, 16), lt);
         }
         break;
-      case SIM_OP_LEAVE_FINISH:  // api.rs:474-497
-        if (SIM_RF_STATE(n.flags) == SIM_SERF_LEAVING) {
+      case SIM_OP_LEAVE_FINISH:  // api.rs:474-497: memberlist.leave (dead{self, from = self}), state = Left
+        if (up && SIM_RF_STATE(n.flags) == SIM_SERF_LEAVING) {
+          if (d.swim) {
+            uint4* p = view_ptr(c, gid);
+            swim_dead(c, n, gid, n.inc, gid, wire_meta(SIM_K_DEAD, 0, 32), p, p ? p[0] : make_uint4(0, 0, 0, 0), dirty);
+          }
           n.flags = (n.flags & ~(3u << 1)) | (SIM_SERF_LEFT << 1);
-          n.flags &= ~SIM_RF_UP;
         }
         break;
       case SIM_OP_JOIN:  // api.rs:318-364
         n.flags |= SIM_RF_UP;
         n.flags = (n.flags & ~(3u << 1)) | (SIM_SERF_ALIVE << 1);
-        broadcast_join(c, n, n.clock);
+        if (d.swim) {
+          uint4* p = view_ptr(c, gid);
+          u32 old = SIM_SWIM_ALIVE, accused = n.inc;
+          if (p) {
+            uint4 e = p[0];
+            old = SIM_VB_SWIM(e.w);
+            accused = e.z;
+            e.w = vb_set_nconf(vb_set_swim(e.w, SIM_SWIM_ALIVE), 0);
+            p[0] = e;
+          }
+          swim_refute(c, n, accused);
+          aw_delta(n, -1);
+          if (p && (old == SIM_SWIM_DEAD || old == SIM_SWIM_LEFT)) {
+            uint4 e = p[0];
+            node_join_e(c, n, e, gid);
+            p[0] = e;
+          }
+        }
+        broadcast_join(c, n, n.clock, dirty);
         break;
       case SIM_OP_FORCE_LEAVE:  // base.rs:452-480
         if (up) {
           u64 lt = n.clock;
-          handle_leave_intent(c, n, a, lt, b != 0);
-          if (has_alive) q_insert(n, a, wire_meta(SIM_K_LEAVE, b ? SIM_F_PRUNE : 0, 16), lt);
+          uint4* p = view_ptr(c, a);
+          handle_leave_intent(c, n, a, lt, b != 0, p, p ? p[0] : make_uint4(0, 0, 0, 0), dirty);
+          if (has_alive) q_insert(c, n, a, wire_meta(SIM_K_LEAVE, b ? SIM_F_PRUNE : 0, 16), lt);
         }
         break;
       case SIM_OP_CRASH: n.flags &= ~SIM_RF_UP; break;
@@ -591,12 +952,9 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// support kernels: fills, digest, members, convergence, stats
+// support kernels: fills, canonical forms, digest, members, convergence, stats
 // ------------------------------------------------------------------------------------------------
 __global__ void fill_u32(u32* p, size_t n, u32 v) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
-}
-__global__ void fill_u64(u64* p, size_t n, u64 v) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 __global__ void fill_u4(uint4* p, size_t n, uint4 v) {
@@ -613,6 +971,44 @@ __global__ void init_dense_self(Dev d) {  // new_in's synthetic notify_join(loca
   for (size_t l = blockIdx.x * (size_t)blockDim.x + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * blockDim.x) {
     u32 gid = d.shard0 + (u32)l;
     d.view[((size_t)gid * d.Nl + l) * 2] = make_uint4(0, 0, 0, 1u | (SIM_STATUS_ALIVE << 1));
+  }
+}
+
+// canonical sim_row (12 x u64 words) of node l
+__device__ static inline void canon_row(const Dev& d, size_t l, u64 (&w)[12]) {
+  uint4 r0 = d.R0[l], r1 = d.R1[l], r2 = d.R2[l], r3 = d.R3[l], r4 = d.R4[l], r5 = d.R5[l];
+  w[0] = (u64)r0.x | ((u64)r0.y << 32);
+  w[1] = (u64)r0.z | ((u64)r0.w << 32);
+  w[2] = (u64)r1.x | ((u64)r1.y << 32);
+  w[3] = (u64)r5.x | ((u64)r5.y << 32);
+  w[4] = (u64)r5.z | ((u64)r5.w << 32);
+  w[5] = (u64)r1.z | ((u64)r3.x << 32);              // flags, inc
+  w[6] = (u64)r1.w | ((u64)r2.x << 32);              // n_known, n_failed
+  w[7] = (u64)r2.y | ((u64)(r2.z & 0xFFFFu) << 32);  // n_left, next_seq
+  w[8] = (u64)r2.w | ((u64)r3.y << 32);              // overflow, susp_next
+  w[9] = (u64)r3.z | ((u64)r3.w << 32);              // awareness, probe_pending
+  w[10] = (u64)r4.x | ((u64)r4.y << 32);
+  w[11] = (u64)r4.z | ((u64)r4.w << 32);
+}
+// canonical sim_record i (drain order) of node l
+__device__ static inline uint4 canon_qrec(const Dev& d, size_t l, u32 i, u32 cnt) {
+  if (i >= cnt) return make_uint4(0u, SIM_META_EMPTY, 0u, 0u);
+  uint4 kq = d.qkeys[(size_t)(i >> 2) * d.Nl + l];
+  u32 k = (i & 3) == 0 ? kq.x : (i & 3) == 1 ? kq.y : (i & 3) == 2 ? kq.z : kq.w;
+  uint4 pay = d.qpay[(size_t)(k & 15u) * d.Nl + l];
+  return make_uint4(pay.x, ((k >> 4) << 8) | (pay.y & 0xFFu), pay.z, pay.w);
+}
+__global__ void canon_rows_kernel(Dev d, u64* out) {
+  for (size_t l = blockIdx.x * (size_t)blockDim.x + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * blockDim.x) {
+    u64 w[12];
+    canon_row(d, l, w);
+    for (int i = 0; i < 12; ++i) out[l * 12 + i] = w[i];
+  }
+}
+__global__ void canon_queue_kernel(Dev d, uint4* out) {
+  for (size_t l = blockIdx.x * (size_t)blockDim.x + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * blockDim.x) {
+    u32 cnt = __popc(d.R2[l].z >> 16);
+    for (u32 i = 0; i < SIM_Q; ++i) out[l * SIM_Q + i] = canon_qrec(d, l, i, cnt);
   }
 }
 
@@ -635,24 +1031,31 @@ __global__ void digest_flat(const u64* w, size_t n_words, u64* out) {
   for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < n_words; i += (size_t)gridDim.x * BLOCK) acc += dig(w[i], i);
   block_sum_add(acc, out);
 }
-__global__ void digest_u32(const u32* w, size_t n, u64* out) {
+// aux digest: slot map, then the liveness bitmap (bits past N masked)
+__global__ void digest_aux(const u32* slot_of, const u32* upmap, u32 N, u64* out) {
   u64 acc = 0;
-  for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) acc += dig((u64)w[i], i);
+  size_t nw = ((size_t)N + 31) / 32;
+  for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < (size_t)N + nw; i += (size_t)gridDim.x * BLOCK) {
+    if (i < N) {
+      acc += dig((u64)slot_of[i], i);
+    } else {
+      size_t j = i - N;
+      u32 w = upmap[j];
+      if (j == N / 32 && (N & 31)) w &= (1u << (N & 31)) - 1u;
+      acc += dig((u64)w, i);
+    }
+  }
   block_sum_add(acc, out);
 }
-// rows (canonical AoS sim_row, 10 words per node) and queue (canonical [node][Q])
 __global__ void digest_rows_queue(Dev d, u64* out_rows, u64* out_queue) {
   u64 ar = 0, aq = 0;
   for (size_t l = blockIdx.x * (size_t)BLOCK + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * BLOCK) {
-    u32 sc = d.seqcnt[l];
-    u64 w[10] = {d.clock[l], d.eclock[l], d.qclock[l], d.emin[l], d.qmin[l],
-                 (u64)d.flags[l] | ((u64)d.inc[l] << 32), (u64)d.nknown[l] | ((u64)d.nfailed[l] << 32),
-                 (u64)d.nleft[l] | ((u64)(sc & 0xFFFFu) << 32), (u64)d.overflow[l] | ((u64)d.suspnext[l] << 32),
-                 (u64)d.awareness[l] | ((u64)d.probepend[l] << 32)};
-    for (int i = 0; i < 10; ++i) ar += dig(w[i], l * 10 + i);
-    u32 cnt = sc >> 16;
+    u64 w[12];
+    canon_row(d, l, w);
+    for (int i = 0; i < 12; ++i) ar += dig(w[i], l * 12 + i);
+    u32 cnt = __popc(d.R2[l].z >> 16);
     for (u32 q = 0; q < SIM_Q; ++q) {
-      uint4 e = q < cnt ? d.queue[(size_t)q * d.Nl + l] : QEMPTY;
+      uint4 e = canon_qrec(d, l, q, cnt);
       aq += dig((u64)e.x | ((u64)e.y << 32), (l * SIM_Q + q) * 2);
       aq += dig((u64)e.z | ((u64)e.w << 32), (l * SIM_Q + q) * 2 + 1);
     }
@@ -673,7 +1076,7 @@ __global__ void members_kernel(Dev d, const uint4* base, u32 obs_l, uint8_t* st,
 __global__ void convergence_kernel(Dev d, const uint4* base, u32 kind, u32 key, u64 ltime, u64* out /*[2]*/) {
   u64 seen = 0, upc = 0;
   for (size_t l = blockIdx.x * (size_t)BLOCK + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * BLOCK) {
-    if (!(d.flags[l] & SIM_RF_UP)) continue;
+    if (!(d.R1[l].z & SIM_RF_UP)) continue;
     upc++;
     if (kind == SIM_K_JOIN || kind == SIM_K_LEAVE) {
       u32 a = d.slot_of[key];
@@ -694,20 +1097,25 @@ __global__ void stats_kernel(Dev d, u32 l, sim_stats* o) {
   if (threadIdx.x || blockIdx.x) return;
   sim_stats s;
   memset(&s, 0, sizeof s);
-  s.members = d.nknown[l]; s.failed = d.nfailed[l]; s.left = d.nleft[l];
-  s.health_score = d.awareness[l];
-  s.member_time = d.clock[l]; s.event_time = d.eclock[l]; s.query_time = d.qclock[l];
-  u32 cnt = d.seqcnt[l] >> 16;
+  uint4 r0 = d.R0[l], r1 = d.R1[l], r2 = d.R2[l], r3 = d.R3[l];
+  s.members = r1.w; s.failed = r2.x; s.left = r2.y;
+  s.health_score = r3.z;
+  s.member_time = (u64)r0.x | ((u64)r0.y << 32);
+  s.event_time = (u64)r0.z | ((u64)r0.w << 32);
+  s.query_time = (u64)r1.x | ((u64)r1.y << 32);
+  u32 cnt = __popc(r2.z >> 16);
   for (u32 q = 0; q < cnt; ++q) {
-    u32 cls = d.queue[(size_t)q * d.Nl + l].y >> 30;
+    uint4 kq = d.qkeys[(size_t)(q >> 2) * d.Nl + l];
+    u32 k = (q & 3) == 0 ? kq.x : (q & 3) == 1 ? kq.y : (q & 3) == 2 ? kq.z : kq.w;
+    u32 cls = k >> 26;
     if (cls == 0) s.swim_queue++; else if (cls == 1) s.intent_queue++; else if (cls == 2) s.query_queue++; else s.event_queue++;
   }
-  s.serf_state = SIM_RF_STATE(d.flags[l]); s.up = d.flags[l] & SIM_RF_UP; s.incarnation = d.inc[l];
-  s.queue_overflow = d.overflow[l];
+  s.serf_state = SIM_RF_STATE(r1.z); s.up = r1.z & SIM_RF_UP; s.incarnation = r3.x;
+  s.queue_overflow = r2.w;
   *o = s;
 }
-__global__ void set_flag_bits(u32* flags, u32 l, u32 bits) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) flags[l] |= bits;
+__global__ void set_flag_bits(uint4* R1, u32 l, u32 bits) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) R1[l].z |= bits;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -765,6 +1173,30 @@ static int cfg_check(const sim_config* c) {
   if (c->retransmit_mult * h_digits10(c->n_nodes) > 63u) return SIM_EINVAL;
   return SIM_OK;
 }
+// Suspicion parameters in ticks (memberlist suspicion.go / util.go); the same
+// arithmetic, in the same order, as the spec (DESIGN.md SIMSPEC §6).
+static void swim_params(const sim_config* c, u32* swim, u32* k_out, u32 T[SIM_MAX_CONF]) {
+  *swim = c->probe_interval > 0;
+  u32 k = c->suspicion_mult >= 2 ? c->suspicion_mult - 2 : 0;
+  if (k > SIM_MAX_CONF - 1) k = SIM_MAX_CONF - 1;
+  if (c->n_nodes < 2 || c->n_nodes - 2 < k) k = 0;
+  double scale = std::log10(c->n_nodes > 1 ? (double)c->n_nodes : 1.0);
+  if (scale < 1.0) scale = 1.0;
+  u64 mn = (u64)c->suspicion_mult * (u64)std::floor(scale * 1000.0) * c->probe_interval / 1000u;
+  if (mn < 1) mn = 1;
+  u64 mx = (u64)c->suspicion_max_mult * mn;
+  if (mx < mn) mx = mn;
+  for (u32 i = 0; i < SIM_MAX_CONF; ++i) {
+    double t = (double)mn;
+    if (k >= 1 && i <= k) {
+      double frac = std::log((double)i + 1.0) / std::log((double)k + 1.0);
+      t = std::floor((double)mx - frac * (double)(mx - mn));
+      if (t < (double)mn) t = (double)mn;
+    }
+    T[i] = t > 2000000.0 ? 2000000u : (u32)t;
+  }
+  *k_out = k;
+}
 
 template <typename T>
 static int dalloc(sim_handle* h, T** p, size_t n) {
@@ -775,6 +1207,7 @@ static int dalloc(sim_handle* h, T** p, size_t n) {
   return SIM_OK;
 }
 static inline int grid_for(size_t n) { return (int)std::min<size_t>((n + BLOCK - 1) / BLOCK, 8192); }
+#define EV_CAP (1u << 20)
 
 extern "C" {
 
@@ -804,6 +1237,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   h->stream = nullptr;
   h->op_cursor = 0;
   h->bound = false;
+  memset(&h->prev, 0, sizeof h->prev);
   (void)hipGetDevice(&h->device);
   Dev& d = h->d;
   memset(&d, 0, sizeof d);
@@ -815,22 +1249,27 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   h->dense = (cfg->view_slots == 0 || cfg->view_slots >= d.N);
   d.A = h->dense ? d.N : cfg->view_slots;
   d.Bev = cfg->event_ring; d.Bq = cfg->query_ring; d.f = cfg->fanout;
+  d.bev_mask = (d.Bev > 1 && !(d.Bev & (d.Bev - 1))) ? d.Bev - 1 : 0;
+  d.bq_mask = (d.Bq > 1 && !(d.Bq & (d.Bq - 1))) ? d.Bq - 1 : 0;
   d.retransmit_mult = cfg->retransmit_mult;
-  size_t Nl = d.Nl;
+  swim_params(cfg, &d.swim, &d.kconf, d.T);
+  d.PI = cfg->probe_interval;
+  d.ic = cfg->indirect_checks;
+  d.ev_cap = EV_CAP;
+  size_t Nl = d.Nl, nup = ((size_t)d.N + 31) / 32;
 #define DA(ptr, n)                                   \
   if ((rc = dalloc(h, &(ptr), (n))) != SIM_OK) {     \
     sim_destroy(h);                                  \
     return rc;                                       \
   }
-  DA(d.clock, Nl) DA(d.eclock, Nl) DA(d.qclock, Nl) DA(d.emin, Nl) DA(d.qmin, Nl)
-  DA(d.flags, Nl) DA(d.inc, Nl) DA(d.nknown, Nl) DA(d.nfailed, Nl) DA(d.nleft, Nl) DA(d.seqcnt, Nl)
-  DA(d.overflow, Nl) DA(d.suspnext, Nl) DA(d.awareness, Nl) DA(d.probepend, Nl)
-  DA(d.queue, (size_t)SIM_Q * Nl)
+  DA(d.R0, Nl) DA(d.R1, Nl) DA(d.R2, Nl) DA(d.R3, Nl) DA(d.R4, Nl) DA(d.R5, Nl)
+  DA(d.qkeys, 4 * Nl) DA(d.qpay, (size_t)SIM_Q * Nl)
   if (!d.sharded) { DA(d.inbox[0], (size_t)d.f * Nl * 4) DA(d.inbox[1], (size_t)d.f * Nl * 4) }
   DA(d.view, (size_t)d.A * Nl * 2)
   DA(d.ering, (size_t)d.Bev * Nl * 2)
   DA(d.qring, (size_t)d.Bq * Nl * 2)
-  DA(d.slot_of, d.N)
+  DA(d.slot_of, d.N) DA(d.subject_of, d.A) DA(d.upmap, nup)
+  DA(d.events, (size_t)EV_CAP) DA(d.ev_count, 1)
   DA(h->d_base, (size_t)d.N * 2)
   DA(h->d_scratch, 16)
   DA(h->d_mst, d.N)
@@ -840,20 +1279,18 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   bool joined = cfg->flags & SIM_CF_BASELINE_JOINED;
   hipStream_t s = h->stream;
   auto zero = [&](void* p, size_t bytes) { return hipMemsetAsync(p, 0, bytes, s); };
-  HCHECK(zero(d.emin, Nl * 8)); HCHECK(zero(d.qmin, Nl * 8)); HCHECK(zero(d.inc, Nl * 4));
-  HCHECK(zero(d.nfailed, Nl * 4)); HCHECK(zero(d.nleft, Nl * 4)); HCHECK(zero(d.seqcnt, Nl * 4));
-  HCHECK(zero(d.overflow, Nl * 4)); HCHECK(zero(d.suspnext, Nl * 4)); HCHECK(zero(d.awareness, Nl * 4));
-  HCHECK(zero(d.probepend, Nl * 4));
+  HCHECK(zero(d.R2, Nl * 16)); HCHECK(zero(d.R3, Nl * 16)); HCHECK(zero(d.R4, Nl * 16)); HCHECK(zero(d.R5, Nl * 16));
+  HCHECK(zero(d.qpay, (size_t)SIM_Q * Nl * 16));
+  HCHECK(zero(d.ev_count, 4));
   if (!d.sharded) { HCHECK(zero(d.inbox[0], (size_t)d.f * Nl * 64)); HCHECK(zero(d.inbox[1], (size_t)d.f * Nl * 64)); }
   HCHECK(zero(d.view, (size_t)d.A * Nl * 32));
   HCHECK(zero(d.ering, (size_t)d.Bev * Nl * 32));
   HCHECK(zero(d.qring, (size_t)d.Bq * Nl * 32));
-  fill_u64<<<grid_for(Nl), BLOCK, 0, s>>>(d.clock, Nl, joined ? 2 : 1);  // base.rs:196-205 (+ own join)
-  fill_u64<<<grid_for(Nl), BLOCK, 0, s>>>(d.eclock, Nl, 1);
-  fill_u64<<<grid_for(Nl), BLOCK, 0, s>>>(d.qclock, Nl, 1);
-  fill_u32<<<grid_for(Nl), BLOCK, 0, s>>>(d.flags, Nl, SIM_RF_UP | (SIM_SERF_ALIVE << 1));
-  fill_u32<<<grid_for(Nl), BLOCK, 0, s>>>(d.nknown, Nl, joined ? d.N : 1);
-  fill_u4<<<grid_for((size_t)SIM_Q * Nl), BLOCK, 0, s>>>(d.queue, (size_t)SIM_Q * Nl, QEMPTY);
+  HCHECK(hipMemsetAsync(d.upmap, 0xFF, nup * 4, s));
+  // base.rs:196-205: every clock starts at 1 (+ the own join at ltime 1 when pre-joined)
+  fill_u4<<<grid_for(Nl), BLOCK, 0, s>>>(d.R0, Nl, make_uint4(joined ? 2 : 1, 0, 1, 0));
+  fill_u4<<<grid_for(Nl), BLOCK, 0, s>>>(d.R1, Nl, make_uint4(1, 0, SIM_RF_UP | (SIM_SERF_ALIVE << 1), joined ? d.N : 1));
+  fill_u4<<<grid_for(4 * Nl), BLOCK, 0, s>>>(d.qkeys, 4 * Nl, make_uint4(KEMPTY, KEMPTY, KEMPTY, KEMPTY));
   // slot map + baseline
   h->slot_of.assign(d.N, NOSLOT);
   h->subject_of.assign(d.A, NOSLOT);
@@ -867,7 +1304,6 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
     h->n_slots = d.N;
     for (u32 i = 0; i < d.N; ++i) h->slot_of[i] = h->subject_of[i] = i;
     if (joined) {
-      // every entry of the dense table = baseline
       size_t tot = (size_t)d.A * Nl;
       fill_view_col<<<grid_for(tot), BLOCK, 0, s>>>(d.view, tot, 0, e0, e1);
     } else {
@@ -877,6 +1313,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
     h->n_slots = 0;
   }
   HCHECK(hipMemcpyAsync(d.slot_of, h->slot_of.data(), (size_t)d.N * 4, hipMemcpyHostToDevice, s));
+  HCHECK(hipMemcpyAsync(d.subject_of, h->subject_of.data(), (size_t)d.A * 4, hipMemcpyHostToDevice, s));
   HCHECK(hipStreamSynchronize(s));
   HCHECK(hipGetLastError());
   *out = h;
@@ -903,6 +1340,7 @@ static int ensure_slot(sim_handle* h, u32 subject) {
   uint4 e1 = make_uint4(b.conf[0], b.conf[1], b.conf[2], b.conf[3]);
   fill_view_col<<<grid_for(d.Nl), BLOCK, 0, h->stream>>>(d.view, d.Nl, a, e0, e1);
   HCHECK(hipMemcpyAsync(d.slot_of + subject, &h->slot_of[subject], 4, hipMemcpyHostToDevice, h->stream));
+  HCHECK(hipMemcpyAsync(d.subject_of + a, &h->subject_of[a], 4, hipMemcpyHostToDevice, h->stream));
   return SIM_OK;
 }
 
@@ -915,7 +1353,7 @@ int sim_inject(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, uint32_
     case SIM_OP_QUERY: if (!a) return SIM_EINVAL; break;
     case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: rc = ensure_slot(h, node); break;
     case SIM_OP_FORCE_LEAVE: rc = ensure_slot(h, a); break;
-    case SIM_OP_CRASH: case SIM_OP_REVIVE: break;
+    case SIM_OP_CRASH: case SIM_OP_REVIVE: if (h->d.swim) rc = ensure_slot(h, node); break;
     default: return SIM_EINVAL;
   }
   if (rc) return rc;
@@ -927,9 +1365,13 @@ int sim_inject(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, uint32_
 int sim_join(sim_handle* h, uint32_t node, uint32_t peer) { return sim_inject(h, h ? h->tick : 0, SIM_OP_JOIN, node, peer, 0); }
 int sim_leave(sim_handle* h, uint32_t node) {
   if (!h) return SIM_EINVAL;
+  // api.rs:422-499: leave intent now; memberlist.leave after broadcast_timeout; the caller's
+  // shutdown() (api.rs:525) after leave_propagate_delay — both modelled as leave_delay ticks
   int rc = sim_inject(h, h->tick, SIM_OP_LEAVE, node, 0, 0);
   if (rc) return rc;
-  return sim_inject(h, h->tick + h->cfg.leave_delay + 1, SIM_OP_LEAVE_FINISH, node, 0, 0);
+  rc = sim_inject(h, h->tick + h->cfg.leave_delay + 1, SIM_OP_LEAVE_FINISH, node, 0, 0);
+  if (rc) return rc;
+  return sim_inject(h, h->tick + 2 * h->cfg.leave_delay + 2, SIM_OP_CRASH, node, 0, 0);
 }
 int sim_force_leave(sim_handle* h, uint32_t node, uint32_t subject, int prune) {
   return sim_inject(h, h ? h->tick : 0, SIM_OP_FORCE_LEAVE, node, subject, prune ? 1u : 0u);
@@ -962,8 +1404,8 @@ int sim_step(sim_handle* h, uint32_t n_ticks) {
     }
     int grid = (int)((d.Nl + BLOCK - 1) / BLOCK);
     u32 cur = (u32)(h->tick & 1);
-    if (d.sharded) tick_kernel<true><<<grid, BLOCK, 0, h->stream>>>(d, tp, cur);
-    else tick_kernel<false><<<grid, BLOCK, 0, h->stream>>>(d, tp, cur);
+    if (d.sharded) tick_kernel<true><<<grid, BLOCK, 0, h->stream>>>(d, tp, cur, h->d_base);
+    else tick_kernel<false><<<grid, BLOCK, 0, h->stream>>>(d, tp, cur, h->d_base);
     h->prev = tp;
     h->tick++;
   }
@@ -1005,13 +1447,29 @@ int sim_watch(sim_handle* h, uint32_t obs) {
   if (!h) return SIM_EINVAL;
   Dev& d = h->d;
   if (obs < d.shard0 || obs >= d.shard0 + d.Nl) return SIM_EINVAL;
-  set_flag_bits<<<1, 64, 0, h->stream>>>(d.flags, obs - d.shard0, SIM_RF_WATCHED);
+  set_flag_bits<<<1, 64, 0, h->stream>>>(d.R1, obs - d.shard0, SIM_RF_WATCHED);
   return SIM_OK;
 }
 int sim_drain_events(sim_handle* h, sim_event* out, uint32_t cap, uint32_t* n) {
-  (void)out; (void)cap;
   if (!h || !n) return SIM_EINVAL;
-  *n = 0;  // event log of watched observers: not yet surfaced by the HIP path
+  Dev& d = h->d;
+  HCHECK(hipStreamSynchronize(h->stream));
+  u32 cnt = 0;
+  HCHECK(hipMemcpy(&cnt, d.ev_count, 4, hipMemcpyDeviceToHost));
+  if (cnt > d.ev_cap) cnt = d.ev_cap;
+  std::vector<sim_event> ev(cnt);
+  if (cnt) HCHECK(hipMemcpy(ev.data(), d.events, (size_t)cnt * sizeof(sim_event), hipMemcpyDeviceToHost));
+  // per node the log is in program order; across nodes the oracle's order is (tick, observer)
+  std::stable_sort(ev.begin(), ev.end(), [](const sim_event& a, const sim_event& b) {
+    return a.tick != b.tick ? a.tick < b.tick : a.observer < b.observer;
+  });
+  u32 m = std::min(cnt, cap);
+  if (out && m) memcpy(out, ev.data(), (size_t)m * sizeof(sim_event));
+  // keep what did not fit
+  u32 rest = cnt - m;
+  if (rest) HCHECK(hipMemcpy(d.events, ev.data() + m, (size_t)rest * sizeof(sim_event), hipMemcpyHostToDevice));
+  HCHECK(hipMemcpy(d.ev_count, &rest, 4, hipMemcpyHostToDevice));
+  *n = m;
   return SIM_OK;
 }
 
@@ -1029,7 +1487,7 @@ int sim_state_digest(sim_handle* h, uint64_t out[8]) {
   nw = (size_t)d.A * d.Nl * 4; digest_flat<<<grid_for(nw), BLOCK, 0, s>>>((const u64*)d.view, nw, h->d_scratch + 3);
   nw = (size_t)d.Bev * d.Nl * 4; digest_flat<<<grid_for(nw), BLOCK, 0, s>>>((const u64*)d.ering, nw, h->d_scratch + 4);
   nw = (size_t)d.Bq * d.Nl * 4; digest_flat<<<grid_for(nw), BLOCK, 0, s>>>((const u64*)d.qring, nw, h->d_scratch + 5);
-  digest_u32<<<grid_for(d.N), BLOCK, 0, s>>>(d.slot_of, d.N, h->d_scratch + 6);
+  digest_aux<<<grid_for((size_t)d.N + d.N / 32 + 1), BLOCK, 0, s>>>(d.slot_of, d.upmap, d.N, h->d_scratch + 6);
   HCHECK(hipMemcpyAsync(out, h->d_scratch, 8 * 8, hipMemcpyDeviceToHost, s));
   HCHECK(hipStreamSynchronize(s));
   out[7] = 0;
@@ -1055,32 +1513,14 @@ int sim_dump_state(sim_handle* h, uint32_t which, void* buf, size_t cap, size_t*
   if (!buf) return SIM_OK;
   if (cap < n) return SIM_ERANGE;
   HCHECK(hipStreamSynchronize(h->stream));
-  if (which == SIM_ARR_ROWS) {
-    std::vector<u64> c64(Nl);
-    std::vector<u32> c32(Nl);
-    sim_row* r = (sim_row*)buf;
-    memset(r, 0, n);
-#define G64(field, ptr) HCHECK(hipMemcpy(c64.data(), ptr, Nl * 8, hipMemcpyDeviceToHost)); for (size_t i = 0; i < Nl; ++i) r[i].field = c64[i];
-#define G32(field, ptr) HCHECK(hipMemcpy(c32.data(), ptr, Nl * 4, hipMemcpyDeviceToHost)); for (size_t i = 0; i < Nl; ++i) r[i].field = c32[i];
-    G64(clock, d.clock) G64(event_clock, d.eclock) G64(query_clock, d.qclock) G64(event_min, d.emin) G64(query_min, d.qmin)
-    G32(flags, d.flags) G32(inc, d.inc) G32(n_known, d.nknown) G32(n_failed, d.nfailed) G32(n_left, d.nleft)
-    G32(next_seq, d.seqcnt) G32(overflow, d.overflow) G32(susp_next, d.suspnext) G32(awareness, d.awareness) G32(probe_pending, d.probepend)
-#undef G64
-#undef G32
-    for (size_t i = 0; i < Nl; ++i) r[i].next_seq &= 0xFFFFu;
-    return SIM_OK;
-  }
-  if (which == SIM_ARR_QUEUE) {
-    std::vector<sim_record> t((size_t)SIM_Q * Nl);
-    std::vector<u32> sc(Nl);
-    HCHECK(hipMemcpy(t.data(), d.queue, t.size() * sizeof(sim_record), hipMemcpyDeviceToHost));
-    HCHECK(hipMemcpy(sc.data(), d.seqcnt, Nl * 4, hipMemcpyDeviceToHost));
-    sim_record* o = (sim_record*)buf;
-    for (size_t l = 0; l < Nl; ++l)
-      for (u32 q = 0; q < SIM_Q; ++q) {
-        if (q < (sc[l] >> 16)) o[l * SIM_Q + q] = t[(size_t)q * Nl + l];
-        else { o[l * SIM_Q + q].key = 0; o[l * SIM_Q + q].meta = SIM_META_EMPTY; o[l * SIM_Q + q].val = 0; }
-      }
+  if (which == SIM_ARR_ROWS || which == SIM_ARR_QUEUE) {  // canonical form is assembled on the device
+    void* tmp = nullptr;
+    if (hipMalloc(&tmp, std::max<size_t>(n, 16)) != hipSuccess) return SIM_ENOMEM;
+    if (which == SIM_ARR_ROWS) canon_rows_kernel<<<grid_for(Nl), BLOCK, 0, h->stream>>>(d, (u64*)tmp);
+    else canon_queue_kernel<<<grid_for(Nl), BLOCK, 0, h->stream>>>(d, (uint4*)tmp);
+    hipError_t e = hipMemcpy(buf, tmp, n, hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    HCHECK(e);
     return SIM_OK;
   }
   if (!src) { memset(buf, 0, n); return SIM_OK; }

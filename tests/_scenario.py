@@ -33,8 +33,9 @@ def schedule(n_nodes, n_ticks, rate, seed=1234, mix=(0.5, 0.15, 0.15, 0.1, 0.1),
                 node = int(rng.integers(0, n_nodes))
             used.add(node)
             if k == 2:
-                ops.append((t, _ffi.OP_LEAVE, node, 0, 0))
-                ops.append((t + 8, _ffi.OP_LEAVE_FINISH, node, 0, 0))
+                ops.append((t, _ffi.OP_LEAVE, node, 0, 0))          # Serf::leave: intent ...
+                ops.append((t + 8, _ffi.OP_LEAVE_FINISH, node, 0, 0))  # ... memberlist.leave ...
+                ops.append((t + 16, _ffi.OP_CRASH, node, 0, 0))        # ... shutdown
                 if rng.random() < 0.5:
                     ops.append((t + 30, _ffi.OP_JOIN, node, 0, 0))
             elif k == 3:

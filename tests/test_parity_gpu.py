@@ -16,21 +16,26 @@ def pair(oracle, hiplib, n, **kw):
 
 def test_backend_is_hip(hiplib):
     assert hiplib.backend_name() == "hip-gfx950"
-    assert hiplib.abi_version() == 1
+    assert hiplib.abi_version() == 2
 
 
+@pytest.mark.parametrize("swim", [0, 5, 2])
 @pytest.mark.parametrize("n,fanout,dense", [(128, 3, True), (100, 3, True), (257, 4, False), (1024, 4, False), (2, 3, True), (1, 3, True), (5, 4, True)])
-def test_full_state_every_tick_small(oracle, hiplib, n, fanout, dense):
-    # config 1 shape (128 nodes, fan-out 3) and ragged sizes; every array compared after every tick
-    kw = dict(fanout=fanout, view_slots=0 if dense else 64, event_ring=16, query_ring=8, leave_delay=6)
+def test_full_state_every_tick_small(oracle, hiplib, n, fanout, dense, swim):
+    # config 1 shape (128 nodes, fan-out 3) and ragged sizes; every array compared after every tick;
+    # swim = probe interval in ticks (0: serf layer only)
+    kw = dict(fanout=fanout, view_slots=0 if dense else 64, event_ring=16, query_ring=8, leave_delay=6,
+              probe_interval=swim, suspicion_mult=3 if swim == 2 else 4, suspicion_max_mult=2 if swim == 2 else 6)
     g, o = pair(oracle, hiplib, n, **kw)
     ops = sc.schedule(n, 60, rate=0.6, seed=n * 7 + fanout, max_member_subjects=min(n // 2, 40))
     sc.apply_schedule(g, ops)
     sc.apply_schedule(o, ops)
-    for t in range(90):
+    for t in range(90 if not swim else 160):
         g.step(1)
         o.step(1)
-        assert g.digest() == o.digest(), f"digest differs after tick {t}"
+        if g.digest() != o.digest():
+            sc.assert_same_state(g, o, f"n={n} tick {t}")
+            raise AssertionError(f"digest differs after tick {t} but the arrays agree")
         if t % 10 == 0 or t < 5:
             sc.assert_same_state(g, o, f"n={n} tick {t}")
     sc.assert_same_state(g, o, f"n={n} final")
@@ -50,6 +55,36 @@ def test_packet_loss_and_overload(oracle, hiplib):
     assert o.dump(_ffi.ARR_ROWS)["overflow"].sum() > 0, "scenario should exercise the overflow path"
 
 
+def test_swim_crash_refute_leave_events(oracle, hiplib):
+    # memberlist layer end to end: crashes detected through probes and suspicion timers, a revived node
+    # refuting, graceful leaves, packet loss causing false suspicions; watched observers' event logs
+    n = 256
+    kw = dict(fanout=3, view_slots=0, event_ring=16, query_ring=8, leave_delay=5, probe_interval=3,
+              suspicion_mult=4, suspicion_max_mult=3, indirect_checks=1, loss=0.2)
+    g, o = pair(oracle, hiplib, n, **kw)
+    for s in (g, o):
+        for w in (0, 7, 200):
+            s.watch(w)
+        s.inject(2, _ffi.OP_CRASH, 50)
+        s.inject(3, _ffi.OP_CRASH, 51)
+        s.inject(40, _ffi.OP_REVIVE, 51)
+        s.inject(5, _ffi.OP_USER_EVENT, 9, 77, 40)
+        s.step(1)
+        s.leave(60)
+        s.inject(90, _ffi.OP_JOIN, 60)
+    for t in range(260):
+        g.step(1)
+        o.step(1)
+        if g.digest() != o.digest():
+            sc.assert_same_state(g, o, f"swim tick {t}")
+            raise AssertionError(f"digest differs after tick {t}")
+    sc.assert_same_state(g, o, "swim final")
+    eg, eo = g.drain_events(), o.drain_events()
+    assert eg == eo and len(eo) > 0
+    assert o.dump(_ffi.ARR_ROWS)["inc"].max() >= 1, "scenario should exercise refutation"
+    assert o.dump(_ffi.ARR_ROWS)["n_failed"].max() >= 1, "scenario should declare the crashed node failed"
+
+
 def test_seq_renormalisation(oracle, hiplib):
     # > 1023 queue ids on one node forces the id renumbering path
     g, o = pair(oracle, hiplib, 64, fanout=3, event_ring=2048)
@@ -66,7 +101,7 @@ def test_seq_renormalisation(oracle, hiplib):
 def test_config2_64k_bit_exact(oracle, hiplib):
     # BASELINE config 2: 64 Ki nodes, fan-out 3, bit-exact vs CPU replay, >= 256 ticks
     n = 65536
-    g, o = pair(oracle, hiplib, n, fanout=3, view_slots=128, event_ring=64, query_ring=64)
+    g, o = pair(oracle, hiplib, n, fanout=3, view_slots=128, event_ring=64, query_ring=64, probe_interval=5)
     ops = sc.schedule(n, 200, rate=0.5, seed=2, max_member_subjects=100)
     sc.apply_schedule(g, ops)
     sc.apply_schedule(o, ops)
