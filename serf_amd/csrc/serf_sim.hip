@@ -189,6 +189,16 @@ struct Ctx {
   u32 l, gid;
   u32 tick;  // low 32 bits of the tick
 };
+// A handler invocation queues at most one broadcast (the rebroadcast of the record it was given, or
+// the refutation it answers with); it is parked here so that the kernel has ONE queue_broadcast
+// site per call site of the handlers instead of one per `return true`.
+struct Ins {
+  u32 has, key, wmeta;
+  u64 val;
+};
+__device__ static inline void ins_set(Ins& q, u32 key, u32 wmeta, u64 val) {
+  q.has = 1; q.key = key; q.wmeta = wmeta; q.val = val;
+}
 
 __device__ static inline u32 kind_class(u32 kind) {
   return (kind == SIM_K_JOIN || kind == SIM_K_LEAVE) ? 1u : kind == SIM_K_QUERY ? 2u : kind == SIM_K_EVENT ? 3u : 0u;
@@ -417,14 +427,14 @@ __device__ static bool handle_join_intent(const Ctx& c, Node& n, u32 subject, u6
   return rb;
 }
 // broadcast_join: base.rs:381-397
-__device__ static void broadcast_join(const Ctx& c, Node& n, u64 ltime, bool& dirty) {
+__device__ static void broadcast_join(const Ctx& c, Node& n, u64 ltime, bool& dirty, Ins& ins) {
   witness(n.clock, ltime);
   uint4* p = view_ptr(c, c.gid);
   handle_join_intent(c, n, c.gid, ltime, p, p ? p[0] : make_uint4(0, 0, 0, 0), dirty);
-  q_insert(c, n, c.gid, wire_meta(SIM_K_JOIN, 0, 16), ltime);
+  ins_set(ins, c.gid, wire_meta(SIM_K_JOIN, 0, 16), ltime);
 }
 // handle_node_leave_intent: base.rs:1442-1572
-__device__ static bool handle_leave_intent(const Ctx& c, Node& n, u32 subject, u64 ltime, bool prune, uint4* p, uint4 e, bool& dirty) {
+__device__ static bool handle_leave_intent(const Ctx& c, Node& n, u32 subject, u64 ltime, bool prune, uint4* p, uint4 e, bool& dirty, Ins& ins) {
   u32 state = SIM_RF_STATE(n.flags);
   witness(n.clock, ltime);
   if (!p) return false;
@@ -435,7 +445,7 @@ __device__ static bool handle_leave_intent(const Ctx& c, Node& n, u32 subject, u
   }
   if (ltime <= E_LTIME(e)) return false;
   if (subject == c.gid && state == SIM_SERF_ALIVE) {  // refute: base.rs:1470-1480
-    broadcast_join(c, n, n.clock, dirty);
+    broadcast_join(c, n, n.clock, dirty, ins);
     return false;
   }
   E_SET_LTIME(e, ltime);
@@ -569,21 +579,21 @@ __device__ static inline void susp_track(const Ctx& c, Node& n, u32 slot, u32 de
   c.d.R4[c.l] = s;
   if (!n.susp_next || deadline < n.susp_next) n.susp_next = deadline;
 }
-__device__ static void swim_refute(const Ctx& c, Node& n, u32 accused_inc) {
+__device__ static void swim_refute(const Ctx& c, Node& n, u32 accused_inc, Ins& ins) {
   u32 inc = n.inc + 1;
   if (accused_inc >= inc) inc = accused_inc + 1;
   n.inc = inc;
   uint4* p = view_ptr(c, c.gid);
   if (p) { uint4 e = p[0]; e.z = inc; p[0] = e; }
   aw_delta(n, +1);
-  q_insert(c, n, c.gid, wire_meta(SIM_K_ALIVE, 0, 64), inc);
+  ins_set(ins, c.gid, wire_meta(SIM_K_ALIVE, 0, 64), inc);
 }
-__device__ static void swim_alive(const Ctx& c, Node& n, u32 subject, u32 inc, u32 wmeta, uint4* p, uint4 e, bool& dirty) {
+__device__ static void swim_alive(const Ctx& c, Node& n, u32 subject, u32 inc, u32 wmeta, uint4* p, uint4 e, bool& dirty, Ins& ins) {
   if (!p) return;
   if (subject == c.gid) {
     if (inc <= n.inc) return;
     dirty = true;
-    swim_refute(c, n, inc);
+    swim_refute(c, n, inc, ins);
     return;
   }
   if (!(e.w & SIM_VB_KNOWN)) {  // new member: notify_join
@@ -592,7 +602,7 @@ __device__ static void swim_alive(const Ctx& c, Node& n, u32 subject, u32 inc, u
     e.z = inc;
     p[0] = e;
     dirty = true;
-    q_insert(c, n, subject, wmeta, inc);
+    ins_set(ins, subject, wmeta, inc);
     return;
   }
   if (inc <= e.z) return;
@@ -600,12 +610,12 @@ __device__ static void swim_alive(const Ctx& c, Node& n, u32 subject, u32 inc, u
   if (old == SIM_SWIM_SUSPECT) susp_forget(c, c.d.slot_of[subject]);
   e.z = inc;
   e.w = vb_set_nconf(vb_set_swim(e.w, SIM_SWIM_ALIVE), 0);
-  q_insert(c, n, subject, wmeta, inc);
+  ins_set(ins, subject, wmeta, inc);
   if (old == SIM_SWIM_DEAD || old == SIM_SWIM_LEFT) node_join_e(c, n, e, subject);
   p[0] = e;
   dirty = true;
 }
-__device__ static void swim_suspect(const Ctx& c, Node& n, u32 subject, u32 inc, u32 from, u32 wmeta, uint4* p, uint4 e, bool& dirty) {
+__device__ static void swim_suspect(const Ctx& c, Node& n, u32 subject, u32 inc, u32 from, u32 wmeta, uint4* p, uint4 e, bool& dirty, Ins& ins) {
   const Dev& d = c.d;
   if (!p || !(e.w & SIM_VB_KNOWN)) return;
   if (inc < e.z) return;
@@ -627,12 +637,12 @@ __device__ static void swim_suspect(const Ctx& c, Node& n, u32 subject, u32 inc,
     dirty = true;
     u32 deadline = c.tick - ((c.tick - SIM_VB_STAMP(e.w)) & STAMP_MASK) + d.T[k + 1];
     if (n.susp_next && deadline < n.susp_next) n.susp_next = deadline;
-    q_insert(c, n, subject, wmeta, val);
+    ins_set(ins, subject, wmeta, val);
     return;
   }
   if (SIM_VB_SWIM(e.w) != SIM_SWIM_ALIVE) return;
-  if (subject == c.gid) { dirty = true; swim_refute(c, n, inc); return; }
-  q_insert(c, n, subject, wmeta, val);
+  if (subject == c.gid) { dirty = true; swim_refute(c, n, inc, ins); return; }
+  ins_set(ins, subject, wmeta, val);
   e.z = inc;
   e.w = vb_set_stamp(vb_set_nconf(vb_set_swim(e.w, SIM_SWIM_SUSPECT), 0), c.tick & STAMP_MASK);
   p[0] = e;
@@ -640,7 +650,7 @@ __device__ static void swim_suspect(const Ctx& c, Node& n, u32 subject, u32 inc,
   dirty = true;
   susp_track(c, n, d.slot_of[subject], c.tick + d.T[0]);
 }
-__device__ static void swim_dead(const Ctx& c, Node& n, u32 subject, u32 inc, u32 from, u32 wmeta, uint4* p, uint4 e, bool& dirty) {
+__device__ static void swim_dead(const Ctx& c, Node& n, u32 subject, u32 inc, u32 from, u32 wmeta, uint4* p, uint4 e, bool& dirty, Ins& ins) {
   if (!p || !(e.w & SIM_VB_KNOWN)) return;
   if (inc < e.z) return;
   u32 old = SIM_VB_SWIM(e.w);
@@ -654,44 +664,40 @@ __device__ static void swim_dead(const Ctx& c, Node& n, u32 subject, u32 inc, u3
   u32 st = SIM_RF_STATE(n.flags);
   if (subject == c.gid && st != SIM_SERF_LEAVING && st != SIM_SERF_LEFT) {  // not leaving: refute
     dirty = true;
-    swim_refute(c, n, inc);
+    swim_refute(c, n, inc, ins);
     return;
   }
-  q_insert(c, n, subject, wmeta, (u64)inc | ((u64)from << 32));
+  ins_set(ins, subject, wmeta, (u64)inc | ((u64)from << 32));
   e.z = inc;
   e.w = vb_set_swim(e.w, from == subject ? SIM_SWIM_LEFT : SIM_SWIM_DEAD);
   node_leave_e(c, n, e, subject);  // notify_leave
   p[0] = e;
   dirty = true;
 }
-// suspicion timers (B.5): fire -> deadNode(inc, from = self)
-__device__ static void swim_timers(const Ctx& c, Node& n) {
+// suspicion timers (B.5): fire -> deadNode(inc, from = self).  One call examines timer j;
+// `next` accumulates the earliest deadline still pending.
+__device__ static void swim_timer_j(const Ctx& c, Node& n, u32 j, u32& next, Ins& ins) {
   const Dev& d = c.d;
   u32 now = c.tick;
-  if (!n.susp_next || now < n.susp_next) return;
-  u32 next = 0;
-  bool dirty = false;
-  for (u32 j = 0; j < SIM_S; ++j) {
-    uint4 s4 = d.R4[c.l];  // reloaded: swim_dead's susp_forget rewrites it
-    u32 a = j == 0 ? s4.x : j == 1 ? s4.y : j == 2 ? s4.z : s4.w;
-    if (!a) continue;
-    uint4* p = view_slot_ptr(c, a - 1);
-    uint4 e = p[0];
-    if (SIM_VB_SWIM(e.w) != SIM_SWIM_SUSPECT) {
-      if (j == 0) s4.x = 0; else if (j == 1) s4.y = 0; else if (j == 2) s4.z = 0; else s4.w = 0;
-      d.R4[c.l] = s4;
-      continue;
-    }
-    u32 age = (now - SIM_VB_STAMP(e.w)) & STAMP_MASK;
-    u32 T = d.T[SIM_VB_NCONF(e.w)];
-    if (age >= T) {
-      swim_dead(c, n, d.subject_of[a - 1], e.z, c.gid, wire_meta(SIM_K_DEAD, 0, 32), p, e, dirty);
-    } else {
-      u32 deadline = now - age + T;
-      if (!next || deadline < next) next = deadline;
-    }
+  uint4 s4 = d.R4[c.l];  // re-read every time: swim_dead's susp_forget rewrites it
+  u32 a = j == 0 ? s4.x : j == 1 ? s4.y : j == 2 ? s4.z : s4.w;
+  if (!a) return;
+  uint4* p = view_slot_ptr(c, a - 1);
+  uint4 e = p[0];
+  if (SIM_VB_SWIM(e.w) != SIM_SWIM_SUSPECT) {
+    if (j == 0) s4.x = 0; else if (j == 1) s4.y = 0; else if (j == 2) s4.z = 0; else s4.w = 0;
+    d.R4[c.l] = s4;
+    return;
   }
-  n.susp_next = next;
+  u32 age = (now - SIM_VB_STAMP(e.w)) & STAMP_MASK;
+  u32 T = d.T[SIM_VB_NCONF(e.w)];
+  if (age >= T) {
+    bool dirty = false;
+    swim_dead(c, n, d.subject_of[a - 1], e.z, c.gid, wire_meta(SIM_K_DEAD, 0, 32), p, e, dirty, ins);
+  } else {
+    u32 deadline = now - age + T;
+    if (!next || deadline < next) next = deadline;
+  }
 }
 // probe (B.3)
 __device__ static inline u64 probe_draw(const TickP& tp, u32 gid, u32 j) { return mix64(tp.probe_base ^ ((u64)gid * 32u + j)); }
@@ -699,9 +705,8 @@ __device__ static inline bool leg_lost(const TickP& tp, u32 gid, u32 j) {
   return tp.loss_u32 && (u32)(probe_draw(tp, gid, j) >> 32) < tp.loss_u32;
 }
 __device__ static inline bool up_of(const Dev& d, u32 gid) { return (d.upmap[gid >> 5] >> (gid & 31)) & 1u; }
-__device__ static void swim_probe(const Ctx& c, Node& n, const TickP& tp, const uint4* base) {
+__device__ static void swim_probe(const Ctx& c, Node& n, const TickP& tp, const uint4* base, Ins& ins) {
   const Dev& d = c.d;
-  if (d.N < 2 || (c.tick + c.gid) % d.PI) return;
   u32 t = (u32)(probe_draw(tp, c.gid, PD_TARGET) % (u64)(d.N - 1));
   if (t >= c.gid) ++t;
   uint4* p = view_ptr(c, t);
@@ -723,7 +728,7 @@ __device__ static void swim_probe(const Ctx& c, Node& n, const TickP& tp, const 
   aw_delta(n, +1);
   if (!p) { n.overflow++; return; }  // model bound: no view slot to hold the suspicion
   bool dirty = false;
-  swim_suspect(c, n, t, e.z, c.gid, wire_meta(SIM_K_SUSPECT, 0, 32), p, e, dirty);
+  swim_suspect(c, n, t, e.z, c.gid, wire_meta(SIM_K_SUSPECT, 0, 32), p, e, dirty, ins);
 }
 
 // ---- SerfDelegate::notify_message: delegate.rs:183-300 -----------------------------------------------
@@ -737,20 +742,24 @@ __device__ static inline uint4* lookup_ptr(const Ctx& c, u32 kind, u32 key, u64 
   if (kind == SIM_K_EMPTY || slot == NOSLOT) return nullptr;
   return view_slot_ptr(c, slot);
 }
-__device__ static void dispatch(const Ctx& c, Node& n, const uint4& r, uint4* p, const uint4& e, bool& dirty) {
+__device__ static inline void dispatch(const Ctx& c, Node& n, const uint4& r, uint4* p, const uint4& e, bool& dirty, Ins& ins) {
   u32 kind = SIM_META_KIND(r.y), flags = SIM_META_FLAGS(r.y);
   u64 val = (u64)r.z | ((u64)r.w << 32);
   bool rb = false;
   if (kind == SIM_K_EVENT) rb = handle_user_event(c, n, r.x, val, p, e, dirty);
   else if (kind == SIM_K_QUERY) rb = handle_query(c, n, r.x, val, flags, p, e, dirty);
   else if (kind == SIM_K_JOIN) rb = handle_join_intent(c, n, r.x, val, p, e, dirty);
-  else if (kind == SIM_K_LEAVE) rb = handle_leave_intent(c, n, r.x, val, flags & SIM_F_PRUNE, p, e, dirty);
+  else if (kind == SIM_K_LEAVE) rb = handle_leave_intent(c, n, r.x, val, flags & SIM_F_PRUNE, p, e, dirty, ins);
   else if (c.d.swim) {  // memberlist's own broadcasts are handled below the serf delegate
-    if (kind == SIM_K_ALIVE) swim_alive(c, n, r.x, r.z, r.y, p, e, dirty);
-    else if (kind == SIM_K_SUSPECT) swim_suspect(c, n, r.x, r.z, r.w, r.y, p, e, dirty);
-    else if (kind == SIM_K_DEAD) swim_dead(c, n, r.x, r.z, r.w, r.y, p, e, dirty);
+    if (kind == SIM_K_ALIVE) swim_alive(c, n, r.x, r.z, r.y, p, e, dirty, ins);
+    else if (kind == SIM_K_SUSPECT) swim_suspect(c, n, r.x, r.z, r.w, r.y, p, e, dirty, ins);
+    else if (kind == SIM_K_DEAD) swim_dead(c, n, r.x, r.z, r.w, r.y, p, e, dirty, ins);
   }
-  if (rb) q_insert(c, n, r.x, r.y, val);  // re-queue the original message unchanged (delegate.rs:294-300)
+  if (rb) ins_set(ins, r.x, r.y, val);  // re-queue the original message unchanged (delegate.rs:294-300)
+}
+#define SEL4(i, a, b, c, d) ((i) == 0 ? (a) : (i) == 1 ? (b) : (i) == 2 ? (c) : (d))
+__device__ static inline uint4 sel4(u32 i, const uint4& a, const uint4& b, const uint4& c, const uint4& d) {
+  return make_uint4(SEL4(i, a.x, b.x, c.x, d.x), SEL4(i, a.y, b.y, c.y, d.y), SEL4(i, a.z, b.z, c.z, d.z), SEL4(i, a.w, b.w, c.w, d.w));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -780,43 +789,57 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
         } else {
           cell = d.inbox[cur] + ((size_t)k * d.Nl + l) * 4;
         }
-        uint4 r[SIM_P];
-#pragma unroll
-        for (int p = 0; p < (int)SIM_P; ++p) r[p] = cell[p];
-        // wave-uniform early out: nobody in this wave received anything in packet k
-        bool any = false;
-#pragma unroll
-        for (int p = 0; p < (int)SIM_P; ++p) any |= SIM_META_KIND(r[p].y) != SIM_K_EMPTY;
-        if (!__any(any)) continue;
-        // phase A: the four lookups of this packet, independent of each other
-        u32 sl[SIM_P];
-#pragma unroll
-        for (int p = 0; p < (int)SIM_P; ++p) {
-          u32 kind = SIM_META_KIND(r[p].y);
-          sl[p] = (member_kind(kind) && r[p].x < d.N) ? d.slot_of[r[p].x] : NOSLOT;
-        }
-        uint4* ptr[SIM_P];
-        uint4 e0[SIM_P];
-#pragma unroll
-        for (int p = 0; p < (int)SIM_P; ++p) {
-          ptr[p] = lookup_ptr(c, SIM_META_KIND(r[p].y), r[p].x, (u64)r[p].z | ((u64)r[p].w << 32), sl[p]);
-          e0[p] = ptr[p] ? ptr[p][0] : zero;
-        }
-        // phase B: the handlers, in arrival order; an entry is re-read if an earlier record of
-        // this packet changed anything (rare: most records are duplicates)
+        uint4 r0 = cell[0], r1 = cell[1], r2 = cell[2], r3 = cell[3];
+        u32 k0 = SIM_META_KIND(r0.y), k1 = SIM_META_KIND(r1.y), k2 = SIM_META_KIND(r2.y), k3 = SIM_META_KIND(r3.y);
+        // wave-ballot early out: nobody in this wave received anything in packet k
+        if (!__any((k0 | k1 | k2 | k3) != SIM_K_EMPTY)) continue;
+        // phase A: the four lookups of this packet, independent of each other — first the slot
+        // map (member records), then the 16-byte head of the view entry / ring bucket
+        u32 s0 = (member_kind(k0) && r0.x < d.N) ? d.slot_of[r0.x] : NOSLOT;
+        u32 s1 = (member_kind(k1) && r1.x < d.N) ? d.slot_of[r1.x] : NOSLOT;
+        u32 s2 = (member_kind(k2) && r2.x < d.N) ? d.slot_of[r2.x] : NOSLOT;
+        u32 s3 = (member_kind(k3) && r3.x < d.N) ? d.slot_of[r3.x] : NOSLOT;
+        uint4* p0 = lookup_ptr(c, k0, r0.x, (u64)r0.z | ((u64)r0.w << 32), s0);
+        uint4* p1 = lookup_ptr(c, k1, r1.x, (u64)r1.z | ((u64)r1.w << 32), s1);
+        uint4* p2 = lookup_ptr(c, k2, r2.x, (u64)r2.z | ((u64)r2.w << 32), s2);
+        uint4* p3 = lookup_ptr(c, k3, r3.x, (u64)r3.z | ((u64)r3.w << 32), s3);
+        uint4 e0 = p0 ? p0[0] : zero, e1 = p1 ? p1[0] : zero, e2 = p2 ? p2[0] : zero, e3 = p3 ? p3[0] : zero;
+        // phase B: the handlers, in arrival order (one rolled loop = one copy of the handler code);
+        // an entry is re-read if an earlier record of this packet changed anything (rare: most
+        // records are duplicates)
         bool dirty = false;
-#pragma unroll
-        for (int p = 0; p < (int)SIM_P; ++p) {
-          if (SIM_META_KIND(r[p].y) == SIM_K_EMPTY) continue;
-          uint4 e = e0[p];
-          if (dirty && ptr[p]) e = ptr[p][0];
-          dispatch(c, n, r[p], ptr[p], e, dirty);
+#pragma unroll 1
+        for (u32 p = 0; p < SIM_P; ++p) {
+          uint4 r = sel4(p, r0, r1, r2, r3);
+          if (SIM_META_KIND(r.y) == SIM_K_EMPTY) continue;
+          uint4* ptr = SEL4(p, p0, p1, p2, p3);
+          uint4 e = sel4(p, e0, e1, e2, e3);
+          if (dirty && ptr) e = ptr[0];
+          Ins ins;
+          ins.has = 0;
+          dispatch(c, n, r, ptr, e, dirty, ins);
+          if (ins.has) q_insert(c, n, ins.key, ins.wmeta, ins.val);
         }
       }
     }
     if (d.swim) {
-      swim_timers(c, n);
-      swim_probe(c, n, tp, base);
+      // suspicion timers (4 slots), then the probe: five producers, one queue_broadcast site
+      bool due = n.susp_next && (u32)tp.tick >= n.susp_next;
+      bool probing = d.N >= 2 && ((u32)tp.tick + gid) % d.PI == 0;
+      if (__any(due || probing)) {
+        u32 next = 0;
+#pragma unroll 1
+        for (u32 j = 0; j <= SIM_S; ++j) {
+          Ins ins;
+          ins.has = 0;
+          if (j < SIM_S) { if (due) swim_timer_j(c, n, j, next, ins); }
+          else {
+            if (due) n.susp_next = next;
+            if (probing) swim_probe(c, n, tp, base, ins);
+          }
+          if (ins.has) q_insert(c, n, ins.key, ins.wmeta, ins.val);
+        }
+      }
     }
   }
   u32 limit = up ? d.retransmit_mult * digits10(n.nknown) : 0;
@@ -874,6 +897,8 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive) {
     if (n.next_seq > 1023u - 64u) q_renorm(n);
     bool up = n.flags & SIM_RF_UP, dirty = false;
     u32 a = ob.a[i], b = ob.b[i];
+    Ins ins, ins2;  // ins: what the handler queues; ins2: the op's own broadcast, queued after it
+    ins.has = ins2.has = 0;
     switch (op) {
       case SIM_OP_USER_EVENT:  // api.rs:241-299
         if (up) {
@@ -881,7 +906,7 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive) {
           n.eclock++;
           uint4* p = ering_ptr(c, lt);
           handle_user_event(c, n, a, lt, p, p[0], dirty);
-          q_insert(c, n, a, wire_meta(SIM_K_EVENT, 0, b), lt);
+          ins_set(ins2, a, wire_meta(SIM_K_EVENT, 0, b), lt);
         }
         break;
       case SIM_OP_QUERY:  // base.rs:875-942
@@ -889,7 +914,7 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive) {
           u64 lt = n.qclock;
           uint4* p = qring_ptr(c, lt);
           handle_query(c, n, a, lt, b, p, p[0], dirty);
-          q_insert(c, n, a, wire_meta(SIM_K_QUERY, b, 32), lt);
+          ins_set(ins2, a, wire_meta(SIM_K_QUERY, b, 32), lt);
         }
         break;
       case SIM_OP_LEAVE:  // api.rs:422-460
@@ -898,15 +923,15 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive) {
           u64 lt = n.clock;
           n.clock++;
           uint4* p = view_ptr(c, gid);
-          handle_leave_intent(c, n, gid, lt, false, p, p ? p[0] : make_uint4(0, 0, 0, 0), dirty);
-          if (has_alive) q_insert(c, n, gid, wire_meta(SIM_K_LEAVE, 0, 16), lt);
+          handle_leave_intent(c, n, gid, lt, false, p, p ? p[0] : make_uint4(0, 0, 0, 0), dirty, ins);
+          if (has_alive) ins_set(ins2, gid, wire_meta(SIM_K_LEAVE, 0, 16), lt);
         }
         break;
       case SIM_OP_LEAVE_FINISH:  // api.rs:474-497: memberlist.leave (dead{self, from = self}), state = Left
         if (up && SIM_RF_STATE(n.flags) == SIM_SERF_LEAVING) {
           if (d.swim) {
             uint4* p = view_ptr(c, gid);
-            swim_dead(c, n, gid, n.inc, gid, wire_meta(SIM_K_DEAD, 0, 32), p, p ? p[0] : make_uint4(0, 0, 0, 0), dirty);
+            swim_dead(c, n, gid, n.inc, gid, wire_meta(SIM_K_DEAD, 0, 32), p, p ? p[0] : make_uint4(0, 0, 0, 0), dirty, ins);
           }
           n.flags = (n.flags & ~(3u << 1)) | (SIM_SERF_LEFT << 1);
         }
@@ -924,7 +949,7 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive) {
             e.w = vb_set_nconf(vb_set_swim(e.w, SIM_SWIM_ALIVE), 0);
             p[0] = e;
           }
-          swim_refute(c, n, accused);
+          swim_refute(c, n, accused, ins);
           aw_delta(n, -1);
           if (p && (old == SIM_SWIM_DEAD || old == SIM_SWIM_LEFT)) {
             uint4 e = p[0];
@@ -932,20 +957,22 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive) {
             p[0] = e;
           }
         }
-        broadcast_join(c, n, n.clock, dirty);
+        broadcast_join(c, n, n.clock, dirty, ins2);
         break;
       case SIM_OP_FORCE_LEAVE:  // base.rs:452-480
         if (up) {
           u64 lt = n.clock;
           uint4* p = view_ptr(c, a);
-          handle_leave_intent(c, n, a, lt, b != 0, p, p ? p[0] : make_uint4(0, 0, 0, 0), dirty);
-          if (has_alive) q_insert(c, n, a, wire_meta(SIM_K_LEAVE, b ? SIM_F_PRUNE : 0, 16), lt);
+          handle_leave_intent(c, n, a, lt, b != 0, p, p ? p[0] : make_uint4(0, 0, 0, 0), dirty, ins);
+          if (has_alive) ins_set(ins2, a, wire_meta(SIM_K_LEAVE, b ? SIM_F_PRUNE : 0, 16), lt);
         }
         break;
       case SIM_OP_CRASH: n.flags &= ~SIM_RF_UP; break;
       case SIM_OP_REVIVE: n.flags |= SIM_RF_UP; break;
       default: break;
     }
+    if (ins.has) q_insert(c, n, ins.key, ins.wmeta, ins.val);
+    if (ins2.has) q_insert(c, n, ins2.key, ins2.wmeta, ins2.val);
     node_store(d, l, n, o);
     __threadfence();  // the next op of this batch may touch the same node
   }
