@@ -699,14 +699,18 @@ static void swim_timers(nctx* c) {
 static inline uint64_t probe_draw(const tickp* p, uint32_t gid, uint32_t j) {
   return mix64(p->probe_base ^ ((uint64_t)gid * 32u + j));
 }
+/* uniform draw in [0, n): multiply-shift range reduction of the draw's high 32 bits */
+static inline uint32_t draw_below(uint64_t draw, uint32_t n) { return (uint32_t)(((draw >> 32) * (uint64_t)n) >> 32); }
 static inline int leg_lost(const tickp* p, uint32_t gid, uint32_t j) {
   return p->loss_u32 && (uint32_t)(probe_draw(p, gid, j) >> 32) < p->loss_u32;
 }
 static void swim_probe(nctx* c, const tickp* p) {
   osim* s = c->s;
   uint32_t PI = s->cfg.probe_interval;
-  if (s->N < 2 || ((uint32_t)s->tick + c->gid) % PI) return;
-  uint32_t t = (uint32_t)(probe_draw(p, c->gid, PD_TARGET) % (uint64_t)(s->N - 1));
+  /* probe phase: the 64 nodes of an id-aligned group share it (one wavefront on the GPU), groups
+   * are staggered over the probe interval like memberlist's randomly started probe tickers */
+  if (s->N < 2 || ((uint32_t)s->tick + (c->gid >> 6)) % PI) return;
+  uint32_t t = draw_below(probe_draw(p, c->gid, PD_TARGET), s->N - 1);
   if (t >= c->gid) ++t; /* uniform over the other N-1 nodes */
   sim_view* e = view_at(s, c->l, t);
   const sim_view* ev = e ? e : &s->base[t];
@@ -717,7 +721,7 @@ static void swim_probe(nctx* c, const tickp* p) {
   if (up_of(s, t)) {
     ok = !leg_lost(p, c->gid, PD_PING) && !leg_lost(p, c->gid, PD_ACK);
     for (uint32_t j = 0; !ok && j < s->cfg.indirect_checks && j < 4; ++j) {
-      uint32_t r = (uint32_t)(probe_draw(p, c->gid, PD_RELAY0 + 5 * j) % (uint64_t)s->N);
+      uint32_t r = draw_below(probe_draw(p, c->gid, PD_RELAY0 + 5 * j), s->N);
       if (r == c->gid || r == t || !up_of(s, r)) continue;
       ok = !leg_lost(p, c->gid, PD_RELAY0 + 5 * j + 1) && !leg_lost(p, c->gid, PD_RELAY0 + 5 * j + 2) &&
            !leg_lost(p, c->gid, PD_RELAY0 + 5 * j + 3) && !leg_lost(p, c->gid, PD_RELAY0 + 5 * j + 4);

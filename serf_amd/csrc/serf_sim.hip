@@ -154,6 +154,7 @@ struct Dev {
   u32* slot_of;     // [N]
   u32* subject_of;  // [A]
   u32* upmap;       // [ceil(N/32)] ground-truth liveness of every node (all shards)
+  uint4* nullcell;  // 2 x uint4 of zeros: where the prefetch of a record without a lookup points
   sim_event* events;
   u32* ev_count;
   u32 ev_cap;
@@ -177,12 +178,11 @@ struct Node {  // one node's state in registers
   u64 clock, eclock, qclock;
   u32 flags, nknown, nfailed, nleft, next_seq, used, overflow;
   u32 inc, susp_next, awareness, ppend;
+  u32 dirty;  // DR* bits: row groups that must be written back
+  u32 cnt0;   // queue entries at load time
   u32 sk[SIM_Q];
 };
-struct Orig {  // what was loaded, to store only what changed
-  uint4 r0, r1, r2, r3;
-  u32 cnt;
-};
+enum { DR0 = 1, DR1 = 2, DR2 = 4, DR3 = 8 };  // R0 {clock, event_clock} R1 {query_clock, flags, n_known} R2 {n_failed, n_left, seq/used, overflow} R3 {inc, susp_next, awareness}
 
 struct Ctx {
   const Dev& d;
@@ -209,34 +209,43 @@ __host__ __device__ static inline u32 wire_meta(u32 kind, u32 flags, u32 len_byt
   return ((63u - len64) << 18) | ((kind & 15u) << 4) | (flags & 15u);
 }
 
+// 16-byte accesses through a native vector type: one global_load/store_dwordx4 each, also when
+// the access sits under a condition (a conditional uint4 load is otherwise split per component)
+typedef u32 v4u __attribute__((ext_vector_type(4)));
+__device__ static inline uint4 ld4(const uint4* p) {
+  v4u v = *reinterpret_cast<const v4u*>(p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // ---- row / queue load-store -------------------------------------------------------------------
-__device__ static inline void node_load(const Dev& d, u32 l, Node& n, Orig& o) {
-  o.r0 = d.R0[l]; o.r1 = d.R1[l]; o.r2 = d.R2[l];
-  o.r3 = d.swim ? d.R3[l] : make_uint4(0, 0, 0, 0);
-  n.clock = (u64)o.r0.x | ((u64)o.r0.y << 32);
-  n.eclock = (u64)o.r0.z | ((u64)o.r0.w << 32);
-  n.qclock = (u64)o.r1.x | ((u64)o.r1.y << 32);
-  n.flags = o.r1.z; n.nknown = o.r1.w;
-  n.nfailed = o.r2.x; n.nleft = o.r2.y; n.next_seq = o.r2.z & 0xFFFFu; n.used = o.r2.z >> 16; n.overflow = o.r2.w;
-  n.inc = o.r3.x; n.susp_next = o.r3.y; n.awareness = o.r3.z; n.ppend = o.r3.w;
-  o.cnt = __popc(n.used);
+__device__ static inline void node_load(const Dev& d, u32 l, Node& n) {
+  uint4 r0 = d.R0[l], r1 = d.R1[l], r2 = d.R2[l];
+  uint4 r3 = make_uint4(0, 0, 0, 0);
+  if (d.swim) r3 = ld4(&d.R3[l]);
+  n.clock = (u64)r0.x | ((u64)r0.y << 32);
+  n.eclock = (u64)r0.z | ((u64)r0.w << 32);
+  n.qclock = (u64)r1.x | ((u64)r1.y << 32);
+  n.flags = r1.z; n.nknown = r1.w;
+  n.nfailed = r2.x; n.nleft = r2.y; n.next_seq = r2.z & 0xFFFFu; n.used = r2.z >> 16; n.overflow = r2.w;
+  n.inc = r3.x; n.susp_next = r3.y; n.awareness = r3.z; n.ppend = r3.w;
+  n.dirty = 0;
+  n.cnt0 = __popc(n.used);
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    uint4 k = (o.cnt > (u32)(4 * g)) ? d.qkeys[(size_t)g * d.Nl + l] : make_uint4(KEMPTY, KEMPTY, KEMPTY, KEMPTY);
+    uint4 k = make_uint4(KEMPTY, KEMPTY, KEMPTY, KEMPTY);
+    if (n.cnt0 > (u32)(4 * g)) k = ld4(&d.qkeys[(size_t)g * d.Nl + l]);
     n.sk[4 * g] = k.x; n.sk[4 * g + 1] = k.y; n.sk[4 * g + 2] = k.z; n.sk[4 * g + 3] = k.w;
   }
 }
 __device__ static inline bool ne4(const uint4& a, const uint4& b) { return a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w; }
-__device__ static inline void node_store(const Dev& d, u32 l, const Node& n, const Orig& o) {
-  uint4 r0 = make_uint4((u32)n.clock, (u32)(n.clock >> 32), (u32)n.eclock, (u32)(n.eclock >> 32));
-  uint4 r1 = make_uint4((u32)n.qclock, (u32)(n.qclock >> 32), n.flags, n.nknown);
-  uint4 r2 = make_uint4(n.nfailed, n.nleft, (n.next_seq & 0xFFFFu) | (n.used << 16), n.overflow);
-  uint4 r3 = make_uint4(n.inc, n.susp_next, n.awareness, n.ppend);
-  if (ne4(r0, o.r0)) d.R0[l] = r0;
-  if (ne4(r1, o.r1)) d.R1[l] = r1;
-  if (ne4(r2, o.r2)) d.R2[l] = r2;
-  if (d.swim && ne4(r3, o.r3)) d.R3[l] = r3;
-  u32 cnt = max(o.cnt, (u32)__popc(n.used));
+// Write back the row groups some handler touched (every mutation site sets its DR* bit) and the
+// key groups that hold, or held, queue entries (a drain changes every live key).
+__device__ static inline void node_store(const Dev& d, u32 l, const Node& n) {
+  if (n.dirty & DR0) d.R0[l] = make_uint4((u32)n.clock, (u32)(n.clock >> 32), (u32)n.eclock, (u32)(n.eclock >> 32));
+  if (n.dirty & DR1) d.R1[l] = make_uint4((u32)n.qclock, (u32)(n.qclock >> 32), n.flags, n.nknown);
+  if (n.dirty & DR2) d.R2[l] = make_uint4(n.nfailed, n.nleft, (n.next_seq & 0xFFFFu) | (n.used << 16), n.overflow);
+  if (n.dirty & DR3) d.R3[l] = make_uint4(n.inc, n.susp_next, n.awareness, n.ppend);
+  u32 cnt = max(n.cnt0, (u32)__popc(n.used));
 #pragma unroll
   for (int g = 0; g < 4; ++g)
     if (cnt > (u32)(4 * g)) d.qkeys[(size_t)g * d.Nl + l] = make_uint4(n.sk[4 * g], n.sk[4 * g + 1], n.sk[4 * g + 2], n.sk[4 * g + 3]);
@@ -248,6 +257,13 @@ __device__ static inline void cas32(u32& a, u32& b) {
   a = lo;
   b = hi;
 }
+__device__ static inline u32 sk_get(const Node& n, u32 i) {  // n.sk[i] for a wave-uniform i, as a select tree
+  u32 a = (i & 1) ? n.sk[1] : n.sk[0], b = (i & 1) ? n.sk[3] : n.sk[2], c = (i & 1) ? n.sk[5] : n.sk[4], d = (i & 1) ? n.sk[7] : n.sk[6];
+  u32 e = (i & 1) ? n.sk[9] : n.sk[8], f = (i & 1) ? n.sk[11] : n.sk[10], g = (i & 1) ? n.sk[13] : n.sk[12], h = (i & 1) ? n.sk[15] : n.sk[14];
+  u32 ab = (i & 2) ? b : a, cd = (i & 2) ? d : c, ef = (i & 2) ? f : e, gh = (i & 2) ? h : g;
+  u32 lo = (i & 4) ? cd : ab, hi = (i & 4) ? gh : ef;
+  return (i & 8) ? hi : lo;
+}
 // queue_broadcast (memberlist TransmitLimitedQueue, App. B.1): fresh id, a class-0 broadcast
 // invalidates the queued class-0 broadcast about the same node, the entry that drains last falls
 // off a full pool (counted as overflow); the record goes to the lowest free payload slot.
@@ -255,16 +271,19 @@ __device__ static void q_insert(const Ctx& c, Node& n, u32 key, u32 wmeta, u64 v
   const Dev& d = c.d;
   u32 kind = (wmeta >> 4) & 15u, cls = kind_class(kind);
   u32 seq = n.next_seq++;
+  n.dirty |= DR2;  // next_seq, used, overflow
   u32 k32 = (cls << 26) | (((wmeta >> 18) & 63u) << 14) | ((1023u - seq) << 4);
   if (cls == 0 && n.used) {
+    // class-0 entries drain first, so they sit at the front of the key array; at most one of
+    // them is about `key` (every insert removes its predecessor).  Rolled loop: one load in
+    // flight at a time instead of sixteen address/value register pairs.
     u32 pos = SIM_Q, slot = 0;
-#pragma unroll
-    for (int i = 0; i < (int)SIM_Q; ++i) {
-      u32 k = n.sk[i];
-      if (k != KEMPTY && (k >> 26) == 0) {
-        u32 sl = k & 15u;
-        if (d.qpay[(size_t)sl * d.Nl + c.l].x == key) { pos = i; slot = sl; }
-      }
+#pragma unroll 1
+    for (u32 i = 0; i < SIM_Q; ++i) {
+      u32 k = sk_get(n, i);
+      if (k == KEMPTY || (k >> 26) != 0) break;
+      u32 sl = k & 15u;
+      if (d.qpay[(size_t)sl * d.Nl + c.l].x == key) { pos = i; slot = sl; break; }
     }
     if (pos < SIM_Q) {
       n.used &= ~(1u << slot);
@@ -304,7 +323,7 @@ __device__ static inline u32 q_round(Node& n, u32 limit) {
     u32 t = ((k >> 20) & 63u) + 1u;
     bool drop = t >= limit;
     slots |= (valid ? (k & 15u) : 0xFFu) << (8 * p);
-    if (valid && drop) n.used &= ~(1u << (k & 15u));
+    if (valid && drop) { n.used &= ~(1u << (k & 15u)); n.dirty |= DR2; }
     a[p] = valid ? (drop ? KEMPTY : k + (1u << 20)) : k;
   }
   cas32(a[0], a[1]); cas32(a[2], a[3]); cas32(a[0], a[2]); cas32(a[1], a[3]); cas32(a[1], a[2]);
@@ -338,6 +357,7 @@ __device__ static void q_renorm(Node& n) {
     cnt++;
   }
   n.next_seq = cnt;
+  n.dirty |= DR2;
 }
 
 // ---- view / ring access -------------------------------------------------------------------------
@@ -383,8 +403,8 @@ __device__ static inline void emit_event(const Ctx& c, const Node& n, u32 type, 
 }
 
 // ---- serf-core handlers --------------------------------------------------------------------------
-__device__ static inline void witness(u64& c, u64 t) {  // types/clock.rs:155-172
-  if (t >= c) c = t + 1;
+__device__ static inline void witness(Node& n, u64& c, u64 t, u32 group) {  // types/clock.rs:155-172
+  if (t >= c) { c = t + 1; n.dirty |= group; }
 }
 // upsert_intent: base.rs:1835-1866
 __device__ static inline bool upsert_intent(uint4& e, u32 ty, u64 ltime, u32 stamp) {
@@ -408,11 +428,12 @@ __device__ static inline void erase_member(const Ctx& c, Node& n, uint4* p, cons
   p[0] = make_uint4(0, 0, 0, 0);
   p[1] = make_uint4(0, 0, 0, 0);
   if (n.nknown) n.nknown--;
+  n.dirty |= DR1 | DR2;
   emit_event(c, n, SIM_EV_REAP, subject, 0);
 }
 // handle_node_join_intent: base.rs:1338-1373.  (p, e) = the subject's view entry, e preloaded.
 __device__ static bool handle_join_intent(const Ctx& c, Node& n, u32 subject, u64 ltime, uint4* p, uint4 e, bool& dirty) {
-  witness(n.clock, ltime);
+  witness(n, n.clock, ltime, DR0);
   if (!p) return false;
   if (e.w & SIM_VB_KNOWN) {
     if (ltime <= E_LTIME(e)) return false;
@@ -428,7 +449,7 @@ __device__ static bool handle_join_intent(const Ctx& c, Node& n, u32 subject, u6
 }
 // broadcast_join: base.rs:381-397
 __device__ static void broadcast_join(const Ctx& c, Node& n, u64 ltime, bool& dirty, Ins& ins) {
-  witness(n.clock, ltime);
+  witness(n, n.clock, ltime, DR0);
   uint4* p = view_ptr(c, c.gid);
   handle_join_intent(c, n, c.gid, ltime, p, p ? p[0] : make_uint4(0, 0, 0, 0), dirty);
   ins_set(ins, c.gid, wire_meta(SIM_K_JOIN, 0, 16), ltime);
@@ -436,7 +457,7 @@ __device__ static void broadcast_join(const Ctx& c, Node& n, u64 ltime, bool& di
 // handle_node_leave_intent: base.rs:1442-1572
 __device__ static bool handle_leave_intent(const Ctx& c, Node& n, u32 subject, u64 ltime, bool prune, uint4* p, uint4 e, bool& dirty, Ins& ins) {
   u32 state = SIM_RF_STATE(n.flags);
-  witness(n.clock, ltime);
+  witness(n, n.clock, ltime, DR0);
   if (!p) return false;
   if (!(e.w & SIM_VB_KNOWN)) {
     bool rb = upsert_intent(e, 2, ltime, c.tick & STAMP_MASK);
@@ -460,6 +481,7 @@ __device__ static bool handle_leave_intent(const Ctx& c, Node& n, u32 subject, u
     e.w = vb_set_status(e.w, SIM_STATUS_LEFT);
     if (n.nfailed) n.nfailed--;
     n.nleft++;
+    n.dirty |= DR2;
     emit_event(c, n, SIM_EV_LEAVE, subject, 0);
   } else {
     e.w = vb_set_status(e.w, SIM_STATUS_LEAVING);
@@ -476,6 +498,7 @@ __device__ static void node_join_e(const Ctx& c, Node& n, uint4& e, u32 subject)
     e.w = vb_set_stamp(vb_set_status(e.w, SIM_STATUS_ALIVE), 0);
     if (old == SIM_STATUS_FAILED && n.nfailed) n.nfailed--;
     if (old == SIM_STATUS_LEFT && n.nleft) n.nleft--;
+    n.dirty |= DR2;
   } else {
     u32 status = SIM_STATUS_ALIVE, it = SIM_VB_INTENT(e.w);
     u64 lt = 0;
@@ -484,6 +507,7 @@ __device__ static void node_join_e(const Ctx& c, Node& n, uint4& e, u32 subject)
     E_SET_LTIME(e, lt);
     e.w = vb_make(1, status, SIM_VB_SWIM(e.w), 0, 0, 0);
     n.nknown++;
+    n.dirty |= DR1;
   }
   emit_event(c, n, SIM_EV_JOIN, subject, 0);
 }
@@ -494,10 +518,12 @@ __device__ static void node_leave_e(const Ctx& c, Node& n, uint4& e, u32 subject
   if (st == SIM_STATUS_LEAVING) {
     e.w = vb_set_stamp(vb_set_status(e.w, SIM_STATUS_LEFT), stamp);
     n.nleft++;
+    n.dirty |= DR2;
     emit_event(c, n, SIM_EV_LEAVE, subject, 0);
   } else if (st == SIM_STATUS_ALIVE) {
     e.w = vb_set_stamp(vb_set_status(e.w, SIM_STATUS_FAILED), stamp);
     n.nfailed++;
+    n.dirty |= DR2;
     emit_event(c, n, SIM_EV_FAILED, subject, 0);
   }
 }
@@ -513,13 +539,13 @@ __device__ static inline bool bucket_add(uint4* p, uint4& b0, u32 key, bool same
   else if (b1.y == 0) b1.y = key;
   else if (b1.z == 0) b1.z = key;
   else if (b1.w == 0) b1.w = key;
-  else { n.overflow++; return false; }  // model bound: bucket full => treated as seen
+  else { n.overflow++; n.dirty |= DR2; return false; }  // model bound: bucket full => treated as seen
   p[1] = b1;
   return true;
 }
 // handle_user_event: base.rs:750-837 (quirk U1 kept).  (p, b0) = ring bucket of ltime, preloaded.
 __device__ static bool handle_user_event(const Ctx& c, Node& n, u32 key, u64 ltime, uint4* p, uint4 b0, bool& dirty) {
-  witness(n.eclock, ltime);
+  witness(n, n.eclock, ltime, DR0);
   if (n.flags & SIM_RF_MINTIME) {
     uint4 mn = c.d.R5[c.l];
     if (ltime < ((u64)mn.x | ((u64)mn.y << 32))) return false;
@@ -538,7 +564,7 @@ __device__ static bool handle_user_event(const Ctx& c, Node& n, u32 key, u64 lti
 }
 // handle_query, de-dup part: base.rs:972-1073 (quirks Q1, Q2 kept)
 __device__ static bool handle_query(const Ctx& c, Node& n, u32 id, u64 ltime, u32 flags, uint4* p, uint4 b0, bool& dirty) {
-  witness(n.qclock, ltime);
+  witness(n, n.qclock, ltime, DR1);
   if (n.flags & SIM_RF_MINTIME) {
     uint4 mn = c.d.R5[c.l];
     if (ltime < ((u64)mn.z | ((u64)mn.w << 32))) return false;
@@ -560,6 +586,7 @@ __device__ static bool handle_query(const Ctx& c, Node& n, u32 id, u64 ltime, u3
 __device__ static inline void aw_delta(Node& n, int dlt) {
   int a = (int)n.awareness + dlt;
   n.awareness = a < 0 ? 0u : a > (int)SIM_MAX_AWARENESS ? SIM_MAX_AWARENESS : (u32)a;
+  n.dirty |= DR3;
 }
 __device__ static inline void susp_forget(const Ctx& c, u32 slot) {
   uint4 s = c.d.R4[c.l], t = s;
@@ -575,14 +602,15 @@ __device__ static inline void susp_track(const Ctx& c, Node& n, u32 slot, u32 de
   else if (s.y == 0) s.y = slot + 1;
   else if (s.z == 0) s.z = slot + 1;
   else if (s.w == 0) s.w = slot + 1;
-  else { n.overflow++; return; }  // model bound: the timer is not tracked
+  else { n.overflow++; n.dirty |= DR2; return; }  // model bound: the timer is not tracked
   c.d.R4[c.l] = s;
-  if (!n.susp_next || deadline < n.susp_next) n.susp_next = deadline;
+  if (!n.susp_next || deadline < n.susp_next) { n.susp_next = deadline; n.dirty |= DR3; }
 }
 __device__ static void swim_refute(const Ctx& c, Node& n, u32 accused_inc, Ins& ins) {
   u32 inc = n.inc + 1;
   if (accused_inc >= inc) inc = accused_inc + 1;
   n.inc = inc;
+  n.dirty |= DR3;
   uint4* p = view_ptr(c, c.gid);
   if (p) { uint4 e = p[0]; e.z = inc; p[0] = e; }
   aw_delta(n, +1);
@@ -636,7 +664,7 @@ __device__ static void swim_suspect(const Ctx& c, Node& n, u32 subject, u32 inc,
     p[0] = e;
     dirty = true;
     u32 deadline = c.tick - ((c.tick - SIM_VB_STAMP(e.w)) & STAMP_MASK) + d.T[k + 1];
-    if (n.susp_next && deadline < n.susp_next) n.susp_next = deadline;
+    if (n.susp_next && deadline < n.susp_next) { n.susp_next = deadline; n.dirty |= DR3; }
     ins_set(ins, subject, wmeta, val);
     return;
   }
@@ -701,13 +729,14 @@ __device__ static void swim_timer_j(const Ctx& c, Node& n, u32 j, u32& next, Ins
 }
 // probe (B.3)
 __device__ static inline u64 probe_draw(const TickP& tp, u32 gid, u32 j) { return mix64(tp.probe_base ^ ((u64)gid * 32u + j)); }
+__device__ static inline u32 draw_below(u64 draw, u32 n) { return (u32)(((draw >> 32) * (u64)n) >> 32); }
 __device__ static inline bool leg_lost(const TickP& tp, u32 gid, u32 j) {
   return tp.loss_u32 && (u32)(probe_draw(tp, gid, j) >> 32) < tp.loss_u32;
 }
 __device__ static inline bool up_of(const Dev& d, u32 gid) { return (d.upmap[gid >> 5] >> (gid & 31)) & 1u; }
 __device__ static void swim_probe(const Ctx& c, Node& n, const TickP& tp, const uint4* base, Ins& ins) {
   const Dev& d = c.d;
-  u32 t = (u32)(probe_draw(tp, c.gid, PD_TARGET) % (u64)(d.N - 1));
+  u32 t = draw_below(probe_draw(tp, c.gid, PD_TARGET), d.N - 1);
   if (t >= c.gid) ++t;
   uint4* p = view_ptr(c, t);
   uint4 e = p ? p[0] : base[(size_t)t * 2];
@@ -718,7 +747,7 @@ __device__ static void swim_probe(const Ctx& c, Node& n, const TickP& tp, const 
   if (up_of(d, t)) {
     ok = !leg_lost(tp, c.gid, PD_PING) && !leg_lost(tp, c.gid, PD_ACK);
     for (u32 j = 0; !ok && j < d.ic && j < 4; ++j) {
-      u32 r = (u32)(probe_draw(tp, c.gid, PD_RELAY0 + 5 * j) % (u64)d.N);
+      u32 r = draw_below(probe_draw(tp, c.gid, PD_RELAY0 + 5 * j), d.N);
       if (r == c.gid || r == t || !up_of(d, r)) continue;
       ok = !leg_lost(tp, c.gid, PD_RELAY0 + 5 * j + 1) && !leg_lost(tp, c.gid, PD_RELAY0 + 5 * j + 2) &&
            !leg_lost(tp, c.gid, PD_RELAY0 + 5 * j + 3) && !leg_lost(tp, c.gid, PD_RELAY0 + 5 * j + 4);
@@ -726,7 +755,7 @@ __device__ static void swim_probe(const Ctx& c, Node& n, const TickP& tp, const 
   }
   if (ok) { aw_delta(n, -1); return; }
   aw_delta(n, +1);
-  if (!p) { n.overflow++; return; }  // model bound: no view slot to hold the suspicion
+  if (!p) { n.overflow++; n.dirty |= DR2; return; }  // model bound: no view slot to hold the suspicion
   bool dirty = false;
   swim_suspect(c, n, t, e.z, c.gid, wire_meta(SIM_K_SUSPECT, 0, 32), p, e, dirty, ins);
 }
@@ -774,8 +803,7 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
   Ctx c{d, l, gid, (u32)tp.tick};
   const uint4 zero = make_uint4(0, 0, 0, 0);
   Node n;
-  Orig o;
-  node_load(d, l, n, o);
+  node_load(d, l, n);
   bool up = n.flags & SIM_RF_UP;
   if (up) {
     if (n.next_seq > 1023u - 64u) q_renorm(n);
@@ -803,7 +831,7 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
         uint4* p1 = lookup_ptr(c, k1, r1.x, (u64)r1.z | ((u64)r1.w << 32), s1);
         uint4* p2 = lookup_ptr(c, k2, r2.x, (u64)r2.z | ((u64)r2.w << 32), s2);
         uint4* p3 = lookup_ptr(c, k3, r3.x, (u64)r3.z | ((u64)r3.w << 32), s3);
-        uint4 e0 = p0 ? p0[0] : zero, e1 = p1 ? p1[0] : zero, e2 = p2 ? p2[0] : zero, e3 = p3 ? p3[0] : zero;
+        uint4 e0 = ld4(p0 ? p0 : d.nullcell), e1 = ld4(p1 ? p1 : d.nullcell), e2 = ld4(p2 ? p2 : d.nullcell), e3 = ld4(p3 ? p3 : d.nullcell);
         // phase B: the handlers, in arrival order (one rolled loop = one copy of the handler code);
         // an entry is re-read if an earlier record of this packet changed anything (rare: most
         // records are duplicates)
@@ -814,7 +842,7 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
           if (SIM_META_KIND(r.y) == SIM_K_EMPTY) continue;
           uint4* ptr = SEL4(p, p0, p1, p2, p3);
           uint4 e = sel4(p, e0, e1, e2, e3);
-          if (dirty && ptr) e = ptr[0];
+          if (dirty && ptr) e = ld4(ptr);
           Ins ins;
           ins.has = 0;
           dispatch(c, n, r, ptr, e, dirty, ins);
@@ -825,7 +853,8 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
     if (d.swim) {
       // suspicion timers (4 slots), then the probe: five producers, one queue_broadcast site
       bool due = n.susp_next && (u32)tp.tick >= n.susp_next;
-      bool probing = d.N >= 2 && ((u32)tp.tick + gid) % d.PI == 0;
+      // probe phase is shared by the 64 nodes of an id-aligned group: wave-uniform when shard0 % 64 == 0
+      bool probing = d.N >= 2 && ((u32)tp.tick + (gid >> 6)) % d.PI == 0;
       if (__any(due || probing)) {
         u32 next = 0;
 #pragma unroll 1
@@ -834,7 +863,7 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
           ins.has = 0;
           if (j < SIM_S) { if (due) swim_timer_j(c, n, j, next, ins); }
           else {
-            if (due) n.susp_next = next;
+            if (due) { n.susp_next = next; n.dirty |= DR3; }
             if (probing) swim_probe(c, n, tp, base, ins);
           }
           if (ins.has) q_insert(c, n, ins.key, ins.wmeta, ins.val);
@@ -853,7 +882,7 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
 #pragma unroll
         for (int p = 0; p < (int)SIM_P; ++p) {
           u32 s = (slots >> (8 * p)) & 0xFFu;
-          if (s != 0xFFu) pk[p] = d.qpay[(size_t)s * d.Nl + l];
+          if (s != 0xFFu) pk[p] = ld4(&d.qpay[(size_t)s * d.Nl + l]);
         }
       }
     }
@@ -867,7 +896,7 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
     else dst = d.inbox[cur ^ 1] + ((size_t)k * d.Nl + (size_t)h * tp.M + t) * 4;
     dst[0] = pk[0]; dst[1] = pk[1]; dst[2] = pk[2]; dst[3] = pk[3];
   }
-  if (up) node_store(d, l, n, o);
+  if (up) node_store(d, l, n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -892,9 +921,9 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive) {
     u32 l = gid - d.shard0;
     Ctx c{d, l, gid, (u32)tick};
     Node n;
-    Orig o;
-    node_load(d, l, n, o);
+    node_load(d, l, n);
     if (n.next_seq > 1023u - 64u) q_renorm(n);
+    n.dirty = DR0 | DR1 | DR2 | DR3;  // ops are rare: write the whole row back
     bool up = n.flags & SIM_RF_UP, dirty = false;
     u32 a = ob.a[i], b = ob.b[i];
     Ins ins, ins2;  // ins: what the handler queues; ins2: the op's own broadcast, queued after it
@@ -973,7 +1002,7 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive) {
     }
     if (ins.has) q_insert(c, n, ins.key, ins.wmeta, ins.val);
     if (ins2.has) q_insert(c, n, ins2.key, ins2.wmeta, ins2.val);
-    node_store(d, l, n, o);
+    node_store(d, l, n);
     __threadfence();  // the next op of this batch may touch the same node
   }
 }
@@ -1295,7 +1324,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   DA(d.view, (size_t)d.A * Nl * 2)
   DA(d.ering, (size_t)d.Bev * Nl * 2)
   DA(d.qring, (size_t)d.Bq * Nl * 2)
-  DA(d.slot_of, d.N) DA(d.subject_of, d.A) DA(d.upmap, nup)
+  DA(d.slot_of, d.N) DA(d.subject_of, d.A) DA(d.upmap, nup) DA(d.nullcell, 2)
   DA(d.events, (size_t)EV_CAP) DA(d.ev_count, 1)
   DA(h->d_base, (size_t)d.N * 2)
   DA(h->d_scratch, 16)
@@ -1309,6 +1338,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   HCHECK(zero(d.R2, Nl * 16)); HCHECK(zero(d.R3, Nl * 16)); HCHECK(zero(d.R4, Nl * 16)); HCHECK(zero(d.R5, Nl * 16));
   HCHECK(zero(d.qpay, (size_t)SIM_Q * Nl * 16));
   HCHECK(zero(d.ev_count, 4));
+  HCHECK(zero(d.nullcell, 32));
   if (!d.sharded) { HCHECK(zero(d.inbox[0], (size_t)d.f * Nl * 64)); HCHECK(zero(d.inbox[1], (size_t)d.f * Nl * 64)); }
   HCHECK(zero(d.view, (size_t)d.A * Nl * 32));
   HCHECK(zero(d.ering, (size_t)d.Bev * Nl * 32));
