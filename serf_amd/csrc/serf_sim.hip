@@ -41,6 +41,7 @@ typedef uint64_t u64;
 #define STAMP_MASK 0x1FFFFFu
 #define BLOCK 256
 #define KEMPTY 0xFFFFFFFFu  // empty sort key
+#define SIM_PEND 24u  // >= SIM_MAX_FANOUT * SIM_P records + SIM_S timers + 1 probe per node and tick
 
 // ------------------------------------------------------------------------------------------------
 // hashing / permutation (same arithmetic as the spec; host and device)
@@ -146,6 +147,7 @@ struct Dev {
   uint4* R5;  // {event_min.lo, event_min.hi, query_min.lo, query_min.hi} (read when SIM_RF_MINTIME)
   uint4* qkeys;  // [4][Nl]  the 16 sort keys of a node's queue, ascending, 4 per uint4
   uint4* qpay;   // [Q][Nl]  slot-stable wire records {key, wire meta, val.lo, val.hi}
+  uint4* pend;   // [SIM_PEND][Nl] broadcasts requested by the handlers of the running tick, arrival order
   uint4* inbox[2];       // [f][Nl] packets of 4 x uint4 (local mode)
   uint4 *xsend, *xrecv;  // sharded mode: [V][f][blk] packets
   uint4* view;   // [A][Nl] entries of 2 x uint4 {ltime.lo, ltime.hi, inc, bits}{conf[4]}
@@ -179,9 +181,9 @@ struct Node {  // one node's state in registers
   u32 flags, nknown, nfailed, nleft, next_seq, used, overflow;
   u32 inc, susp_next, awareness, ppend;
   u32 dirty;  // DR* bits: row groups that must be written back
-  u32 cnt0;   // queue entries at load time
-  u32 sk[SIM_Q];
+  u32 npend;  // broadcasts parked in d.pend[] by this tick's handlers, queued once they are all done
 };
+typedef u32 (&SK)[SIM_Q];  // the 16 sort keys of a node's queue, ascending (phase 2 of the tick only)
 enum { DR0 = 1, DR1 = 2, DR2 = 4, DR3 = 8 };  // R0 {clock, event_clock} R1 {query_clock, flags, n_known} R2 {n_failed, n_left, seq/used, overflow} R3 {inc, susp_next, awareness}
 
 struct Ctx {
@@ -229,26 +231,30 @@ __device__ static inline void node_load(const Dev& d, u32 l, Node& n) {
   n.nfailed = r2.x; n.nleft = r2.y; n.next_seq = r2.z & 0xFFFFu; n.used = r2.z >> 16; n.overflow = r2.w;
   n.inc = r3.x; n.susp_next = r3.y; n.awareness = r3.z; n.ppend = r3.w;
   n.dirty = 0;
-  n.cnt0 = __popc(n.used);
+  n.npend = 0;
+}
+__device__ static inline void keys_load(const Dev& d, u32 l, u32 cnt0, SK sk) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     uint4 k = make_uint4(KEMPTY, KEMPTY, KEMPTY, KEMPTY);
-    if (n.cnt0 > (u32)(4 * g)) k = ld4(&d.qkeys[(size_t)g * d.Nl + l]);
-    n.sk[4 * g] = k.x; n.sk[4 * g + 1] = k.y; n.sk[4 * g + 2] = k.z; n.sk[4 * g + 3] = k.w;
+    if (cnt0 > (u32)(4 * g)) k = ld4(&d.qkeys[(size_t)g * d.Nl + l]);
+    sk[4 * g] = k.x; sk[4 * g + 1] = k.y; sk[4 * g + 2] = k.z; sk[4 * g + 3] = k.w;
   }
 }
+// the key groups that hold, or held, queue entries (a drain changes every live key)
+__device__ static inline void keys_store(const Dev& d, u32 l, u32 cnt0, u32 used, const u32 (&sk)[SIM_Q]) {
+  u32 cnt = max(cnt0, (u32)__popc(used));
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    if (cnt > (u32)(4 * g)) d.qkeys[(size_t)g * d.Nl + l] = make_uint4(sk[4 * g], sk[4 * g + 1], sk[4 * g + 2], sk[4 * g + 3]);
+}
 __device__ static inline bool ne4(const uint4& a, const uint4& b) { return a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w; }
-// Write back the row groups some handler touched (every mutation site sets its DR* bit) and the
-// key groups that hold, or held, queue entries (a drain changes every live key).
+// Write back the row groups some handler touched (every mutation site sets its DR* bit).
 __device__ static inline void node_store(const Dev& d, u32 l, const Node& n) {
   if (n.dirty & DR0) d.R0[l] = make_uint4((u32)n.clock, (u32)(n.clock >> 32), (u32)n.eclock, (u32)(n.eclock >> 32));
   if (n.dirty & DR1) d.R1[l] = make_uint4((u32)n.qclock, (u32)(n.qclock >> 32), n.flags, n.nknown);
   if (n.dirty & DR2) d.R2[l] = make_uint4(n.nfailed, n.nleft, (n.next_seq & 0xFFFFu) | (n.used << 16), n.overflow);
   if (n.dirty & DR3) d.R3[l] = make_uint4(n.inc, n.susp_next, n.awareness, n.ppend);
-  u32 cnt = max(n.cnt0, (u32)__popc(n.used));
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-    if (cnt > (u32)(4 * g)) d.qkeys[(size_t)g * d.Nl + l] = make_uint4(n.sk[4 * g], n.sk[4 * g + 1], n.sk[4 * g + 2], n.sk[4 * g + 3]);
 }
 
 // ---- TransmitLimitedQueue on sort keys ----------------------------------------------------------
@@ -257,9 +263,9 @@ __device__ static inline void cas32(u32& a, u32& b) {
   a = lo;
   b = hi;
 }
-__device__ static inline u32 sk_get(const Node& n, u32 i) {  // n.sk[i] for a wave-uniform i, as a select tree
-  u32 a = (i & 1) ? n.sk[1] : n.sk[0], b = (i & 1) ? n.sk[3] : n.sk[2], c = (i & 1) ? n.sk[5] : n.sk[4], d = (i & 1) ? n.sk[7] : n.sk[6];
-  u32 e = (i & 1) ? n.sk[9] : n.sk[8], f = (i & 1) ? n.sk[11] : n.sk[10], g = (i & 1) ? n.sk[13] : n.sk[12], h = (i & 1) ? n.sk[15] : n.sk[14];
+__device__ static inline u32 sk_get(const u32 (&sk)[SIM_Q], u32 i) {  // sk[i] for a wave-uniform i, as a select tree
+  u32 a = (i & 1) ? sk[1] : sk[0], b = (i & 1) ? sk[3] : sk[2], c = (i & 1) ? sk[5] : sk[4], d = (i & 1) ? sk[7] : sk[6];
+  u32 e = (i & 1) ? sk[9] : sk[8], f = (i & 1) ? sk[11] : sk[10], g = (i & 1) ? sk[13] : sk[12], h = (i & 1) ? sk[15] : sk[14];
   u32 ab = (i & 2) ? b : a, cd = (i & 2) ? d : c, ef = (i & 2) ? f : e, gh = (i & 2) ? h : g;
   u32 lo = (i & 4) ? cd : ab, hi = (i & 4) ? gh : ef;
   return (i & 8) ? hi : lo;
@@ -267,7 +273,7 @@ __device__ static inline u32 sk_get(const Node& n, u32 i) {  // n.sk[i] for a wa
 // queue_broadcast (memberlist TransmitLimitedQueue, App. B.1): fresh id, a class-0 broadcast
 // invalidates the queued class-0 broadcast about the same node, the entry that drains last falls
 // off a full pool (counted as overflow); the record goes to the lowest free payload slot.
-__device__ static void q_insert(const Ctx& c, Node& n, u32 key, u32 wmeta, u64 val) {
+__device__ static void q_insert(const Ctx& c, Node& n, SK sk, u32 key, u32 wmeta, u64 val) {
   const Dev& d = c.d;
   u32 kind = (wmeta >> 4) & 15u, cls = kind_class(kind);
   u32 seq = n.next_seq++;
@@ -280,7 +286,7 @@ __device__ static void q_insert(const Ctx& c, Node& n, u32 key, u32 wmeta, u64 v
     u32 pos = SIM_Q, slot = 0;
 #pragma unroll 1
     for (u32 i = 0; i < SIM_Q; ++i) {
-      u32 k = sk_get(n, i);
+      u32 k = sk_get(sk, i);
       if (k == KEMPTY || (k >> 26) != 0) break;
       u32 sl = k & 15u;
       if (d.qpay[(size_t)sl * d.Nl + c.l].x == key) { pos = i; slot = sl; break; }
@@ -288,15 +294,15 @@ __device__ static void q_insert(const Ctx& c, Node& n, u32 key, u32 wmeta, u64 v
     if (pos < SIM_Q) {
       n.used &= ~(1u << slot);
 #pragma unroll
-      for (int i = 0; i < (int)SIM_Q - 1; ++i) n.sk[i] = ((u32)i >= pos) ? n.sk[i + 1] : n.sk[i];
-      n.sk[SIM_Q - 1] = KEMPTY;
+      for (int i = 0; i < (int)SIM_Q - 1; ++i) sk[i] = ((u32)i >= pos) ? sk[i + 1] : sk[i];
+      sk[SIM_Q - 1] = KEMPTY;
     }
   }
-  if (n.sk[SIM_Q - 1] != KEMPTY) {  // pool full
+  if (sk[SIM_Q - 1] != KEMPTY) {  // pool full
     n.overflow++;
-    if (k32 > n.sk[SIM_Q - 1]) return;  // the newcomer drains last: it is the one dropped
-    n.used &= ~(1u << (n.sk[SIM_Q - 1] & 15u));
-    n.sk[SIM_Q - 1] = KEMPTY;
+    if (k32 > sk[SIM_Q - 1]) return;  // the newcomer drains last: it is the one dropped
+    n.used &= ~(1u << (sk[SIM_Q - 1] & 15u));
+    sk[SIM_Q - 1] = KEMPTY;
   }
   u32 slot = (u32)__ffs((int)(~n.used & 0xFFFFu)) - 1u;
   n.used |= 1u << slot;
@@ -304,21 +310,21 @@ __device__ static void q_insert(const Ctx& c, Node& n, u32 key, u32 wmeta, u64 v
   d.qpay[(size_t)slot * d.Nl + c.l] = make_uint4(key, wmeta & SIM_META_WIRE_MASK, (u32)val, (u32)(val >> 32));
 #pragma unroll
   for (int i = SIM_Q - 1; i >= 1; --i) {
-    bool below = n.sk[i - 1] > k32;  // predecessor sorts after the newcomer => shift it right
-    bool here = !below && n.sk[i] > k32;
-    n.sk[i] = below ? n.sk[i - 1] : (here ? k32 : n.sk[i]);
+    bool below = sk[i - 1] > k32;  // predecessor sorts after the newcomer => shift it right
+    bool here = !below && sk[i] > k32;
+    sk[i] = below ? sk[i - 1] : (here ? k32 : sk[i]);
   }
-  if (n.sk[0] > k32) n.sk[0] = k32;
+  if (sk[0] > k32) sk[0] = k32;
 }
 
 // get_broadcasts for one packet: the first SIM_P entries in drain order, transmits+1, drop at the
 // retransmit limit, then restore the sorted order (4-sort + bitonic merge on 32-bit keys).
 // Returns the payload slots of the emitted entries, 0xFF where there is none.
-__device__ static inline u32 q_round(Node& n, u32 limit) {
+__device__ static inline u32 q_round(Node& n, SK sk, u32 limit) {
   u32 a[SIM_P], slots = 0;
 #pragma unroll
   for (int p = 0; p < (int)SIM_P; ++p) {
-    u32 k = n.sk[p];
+    u32 k = sk[p];
     bool valid = k != KEMPTY;
     u32 t = ((k >> 20) & 63u) + 1u;
     bool drop = t >= limit;
@@ -329,7 +335,7 @@ __device__ static inline u32 q_round(Node& n, u32 limit) {
   cas32(a[0], a[1]); cas32(a[2], a[3]); cas32(a[0], a[2]); cas32(a[1], a[3]); cas32(a[1], a[2]);
   u32 s[SIM_Q];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) s[i] = n.sk[i + 4];
+  for (int i = 0; i < 12; ++i) s[i] = sk[i + 4];
   s[12] = a[3]; s[13] = a[2]; s[14] = a[1]; s[15] = a[0];
 #pragma unroll
   for (int dd = 8; dd >= 1; dd >>= 1) {
@@ -338,26 +344,33 @@ __device__ static inline u32 q_round(Node& n, u32 limit) {
       if ((i & dd) == 0) cas32(s[i], s[i + dd]);
   }
 #pragma unroll
-  for (int i = 0; i < (int)SIM_Q; ++i) n.sk[i] = s[i];
+  for (int i = 0; i < (int)SIM_Q; ++i) sk[i] = s[i];
   return slots;
 }
 
 // rare: renumber the queue ids when the 10-bit id space is nearly used up (order-preserving)
-__device__ static void q_renorm(Node& n) {
+__device__ static void q_renorm(Node& n, SK sk) {
   u32 o[SIM_Q], cnt = 0;
 #pragma unroll
-  for (int i = 0; i < (int)SIM_Q; ++i) o[i] = n.sk[i];
+  for (int i = 0; i < (int)SIM_Q; ++i) o[i] = sk[i];
 #pragma unroll
   for (int i = 0; i < (int)SIM_Q; ++i) {
     if (o[i] == KEMPTY) continue;
     u32 fi = (o[i] >> 4) & 0x3FFu, rank = 0;  // field = 1023 - seq: larger field = older
 #pragma unroll
     for (int j = 0; j < (int)SIM_Q; ++j) rank += (o[j] != KEMPTY && ((o[j] >> 4) & 0x3FFu) > fi) ? 1u : 0u;
-    n.sk[i] = (o[i] & ~(0x3FFu << 4)) | ((1023u - rank) << 4);
+    sk[i] = (o[i] & ~(0x3FFu << 4)) | ((1023u - rank) << 4);
     cnt++;
   }
   n.next_seq = cnt;
   n.dirty |= DR2;
+}
+
+// Park a broadcast request; phase 2 of the tick queues them in this order (queue_broadcast order
+// is arrival order, and no handler looks at the queue, so deferring is exact).
+__device__ static inline void pend_push(const Ctx& c, Node& n, const Ins& q) {
+  c.d.pend[(size_t)n.npend * c.d.Nl + c.l] = make_uint4(q.key, q.wmeta, (u32)q.val, (u32)(q.val >> 32));
+  n.npend++;
 }
 
 // ---- view / ring access -------------------------------------------------------------------------
@@ -771,6 +784,50 @@ __device__ static inline uint4* lookup_ptr(const Ctx& c, u32 kind, u32 key, u64 
   if (kind == SIM_K_EMPTY || slot == NOSLOT) return nullptr;
   return view_slot_ptr(c, slot);
 }
+// Fast classification of one record against the prefetched head `e` of the state it is checked
+// against (null-ness of the lookup in `has`).  Returns true when the handler would change nothing
+// but the Lamport clock it witnesses — a duplicate, an old message, a subject without a view slot —
+// which is the fate of ~95 % of all records; the caller then applies the witness and is done.
+// Anything else (a new rumour, a refutation, a confirmation...) is left to the full handlers.
+// The conditions are the early `return false` exits of the handlers, in the handlers' order.
+__device__ static inline bool fast_noop(const Ctx& c, const Node& n, u32 kind, const uint4& r, bool has, const uint4& e) {
+  u64 lt = (u64)r.z | ((u64)r.w << 32);
+  if (kind == SIM_K_EVENT) {  // handle_user_event: base.rs:750-837
+    if (n.flags & SIM_RF_MINTIME) return false;
+    u64 B = c.d.Bev, cur = lt >= n.eclock ? lt + 1 : n.eclock;
+    if (cur > B && lt < cur - B) return true;
+    return e.z != 0 && (e.z == r.x || e.w == r.x);
+  }
+  if (kind == SIM_K_QUERY) {  // handle_query: base.rs:972-1073
+    if (n.flags & SIM_RF_MINTIME) return false;
+    u64 qt = c.d.Bq, cur = lt >= n.qclock ? lt + 1 : n.qclock;
+    if (cur > qt && qt < cur - qt) return true;
+    return e.z != 0 && E_LTIME(e) == lt && (e.z == r.x || e.w == r.x);
+  }
+  if (kind == SIM_K_JOIN || kind == SIM_K_LEAVE) {  // base.rs:1338-1373, 1442-1572
+    if (!has) return true;
+    if (e.w & SIM_VB_KNOWN) return lt <= E_LTIME(e);
+    return SIM_VB_INTENT(e.w) != 0 && !(lt > E_LTIME(e));
+  }
+  if (kind == SIM_K_EMPTY || kind > SIM_K_DEAD || !c.d.swim || !has) return true;
+  if (kind == SIM_K_ALIVE) {
+    if (r.x == c.gid) return r.z <= n.inc;
+    return (e.w & SIM_VB_KNOWN) && r.z <= e.z;
+  }
+  if (!(e.w & SIM_VB_KNOWN) || r.z < e.z) return true;
+  u32 sw = SIM_VB_SWIM(e.w);
+  if (kind == SIM_K_SUSPECT) {
+    if (sw == SIM_SWIM_SUSPECT) return SIM_VB_NCONF(e.w) >= c.d.kconf;
+    return sw != SIM_SWIM_ALIVE;
+  }
+  return sw == SIM_SWIM_DEAD || sw == SIM_SWIM_LEFT;  // SIM_K_DEAD
+}
+__device__ static inline void fast_witness(Node& n, u32 kind, const uint4& r) {
+  u64 lt = (u64)r.z | ((u64)r.w << 32);
+  if (kind == SIM_K_EVENT) witness(n, n.eclock, lt, DR0);
+  else if (kind == SIM_K_QUERY) witness(n, n.qclock, lt, DR1);
+  else if (kind == SIM_K_JOIN || kind == SIM_K_LEAVE) witness(n, n.clock, lt, DR0);
+}
 __device__ static inline void dispatch(const Ctx& c, Node& n, const uint4& r, uint4* p, const uint4& e, bool& dirty, Ins& ins) {
   u32 kind = SIM_META_KIND(r.y), flags = SIM_META_FLAGS(r.y);
   u64 val = (u64)r.z | ((u64)r.w << 32);
@@ -805,8 +862,8 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
   Node n;
   node_load(d, l, n);
   bool up = n.flags & SIM_RF_UP;
+  // ---- phase 1: deliver.  The queue is not touched: handlers park their broadcasts in d.pend.
   if (up) {
-    if (n.next_seq > 1023u - 64u) q_renorm(n);
     if (!tp.first) {
       for (u32 k = 0; k < d.f; ++k) {
         const uint4* cell;
@@ -832,21 +889,30 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
         uint4* p2 = lookup_ptr(c, k2, r2.x, (u64)r2.z | ((u64)r2.w << 32), s2);
         uint4* p3 = lookup_ptr(c, k3, r3.x, (u64)r3.z | ((u64)r3.w << 32), s3);
         uint4 e0 = ld4(p0 ? p0 : d.nullcell), e1 = ld4(p1 ? p1 : d.nullcell), e2 = ld4(p2 ? p2 : d.nullcell), e3 = ld4(p3 ? p3 : d.nullcell);
-        // phase B: the handlers, in arrival order (one rolled loop = one copy of the handler code);
-        // an entry is re-read if an earlier record of this packet changed anything (rare: most
-        // records are duplicates)
-        bool dirty = false;
+        // phase B: duplicates and other no-ops are retired against the prefetched heads; `slow` is
+        // the first record of the packet that needs a real handler (4 = none)
+        u32 slow = SIM_P;
+        if (fast_noop(c, n, k0, r0, p0 != nullptr, e0)) fast_witness(n, k0, r0); else slow = 0;
+        if (slow == SIM_P) { if (fast_noop(c, n, k1, r1, p1 != nullptr, e1)) fast_witness(n, k1, r1); else slow = 1; }
+        if (slow == SIM_P) { if (fast_noop(c, n, k2, r2, p2 != nullptr, e2)) fast_witness(n, k2, r2); else slow = 2; }
+        if (slow == SIM_P) { if (fast_noop(c, n, k3, r3, p3 != nullptr, e3)) fast_witness(n, k3, r3); else slow = 3; }
+        // phase C: from that record on, the full handlers in arrival order (one rolled loop = one
+        // copy of the handler code).  Nothing prefetched is kept: the record is re-read from the
+        // inbox cell, slot map and entry from the caches phase A just filled.
+        if (!__any(slow < SIM_P)) continue;
 #pragma unroll 1
-        for (u32 p = 0; p < SIM_P; ++p) {
-          uint4 r = sel4(p, r0, r1, r2, r3);
-          if (SIM_META_KIND(r.y) == SIM_K_EMPTY) continue;
-          uint4* ptr = SEL4(p, p0, p1, p2, p3);
-          uint4 e = sel4(p, e0, e1, e2, e3);
-          if (dirty && ptr) e = ld4(ptr);
+        for (u32 p = slow; p < SIM_P; ++p) {
+          uint4 r = ld4(cell + p);
+          u32 kind = SIM_META_KIND(r.y);
+          if (kind == SIM_K_EMPTY) continue;
+          u32 sl = (member_kind(kind) && r.x < d.N) ? d.slot_of[r.x] : NOSLOT;
+          uint4* ptr = lookup_ptr(c, kind, r.x, (u64)r.z | ((u64)r.w << 32), sl);
+          uint4 e = ld4(ptr ? ptr : d.nullcell);
+          bool dirty = false;
           Ins ins;
           ins.has = 0;
           dispatch(c, n, r, ptr, e, dirty, ins);
-          if (ins.has) q_insert(c, n, ins.key, ins.wmeta, ins.val);
+          if (ins.has) pend_push(c, n, ins);
         }
       }
     }
@@ -866,9 +932,21 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
             if (due) { n.susp_next = next; n.dirty |= DR3; }
             if (probing) swim_probe(c, n, tp, base, ins);
           }
-          if (ins.has) q_insert(c, n, ins.key, ins.wmeta, ins.val);
+          if (ins.has) pend_push(c, n, ins);
         }
       }
+    }
+  }
+  // ---- phase 2: queue.  Load the sort keys, queue what phase 1 parked, drain `fanout` packets.
+  u32 sk[SIM_Q];
+  u32 cnt0 = __popc(n.used);
+  if (up) {
+    keys_load(d, l, cnt0, sk);
+    if (n.next_seq > 1023u - 64u) q_renorm(n, sk);
+#pragma unroll 1
+    for (u32 i = 0; i < n.npend; ++i) {
+      uint4 q = ld4(&d.pend[(size_t)i * d.Nl + l]);
+      q_insert(c, n, sk, q.x, q.y, (u64)q.z | ((u64)q.w << 32));
     }
   }
   u32 limit = up ? d.retransmit_mult * digits10(n.nknown) : 0;
@@ -876,7 +954,7 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
   for (u32 k = 0; k < tp.feff; ++k) {
     uint4 pk[SIM_P] = {zero, zero, zero, zero};
     if (up) {
-      u32 slots = q_round(n, limit);
+      u32 slots = q_round(n, sk, limit);
       bool lost = tp.loss_u32 && (u32)(mix64(tp.loss_base ^ ((u64)gid * 4u + k)) >> 32) < tp.loss_u32;
       if (!lost) {
 #pragma unroll
@@ -896,7 +974,10 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
     else dst = d.inbox[cur ^ 1] + ((size_t)k * d.Nl + (size_t)h * tp.M + t) * 4;
     dst[0] = pk[0]; dst[1] = pk[1]; dst[2] = pk[2]; dst[3] = pk[3];
   }
-  if (up) node_store(d, l, n);
+  if (up) {
+    node_store(d, l, n);
+    keys_store(d, l, cnt0, n.used, sk);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -922,7 +1003,10 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive) {
     Ctx c{d, l, gid, (u32)tick};
     Node n;
     node_load(d, l, n);
-    if (n.next_seq > 1023u - 64u) q_renorm(n);
+    u32 sk[SIM_Q];
+    u32 cnt0 = __popc(n.used);
+    keys_load(d, l, cnt0, sk);
+    if (n.next_seq > 1023u - 64u) q_renorm(n, sk);
     n.dirty = DR0 | DR1 | DR2 | DR3;  // ops are rare: write the whole row back
     bool up = n.flags & SIM_RF_UP, dirty = false;
     u32 a = ob.a[i], b = ob.b[i];
@@ -1000,9 +1084,10 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive) {
       case SIM_OP_REVIVE: n.flags |= SIM_RF_UP; break;
       default: break;
     }
-    if (ins.has) q_insert(c, n, ins.key, ins.wmeta, ins.val);
-    if (ins2.has) q_insert(c, n, ins2.key, ins2.wmeta, ins2.val);
+    if (ins.has) q_insert(c, n, sk, ins.key, ins.wmeta, ins.val);
+    if (ins2.has) q_insert(c, n, sk, ins2.key, ins2.wmeta, ins2.val);
     node_store(d, l, n);
+    keys_store(d, l, cnt0, n.used, sk);
     __threadfence();  // the next op of this batch may touch the same node
   }
 }
@@ -1319,7 +1404,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
     return rc;                                       \
   }
   DA(d.R0, Nl) DA(d.R1, Nl) DA(d.R2, Nl) DA(d.R3, Nl) DA(d.R4, Nl) DA(d.R5, Nl)
-  DA(d.qkeys, 4 * Nl) DA(d.qpay, (size_t)SIM_Q * Nl)
+  DA(d.qkeys, 4 * Nl) DA(d.qpay, (size_t)SIM_Q * Nl) DA(d.pend, (size_t)SIM_PEND * Nl)
   if (!d.sharded) { DA(d.inbox[0], (size_t)d.f * Nl * 4) DA(d.inbox[1], (size_t)d.f * Nl * 4) }
   DA(d.view, (size_t)d.A * Nl * 2)
   DA(d.ering, (size_t)d.Bev * Nl * 2)
