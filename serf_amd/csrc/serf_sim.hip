@@ -851,8 +851,25 @@ __device__ static inline uint4 sel4(u32 i, const uint4& a, const uint4& b, const
 // ------------------------------------------------------------------------------------------------
 // the tick kernel
 // ------------------------------------------------------------------------------------------------
+#ifdef TICK_TIMING
+__device__ unsigned long long g_tt[16];
+// wave-uniform accumulation in scalar registers; one set of atomics per wave at the very end
+#define TT(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define TT(i)
+#endif
 template <bool SHARDED>
 __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, const uint4* base) {
+#ifdef TICK_TIMING
+  unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
+  // LDS staging of the per-node inbox: the packet being delivered, the slot of each record's
+  // subject and the head of the entry it is checked against (36 KiB per block: 4 blocks per CU)
+  __shared__ uint4 lds_r[SIM_P][BLOCK];
+  __shared__ uint4 lds_e[SIM_P][BLOCK];
+  __shared__ u32 lds_s[SIM_P][BLOCK];
+  const u32 tid = threadIdx.x;
   u32 l = blockIdx.x * BLOCK + threadIdx.x;
   if (l >= d.Nl) return;
   u32 gid = d.shard0 + l;
@@ -862,6 +879,7 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
   Node n;
   node_load(d, l, n);
   bool up = n.flags & SIM_RF_UP;
+  TT(0);
   // ---- phase 1: deliver.  The queue is not touched: handlers park their broadcasts in d.pend.
   if (up) {
     if (!tp.first) {
@@ -874,46 +892,52 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
         } else {
           cell = d.inbox[cur] + ((size_t)k * d.Nl + l) * 4;
         }
-        uint4 r0 = cell[0], r1 = cell[1], r2 = cell[2], r3 = cell[3];
-        u32 k0 = SIM_META_KIND(r0.y), k1 = SIM_META_KIND(r1.y), k2 = SIM_META_KIND(r2.y), k3 = SIM_META_KIND(r3.y);
-        // wave-ballot early out: nobody in this wave received anything in packet k
-        if (!__any((k0 | k1 | k2 | k3) != SIM_K_EMPTY)) continue;
-        // phase A: the four lookups of this packet, independent of each other — first the slot
-        // map (member records), then the 16-byte head of the view entry / ring bucket
-        u32 s0 = (member_kind(k0) && r0.x < d.N) ? d.slot_of[r0.x] : NOSLOT;
-        u32 s1 = (member_kind(k1) && r1.x < d.N) ? d.slot_of[r1.x] : NOSLOT;
-        u32 s2 = (member_kind(k2) && r2.x < d.N) ? d.slot_of[r2.x] : NOSLOT;
-        u32 s3 = (member_kind(k3) && r3.x < d.N) ? d.slot_of[r3.x] : NOSLOT;
-        uint4* p0 = lookup_ptr(c, k0, r0.x, (u64)r0.z | ((u64)r0.w << 32), s0);
-        uint4* p1 = lookup_ptr(c, k1, r1.x, (u64)r1.z | ((u64)r1.w << 32), s1);
-        uint4* p2 = lookup_ptr(c, k2, r2.x, (u64)r2.z | ((u64)r2.w << 32), s2);
-        uint4* p3 = lookup_ptr(c, k3, r3.x, (u64)r3.z | ((u64)r3.w << 32), s3);
-        uint4 e0 = ld4(p0 ? p0 : d.nullcell), e1 = ld4(p1 ? p1 : d.nullcell), e2 = ld4(p2 ? p2 : d.nullcell), e3 = ld4(p3 ? p3 : d.nullcell);
-        // phase B: duplicates and other no-ops are retired against the prefetched heads; `slow` is
-        // the first record of the packet that needs a real handler (4 = none)
-        u32 slow = SIM_P;
-        if (fast_noop(c, n, k0, r0, p0 != nullptr, e0)) fast_witness(n, k0, r0); else slow = 0;
-        if (slow == SIM_P) { if (fast_noop(c, n, k1, r1, p1 != nullptr, e1)) fast_witness(n, k1, r1); else slow = 1; }
-        if (slow == SIM_P) { if (fast_noop(c, n, k2, r2, p2 != nullptr, e2)) fast_witness(n, k2, r2); else slow = 2; }
-        if (slow == SIM_P) { if (fast_noop(c, n, k3, r3, p3 != nullptr, e3)) fast_witness(n, k3, r3); else slow = 3; }
-        // phase C: from that record on, the full handlers in arrival order (one rolled loop = one
-        // copy of the handler code).  Nothing prefetched is kept: the record is re-read from the
-        // inbox cell, slot map and entry from the caches phase A just filled.
-        if (!__any(slow < SIM_P)) continue;
+        // ---- stage the packet in LDS (one 16-byte column per record and lane: conflict-free) ----
+        // phase A: the four records, then their four independent lookups — slot map for member
+        // records, then the 16-byte head of the view entry / ring bucket each record is checked
+        // against.  Everything lands in this lane's LDS cells so that the handler loop below can
+        // index it by record number without holding 40 registers across the handlers.
+        {
+          uint4 r0 = ld4(cell), r1 = ld4(cell + 1), r2 = ld4(cell + 2), r3 = ld4(cell + 3);
+          TT(1);
+          u32 k0 = SIM_META_KIND(r0.y), k1 = SIM_META_KIND(r1.y), k2 = SIM_META_KIND(r2.y), k3 = SIM_META_KIND(r3.y);
+          // wave-ballot early out: nobody in this wave received anything in packet k
+          if (!__any((k0 | k1 | k2 | k3) != SIM_K_EMPTY)) continue;
+          lds_r[0][tid] = r0; lds_r[1][tid] = r1; lds_r[2][tid] = r2; lds_r[3][tid] = r3;
+          u32 s0 = (member_kind(k0) && r0.x < d.N) ? d.slot_of[r0.x] : NOSLOT;
+          u32 s1 = (member_kind(k1) && r1.x < d.N) ? d.slot_of[r1.x] : NOSLOT;
+          u32 s2 = (member_kind(k2) && r2.x < d.N) ? d.slot_of[r2.x] : NOSLOT;
+          u32 s3 = (member_kind(k3) && r3.x < d.N) ? d.slot_of[r3.x] : NOSLOT;
+          TT(2);
+          lds_s[0][tid] = s0; lds_s[1][tid] = s1; lds_s[2][tid] = s2; lds_s[3][tid] = s3;
+          uint4* p0 = lookup_ptr(c, k0, r0.x, (u64)r0.z | ((u64)r0.w << 32), s0);
+          uint4* p1 = lookup_ptr(c, k1, r1.x, (u64)r1.z | ((u64)r1.w << 32), s1);
+          uint4* p2 = lookup_ptr(c, k2, r2.x, (u64)r2.z | ((u64)r2.w << 32), s2);
+          uint4* p3 = lookup_ptr(c, k3, r3.x, (u64)r3.z | ((u64)r3.w << 32), s3);
+          uint4 e0 = ld4(p0 ? p0 : d.nullcell), e1 = ld4(p1 ? p1 : d.nullcell), e2 = ld4(p2 ? p2 : d.nullcell), e3 = ld4(p3 ? p3 : d.nullcell);
+          TT(3);
+          lds_e[0][tid] = e0; lds_e[1][tid] = e1; lds_e[2][tid] = e2; lds_e[3][tid] = e3;
+        }
+        // phase B: the records in arrival order, one rolled loop = one copy of the handler code.
+        // Duplicates, old messages and subjects without a view slot (~95 % of all records) are
+        // retired by fast_noop against the staged head; the rest runs the full handlers.  Once a
+        // handler of this packet has written state, later heads are re-read (rare).
+        bool dirty = false;
 #pragma unroll 1
-        for (u32 p = slow; p < SIM_P; ++p) {
-          uint4 r = ld4(cell + p);
+        for (u32 p = 0; p < SIM_P; ++p) {
+          uint4 r = lds_r[p][tid];
           u32 kind = SIM_META_KIND(r.y);
           if (kind == SIM_K_EMPTY) continue;
-          u32 sl = (member_kind(kind) && r.x < d.N) ? d.slot_of[r.x] : NOSLOT;
-          uint4* ptr = lookup_ptr(c, kind, r.x, (u64)r.z | ((u64)r.w << 32), sl);
-          uint4 e = ld4(ptr ? ptr : d.nullcell);
-          bool dirty = false;
+          uint4* ptr = lookup_ptr(c, kind, r.x, (u64)r.z | ((u64)r.w << 32), lds_s[p][tid]);
+          uint4 e = lds_e[p][tid];
+          if (dirty && ptr) e = ld4(ptr);
+          if (fast_noop(c, n, kind, r, ptr != nullptr, e)) { fast_witness(n, kind, r); continue; }
           Ins ins;
           ins.has = 0;
           dispatch(c, n, r, ptr, e, dirty, ins);
           if (ins.has) pend_push(c, n, ins);
         }
+        TT(5);
       }
     }
     if (d.swim) {
@@ -937,6 +961,7 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
       }
     }
   }
+  TT(6);
   // ---- phase 2: queue.  Load the sort keys, queue what phase 1 parked, drain `fanout` packets.
   u32 sk[SIM_Q];
   u32 cnt0 = __popc(n.used);
@@ -949,12 +974,14 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
       q_insert(c, n, sk, q.x, q.y, (u64)q.z | ((u64)q.w << 32));
     }
   }
+  TT(7);
   u32 limit = up ? d.retransmit_mult * digits10(n.nknown) : 0;
   u32 sx = tp.feff ? sigma(tp, ll) : 0;
   for (u32 k = 0; k < tp.feff; ++k) {
     uint4 pk[SIM_P] = {zero, zero, zero, zero};
     if (up) {
       u32 slots = q_round(n, sk, limit);
+      TT(8);
       bool lost = tp.loss_u32 && (u32)(mix64(tp.loss_base ^ ((u64)gid * 4u + k)) >> 32) < tp.loss_u32;
       if (!lost) {
 #pragma unroll
@@ -964,6 +991,7 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
         }
       }
     }
+    TT(9);
     u32 y = sx + tp.off[k];
     if (y >= tp.M) y -= tp.M;
     u32 t = sigma_inv(tp, y);
@@ -973,11 +1001,17 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
     if (SHARDED) dst = d.xsend + (((size_t)h * d.f + k) * tp.blk + (t - b * tp.blk)) * 4;
     else dst = d.inbox[cur ^ 1] + ((size_t)k * d.Nl + (size_t)h * tp.M + t) * 4;
     dst[0] = pk[0]; dst[1] = pk[1]; dst[2] = pk[2]; dst[3] = pk[3];
+    TT(10);
   }
   if (up) {
     node_store(d, l, n);
     keys_store(d, l, cnt0, n.used, sk);
   }
+  TT(11);
+#ifdef TICK_TIMING
+  if ((threadIdx.x & 63) == 0)
+    for (int i = 0; i < 12; ++i) atomicAdd(&g_tt[i], tacc[i]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1352,6 +1386,13 @@ static inline int grid_for(size_t n) { return (int)std::min<size_t>((n + BLOCK -
 
 extern "C" {
 
+#ifdef TICK_TIMING
+int sim_debug_timing(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tt), 16 * 8) != hipSuccess) return SIM_EDEVICE;
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tt), z, 16 * 8); }
+  return SIM_OK;
+}
+#endif
 uint32_t sim_abi_version(void) { return SIM_ABI_VERSION; }
 const char* sim_backend_name(void) { return "hip-gfx950"; }
 
