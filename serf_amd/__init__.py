@@ -19,6 +19,13 @@ def load() -> SimLib:
     """Load the HIP product library (fails loudly when it is missing)."""
     global _lib
     if _lib is None:
+        # One HIP runtime per process: torch bundles its own libamdhip64; when torch is going to be
+        # used at all (device buffers for the sharded exchange, streams) it has to be loaded first so
+        # that this library binds to the same runtime instead of bringing in a second one.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = SimLib(LIB_PATH, prefix="sim_")
     return _lib
 

@@ -126,10 +126,16 @@ __device__ static inline u32 perm_fi(const TickP& p, u32 y) {
   return y;
 }
 __device__ static inline u32 sigma(const TickP& p, u32 x) {
+#ifdef TICK_TIMING_IDENTITY  // measurement only: coalesced fan-out (target = node + off) instead of the bijection
+  return x;
+#endif
   do x = perm_f(p, x); while (x >= p.M);
   return x;
 }
 __device__ static inline u32 sigma_inv(const TickP& p, u32 y) {
+#ifdef TICK_TIMING_IDENTITY
+  return y;
+#endif
   do y = perm_fi(p, y); while (y >= p.M);
   return y;
 }

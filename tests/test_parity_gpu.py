@@ -148,3 +148,53 @@ def test_config3_1m_properties(hiplib):
     d2 = g.digest()
     assert d1[:2] == d2[:2] and d1[3:] == d2[3:]
     assert g.dump(_ffi.ARR_QUEUE)["meta"].min() == 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("swim", [0, 4])
+def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim):
+    # BASELINE configs[3] shape (G shards by node-id range, one all-to-all per round), scaled down and
+    # run as 4 handles on ONE GPU: the exchange of serf_amd/shard.py is done with device-to-device
+    # copies (chunk g of shard s's send buffer -> chunk s of shard g's receive buffer), which is what
+    # all_to_all_single does over RCCL.  Every shard is compared with the oracle's matching slice.
+    import torch
+
+    n, V, ticks = 2048, 4, 50
+    m = n // V
+    kw = dict(fanout=4, view_slots=96, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=0.02)
+    ref = _ffi.Sim(oracle, _ffi.make_config(n, vshards=V, **kw))
+    shards, send, recv = [], [], []
+    for g in range(V):
+        s = _ffi.Sim(hiplib, _ffi.make_config(n, vshards=V, shard_rank=g, shard_count=V, **kw))
+        nb = s.exchange_bytes()
+        send.append(torch.zeros(nb, dtype=torch.uint8, device="cuda"))
+        recv.append(torch.zeros(nb, dtype=torch.uint8, device="cuda"))
+        s.bind_exchange(send[-1].data_ptr(), recv[-1].data_ptr())
+        shards.append(s)
+    ops = sc.schedule(n, ticks // 2, rate=0.8, seed=5, max_member_subjects=60)
+    for s in shards + [ref]:
+        sc.apply_schedule(s, ops)
+    chunk = send[0].numel() // V
+    for t in range(ticks):
+        for s in shards:
+            s.step(1)
+        for s in shards:
+            s.sync()
+        for g in range(V):          # the all-to-all
+            for src in range(V):
+                recv[g][src * chunk:(src + 1) * chunk].copy_(send[src][g * chunk:(g + 1) * chunk])
+        torch.cuda.synchronize()
+        ref.step(1)
+        if t % 7 == 0 or t == ticks - 1:
+            for g, s in enumerate(shards):
+                lo = g * m
+                for which in (_ffi.ARR_ROWS, _ffi.ARR_QUEUE):
+                    a, b = s.dump(which), ref.dump(which)
+                    per = len(b) // n
+                    i = sc.first_diff(a, b[lo * per:(lo + m) * per])
+                    assert i is None, f"shard {g} array {which} element {i} differs at tick {t}"
+                for which, rows in ((_ffi.ARR_VIEW, 96), (_ffi.ARR_ERING, 16), (_ffi.ARR_QRING, 8)):
+                    a = s.dump(which).reshape(rows, m)
+                    b = np.ascontiguousarray(ref.dump(which).reshape(rows, n)[:, lo:lo + m])
+                    assert a.tobytes() == b.tobytes(), f"shard {g} array {which} differs at tick {t}"
+    tot = [sum(x) for x in zip(*(s.convergence(_ffi.K_LEAVE, next(o for o in ops if o[1] == _ffi.OP_LEAVE)[2], 1) for s in shards))]
+    assert tuple(tot) == ref.convergence(_ffi.K_LEAVE, next(o for o in ops if o[1] == _ffi.OP_LEAVE)[2], 1)

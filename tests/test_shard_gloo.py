@@ -1,0 +1,73 @@
+"""N > 1 path on CPU: two processes (gloo), one shard each, ONE all_to_all_single per tick
+(serf_amd/shard.py).  The compute behind the exchange is the CPU oracle here (this container has no
+GPU); on the GPU box the same ShardedSim drives the HIP library over RCCL.  Each rank checks its
+shard against the matching slice of a single-process run of the same cluster."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n, ticks, swim, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    from serf_amd import _ffi
+    from serf_amd.shard import ShardedSim
+    from tests import _scenario as sc
+    from tests._oracle import load_oracle
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lib = load_oracle()
+        kw = dict(fanout=3, view_slots=64, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=0.02)
+        sh = ShardedSim(lib, n, torch.device("cpu"), **kw)
+        ref = _ffi.Sim(lib, _ffi.make_config(n, vshards=world, **kw))  # all shards in one process
+        ops = sc.schedule(n, ticks // 2, rate=0.7, seed=17, max_member_subjects=40)
+        for t, op, node, a, b in ops:
+            sh.inject(t, op, node, a, b)
+            ref.inject(t, op, node, a, b)
+        m = n // world
+        lo = rank * m
+        for t in range(0, ticks, 5):
+            sh.step(5)
+            ref.step(5)
+            for which in (_ffi.ARR_ROWS, _ffi.ARR_QUEUE):
+                a = sh.sim.dump(which)
+                b = ref.dump(which)
+                per = len(b) // n
+                assert (a.tobytes() == b[lo * per:(lo + m) * per].tobytes()), f"rank {rank} array {which} differs at tick {t + 5}"
+            for which, rows in ((_ffi.ARR_VIEW, 64), (_ffi.ARR_ERING, 16), (_ffi.ARR_QRING, 8)):
+                a = sh.sim.dump(which).reshape(rows, m)
+                b = ref.dump(which).reshape(rows, n)[:, lo:lo + m]
+                assert a.tobytes() == np.ascontiguousarray(b).tobytes(), f"rank {rank} array {which} differs at tick {t + 5}"
+        ev = next(op for op in ops if op[1] == _ffi.OP_USER_EVENT)
+        assert sh.convergence(_ffi.K_EVENT, ev[3], 1) == ref.convergence(_ffi.K_EVENT, ev[3], 1)
+        q.put((rank, "ok"))
+    except BaseException as e:  # noqa: BLE001 — report to the parent, then re-raise
+        q.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("swim", [0, 4])
+def test_two_shards_gloo_match_single_process(swim):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 300) + swim
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 512, 60, swim, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    res = sorted(q.get(timeout=5) for _ in procs)
+    assert res == [(0, "ok"), (1, "ok")], res
