@@ -1,0 +1,153 @@
+// serf.hpp — C++ host-side mirror of the reference's `Serf` API (serf-core/src/serf/api.rs) for the
+// bulk simulation path, header-only, on top of the C ABI of include/serf_sim.h.
+//
+// The reference's host language is Rust; this image has no Rust toolchain, so the host above the C
+// ABI is C++ (the Rust binding a maintainer would add is in INTEGRATION.md).  Names and argument
+// meaning follow the reference: a `Cluster` owns all N simulated nodes (one `Serf::new` each,
+// api.rs:25), `Cluster::node(i)` is the `Serf` handle of node i and has the reference's methods.
+// Errors: the reference returns `Result<_, Error>` (error.rs:64-81); here a `serf::Error` exception
+// carries the SIM_E* code.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/serf_sim.h"
+
+namespace serf {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const char* what) : std::runtime_error(std::string(what) + ": SIM error " + std::to_string(c)), code(c) {}
+};
+inline void check(int rc, const char* what) {
+  if (rc < 0) throw Error(rc, what);
+}
+
+// MemberStatus — types/member.rs:54-87
+enum class MemberStatus : uint8_t { None = 0, Alive = 1, Leaving = 2, Left = 3, Failed = 4 };
+// MemberEventType — event.rs:263-279 (+ user / query events, event.rs:367-378)
+enum class EventType : uint32_t { Join = 0, Leave = 1, Failed = 2, Update = 3, Reap = 4, User = 5, Query = 6 };
+
+struct Member {  // types/member.rs:135-185 (id + status; tags/addresses are not on the simulated path)
+  uint32_t id;
+  MemberStatus status;
+  uint64_t status_ltime;
+};
+using Stats = sim_stats;  // api.rs:586-602
+using Event = sim_event;
+
+// Options — options.rs:16-469 (the fields the simulated path reads) + MemberlistOptions::lan()/wan()
+struct Options {
+  sim_config c{};
+  explicit Options(uint32_t n_nodes) {
+    c.struct_size = sizeof(sim_config);
+    c.n_nodes = n_nodes; c.vshards = 1; c.shard_rank = 0; c.shard_count = 1;
+    c.fanout = 3;                                  // lan(): gossip_nodes
+    c.view_slots = 0;
+    c.event_ring = 512; c.query_ring = 512;        // options.rs:516-517
+    c.retransmit_mult = 4; c.probe_interval = 5;   // lan(): 1 s / 200 ms
+    c.suspicion_mult = 4; c.suspicion_max_mult = 6; c.indirect_checks = 3;
+    c.loss_u32 = 0; c.intent_timeout = 0;
+    c.leave_delay = 30;                            // broadcast_timeout 5 s + leave_propagate_delay 1 s
+    c.flags = SIM_CF_BASELINE_JOINED;
+    c.seed = SIM_DEFAULT_SEED;
+  }
+  static Options lan(uint32_t n) { return Options(n); }
+  static Options wan(uint32_t n) {  // gossip 500 ms, probe 5 s, fan-out 4, suspicion_mult 6 (k capped at 3)
+    Options o(n);
+    o.c.fanout = 4; o.c.probe_interval = 10; o.c.suspicion_mult = 5;
+    return o;
+  }
+  Options& with_fanout(uint32_t f) { c.fanout = f; return *this; }
+  Options& with_view_slots(uint32_t a) { c.view_slots = a; return *this; }
+  Options& with_event_buffer_size(uint32_t b) { c.event_ring = b; return *this; }
+  Options& with_query_buffer_size(uint32_t b) { c.query_ring = b; return *this; }
+  Options& with_packet_loss(double p) { c.loss_u32 = p >= 1.0 ? 0xFFFFFFFFu : (uint32_t)(p * 4294967296.0); return *this; }
+  Options& with_seed(uint64_t s) { c.seed = s; return *this; }
+};
+
+class Cluster;
+
+// One simulated node: the reference's `Serf<T, D>` (serf.rs:171-254) for the simulated path.
+class Serf {
+ public:
+  uint32_t local_id() const { return id_; }                                   // api.rs:100
+  inline std::vector<Member> members() const;                                 // api.rs:136
+  inline Stats stats() const;                                                 // api.rs:150
+  inline size_t num_members() const { return stats().members; }               // api.rs:188
+  // api.rs:241 — `name`/`payload` identity is a 32-bit key, `encoded_len` its wire size in bytes
+  inline void user_event(uint32_t event_key, uint32_t encoded_len = 32, bool coalesce = true);
+  inline void query(uint32_t query_id, uint32_t flags = 0);                   // api.rs:304
+  inline void join(uint32_t peer);                                            // api.rs:318
+  inline void leave();                                                        // api.rs:422
+  inline void remove_failed_node(uint32_t id);                                // api.rs:505
+  inline void remove_failed_node_prune(uint32_t id);                          // api.rs:513
+  inline void subscribe();                                                    // EventSubscriber, event.rs:430-491
+
+ private:
+  friend class Cluster;
+  Serf(Cluster* c, uint32_t id) : c_(c), id_(id) {}
+  Cluster* c_;
+  uint32_t id_;
+};
+
+class Cluster {
+ public:
+  explicit Cluster(const Options& o) : n_(o.c.n_nodes) { check(sim_create(&o.c, &h_), "sim_create"); }
+  ~Cluster() { if (h_) sim_destroy(h_); }
+  Cluster(const Cluster&) = delete;
+  Cluster& operator=(const Cluster&) = delete;
+  Serf node(uint32_t id) { return Serf(this, id); }
+  uint32_t size() const { return n_; }
+  void step(uint32_t ticks = 1) { check(sim_step(h_, ticks), "sim_step"); }   // the gossip loop
+  void sync() { check(sim_sync(h_), "sim_sync"); }
+  uint64_t tick() const { uint64_t t = 0; check(sim_tick(h_, &t), "sim_tick"); return t; }
+  // churn / fault injection (the reference tests shutdown() nodes: tests/serf/event.rs:112)
+  void crash(uint32_t node, uint64_t at_tick) { check(sim_inject(h_, at_tick, SIM_OP_CRASH, node, 0, 0), "sim_inject"); }
+  void revive(uint32_t node, uint64_t at_tick) { check(sim_inject(h_, at_tick, SIM_OP_REVIVE, node, 0, 0), "sim_inject"); }
+  std::vector<Event> drain_events() {
+    std::vector<Event> ev(1 << 16);
+    uint32_t n = 0;
+    check(sim_drain_events(h_, ev.data(), (uint32_t)ev.size(), &n), "sim_drain_events");
+    ev.resize(n);
+    return ev;
+  }
+  // fraction of running nodes that have applied the rumour (rounds-to-99 % = first tick >= 0.99)
+  double convergence(uint32_t kind, uint32_t key, uint64_t ltime) {
+    uint64_t seen = 0, up = 0;
+    check(sim_convergence(h_, kind, key, ltime, &seen, &up), "sim_convergence");
+    return up ? (double)seen / (double)up : 0.0;
+  }
+  sim_handle* raw() { return h_; }
+
+ private:
+  sim_handle* h_ = nullptr;
+  uint32_t n_;
+};
+
+inline std::vector<Member> Serf::members() const {
+  std::vector<uint8_t> st(c_->size());
+  std::vector<uint64_t> lt(c_->size());
+  check(sim_members(c_->raw(), id_, st.data(), lt.data(), c_->size()), "sim_members");
+  std::vector<Member> out;
+  for (uint32_t i = 0; i < c_->size(); ++i)
+    if (st[i] != 0) out.push_back(Member{i, (MemberStatus)st[i], lt[i]});
+  return out;
+}
+inline Stats Serf::stats() const {
+  Stats s;
+  check(sim_stats_get(c_->raw(), id_, &s), "sim_stats_get");
+  return s;
+}
+inline void Serf::user_event(uint32_t key, uint32_t len, bool cc) { check(sim_user_event(c_->raw(), id_, key, len, cc), "sim_user_event"); }
+inline void Serf::query(uint32_t qid, uint32_t flags) { check(sim_query(c_->raw(), id_, qid, flags), "sim_query"); }
+inline void Serf::join(uint32_t peer) { check(sim_join(c_->raw(), id_, peer), "sim_join"); }
+inline void Serf::leave() { check(sim_leave(c_->raw(), id_), "sim_leave"); }
+inline void Serf::remove_failed_node(uint32_t id) { check(sim_force_leave(c_->raw(), id_, id, 0), "sim_force_leave"); }
+inline void Serf::remove_failed_node_prune(uint32_t id) { check(sim_force_leave(c_->raw(), id_, id, 1), "sim_force_leave"); }
+inline void Serf::subscribe() { check(sim_watch(c_->raw(), id_), "sim_watch"); }
+
+}  // namespace serf
