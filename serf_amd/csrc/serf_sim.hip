@@ -202,6 +202,7 @@ struct Ctx {
 // site per call site of the handlers instead of one per `return true`.
 struct Ins {
   u32 has, key, wmeta;
+  u32 wide;  // the handler also wrote the node's OWN view entry (refutation), not only the record's
   u64 val;
 };
 __device__ static inline void ins_set(Ins& q, u32 key, u32 wmeta, u64 val) {
@@ -471,6 +472,7 @@ __device__ static void broadcast_join(const Ctx& c, Node& n, u64 ltime, bool& di
   witness(n, n.clock, ltime, DR0);
   uint4* p = view_ptr(c, c.gid);
   handle_join_intent(c, n, c.gid, ltime, p, p ? p[0] : make_uint4(0, 0, 0, 0), dirty);
+  ins.wide = 1;
   ins_set(ins, c.gid, wire_meta(SIM_K_JOIN, 0, 16), ltime);
 }
 // handle_node_leave_intent: base.rs:1442-1572
@@ -633,6 +635,7 @@ __device__ static void swim_refute(const Ctx& c, Node& n, u32 accused_inc, Ins& 
   uint4* p = view_ptr(c, c.gid);
   if (p) { uint4 e = p[0]; e.z = inc; p[0] = e; }
   aw_delta(n, +1);
+  ins.wide = 1;
   ins_set(ins, c.gid, wire_meta(SIM_K_ALIVE, 0, 64), inc);
 }
 __device__ static void swim_alive(const Ctx& c, Node& n, u32 subject, u32 inc, u32 wmeta, uint4* p, uint4 e, bool& dirty, Ins& ins) {
@@ -860,11 +863,11 @@ __device__ static inline uint4 sel4(u32 i, const uint4& a, const uint4& b, const
 #ifdef TICK_TIMING
 __device__ unsigned long long g_tt[16];
 // wave-uniform accumulation in scalar registers; one set of atomics per wave at the very end
-#define TT(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tprev; tprev = t_; } while (0)
+#define TT(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tprev; tprev = t_; } while (0)
 #else
 #define TT(i)
 #endif
-template <bool SHARDED>
+template <bool SHARDED, int F>
 __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, const uint4* base) {
 #ifdef TICK_TIMING
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -889,22 +892,29 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
   // ---- phase 1: deliver.  The queue is not touched: handlers park their broadcasts in d.pend.
   if (up) {
     if (!tp.first) {
-      for (u32 k = 0; k < d.f; ++k) {
-        const uint4* cell;
+      // inbox cell of fan-out slot k (sharded: the block of the receive buffer the source shard filled)
+      auto cell_of = [&](u32 k) -> const uint4* {
         if (SHARDED) {
           u32 b = l / tp.blk;
           u32 src = (d.shard_rank + b + tp.prot[k]) % tp.V;
-          cell = d.xrecv + (((size_t)src * d.f + k) * tp.blk + (l - b * tp.blk)) * 4;
-        } else {
-          cell = d.inbox[cur] + ((size_t)k * d.Nl + l) * 4;
+          return d.xrecv + (((size_t)src * d.f + k) * tp.blk + (l - b * tp.blk)) * 4;
         }
+        return d.inbox[cur] + ((size_t)k * d.Nl + l) * 4;
+      };
+      const uint4* cell = cell_of(0);
+      uint4 rn = ld4(cell);  // first record of the next packet, fetched one packet ahead
+      for (u32 k = 0; k < d.f; ++k) {
         // ---- stage the packet in LDS (one 16-byte column per record and lane: conflict-free) ----
         // phase A: the four records, then their four independent lookups — slot map for member
         // records, then the 16-byte head of the view entry / ring bucket each record is checked
         // against.  Everything lands in this lane's LDS cells so that the handler loop below can
         // index it by record number without holding 40 registers across the handlers.
         {
-          uint4 r0 = ld4(cell), r1 = ld4(cell + 1), r2 = ld4(cell + 2), r3 = ld4(cell + 3);
+          uint4 r0 = rn, r1 = ld4(cell + 1), r2 = ld4(cell + 2), r3 = ld4(cell + 3);
+          if (k + 1 < d.f) {  // pull the next cell's line towards this CU while this packet is handled
+            cell = cell_of(k + 1);
+            rn = ld4(cell);
+          }
           TT(1);
           u32 k0 = SIM_META_KIND(r0.y), k1 = SIM_META_KIND(r1.y), k2 = SIM_META_KIND(r2.y), k3 = SIM_META_KIND(r3.y);
           // wave-ballot early out: nobody in this wave received anything in packet k
@@ -923,12 +933,16 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
           uint4 e0 = ld4(p0 ? p0 : d.nullcell), e1 = ld4(p1 ? p1 : d.nullcell), e2 = ld4(p2 ? p2 : d.nullcell), e3 = ld4(p3 ? p3 : d.nullcell);
           TT(3);
           lds_e[0][tid] = e0; lds_e[1][tid] = e1; lds_e[2][tid] = e2; lds_e[3][tid] = e3;
+          TT(4);
         }
         // phase B: the records in arrival order, one rolled loop = one copy of the handler code.
         // Duplicates, old messages and subjects without a view slot (~95 % of all records) are
         // retired by fast_noop against the staged head; the rest runs the full handlers.  Once a
         // handler of this packet has written state, later heads are re-read (rare).
-        bool dirty = false;
+        // `wptr`: the one entry a handler of this packet has written so far; `wall`: more than one,
+        // or the node's own entry as well (refutation) — only then is a staged head stale.
+        uint4* wptr = nullptr;
+        bool wall = false;
 #pragma unroll 1
         for (u32 p = 0; p < SIM_P; ++p) {
           uint4 r = lds_r[p][tid];
@@ -936,11 +950,16 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
           if (kind == SIM_K_EMPTY) continue;
           uint4* ptr = lookup_ptr(c, kind, r.x, (u64)r.z | ((u64)r.w << 32), lds_s[p][tid]);
           uint4 e = lds_e[p][tid];
-          if (dirty && ptr) e = ld4(ptr);
+          if (ptr && (wall || ptr == wptr)) e = ld4(ptr);
           if (fast_noop(c, n, kind, r, ptr != nullptr, e)) { fast_witness(n, kind, r); continue; }
           Ins ins;
-          ins.has = 0;
+          ins.has = ins.wide = 0;
+          bool dirty = false;
           dispatch(c, n, r, ptr, e, dirty, ins);
+          if (dirty) {
+            wall |= ins.wide || (wptr != nullptr && wptr != ptr);
+            wptr = ptr;
+          }
           if (ins.has) pend_push(c, n, ins);
         }
         TT(5);
@@ -956,7 +975,7 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
 #pragma unroll 1
         for (u32 j = 0; j <= SIM_S; ++j) {
           Ins ins;
-          ins.has = 0;
+          ins.has = ins.wide = 0;
           if (j < SIM_S) { if (due) swim_timer_j(c, n, j, next, ins); }
           else {
             if (due) { n.susp_next = next; n.dirty |= DR3; }
@@ -982,22 +1001,35 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
   }
   TT(7);
   u32 limit = up ? d.retransmit_mult * digits10(n.nknown) : 0;
-  u32 sx = tp.feff ? sigma(tp, ll) : 0;
-  for (u32 k = 0; k < tp.feff; ++k) {
-    uint4 pk[SIM_P] = {zero, zero, zero, zero};
-    if (up) {
-      u32 slots = q_round(n, sk, limit);
-      TT(8);
-      bool lost = tp.loss_u32 && (u32)(mix64(tp.loss_base ^ ((u64)gid * 4u + k)) >> 32) < tp.loss_u32;
-      if (!lost) {
+  // all F drain rounds first (pure register work on the sort keys) ...
+  u32 slots[F];
 #pragma unroll
-        for (int p = 0; p < (int)SIM_P; ++p) {
-          u32 s = (slots >> (8 * p)) & 0xFFu;
-          if (s != 0xFFu) pk[p] = ld4(&d.qpay[(size_t)s * d.Nl + l]);
-        }
-      }
+  for (int k = 0; k < F; ++k) {
+    slots[k] = 0xFFFFFFFFu;
+    if (up && (u32)k < tp.feff) {
+      u32 s = q_round(n, sk, limit);
+      bool lost = tp.loss_u32 && (u32)(mix64(tp.loss_base ^ ((u64)gid * 4u + k)) >> 32) < tp.loss_u32;
+      if (!lost) slots[k] = s;
     }
-    TT(9);
+  }
+  TT(8);
+  // ... then every payload gather of the tick in flight at once (one memory round trip, not F) ...
+  uint4 pk[F][SIM_P];
+#pragma unroll
+  for (int k = 0; k < F; ++k) {
+#pragma unroll
+    for (int p = 0; p < (int)SIM_P; ++p) {
+      u32 s = (slots[k] >> (8 * p)) & 0xFFu;
+      pk[k][p] = zero;
+      if (s != 0xFFu) pk[k][p] = ld4(&d.qpay[(size_t)s * d.Nl + l]);
+    }
+  }
+  TT(9);
+  // ... then the F scatters: packet k goes to the inbox cell of T_k(l)
+  u32 sx = tp.feff ? sigma(tp, ll) : 0;
+#pragma unroll
+  for (int k = 0; k < F; ++k) {
+    if ((u32)k >= tp.feff) break;
     u32 y = sx + tp.off[k];
     if (y >= tp.M) y -= tp.M;
     u32 t = sigma_inv(tp, y);
@@ -1006,9 +1038,9 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
     uint4* dst;
     if (SHARDED) dst = d.xsend + (((size_t)h * d.f + k) * tp.blk + (t - b * tp.blk)) * 4;
     else dst = d.inbox[cur ^ 1] + ((size_t)k * d.Nl + (size_t)h * tp.M + t) * 4;
-    dst[0] = pk[0]; dst[1] = pk[1]; dst[2] = pk[2]; dst[3] = pk[3];
-    TT(10);
+    dst[0] = pk[k][0]; dst[1] = pk[k][1]; dst[2] = pk[k][2]; dst[3] = pk[k][3];
   }
+  TT(10);
   if (up) {
     node_store(d, l, n);
     keys_store(d, l, cnt0, n.used, sk);
@@ -1051,7 +1083,7 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive) {
     bool up = n.flags & SIM_RF_UP, dirty = false;
     u32 a = ob.a[i], b = ob.b[i];
     Ins ins, ins2;  // ins: what the handler queues; ins2: the op's own broadcast, queued after it
-    ins.has = ins2.has = 0;
+    ins.has = ins2.has = ins.wide = ins2.wide = 0;
     switch (op) {
       case SIM_OP_USER_EVENT:  // api.rs:241-299
         if (up) {
@@ -1593,8 +1625,18 @@ int sim_step(sim_handle* h, uint32_t n_ticks) {
     }
     int grid = (int)((d.Nl + BLOCK - 1) / BLOCK);
     u32 cur = (u32)(h->tick & 1);
-    if (d.sharded) tick_kernel<true><<<grid, BLOCK, 0, h->stream>>>(d, tp, cur, h->d_base);
-    else tick_kernel<false><<<grid, BLOCK, 0, h->stream>>>(d, tp, cur, h->d_base);
+#define LAUNCH_TICK(SH, FF) tick_kernel<SH, FF><<<grid, BLOCK, 0, h->stream>>>(d, tp, cur, h->d_base)
+    switch (tp.feff + (d.sharded ? 4u : 0u)) {  // one instantiation per fan-out: the drain loop is fully unrolled
+      case 0: case 1: LAUNCH_TICK(false, 1); break;
+      case 2: LAUNCH_TICK(false, 2); break;
+      case 3: LAUNCH_TICK(false, 3); break;
+      case 4: LAUNCH_TICK(false, 4); break;
+      case 5: LAUNCH_TICK(true, 1); break;
+      case 6: LAUNCH_TICK(true, 2); break;
+      case 7: LAUNCH_TICK(true, 3); break;
+      default: LAUNCH_TICK(true, 4); break;
+    }
+#undef LAUNCH_TICK
     h->prev = tp;
     h->tick++;
   }

@@ -15,7 +15,7 @@ buf = (C.c_ulonglong * 16)()
 lib.dll.sim_debug_timing(buf, 1)
 sim.step(50); sim.sync()
 lib.dll.sim_debug_timing(buf, 1)
-names = ["row load", "cell load (x4)", "slot_of (x4)", "entry heads (x4)", "fast checks (x4)", "slow loop (x4)", "timers+probe", "keys+pend inserts", "q_round (x4)", "payload gather (x4)", "perm+store (x4)", "row/keys store"]
+names = ["row load", "cell r1-3 (x4)", "slot_of (x4)", "entry ptrs+issue (x4)", "entry heads wait (x4)", "handler loop (x4)", "timers+probe", "keys+pend inserts", "q_round x4", "payload gather (all)", "perm+store x4", "row/keys store"]
 waves = n // 64 * 50
 tot = sum(buf[:12])
 for i, nm in enumerate(names):
