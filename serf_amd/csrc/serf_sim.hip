@@ -787,11 +787,26 @@ __device__ static inline bool member_kind(u32 kind) {
   return kind == SIM_K_JOIN || kind == SIM_K_LEAVE || kind >= SIM_K_ALIVE;
 }
 // address of the state a record is checked against (null: nothing to look at)
+// Branch-free on the per-lane values (divergent branches cost scalar exec-mask work on every
+// record): the ring index and the view address are both formed, then selected by kind.
 __device__ static inline uint4* lookup_ptr(const Ctx& c, u32 kind, u32 key, u64 val, u32 slot) {
-  if (kind == SIM_K_EVENT) return ering_ptr(c, val);
-  if (kind == SIM_K_QUERY) return qring_ptr(c, val);
-  if (kind == SIM_K_EMPTY || slot == NOSLOT) return nullptr;
-  return view_slot_ptr(c, slot);
+  const Dev& d = c.d;
+  bool isq = kind == SIM_K_QUERY, isring = isq || kind == SIM_K_EVENT;
+  u32 B = isq ? d.Bq : d.Bev, mask = isq ? d.bq_mask : d.bev_mask;
+  u32 idx = (u32)val & mask;
+  if (!(d.bev_mask && d.bq_mask)) idx = ring_idx(val, B, mask);  // uniform: a ring size that is not a power of two
+  uint4* ring = isq ? d.qring : d.ering;
+  size_t row = isring ? (size_t)idx : (size_t)slot;
+  uint4* basep = isring ? ring : d.view;
+  bool none = !isring && (kind == SIM_K_EMPTY || slot == NOSLOT);
+  uint4* p = basep + (row * d.Nl + c.l) * 2;
+  return none ? nullptr : p;
+}
+// slot of a member record's subject (NOSLOT for other kinds and for ids out of range)
+__device__ static inline u32 slot_load(const Dev& d, u32 kind, u32 key) {
+  u32 s = NOSLOT;
+  if (member_kind(kind) && key < d.N) s = d.slot_of[key];
+  return s;
 }
 // Fast classification of one record against the prefetched head `e` of the state it is checked
 // against (null-ness of the lookup in `has`).  Returns true when the handler would change nothing
@@ -800,42 +815,38 @@ __device__ static inline uint4* lookup_ptr(const Ctx& c, u32 kind, u32 key, u64 
 // Anything else (a new rumour, a refutation, a confirmation...) is left to the full handlers.
 // The conditions are the early `return false` exits of the handlers, in the handlers' order.
 __device__ static inline bool fast_noop(const Ctx& c, const Node& n, u32 kind, const uint4& r, bool has, const uint4& e) {
-  u64 lt = (u64)r.z | ((u64)r.w << 32);
-  if (kind == SIM_K_EVENT) {  // handle_user_event: base.rs:750-837
-    if (n.flags & SIM_RF_MINTIME) return false;
-    u64 B = c.d.Bev, cur = lt >= n.eclock ? lt + 1 : n.eclock;
-    if (cur > B && lt < cur - B) return true;
-    return e.z != 0 && (e.z == r.x || e.w == r.x);
-  }
-  if (kind == SIM_K_QUERY) {  // handle_query: base.rs:972-1073
-    if (n.flags & SIM_RF_MINTIME) return false;
-    u64 qt = c.d.Bq, cur = lt >= n.qclock ? lt + 1 : n.qclock;
-    if (cur > qt && qt < cur - qt) return true;
-    return e.z != 0 && E_LTIME(e) == lt && (e.z == r.x || e.w == r.x);
-  }
-  if (kind == SIM_K_JOIN || kind == SIM_K_LEAVE) {  // base.rs:1338-1373, 1442-1572
-    if (!has) return true;
-    if (e.w & SIM_VB_KNOWN) return lt <= E_LTIME(e);
-    return SIM_VB_INTENT(e.w) != 0 && !(lt > E_LTIME(e));
-  }
-  if (kind == SIM_K_EMPTY || kind > SIM_K_DEAD || !c.d.swim || !has) return true;
-  if (kind == SIM_K_ALIVE) {
-    if (r.x == c.gid) return r.z <= n.inc;
-    return (e.w & SIM_VB_KNOWN) && r.z <= e.z;
-  }
-  if (!(e.w & SIM_VB_KNOWN) || r.z < e.z) return true;
+  // written with selects, not branches: this runs for every record of every node
+  const Dev& d = c.d;
+  u64 lt = (u64)r.z | ((u64)r.w << 32), elt = E_LTIME(e);
+  bool isev = kind == SIM_K_EVENT, isq = kind == SIM_K_QUERY, isjl = kind == SIM_K_JOIN || kind == SIM_K_LEAVE;
+  bool known = e.w & SIM_VB_KNOWN;
+  // rings — handle_user_event base.rs:750-837, handle_query base.rs:972-1073
+  u64 clk = isev ? n.eclock : n.qclock, B = isev ? d.Bev : d.Bq;
+  u64 cur = lt >= clk ? lt + 1 : clk;
+  bool old = cur > B && (isev ? lt < cur - B : B < cur - B);
+  bool dup = e.z != 0 && (isev || elt == lt) && (e.z == r.x || e.w == r.x);
+  bool ring_fast = !(n.flags & SIM_RF_MINTIME) && (old || dup);
+  // intents — base.rs:1338-1373, 1442-1572
+  bool jl_fast = !has || (known ? lt <= elt : (SIM_VB_INTENT(e.w) != 0 && !(lt > elt)));
+  // memberlist — App. B.4
   u32 sw = SIM_VB_SWIM(e.w);
-  if (kind == SIM_K_SUSPECT) {
-    if (sw == SIM_SWIM_SUSPECT) return SIM_VB_NCONF(e.w) >= c.d.kconf;
-    return sw != SIM_SWIM_ALIVE;
-  }
-  return sw == SIM_SWIM_DEAD || sw == SIM_SWIM_LEFT;  // SIM_K_DEAD
+  bool alive_fast = r.x == c.gid ? r.z <= n.inc : (known && r.z <= e.z);
+  bool susp_fast = sw == SIM_SWIM_SUSPECT ? SIM_VB_NCONF(e.w) >= d.kconf : sw != SIM_SWIM_ALIVE;
+  bool dead_fast = sw == SIM_SWIM_DEAD || sw == SIM_SWIM_LEFT;
+  bool sd_fast = !known || r.z < e.z || (kind == SIM_K_SUSPECT ? susp_fast : dead_fast);
+  bool swim_fast = !d.swim || !has || (kind == SIM_K_ALIVE ? alive_fast : sd_fast);
+  bool other = kind == SIM_K_EMPTY || kind > SIM_K_DEAD;
+  return (isev || isq) ? ring_fast : isjl ? jl_fast : (other || swim_fast);
 }
-__device__ static inline void fast_witness(Node& n, u32 kind, const uint4& r) {
+__device__ static inline void fast_witness(Node& n, u32 kind, const uint4& r, bool apply) {
   u64 lt = (u64)r.z | ((u64)r.w << 32);
-  if (kind == SIM_K_EVENT) witness(n, n.eclock, lt, DR0);
-  else if (kind == SIM_K_QUERY) witness(n, n.qclock, lt, DR1);
-  else if (kind == SIM_K_JOIN || kind == SIM_K_LEAVE) witness(n, n.clock, lt, DR0);
+  bool ev = apply && kind == SIM_K_EVENT && lt >= n.eclock;
+  bool qu = apply && kind == SIM_K_QUERY && lt >= n.qclock;
+  bool jl = apply && (kind == SIM_K_JOIN || kind == SIM_K_LEAVE) && lt >= n.clock;
+  n.eclock = ev ? lt + 1 : n.eclock;
+  n.qclock = qu ? lt + 1 : n.qclock;
+  n.clock = jl ? lt + 1 : n.clock;
+  n.dirty |= ((ev || jl) ? DR0 : 0u) | (qu ? DR1 : 0u);
 }
 __device__ static inline void dispatch(const Ctx& c, Node& n, const uint4& r, uint4* p, const uint4& e, bool& dirty, Ins& ins) {
   u32 kind = SIM_META_KIND(r.y), flags = SIM_META_FLAGS(r.y);
@@ -920,10 +931,10 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
           // wave-ballot early out: nobody in this wave received anything in packet k
           if (!__any((k0 | k1 | k2 | k3) != SIM_K_EMPTY)) continue;
           lds_r[0][tid] = r0; lds_r[1][tid] = r1; lds_r[2][tid] = r2; lds_r[3][tid] = r3;
-          u32 s0 = (member_kind(k0) && r0.x < d.N) ? d.slot_of[r0.x] : NOSLOT;
-          u32 s1 = (member_kind(k1) && r1.x < d.N) ? d.slot_of[r1.x] : NOSLOT;
-          u32 s2 = (member_kind(k2) && r2.x < d.N) ? d.slot_of[r2.x] : NOSLOT;
-          u32 s3 = (member_kind(k3) && r3.x < d.N) ? d.slot_of[r3.x] : NOSLOT;
+          u32 s0 = slot_load(d, k0, r0.x);
+          u32 s1 = slot_load(d, k1, r1.x);
+          u32 s2 = slot_load(d, k2, r2.x);
+          u32 s3 = slot_load(d, k3, r3.x);
           TT(2);
           lds_s[0][tid] = s0; lds_s[1][tid] = s1; lds_s[2][tid] = s2; lds_s[3][tid] = s3;
           uint4* p0 = lookup_ptr(c, k0, r0.x, (u64)r0.z | ((u64)r0.w << 32), s0);
@@ -947,11 +958,12 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
         for (u32 p = 0; p < SIM_P; ++p) {
           uint4 r = lds_r[p][tid];
           u32 kind = SIM_META_KIND(r.y);
-          if (kind == SIM_K_EMPTY) continue;
           uint4* ptr = lookup_ptr(c, kind, r.x, (u64)r.z | ((u64)r.w << 32), lds_s[p][tid]);
           uint4 e = lds_e[p][tid];
           if (ptr && (wall || ptr == wptr)) e = ld4(ptr);
-          if (fast_noop(c, n, kind, r, ptr != nullptr, e)) { fast_witness(n, kind, r); continue; }
+          bool fast = fast_noop(c, n, kind, r, ptr != nullptr, e);
+          fast_witness(n, kind, r, fast);
+          if (fast) continue;
           Ins ins;
           ins.has = ins.wide = 0;
           bool dirty = false;
