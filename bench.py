@@ -19,7 +19,18 @@ def b_tick_v0(f):
     return 2 * 64 + 2 * 16 * 16 + 2 * f * 4 * 16 + 4 * (f + 2)
 
 
-def cpu_baseline(fanout, probe_interval, seconds_budget=20.0):
+# the same accounting for the frozen layout: rows + (sort keys r/w + payload gathers)
+# + packets written once and read once + one slot-map word and one 16-byte head per received record
+def b_tick_layout(f):
+    return 2 * 64 + (2 * 16 * 4 + f * 4 * 16) + 2 * f * 4 * 16 + f * 4 * (4 + 16)
+
+
+# the benchmark workload: evenly spaced API operations, this mix of
+# (user event, query, graceful leave [+ rejoin], crash + remove_failed_node, crash + revive)
+MIX = (0.55, 0.2, 0.15, 0.05, 0.05)
+
+
+def cpu_baseline(fanout, probe_interval, rate, seconds_budget=20.0):
     """The CPU oracle ("port") on a bounded sample of the same workload, rank 0 only."""
     from serf_amd import _ffi
     from tests import _scenario as sc
@@ -29,7 +40,7 @@ def cpu_baseline(fanout, probe_interval, seconds_budget=20.0):
     n, ticks = 1 << 18, 24
     sim = _ffi.Sim(lib, _ffi.make_config(n, fanout=fanout, view_slots=64, event_ring=64, query_ring=64,
                                          probe_interval=probe_interval))
-    sc.apply_schedule(sim, sc.schedule(n, ticks, rate=0.5, seed=11, max_member_subjects=32))
+    sc.apply_schedule(sim, sc.schedule(n, ticks, rate=rate, seed=11, mix=MIX, max_member_subjects=32, even=True))
     sim.step(4)  # warm-up (page faults, rumors in flight)
     t0 = time.perf_counter()
     done = 0
@@ -40,7 +51,8 @@ def cpu_baseline(fanout, probe_interval, seconds_budget=20.0):
     cores = lib.dll.osim_t_threads()
     sim.close()
     return {"value": n * done / dt, "unit": "member-ticks/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n} nodes x {done} ticks, fan-out {fanout}, same rumor mix, view_slots=64 rings=64 (CPU oracle, OpenMP)"}
+            "sample": f"{n} nodes x {done} ticks, fan-out {fanout}, probe interval {probe_interval}, same operation mix and rate, "
+                      f"view_slots=64 rings=64 (CPU oracle, OpenMP over nodes)"}
 
 
 def main():
@@ -52,7 +64,7 @@ def main():
     ap.add_argument("--fanout", type=int, default=4)
     ap.add_argument("--view-slots", type=int, default=1024)
     ap.add_argument("--ring", type=int, default=512)
-    ap.add_argument("--rate", type=float, default=0.5, help="rumors injected per tick (cluster-wide)")
+    ap.add_argument("--rate", type=float, default=0.4, help="API operations injected per tick (cluster-wide)")
     ap.add_argument("--probe-interval", type=int, default=5, help="memberlist probe interval in ticks (0 = SWIM layer off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -82,7 +94,7 @@ def main():
     kw = dict(fanout=args.fanout, view_slots=args.view_slots, event_ring=args.ring, query_ring=args.ring,
               probe_interval=args.probe_interval)
     total_ticks = args.steps + args.warmup
-    ops = sc.schedule(n_total, total_ticks, rate=args.rate, seed=3, max_member_subjects=args.view_slots // 2)
+    ops = sc.schedule(n_total, total_ticks, rate=args.rate, seed=3, mix=MIX, max_member_subjects=args.view_slots // 2, even=True)
     if world > 1:
         sim = ShardedSim(lib, n_total, dev, **kw)
         step, inject = sim.step, sim.inject
@@ -100,14 +112,30 @@ def main():
 
     step(args.warmup)
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # The launches go to torch's current stream (sim_set_stream above), so torch events bracket them.
+    # N=1: one pair around all K ticks (nothing but tick/ops kernels in between).  N>1: one pair per
+    # tick around sim_step only, so that the all-to-all is not billed to the kernel's roofline.
     t0 = time.perf_counter()
-    ev0.record()
-    step(args.steps)
-    ev1.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
+    if world == 1:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        step(args.steps)
+        ev1.record()
+        barrier()
+        dt = time.perf_counter() - t0
+        ev_ms = ev0.elapsed_time(ev1)
+    else:
+        pairs = []
+        for _ in range(args.steps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            sim.sim.step(1)
+            b.record()
+            dist.all_to_all_single(sim.recv, sim.send, group=sim.group)
+            pairs.append((a, b))
+        barrier()
+        dt = time.perf_counter() - t0
+        ev_ms = sum(a.elapsed_time(b) for a, b in pairs)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -115,12 +143,12 @@ def main():
 
     if rank == 0:
         value = n_total * args.steps / dt
-        bt = b_tick_v0(args.fanout)
+        bt, bt2 = b_tick_v0(args.fanout), b_tick_layout(args.fanout)
         # dominant kernel = tick_kernel: one launch per tick; HIP-event time over the timed region
         kern_s = ev_ms / 1e3 / args.steps
         achieved = args.nodes_per_gpu * bt / kern_s / 1e9
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
@@ -132,15 +160,17 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": f"{n_total} nodes ({args.nodes_per_gpu}/GPU), fan-out {args.fanout}, "
-                                   f"{args.rate} rumors/tick (events/queries/leaves/force-leaves/crashes), "
+                                   f"{args.rate} API ops/tick evenly spaced, mix {MIX} of (user event, query, leave, crash+remove, crash+revive), "
                                    f"view_slots {args.view_slots}, rings {args.ring}, probe interval {args.probe_interval} ticks — BASELINE configs[2]",
                        "parallelism": f"node-id range shards x{world}, 1 all_to_all_single/tick" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "tick_kernel", "kernel_ms": kern_s * 1e3, "b_tick_bytes": bt},
+                         "kernel": "tick_kernel", "kernel_ms": kern_s * 1e3, "b_tick_bytes": bt,
+                         "achieved_revised": args.nodes_per_gpu * bt2 / kern_s / 1e9, "b_tick_layout_bytes": bt2,
+                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch)"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.fanout, args.probe_interval)
+            out["cpu_baseline"] = cpu_baseline(args.fanout, args.probe_interval, args.rate)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

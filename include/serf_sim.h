@@ -36,7 +36,7 @@ extern "C" {
 #define SIM_C 6u  /* keys per de-dup ring bucket (32-byte bucket)                     */
 #define SIM_MAX_FANOUT 4u
 #define SIM_MAX_CONF 4u /* conf[0] = node that started the suspicion, conf[1..3] = confirmers (k <= 3) */
-#define SIM_S 4u        /* suspicion timers a node can track at once                   */
+#define SIM_S 8u        /* suspicion timers a node can track at once (16-bit view slots) */
 #define SIM_MAX_AWARENESS 7u /* memberlist awareness_max_multiplier - 1 (lan: 8)      */
 
 /* error codes (serf-core/src/error.rs:64-81 maps its enum onto these for the bulk path) */
@@ -164,7 +164,8 @@ typedef struct sim_row {
   uint32_t susp_next;                       /* earliest suspicion deadline (tick), 0 = none */
   uint32_t awareness;                       /* memberlist health score                 */
   uint32_t probe_pending;                   /* reserved (0)                            */
-  uint32_t susp[SIM_S];                     /* view slot + 1 of each running suspicion timer, 0 = free */
+  uint16_t susp[SIM_S];                     /* view slot + 1 of each running suspicion timer, 0 = free
+                                             * (the SWIM layer therefore needs view_slots <= 65534)    */
 } sim_row;
 
 #define SIM_RF_UP 1u

@@ -583,7 +583,7 @@ static void susp_track(nctx* c, uint32_t slot, uint32_t deadline) {
   uint32_t j = 0;
   while (j < SIM_S && row->susp[j]) ++j;
   if (j == SIM_S) { row->overflow++; return; } /* model bound: the timer is not tracked (B.5) */
-  row->susp[j] = slot + 1;
+  row->susp[j] = (uint16_t)(slot + 1);
   if (!row->susp_next || deadline < row->susp_next) row->susp_next = deadline;
 }
 /* refute (memberlist state.go `refute`): bump the incarnation past the accusation, gossip alive */
@@ -956,6 +956,10 @@ static int cfg_check(const sim_config* c) {
   if (c->fanout < 1 || c->fanout > SIM_MAX_FANOUT) return SIM_EINVAL;
   if (c->event_ring < 1 || c->query_ring < 1) return SIM_EINVAL;
   if (c->retransmit_mult * digits10(c->n_nodes) > 63u) return SIM_EINVAL;
+  if (c->probe_interval) { /* suspicion timers name view slots with 16 bits */
+    uint32_t A = (c->view_slots == 0 || c->view_slots >= c->n_nodes) ? c->n_nodes : c->view_slots;
+    if (A > 65534u) return SIM_EINVAL;
+  }
   return SIM_OK;
 }
 

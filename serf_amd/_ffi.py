@@ -66,7 +66,7 @@ ROW_DTYPE = np.dtype([("clock", "<u8"), ("event_clock", "<u8"), ("query_clock", 
                       ("event_min", "<u8"), ("query_min", "<u8"), ("flags", "<u4"), ("inc", "<u4"),
                       ("n_known", "<u4"), ("n_failed", "<u4"), ("n_left", "<u4"),
                       ("next_seq", "<u4"), ("overflow", "<u4"), ("susp_next", "<u4"),
-                      ("awareness", "<u4"), ("probe_pending", "<u4"), ("susp", "<u4", (4,))])
+                      ("awareness", "<u4"), ("probe_pending", "<u4"), ("susp", "<u2", (8,))])
 REC_DTYPE = np.dtype([("key", "<u4"), ("meta", "<u4"), ("val", "<u8")])
 VIEW_DTYPE = np.dtype([("ltime", "<u8"), ("inc", "<u4"), ("bits", "<u4"), ("conf", "<u4", (4,))])
 BUCKET_DTYPE = np.dtype([("ltime", "<u8"), ("keys", "<u4", (CKEYS,))])

@@ -149,7 +149,7 @@ struct Dev {
   uint4* R1;  // {query_clock.lo, query_clock.hi, flags, n_known}
   uint4* R2;  // {n_failed, n_left, next_seq | used-slot mask << 16, overflow}
   uint4* R3;  // {incarnation, susp_next, awareness, probe_pending}      (memberlist layer)
-  uint4* R4;  // susp[4]: view slot + 1 of each running suspicion timer   (memberlist layer)
+  uint4* R4;  // susp[8] x u16: view slot + 1 of each running suspicion timer (memberlist layer)
   uint4* R5;  // {event_min.lo, event_min.hi, query_min.lo, query_min.hi} (read when SIM_RF_MINTIME)
   uint4* qkeys;  // [4][Nl]  the 16 sort keys of a node's queue, ascending, 4 per uint4
   uint4* qpay;   // [Q][Nl]  slot-stable wire records {key, wire meta, val.lo, val.hi}
@@ -609,22 +609,20 @@ __device__ static inline void aw_delta(Node& n, int dlt) {
   n.awareness = a < 0 ? 0u : a > (int)SIM_MAX_AWARENESS ? SIM_MAX_AWARENESS : (u32)a;
   n.dirty |= DR3;
 }
+// R4 holds SIM_S = 8 sixteen-bit entries: view slot + 1 of each running suspicion timer (rare paths:
+// plain 2-byte accesses)
+__device__ static inline uint16_t* susp_of(const Ctx& c) { return reinterpret_cast<uint16_t*>(&c.d.R4[c.l]); }
 __device__ static inline void susp_forget(const Ctx& c, u32 slot) {
-  uint4 s = c.d.R4[c.l], t = s;
-  if (t.x == slot + 1) t.x = 0;
-  if (t.y == slot + 1) t.y = 0;
-  if (t.z == slot + 1) t.z = 0;
-  if (t.w == slot + 1) t.w = 0;
-  if (ne4(s, t)) c.d.R4[c.l] = t;
+  uint16_t* sp = susp_of(c);
+  for (u32 j = 0; j < SIM_S; ++j)
+    if (sp[j] == slot + 1) sp[j] = 0;
 }
 __device__ static inline void susp_track(const Ctx& c, Node& n, u32 slot, u32 deadline) {
-  uint4 s = c.d.R4[c.l];
-  if (s.x == 0) s.x = slot + 1;
-  else if (s.y == 0) s.y = slot + 1;
-  else if (s.z == 0) s.z = slot + 1;
-  else if (s.w == 0) s.w = slot + 1;
-  else { n.overflow++; n.dirty |= DR2; return; }  // model bound: the timer is not tracked
-  c.d.R4[c.l] = s;
+  uint16_t* sp = susp_of(c);
+  u32 j = 0;
+  while (j < SIM_S && sp[j]) ++j;
+  if (j == SIM_S) { n.overflow++; n.dirty |= DR2; return; }  // model bound: the timer is not tracked
+  sp[j] = (uint16_t)(slot + 1);
   if (!n.susp_next || deadline < n.susp_next) { n.susp_next = deadline; n.dirty |= DR3; }
 }
 __device__ static void swim_refute(const Ctx& c, Node& n, u32 accused_inc, Ins& ins) {
@@ -729,14 +727,13 @@ __device__ static void swim_dead(const Ctx& c, Node& n, u32 subject, u32 inc, u3
 __device__ static void swim_timer_j(const Ctx& c, Node& n, u32 j, u32& next, Ins& ins) {
   const Dev& d = c.d;
   u32 now = c.tick;
-  uint4 s4 = d.R4[c.l];  // re-read every time: swim_dead's susp_forget rewrites it
-  u32 a = j == 0 ? s4.x : j == 1 ? s4.y : j == 2 ? s4.z : s4.w;
+  uint16_t* sp = susp_of(c);
+  u32 a = sp[j];
   if (!a) return;
   uint4* p = view_slot_ptr(c, a - 1);
   uint4 e = p[0];
   if (SIM_VB_SWIM(e.w) != SIM_SWIM_SUSPECT) {
-    if (j == 0) s4.x = 0; else if (j == 1) s4.y = 0; else if (j == 2) s4.z = 0; else s4.w = 0;
-    d.R4[c.l] = s4;
+    sp[j] = 0;
     return;
   }
   u32 age = (now - SIM_VB_STAMP(e.w)) & STAMP_MASK;
@@ -1396,6 +1393,10 @@ static int cfg_check(const sim_config* c) {
   if (c->fanout < 1 || c->fanout > SIM_MAX_FANOUT) return SIM_EINVAL;
   if (c->event_ring < 1 || c->query_ring < 1) return SIM_EINVAL;
   if (c->retransmit_mult * h_digits10(c->n_nodes) > 63u) return SIM_EINVAL;
+  if (c->probe_interval) {  // suspicion timers name view slots with 16 bits
+    u32 A = (c->view_slots == 0 || c->view_slots >= c->n_nodes) ? c->n_nodes : c->view_slots;
+    if (A > 65534u) return SIM_EINVAL;
+  }
   return SIM_OK;
 }
 // Suspicion parameters in ticks (memberlist suspicion.go / util.go); the same

@@ -4,7 +4,7 @@ import numpy as np
 from serf_amd import _ffi
 
 
-def schedule(n_nodes, n_ticks, rate, seed=1234, mix=(0.5, 0.15, 0.15, 0.1, 0.1), max_member_subjects=None):
+def schedule(n_nodes, n_ticks, rate, seed=1234, mix=(0.5, 0.15, 0.15, 0.1, 0.1), max_member_subjects=None, even=False):
     """Return a list of (tick, op, node, a, b).
 
     mix = fractions of (user event, query, graceful leave, force-leave of a crashed node,
@@ -13,6 +13,8 @@ def schedule(n_nodes, n_ticks, rate, seed=1234, mix=(0.5, 0.15, 0.15, 0.1, 0.1),
     rng = np.random.default_rng(seed)
     n_ops = max(1, int(round(rate * n_ticks)))
     ticks = np.sort(rng.integers(0, n_ticks, n_ops))
+    if even:  # evenly spaced injections: a steady load for benchmarks (the draw above keeps the stream aligned)
+        ticks = (np.arange(n_ops) * (n_ticks / n_ops)).astype(np.int64)
     kinds = rng.choice(5, n_ops, p=np.array(mix) / np.sum(mix))
     used = set()
     ops = []
