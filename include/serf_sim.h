@@ -29,7 +29,7 @@ extern "C" {
 
 /* ------------------------------------------------------------------ constants */
 
-#define SIM_ABI_VERSION 2u
+#define SIM_ABI_VERSION 3u
 
 #define SIM_P 4u  /* piggyback records per gossip packet (64-byte packet)             */
 #define SIM_Q 16u /* retransmit-queue slots per node (all four queues share the pool) */
@@ -163,7 +163,7 @@ typedef struct sim_row {
   uint32_t overflow;                        /* records dropped by the Q bound          */
   uint32_t susp_next;                       /* earliest suspicion deadline (tick), 0 = none */
   uint32_t awareness;                       /* memberlist health score                 */
-  uint32_t probe_pending;                   /* reserved (0)                            */
+  uint32_t reap_next;                       /* earliest tick the Reaper has work for this node, 0 = none */
   uint16_t susp[SIM_S];                     /* view slot + 1 of each running suspicion timer, 0 = free
                                              * (the SWIM layer therefore needs view_slots <= 65534)    */
 } sim_row;
@@ -193,6 +193,12 @@ typedef struct sim_config {
   uint32_t loss_u32;          /* packet loss probability * 2^32 (0 = lossless)                  */
   uint32_t intent_timeout;    /* recent_intent_timeout in ticks (options.rs:515), 0 = never     */
   uint32_t leave_delay;       /* broadcast_timeout + leave_propagate_delay in ticks             */
+  uint32_t reap_interval;     /* Reaper period in ticks (options.rs:506, 15 s), 0 = reaper off  */
+  uint32_t reconnect_timeout; /* failed members are reaped after this many ticks (24 h)         */
+  uint32_t tombstone_timeout; /* left members are reaped after this many ticks (24 h)           */
+  uint32_t queue_check_interval; /* QueueChecker period in ticks (30 s), 0 = off               */
+  uint32_t max_queue_depth;   /* options.rs:513 (4096)                                          */
+  uint32_t min_queue_depth;   /* options.rs:514: > 0 => cap = max(2 * members, min)             */
   uint32_t flags;             /* SIM_CF_*                                                       */
   uint64_t seed;              /* master seed; default 0x5EEDC0DE5E4F0001                        */
 } sim_config;

@@ -356,6 +356,15 @@ static void queue_emit(sim_row* row, sim_record* q, uint32_t limit, sim_packet* 
   qsort(q, SIM_Q, sizeof(sim_record), rec_cmp);
 }
 
+/* Reaper bookkeeping: row->reap_next is the earliest tick at which some entry of this node has
+ * out-lived its timeout (0 = nothing to reap), so that the periodic Reaper (base.rs:483-610) only
+ * walks the view when there is work.  `age` = ticks since the entry's stamp. */
+static void reap_arm(nctx* c, uint32_t age, uint32_t timeout) {
+  if (!c->s->cfg.reap_interval) return;
+  uint32_t due = (uint32_t)c->s->tick - age + timeout + 1u;
+  if (!c->row->reap_next || due < c->row->reap_next) c->row->reap_next = due;
+}
+
 /* ---- intent buffer: base.rs:1820-1866 ---- */
 static int upsert_intent(osim* s, sim_view* e, uint32_t ty, uint64_t ltime) {
   uint32_t stamp = (uint32_t)s->tick & STAMP_MASK;
@@ -401,7 +410,9 @@ static int handle_join_intent(nctx* c, uint32_t subject, uint64_t ltime) {
       e->bits = vb_set_status(e->bits, SIM_STATUS_ALIVE);
     return 1;
   }
-  return upsert_intent(c->s, e, 1, ltime); /* base.rs:1362-1369 */
+  int rb = upsert_intent(c->s, e, 1, ltime); /* base.rs:1362-1369 */
+  if (rb && c->s->cfg.intent_timeout) reap_arm(c, 0, c->s->cfg.intent_timeout);
+  return rb;
 }
 
 /* broadcast_join: base.rs:381-397 */
@@ -421,7 +432,11 @@ static int handle_leave_intent(nctx* c, uint32_t subject, uint64_t ltime, int pr
   lc_witness(&c->row->clock, ltime);            /* base.rs:1446 */
   sim_view* e = view_at(c->s, c->l, subject);
   if (!e) return 0;
-  if (!(e->bits & SIM_VB_KNOWN)) return upsert_intent(c->s, e, 2, ltime); /* base.rs:1450-1458 */
+  if (!(e->bits & SIM_VB_KNOWN)) { /* base.rs:1450-1458 */
+    int rb = upsert_intent(c->s, e, 2, ltime);
+    if (rb && c->s->cfg.intent_timeout) reap_arm(c, 0, c->s->cfg.intent_timeout);
+    return rb;
+  }
   if (ltime <= e->ltime) return 0;                                        /* base.rs:1464 */
   if (subject == c->gid && state == SIM_SERF_ALIVE) {                     /* base.rs:1470-1480 */
     broadcast_join(c, c->row->clock); /* refute with clock.time(); spawned task => same tick */
@@ -442,6 +457,7 @@ static int handle_leave_intent(nctx* c, uint32_t subject, uint64_t ltime, int pr
       e->bits = vb_set_status(e->bits, SIM_STATUS_LEFT);
       if (c->row->n_failed) c->row->n_failed--;
       c->row->n_left++;
+      reap_arm(c, ((uint32_t)c->s->tick - SIM_VB_STAMP(e->bits)) & STAMP_MASK, c->s->cfg.tombstone_timeout);
       emit_event(c, SIM_EV_LEAVE, subject, 0);
       if (prune) handle_prune(c, e, subject);
       return 1;
@@ -482,11 +498,13 @@ static void handle_node_leave(nctx* c, uint32_t subject) {
     case SIM_STATUS_LEAVING: /* base.rs:1384-1393 */
       e->bits = vb_set_stamp(vb_set_status(e->bits, SIM_STATUS_LEFT), stamp);
       c->row->n_left++;
+      reap_arm(c, 0, c->s->cfg.tombstone_timeout);
       emit_event(c, SIM_EV_LEAVE, subject, 0);
       break;
     case SIM_STATUS_ALIVE: /* base.rs:1394-1402 */
       e->bits = vb_set_stamp(vb_set_status(e->bits, SIM_STATUS_FAILED), stamp);
       c->row->n_failed++;
+      reap_arm(c, 0, c->s->cfg.reconnect_timeout);
       emit_event(c, SIM_EV_FAILED, subject, 0);
       break;
     default: return; /* base.rs:1403-1406 */
@@ -733,6 +751,59 @@ static void swim_probe(nctx* c, const tickp* p) {
   swim_suspect(c, t, e->inc, c->gid, wire_meta(SIM_K_SUSPECT, 0, 32));
 }
 
+/* Reaper::run (base.rs:483-610, reap! 521-553, reap_intents 1820-1822), every reap_interval ticks
+ * (phase shared by a 64-node group, like the probe): failed members older than reconnect_timeout
+ * and left members older than tombstone_timeout are erased (Reap event), buffered intents older
+ * than recent_intent_timeout are forgotten. */
+static void reap_run(nctx* c) {
+  osim* s = c->s;
+  sim_row* row = c->row;
+  uint32_t now = (uint32_t)s->tick, RI = s->cfg.reap_interval;
+  if (!RI || (now + (c->gid >> 6)) % RI) return;
+  if (!row->reap_next || now < row->reap_next) return;
+  uint32_t next = 0;
+  for (uint32_t a = 0; a < s->n_slots; ++a) {
+    sim_view* e = &s->view[(size_t)a * s->Nl + c->l];
+    uint32_t age = (now - SIM_VB_STAMP(e->bits)) & STAMP_MASK, timeout;
+    if (e->bits & SIM_VB_KNOWN) {
+      uint32_t st = SIM_VB_STATUS(e->bits);
+      if (st == SIM_STATUS_FAILED) timeout = s->cfg.reconnect_timeout;
+      else if (st == SIM_STATUS_LEFT) timeout = s->cfg.tombstone_timeout;
+      else continue;
+      if (age > timeout) { erase_member(c, e, s->subject_of[a]); continue; }
+    } else if (SIM_VB_INTENT(e->bits) && s->cfg.intent_timeout) {
+      timeout = s->cfg.intent_timeout;
+      if (age > timeout) { memset(e, 0, sizeof *e); continue; }
+    } else {
+      continue;
+    }
+    uint32_t due = now - age + timeout + 1u;
+    if (!next || due < next) next = due;
+  }
+  row->reap_next = next;
+}
+/* QueueChecker (base.rs:683-740), every queue_check_interval ticks, for each of serf's three queues
+ * (classes 1-3 of the pooled queue): `if numq >= max { prune(max) }`, max = max_queue_depth or, when
+ * min_queue_depth > 0, max(2 * members, min_queue_depth).  prune drops the entries that drain last. */
+static void queue_check(nctx* c) {
+  osim* s = c->s;
+  uint32_t QI = s->cfg.queue_check_interval;
+  if (!QI || ((uint32_t)s->tick + (c->gid >> 6)) % QI) return;
+  uint32_t max = s->cfg.max_queue_depth;
+  if (s->cfg.min_queue_depth > 0) {
+    max = 2u * c->row->n_known;
+    if (max < s->cfg.min_queue_depth) max = s->cfg.min_queue_depth;
+  }
+  int changed = 0;
+  for (uint32_t cls = 1; cls <= 3; ++cls) {
+    uint32_t cnt = 0;
+    for (uint32_t i = 0; i < SIM_Q; ++i) cnt += c->q[i].meta != SIM_META_EMPTY && (c->q[i].meta >> 30) == cls;
+    for (uint32_t i = SIM_Q; i-- > 0 && cnt > max;)
+      if (c->q[i].meta != SIM_META_EMPTY && (c->q[i].meta >> 30) == cls) { rec_clear(&c->q[i]); --cnt; changed = 1; }
+  }
+  if (changed) qsort(c->q, SIM_Q, sizeof(sim_record), rec_cmp);
+}
+
 /* SerfDelegate::notify_message dispatch: delegate.rs:183-300 */
 static void dispatch_record(nctx* c, const sim_record* r) {
   uint32_t kind = SIM_META_KIND(r->meta), flags = SIM_META_FLAGS(r->meta);
@@ -878,6 +949,8 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
       swim_timers(&c);
       swim_probe(&c, p);
     }
+    reap_run(&c);
+    queue_check(&c);
     uint32_t limit = s->cfg.retransmit_mult * digits10(row->n_known); /* B.1, serf.rs:123-131 */
     for (uint32_t k = 0; k < p->feff; ++k) queue_emit(row, q, limit, &out[k]);
   }

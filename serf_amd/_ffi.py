@@ -44,7 +44,8 @@ class Config(C.Structure):
         "struct_size", "n_nodes", "vshards", "shard_rank", "shard_count", "fanout", "view_slots",
         "event_ring", "query_ring", "retransmit_mult", "probe_interval", "suspicion_mult",
         "suspicion_max_mult", "indirect_checks", "loss_u32", "intent_timeout", "leave_delay",
-        "flags")] + [("seed", C.c_uint64)]
+        "reap_interval", "reconnect_timeout", "tombstone_timeout", "queue_check_interval", "max_queue_depth",
+        "min_queue_depth", "flags")] + [("seed", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -66,7 +67,7 @@ ROW_DTYPE = np.dtype([("clock", "<u8"), ("event_clock", "<u8"), ("query_clock", 
                       ("event_min", "<u8"), ("query_min", "<u8"), ("flags", "<u4"), ("inc", "<u4"),
                       ("n_known", "<u4"), ("n_failed", "<u4"), ("n_left", "<u4"),
                       ("next_seq", "<u4"), ("overflow", "<u4"), ("susp_next", "<u4"),
-                      ("awareness", "<u4"), ("probe_pending", "<u4"), ("susp", "<u2", (8,))])
+                      ("awareness", "<u4"), ("reap_next", "<u4"), ("susp", "<u2", (8,))])
 REC_DTYPE = np.dtype([("key", "<u4"), ("meta", "<u4"), ("val", "<u8")])
 VIEW_DTYPE = np.dtype([("ltime", "<u8"), ("inc", "<u4"), ("bits", "<u4"), ("conf", "<u4", (4,))])
 BUCKET_DTYPE = np.dtype([("ltime", "<u8"), ("keys", "<u4", (CKEYS,))])
@@ -83,7 +84,9 @@ ABI_SYMBOLS = ("create", "destroy", "set_stream", "join", "leave", "force_leave"
 def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, view_slots=0,
                 event_ring=512, query_ring=512, retransmit_mult=4, probe_interval=0,
                 suspicion_mult=4, suspicion_max_mult=6, indirect_checks=3, loss=0.0,
-                intent_timeout=0, leave_delay=30, flags=CF_BASELINE_JOINED, seed=DEFAULT_SEED):
+                intent_timeout=0, leave_delay=30, reap_interval=0, reconnect_timeout=432000, tombstone_timeout=432000,
+                queue_check_interval=0, max_queue_depth=4096, min_queue_depth=0,
+                flags=CF_BASELINE_JOINED, seed=DEFAULT_SEED):
     cfg = Config()
     cfg.struct_size = C.sizeof(Config)
     cfg.n_nodes, cfg.vshards, cfg.shard_rank, cfg.shard_count = n_nodes, vshards, shard_rank, shard_count
@@ -92,6 +95,8 @@ def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, vi
     cfg.suspicion_mult, cfg.suspicion_max_mult, cfg.indirect_checks = suspicion_mult, suspicion_max_mult, indirect_checks
     cfg.loss_u32 = min(0xFFFFFFFF, int(round(loss * 2 ** 32)))
     cfg.intent_timeout, cfg.leave_delay, cfg.flags, cfg.seed = intent_timeout, leave_delay, flags, seed
+    cfg.reap_interval, cfg.reconnect_timeout, cfg.tombstone_timeout = reap_interval, reconnect_timeout, tombstone_timeout
+    cfg.queue_check_interval, cfg.max_queue_depth, cfg.min_queue_depth = queue_check_interval, max_queue_depth, min_queue_depth
     return cfg
 
 

@@ -63,6 +63,7 @@ struct TickP {  // per-tick parameters, passed by value (lands in SGPRs)
   u64 tick;
   u64 loss_base, probe_base;
   u32 M, mask, shift, feff, V, blk, loss_u32, first;  // first: tick 0 has no inbox yet
+  u32 n_slots;  // view slots allocated so far (the Reaper walks them)
   u32 mul[3], add[3], imul[3];
   u32 off[SIM_MAX_FANOUT], rot[SIM_MAX_FANOUT];
   u32 prot[SIM_MAX_FANOUT];  // rot[] of the previous tick (sharded reads)
@@ -148,7 +149,7 @@ struct Dev {
   uint4* R0;  // {clock.lo, clock.hi, event_clock.lo, event_clock.hi}
   uint4* R1;  // {query_clock.lo, query_clock.hi, flags, n_known}
   uint4* R2;  // {n_failed, n_left, next_seq | used-slot mask << 16, overflow}
-  uint4* R3;  // {incarnation, susp_next, awareness, probe_pending}      (memberlist layer)
+  uint4* R3;  // {incarnation, susp_next, awareness, reap_next}          (memberlist layer / Reaper)
   uint4* R4;  // susp[8] x u16: view slot + 1 of each running suspicion timer (memberlist layer)
   uint4* R5;  // {event_min.lo, event_min.hi, query_min.lo, query_min.hi} (read when SIM_RF_MINTIME)
   uint4* qkeys;  // [4][Nl]  the 16 sort keys of a node's queue, ascending, 4 per uint4
@@ -169,6 +170,9 @@ struct Dev {
   u32 N, Nl, M, V, A, Bev, Bq, f, shard0, shard_rank, sharded, retransmit_mult;
   u32 bev_mask, bq_mask;  // B - 1 when B is a power of two (> 1), else 0
   u32 swim, PI, kconf, ic, T[SIM_MAX_CONF];
+  u32 r3on;  // R3 is live: SWIM layer or Reaper configured
+  u32 reap_interval, reconnect_timeout, tombstone_timeout, intent_timeout;
+  u32 queue_check_interval, max_queue_depth, min_queue_depth;
 };
 
 __device__ static inline u32 digits10(u32 n) {
@@ -185,7 +189,7 @@ __device__ static inline u32 digits10(u32 n) {
 struct Node {  // one node's state in registers
   u64 clock, eclock, qclock;
   u32 flags, nknown, nfailed, nleft, next_seq, used, overflow;
-  u32 inc, susp_next, awareness, ppend;
+  u32 inc, susp_next, awareness, reap_next;
   u32 dirty;  // DR* bits: row groups that must be written back
   u32 npend;  // broadcasts parked in d.pend[] by this tick's handlers, queued once they are all done
 };
@@ -230,13 +234,13 @@ __device__ static inline uint4 ld4(const uint4* p) {
 __device__ static inline void node_load(const Dev& d, u32 l, Node& n) {
   uint4 r0 = d.R0[l], r1 = d.R1[l], r2 = d.R2[l];
   uint4 r3 = make_uint4(0, 0, 0, 0);
-  if (d.swim) r3 = ld4(&d.R3[l]);
+  if (d.r3on) r3 = ld4(&d.R3[l]);
   n.clock = (u64)r0.x | ((u64)r0.y << 32);
   n.eclock = (u64)r0.z | ((u64)r0.w << 32);
   n.qclock = (u64)r1.x | ((u64)r1.y << 32);
   n.flags = r1.z; n.nknown = r1.w;
   n.nfailed = r2.x; n.nleft = r2.y; n.next_seq = r2.z & 0xFFFFu; n.used = r2.z >> 16; n.overflow = r2.w;
-  n.inc = r3.x; n.susp_next = r3.y; n.awareness = r3.z; n.ppend = r3.w;
+  n.inc = r3.x; n.susp_next = r3.y; n.awareness = r3.z; n.reap_next = r3.w;
   n.dirty = 0;
   n.npend = 0;
 }
@@ -261,7 +265,7 @@ __device__ static inline void node_store(const Dev& d, u32 l, const Node& n) {
   if (n.dirty & DR0) d.R0[l] = make_uint4((u32)n.clock, (u32)(n.clock >> 32), (u32)n.eclock, (u32)(n.eclock >> 32));
   if (n.dirty & DR1) d.R1[l] = make_uint4((u32)n.qclock, (u32)(n.qclock >> 32), n.flags, n.nknown);
   if (n.dirty & DR2) d.R2[l] = make_uint4(n.nfailed, n.nleft, (n.next_seq & 0xFFFFu) | (n.used << 16), n.overflow);
-  if (n.dirty & DR3) d.R3[l] = make_uint4(n.inc, n.susp_next, n.awareness, n.ppend);
+  if (n.dirty & DR3) d.R3[l] = make_uint4(n.inc, n.susp_next, n.awareness, n.reap_next);
 }
 
 // ---- TransmitLimitedQueue on sort keys ----------------------------------------------------------
@@ -426,6 +430,12 @@ __device__ static inline void emit_event(const Ctx& c, const Node& n, u32 type, 
 __device__ static inline void witness(Node& n, u64& c, u64 t, u32 group) {  // types/clock.rs:155-172
   if (t >= c) { c = t + 1; n.dirty |= group; }
 }
+// Reaper bookkeeping (see reap_run): earliest tick at which an entry of this node out-lives its timeout
+__device__ static inline void reap_arm(const Ctx& c, Node& n, u32 age, u32 timeout) {
+  if (!c.d.reap_interval) return;
+  u32 due = c.tick - age + timeout + 1u;
+  if (!n.reap_next || due < n.reap_next) { n.reap_next = due; n.dirty |= DR3; }
+}
 // upsert_intent: base.rs:1835-1866
 __device__ static inline bool upsert_intent(uint4& e, u32 ty, u64 ltime, u32 stamp) {
   if (SIM_VB_INTENT(e.w)) {
@@ -464,7 +474,11 @@ __device__ static bool handle_join_intent(const Ctx& c, Node& n, u32 subject, u6
     return true;
   }
   bool rb = upsert_intent(e, 1, ltime, c.tick & STAMP_MASK);
-  if (rb) { p[0] = e; dirty = true; }
+  if (rb) {
+    p[0] = e;
+    dirty = true;
+    if (c.d.intent_timeout) reap_arm(c, n, 0, c.d.intent_timeout);
+  }
   return rb;
 }
 // broadcast_join: base.rs:381-397
@@ -482,7 +496,11 @@ __device__ static bool handle_leave_intent(const Ctx& c, Node& n, u32 subject, u
   if (!p) return false;
   if (!(e.w & SIM_VB_KNOWN)) {
     bool rb = upsert_intent(e, 2, ltime, c.tick & STAMP_MASK);
-    if (rb) { p[0] = e; dirty = true; }
+    if (rb) {
+      p[0] = e;
+      dirty = true;
+      if (c.d.intent_timeout) reap_arm(c, n, 0, c.d.intent_timeout);
+    }
     return rb;
   }
   if (ltime <= E_LTIME(e)) return false;
@@ -503,6 +521,7 @@ __device__ static bool handle_leave_intent(const Ctx& c, Node& n, u32 subject, u
     if (n.nfailed) n.nfailed--;
     n.nleft++;
     n.dirty |= DR2;
+    reap_arm(c, n, (c.tick - SIM_VB_STAMP(e.w)) & STAMP_MASK, c.d.tombstone_timeout);
     emit_event(c, n, SIM_EV_LEAVE, subject, 0);
   } else {
     e.w = vb_set_status(e.w, SIM_STATUS_LEAVING);
@@ -540,11 +559,13 @@ __device__ static void node_leave_e(const Ctx& c, Node& n, uint4& e, u32 subject
     e.w = vb_set_stamp(vb_set_status(e.w, SIM_STATUS_LEFT), stamp);
     n.nleft++;
     n.dirty |= DR2;
+    reap_arm(c, n, 0, c.d.tombstone_timeout);
     emit_event(c, n, SIM_EV_LEAVE, subject, 0);
   } else if (st == SIM_STATUS_ALIVE) {
     e.w = vb_set_stamp(vb_set_status(e.w, SIM_STATUS_FAILED), stamp);
     n.nfailed++;
     n.dirty |= DR2;
+    reap_arm(c, n, 0, c.d.reconnect_timeout);
     emit_event(c, n, SIM_EV_FAILED, subject, 0);
   }
 }
@@ -805,6 +826,72 @@ __device__ static inline u32 slot_load(const Dev& d, u32 kind, u32 key) {
   if (member_kind(kind) && key < d.N) s = d.slot_of[key];
   return s;
 }
+// Reaper::run (base.rs:483-610; reap! 521-553; reap_intents 1820-1822) — see oracle reap_run
+__device__ static void reap_run(const Ctx& c, Node& n, u32 n_slots) {
+  const Dev& d = c.d;
+  u32 now = c.tick, next = 0;
+#pragma unroll 1
+  for (u32 a = 0; a < n_slots; ++a) {
+    uint4* p = view_slot_ptr(c, a);
+    uint4 e = p[0];
+    u32 age = (now - SIM_VB_STAMP(e.w)) & STAMP_MASK, timeout;
+    if (e.w & SIM_VB_KNOWN) {
+      u32 st = SIM_VB_STATUS(e.w);
+      if (st == SIM_STATUS_FAILED) timeout = d.reconnect_timeout;
+      else if (st == SIM_STATUS_LEFT) timeout = d.tombstone_timeout;
+      else continue;
+      if (age > timeout) { erase_member(c, n, p, e, d.subject_of[a]); continue; }
+    } else if (SIM_VB_INTENT(e.w) && d.intent_timeout) {
+      timeout = d.intent_timeout;
+      if (age > timeout) { p[0] = make_uint4(0, 0, 0, 0); p[1] = make_uint4(0, 0, 0, 0); continue; }
+    } else {
+      continue;
+    }
+    u32 due = now - age + timeout + 1u;
+    if (!next || due < next) next = due;
+  }
+  n.reap_next = next;
+  n.dirty |= DR3;
+}
+// QueueChecker (base.rs:683-740) — see oracle queue_check.  The entries of a class are contiguous
+// in the sorted key array; the ones that drain last go.
+__device__ static void queue_check(const Ctx& c, Node& n, SK sk) {
+  const Dev& d = c.d;
+  u32 mx = d.max_queue_depth;
+  if (d.min_queue_depth > 0) mx = max(2u * n.nknown, d.min_queue_depth);
+  bool changed = false;
+#pragma unroll 1
+  for (u32 cls = 1; cls <= 3; ++cls) {
+    u32 cnt = 0;
+#pragma unroll
+    for (int i = 0; i < (int)SIM_Q; ++i) cnt += (sk[i] != KEMPTY && (sk[i] >> 26) == cls) ? 1u : 0u;
+#pragma unroll
+    for (int i = SIM_Q - 1; i >= 0; --i) {
+      bool drop = cnt > mx && sk[i] != KEMPTY && (sk[i] >> 26) == cls;
+      if (drop) { n.used &= ~(1u << (sk[i] & 15u)); sk[i] = KEMPTY; --cnt; changed = true; }
+    }
+  }
+  if (__any(changed)) {  // re-sort (bitonic sort network on 16 keys)
+    n.dirty |= changed ? DR2 : 0u;
+#pragma unroll
+    for (int k = 2; k <= (int)SIM_Q; k <<= 1) {
+#pragma unroll
+      for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+        for (int i = 0; i < (int)SIM_Q; ++i) {
+          int l = i ^ j;
+          if (l > i) {
+            bool up = (i & k) == 0;
+            u32 lo = min(sk[i], sk[l]), hi = max(sk[i], sk[l]);
+            sk[i] = up ? lo : hi;
+            sk[l] = up ? hi : lo;
+          }
+        }
+      }
+    }
+  }
+}
+
 // Fast classification of one record against the prefetched head `e` of the state it is checked
 // against (null-ness of the lookup in `has`).  Returns true when the handler would change nothing
 // but the Lamport clock it witnesses — a duplicate, an old message, a subject without a view slot —
@@ -876,7 +963,7 @@ __device__ unsigned long long g_tt[16];
 #define TT(i)
 #endif
 template <bool SHARDED, int F>
-__global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, const uint4* base) {
+__global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur, const uint4* base) {
 #ifdef TICK_TIMING
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -995,6 +1082,10 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
       }
     }
   }
+  if (up && d.reap_interval) {  // Reaper: wave-uniform phase, per-lane due check
+    bool due = ((u32)tp.tick + (gid >> 6)) % d.reap_interval == 0 && n.reap_next && (u32)tp.tick >= n.reap_next;
+    if (due) reap_run(c, n, tp.n_slots);
+  }
   TT(6);
   // ---- phase 2: queue.  Load the sort keys, queue what phase 1 parked, drain `fanout` packets.
   u32 sk[SIM_Q];
@@ -1007,6 +1098,7 @@ __global__ __launch_bounds__(BLOCK) void tick_kernel(Dev d, TickP tp, u32 cur, c
       uint4 q = ld4(&d.pend[(size_t)i * d.Nl + l]);
       q_insert(c, n, sk, q.x, q.y, (u64)q.z | ((u64)q.w << 32));
     }
+    if (d.queue_check_interval && ((u32)tp.tick + (gid >> 6)) % d.queue_check_interval == 0) queue_check(c, n, sk);
   }
   TT(7);
   u32 limit = up ? d.retransmit_mult * digits10(n.nknown) : 0;
@@ -1208,7 +1300,7 @@ __device__ static inline void canon_row(const Dev& d, size_t l, u64 (&w)[12]) {
   w[6] = (u64)r1.w | ((u64)r2.x << 32);              // n_known, n_failed
   w[7] = (u64)r2.y | ((u64)(r2.z & 0xFFFFu) << 32);  // n_left, next_seq
   w[8] = (u64)r2.w | ((u64)r3.y << 32);              // overflow, susp_next
-  w[9] = (u64)r3.z | ((u64)r3.w << 32);              // awareness, probe_pending
+  w[9] = (u64)r3.z | ((u64)r3.w << 32);              // awareness, reap_next
   w[10] = (u64)r4.x | ((u64)r4.y << 32);
   w[11] = (u64)r4.z | ((u64)r4.w << 32);
 }
@@ -1488,6 +1580,11 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   swim_params(cfg, &d.swim, &d.kconf, d.T);
   d.PI = cfg->probe_interval;
   d.ic = cfg->indirect_checks;
+  d.reap_interval = cfg->reap_interval; d.reconnect_timeout = cfg->reconnect_timeout;
+  d.tombstone_timeout = cfg->tombstone_timeout; d.intent_timeout = cfg->intent_timeout;
+  d.queue_check_interval = cfg->queue_check_interval; d.max_queue_depth = cfg->max_queue_depth;
+  d.min_queue_depth = cfg->min_queue_depth;
+  d.r3on = d.swim || d.reap_interval;
   d.ev_cap = EV_CAP;
   size_t Nl = d.Nl, nup = ((size_t)d.N + 31) / 32;
 #define DA(ptr, n)                                   \
@@ -1626,6 +1723,7 @@ int sim_step(sim_handle* h, uint32_t n_ticks) {
     TickP tp;
     tickp_make(&tp, &h->cfg, h->tick);
     for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) tp.prot[k] = h->prev.rot[k];
+    tp.n_slots = h->n_slots;
     while (h->op_cursor < h->ops.size() && h->ops[h->op_cursor].tick <= h->tick) {
       OpBatch ob;
       memset(&ob, 0, sizeof ob);

@@ -52,6 +52,9 @@ struct Options {
     c.suspicion_mult = 4; c.suspicion_max_mult = 6; c.indirect_checks = 3;
     c.loss_u32 = 0; c.intent_timeout = 0;
     c.leave_delay = 30;                            // broadcast_timeout 5 s + leave_propagate_delay 1 s
+    c.reap_interval = 75;                          // options.rs:506 reap_interval 15 s
+    c.reconnect_timeout = c.tombstone_timeout = 432000;  // 24 h (options.rs:507-508)
+    c.queue_check_interval = 150; c.max_queue_depth = 4096; c.min_queue_depth = 0;  // options.rs:512-514
     c.flags = SIM_CF_BASELINE_JOINED;
     c.seed = SIM_DEFAULT_SEED;
   }

@@ -295,3 +295,47 @@ def test_packet_loss_causes_refuted_false_suspicions(oracle):
     assert rows["awareness"].max() >= 1
     v = sim.dump(_ffi.ARR_VIEW).reshape(n, n)
     assert (v["inc"].max(axis=1) <= rows["inc"]).all(), "nobody knows a higher incarnation than the owner's"
+
+
+def test_failed_member_is_reaped(oracle):
+    # event.rs:88-130 (serf_events_failed): Join, Failed, Reap — the Reaper (base.rs:483-610) erases a
+    # failed member reconnect_timeout after it failed, on its next reap_interval boundary
+    n, victim = 64, 20
+    sim, _ = cluster(oracle, n, fanout=3, reap_interval=10, reconnect_timeout=30, tombstone_timeout=30)
+    k, T = params(oracle, sim)
+    sim.watch(5)
+    sim.inject(1, _ffi.OP_CRASH, victim)
+    t_failed = run_until(sim, lambda: statuses_of(sim, victim, (5,)) == [FAILED], 8 * T[0])
+    assert t_failed is not None
+    assert sim.stats(5).members == n and sim.stats(5).failed == 1
+    assert sim.dump(_ffi.ARR_ROWS)[5]["reap_next"] > 0
+    sim.step(30 + 2 * 10 + 2)
+    assert statuses_of(sim, victim, (5, 6, 40)) == [NONE] * 3
+    st = sim.stats(5)
+    assert (st.members, st.failed) == (n - 1, 0)
+    assert [e[2] for e in sim.drain_events() if e[3] == victim] == [EV_FAILED, 4]   # Failed, then Reap
+    assert sim.dump(_ffi.ARR_ROWS)[5]["reap_next"] == 0
+
+
+def test_left_member_outlives_failed_one_with_longer_tombstone(oracle):
+    # reap.rs:41-129: tombstone_timeout governs left members, reconnect_timeout failed ones
+    n = 64
+    sim, _ = cluster(oracle, n, fanout=3, leave_delay=4, reap_interval=5, reconnect_timeout=10, tombstone_timeout=400)
+    sim.step(1)
+    sim.leave(9)
+    sim.inject(2, _ffi.OP_CRASH, 30)
+    sim.step(300)
+    st, _lt = sim.members(0)
+    assert st[9] == LEFT          # still inside its tombstone
+    assert st[30] == NONE         # failed and already reaped
+    assert (sim.stats(0).left, sim.stats(0).failed, sim.stats(0).members) == (1, 0, n - 1)
+
+
+def test_queue_checker_prunes_to_dynamic_cap(oracle):
+    # base.rs:683-740 / serf.rs tests 57-160: with min_queue_depth > 0 the cap is max(2 * members, min)
+    sim, s1 = cluster(oracle, 3, probe_interval=0, flags=0, queue_check_interval=4, min_queue_depth=1, event_ring=64)
+    for key in range(1, 13):
+        s1.user_event(key, key)          # 12 events queued on node 0 (it knows only itself: cap = max(2, 1) = 2)
+    assert sim.stats(0).event_queue == 12
+    sim.step(4)                          # a queue-check tick for group 0 falls inside
+    assert sim.stats(0).event_queue <= 2

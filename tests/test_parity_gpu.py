@@ -16,7 +16,7 @@ def pair(oracle, hiplib, n, **kw):
 
 def test_backend_is_hip(hiplib):
     assert hiplib.backend_name() == "hip-gfx950"
-    assert hiplib.abi_version() == 2
+    assert hiplib.abi_version() == 3
 
 
 @pytest.mark.parametrize("swim", [0, 5, 2])
@@ -25,7 +25,9 @@ def test_full_state_every_tick_small(oracle, hiplib, n, fanout, dense, swim):
     # config 1 shape (128 nodes, fan-out 3) and ragged sizes; every array compared after every tick;
     # swim = probe interval in ticks (0: serf layer only)
     kw = dict(fanout=fanout, view_slots=0 if dense else 64, event_ring=16, query_ring=8, leave_delay=6,
-              probe_interval=swim, suspicion_mult=3 if swim == 2 else 4, suspicion_max_mult=2 if swim == 2 else 6)
+              probe_interval=swim, suspicion_mult=3 if swim == 2 else 4, suspicion_max_mult=2 if swim == 2 else 6,
+              reap_interval=7 if swim else 0, reconnect_timeout=25, tombstone_timeout=40, intent_timeout=20,
+              queue_check_interval=9 if swim == 2 else 0, min_queue_depth=3 if swim == 2 else 0)
     g, o = pair(oracle, hiplib, n, **kw)
     ops = sc.schedule(n, 60, rate=0.6, seed=n * 7 + fanout, max_member_subjects=min(n // 2, 40))
     sc.apply_schedule(g, ops)
@@ -60,7 +62,8 @@ def test_swim_crash_refute_leave_events(oracle, hiplib):
     # refuting, graceful leaves, packet loss causing false suspicions; watched observers' event logs
     n = 256
     kw = dict(fanout=3, view_slots=0, event_ring=16, query_ring=8, leave_delay=5, probe_interval=3,
-              suspicion_mult=4, suspicion_max_mult=3, indirect_checks=1, loss=0.2)
+              suspicion_mult=4, suspicion_max_mult=3, indirect_checks=1, loss=0.2,
+              reap_interval=10, reconnect_timeout=60, tombstone_timeout=80)
     g, o = pair(oracle, hiplib, n, **kw)
     for s in (g, o):
         for w in (0, 7, 200):
