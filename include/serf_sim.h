@@ -29,7 +29,7 @@ extern "C" {
 
 /* ------------------------------------------------------------------ constants */
 
-#define SIM_ABI_VERSION 3u
+#define SIM_ABI_VERSION 4u
 
 #define SIM_P 4u  /* piggyback records per gossip packet (64-byte packet)             */
 #define SIM_Q 16u /* retransmit-queue slots per node (all four queues share the pool) */
@@ -199,6 +199,9 @@ typedef struct sim_config {
   uint32_t queue_check_interval; /* QueueChecker period in ticks (30 s), 0 = off               */
   uint32_t max_queue_depth;   /* options.rs:513 (4096)                                          */
   uint32_t min_queue_depth;   /* options.rs:514: > 0 => cap = max(2 * members, min)             */
+  uint32_t push_pull_interval;/* memberlist push_pull_interval in ticks (lan: 30 s = 150), before its
+                               * log2(N) scaling; 0 = no anti-entropy                             */
+  uint32_t reserved0;         /* keeps `seed` 8-byte aligned                                    */
   uint32_t flags;             /* SIM_CF_*                                                       */
   uint64_t seed;              /* master seed; default 0x5EEDC0DE5E4F0001                        */
 } sim_config;

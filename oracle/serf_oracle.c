@@ -212,6 +212,7 @@ struct sim_handle {
   uint32_t k_conf;      /* confirmations that shrink a suspicion timer (B.5) */
   uint32_t T[SIM_MAX_CONF]; /* timeout in ticks after c confirmations */
   const tickp* tp;      /* parameters of the tick being executed */
+  uint32_t pp_step, pp_groups; /* push-pull batches: every pp_step ticks one of pp_groups pair classes syncs */
 };
 typedef struct sim_handle osim;
 
@@ -915,6 +916,86 @@ static void apply_op(osim* s, const sim_opent* op) {
 }
 
 /* =====================================================================================
+ * Push-pull anti-entropy (memberlist pushPull, App. B.6; serf side: SerfDelegate::local_state
+ * delegate.rs:386-425 and merge_remote_state delegate.rs:427-554).
+ *
+ * Tick model (DESIGN.md SIMSPEC §2.10): the interval is push_pull_interval scaled by memberlist's
+ * pushPullScale (x (ceil(log2 N - 5) + 1) above 32 nodes).  Peers are this tick's perfect matching
+ * {sigma^-1(2p), sigma^-1(2p+1)} of the in-shard index space; the pairs are split into PP_GROUPS
+ * classes (p mod PP_GROUPS) and every interval/PP_GROUPS ticks one class synchronises, so each node
+ * takes part once per interval on average.  Both processes must be running.  The node with the
+ * even sigma value merges the other's state first, then the other merges its (updated) state.
+ * ===================================================================================== */
+#define PP_GROUPS 8u
+static void pp_params(const sim_config* c, uint32_t* step, uint32_t* groups) {
+  *step = 0;
+  *groups = PP_GROUPS;
+  if (!c->push_pull_interval) return;
+  uint64_t mult = 1;
+  if (c->n_nodes > 32) mult = (uint64_t)ceil(log2((double)c->n_nodes) - 5.0) + 1; /* pushPullScale */
+  uint64_t iv = (uint64_t)c->push_pull_interval * mult;
+  uint64_t st = iv / PP_GROUPS;
+  *step = st < 1 ? 1u : st > 0x7FFFFFFFu ? 0x7FFFFFFFu : (uint32_t)st;
+}
+/* local <- remote: memberlist mergeState, then SerfDelegate::merge_remote_state(is_join = false) */
+static void pp_merge(osim* s, uint32_t ll, uint32_t lr) {
+  nctx c;
+  nctx_init(&c, s, ll);
+  const sim_row* rr = &s->rows[lr];
+  /* queue ids: renumber whenever fewer than 64 are left, before anything can be queued (a merge can
+   * queue one broadcast per view slot) */
+#define PP_GUARD() do { if (c.row->next_seq > 1023u - 64u) queue_renorm(c.row, c.q); } while (0)
+  PP_GUARD();
+  if (s->swim) { /* mergeState (B.6): alive as alive, left as dead{from = node}, suspect and dead as suspect */
+    for (uint32_t a = 0; a < s->n_slots; ++a) {
+      const sim_view* re = &s->view[(size_t)a * s->Nl + lr];
+      if (!(re->bits & SIM_VB_KNOWN)) continue;
+      PP_GUARD();
+      uint32_t subj = s->subject_of[a], sw = SIM_VB_SWIM(re->bits), inc = re->inc;
+      if (sw == SIM_SWIM_ALIVE) swim_alive(&c, subj, inc, wire_meta(SIM_K_ALIVE, 0, 64));
+      else if (sw == SIM_SWIM_LEFT) swim_dead(&c, subj, inc, subj, wire_meta(SIM_K_DEAD, 0, 32));
+      else swim_suspect(&c, subj, inc, c.gid, wire_meta(SIM_K_SUSPECT, 0, 32));
+    }
+  }
+  if (rr->clock > 0) lc_witness(&c.row->clock, rr->clock - 1);                   /* delegate.rs:466-468 */
+  if (rr->event_clock > 0) lc_witness(&c.row->event_clock, rr->event_clock - 1); /* delegate.rs:469-474 */
+  if (rr->query_clock > 0) lc_witness(&c.row->query_clock, rr->query_clock - 1); /* delegate.rs:475-480 */
+  for (uint32_t a = 0; a < s->n_slots; ++a) { /* left members first, at status_ltime + 1: delegate.rs:495-512 */
+    const sim_view* re = &s->view[(size_t)a * s->Nl + lr];
+    if ((re->bits & SIM_VB_KNOWN) && SIM_VB_STATUS(re->bits) == SIM_STATUS_LEFT) {
+      PP_GUARD();
+      handle_leave_intent(&c, s->subject_of[a], re->ltime + 1, 0);
+    }
+  }
+  for (uint32_t a = 0; a < s->n_slots; ++a) { /* every other status_ltime as a join intent: delegate.rs:515-526 */
+    const sim_view* re = &s->view[(size_t)a * s->Nl + lr];
+    if ((re->bits & SIM_VB_KNOWN) && SIM_VB_STATUS(re->bits) != SIM_STATUS_LEFT)
+      handle_join_intent(&c, s->subject_of[a], re->ltime);
+  }
+  for (uint32_t idx = 0; idx < s->Bev; ++idx) { /* replay the remote event buffer: delegate.rs:540-552 */
+    const sim_bucket* rb = &s->ering[(size_t)idx * s->Nl + lr];
+    for (uint32_t k = 0; k < SIM_C && rb->keys[k]; ++k) handle_user_event(&c, rb->keys[k], rb->ltime);
+  }
+#undef PP_GUARD
+}
+static void pp_pair(osim* s, const tickp* p, uint32_t g, uint32_t pi) {
+  uint32_t xa = 2 * pi, xb = 2 * pi + 1;
+  if (xb >= p->M) return;
+  uint32_t base = s->cfg.shard_count > 1 ? 0 : g * p->M; /* local index of the shard's first node */
+  uint32_t la = base + sigma_inv(p, xa), lb = base + sigma_inv(p, xb);
+  if (!(s->rows[la].flags & SIM_RF_UP) || !(s->rows[lb].flags & SIM_RF_UP)) return;
+  pp_merge(s, la, lb);
+  pp_merge(s, lb, la);
+}
+static void pp_round(osim* s, const tickp* p) {
+  if (!s->pp_step || s->tick == 0 || s->tick % s->pp_step) return;
+  uint32_t cls = (uint32_t)((s->tick / s->pp_step) % s->pp_groups);
+  uint32_t shards = s->cfg.shard_count > 1 ? 1 : p->V;
+  for (uint32_t g = 0; g < shards; ++g)
+    for (uint32_t pi = cls; 2 * pi + 1 < p->M; pi += s->pp_groups) pp_pair(s, p, g, pi);
+}
+
+/* =====================================================================================
  * The tick (DESIGN.md SIMSPEC §4)
  * ===================================================================================== */
 static inline const sim_packet* inbox_cell(const osim* s, uint32_t k, uint32_t l) {
@@ -974,6 +1055,7 @@ static void step_one(osim* s) {
     apply_op(s, &s->ops[s->op_cursor]);
     s->op_cursor++;
   }
+  pp_round(s, &p);
   if (s->n_watched) {
     for (uint32_t l = 0; l < s->Nl; ++l) tick_node(s, &p, l);
   } else {
@@ -1079,6 +1161,7 @@ int API(create)(const sim_config* cfg, osim** out) {
   s->upmap = (uint32_t*)malloc(((size_t)s->N + 31) / 32 * sizeof(uint32_t));
   if (s->upmap) memset(s->upmap, 0xFF, ((size_t)s->N + 31) / 32 * sizeof(uint32_t));
   swim_params(cfg, &s->swim, &s->k_conf, s->T);
+  pp_params(cfg, &s->pp_step, &s->pp_groups);
   if (!s->upmap || !s->rows || !s->queue || !s->view || !s->ering || !s->qring || !s->slot_of ||
       !s->subject_of || !s->base || (cfg->shard_count > 1 ? (!s->xsend || !s->xrecv)
                                                           : (!s->inbox[0] || !s->inbox[1]))) {

@@ -1266,6 +1266,95 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// push-pull anti-entropy (memberlist pushPull, App. B.6; SerfDelegate::local_state / merge_remote_state,
+// serf-core/src/serf/delegate.rs:386-554) — SIMSPEC §2.10, oracle pp_round/pp_pair/pp_merge.
+// One lane per synchronising pair; a batch holds 1/PP_GROUPS of all pairs, so the launch fills the chip
+// and happens once per (scaled interval / PP_GROUPS) ticks: off the per-tick critical path.
+// ------------------------------------------------------------------------------------------------
+#define PP_GROUPS 8u
+// local <- remote: memberlist mergeState, then merge_remote_state(is_join = false)
+__device__ static void pp_merge(const Dev& d, const TickP& tp, u32 ll, u32 lr) {
+  Ctx c{d, ll, d.shard0 + ll, (u32)tp.tick};
+  Node n;
+  node_load(d, ll, n);
+  u32 sk[SIM_Q];
+  u32 cnt0 = __popc(n.used);
+  keys_load(d, ll, cnt0, sk);
+  if (n.next_seq > 1023u - 64u) q_renorm(n, sk);
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+  bool dirty = false;
+  if (d.swim) {  // alive as alive, left as dead{from = node}, suspect and dead as suspect
+#pragma unroll 1
+    for (u32 a = 0; a < tp.n_slots; ++a) {
+      uint4 re = d.view[((size_t)a * d.Nl + lr) * 2];
+      if (!(re.w & SIM_VB_KNOWN)) continue;
+      if (n.next_seq > 1023u - 64u) q_renorm(n, sk);  // a merge can queue one broadcast per view slot
+      u32 subj = d.subject_of[a], sw = SIM_VB_SWIM(re.w), inc = re.z;
+      uint4* p = view_slot_ptr(c, a);
+      uint4 e = p[0];
+      Ins ins;
+      ins.has = ins.wide = 0;
+      if (sw == SIM_SWIM_ALIVE) swim_alive(c, n, subj, inc, wire_meta(SIM_K_ALIVE, 0, 64), p, e, dirty, ins);
+      else if (sw == SIM_SWIM_LEFT) swim_dead(c, n, subj, inc, subj, wire_meta(SIM_K_DEAD, 0, 32), p, e, dirty, ins);
+      else swim_suspect(c, n, subj, inc, c.gid, wire_meta(SIM_K_SUSPECT, 0, 32), p, e, dirty, ins);
+      if (ins.has) q_insert(c, n, sk, ins.key, ins.wmeta, ins.val);
+    }
+  }
+  uint4 r0 = d.R0[lr], r1 = d.R1[lr];
+  u64 rclock = (u64)r0.x | ((u64)r0.y << 32), reclock = (u64)r0.z | ((u64)r0.w << 32), rqclock = (u64)r1.x | ((u64)r1.y << 32);
+  if (rclock > 0) witness(n, n.clock, rclock - 1, DR0);     // delegate.rs:466-480
+  if (reclock > 0) witness(n, n.eclock, reclock - 1, DR0);
+  if (rqclock > 0) witness(n, n.qclock, rqclock - 1, DR1);
+#pragma unroll 1
+  for (u32 pass = 0; pass < 2; ++pass) {  // left members first (at status_ltime + 1), then the join intents
+#pragma unroll 1
+    for (u32 a = 0; a < tp.n_slots; ++a) {
+      uint4 re = d.view[((size_t)a * d.Nl + lr) * 2];
+      if (!(re.w & SIM_VB_KNOWN)) continue;
+      bool left = SIM_VB_STATUS(re.w) == SIM_STATUS_LEFT;
+      if (left != (pass == 0)) continue;
+      if (left && n.next_seq > 1023u - 64u) q_renorm(n, sk);
+      u32 subj = d.subject_of[a];
+      uint4* p = view_slot_ptr(c, a);
+      uint4 e = p[0];
+      Ins ins;
+      ins.has = ins.wide = 0;
+      if (left) handle_leave_intent(c, n, subj, E_LTIME(re) + 1, false, p, e, dirty, ins);  // delegate.rs:495-512
+      else handle_join_intent(c, n, subj, E_LTIME(re), p, e, dirty);                        // delegate.rs:515-526
+      if (ins.has) q_insert(c, n, sk, ins.key, ins.wmeta, ins.val);                         // a refutation
+    }
+  }
+#pragma unroll 1
+  for (u32 idx = 0; idx < d.Bev; ++idx) {  // replay the remote event buffer: delegate.rs:540-552
+    const uint4* rb = d.ering + ((size_t)idx * d.Nl + lr) * 2;
+    uint4 b0 = rb[0];
+    if (!b0.z) continue;
+    uint4 b1 = b0.w ? rb[1] : zero;
+    u64 lt = E_LTIME(b0);
+    u32 keys[SIM_C] = {b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int k = 0; k < (int)SIM_C; ++k) {
+      if (!keys[k]) break;
+      uint4* p = ering_ptr(c, lt);
+      handle_user_event(c, n, keys[k], lt, p, p[0], dirty);
+    }
+  }
+  node_store(d, ll, n);
+  keys_store(d, ll, cnt0, n.used, sk);
+}
+__global__ void pushpull_kernel(Dev d, TickP tp, u32 cls, u32 per_shard, u32 shards) {
+  u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= per_shard * shards) return;
+  u32 g = j / per_shard, pi = cls + (j - g * per_shard) * PP_GROUPS;
+  if (2 * pi + 1 >= tp.M) return;
+  u32 base = d.sharded ? 0u : g * tp.M;
+  u32 la = base + sigma_inv(tp, 2 * pi), lb = base + sigma_inv(tp, 2 * pi + 1);
+  if (!(d.R1[la].z & SIM_RF_UP) || !(d.R1[lb].z & SIM_RF_UP)) return;  // a TCP exchange needs both ends
+  pp_merge(d, tp, la, lb);
+  pp_merge(d, tp, lb, la);
+}
+
+// ------------------------------------------------------------------------------------------------
 // support kernels: fills, canonical forms, digest, members, convergence, stats
 // ------------------------------------------------------------------------------------------------
 __global__ void fill_u32(u32* p, size_t n, u32 v) {
@@ -1459,6 +1548,7 @@ struct sim_handle {
   TickP prev;
   bool bound;
   int device;
+  u32 pp_step;  // push-pull batches: every pp_step ticks one of PP_GROUPS pair classes synchronises (0 = off)
 };
 
 #define HCHECK(x)                                                                        \
@@ -1585,6 +1675,13 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   d.queue_check_interval = cfg->queue_check_interval; d.max_queue_depth = cfg->max_queue_depth;
   d.min_queue_depth = cfg->min_queue_depth;
   d.r3on = d.swim || d.reap_interval;
+  h->pp_step = 0;
+  if (cfg->push_pull_interval) {  // memberlist pushPullScale: x (ceil(log2 N - 5) + 1) above 32 nodes
+    u64 mult = 1;
+    if (cfg->n_nodes > 32) mult = (u64)std::ceil(std::log2((double)cfg->n_nodes) - 5.0) + 1;
+    u64 st = (u64)cfg->push_pull_interval * mult / PP_GROUPS;
+    h->pp_step = st < 1 ? 1u : st > 0x7FFFFFFFu ? 0x7FFFFFFFu : (u32)st;
+  }
   d.ev_cap = EV_CAP;
   size_t Nl = d.Nl, nup = ((size_t)d.N + 31) / 32;
 #define DA(ptr, n)                                   \
@@ -1733,6 +1830,12 @@ int sim_step(sim_handle* h, uint32_t n_ticks) {
         ob.n++;
       }
       ops_kernel<<<1, 64, 0, h->stream>>>(d, ob, h->tick, d.N > 1 ? 1u : 0u);
+    }
+    if (h->pp_step && h->tick > 0 && h->tick % h->pp_step == 0) {
+      u32 cls = (u32)((h->tick / h->pp_step) % PP_GROUPS);
+      u32 half = tp.M / 2, per_shard = half > cls ? (half - cls + PP_GROUPS - 1) / PP_GROUPS : 0;
+      u32 shards = d.sharded ? 1u : tp.V;
+      if (per_shard) pushpull_kernel<<<(per_shard * shards + 63) / 64, 64, 0, h->stream>>>(d, tp, cls, per_shard, shards);
     }
     int grid = (int)((d.Nl + BLOCK - 1) / BLOCK);
     u32 cur = (u32)(h->tick & 1);

