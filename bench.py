@@ -30,7 +30,7 @@ def b_tick_layout(f):
 MIX = (0.55, 0.2, 0.15, 0.05, 0.05)
 
 
-def cpu_baseline(fanout, probe_interval, rate, seconds_budget=20.0):
+def cpu_baseline(fanout, probe_interval, push_pull_interval, rate, seconds_budget=20.0):
     """The CPU oracle ("port") on a bounded sample of the same workload, rank 0 only."""
     from serf_amd import _ffi
     from tests import _scenario as sc
@@ -39,7 +39,8 @@ def cpu_baseline(fanout, probe_interval, rate, seconds_budget=20.0):
     lib = load_oracle()
     n, ticks = 1 << 18, 24
     sim = _ffi.Sim(lib, _ffi.make_config(n, fanout=fanout, view_slots=64, event_ring=64, query_ring=64,
-                                         probe_interval=probe_interval))
+                                         probe_interval=probe_interval, push_pull_interval=push_pull_interval,
+                                         reap_interval=75, queue_check_interval=150))
     sc.apply_schedule(sim, sc.schedule(n, ticks, rate=rate, seed=11, mix=MIX, max_member_subjects=32, even=True))
     sim.step(4)  # warm-up (page faults, rumors in flight)
     t0 = time.perf_counter()
@@ -66,7 +67,9 @@ def main():
     ap.add_argument("--ring", type=int, default=512)
     ap.add_argument("--rate", type=float, default=0.4, help="API operations injected per tick (cluster-wide)")
     ap.add_argument("--probe-interval", type=int, default=5, help="memberlist probe interval in ticks (0 = SWIM layer off)")
+    ap.add_argument("--push-pull-interval", type=int, default=150, help="memberlist push_pull_interval in ticks before log2(N) scaling (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-convergence", action="store_true", help="skip the rounds-to-99 %% measurement (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -92,7 +95,8 @@ def main():
     n_total = args.nodes_per_gpu * world
     lib = serf_amd.load()
     kw = dict(fanout=args.fanout, view_slots=args.view_slots, event_ring=args.ring, query_ring=args.ring,
-              probe_interval=args.probe_interval)
+              probe_interval=args.probe_interval, push_pull_interval=args.push_pull_interval,
+              reap_interval=75, queue_check_interval=150)  # options.rs defaults: reap 15 s, queue check 30 s, timeouts 24 h
     total_ticks = args.steps + args.warmup
     ops = sc.schedule(n_total, total_ticks, rate=args.rate, seed=3, mix=MIX, max_member_subjects=args.view_slots // 2, even=True)
     if world > 1:
@@ -112,6 +116,8 @@ def main():
 
     step(args.warmup)
     barrier()
+    raw = sim.sim if world > 1 else sim
+    raw.profile(True)  # HIP events around every tick-kernel launch, on the stream it is launched on
     # The launches go to torch's current stream (sim_set_stream above), so torch events bracket them.
     # N=1: one pair around all K ticks (nothing but tick/ops kernels in between).  N>1: one pair per
     # tick around sim_step only, so that the all-to-all is not billed to the kernel's roofline.
@@ -141,13 +147,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
 
+    prof_ms, prof_n = raw.profile_read()
+    raw.profile(False)
     # second half of the metric: rounds to 99 % convergence, measured after the timed region on 8
     # fresh user events, one at a time, under the same background load (every rank issues the same
     # calls; the originator's rank reads the Lamport time the event is going to get)
     import numpy as _np
     rng = _np.random.default_rng(99)
     rounds = []
-    for i in range(8):
+    for i in range(0 if args.no_convergence else 8):
         node, key = int(rng.integers(0, n_total)), 0x7F000000 + i
         owner = node // args.nodes_per_gpu
         lt = (sim.sim if world > 1 else sim).stats(node).event_time if owner == rank else 0
@@ -167,8 +175,9 @@ def main():
     if rank == 0:
         value = n_total * args.steps / dt
         bt, bt2 = b_tick_v0(args.fanout), b_tick_layout(args.fanout)
-        # dominant kernel = tick_kernel: one launch per tick; HIP-event time over the timed region
-        kern_s = ev_ms / 1e3 / args.steps
+        # dominant kernel = tick_kernel: one launch per tick; HIP events around each launch of the timed
+        # region (sim_profile); ev_ms (everything on the stream, ops + push-pull included) for reference
+        kern_s = prof_ms / 1e3 / max(1, prof_n)
         achieved = args.nodes_per_gpu * bt / kern_s / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
@@ -184,18 +193,21 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{n_total} nodes ({args.nodes_per_gpu}/GPU), fan-out {args.fanout}, "
                                    f"{args.rate} API ops/tick evenly spaced, mix {MIX} of (user event, query, leave, crash+remove, crash+revive), "
-                                   f"view_slots {args.view_slots}, rings {args.ring}, probe interval {args.probe_interval} ticks — BASELINE configs[2]",
+                                   f"view_slots {args.view_slots}, rings {args.ring}, probe interval {args.probe_interval} ticks, push-pull interval "
+                                   f"{args.push_pull_interval} ticks (x log2 scaling), reaper and queue checker on — BASELINE configs[2]",
                        "parallelism": f"node-id range shards x{world}, 1 all_to_all_single/tick" if world > 1 else "single GPU"},
-            "rounds_to_99": {"median": float(_np.median(rounds)), "max": int(max(rounds)), "min": int(min(rounds)), "n": len(rounds),
-                             "what": "gossip rounds until >= 99 % of running nodes have applied a fresh user event, under the bench load"},
+            "rounds_to_99": ({"median": float(_np.median(rounds)), "max": int(max(rounds)), "min": int(min(rounds)), "n": len(rounds),
+                              "what": "gossip rounds until >= 99 % of running nodes have applied a fresh user event, under the bench load"}
+                             if rounds else None),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "tick_kernel", "kernel_ms": kern_s * 1e3, "b_tick_bytes": bt,
+                         "kernel": "tick_kernel", "kernel_ms": kern_s * 1e3, "kernel_launches": int(prof_n),
+                         "stream_ms_per_step": ev_ms / args.steps, "b_tick_bytes": bt,
                          "achieved_revised": args.nodes_per_gpu * bt2 / kern_s / 1e9, "b_tick_layout_bytes": bt2,
                          "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch)"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.fanout, args.probe_interval, args.rate)
+            out["cpu_baseline"] = cpu_baseline(args.fanout, args.probe_interval, args.push_pull_interval, args.rate)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

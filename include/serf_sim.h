@@ -306,6 +306,12 @@ int sim_convergence(sim_handle* h, uint32_t kind, uint32_t key, uint64_t ltime,
 int sim_exchange_bytes(const sim_handle* h, size_t* bytes);
 int sim_bind_exchange(sim_handle* h, void* send_dev, void* recv_dev);
 
+/* Measurement: with profiling on, every launch of the tick kernel is bracketed by HIP events on the
+ * handle's stream; sim_profile_read waits for the stream and returns the summed kernel time and the
+ * number of launches since the last read (bench.py's roofline figure).  No reference counterpart. */
+int sim_profile(sim_handle* h, int enable);
+int sim_profile_read(sim_handle* h, double* tick_kernel_ms, uint64_t* launches);
+
 uint32_t sim_abi_version(void);
 const char* sim_backend_name(void);
 

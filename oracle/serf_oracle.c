@@ -1422,6 +1422,13 @@ int API(convergence)(osim* s, uint32_t kind, uint32_t key, uint64_t ltime, uint6
   return SIM_OK;
 }
 
+int API(profile)(osim* s, int enable) { (void)enable; return s ? SIM_OK : SIM_EINVAL; }
+int API(profile_read)(osim* s, double* ms, uint64_t* launches) {
+  if (!s || !ms || !launches) return SIM_EINVAL;
+  *ms = 0.0;
+  *launches = 0;
+  return SIM_OK;
+}
 int API(exchange_bytes)(const osim* s, size_t* bytes) {
   if (!s || !bytes) return SIM_EINVAL;
   *bytes = s->cfg.shard_count > 1 ? (size_t)s->f * s->M * sizeof(sim_packet) : 0;

@@ -78,7 +78,7 @@ _ARR_DTYPE = {ARR_ROWS: ROW_DTYPE, ARR_QUEUE: REC_DTYPE, ARR_INBOX: REC_DTYPE, A
 ABI_SYMBOLS = ("create", "destroy", "set_stream", "join", "leave", "force_leave", "user_event",
                "query", "inject", "step", "sync", "tick", "members", "stats_get", "watch",
                "drain_events", "state_digest", "dump_state", "convergence", "exchange_bytes",
-               "bind_exchange", "abi_version", "backend_name")
+               "bind_exchange", "profile", "profile_read", "abi_version", "backend_name")
 
 
 def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, view_slots=0,
@@ -134,6 +134,8 @@ class SimLib:
             "convergence": (C.c_int, [H, u32, u32, u64, C.POINTER(u64), C.POINTER(u64)]),
             "exchange_bytes": (C.c_int, [H, C.POINTER(C.c_size_t)]),
             "bind_exchange": (C.c_int, [H, vp, vp]),
+            "profile": (C.c_int, [H, C.c_int]),
+            "profile_read": (C.c_int, [H, C.POINTER(C.c_double), C.POINTER(u64)]),
             "abi_version": (u32, []),
             "backend_name": (C.c_char_p, []),
         }
@@ -247,6 +249,15 @@ class Sim:
         seen, up = C.c_uint64(), C.c_uint64()
         self._ck(self.lib.f["convergence"](self.h, kind, key, ltime, C.byref(seen), C.byref(up)), "sim_convergence")
         return seen.value, up.value
+
+    def profile(self, enable=True):
+        self._ck(self.lib.f["profile"](self.h, int(enable)), "sim_profile")
+
+    def profile_read(self):
+        """(summed tick-kernel milliseconds, launches) since the last read."""
+        ms, n = C.c_double(), C.c_uint64()
+        self._ck(self.lib.f["profile_read"](self.h, C.byref(ms), C.byref(n)), "sim_profile_read")
+        return ms.value, n.value
 
     def exchange_bytes(self):
         n = C.c_size_t()

@@ -1548,6 +1548,8 @@ struct sim_handle {
   TickP prev;
   bool bound;
   int device;
+  bool profiling;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof;  // one event pair per tick-kernel launch
   u32 pp_step;  // push-pull batches: every pp_step ticks one of PP_GROUPS pair classes synchronises (0 = off)
 };
 
@@ -1632,6 +1634,7 @@ const char* sim_backend_name(void) { return "hip-gfx950"; }
 int sim_destroy(sim_handle* h) {
   if (!h) return SIM_EINVAL;
   (void)hipStreamSynchronize(h->stream);
+  for (auto& pr : h->prof) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (void* p : h->allocs) (void)hipFree(p);
   delete h;
   return SIM_OK;
@@ -1652,6 +1655,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   h->stream = nullptr;
   h->op_cursor = 0;
   h->bound = false;
+  h->profiling = false;
   memset(&h->prev, 0, sizeof h->prev);
   (void)hipGetDevice(&h->device);
   Dev& d = h->d;
@@ -1839,6 +1843,12 @@ int sim_step(sim_handle* h, uint32_t n_ticks) {
     }
     int grid = (int)((d.Nl + BLOCK - 1) / BLOCK);
     u32 cur = (u32)(h->tick & 1);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (h->profiling) {
+      HCHECK(hipEventCreate(&ev0));
+      HCHECK(hipEventCreate(&ev1));
+      HCHECK(hipEventRecord(ev0, h->stream));
+    }
 #define LAUNCH_TICK(SH, FF) tick_kernel<SH, FF><<<grid, BLOCK, 0, h->stream>>>(d, tp, cur, h->d_base)
     switch (tp.feff + (d.sharded ? 4u : 0u)) {  // one instantiation per fan-out: the drain loop is fully unrolled
       case 0: case 1: LAUNCH_TICK(false, 1); break;
@@ -1851,6 +1861,10 @@ int sim_step(sim_handle* h, uint32_t n_ticks) {
       default: LAUNCH_TICK(true, 4); break;
     }
 #undef LAUNCH_TICK
+    if (h->profiling) {
+      HCHECK(hipEventRecord(ev1, h->stream));
+      h->prof.emplace_back(ev0, ev1);
+    }
     h->prev = tp;
     h->tick++;
   }
@@ -1989,6 +2003,27 @@ int sim_convergence(sim_handle* h, uint32_t kind, uint32_t key, uint64_t ltime, 
   return SIM_OK;
 }
 
+int sim_profile(sim_handle* h, int enable) {
+  if (!h) return SIM_EINVAL;
+  h->profiling = enable != 0;
+  return SIM_OK;
+}
+int sim_profile_read(sim_handle* h, double* ms, uint64_t* launches) {
+  if (!h || !ms || !launches) return SIM_EINVAL;
+  HCHECK(hipStreamSynchronize(h->stream));
+  double tot = 0.0;
+  for (auto& pr : h->prof) {
+    float t = 0.f;
+    HCHECK(hipEventElapsedTime(&t, pr.first, pr.second));
+    tot += t;
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  *ms = tot;
+  *launches = h->prof.size();
+  h->prof.clear();
+  return SIM_OK;
+}
 int sim_exchange_bytes(const sim_handle* h, size_t* bytes) {
   if (!h || !bytes) return SIM_EINVAL;
   *bytes = h->d.sharded ? (size_t)h->d.f * h->d.M * sizeof(sim_packet) : 0;
