@@ -965,7 +965,7 @@ __device__ unsigned long long g_tt[16];
 template <bool SHARDED, int F>
 __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur, const uint4* base) {
 #ifdef TICK_TIMING
-  unsigned long long tacc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #endif
   // LDS staging of the per-node inbox: the packet being delivered, the slot of each record's
@@ -1030,78 +1030,33 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
           lds_e[0][tid] = e0; lds_e[1][tid] = e1; lds_e[2][tid] = e2; lds_e[3][tid] = e3;
           TT(4);
         }
-        // phase B: retire the no-ops.  Duplicates, old messages and subjects without a view slot
-        // (~95 % of all records) only witness a Lamport clock (fast_noop against the staged head,
-        // select-based, no divergent branches).  The FIRST record of the packet that needs a real
-        // handler is deferred to phase C together with the value its Lamport clock had at that
-        // point, and the pass goes on: later no-ops cannot be affected by it (status times,
-        // incarnations and ring buckets only grow; the one exception, an erase, is covered by the
-        // same-entry test) and clocks are maxima, so their order does not matter — only what the
-        // deferred handler itself reads does, hence the snapshot.  A SECOND such record ends the
-        // pass: from there on the packet is handled strictly in order (rare).
-        u32 pendp = SIM_P, seq_from = SIM_P;
-        uint4* pend_ptr = nullptr;
-        u64 snap = 0;
+        // phase B: the records in arrival order, one rolled loop = one copy of the handler code.
+        // Duplicates, old messages and subjects without a view slot (~95 % of all records) are
+        // retired by fast_noop against the staged head; the rest runs the full handlers.  Once a
+        // handler of this packet has written state, later heads are re-read (rare).
+        // `wptr`: the one entry a handler of this packet has written so far; `wall`: more than one,
+        // or the node's own entry as well (refutation) — only then is a staged head stale.
+        uint4* wptr = nullptr;
+        bool wall = false;
 #pragma unroll 1
         for (u32 p = 0; p < SIM_P; ++p) {
-          if (seq_from != SIM_P) continue;
           uint4 r = lds_r[p][tid];
           u32 kind = SIM_META_KIND(r.y);
           uint4* ptr = lookup_ptr(c, kind, r.x, (u64)r.z | ((u64)r.w << 32), lds_s[p][tid]);
           uint4 e = lds_e[p][tid];
-          bool fast = fast_noop(c, n, kind, r, ptr != nullptr, e) && !(pendp != SIM_P && ptr != nullptr && ptr == pend_ptr);
+          if (ptr && (wall || ptr == wptr)) e = ld4(ptr);
+          bool fast = fast_noop(c, n, kind, r, ptr != nullptr, e);
           fast_witness(n, kind, r, fast);
-          bool first = !fast && pendp == SIM_P;
-          snap = first ? (kind == SIM_K_EVENT ? n.eclock : kind == SIM_K_QUERY ? n.qclock : n.clock) : snap;
-          pend_ptr = first ? ptr : pend_ptr;
-          seq_from = (!fast && !first) ? p : seq_from;
-          pendp = first ? p : pendp;
-        }
-        TT(12);
-        // phase C: the full handlers — one site, executed once per packet for the deferred records of
-        // all lanes, then (rarely) again for each record of a lane's in-order remainder.
-        // `wptr`: the one entry a handler of this packet has written so far; `wall`: more than one,
-        // or the node's own entry as well (refutation) — only then is a staged head stale.
-        uint4* wptr = nullptr;
-        bool wall = false, deferred = true;
-        u32 next = pendp;
-#pragma unroll 1
-        while (__any(next < SIM_P)) {
-          if (next < SIM_P) {
-            uint4 r = lds_r[next][tid];
-            u32 kind = SIM_META_KIND(r.y);
-            uint4* ptr = lookup_ptr(c, kind, r.x, (u64)r.z | ((u64)r.w << 32), lds_s[next][tid]);
-            uint4 e = lds_e[next][tid];
-            bool fast = false;
-            if (!deferred) {  // in-order remainder: nothing was retired or witnessed yet
-              if (ptr && (wall || ptr == wptr)) e = ld4(ptr);
-              fast = fast_noop(c, n, kind, r, ptr != nullptr, e);
-              fast_witness(n, kind, r, fast);
-            }
-            if (!fast) {
-              // the deferred record's handler sees its clock as it was at the record's position
-              bool sev = deferred && kind == SIM_K_EVENT, sq = deferred && kind == SIM_K_QUERY;
-              bool sc = deferred && !sev && !sq;
-              u64 live = sev ? n.eclock : sq ? n.qclock : n.clock;
-              n.eclock = sev ? snap : n.eclock;
-              n.qclock = sq ? snap : n.qclock;
-              n.clock = sc ? snap : n.clock;
-              Ins ins;
-              ins.has = ins.wide = 0;
-              bool dirty = false;
-              dispatch(c, n, r, ptr, e, dirty, ins);
-              n.eclock = (sev && live > n.eclock) ? live : n.eclock;
-              n.qclock = (sq && live > n.qclock) ? live : n.qclock;
-              n.clock = (sc && live > n.clock) ? live : n.clock;
-              if (dirty) {
-                wall |= ins.wide || (wptr != nullptr && wptr != ptr);
-                wptr = ptr;
-              }
-              if (ins.has) pend_push(c, n, ins);
-            }
-            next = deferred ? seq_from : next + 1;
-            deferred = false;
+          if (fast) continue;
+          Ins ins;
+          ins.has = ins.wide = 0;
+          bool dirty = false;
+          dispatch(c, n, r, ptr, e, dirty, ins);
+          if (dirty) {
+            wall |= ins.wide || (wptr != nullptr && wptr != ptr);
+            wptr = ptr;
           }
+          if (ins.has) pend_push(c, n, ins);
         }
         TT(5);
       }
@@ -1194,7 +1149,7 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
   TT(11);
 #ifdef TICK_TIMING
   if ((threadIdx.x & 63) == 0)
-    for (int i = 0; i < 13; ++i) atomicAdd(&g_tt[i], tacc[i]);
+    for (int i = 0; i < 12; ++i) atomicAdd(&g_tt[i], tacc[i]);
 #endif
 }
 

@@ -15,9 +15,9 @@ buf = (C.c_ulonglong * 16)()
 lib.dll.sim_debug_timing(buf, 1)
 sim.step(50); sim.sync()
 lib.dll.sim_debug_timing(buf, 1)
-names = ["row load", "cell r1-3 (x4)", "slot_of (x4)", "entry ptrs+issue (x4)", "entry heads wait (x4)", "phase C handlers (x4)", "timers+probe", "keys+pend inserts", "q_round x4", "payload gather (all)", "perm+store x4", "row/keys store", "fast pass (x4)"]
+names = ["row load", "cell r1-3 (x4)", "slot_of (x4)", "entry ptrs+issue (x4)", "entry heads wait (x4)", "handler loop (x4)", "timers+probe", "keys+pend inserts", "q_round x4", "payload gather (all)", "perm+store x4", "row/keys store"]
 waves = n // 64 * 50
-tot = sum(buf[:13])
+tot = sum(buf[:12])
 for i, nm in enumerate(names):
     print(f"{nm:24s} {buf[i]/waves:10.0f} cyc/wave  {100*buf[i]/tot:5.1f}%")
 print(f"{'total':24s} {tot/waves:10.0f} cyc/wave (clock ticks of s_memtime / readcyclecounter)")
