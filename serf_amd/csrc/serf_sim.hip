@@ -969,10 +969,10 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #endif
   // LDS staging of the per-node inbox: the packet being delivered, the slot of each record's
-  // subject and the head of the entry it is checked against (36 KiB per block: 4 blocks per CU)
+  // subject's entry and the head of that entry (40 KiB per block: exactly 4 blocks per CU)
   __shared__ uint4 lds_r[SIM_P][BLOCK];
   __shared__ uint4 lds_e[SIM_P][BLOCK];
-  __shared__ u32 lds_s[SIM_P][BLOCK];
+  __shared__ uint4* lds_p[SIM_P][BLOCK];  // where each record's entry lives (null: nothing to look at)
   const u32 tid = threadIdx.x;
   u32 l = blockIdx.x * BLOCK + threadIdx.x;
   if (l >= d.Nl) return;
@@ -1020,11 +1020,11 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
           u32 s2 = slot_load(d, k2, r2.x);
           u32 s3 = slot_load(d, k3, r3.x);
           TT(2);
-          lds_s[0][tid] = s0; lds_s[1][tid] = s1; lds_s[2][tid] = s2; lds_s[3][tid] = s3;
           uint4* p0 = lookup_ptr(c, k0, r0.x, (u64)r0.z | ((u64)r0.w << 32), s0);
           uint4* p1 = lookup_ptr(c, k1, r1.x, (u64)r1.z | ((u64)r1.w << 32), s1);
           uint4* p2 = lookup_ptr(c, k2, r2.x, (u64)r2.z | ((u64)r2.w << 32), s2);
           uint4* p3 = lookup_ptr(c, k3, r3.x, (u64)r3.z | ((u64)r3.w << 32), s3);
+          lds_p[0][tid] = p0; lds_p[1][tid] = p1; lds_p[2][tid] = p2; lds_p[3][tid] = p3;
           uint4 e0 = ld4(p0 ? p0 : d.nullcell), e1 = ld4(p1 ? p1 : d.nullcell), e2 = ld4(p2 ? p2 : d.nullcell), e3 = ld4(p3 ? p3 : d.nullcell);
           TT(3);
           lds_e[0][tid] = e0; lds_e[1][tid] = e1; lds_e[2][tid] = e2; lds_e[3][tid] = e3;
@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
         for (u32 p = 0; p < SIM_P; ++p) {
           uint4 r = lds_r[p][tid];
           u32 kind = SIM_META_KIND(r.y);
-          uint4* ptr = lookup_ptr(c, kind, r.x, (u64)r.z | ((u64)r.w << 32), lds_s[p][tid]);
+          uint4* ptr = lds_p[p][tid];
           uint4 e = lds_e[p][tid];
           if (ptr && (wall || ptr == wptr)) e = ld4(ptr);
           bool fast = fast_noop(c, n, kind, r, ptr != nullptr, e);
