@@ -29,7 +29,7 @@ extern "C" {
 
 /* ------------------------------------------------------------------ constants */
 
-#define SIM_ABI_VERSION 4u
+#define SIM_ABI_VERSION 5u
 
 #define SIM_P 4u  /* piggyback records per gossip packet (64-byte packet)             */
 #define SIM_Q 16u /* retransmit-queue slots per node (all four queues share the pool) */
@@ -92,6 +92,9 @@ enum sim_kind {
 #define SIM_F_PRUNE 1u        /* LeaveMessage.prune                       */
 #define SIM_F_NO_BROADCAST 1u /* QueryFlag::NO_BROADCAST (types/query.rs) */
 #define SIM_F_ACK 2u          /* QueryFlag::ACK                           */
+#define SIM_F_RESPOND 4u      /* simulation: every node that processes the query also calls respond() (query.rs:117-149) */
+#define SIM_QT 256u           /* running-query table, direct-mapped by query_id % SIM_QT (a newer query with the
+                               * same residue takes the entry over: model bound)                 */
 #define SIM_F_CC 1u           /* UserEventMessage.cc (coalesce)           */
 
 /*
@@ -305,6 +308,13 @@ int sim_convergence(sim_handle* h, uint32_t kind, uint32_t key, uint64_t ltime,
  * moves send -> recv between sim_step(h,1) calls. */
 int sim_exchange_bytes(const sim_handle* h, size_t* bytes);
 int sim_bind_exchange(sim_handle* h, void* send_dev, void* recv_dev);
+
+/* Query acks and responses (serf-core/src/serf/base.rs:1075-1154 sender side, 1158-1204 and
+ * serf/query.rs:240-303 origin side): number of distinct nodes whose ack (QueryFlag::ACK) / response
+ * (SIM_F_RESPOND) reached the origin of the running query `query_id` before its deadline
+ * (query.rs:421-427: gossip_interval * query_timeout_mult (16) * ceil(log10(N+1))); `open` = still
+ * inside the deadline.  SIM_EINVAL if the id does not own its entry of the running-query table. */
+int sim_query_status(sim_handle* h, uint32_t query_id, uint64_t* acks, uint64_t* responses, int* open);
 
 /* Measurement: with profiling on, every launch of the tick kernel is bracketed by HIP events on the
  * handle's stream; sim_profile_read waits for the stream and returns the summed kernel time and the

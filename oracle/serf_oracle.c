@@ -68,7 +68,7 @@ static inline uint64_t mix64(uint64_t z) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-enum { STREAM_PERM = 1, STREAM_OFF = 2, STREAM_ROT = 3, STREAM_LOSS = 4, STREAM_PROBE = 5 };
+enum { STREAM_PERM = 1, STREAM_OFF = 2, STREAM_ROT = 3, STREAM_LOSS = 4, STREAM_PROBE = 5, STREAM_QUERY = 6 };
 /* sub-draws of the per-(tick, prober) probe stream */
 enum { PD_TARGET = 0, PD_PING = 1, PD_ACK = 2, PD_RELAY0 = 3 /* + 5*j: relay, 4 legs */ };
 static inline uint64_t rng_base(uint64_t seed, uint64_t stream, uint64_t a) {
@@ -212,6 +212,10 @@ struct sim_handle {
   uint32_t k_conf;      /* confirmations that shrink a suspicion timer (B.5) */
   uint32_t T[SIM_MAX_CONF]; /* timeout in ticks after c confirmations */
   const tickp* tp;      /* parameters of the tick being executed */
+  /* running queries (QueryCore.responses, serf.rs:152-160): who acked / responded, per tracked query */
+  struct { uint32_t qid, origin, deadline, flags; } qtab[SIM_QT];
+  uint32_t* qbits;      /* [SIM_QT][2][ceil(N/32)]: ack bitmap, response bitmap, by global node id */
+  uint32_t qt_cursor, q_timeout;
   uint32_t pp_step, pp_groups; /* push-pull batches: every pp_step ticks one of pp_groups pair classes syncs */
 };
 typedef struct sim_handle osim;
@@ -544,6 +548,30 @@ static int handle_user_event(nctx* c, uint32_t key, uint64_t ltime) {
   return 1;
 }
 
+static inline int up_of_early(const osim* s, uint32_t gid) { return (s->upmap[gid >> 5] >> (gid & 31)) & 1u; }
+/* The responder half of handle_query (base.rs:1075-1154): ack without waiting for the user
+ * (QueryFlag::ACK), response when the simulated user code calls respond() (SIM_F_RESPOND); both go
+ * straight to the query's origin (memberlist.send, base.rs:1097) and are subject to packet loss.
+ * The origin half (handle_query_response base.rs:1158-1204, QueryResponse::handle_query_response
+ * query.rs:240-303): dropped after the deadline or when the origin is not running, duplicates from
+ * the same node are dropped — a bit per (query, node).  Relays (relay_factor) are not modelled. */
+static void query_respond(nctx* c, uint32_t id, uint32_t flags) {
+  osim* s = c->s;
+  if (!(flags & (SIM_F_ACK | SIM_F_RESPOND))) return;
+  uint32_t j = id % SIM_QT;
+  if (s->qtab[j].qid != id) return; /* "reply for non-running query" */
+  uint32_t now = (uint32_t)s->tick;
+  if (now > s->qtab[j].deadline || !up_of_early(s, s->qtab[j].origin)) return;
+  uint64_t base = mix64(rng_base(s->cfg.seed, STREAM_QUERY, s->tick) ^ ((uint64_t)id << 32));
+  size_t words = ((size_t)s->N + 31) / 32;
+  for (uint32_t which = 0; which < 2; ++which) {
+    if (!(flags & (which ? SIM_F_RESPOND : SIM_F_ACK))) continue;
+    if (s->cfg.loss_u32 && (uint32_t)(mix64(base ^ ((uint64_t)c->gid * 4u + which)) >> 32) < s->cfg.loss_u32) continue;
+    uint32_t* w = &s->qbits[((size_t)j * 2 + which) * words + (c->gid >> 5)];
+    __atomic_fetch_or(w, 1u << (c->gid & 31), __ATOMIC_RELAXED);
+  }
+}
+
 /* handle_query (de-dup + rebroadcast decision): base.rs:972-1073.
  * Quirk Q1 (age test uses the ring length, base.rs:1012-1014) and quirk Q2 (bucket ltime not
  * updated, base.rs:1027-1036) are reproduced. */
@@ -568,7 +596,8 @@ static int handle_query(nctx* c, uint32_t id, uint64_t ltime, uint32_t flags) {
     b->ltime = ltime;
     b->keys[0] = id;
   }
-  emit_event(c, SIM_EV_QUERY, id, ltime);
+  query_respond(c, id, flags);            /* base.rs:1075-1124 */
+  emit_event(c, SIM_EV_QUERY, id, ltime); /* base.rs:1126-1151 */
   return (flags & SIM_F_NO_BROADCAST) ? 0 : 1; /* base.rs:1062-1073 */
 }
 
@@ -844,6 +873,13 @@ static void apply_op(osim* s, const sim_opent* op) {
   /* ground-truth liveness is replicated on every shard (probes read it, B.3) */
   if (op->op == SIM_OP_CRASH) up_set(s, op->node, 0);
   if (op->op == SIM_OP_REVIVE || op->op == SIM_OP_JOIN) up_set(s, op->node, 1);
+  if (op->op == SIM_OP_QUERY) { /* base.rs:905-930: register the QueryResponse before sending (every shard counts its own nodes) */
+    uint32_t j = op->a % SIM_QT;
+    size_t words = ((size_t)s->N + 31) / 32;
+    s->qtab[j].qid = op->a; s->qtab[j].origin = op->node; s->qtab[j].flags = op->b;
+    s->qtab[j].deadline = (uint32_t)s->tick + s->q_timeout;
+    memset(&s->qbits[(size_t)j * 2 * words], 0, 2 * words * sizeof(uint32_t));
+  }
   if (op->node < s->shard0 || op->node >= s->shard0 + s->Nl) return; /* another shard's node */
   uint32_t l = op->node - s->shard0;
   nctx c;
@@ -1123,7 +1159,7 @@ int API(destroy)(osim* s) {
   free(s->rows); free(s->queue); free(s->inbox[0]); free(s->inbox[1]);
   if (s->own_x) { free(s->xsend); free(s->xrecv); }
   free(s->view); free(s->ering); free(s->qring); free(s->slot_of); free(s->subject_of);
-  free(s->base); free(s->ops); free(s->events); free(s->upmap); free(s);
+  free(s->base); free(s->ops); free(s->events); free(s->upmap); free(s->qbits); free(s);
   return SIM_OK;
 }
 
@@ -1161,8 +1197,10 @@ int API(create)(const sim_config* cfg, osim** out) {
   s->upmap = (uint32_t*)malloc(((size_t)s->N + 31) / 32 * sizeof(uint32_t));
   if (s->upmap) memset(s->upmap, 0xFF, ((size_t)s->N + 31) / 32 * sizeof(uint32_t));
   swim_params(cfg, &s->swim, &s->k_conf, s->T);
+  s->qbits = (uint32_t*)calloc((size_t)SIM_QT * 2 * (((size_t)s->N + 31) / 32), sizeof(uint32_t));
+  s->q_timeout = 16u * digits10(s->N); /* query.rs:421-427 with query_timeout_mult = 16 (options.rs:518) */
   pp_params(cfg, &s->pp_step, &s->pp_groups);
-  if (!s->upmap || !s->rows || !s->queue || !s->view || !s->ering || !s->qring || !s->slot_of ||
+  if (!s->qbits || !s->upmap || !s->rows || !s->queue || !s->view || !s->ering || !s->qring || !s->slot_of ||
       !s->subject_of || !s->base || (cfg->shard_count > 1 ? (!s->xsend || !s->xrecv)
                                                           : (!s->inbox[0] || !s->inbox[1]))) {
     API(destroy)(s);
@@ -1371,6 +1409,16 @@ int API(state_digest)(osim* s, uint64_t out[8]) {
     }
     out[6] = acc;
   }
+  { /* running queries: tracker table, then the ack / response bitmaps */
+    uint64_t acc = 0;
+    size_t words = ((size_t)s->N + 31) / 32;
+    for (uint32_t j = 0; j < SIM_QT; ++j) {
+      acc += dig((uint64_t)s->qtab[j].qid | ((uint64_t)s->qtab[j].origin << 32), (uint64_t)j * 2);
+      acc += dig((uint64_t)s->qtab[j].deadline | ((uint64_t)s->qtab[j].flags << 32), (uint64_t)j * 2 + 1);
+    }
+    for (size_t i = 0; i < (size_t)SIM_QT * 2 * words; ++i) acc += dig((uint64_t)s->qbits[i], 2 * SIM_QT + (uint64_t)i);
+    out[7] = acc;
+  }
   return SIM_OK;
 }
 int API(dump_state)(osim* s, uint32_t which, void* buf, size_t cap, size_t* bytes) {
@@ -1422,6 +1470,18 @@ int API(convergence)(osim* s, uint32_t kind, uint32_t key, uint64_t ltime, uint6
   return SIM_OK;
 }
 
+int API(query_status)(osim* s, uint32_t qid, uint64_t* acks, uint64_t* responses, int* open) {
+  if (!s || !acks || !responses || !open || !qid) return SIM_EINVAL;
+  uint32_t j = qid % SIM_QT;
+  if (s->qtab[j].qid != qid) return SIM_EINVAL;
+  size_t words = ((size_t)s->N + 31) / 32;
+  uint64_t n[2] = {0, 0};
+  for (uint32_t which = 0; which < 2; ++which)
+    for (size_t i = 0; i < words; ++i) n[which] += (uint64_t)__builtin_popcount(s->qbits[((size_t)j * 2 + which) * words + i]);
+  *acks = n[0]; *responses = n[1];
+  *open = (uint32_t)s->tick <= s->qtab[j].deadline;
+  return SIM_OK;
+}
 int API(profile)(osim* s, int enable) { (void)enable; return s ? SIM_OK : SIM_EINVAL; }
 int API(profile_read)(osim* s, double* ms, uint64_t* launches) {
   if (!s || !ms || !launches) return SIM_EINVAL;

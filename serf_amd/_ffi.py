@@ -30,7 +30,7 @@ ARR_ROWS, ARR_QUEUE, ARR_INBOX, ARR_VIEW, ARR_ERING, ARR_QRING, ARR_SLOTMAP = ra
 # enum sim_swim_state (memberlist node state)
 SWIM_ALIVE, SWIM_SUSPECT, SWIM_DEAD, SWIM_LEFT = 0, 1, 2, 3
 CF_BASELINE_JOINED = 1
-F_NO_BROADCAST = 1
+F_NO_BROADCAST, F_ACK, F_RESPOND = 1, 2, 4
 
 
 class SimError(RuntimeError):
@@ -78,7 +78,7 @@ _ARR_DTYPE = {ARR_ROWS: ROW_DTYPE, ARR_QUEUE: REC_DTYPE, ARR_INBOX: REC_DTYPE, A
 ABI_SYMBOLS = ("create", "destroy", "set_stream", "join", "leave", "force_leave", "user_event",
                "query", "inject", "step", "sync", "tick", "members", "stats_get", "watch",
                "drain_events", "state_digest", "dump_state", "convergence", "exchange_bytes",
-               "bind_exchange", "profile", "profile_read", "abi_version", "backend_name")
+               "bind_exchange", "query_status", "profile", "profile_read", "abi_version", "backend_name")
 
 
 def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, view_slots=0,
@@ -134,6 +134,7 @@ class SimLib:
             "convergence": (C.c_int, [H, u32, u32, u64, C.POINTER(u64), C.POINTER(u64)]),
             "exchange_bytes": (C.c_int, [H, C.POINTER(C.c_size_t)]),
             "bind_exchange": (C.c_int, [H, vp, vp]),
+            "query_status": (C.c_int, [H, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_int)]),
             "profile": (C.c_int, [H, C.c_int]),
             "profile_read": (C.c_int, [H, C.POINTER(C.c_double), C.POINTER(u64)]),
             "abi_version": (u32, []),
@@ -249,6 +250,12 @@ class Sim:
         seen, up = C.c_uint64(), C.c_uint64()
         self._ck(self.lib.f["convergence"](self.h, kind, key, ltime, C.byref(seen), C.byref(up)), "sim_convergence")
         return seen.value, up.value
+
+    def query_status(self, query_id):
+        """(acks, responses, still_open) of a running query, as its origin counts them (query.rs:240-303)."""
+        a, r, o = C.c_uint64(), C.c_uint64(), C.c_int()
+        self._ck(self.lib.f["query_status"](self.h, query_id, C.byref(a), C.byref(r), C.byref(o)), "sim_query_status")
+        return a.value, r.value, bool(o.value)
 
     def profile(self, enable=True):
         self._ck(self.lib.f["profile"](self.h, int(enable)), "sim_profile")

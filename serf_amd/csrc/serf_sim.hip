@@ -52,7 +52,7 @@ __host__ __device__ static inline u64 mix64(u64 z) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-enum { STREAM_PERM = 1, STREAM_OFF = 2, STREAM_ROT = 3, STREAM_LOSS = 4, STREAM_PROBE = 5 };
+enum { STREAM_PERM = 1, STREAM_OFF = 2, STREAM_ROT = 3, STREAM_LOSS = 4, STREAM_PROBE = 5, STREAM_QUERY = 6 };
 enum { PD_TARGET = 0, PD_PING = 1, PD_ACK = 2, PD_RELAY0 = 3 };
 static inline u64 rng_base(u64 seed, u64 stream, u64 a) {
   return mix64(mix64(seed ^ (stream * 0xD6E8FEB86659FD93ull)) ^ a);
@@ -61,7 +61,7 @@ static inline u64 rng4(u64 seed, u64 stream, u64 a, u64 b) { return mix64(rng_ba
 
 struct TickP {  // per-tick parameters, passed by value (lands in SGPRs)
   u64 tick;
-  u64 loss_base, probe_base;
+  u64 loss_base, probe_base, query_base;
   u32 M, mask, shift, feff, V, blk, loss_u32, first;  // first: tick 0 has no inbox yet
   u32 n_slots;  // view slots allocated so far (the Reaper walks them)
   u32 mul[3], add[3], imul[3];
@@ -106,6 +106,7 @@ static void tickp_make(TickP* p, const sim_config* c, u64 tick) {
   }
   p->loss_base = rng_base(c->seed, STREAM_LOSS, tick);
   p->probe_base = rng_base(c->seed, STREAM_PROBE, tick);
+  p->query_base = rng_base(c->seed, STREAM_QUERY, tick);
   p->loss_u32 = c->loss_u32;
   p->first = (tick == 0);
 }
@@ -163,6 +164,8 @@ struct Dev {
   u32* slot_of;     // [N]
   u32* subject_of;  // [A]
   u32* upmap;       // [ceil(N/32)] ground-truth liveness of every node (all shards)
+  uint4* qtab;      // [SIM_QT] running queries {qid, origin, deadline, flags}
+  u32* qbits;       // [SIM_QT][2][ceil(N/32)] who acked / responded, by global node id
   uint4* nullcell;  // 2 x uint4 of zeros: where the prefetch of a record without a lookup points
   sim_event* events;
   u32* ev_count;
@@ -170,6 +173,7 @@ struct Dev {
   u32 N, Nl, M, V, A, Bev, Bq, f, shard0, shard_rank, sharded, retransmit_mult;
   u32 bev_mask, bq_mask;  // B - 1 when B is a power of two (> 1), else 0
   u32 swim, PI, kconf, ic, T[SIM_MAX_CONF];
+  u32 loss_u32;
   u32 r3on;  // R3 is live: SWIM layer or Reaper configured
   u32 reap_interval, reconnect_timeout, tombstone_timeout, intent_timeout;
   u32 queue_check_interval, max_queue_depth, min_queue_depth;
@@ -199,7 +203,8 @@ enum { DR0 = 1, DR1 = 2, DR2 = 4, DR3 = 8 };  // R0 {clock, event_clock} R1 {que
 struct Ctx {
   const Dev& d;
   u32 l, gid;
-  u32 tick;  // low 32 bits of the tick
+  u32 tick;   // low 32 bits of the tick
+  u64 qbase;  // per-tick base of the query-response loss draws
 };
 // A handler invocation queues at most one broadcast (the rebroadcast of the record it was given, or
 // the refutation it answers with); it is parked here so that the kernel has ONE queue_broadcast
@@ -604,6 +609,24 @@ __device__ static bool handle_user_event(const Ctx& c, Node& n, u32 key, u64 lti
   emit_event(c, n, SIM_EV_USER, key, ltime);
   return true;
 }
+// Responder half of handle_query (base.rs:1075-1154) and origin half (base.rs:1158-1204,
+// query.rs:240-303) — see oracle query_respond: one bit per (running query, node) for acks, one for
+// responses; the counts are popcounts taken when somebody asks (no hot atomic counter).
+__device__ static void query_respond(const Ctx& c, u32 id, u32 flags) {
+  const Dev& d = c.d;
+  if (!(flags & (SIM_F_ACK | SIM_F_RESPOND))) return;
+  u32 j = id % SIM_QT;
+  uint4 t = d.qtab[j];
+  if (t.x != id) return;  // "reply for non-running query"
+  if (c.tick > t.z || !((d.upmap[t.y >> 5] >> (t.y & 31)) & 1u)) return;
+  u64 base = mix64(c.qbase ^ ((u64)id << 32));
+  size_t words = ((size_t)d.N + 31) / 32;
+  for (u32 which = 0; which < 2; ++which) {
+    if (!(flags & (which ? SIM_F_RESPOND : SIM_F_ACK))) continue;
+    if (d.loss_u32 && (u32)(mix64(base ^ ((u64)c.gid * 4u + which)) >> 32) < d.loss_u32) continue;
+    atomicOr(&d.qbits[((size_t)j * 2 + which) * words + (c.gid >> 5)], 1u << (c.gid & 31));
+  }
+}
 // handle_query, de-dup part: base.rs:972-1073 (quirks Q1, Q2 kept)
 __device__ static bool handle_query(const Ctx& c, Node& n, u32 id, u64 ltime, u32 flags, uint4* p, uint4 b0, bool& dirty) {
   witness(n, n.qclock, ltime, DR1);
@@ -620,6 +643,7 @@ __device__ static bool handle_query(const Ctx& c, Node& n, u32 id, u64 ltime, u3
     p[0] = make_uint4((u32)ltime, (u32)(ltime >> 32), id, 0);
   }
   dirty = true;
+  query_respond(c, id, flags);
   emit_event(c, n, SIM_EV_QUERY, id, ltime);
   return !(flags & SIM_F_NO_BROADCAST);
 }
@@ -978,7 +1002,7 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
   if (l >= d.Nl) return;
   u32 gid = d.shard0 + l;
   u32 g = gid / tp.M, ll = gid - g * tp.M;
-  Ctx c{d, l, gid, (u32)tp.tick};
+  Ctx c{d, l, gid, (u32)tp.tick, tp.query_base};
   const uint4 zero = make_uint4(0, 0, 0, 0);
   Node n;
   node_load(d, l, n);
@@ -1159,21 +1183,24 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
 struct OpBatch {
   u32 n;
   u32 op[8], node[8], a[8], b[8];
+  u32 c[8];  // SIM_OP_QUERY: tracker index
 };
 __device__ static inline void up_set(const Dev& d, u32 gid, bool up) {
   u32 w = d.upmap[gid >> 5];
   d.upmap[gid >> 5] = up ? (w | (1u << (gid & 31))) : (w & ~(1u << (gid & 31)));
 }
-__global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive) {
+__global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase, u32 q_timeout) {
   if (threadIdx.x || blockIdx.x) return;
   for (u32 i = 0; i < ob.n; ++i) {
     u32 gid = ob.node[i], op = ob.op[i];
     // ground-truth liveness is replicated on every shard (probes read it)
     if (op == SIM_OP_CRASH) up_set(d, gid, false);
     if (op == SIM_OP_REVIVE || op == SIM_OP_JOIN) up_set(d, gid, true);
+    // base.rs:905-930: the QueryResponse is registered before the query goes out (every shard counts its own nodes)
+    if (op == SIM_OP_QUERY) d.qtab[ob.c[i]] = make_uint4(ob.a[i], gid, (u32)tick + q_timeout, ob.b[i]);
     if (gid < d.shard0 || gid >= d.shard0 + d.Nl) continue;
     u32 l = gid - d.shard0;
-    Ctx c{d, l, gid, (u32)tick};
+    Ctx c{d, l, gid, (u32)tick, qbase};
     Node n;
     node_load(d, l, n);
     u32 sk[SIM_Q];
@@ -1274,7 +1301,7 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive) {
 #define PP_GROUPS 8u
 // local <- remote: memberlist mergeState, then merge_remote_state(is_join = false)
 __device__ static void pp_merge(const Dev& d, const TickP& tp, u32 ll, u32 lr) {
-  Ctx c{d, ll, d.shard0 + ll, (u32)tp.tick};
+  Ctx c{d, ll, d.shard0 + ll, (u32)tp.tick, tp.query_base};
   Node n;
   node_load(d, ll, n);
   u32 sk[SIM_Q];
@@ -1434,6 +1461,29 @@ __global__ void digest_flat(const u64* w, size_t n_words, u64* out) {
   for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < n_words; i += (size_t)gridDim.x * BLOCK) acc += dig(w[i], i);
   block_sum_add(acc, out);
 }
+// running queries: tracker table, then the ack / response bitmaps (canonical order = physical order)
+__global__ void digest_queries(const uint4* qtab, const u32* qbits, size_t n_bits_words, u64* out) {
+  u64 acc = 0;
+  for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < 2 * SIM_QT + n_bits_words; i += (size_t)gridDim.x * BLOCK) {
+    if (i < 2 * SIM_QT) {
+      uint4 t = qtab[i >> 1];
+      u64 w = (i & 1) ? ((u64)t.z | ((u64)t.w << 32)) : ((u64)t.x | ((u64)t.y << 32));
+      acc += dig(w, i);
+    } else {
+      acc += dig((u64)qbits[i - 2 * SIM_QT], i);
+    }
+  }
+  block_sum_add(acc, out);
+}
+__global__ void query_count_kernel(const u32* bits, size_t words, u64* out /*[2]*/) {
+  u64 a = 0, r = 0;
+  for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < words; i += (size_t)gridDim.x * BLOCK) {
+    a += __popc(bits[i]);
+    r += __popc(bits[words + i]);
+  }
+  block_sum_add(a, out);
+  block_sum_add(r, out + 1);
+}
 // aux digest: slot map, then the liveness bitmap (bits past N masked)
 __global__ void digest_aux(const u32* slot_of, const u32* upmap, u32 N, u64* out) {
   u64 acc = 0;
@@ -1548,6 +1598,7 @@ struct sim_handle {
   TickP prev;
   bool bound;
   int device;
+  u32 qt_cursor, q_timeout;  // running-query trackers (SIM_QT, round robin); query timeout in ticks
   bool profiling;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof;  // one event pair per tick-kernel launch
   u32 pp_step;  // push-pull batches: every pp_step ticks one of PP_GROUPS pair classes synchronises (0 = off)
@@ -1679,6 +1730,9 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   d.queue_check_interval = cfg->queue_check_interval; d.max_queue_depth = cfg->max_queue_depth;
   d.min_queue_depth = cfg->min_queue_depth;
   d.r3on = d.swim || d.reap_interval;
+  d.loss_u32 = cfg->loss_u32;
+  h->qt_cursor = 0;
+  h->q_timeout = 16u * h_digits10(cfg->n_nodes);  // query.rs:421-427, query_timeout_mult = 16 (options.rs:518)
   h->pp_step = 0;
   if (cfg->push_pull_interval) {  // memberlist pushPullScale: x (ceil(log2 N - 5) + 1) above 32 nodes
     u64 mult = 1;
@@ -1700,6 +1754,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   DA(d.ering, (size_t)d.Bev * Nl * 2)
   DA(d.qring, (size_t)d.Bq * Nl * 2)
   DA(d.slot_of, d.N) DA(d.subject_of, d.A) DA(d.upmap, nup) DA(d.nullcell, 2)
+  DA(d.qtab, SIM_QT) DA(d.qbits, (size_t)SIM_QT * 2 * nup)
   DA(d.events, (size_t)EV_CAP) DA(d.ev_count, 1)
   DA(h->d_base, (size_t)d.N * 2)
   DA(h->d_scratch, 16)
@@ -1714,6 +1769,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   HCHECK(zero(d.qpay, (size_t)SIM_Q * Nl * 16));
   HCHECK(zero(d.ev_count, 4));
   HCHECK(zero(d.nullcell, 32));
+  HCHECK(zero(d.qtab, SIM_QT * 16)); HCHECK(zero(d.qbits, (size_t)SIM_QT * 2 * nup * 4));
   if (!d.sharded) { HCHECK(zero(d.inbox[0], (size_t)d.f * Nl * 64)); HCHECK(zero(d.inbox[1], (size_t)d.f * Nl * 64)); }
   HCHECK(zero(d.view, (size_t)d.A * Nl * 32));
   HCHECK(zero(d.ering, (size_t)d.Bev * Nl * 32));
@@ -1831,9 +1887,15 @@ int sim_step(sim_handle* h, uint32_t n_ticks) {
       while (ob.n < 8 && h->op_cursor < h->ops.size() && h->ops[h->op_cursor].tick <= h->tick) {
         const OpEnt& e = h->ops[h->op_cursor++];
         ob.op[ob.n] = e.op; ob.node[ob.n] = e.node; ob.a[ob.n] = e.a; ob.b[ob.n] = e.b;
+        if (e.op == SIM_OP_QUERY) {  // a fresh tracker: who acked / responded starts empty
+          u32 j = e.a % SIM_QT;
+          size_t words = ((size_t)d.N + 31) / 32;
+          ob.c[ob.n] = j;
+          HCHECK(hipMemsetAsync(d.qbits + (size_t)j * 2 * words, 0, 2 * words * 4, h->stream));
+        }
         ob.n++;
       }
-      ops_kernel<<<1, 64, 0, h->stream>>>(d, ob, h->tick, d.N > 1 ? 1u : 0u);
+      ops_kernel<<<1, 64, 0, h->stream>>>(d, ob, h->tick, d.N > 1 ? 1u : 0u, tp.query_base, h->q_timeout);
     }
     if (h->pp_step && h->tick > 0 && h->tick % h->pp_step == 0) {
       u32 cls = (u32)((h->tick / h->pp_step) % PP_GROUPS);
@@ -1947,9 +2009,10 @@ int sim_state_digest(sim_handle* h, uint64_t out[8]) {
   nw = (size_t)d.Bev * d.Nl * 4; digest_flat<<<grid_for(nw), BLOCK, 0, s>>>((const u64*)d.ering, nw, h->d_scratch + 4);
   nw = (size_t)d.Bq * d.Nl * 4; digest_flat<<<grid_for(nw), BLOCK, 0, s>>>((const u64*)d.qring, nw, h->d_scratch + 5);
   digest_aux<<<grid_for((size_t)d.N + d.N / 32 + 1), BLOCK, 0, s>>>(d.slot_of, d.upmap, d.N, h->d_scratch + 6);
+  nw = (size_t)SIM_QT * 2 * (((size_t)d.N + 31) / 32);
+  digest_queries<<<grid_for(nw + 2 * SIM_QT), BLOCK, 0, s>>>(d.qtab, d.qbits, nw, h->d_scratch + 7);
   HCHECK(hipMemcpyAsync(out, h->d_scratch, 8 * 8, hipMemcpyDeviceToHost, s));
   HCHECK(hipStreamSynchronize(s));
-  out[7] = 0;
   return SIM_OK;
 }
 
@@ -2003,6 +2066,26 @@ int sim_convergence(sim_handle* h, uint32_t kind, uint32_t key, uint64_t ltime, 
   return SIM_OK;
 }
 
+int sim_query_status(sim_handle* h, uint32_t qid, uint64_t* acks, uint64_t* responses, int* open) {
+  if (!h || !acks || !responses || !open || !qid) return SIM_EINVAL;
+  Dev& d = h->d;
+  hipStream_t s = h->stream;
+  u32 j = qid % SIM_QT;
+  uint4 tj;
+  HCHECK(hipMemcpyAsync(&tj, d.qtab + j, sizeof tj, hipMemcpyDeviceToHost, s));
+  HCHECK(hipStreamSynchronize(s));
+  if (tj.x != qid) return SIM_EINVAL;
+  size_t words = ((size_t)d.N + 31) / 32;
+  HCHECK(hipMemsetAsync(h->d_scratch + 10, 0, 16, s));
+  query_count_kernel<<<grid_for(words), BLOCK, 0, s>>>(d.qbits + (size_t)j * 2 * words, words, h->d_scratch + 10);
+  u64 r[2];
+  HCHECK(hipMemcpyAsync(r, h->d_scratch + 10, 16, hipMemcpyDeviceToHost, s));
+  HCHECK(hipStreamSynchronize(s));
+  *acks = r[0];
+  *responses = r[1];
+  *open = (u32)h->tick <= tj.z;
+  return SIM_OK;
+}
 int sim_profile(sim_handle* h, int enable) {
   if (!h) return SIM_EINVAL;
   h->profiling = enable != 0;

@@ -85,6 +85,8 @@ class Serf {
   // api.rs:241 — `name`/`payload` identity is a 32-bit key, `encoded_len` its wire size in bytes
   inline void user_event(uint32_t event_key, uint32_t encoded_len = 32, bool coalesce = true);
   inline void query(uint32_t query_id, uint32_t flags = 0);                   // api.rs:304
+  struct QueryStatus { uint64_t acks, responses; bool open; };                // QueryResponse, query.rs:117-303
+  inline QueryStatus query_status(uint32_t query_id) const;
   inline void join(uint32_t peer);                                            // api.rs:318
   inline void leave();                                                        // api.rs:422
   inline void remove_failed_node(uint32_t id);                                // api.rs:505
@@ -148,6 +150,13 @@ inline Stats Serf::stats() const {
 }
 inline void Serf::user_event(uint32_t key, uint32_t len, bool cc) { check(sim_user_event(c_->raw(), id_, key, len, cc), "sim_user_event"); }
 inline void Serf::query(uint32_t qid, uint32_t flags) { check(sim_query(c_->raw(), id_, qid, flags), "sim_query"); }
+inline Serf::QueryStatus Serf::query_status(uint32_t qid) const {
+  QueryStatus st{0, 0, false};
+  int open = 0;
+  check(sim_query_status(c_->raw(), qid, &st.acks, &st.responses, &open), "sim_query_status");
+  st.open = open != 0;
+  return st;
+}
 inline void Serf::join(uint32_t peer) { check(sim_join(c_->raw(), id_, peer), "sim_join"); }
 inline void Serf::leave() { check(sim_leave(c_->raw(), id_), "sim_leave"); }
 inline void Serf::remove_failed_node(uint32_t id) { check(sim_force_leave(c_->raw(), id_, id, 0), "sim_force_leave"); }

@@ -74,5 +74,11 @@ class ShardedSim:
         dist.all_reduce(t, group=self.group)
         return int(t[0]), int(t[1])
 
+    def query_status(self, query_id):
+        acks, resp, is_open = self.sim.query_status(query_id)   # this shard's responders
+        t = torch.tensor([acks, resp], dtype=torch.int64, device=self.device)
+        dist.all_reduce(t, group=self.group)
+        return int(t[0]), int(t[1]), is_open
+
     def close(self):
         self.sim.close()

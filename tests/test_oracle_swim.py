@@ -392,3 +392,40 @@ def test_push_pull_merges_clocks_and_intents(oracle):
     # b is told "you left at 8" while alive: it refutes with a join at its clock (base.rs:1470-1480), and
     # the next exchange carries that newer status time back to a
     assert a.member(1)[0] == LEFT or a.member(1)[1] > 7
+
+
+def test_query_acks_and_responses_reach_the_origin(oracle):
+    # serf/base.rs:1075-1204 + serf/query.rs:240-303: every node that processes the query acks
+    # (QueryFlag::ACK) and responds; the origin counts each sender once, until the deadline
+    n = 256
+    sim, _ = cluster(oracle, n, fanout=3, probe_interval=0)
+    sim.query(7, 0xABC, _ffi.F_ACK | _ffi.F_RESPOND)
+    sim.query(9, 0xDEF, _ffi.F_ACK)
+    sim.step(1)
+    a, r, is_open = sim.query_status(0xABC)
+    assert (a, r, is_open) == (1, 1, True)          # the origin handles its own query first (base.rs:932)
+    sim.step(30)
+    assert sim.query_status(0xABC) == (n, n, True)
+    assert sim.query_status(0xDEF) == (n, 0, True)
+    sim.step(60)                                     # 16 * ceil(log10(257)) = 48 ticks: closed now
+    assert sim.query_status(0xABC) == (n, n, False)
+    with pytest.raises(_ffi.SimError):
+        sim.query_status(0x123)                      # "reply for non-running query"
+
+
+def test_query_responses_after_the_deadline_or_to_a_dead_origin_are_dropped(oracle):
+    n = 64
+    sim, _ = cluster(oracle, n, fanout=1, probe_interval=0, loss=0.6, retransmit_mult=6)   # slow, lossy spread
+    sim.query(3, 77, _ffi.F_ACK)
+    sim.step(32 + 2)                                 # deadline = 16 * 2 ticks
+    a_deadline = sim.query_status(77)[0]
+    sim.step(200)
+    seen, up = sim.convergence(_ffi.K_QUERY, 77, 1)
+    a_final, _, is_open = sim.query_status(77)
+    assert not is_open and a_final == a_deadline     # nothing is counted after the deadline ...
+    assert seen > a_final                            # ... although more nodes processed the query later
+    sim2, _ = cluster(oracle, n, fanout=3, probe_interval=0)
+    sim2.query(5, 88, _ffi.F_ACK)
+    sim2.inject(1, _ffi.OP_CRASH, 5)                 # the origin dies right after sending
+    sim2.step(30)
+    assert sim2.query_status(88)[0] <= 4             # only what arrived while it was up
