@@ -12,6 +12,29 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
 
 
+def _stale(target, *sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(s) and os.path.getmtime(s) > t for s in sources)
+
+
+def pytest_sessionstart(session):
+    """Build what is missing or older than its source (hipcc cross-compiles gfx950 without a GPU), so
+    that a fresh checkout can run the suite directly; the GPU box receives the built files."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "serf_sim.h")
+    hip = os.path.join(ROOT, "serf_amd", "csrc", "serf_sim.hip")
+    so = os.path.join(ROOT, "serf_amd", "csrc", "libserf_sim.so")
+    if _stale(so, hip, hdr):
+        import shutil
+        if shutil.which("hipcc"):
+            subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", so, hip])
+    osrc = os.path.join(ROOT, "oracle", "serf_oracle.c")
+    if _stale(os.path.join(ROOT, "oracle", "liboracle.so"), osrc, hdr):
+        subprocess.check_call(["make", "-B", "-C", os.path.join(ROOT, "oracle")])
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from tests._oracle import load_oracle
