@@ -56,7 +56,7 @@ def cpu_baseline(fanout, probe_interval, push_pull_interval, rate, seconds_budge
                       f"view_slots=64 rings=64 (CPU oracle, OpenMP over nodes)"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -70,8 +70,13 @@ def main():
     ap.add_argument("--push-pull-interval", type=int, default=150, help="memberlist push_pull_interval in ticks before log2(N) scaling (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence", action="store_true", help="skip the rounds-to-99 %% measurement (profiling runs)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def run(args, lib=None, dev=None, backend="nccl"):
+    """The benchmark proper.  `lib`/`dev`/`backend` exist so that tests/test_bench_plumbing.py can drive the
+    SAME control flow (sharded stepping, all-to-all, convergence, JSON) on CPU with gloo; main() always
+    passes the HIP library, a CUDA device and RCCL."""
     import torch
     import torch.distributed as dist
 
@@ -83,17 +88,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    on_gpu = dev is None
+    if on_gpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if on_gpu:
+            dist.init_process_group(backend, device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     n_total = args.nodes_per_gpu * world
-    lib = serf_amd.load()
+    if lib is None:
+        lib = serf_amd.load()
     kw = dict(fanout=args.fanout, view_slots=args.view_slots, event_ring=args.ring, query_ring=args.ring,
               probe_interval=args.probe_interval, push_pull_interval=args.push_pull_interval,
               reap_interval=75, queue_check_interval=150)  # options.rs defaults: reap 15 s, queue check 30 s, timeouts 24 h
@@ -104,7 +115,8 @@ def main():
         step, inject = sim.step, sim.inject
     else:
         sim = _ffi.Sim(lib, _ffi.make_config(n_total, **kw))
-        sim.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        if on_gpu:
+            sim.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         step, inject = sim.step, sim.inject
     for t, op, node, a, b in ops:
         inject(t, op, node, a, b)
@@ -112,7 +124,22 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
+        else:
+            (sim.sim if world > 1 else sim).sync()
+
+    class _HostEvent:  # CPU stand-in for torch.cuda.Event in the plumbing test
+        def __init__(self, enable_timing=True):
+            self.t = 0.0
+
+        def record(self):
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+
+    Event = torch.cuda.Event if on_gpu else _HostEvent
 
     step(args.warmup)
     barrier()
@@ -123,7 +150,7 @@ def main():
     # tick around sim_step only, so that the all-to-all is not billed to the kernel's roofline.
     t0 = time.perf_counter()
     if world == 1:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0, ev1 = Event(enable_timing=True), Event(enable_timing=True)
         ev0.record()
         step(args.steps)
         ev1.record()
@@ -133,7 +160,7 @@ def main():
     else:
         pairs = []
         for _ in range(args.steps):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a, b = Event(enable_timing=True), Event(enable_timing=True)
             a.record()
             sim.sim.step(1)
             b.record()
@@ -177,7 +204,7 @@ def main():
         bt, bt2 = b_tick_v0(args.fanout), b_tick_layout(args.fanout)
         # dominant kernel = tick_kernel: one launch per tick; HIP events around each launch of the timed
         # region (sim_profile); ev_ms (everything on the stream, ops + push-pull included) for reference
-        kern_s = prof_ms / 1e3 / max(1, prof_n)
+        kern_s = prof_ms / 1e3 / max(1, prof_n) if prof_ms > 0 else ev_ms / 1e3 / args.steps
         achieved = args.nodes_per_gpu * bt / kern_s / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
@@ -211,6 +238,11 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return out if rank == 0 else None
+
+
+def main():
+    run(parse_args())
 
 
 if __name__ == "__main__":
