@@ -201,5 +201,8 @@ def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim):
                     a = s.dump(which).reshape(rows, m)
                     b = np.ascontiguousarray(ref.dump(which).reshape(rows, n)[:, lo:lo + m])
                     assert a.tobytes() == b.tobytes(), f"shard {g} array {which} differs at tick {t}"
+    for qop in [op for op in ops if op[1] == _ffi.OP_QUERY and op[4] & _ffi.F_ACK][:3]:
+        parts = [s.query_status(qop[3]) for s in shards]
+        assert (sum(p[0] for p in parts), sum(p[1] for p in parts), parts[0][2]) == ref.query_status(qop[3])
     tot = [sum(x) for x in zip(*(s.convergence(_ffi.K_LEAVE, next(o for o in ops if o[1] == _ffi.OP_LEAVE)[2], 1) for s in shards))]
     assert tuple(tot) == ref.convergence(_ffi.K_LEAVE, next(o for o in ops if o[1] == _ffi.OP_LEAVE)[2], 1)

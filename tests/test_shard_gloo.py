@@ -50,6 +50,8 @@ def _worker(rank, world, port, n, ticks, swim, q):
                 assert a.tobytes() == np.ascontiguousarray(b).tobytes(), f"rank {rank} array {which} differs at tick {t + 5}"
         ev = next(op for op in ops if op[1] == _ffi.OP_USER_EVENT)
         assert sh.convergence(_ffi.K_EVENT, ev[3], 1) == ref.convergence(_ffi.K_EVENT, ev[3], 1)
+        for qop in [op for op in ops if op[1] == _ffi.OP_QUERY and op[4] & _ffi.F_ACK][:3]:
+            assert sh.query_status(qop[3]) == ref.query_status(qop[3])   # acks summed over the shards
         q.put((rank, "ok"))
     except BaseException as e:  # noqa: BLE001 — report to the parent, then re-raise
         q.put((rank, repr(e)))
