@@ -29,7 +29,7 @@ extern "C" {
 
 /* ------------------------------------------------------------------ constants */
 
-#define SIM_ABI_VERSION 5u
+#define SIM_ABI_VERSION 6u
 
 #define SIM_P 4u  /* piggyback records per gossip packet (64-byte packet)             */
 #define SIM_Q 16u /* retransmit-queue slots per node (all four queues share the pool) */
@@ -308,6 +308,15 @@ int sim_convergence(sim_handle* h, uint32_t kind, uint32_t key, uint64_t ltime,
  * moves send -> recv between sim_step(h,1) calls. */
 int sim_exchange_bytes(const sim_handle* h, size_t* bytes);
 int sim_bind_exchange(sim_handle* h, void* send_dev, void* recv_dev);
+
+/* Checkpoint / resume of the whole simulated cluster (the reference checkpoints one node's members and
+ * clocks, serf-core/src/snapshot.rs:117-126,228-347; here the unit is the simulation).  The image is the
+ * CANONICAL state — the arrays of sim_dump_state plus slot maps, liveness, running queries, the pending
+ * operation schedule and the tick — so an image written by one implementation of this ABI restores into
+ * another.  sim_snapshot with buf == NULL returns the size.  sim_restore needs a handle created with the
+ * same sim_config (checked) that has not been stepped yet; un-drained events are not part of the image. */
+int sim_snapshot(sim_handle* h, void* buf, size_t cap_bytes, size_t* bytes);
+int sim_restore(sim_handle* h, const void* buf, size_t bytes);
 
 /* Query acks and responses (serf-core/src/serf/base.rs:1075-1154 sender side, 1158-1204 and
  * serf/query.rs:240-303 origin side): number of distinct nodes whose ack (QueryFlag::ACK) / response

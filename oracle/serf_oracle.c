@@ -1441,6 +1441,90 @@ int API(dump_state)(osim* s, uint32_t which, void* buf, size_t cap, size_t* byte
   return SIM_OK;
 }
 
+/* =====================================================================================
+ * Checkpoint / resume (include/serf_sim.h sim_snapshot / sim_restore): canonical image.
+ * header, then 13 sections, each = u64 byte count + payload, in this order:
+ * rows, queue, inbox, view, event ring, query ring, slot_of, subject_of, baseline, liveness bitmap,
+ * running-query table, running-query bitmaps, pending operations.
+ * ===================================================================================== */
+typedef struct snap_header {
+  uint32_t magic, abi;
+  sim_config cfg;
+  uint64_t tick;
+  uint32_t n_slots, n_pending_ops;
+  uint32_t prev_rot[SIM_MAX_FANOUT];
+} snap_header;
+#define SNAP_MAGIC 0x53465253u /* "SRFS" */
+#define SNAP_SECTIONS 13
+static void snap_sections(osim* s, const void* ptr[SNAP_SECTIONS], size_t len[SNAP_SECTIONS]) {
+  size_t nup = ((size_t)s->N + 31) / 32;
+  const void* p[SNAP_SECTIONS] = {s->rows, s->queue, cur_inbox(s), s->view, s->ering, s->qring, s->slot_of, s->subject_of,
+                                  s->base, s->upmap, s->qtab, s->qbits, s->ops + s->op_cursor};
+  size_t n[SNAP_SECTIONS] = {(size_t)s->Nl * sizeof(sim_row), (size_t)s->Nl * SIM_Q * sizeof(sim_record),
+                             (size_t)s->f * s->Nl * sizeof(sim_packet), (size_t)s->A * s->Nl * sizeof(sim_view),
+                             (size_t)s->Bev * s->Nl * sizeof(sim_bucket), (size_t)s->Bq * s->Nl * sizeof(sim_bucket),
+                             (size_t)s->N * 4, (size_t)s->A * 4, (size_t)s->N * sizeof(sim_view), nup * 4,
+                             sizeof s->qtab, (size_t)SIM_QT * 2 * nup * 4, (s->n_ops - s->op_cursor) * sizeof(sim_opent)};
+  memcpy(ptr, p, sizeof p);
+  memcpy(len, n, sizeof n);
+}
+int API(snapshot)(osim* s, void* buf, size_t cap, size_t* bytes) {
+  if (!s || !bytes) return SIM_EINVAL;
+  const void* ptr[SNAP_SECTIONS];
+  size_t len[SNAP_SECTIONS], tot = sizeof(snap_header);
+  snap_sections(s, ptr, len);
+  for (int i = 0; i < SNAP_SECTIONS; ++i) tot += 8 + len[i];
+  *bytes = tot;
+  if (!buf) return SIM_OK;
+  if (cap < tot) return SIM_ERANGE;
+  snap_header h;
+  memset(&h, 0, sizeof h);
+  h.magic = SNAP_MAGIC; h.abi = SIM_ABI_VERSION; h.cfg = s->cfg; h.tick = s->tick; h.n_slots = s->n_slots;
+  h.n_pending_ops = (uint32_t)(s->n_ops - s->op_cursor);
+  for (uint32_t k = 0; k < SIM_MAX_FANOUT; ++k) h.prev_rot[k] = s->prev.rot[k];
+  uint8_t* o = (uint8_t*)buf;
+  memcpy(o, &h, sizeof h); o += sizeof h;
+  for (int i = 0; i < SNAP_SECTIONS; ++i) {
+    uint64_t n = len[i];
+    memcpy(o, &n, 8); o += 8;
+    if (n) memcpy(o, ptr[i], n);
+    o += n;
+  }
+  return SIM_OK;
+}
+int API(restore)(osim* s, const void* buf, size_t bytes) {
+  if (!s || !buf || bytes < sizeof(snap_header)) return SIM_EINVAL;
+  if (s->tick != 0 || s->n_ops != 0) return SIM_ESTATE;
+  snap_header h;
+  memcpy(&h, buf, sizeof h);
+  if (h.magic != SNAP_MAGIC || h.abi != SIM_ABI_VERSION || memcmp(&h.cfg, &s->cfg, sizeof(sim_config))) return SIM_EINVAL;
+  s->tick = h.tick;
+  s->n_slots = h.n_slots;
+  /* the pending schedule first: it sizes the last section */
+  s->cap_ops = h.n_pending_ops ? h.n_pending_ops : 1;
+  s->ops = (sim_opent*)realloc(s->ops, s->cap_ops * sizeof(sim_opent));
+  s->n_ops = h.n_pending_ops;
+  s->op_cursor = 0;
+  const void* cptr[SNAP_SECTIONS];
+  size_t len[SNAP_SECTIONS];
+  snap_sections(s, cptr, len);
+  const uint8_t* in = (const uint8_t*)buf + sizeof h;
+  const uint8_t* end = (const uint8_t*)buf + bytes;
+  for (int i = 0; i < SNAP_SECTIONS; ++i) {
+    uint64_t n;
+    if (in + 8 > end) return SIM_EINVAL;
+    memcpy(&n, in, 8); in += 8;
+    if (n != len[i] || in + n > end) return SIM_EINVAL;
+    if (n) memcpy((void*)cptr[i], in, n);
+    in += n;
+  }
+  for (uint32_t k = 0; k < SIM_MAX_FANOUT; ++k) s->prev.rot[k] = h.prev_rot[k];
+  s->prev.V = s->V; s->prev.blk = (s->N / s->V) / s->V; s->prev.M = s->N / s->V;
+  s->n_watched = 0;
+  for (uint32_t l = 0; l < s->Nl; ++l) s->n_watched += (s->rows[l].flags & SIM_RF_WATCHED) != 0;
+  return SIM_OK;
+}
+
 int API(convergence)(osim* s, uint32_t kind, uint32_t key, uint64_t ltime, uint64_t* seen, uint64_t* up) {
   if (!s || !seen || !up) return SIM_EINVAL;
   uint64_t ns = 0, nu = 0;

@@ -78,7 +78,7 @@ _ARR_DTYPE = {ARR_ROWS: ROW_DTYPE, ARR_QUEUE: REC_DTYPE, ARR_INBOX: REC_DTYPE, A
 ABI_SYMBOLS = ("create", "destroy", "set_stream", "join", "leave", "force_leave", "user_event",
                "query", "inject", "step", "sync", "tick", "members", "stats_get", "watch",
                "drain_events", "state_digest", "dump_state", "convergence", "exchange_bytes",
-               "bind_exchange", "query_status", "profile", "profile_read", "abi_version", "backend_name")
+               "bind_exchange", "snapshot", "restore", "query_status", "profile", "profile_read", "abi_version", "backend_name")
 
 
 def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, view_slots=0,
@@ -134,6 +134,8 @@ class SimLib:
             "convergence": (C.c_int, [H, u32, u32, u64, C.POINTER(u64), C.POINTER(u64)]),
             "exchange_bytes": (C.c_int, [H, C.POINTER(C.c_size_t)]),
             "bind_exchange": (C.c_int, [H, vp, vp]),
+            "snapshot": (C.c_int, [H, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+            "restore": (C.c_int, [H, vp, C.c_size_t]),
             "query_status": (C.c_int, [H, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_int)]),
             "profile": (C.c_int, [H, C.c_int]),
             "profile_read": (C.c_int, [H, C.POINTER(C.c_double), C.POINTER(u64)]),
@@ -250,6 +252,18 @@ class Sim:
         seen, up = C.c_uint64(), C.c_uint64()
         self._ck(self.lib.f["convergence"](self.h, kind, key, ltime, C.byref(seen), C.byref(up)), "sim_convergence")
         return seen.value, up.value
+
+    def snapshot(self):
+        """Canonical image of the whole simulated cluster (bytes); restores into any implementation of the ABI."""
+        n = C.c_size_t()
+        self._ck(self.lib.f["snapshot"](self.h, None, 0, C.byref(n)), "sim_snapshot")
+        buf = np.zeros(n.value, np.uint8)
+        self._ck(self.lib.f["snapshot"](self.h, buf.ctypes.data, n.value, C.byref(n)), "sim_snapshot")
+        return buf
+
+    def restore(self, image):
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        self._ck(self.lib.f["restore"](self.h, image.ctypes.data, image.size), "sim_restore")
 
     def query_status(self, query_id):
         """(acks, responses, still_open) of a running query, as its origin counts them (query.rs:240-303)."""

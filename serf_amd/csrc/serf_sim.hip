@@ -1442,6 +1442,36 @@ __global__ void canon_queue_kernel(Dev d, uint4* out) {
   }
 }
 
+// ---- checkpoint / resume: canonical image -> physical layout ----------------------------------------
+__global__ void restore_rows_kernel(Dev d, const u64* in /* [Nl][12] canonical sim_row */) {
+  for (size_t l = blockIdx.x * (size_t)blockDim.x + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * blockDim.x) {
+    const u64* w = in + l * 12;
+    u32 used = d.R2[l].z >> 16;  // set by restore_queue_kernel, which runs first
+    d.R0[l] = make_uint4((u32)w[0], (u32)(w[0] >> 32), (u32)w[1], (u32)(w[1] >> 32));
+    d.R1[l] = make_uint4((u32)w[2], (u32)(w[2] >> 32), (u32)w[5], (u32)w[6]);
+    d.R2[l] = make_uint4((u32)(w[6] >> 32), (u32)w[7], ((u32)(w[7] >> 32) & 0xFFFFu) | (used << 16), (u32)w[8]);
+    d.R3[l] = make_uint4((u32)(w[5] >> 32), (u32)(w[8] >> 32), (u32)w[9], (u32)(w[9] >> 32));
+    d.R4[l] = make_uint4((u32)w[10], (u32)(w[10] >> 32), (u32)w[11], (u32)(w[11] >> 32));
+    d.R5[l] = make_uint4((u32)w[3], (u32)(w[3] >> 32), (u32)w[4], (u32)(w[4] >> 32));
+  }
+}
+__global__ void restore_queue_kernel(Dev d, const uint4* in /* [Nl][Q] canonical sim_record, drain order */) {
+  for (size_t l = blockIdx.x * (size_t)blockDim.x + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * blockDim.x) {
+    u32 k[SIM_Q], cnt = 0;
+    for (u32 i = 0; i < SIM_Q; ++i) {
+      uint4 r = in[l * SIM_Q + i];
+      if (r.y == SIM_META_EMPTY) { k[i] = KEMPTY; continue; }
+      k[i] = ((r.y >> 8) << 4) | i;  // payload slot = rank
+      d.qpay[(size_t)i * d.Nl + l] = make_uint4(r.x, r.y & SIM_META_WIRE_MASK, r.z, r.w);
+      cnt++;
+    }
+    for (u32 g = 0; g < 4; ++g) d.qkeys[(size_t)g * d.Nl + l] = make_uint4(k[4 * g], k[4 * g + 1], k[4 * g + 2], k[4 * g + 3]);
+    uint4 r2 = d.R2[l];
+    r2.z = (r2.z & 0xFFFFu) | (((1u << cnt) - 1u) << 16);
+    d.R2[l] = r2;
+  }
+}
+
 __device__ static inline u64 dig(u64 w, u64 idx) { return mix64(w ^ (idx * 0xD1342543DE82EF95ull)); }
 __device__ static inline void block_sum_add(u64 v, u64* out) {
   __shared__ u64 sm[BLOCK / 64];
@@ -2066,6 +2096,117 @@ int sim_convergence(sim_handle* h, uint32_t kind, uint32_t key, uint64_t ltime, 
   return SIM_OK;
 }
 
+// ---- checkpoint / resume (canonical image; layout documented in oracle/serf_oracle.c and DESIGN.md) ----
+struct snap_header {
+  uint32_t magic, abi;
+  sim_config cfg;
+  uint64_t tick;
+  uint32_t n_slots, n_pending_ops;
+  uint32_t prev_rot[SIM_MAX_FANOUT];
+};
+#define SNAP_MAGIC 0x53465253u
+#define SNAP_SECTIONS 13
+static void snap_lengths(const sim_handle* h, size_t len[SNAP_SECTIONS]) {
+  const Dev& d = h->d;
+  size_t nup = ((size_t)d.N + 31) / 32;
+  size_t n[SNAP_SECTIONS] = {(size_t)d.Nl * sizeof(sim_row), (size_t)d.Nl * SIM_Q * sizeof(sim_record),
+                             (size_t)d.f * d.Nl * sizeof(sim_packet), (size_t)d.A * d.Nl * sizeof(sim_view),
+                             (size_t)d.Bev * d.Nl * sizeof(sim_bucket), (size_t)d.Bq * d.Nl * sizeof(sim_bucket),
+                             (size_t)d.N * 4, (size_t)d.A * 4, (size_t)d.N * sizeof(sim_view), nup * 4,
+                             (size_t)SIM_QT * 16, (size_t)SIM_QT * 2 * nup * 4, (h->ops.size() - h->op_cursor) * sizeof(OpEnt)};
+  memcpy(len, n, sizeof n);
+}
+int sim_snapshot(sim_handle* h, void* buf, size_t cap, size_t* bytes) {
+  if (!h || !bytes) return SIM_EINVAL;
+  Dev& d = h->d;
+  size_t len[SNAP_SECTIONS], tot = sizeof(snap_header);
+  snap_lengths(h, len);
+  for (int i = 0; i < SNAP_SECTIONS; ++i) tot += 8 + len[i];
+  *bytes = tot;
+  if (!buf) return SIM_OK;
+  if (cap < tot) return SIM_ERANGE;
+  HCHECK(hipStreamSynchronize(h->stream));
+  snap_header hd;
+  memset(&hd, 0, sizeof hd);
+  hd.magic = SNAP_MAGIC; hd.abi = SIM_ABI_VERSION; hd.cfg = h->cfg; hd.tick = h->tick; hd.n_slots = h->n_slots;
+  hd.n_pending_ops = (uint32_t)(h->ops.size() - h->op_cursor);
+  for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) hd.prev_rot[k] = h->prev.rot[k];
+  uint8_t* o = (uint8_t*)buf;
+  memcpy(o, &hd, sizeof hd); o += sizeof hd;
+  const uint32_t dumps[6] = {SIM_ARR_ROWS, SIM_ARR_QUEUE, SIM_ARR_INBOX, SIM_ARR_VIEW, SIM_ARR_ERING, SIM_ARR_QRING};
+  for (int i = 0; i < SNAP_SECTIONS; ++i) {
+    uint64_t n = len[i];
+    memcpy(o, &n, 8); o += 8;
+    if (i < 6) {
+      size_t got = 0;
+      int rc = sim_dump_state(h, dumps[i], o, n, &got);
+      if (rc) return rc;
+    } else if (i == 6) memcpy(o, h->slot_of.data(), n);
+    else if (i == 7) memcpy(o, h->subject_of.data(), n);
+    else if (i == 8) memcpy(o, h->base.data(), n);
+    else if (i == 9) HCHECK(hipMemcpy(o, d.upmap, n, hipMemcpyDeviceToHost));
+    else if (i == 10) HCHECK(hipMemcpy(o, d.qtab, n, hipMemcpyDeviceToHost));
+    else if (i == 11) HCHECK(hipMemcpy(o, d.qbits, n, hipMemcpyDeviceToHost));
+    else if (n) memcpy(o, h->ops.data() + h->op_cursor, n);
+    o += n;
+  }
+  return SIM_OK;
+}
+int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
+  if (!h || !buf || bytes < sizeof(snap_header)) return SIM_EINVAL;
+  if (h->tick != 0 || !h->ops.empty()) return SIM_ESTATE;
+  Dev& d = h->d;
+  snap_header hd;
+  memcpy(&hd, buf, sizeof hd);
+  if (hd.magic != SNAP_MAGIC || hd.abi != SIM_ABI_VERSION || memcmp(&hd.cfg, &h->cfg, sizeof(sim_config))) return SIM_EINVAL;
+  h->tick = hd.tick;
+  h->n_slots = hd.n_slots;
+  h->ops.assign(hd.n_pending_ops, OpEnt{0, 0, 0, 0, 0});
+  h->op_cursor = 0;
+  for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) h->prev.rot[k] = hd.prev_rot[k];
+  size_t len[SNAP_SECTIONS];
+  snap_lengths(h, len);
+  const uint8_t* in = (const uint8_t*)buf + sizeof hd;
+  const uint8_t* end = (const uint8_t*)buf + bytes;
+  hipStream_t s = h->stream;
+  void* tmp_rows = nullptr;
+  void* tmp_queue = nullptr;
+  for (int i = 0; i < SNAP_SECTIONS; ++i) {
+    uint64_t n;
+    if (in + 8 > end) return SIM_EINVAL;
+    memcpy(&n, in, 8); in += 8;
+    if (n != len[i] || in + n > end) return SIM_EINVAL;
+    switch (i) {
+      case 0: if (hipMalloc(&tmp_rows, std::max<size_t>(n, 16)) != hipSuccess) return SIM_ENOMEM;
+              HCHECK(hipMemcpy(tmp_rows, in, n, hipMemcpyHostToDevice)); break;
+      case 1: if (hipMalloc(&tmp_queue, std::max<size_t>(n, 16)) != hipSuccess) return SIM_ENOMEM;
+              HCHECK(hipMemcpy(tmp_queue, in, n, hipMemcpyHostToDevice)); break;
+      case 2: { uint4* dst = d.sharded ? d.xrecv : d.inbox[h->tick & 1];
+                if (n && !dst) return SIM_ESTATE;  // sharded: bind the exchange buffers first
+                if (n) HCHECK(hipMemcpy(dst, in, n, hipMemcpyHostToDevice)); break; }
+      case 3: if (n) HCHECK(hipMemcpy(d.view, in, n, hipMemcpyHostToDevice)); break;
+      case 4: if (n) HCHECK(hipMemcpy(d.ering, in, n, hipMemcpyHostToDevice)); break;
+      case 5: if (n) HCHECK(hipMemcpy(d.qring, in, n, hipMemcpyHostToDevice)); break;
+      case 6: memcpy(h->slot_of.data(), in, n); HCHECK(hipMemcpy(d.slot_of, in, n, hipMemcpyHostToDevice)); break;
+      case 7: memcpy(h->subject_of.data(), in, n); HCHECK(hipMemcpy(d.subject_of, in, n, hipMemcpyHostToDevice)); break;
+      case 8: memcpy(h->base.data(), in, n); HCHECK(hipMemcpy(h->d_base, in, n, hipMemcpyHostToDevice)); break;
+      case 9: HCHECK(hipMemcpy(d.upmap, in, n, hipMemcpyHostToDevice)); break;
+      case 10: HCHECK(hipMemcpy(d.qtab, in, n, hipMemcpyHostToDevice)); break;
+      case 11: HCHECK(hipMemcpy(d.qbits, in, n, hipMemcpyHostToDevice)); break;
+      default: if (n) memcpy(h->ops.data(), in, n); break;
+    }
+    in += n;
+  }
+  // canonical rows / queue -> packed row groups, sort keys + slot-stable payloads
+  HCHECK(hipMemsetAsync(d.R2, 0, (size_t)d.Nl * 16, s));
+  restore_queue_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, (const uint4*)tmp_queue);
+  restore_rows_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, (const u64*)tmp_rows);
+  hipError_t e = hipStreamSynchronize(s);
+  (void)hipFree(tmp_rows);
+  (void)hipFree(tmp_queue);
+  HCHECK(e);
+  return SIM_OK;
+}
 int sim_query_status(sim_handle* h, uint32_t qid, uint64_t* acks, uint64_t* responses, int* open) {
   if (!h || !acks || !responses || !open || !qid) return SIM_EINVAL;
   Dev& d = h->d;

@@ -127,6 +127,15 @@ class Cluster {
     check(sim_convergence(h_, kind, key, ltime, &seen, &up), "sim_convergence");
     return up ? (double)seen / (double)up : 0.0;
   }
+  // checkpoint / resume (canonical image; snapshot.rs:117-126,228-347 is the per-node analogue)
+  std::vector<uint8_t> snapshot() {
+    size_t n = 0;
+    check(sim_snapshot(h_, nullptr, 0, &n), "sim_snapshot");
+    std::vector<uint8_t> img(n);
+    check(sim_snapshot(h_, img.data(), img.size(), &n), "sim_snapshot");
+    return img;
+  }
+  void restore(const std::vector<uint8_t>& img) { check(sim_restore(h_, img.data(), img.size()), "sim_restore"); }
   sim_handle* raw() { return h_; }
 
  private:
