@@ -68,3 +68,34 @@ def test_oracle_image_resumes_on_hip_and_back(oracle, hiplib, vshards):
     g.step(20)
     assert b.digest() == g.digest()
     assert np.array_equal(img2[:64], a.snapshot()[:64])   # same header for the same state
+
+
+@pytest.mark.gpu
+def test_huge_lamport_times_and_odd_ring_sizes(oracle, hiplib):
+    # state no API call can reach quickly — Lamport clocks beyond 2^32, rings whose size is not a power
+    # of two (64-bit modulo on the device), the query ring past quirk Q1's 2*B horizon — is built on the
+    # oracle through its test hooks, carried over as a snapshot image, and must evolve identically on HIP
+    from tests._oracle import Node
+    n = 200
+    kw = dict(KW, event_ring=12, query_ring=7, view_slots=40)
+    a = _ffi.Sim(oracle, _ffi.make_config(n, **kw))
+    for node, (c, e, q) in {3: (2 ** 33 + 5, 2 ** 34 + 1, 9), 77: (5, 2 ** 32 - 2, 2 ** 40), 150: (2 ** 63, 11, 13)}.items():
+        nd = Node(oracle, a, node)
+        nd.set_clock(Node.CLOCK, c)
+        nd.set_clock(Node.EVENT, e)
+        nd.set_clock(Node.QUERY, q)
+    # EventCore / QueryCore min_time (snapshot restore, event_join_ignore: base.rs:146-147, delegate.rs:531-537)
+    assert oracle.t["set_min_time"](a.h, 10, 1, 3) == 0
+    assert oracle.t["set_min_time"](a.h, 11, 2, 2) == 0
+    sc.apply_schedule(a, sc.schedule(n, 50, rate=1.0, seed=8, max_member_subjects=30))
+    for t, node in ((1, 3), (2, 77), (3, 150), (4, 3)):
+        a.inject(t, _ffi.OP_USER_EVENT, node, 9000 + t, 40)
+        a.inject(t, _ffi.OP_QUERY, node, 9100 + t, _ffi.F_ACK)
+    img = a.snapshot()
+    g = resume(hiplib, n, kw, img)
+    for t in range(8):
+        a.step(10)
+        g.step(10)
+        assert a.digest() == g.digest(), f"diverged after {10 * (t + 1)} ticks"
+    sc.assert_same_state(g, a, "huge clocks")
+    assert a.dump(_ffi.ARR_ROWS)["event_clock"].max() > 2 ** 34
