@@ -1001,7 +1001,8 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
   u32 l = blockIdx.x * BLOCK + threadIdx.x;
   if (l >= d.Nl) return;
   u32 gid = d.shard0 + l;
-  u32 g = gid / tp.M, ll = gid - g * tp.M;
+  // V == 1 (one shard holds everything) is wave-uniform: no divisions by run-time values on that path
+  u32 g = tp.V == 1 ? 0u : gid / tp.M, ll = gid - g * tp.M;
   Ctx c{d, l, gid, (u32)tp.tick, tp.query_base};
   const uint4 zero = make_uint4(0, 0, 0, 0);
   Node n;
@@ -1158,8 +1159,11 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
     u32 y = sx + tp.off[k];
     if (y >= tp.M) y -= tp.M;
     u32 t = sigma_inv(tp, y);
-    u32 b = t / tp.blk;
-    u32 h = (g + tp.V - ((b + tp.rot[k]) % tp.V)) % tp.V;
+    u32 b = 0, h = 0;
+    if (tp.V != 1) {
+      b = t / tp.blk;
+      h = (g + tp.V - ((b + tp.rot[k]) % tp.V)) % tp.V;
+    }
     uint4* dst;
     if (SHARDED) dst = d.xsend + (((size_t)h * d.f + k) * tp.blk + (t - b * tp.blk)) * 4;
     else dst = d.inbox[cur ^ 1] + ((size_t)k * d.Nl + (size_t)h * tp.M + t) * 4;

@@ -6,9 +6,11 @@ from serf_amd import _ffi
 from tests import _scenario as sc
 lib = _ffi.SimLib(os.path.join(os.path.dirname(serf_amd.LIB_PATH), "libserf_sim_timing.so"))
 swim = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-n = 1 << 20
-sim = _ffi.Sim(lib, _ffi.make_config(n, fanout=4, view_slots=1024, event_ring=512, query_ring=512, probe_interval=swim))
-for t, op, node, a, b in sc.schedule(n, 200, rate=0.5, seed=3, max_member_subjects=512):
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 20
+sim = _ffi.Sim(lib, _ffi.make_config(n, fanout=4, view_slots=1024, event_ring=512, query_ring=512, probe_interval=swim,
+                                     push_pull_interval=150 if swim else 0, reap_interval=75 if swim else 0))
+import bench
+for t, op, node, a, b in sc.schedule(n, 200, rate=0.4, seed=3, mix=bench.MIX, max_member_subjects=512, even=True):
     sim.inject(t, op, node, a, b)
 sim.step(100); sim.sync()
 buf = (C.c_ulonglong * 16)()
