@@ -264,6 +264,7 @@ int sim_join(sim_handle* h, uint32_t node, uint32_t peer);
 int sim_leave(sim_handle* h, uint32_t node);
 int sim_force_leave(sim_handle* h, uint32_t node, uint32_t subject, int prune);
 int sim_user_event(sim_handle* h, uint32_t node, uint32_t event_key, uint32_t encoded_len, int coalesce);
+/* flags: SIM_F_NO_BROADCAST | SIM_F_ACK | SIM_F_RESPOND, and QueryParam.relay_factor (0..7) in bits [10:8]. */
 int sim_query(sim_handle* h, uint32_t node, uint32_t query_id, uint32_t flags);
 /* Churn / packet-loss / kill / revive schedule: run `op` on `node` at the start of tick `tick`
  * (reference analogue: MessageDropper delegate.rs:42-45 and tests that shutdown() a node). */

@@ -548,6 +548,7 @@ static int handle_user_event(nctx* c, uint32_t key, uint64_t ltime) {
   return 1;
 }
 
+static inline uint32_t draw_below_early(uint64_t draw, uint32_t n) { return (uint32_t)(((draw >> 32) * (uint64_t)n) >> 32); }
 static inline int up_of_early(const osim* s, uint32_t gid) { return (s->upmap[gid >> 5] >> (gid & 31)) & 1u; }
 /* The responder half of handle_query (base.rs:1075-1154): ack without waiting for the user
  * (QueryFlag::ACK), response when the simulated user code calls respond() (SIM_F_RESPOND); both go
@@ -564,9 +565,20 @@ static void query_respond(nctx* c, uint32_t id, uint32_t flags) {
   if (now > s->qtab[j].deadline || !up_of_early(s, s->qtab[j].origin)) return;
   uint64_t base = mix64(rng_base(s->cfg.seed, STREAM_QUERY, s->tick) ^ ((uint64_t)id << 32));
   size_t words = ((size_t)s->N + 31) / 32;
+  uint32_t relay = (s->qtab[j].flags >> 8) & 7u; /* QueryMessage.relay_factor (query.rs:523-601) */
+  if (s->N < relay + 1) relay = 0;               /* "members.states.len() < relay_factor + 1" */
   for (uint32_t which = 0; which < 2; ++which) {
     if (!(flags & (which ? SIM_F_RESPOND : SIM_F_ACK))) continue;
-    if (s->cfg.loss_u32 && (uint32_t)(mix64(base ^ ((uint64_t)c->gid * 4u + which)) >> 32) < s->cfg.loss_u32) continue;
+    uint64_t lane = (uint64_t)c->gid * 64u + which * 32u;
+#define QLOST(i) (s->cfg.loss_u32 && (uint32_t)(mix64(base ^ (lane + (i))) >> 32) < s->cfg.loss_u32)
+    int ok = !QLOST(0); /* memberlist.send straight to the origin (base.rs:1097) */
+    for (uint32_t r = 0; !ok && r < relay; ++r) { /* relay_response: via a random live member, two more legs */
+      uint32_t via = draw_below_early(mix64(base ^ (lane + 1 + 3 * r)), s->N);
+      if (via == c->gid || !up_of_early(s, via)) continue;
+      ok = !QLOST(2 + 3 * r) && !QLOST(3 + 3 * r);
+    }
+#undef QLOST
+    if (!ok) continue;
     uint32_t* w = &s->qbits[((size_t)j * 2 + which) * words + (c->gid >> 5)];
     __atomic_fetch_or(w, 1u << (c->gid & 31), __ATOMIC_RELAXED);
   }

@@ -621,9 +621,20 @@ __device__ static void query_respond(const Ctx& c, u32 id, u32 flags) {
   if (c.tick > t.z || !((d.upmap[t.y >> 5] >> (t.y & 31)) & 1u)) return;
   u64 base = mix64(c.qbase ^ ((u64)id << 32));
   size_t words = ((size_t)d.N + 31) / 32;
+  u32 relay = (t.w >> 8) & 7u;  // QueryMessage.relay_factor (query.rs:523-601)
+  if (d.N < relay + 1) relay = 0;
   for (u32 which = 0; which < 2; ++which) {
     if (!(flags & (which ? SIM_F_RESPOND : SIM_F_ACK))) continue;
-    if (d.loss_u32 && (u32)(mix64(base ^ ((u64)c.gid * 4u + which)) >> 32) < d.loss_u32) continue;
+    u64 lane = (u64)c.gid * 64u + which * 32u;
+#define QLOST(i) (d.loss_u32 && (u32)(mix64(base ^ (lane + (i))) >> 32) < d.loss_u32)
+    bool ok = !QLOST(0);  // memberlist.send straight to the origin (base.rs:1097)
+    for (u32 r = 0; !ok && r < relay; ++r) {  // relay_response: via a random live member, two more legs
+      u32 via = (u32)(((mix64(base ^ (lane + 1 + 3 * r)) >> 32) * (u64)d.N) >> 32);
+      if (via == c.gid || !((d.upmap[via >> 5] >> (via & 31)) & 1u)) continue;
+      ok = !QLOST(2 + 3 * r) && !QLOST(3 + 3 * r);
+    }
+#undef QLOST
+    if (!ok) continue;
     atomicOr(&d.qbits[((size_t)j * 2 + which) * words + (c.gid >> 5)], 1u << (c.gid & 31));
   }
 }

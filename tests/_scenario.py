@@ -28,7 +28,7 @@ def schedule(n_nodes, n_ticks, rate, seed=1234, mix=(0.5, 0.15, 0.15, 0.1, 0.1),
             ops.append((t, _ffi.OP_USER_EVENT, node, key, int(rng.integers(16, 512))))
             key += 1
         elif k == 1:
-            ops.append((t, _ffi.OP_QUERY, node, key, int(rng.choice([0, _ffi.F_ACK, _ffi.F_ACK | _ffi.F_RESPOND]))))
+            ops.append((t, _ffi.OP_QUERY, node, key, int(rng.choice([0, _ffi.F_ACK, _ffi.F_ACK | _ffi.F_RESPOND, _ffi.F_ACK | _ffi.F_RESPOND | (2 << 8)]))))
             key += 1
         else:
             while node in used:

@@ -429,3 +429,18 @@ def test_query_responses_after_the_deadline_or_to_a_dead_origin_are_dropped(orac
     sim2.inject(1, _ffi.OP_CRASH, 5)                 # the origin dies right after sending
     sim2.step(30)
     assert sim2.query_status(88)[0] <= 4             # only what arrived while it was up
+
+
+def test_query_relays_rescue_lost_acks(oracle):
+    # query.rs:523-601 relay_response: with relay_factor r every ack also travels through r random live
+    # members; under heavy loss more acks reach the origin, each sender still counted once
+    n, got = 512, {}
+    for relay in (0, 3):
+        sim, _ = cluster(oracle, n, fanout=3, probe_interval=0, loss=0.5, retransmit_mult=6)
+        sim.query(1, 555, _ffi.F_ACK | (relay << 8))
+        sim.step(45)
+        got[relay] = sim.query_status(555)[0]
+        seen, up = sim.convergence(_ffi.K_QUERY, 555, 1)
+        assert got[relay] <= seen <= n
+    assert 0.35 * n < got[0] < 0.65 * n          # one lossy leg: about half arrive
+    assert got[3] > got[0] + 0.15 * n            # 1 - 0.5 * (1 - 0.25)^3 ~ 0.79
