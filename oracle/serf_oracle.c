@@ -13,10 +13,15 @@
  *     de-dup rings, notify_join/notify_leave, push-pull merge, reaper, queue cap) are PINNED by the
  *     reference's own known-answer tests, restated in tests/test_oracle_kat.py.
  *   - memberlist-core 0.8.1 (TransmitLimitedQueue order/limit, gossip peer selection, probe and
- *     suspicion timing) is NOT in /root/reference: its published algorithm is restated from
- *     SURVEY.md App. B and is "parity unpinned".
+ *     suspicion timing, push-pull scheduling) is NOT in /root/reference: its published algorithm is
+ *     restated from SURVEY.md App. B and is "parity unpinned" (tests/test_oracle_swim.py pins the
+ *     oracle to App. B and replays the reference's event-sequence tests as deterministic scenarios).
+ *   - query acks / responses / relays (base.rs:1075-1204, query.rs:240-303,523-601) follow the
+ *     reference's code; no reference test pins their counts (query_deduplicate, event.rs:995-1073,
+ *     pins the de-duplication by sender, which the per-sender bit reproduces).
+ *   - whole-cluster behaviour is frozen in tests/golden/digests.json (made by tools/make_golden.py).
  *
- * Build: make -C oracle   (gcc -O3 -march=native -std=c11 -fopenmp)
+ * Build: make -C oracle   (gcc -O3 -march=x86-64-v2 -std=c11 -fopenmp -lm)
  */
 #include "../include/serf_sim.h"
 
