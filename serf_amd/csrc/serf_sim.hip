@@ -934,38 +934,39 @@ __device__ static void queue_check(const Ctx& c, Node& n, SK sk) {
 // Anything else (a new rumour, a refutation, a confirmation...) is left to the full handlers.
 // The conditions are the early `return false` exits of the handlers, in the handlers' order.
 __device__ static inline bool fast_noop(const Ctx& c, const Node& n, u32 kind, const uint4& r, bool has, const uint4& e) {
-  // written with selects, not branches: this runs for every record of every node
+  // Straight-line predicate logic (& and |, no ?: on booleans, no short-circuit): this runs for
+  // every record of every node, and the lane masks combine on the scalar unit.
   const Dev& d = c.d;
   u64 lt = (u64)r.z | ((u64)r.w << 32), elt = E_LTIME(e);
-  bool isev = kind == SIM_K_EVENT, isq = kind == SIM_K_QUERY, isjl = kind == SIM_K_JOIN || kind == SIM_K_LEAVE;
+  bool isev = kind == SIM_K_EVENT, isq = kind == SIM_K_QUERY, isring = isev | isq;
+  bool isjl = (kind - SIM_K_JOIN) < 2u, isswim = (kind - SIM_K_ALIVE) < 3u;
   bool known = e.w & SIM_VB_KNOWN;
   // rings — handle_user_event base.rs:750-837, handle_query base.rs:972-1073
   u64 clk = isev ? n.eclock : n.qclock, B = isev ? d.Bev : d.Bq;
-  u64 cur = lt >= clk ? lt + 1 : clk;
-  bool old = cur > B && (isev ? lt < cur - B : B < cur - B);
-  bool dup = e.z != 0 && (isev || elt == lt) && (e.z == r.x || e.w == r.x);
-  bool ring_fast = !(n.flags & SIM_RF_MINTIME) && (old || dup);
+  u64 cur = lt >= clk ? lt + 1 : clk, lo = cur - B;
+  bool old = (cur > B) & ((isev & (lt < lo)) | (isq & (B < lo)));
+  bool dup = (e.z != 0) & (isev | (elt == lt)) & ((e.z == r.x) | (e.w == r.x));
+  bool ring_fast = !(n.flags & SIM_RF_MINTIME) & (old | dup);
   // intents — base.rs:1338-1373, 1442-1572
-  bool jl_fast = !has || (known ? lt <= elt : (SIM_VB_INTENT(e.w) != 0 && !(lt > elt)));
+  bool jl_fast = !has | ((lt <= elt) & (known | (SIM_VB_INTENT(e.w) != 0)));
   // memberlist — App. B.4
   u32 sw = SIM_VB_SWIM(e.w);
-  bool alive_fast = r.x == c.gid ? r.z <= n.inc : (known && r.z <= e.z);
-  bool susp_fast = sw == SIM_SWIM_SUSPECT ? SIM_VB_NCONF(e.w) >= d.kconf : sw != SIM_SWIM_ALIVE;
-  bool dead_fast = sw == SIM_SWIM_DEAD || sw == SIM_SWIM_LEFT;
-  bool sd_fast = !known || r.z < e.z || (kind == SIM_K_SUSPECT ? susp_fast : dead_fast);
-  bool swim_fast = !d.swim || !has || (kind == SIM_K_ALIVE ? alive_fast : sd_fast);
-  bool other = kind == SIM_K_EMPTY || kind > SIM_K_DEAD;
-  return (isev || isq) ? ring_fast : isjl ? jl_fast : (other || swim_fast);
+  bool self = r.x == c.gid;
+  bool alive_fast = (self & (r.z <= n.inc)) | (!self & known & (r.z <= e.z));
+  bool gone = sw >= SIM_SWIM_DEAD;  // dead or left
+  bool sd_fast = !known | (r.z < e.z) | gone | ((kind == SIM_K_SUSPECT) & (sw == SIM_SWIM_SUSPECT) & (SIM_VB_NCONF(e.w) >= d.kconf));
+  bool swim_fast = !d.swim | !has | ((kind == SIM_K_ALIVE) ? alive_fast : sd_fast);
+  return (isring & ring_fast) | (isjl & jl_fast) | (isswim & swim_fast) | !(isring | isjl | isswim);
 }
 __device__ static inline void fast_witness(Node& n, u32 kind, const uint4& r, bool apply) {
   u64 lt = (u64)r.z | ((u64)r.w << 32);
-  bool ev = apply && kind == SIM_K_EVENT && lt >= n.eclock;
-  bool qu = apply && kind == SIM_K_QUERY && lt >= n.qclock;
-  bool jl = apply && (kind == SIM_K_JOIN || kind == SIM_K_LEAVE) && lt >= n.clock;
+  bool ev = apply & (kind == SIM_K_EVENT) & (lt >= n.eclock);
+  bool qu = apply & (kind == SIM_K_QUERY) & (lt >= n.qclock);
+  bool jl = apply & ((kind - SIM_K_JOIN) < 2u) & (lt >= n.clock);
   n.eclock = ev ? lt + 1 : n.eclock;
   n.qclock = qu ? lt + 1 : n.qclock;
   n.clock = jl ? lt + 1 : n.clock;
-  n.dirty |= ((ev || jl) ? DR0 : 0u) | (qu ? DR1 : 0u);
+  n.dirty |= ((ev | jl) ? DR0 : 0u) | (qu ? DR1 : 0u);
 }
 __device__ static inline void dispatch(const Ctx& c, Node& n, const uint4& r, uint4* p, const uint4& e, bool& dirty, Ins& ins) {
   u32 kind = SIM_META_KIND(r.y), flags = SIM_META_FLAGS(r.y);
@@ -1151,14 +1152,19 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
   }
   TT(8);
   // ... then every payload gather of the tick in flight at once (one memory round trip, not F) ...
+  // A queue of at most SIM_P entries sends the same records in every round: a record that sits
+  // in the same place as in the previous packet is copied, not gathered again (the gathers are
+  // scattered 16-byte accesses, one address per lane for the texture addresser).
   uint4 pk[F][SIM_P];
 #pragma unroll
   for (int k = 0; k < F; ++k) {
 #pragma unroll
     for (int p = 0; p < (int)SIM_P; ++p) {
       u32 s = (slots[k] >> (8 * p)) & 0xFFu;
+      bool again = k > 0 && s == ((slots[k > 0 ? k - 1 : 0] >> (8 * p)) & 0xFFu);
       pk[k][p] = zero;
-      if (s != 0xFFu) pk[k][p] = ld4(&d.qpay[(size_t)s * d.Nl + l]);
+      if (again) pk[k][p] = pk[k > 0 ? k - 1 : 0][p];
+      else if (s != 0xFFu) pk[k][p] = ld4(&d.qpay[(size_t)s * d.Nl + l]);
     }
   }
   TT(9);
