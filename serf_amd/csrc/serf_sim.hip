@@ -1170,6 +1170,7 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
   TT(9);
   // ... then the F scatters: packet k goes to the inbox cell of T_k(l)
   u32 sx = tp.feff ? sigma(tp, ll) : 0;
+  const bool coop = (blockIdx.x + 1u) * BLOCK <= d.Nl;  // every lane of the block is here
 #pragma unroll
   for (int k = 0; k < F; ++k) {
     if ((u32)k >= tp.feff) break;
@@ -1184,7 +1185,28 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
     uint4* dst;
     if (SHARDED) dst = d.xsend + (((size_t)h * d.f + k) * tp.blk + (t - b * tp.blk)) * 4;
     else dst = d.inbox[cur ^ 1] + ((size_t)k * d.Nl + (size_t)h * tp.M + t) * 4;
-    dst[0] = pk[k][0]; dst[1] = pk[k][1]; dst[2] = pk[k][2]; dst[3] = pk[k][3];
+    if (coop) {
+      // Four lanes write one 64-byte cell per store instruction (lane i of the quad writes record
+      // i of quad-mate j's packet): the texture addresser sees 64 contiguous bytes per quad and L2
+      // one write per cell instead of four.  The 4x4 transpose goes through this wave's columns of
+      // lds_r (free in phase 2), XOR-swizzled so that neither side has bank conflicts.
+      lds_r[0][tid] = pk[k][0]; lds_r[1][tid ^ 1] = pk[k][1]; lds_r[2][tid ^ 2] = pk[k][2]; lds_r[3][tid ^ 3] = pk[k][3];
+      __builtin_amdgcn_wave_barrier();
+      u32 qi = tid & 3u, qb = tid & ~3u;
+      u32 dlo = (u32)(uintptr_t)dst, dhi = (u32)((uintptr_t)dst >> 32);
+#define COOP_STORE(j)                                                                              \
+      {                                                                                            \
+        uint4 v = lds_r[qi][(qb + j) ^ qi];                                                        \
+        u32 lo = (u32)__builtin_amdgcn_mov_dpp((int)dlo, j * 0x55, 0xF, 0xF, true);                \
+        u32 hi = (u32)__builtin_amdgcn_mov_dpp((int)dhi, j * 0x55, 0xF, 0xF, true);                \
+        ((uint4*)(((uintptr_t)hi << 32) | lo))[qi] = v;                                            \
+      }
+      COOP_STORE(0) COOP_STORE(1) COOP_STORE(2) COOP_STORE(3)
+#undef COOP_STORE
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      dst[0] = pk[k][0]; dst[1] = pk[k][1]; dst[2] = pk[k][2]; dst[3] = pk[k][3];
+    }
   }
   TT(10);
   if (up) {
