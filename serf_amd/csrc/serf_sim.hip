@@ -64,6 +64,8 @@ struct TickP {  // per-tick parameters, passed by value (lands in SGPRs)
   u64 loss_base, probe_base, query_base;
   u32 M, mask, shift, feff, V, blk, loss_u32, first;  // first: tick 0 has no inbox yet
   u32 n_slots;  // view slots allocated so far (the Reaper walks them)
+  u32 zero_;    // always 0 (opaque to the compiler)
+  u32 abl;      // -DTICK_ABLATE measurement builds only: parts of the tick to leave out
   u32 mul[3], add[3], imul[3];
   u32 off[SIM_MAX_FANOUT], rot[SIM_MAX_FANOUT];
   u32 prot[SIM_MAX_FANOUT];  // rot[] of the previous tick (sharded reads)
@@ -998,6 +1000,12 @@ __device__ unsigned long long g_tt[16];
 #else
 #define TT(i)
 #endif
+#ifdef TICK_ABLATE
+static u32 g_ablate = 0;
+#define ABL(bit) (tp.abl & (bit))
+#else
+#define ABL(bit) false
+#endif
 template <bool SHARDED, int F>
 __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur, const uint4* base) {
 #ifdef TICK_TIMING
@@ -1012,6 +1020,12 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
   const u32 tid = threadIdx.x;
   u32 l = blockIdx.x * BLOCK + threadIdx.x;
   if (l >= d.Nl) return;
+#ifdef TICK_ABLATE
+  if (ABL(0xFF00u) && blockIdx.x < 1024u) {  // experiment: stagger the first generation of blocks
+    u32 slot = (blockIdx.x >> 8) & 3u, per = (tp.abl >> 8) & 0xFFu;
+    for (u32 i = 0; i < slot * per; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   u32 gid = d.shard0 + l;
   // V == 1 (one shard holds everything) is wave-uniform: no divisions by run-time values on that path
   u32 g = tp.V == 1 ? 0u : gid / tp.M, ll = gid - g * tp.M;
@@ -1022,7 +1036,7 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
   bool up = n.flags & SIM_RF_UP;
   TT(0);
   // ---- phase 1: deliver.  The queue is not touched: handlers park their broadcasts in d.pend.
-  if (up) {
+  if (up && !ABL(2)) {
     if (!tp.first) {
       // inbox cell of fan-out slot k (sharded: the block of the receive buffer the source shard filled)
       auto cell_of = [&](u32 k) -> const uint4* {
@@ -1051,6 +1065,7 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
           u32 k0 = SIM_META_KIND(r0.y), k1 = SIM_META_KIND(r1.y), k2 = SIM_META_KIND(r2.y), k3 = SIM_META_KIND(r3.y);
           // wave-ballot early out: nobody in this wave received anything in packet k
           if (!__any((k0 | k1 | k2 | k3) != SIM_K_EMPTY)) continue;
+          if (ABL(64)) { n.dirty |= (k0 ^ k1 ^ k2 ^ k3) & tp.zero_; continue; }
           lds_r[0][tid] = r0; lds_r[1][tid] = r1; lds_r[2][tid] = r2; lds_r[3][tid] = r3;
           u32 s0 = slot_load(d, k0, r0.x);
           u32 s1 = slot_load(d, k1, r1.x);
@@ -1073,6 +1088,7 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
         // handler of this packet has written state, later heads are re-read (rare).
         // `wptr`: the one entry a handler of this packet has written so far; `wall`: more than one,
         // or the node's own entry as well (refutation) — only then is a staged head stale.
+        if (ABL(32)) continue;
         uint4* wptr = nullptr;
         bool wall = false;
 #pragma unroll 1
@@ -1124,6 +1140,7 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
     if (due) reap_run(c, n, tp.n_slots);
   }
   TT(6);
+  if (ABL(1)) { if (up) node_store(d, l, n); return; }
   // ---- phase 2: queue.  Load the sort keys, queue what phase 1 parked, drain `fanout` packets.
   u32 sk[SIM_Q];
   u32 cnt0 = __popc(n.used);
@@ -1164,7 +1181,7 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
       bool again = k > 0 && s == ((slots[k > 0 ? k - 1 : 0] >> (8 * p)) & 0xFFu);
       pk[k][p] = zero;
       if (again) pk[k][p] = pk[k > 0 ? k - 1 : 0][p];
-      else if (s != 0xFFu) pk[k][p] = ld4(&d.qpay[(size_t)s * d.Nl + l]);
+      else if (s != 0xFFu && !ABL(8)) pk[k][p] = ld4(&d.qpay[(size_t)s * d.Nl + l]);
     }
   }
   TT(9);
@@ -1173,7 +1190,7 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
   const bool coop = (blockIdx.x + 1u) * BLOCK <= d.Nl;  // every lane of the block is here
 #pragma unroll
   for (int k = 0; k < F; ++k) {
-    if ((u32)k >= tp.feff) break;
+    if ((u32)k >= tp.feff || ABL(4)) break;
     u32 y = sx + tp.off[k];
     if (y >= tp.M) y -= tp.M;
     u32 t = sigma_inv(tp, y);
@@ -1209,7 +1226,7 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
     }
   }
   TT(10);
-  if (up) {
+  if (up && !ABL(16)) {
     node_store(d, l, n);
     keys_store(d, l, cnt0, n.used, sk);
   }
@@ -1745,6 +1762,10 @@ static inline int grid_for(size_t n) { return (int)std::min<size_t>((n + BLOCK -
 
 extern "C" {
 
+#ifdef TICK_ABLATE
+int sim_debug_ablate(unsigned mask) { g_ablate = mask; return SIM_OK; }
+static struct AblEnv { AblEnv() { if (const char* e = getenv("SERF_ABLATE")) g_ablate = (u32)strtoul(e, nullptr, 0); } } g_abl_env;
+#endif
 #ifdef TICK_TIMING
 int sim_debug_timing(unsigned long long* out16, int reset) {
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tt), 16 * 8) != hipSuccess) return SIM_EDEVICE;
@@ -1952,6 +1973,9 @@ int sim_step(sim_handle* h, uint32_t n_ticks) {
   for (u32 it = 0; it < n_ticks; ++it) {
     TickP tp;
     tickp_make(&tp, &h->cfg, h->tick);
+#ifdef TICK_ABLATE
+    tp.abl = g_ablate;
+#endif
     for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) tp.prot[k] = h->prev.rot[k];
     tp.n_slots = h->n_slots;
     while (h->op_cursor < h->ops.size() && h->ops[h->op_cursor].tick <= h->tick) {
