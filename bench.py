@@ -50,10 +50,20 @@ def cpu_baseline(fanout, probe_interval, push_pull_interval, rate, seconds_budge
         done += 4
     dt = time.perf_counter() - t0
     cores = lib.dll.osim_t_threads()
+    # the same run continued on one thread (SURVEY.md §8d asks for both legs), a few ticks only
+    lib.dll.osim_t_set_threads(1)
+    t1 = time.perf_counter()
+    done1 = 0
+    while done1 < 4 and time.perf_counter() - t1 < seconds_budget / 2:
+        sim.step(1)
+        done1 += 1
+    dt1 = time.perf_counter() - t1
+    lib.dll.osim_t_set_threads(0)
     sim.close()
     return {"value": n * done / dt, "unit": "member-ticks/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n} nodes x {done} ticks, fan-out {fanout}, probe interval {probe_interval}, same operation mix and rate, "
-                      f"view_slots=64 rings=64 (CPU oracle, OpenMP over nodes)"}
+            "single_thread_value": n * done1 / dt1,
+            "sample": f"{n} nodes x {done} ticks (all cores) + {done1} ticks (one thread), fan-out {fanout}, probe interval {probe_interval}, "
+                      f"same operation mix and rate, view_slots=64 rings=64 (CPU oracle, OpenMP over nodes)"}
 
 
 def parse_args(argv=None):

@@ -61,6 +61,8 @@ static int oracle_threads(void) {
   return n;
 }
 int osim_t_threads(void) { return oracle_threads(); }
+/* bench.py's single-thread leg: n < 1 goes back to the detected core count */
+void osim_t_set_threads(int n) { g_threads = n > 0 ? n : 0; }
 
 /* =====================================================================================
  * Counter-based PRNG and the per-tick fan-out permutation (DESIGN.md SIMSPEC §2).  The reference
