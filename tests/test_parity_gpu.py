@@ -124,6 +124,20 @@ def test_config2_64k_bit_exact(oracle, hiplib):
     assert g.convergence(_ffi.K_EVENT, k0[3], 1) == o.convergence(_ffi.K_EVENT, k0[3], 1)
 
 
+def test_config3_1m_bit_exact_digests(oracle, hiplib):
+    # BASELINE config 3 size (1 Mi nodes, fan-out 4, SWIM layer on): digests of every array against the
+    # CPU oracle over the first ticks of a busy schedule (what the oracle finishes in seconds)
+    n = 1 << 20
+    g, o = pair(oracle, hiplib, n, fanout=4, view_slots=32, event_ring=32, query_ring=32, probe_interval=5, reap_interval=8)
+    ops = sc.schedule(n, 40, rate=2.0, seed=5, max_member_subjects=24)
+    sc.apply_schedule(g, ops)
+    sc.apply_schedule(o, ops)
+    for t in range(0, 48, 8):
+        g.step(8)
+        o.step(8)
+        assert g.digest() == o.digest(), f"digest differs after tick {t + 8}"
+
+
 def test_config3_1m_properties(hiplib):
     # BASELINE config 3 size (1 Mi nodes, fan-out 4): size-independent properties
     n = 1 << 20
