@@ -326,9 +326,11 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes);
  * inside the deadline.  SIM_EINVAL if the id does not own its entry of the running-query table. */
 int sim_query_status(sim_handle* h, uint32_t query_id, uint64_t* acks, uint64_t* responses, int* open);
 
-/* Measurement: with profiling on, every launch of the tick kernel is bracketed by HIP events on the
- * handle's stream; sim_profile_read waits for the stream and returns the summed kernel time and the
- * number of launches since the last read (bench.py's roofline figure).  No reference counterpart. */
+/* Measurement: with profiling on, launches of the tick kernel are bracketed by HIP events on the
+ * handle's stream — every launch for enable == 1, every n-th for enable == n > 1 (an event pair
+ * costs several microseconds of stream time); sim_profile_read waits for the stream and returns
+ * the summed kernel time and the number of timed launches since the last read (bench.py's
+ * roofline figure).  No reference counterpart. */
 int sim_profile(sim_handle* h, int enable);
 int sim_profile_read(sim_handle* h, double* tick_kernel_ms, uint64_t* launches);
 

@@ -1689,7 +1689,8 @@ struct sim_handle {
   bool bound;
   int device;
   u32 qt_cursor, q_timeout;  // running-query trackers (SIM_QT, round robin); query timeout in ticks
-  bool profiling;
+  u32 profiling;  // 0 = off, n = HIP events around every n-th tick-kernel launch
+  u64 prof_seq;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof;  // one event pair per tick-kernel launch
   u32 pp_step;  // push-pull batches: every pp_step ticks one of PP_GROUPS pair classes synchronises (0 = off)
 };
@@ -1800,7 +1801,8 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   h->stream = nullptr;
   h->op_cursor = 0;
   h->bound = false;
-  h->profiling = false;
+  h->profiling = 0;
+  h->prof_seq = 0;
   memset(&h->prev, 0, sizeof h->prev);
   (void)hipGetDevice(&h->device);
   Dev& d = h->d;
@@ -2003,7 +2005,8 @@ int sim_step(sim_handle* h, uint32_t n_ticks) {
     int grid = (int)((d.Nl + BLOCK - 1) / BLOCK);
     u32 cur = (u32)(h->tick & 1);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (h->profiling) {
+    const bool timed = h->profiling && (h->prof_seq++ % h->profiling) == 0;
+    if (timed) {
       HCHECK(hipEventCreate(&ev0));
       HCHECK(hipEventCreate(&ev1));
       HCHECK(hipEventRecord(ev0, h->stream));
@@ -2020,7 +2023,7 @@ int sim_step(sim_handle* h, uint32_t n_ticks) {
       default: LAUNCH_TICK(true, 4); break;
     }
 #undef LAUNCH_TICK
-    if (h->profiling) {
+    if (timed) {
       HCHECK(hipEventRecord(ev1, h->stream));
       h->prof.emplace_back(ev0, ev1);
     }
@@ -2296,7 +2299,8 @@ int sim_query_status(sim_handle* h, uint32_t qid, uint64_t* acks, uint64_t* resp
 }
 int sim_profile(sim_handle* h, int enable) {
   if (!h) return SIM_EINVAL;
-  h->profiling = enable != 0;
+  h->profiling = enable > 0 ? (u32)enable : 0u;
+  h->prof_seq = 0;
   return SIM_OK;
 }
 int sim_profile_read(sim_handle* h, double* ms, uint64_t* launches) {
