@@ -158,30 +158,17 @@ def run(args, lib=None, dev=None, backend="nccl"):
     barrier()
     raw = sim.sim if world > 1 else sim
     raw.profile(PROFILE_EVERY)  # HIP events around every 4th tick-kernel launch, on the stream it is launched on
-    # The launches go to torch's current stream (sim_set_stream above), so torch events bracket them.
-    # N=1: one pair around all K ticks (nothing but tick/ops kernels in between).  N>1: one pair per
-    # tick around sim_step only, so that the all-to-all is not billed to the kernel's roofline.
+    # The launches go to torch's current stream (sim_set_stream above), so one pair of torch events
+    # brackets the K steps: at N=1 nothing but tick/ops kernels lies in between, at N>1 the all-to-alls
+    # do as well (the kernel's own duration comes from sim_profile either way).
     t0 = time.perf_counter()
-    if world == 1:
-        ev0, ev1 = Event(enable_timing=True), Event(enable_timing=True)
-        ev0.record()
-        step(args.steps)
-        ev1.record()
-        barrier()
-        dt = time.perf_counter() - t0
-        ev_ms = ev0.elapsed_time(ev1)
-    else:
-        pairs = []
-        for _ in range(args.steps):
-            a, b = Event(enable_timing=True), Event(enable_timing=True)
-            a.record()
-            sim.sim.step(1)
-            b.record()
-            dist.all_to_all_single(sim.recv, sim.send, group=sim.group)
-            pairs.append((a, b))
-        barrier()
-        dt = time.perf_counter() - t0
-        ev_ms = sum(a.elapsed_time(b) for a, b in pairs)
+    ev0, ev1 = Event(enable_timing=True), Event(enable_timing=True)
+    ev0.record()
+    step(args.steps)
+    ev1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -217,7 +204,7 @@ def run(args, lib=None, dev=None, backend="nccl"):
         bt, bt2 = b_tick_v0(args.fanout), b_tick_layout(args.fanout)
         # dominant kernel = tick_kernel: one launch per tick; HIP events around each launch of the timed
         # region (sim_profile); ev_ms (everything on the stream, ops + push-pull included) for reference
-        kern_s = prof_ms / 1e3 / max(1, prof_n) if prof_ms > 0 else ev_ms / 1e3 / args.steps
+        kern_s = prof_ms / 1e3 / max(1, prof_n) if prof_ms > 0 else ev_ms / 1e3 / args.steps  # (the oracle behind a CPU test has no kernel)
         achieved = args.nodes_per_gpu * bt / kern_s / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
