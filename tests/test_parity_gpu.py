@@ -124,6 +124,29 @@ def test_config2_64k_bit_exact(oracle, hiplib):
     assert g.convergence(_ffi.K_EVENT, k0[3], 1) == o.convergence(_ffi.K_EVENT, k0[3], 1)
 
 
+def test_long_soak_everything_on(oracle, hiplib):
+    # 16 Ki nodes for 1 600 ticks with every subsystem on and short periods, so that the slow machinery
+    # runs many times: suspicion timers and refutations, push-pull batches, Reaper timeouts, QueueChecker,
+    # query deadlines with acks / responses / relays, packet loss, renumbering of the queue ids
+    n = 1 << 14
+    kw = dict(fanout=3, view_slots=96, event_ring=48, query_ring=48, probe_interval=3, loss=0.02,
+              push_pull_interval=16, reap_interval=25, reconnect_timeout=300, tombstone_timeout=200,
+              queue_check_interval=40, max_queue_depth=12, intent_timeout=120)
+    g, o = pair(oracle, hiplib, n, **kw)
+    for w in (5, 4099, n - 1):
+        g.watch(w)
+        o.watch(w)
+    ops = sc.schedule(n, 1500, rate=0.35, seed=77, max_member_subjects=90)
+    sc.apply_schedule(g, ops)
+    sc.apply_schedule(o, ops)
+    for t in range(0, 1600, 100):
+        g.step(100)
+        o.step(100)
+        assert g.digest() == o.digest(), f"digest differs after tick {t + 100}"
+    ev_g, ev_o = g.drain_events(), o.drain_events()
+    assert len(ev_g) > 100 and ev_g == ev_o  # the watched observers' event streams, in order
+
+
 def test_config3_1m_bit_exact_digests(oracle, hiplib):
     # BASELINE config 3 size (1 Mi nodes, fan-out 4, SWIM layer on): digests of every array against the
     # CPU oracle over the first ticks of a busy schedule (what the oracle finishes in seconds)
