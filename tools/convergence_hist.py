@@ -6,8 +6,11 @@ node crashes and comes back `--down` ticks later (the SWIM layer suspects it, it
 the number of gossip rounds until >= 99 % of the running nodes have applied it is recorded.
 Writes a JSON histogram (default profiles/r01_convergence_hist.json).  Needs an MI355X.
 
-Model bound: every churned node needs a view slot and slots are not recycled, so the number
-of churn events is limited by --view-slots, not by a percentage of N.
+Model bound: with the SWIM layer on, every churned node is a gossip subject that needs a view
+slot and slots are not recycled, so the number of churn events is limited by --view-slots, not by a percentage
+of N.  `--churn-frac 0.05 --probe-interval 0` is BASELINE configs[4]'s "5 % churn + 1 % loss" for the serf layer
+alone: that fraction of the nodes crashes and comes back `--down` ticks later over the run (nobody detects
+them, so nobody needs a slot for them); push-pull repairs what a node missed while it was down.
 """
 import argparse
 import json
@@ -29,6 +32,9 @@ def main():
     ap.add_argument("--churn-every", type=int, default=40)
     ap.add_argument("--down", type=int, default=15)
     ap.add_argument("--view-slots", type=int, default=1024)
+    ap.add_argument("--probe-interval", type=int, default=5, help="0 = SWIM layer off")
+    ap.add_argument("--push-pull-interval", type=int, default=0)
+    ap.add_argument("--churn-frac", type=float, default=0.0, help="fraction of the nodes that crash and come back over the run (needs --probe-interval 0)")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r01_convergence_hist.json"))
     args = ap.parse_args()
 
@@ -38,15 +44,21 @@ def main():
 
     n = args.nodes
     sim = serf_amd.create(n, fanout=args.fanout, view_slots=args.view_slots, event_ring=512, query_ring=512,
-                          probe_interval=5, loss=args.loss)
+                          probe_interval=args.probe_interval, push_pull_interval=args.push_pull_interval, loss=args.loss)
     rng = np.random.default_rng(5)
     total_ticks = args.rumors * args.every + 120
-    n_churn = min(total_ticks // args.churn_every, args.view_slots - 8)
+    if args.churn_frac > 0:
+        assert args.probe_interval == 0, "--churn-frac runs the serf layer alone"
+        n_churn = int(n * args.churn_frac)
+        when = np.sort(rng.integers(10, total_ticks - args.down - 10, n_churn))
+    else:
+        n_churn = min(total_ticks // args.churn_every, args.view_slots - 8)
+        when = 10 + np.arange(n_churn) * args.churn_every
     churned = rng.choice(n, n_churn, replace=False)
-    for i, node in enumerate(churned.tolist()):
-        sim.inject(10 + i * args.churn_every, _ffi.OP_CRASH, node)
-        sim.inject(10 + i * args.churn_every + args.down, _ffi.OP_REVIVE, node)
-    down_until = {int(node): 10 + i * args.churn_every + args.down for i, node in enumerate(churned.tolist())}
+    for t, node in zip(when.tolist(), churned.tolist()):
+        sim.inject(t, _ffi.OP_CRASH, node)
+        sim.inject(t + args.down, _ffi.OP_REVIVE, node)
+    down_until = {int(node): int(t) + args.down for t, node in zip(when.tolist(), churned.tolist())}
     inflight, rounds = [], []
     t0 = time.perf_counter()
     for tick in range(total_ticks):
