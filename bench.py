@@ -4,6 +4,11 @@
 A "step" is one gossip tick of every simulated node.  N=1: BASELINE.json configs[2]
 (1 Mi nodes, fan-out 4, HBM-roofline report).  N>1: one shard of 1 Mi nodes per GPU (weak
 scaling), one RCCL all_to_all_single per tick.  Prints ONE JSON line on rank 0.
+
+The timed region is steady state by construction: run() first rolls the cluster forward
+`--preroll` untimed ticks under the same constant load (rumours live ~20 ticks, suspicion timers
+120+ ticks at this size, so a cold cluster is nearly idle), then does the `--warmup` and `--steps`
+the contract asks for.  The figure therefore does not depend on --steps / --warmup.
 """
 import argparse
 import json
@@ -13,6 +18,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
 
 # SURVEY.md §8d algorithmic bytes per member-tick (v0 layout): 2R + 2QE + 2fPE + 4(f+2)
 def b_tick_v0(f):
@@ -25,48 +31,75 @@ def b_tick_layout(f):
     return 2 * 64 + (2 * 16 * 4 + f * 4 * 16) + 2 * f * 4 * 16 + f * 4 * (4 + 16)
 
 
-# the benchmark workload: evenly spaced API operations, this mix of
-# (user event, query, graceful leave [+ rejoin], crash + remove_failed_node, crash + revive)
-MIX = (0.55, 0.2, 0.15, 0.05, 0.05)
+PMC_TRAFFIC = ("profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json")  # newest first
+CONV_RUMOURS, CONV_MAX_ROUNDS = 8, 60
 
 
-PROFILE_EVERY = 4  # an event pair costs ~10 us of stream time: time a sample of the launches, not all of them
+def workload(args, n_total):
+    """(config kwargs, operation schedule) of the benchmark — the same for the GPU run and the CPU baseline."""
+    from serf_amd import workload as wl
+
+    kw = dict(fanout=args.fanout, view_slots=args.view_slots, event_ring=args.ring, query_ring=args.ring,
+              probe_interval=args.probe_interval, push_pull_interval=args.push_pull_interval,
+              reap_interval=75, queue_check_interval=150)  # options.rs defaults: reap 15 s, queue check 30 s, timeouts 24 h
+    horizon = args.preroll + args.warmup + args.steps + CONV_RUMOURS * (CONV_MAX_ROUNDS + 1)
+    ops = wl.schedule(n_total, horizon, rate=args.rate, seed=3, mix=wl.BENCH_MIX,
+                      max_member_subjects=args.view_slots // 2, even=True)
+    return kw, ops
 
 
-def cpu_baseline(fanout, probe_interval, push_pull_interval, rate, seconds_budget=20.0):
-    """The CPU oracle ("port") on a bounded sample of the same workload, rank 0 only."""
+def cpu_baseline(args, seconds_budget=60.0):
+    """The CPU oracle ("port") on the SAME configuration and schedule as the N=1 GPU run (rank 0 only): the same
+    pre-roll, then a bounded number of timed ticks on all cores and a few on one thread.  When the host cannot hold
+    the configuration (it needs ~64 KiB of address space per node, a fraction of it resident) it falls back to a
+    smaller cluster and says so."""
     from serf_amd import _ffi
-    from tests import _scenario as sc
-    from tests._oracle import load_oracle
 
-    lib = load_oracle()
-    n, ticks = 1 << 18, 24
-    sim = _ffi.Sim(lib, _ffi.make_config(n, fanout=fanout, view_slots=64, event_ring=64, query_ring=64,
-                                         probe_interval=probe_interval, push_pull_interval=push_pull_interval,
-                                         reap_interval=75, queue_check_interval=150))
-    sc.apply_schedule(sim, sc.schedule(n, ticks, rate=rate, seed=11, mix=MIX, max_member_subjects=32, even=True))
-    sim.step(4)  # warm-up (page faults, rumors in flight)
+    lib = _ffi.SimLib(os.path.join(ROOT, "oracle", "liboracle.so"), prefix="osim_")  # test infrastructure: the checker, timed
+    n = args.nodes_per_gpu
+    note = ""
+    while True:
+        kw, ops = workload(args, n)
+        try:
+            sim = _ffi.Sim(lib, _ffi.make_config(n, **kw))
+            break
+        except _ffi.SimError:
+            if n <= 1 << 16:
+                raise
+            n //= 4
+            note = f" (host could not allocate {args.nodes_per_gpu} nodes: sample shrunk to {n})"
+    for t, op, node, a, b in ops:
+        sim.inject(t, op, node, a, b)
+    cores = int(lib.dll.osim_t_threads())
     t0 = time.perf_counter()
+    rolled = 0
+    target = args.preroll + args.warmup
+    while rolled < target and time.perf_counter() - t0 < seconds_budget:  # untimed, like the GPU run's pre-roll
+        sim.step(5)
+        rolled += 5
+    t_roll = time.perf_counter() - t0
+    ticks_all, ticks_one = 32, 8
+    t1 = time.perf_counter()
     done = 0
-    while done < ticks and time.perf_counter() - t0 < seconds_budget:
+    while done < ticks_all and time.perf_counter() - t1 < 20.0:
         sim.step(4)
         done += 4
-    dt = time.perf_counter() - t0
-    cores = lib.dll.osim_t_threads()
-    # the same run continued on one thread (SURVEY.md §8d asks for both legs), a few ticks only
-    lib.dll.osim_t_set_threads(1)
-    t1 = time.perf_counter()
+    dt = time.perf_counter() - t1
+    lib.dll.osim_t_set_threads(1)  # SURVEY.md §8d asks for both legs
+    t2 = time.perf_counter()
     done1 = 0
-    while done1 < 4 and time.perf_counter() - t1 < seconds_budget / 2:
+    while done1 < ticks_one and time.perf_counter() - t2 < 15.0:
         sim.step(1)
         done1 += 1
-    dt1 = time.perf_counter() - t1
+    dt1 = time.perf_counter() - t2
     lib.dll.osim_t_set_threads(0)
+    drops = sim.cluster_stats()["overflow"]
     sim.close()
-    return {"value": n * done / dt, "unit": "member-ticks/s", "cores": int(cores), "kind": "port",
+    return {"value": n * done / dt, "unit": "member-ticks/s", "cores": cores, "kind": "port",
             "single_thread_value": n * done1 / dt1,
-            "sample": f"{n} nodes x {done} ticks (all cores) + {done1} ticks (one thread), fan-out {fanout}, probe interval {probe_interval}, "
-                      f"same operation mix and rate, view_slots=64 rings=64 (CPU oracle, OpenMP over nodes)"}
+            "sample": f"same configuration and schedule as the GPU run{note}: {n} nodes, view_slots {args.view_slots}, rings {args.ring}, "
+                      f"fan-out {args.fanout}; {rolled} untimed pre-roll ticks ({t_roll:.1f} s), then ticks {rolled}..{rolled + done - 1} timed on "
+                      f"{cores} threads (OpenMP over nodes) and {done1} more on one thread; model_bound_drops {drops}"}
 
 
 def parse_args(argv=None):
@@ -74,6 +107,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=60)
+    ap.add_argument("--preroll", type=int, default=320,
+                    help="untimed ticks under the same load before --warmup, so that the timed region is steady state")
     ap.add_argument("--nodes-per-gpu", type=int, default=1 << 20)
     ap.add_argument("--fanout", type=int, default=4)
     ap.add_argument("--view-slots", type=int, default=1024)
@@ -83,6 +118,7 @@ def parse_args(argv=None):
     ap.add_argument("--push-pull-interval", type=int, default=150, help="memberlist push_pull_interval in ticks before log2(N) scaling (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence", action="store_true", help="skip the rounds-to-99 %% measurement (profiling runs)")
+    ap.add_argument("--allow-drops", action="store_true", help="do not fail when the run hit a model bound (overflow > 0)")
     return ap.parse_args(argv)
 
 
@@ -90,13 +126,13 @@ def run(args, lib=None, dev=None, backend="nccl"):
     """The benchmark proper.  `lib`/`dev`/`backend` exist so that tests/test_bench_plumbing.py can drive the
     SAME control flow (sharded stepping, all-to-all, convergence, JSON) on CPU with gloo; main() always
     passes the HIP library, a CUDA device and RCCL."""
+    import numpy as np
     import torch
     import torch.distributed as dist
 
     import serf_amd
     from serf_amd import _ffi
     from serf_amd.shard import ShardedSim
-    from tests import _scenario as sc
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -118,21 +154,17 @@ def run(args, lib=None, dev=None, backend="nccl"):
     n_total = args.nodes_per_gpu * world
     if lib is None:
         lib = serf_amd.load()
-    kw = dict(fanout=args.fanout, view_slots=args.view_slots, event_ring=args.ring, query_ring=args.ring,
-              probe_interval=args.probe_interval, push_pull_interval=args.push_pull_interval,
-              reap_interval=75, queue_check_interval=150)  # options.rs defaults: reap 15 s, queue check 30 s, timeouts 24 h
-    total_ticks = args.steps + args.warmup
-    ops = sc.schedule(n_total, total_ticks, rate=args.rate, seed=3, mix=MIX, max_member_subjects=args.view_slots // 2, even=True)
+    kw, ops = workload(args, n_total)
     if world > 1:
         sim = ShardedSim(lib, n_total, dev, **kw)
-        step, inject = sim.step, sim.inject
     else:
         sim = _ffi.Sim(lib, _ffi.make_config(n_total, **kw))
         if on_gpu:
             sim.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-        step, inject = sim.step, sim.inject
+    raw = sim.sim if world > 1 else sim
+    step = sim.step
     for t, op, node, a, b in ops:
-        inject(t, op, node, a, b)
+        sim.inject(t, op, node, a, b)
 
     def barrier():
         if world > 1:
@@ -140,7 +172,20 @@ def run(args, lib=None, dev=None, backend="nccl"):
         if on_gpu:
             torch.cuda.synchronize()
         else:
-            (sim.sim if world > 1 else sim).sync()
+            raw.sync()
+
+    def allsum(vals):
+        if world == 1:
+            return [int(v) for v in vals]
+        t = torch.tensor([int(v) for v in vals], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        return [int(x) for x in t]
+
+    def load_now():  # cluster-wide load: records per packet in flight, queue entries per node, model-bound drops
+        cs = raw.cluster_stats()
+        inbox, queued, drops, up = allsum([cs["inbox_records"], sum(cs["queued"]), cs["overflow"], cs["up"]])
+        return {"records_per_packet": inbox / (args.fanout * n_total), "queued_per_node": queued / n_total,
+                "drops": drops, "up": up}
 
     class _HostEvent:  # CPU stand-in for torch.cuda.Event in the plumbing test
         def __init__(self, enable_timing=True):
@@ -154,13 +199,25 @@ def run(args, lib=None, dev=None, backend="nccl"):
 
     Event = torch.cuda.Event if on_gpu else _HostEvent
 
+    # ---- untimed: pre-roll to the stationary load, then the contract's warm-up ----
+    trace = []
+    done = 0
+    while done < args.preroll:
+        k = min(40, args.preroll - done)
+        step(k)
+        done += k
+        trace.append(round(load_now()["records_per_packet"], 3))
     step(args.warmup)
     barrier()
-    raw = sim.sim if world > 1 else sim
-    raw.profile(PROFILE_EVERY)  # HIP events around every 4th tick-kernel launch, on the stream it is launched on
-    # The launches go to torch's current stream (sim_set_stream above), so one pair of torch events
-    # brackets the K steps: at N=1 nothing but tick/ops kernels lies in between, at N>1 the all-to-alls
-    # do as well (the kernel's own duration comes from sim_profile either way).
+    load0 = load_now()
+    # an event pair costs ~10 us of stream time: time a sample of the launches on long runs, all of them on short ones
+    profile_every = 4 if args.steps >= 100 else 1
+    raw.profile(profile_every)
+    if world > 1:
+        sim.time_exchange(True)
+    barrier()
+    # ---- timed: exactly K steps between two barriers.  The launches go to torch's current stream
+    # (sim_set_stream above), so one pair of torch events brackets them as well.
     t0 = time.perf_counter()
     ev0, ev1 = Event(enable_timing=True), Event(enable_timing=True)
     ev0.record()
@@ -173,73 +230,101 @@ def run(args, lib=None, dev=None, backend="nccl"):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
-
-    prof_ms, prof_n = raw.profile_read()
+    (prof_ms, prof_min, prof_max), prof_n = raw.profile_read_stats()
     raw.profile(False)
-    # second half of the metric: rounds to 99 % convergence, measured after the timed region on 8
+    exchange_ms = sim.time_exchange(False) if world > 1 else None
+    load1 = load_now()
+
+    # ---- second half of the metric: rounds to 99 % convergence, measured after the timed region on
     # fresh user events, one at a time, under the same background load (every rank issues the same
     # calls; the originator's rank reads the Lamport time the event is going to get)
-    import numpy as _np
-    rng = _np.random.default_rng(99)
+    rng = np.random.default_rng(99)
     rounds = []
-    for i in range(0 if args.no_convergence else 8):
+    for i in range(0 if args.no_convergence else CONV_RUMOURS):
         node, key = int(rng.integers(0, n_total)), 0x7F000000 + i
         owner = node // args.nodes_per_gpu
-        lt = (sim.sim if world > 1 else sim).stats(node).event_time if owner == rank else 0
+        lt = raw.stats(node).event_time if owner == rank else 0
         if world > 1:
             t = torch.tensor([lt], dtype=torch.int64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             lt = int(t[0])
         sim.user_event(node, key, 64)
         got = None
-        for r in range(1, 61):
+        for r in range(1, CONV_MAX_ROUNDS + 1):
             step(1)
             seen, up = sim.convergence(_ffi.K_EVENT, key, lt)
             if seen * 100 >= up * 99:
                 got = r
                 break
-        rounds.append(got if got is not None else 61)
+        rounds.append(got if got is not None else CONV_MAX_ROUNDS + 1)
+    load2 = load_now()
+    out = None
     if rank == 0:
         value = n_total * args.steps / dt
         bt, bt2 = b_tick_v0(args.fanout), b_tick_layout(args.fanout)
-        # dominant kernel = tick_kernel: one launch per tick; HIP events around each launch of the timed
+        # dominant kernel = tick_kernel: one launch per tick; HIP events around the launches of the timed
         # region (sim_profile); ev_ms (everything on the stream, ops + push-pull included) for reference
         kern_s = prof_ms / 1e3 / max(1, prof_n) if prof_ms > 0 else ev_ms / 1e3 / args.steps  # (the oracle behind a CPU test has no kernel)
         achieved = args.nodes_per_gpu * bt / kern_s / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_src, traffic_cal = None, None, None
+        for rel in PMC_TRAFFIC:
+            if os.path.exists(os.path.join(ROOT, rel)):
+                try:
+                    doc = json.load(open(os.path.join(ROOT, rel)))
+                    traffic, traffic_src = doc.get("hbm_bytes_per_launch"), rel
+                    traffic_cal = doc.get("calibration")
+                    break
+                except Exception:
+                    pass
         out = {
             "metric": "member-ticks/sec", "value": value, "unit": "member-ticks/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": f"{n_total} nodes ({args.nodes_per_gpu}/GPU), fan-out {args.fanout}, "
-                                   f"{args.rate} API ops/tick evenly spaced, mix {MIX} of (user event, query, leave, crash+remove, crash+revive), "
+                                   f"{args.rate} API ops/tick evenly spaced, mix (0.55, 0.2, 0.15, 0.05, 0.05) of (user event, query, leave, crash+remove, crash+revive), "
                                    f"view_slots {args.view_slots}, rings {args.ring}, probe interval {args.probe_interval} ticks, push-pull interval "
-                                   f"{args.push_pull_interval} ticks (x log2 scaling), reaper and queue checker on — BASELINE configs[2]",
-                       "parallelism": f"node-id range shards x{world}, 1 all_to_all_single/tick" if world > 1 else "single GPU"},
-            "rounds_to_99": ({"median": float(_np.median(rounds)), "max": int(max(rounds)), "min": int(min(rounds)), "n": len(rounds),
+                                   f"{args.push_pull_interval} ticks (x log2 scaling), reaper and queue checker on — BASELINE configs[2]; "
+                                   f"{args.preroll} untimed pre-roll ticks under the same load before the warm-up (steady state)",
+                       "parallelism": f"node-id range shards x{world}, 1 all_to_all_single/tick" if world > 1 else "single GPU",
+                       "preroll": args.preroll,
+                       "timed_ticks": [args.preroll + args.warmup, args.preroll + args.warmup + args.steps - 1],
+                       "model_bound_drops": load2["drops"],
+                       "load": {"records_per_packet_start": round(load0["records_per_packet"], 3),
+                                "records_per_packet_end": round(load1["records_per_packet"], 3),
+                                "queued_per_node_start": round(load0["queued_per_node"], 3),
+                                "queued_per_node_end": round(load1["queued_per_node"], 3),
+                                "records_per_packet_preroll_every_40_ticks": trace,
+                                "nodes_up": load1["up"]}},
+            "rounds_to_99": ({"median": float(np.median(rounds)), "max": int(max(rounds)), "min": int(min(rounds)), "n": len(rounds),
                               "what": "gossip rounds until >= 99 % of running nodes have applied a fresh user event, under the bench load"}
                              if rounds else None),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "tick_kernel", "kernel_ms": kern_s * 1e3, "kernel_launches": int(prof_n),
-                         "kernel_timing": f"HIP events around every {PROFILE_EVERY}th tick_kernel launch of the timed region, on its stream",
+                         "kernel": "tick_kernel", "kernel_ms": kern_s * 1e3,
+                         "kernel_ms_min": prof_min, "kernel_ms_max": prof_max, "kernel_launches": int(prof_n),
+                         "kernel_timing": f"HIP events around every {profile_every}{'th' if profile_every > 1 else 'st'} tick_kernel launch of the timed region, on its stream",
                          "stream_ms_per_step": ev_ms / args.steps, "b_tick_bytes": bt,
                          "achieved_revised": args.nodes_per_gpu * bt2 / kern_s / 1e9, "b_tick_layout_bytes": bt2,
-                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch)"},
+                         "traffic_over_algorithmic": (traffic / (args.nodes_per_gpu * bt)) if traffic else None,
+                         "traffic_source": traffic_src, "traffic_calibration": traffic_cal},
         }
+        if world > 1:
+            xb = raw.exchange_bytes()
+            out["exchange"] = {"exchange_ms": exchange_ms / args.steps, "kernel_ms": kern_s * 1e3,
+                               "bytes_per_peer": xb // world, "bytes_per_gpu_per_tick": xb,
+                               "bytes_leaving_gpu_per_tick": xb // world * (world - 1),
+                               "what": "exchange_ms = mean time of the all_to_all_single of one round (events on the stream around it, rank 0); "
+                                       "kernel_ms = mean tick_kernel launch; they run back to back, ms_per_step ~ their sum"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.fanout, args.probe_interval, args.push_pull_interval, args.rate)
+            out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
-    return out if rank == 0 else None
+    if load2["drops"] and not args.allow_drops:
+        # a run that hit a model bound is not a run of the protocol the parity tests cover: refuse it
+        raise SystemExit(f"bench.py: model bound hit ({load2['drops']} drops: queue slots / bucket keys / timers) — result invalid")
+    return out
 
 
 def main():

@@ -29,14 +29,25 @@ extern "C" {
 
 /* ------------------------------------------------------------------ constants */
 
-#define SIM_ABI_VERSION 6u
+#define SIM_ABI_VERSION 7u
 
 #define SIM_P 4u  /* piggyback records per gossip packet (64-byte packet)             */
+/* The three capacity bounds of the model.  The product is built with exactly these values; the oracle can ALSO be
+ * built with far larger ones (oracle/Makefile: liboracle_unbounded.so) so that a test can show that a bounded run
+ * which never hit a bound (overflow == 0) is identical to the run without the bounds
+ * (tests/test_oracle_unbounded.py; reference: queues of up to 4096 entries options.rs:513, a Vec per ring bucket
+ * base.rs:783-813, one suspicion timer per suspected member). */
+#ifndef SIM_Q
 #define SIM_Q 16u /* retransmit-queue slots per node (all four queues share the pool) */
+#endif
+#ifndef SIM_C
 #define SIM_C 6u  /* keys per de-dup ring bucket (32-byte bucket)                     */
+#endif
 #define SIM_MAX_FANOUT 4u
 #define SIM_MAX_CONF 4u /* conf[0] = node that started the suspicion, conf[1..3] = confirmers (k <= 3) */
+#ifndef SIM_S
 #define SIM_S 8u        /* suspicion timers a node can track at once (16-bit view slots) */
+#endif
 #define SIM_MAX_AWARENESS 7u /* memberlist awareness_max_multiplier - 1 (lan: 8)      */
 
 /* error codes (serf-core/src/error.rs:64-81 maps its enum onto these for the bulk path) */
@@ -69,7 +80,7 @@ enum sim_event_type {
   SIM_EV_JOIN = 0,
   SIM_EV_LEAVE = 1,
   SIM_EV_FAILED = 2,
-  SIM_EV_UPDATE = 3,
+  SIM_EV_UPDATE = 3, /* reserved: tags/meta are off the simulated path, handle_node_update (base.rs:1576-1624) never fires */
   SIM_EV_REAP = 4,
   SIM_EV_USER = 5,
   SIM_EV_QUERY = 6
@@ -233,6 +244,19 @@ typedef struct sim_event {
   uint64_t ltime; /* Lamport time of the message, 0 for member events from SWIM */
 } sim_event;
 
+/* Cluster-wide load figures of the local shard (no reference counterpart: `Stats` summed over nodes).
+ * `overflow` > 0 means the run hit one of the simulator's model bounds (SIM_Q pooled queue slots, SIM_C
+ * keys per ring bucket, SIM_S suspicion timers, a probe target without a view slot) and is no longer a
+ * run of the unbounded protocol; benchmarks report it and refuse a non-zero value. */
+typedef struct sim_cluster_stats {
+  uint64_t up;            /* nodes whose process is running                                     */
+  uint64_t queued[4];     /* queue entries by class: memberlist, intents, queries, events       */
+  uint64_t overflow;      /* sum of sim_row.overflow                                            */
+  uint64_t inbox_records; /* non-empty records in the packets in flight                         */
+  uint64_t failed, left;  /* sum of n_failed / n_left                                           */
+  uint64_t max_queue;     /* deepest queue of any node                                          */
+} sim_cluster_stats;
+
 typedef struct sim_handle sim_handle;
 
 /* Scheduled operation kinds for sim_inject. */
@@ -333,6 +357,10 @@ int sim_query_status(sim_handle* h, uint32_t query_id, uint64_t* acks, uint64_t*
  * roofline figure).  No reference counterpart. */
 int sim_profile(sim_handle* h, int enable);
 int sim_profile_read(sim_handle* h, double* tick_kernel_ms, uint64_t* launches);
+/* The same read with the spread: out_ms[0] = sum, [1] = min, [2] = max over the timed launches. */
+int sim_profile_read_stats(sim_handle* h, double out_ms[3], uint64_t* launches);
+/* Sums over the local shard's nodes (one reduction kernel; see sim_cluster_stats). */
+int sim_cluster_stats_get(sim_handle* h, sim_cluster_stats* out);
 
 uint32_t sim_abi_version(void);
 const char* sim_backend_name(void);

@@ -206,6 +206,10 @@ struct sim_handle {
   uint32_t* slot_of;    /* [N] global subject -> slot */
   uint32_t* subject_of; /* [A] */
   uint32_t n_slots;
+  uint32_t* walk;       /* [n_walk] allocated slots in ascending SUBJECT order: the order every per-node walk over
+                         * the view uses (Reaper, push-pull merge), so that it does not depend on how slots were
+                         * handed out (an unbounded run with a dense view walks subjects in id order, too) */
+  uint32_t n_walk;
   sim_view* base;       /* [N] baseline entry per subject (non-dense) */
   sim_opent* ops;
   size_t n_ops, cap_ops, op_cursor;
@@ -811,7 +815,8 @@ static void reap_run(nctx* c) {
   if (!RI || (now + (c->gid >> 6)) % RI) return;
   if (!row->reap_next || now < row->reap_next) return;
   uint32_t next = 0;
-  for (uint32_t a = 0; a < s->n_slots; ++a) {
+  for (uint32_t wi = 0; wi < s->n_walk; ++wi) {
+    uint32_t a = s->walk[wi];
     sim_view* e = &s->view[(size_t)a * s->Nl + c->l];
     uint32_t age = (now - SIM_VB_STAMP(e->bits)) & STAMP_MASK, timeout;
     if (e->bits & SIM_VB_KNOWN) {
@@ -912,7 +917,7 @@ static void apply_op(osim* s, const sim_opent* op) {
       uint64_t lt = row->event_clock;               /* api.rs:264 */
       row->event_clock++;                           /* api.rs:285 */
       handle_user_event(&c, op->a, lt);             /* api.rs:288 */
-      q_push(&c, op->a, wire_meta(SIM_K_EVENT, 0, op->b), lt); /* api.rs:290-297 */
+      q_push(&c, op->a, wire_meta(SIM_K_EVENT, (op->b >> 31) ? SIM_F_CC : 0u, op->b & 0x7FFFFFFFu), lt); /* api.rs:290-297 */
       break;
     }
     case SIM_OP_QUERY: { /* base.rs:875-940 */
@@ -1002,7 +1007,8 @@ static void pp_merge(osim* s, uint32_t ll, uint32_t lr) {
 #define PP_GUARD() do { if (c.row->next_seq > 1023u - 64u) queue_renorm(c.row, c.q); } while (0)
   PP_GUARD();
   if (s->swim) { /* mergeState (B.6): alive as alive, left as dead{from = node}, suspect and dead as suspect */
-    for (uint32_t a = 0; a < s->n_slots; ++a) {
+    for (uint32_t wi = 0; wi < s->n_walk; ++wi) {
+      uint32_t a = s->walk[wi];
       const sim_view* re = &s->view[(size_t)a * s->Nl + lr];
       if (!(re->bits & SIM_VB_KNOWN)) continue;
       PP_GUARD();
@@ -1015,14 +1021,16 @@ static void pp_merge(osim* s, uint32_t ll, uint32_t lr) {
   if (rr->clock > 0) lc_witness(&c.row->clock, rr->clock - 1);                   /* delegate.rs:466-468 */
   if (rr->event_clock > 0) lc_witness(&c.row->event_clock, rr->event_clock - 1); /* delegate.rs:469-474 */
   if (rr->query_clock > 0) lc_witness(&c.row->query_clock, rr->query_clock - 1); /* delegate.rs:475-480 */
-  for (uint32_t a = 0; a < s->n_slots; ++a) { /* left members first, at status_ltime + 1: delegate.rs:495-512 */
+  for (uint32_t wi = 0; wi < s->n_walk; ++wi) { /* left members first, at status_ltime + 1: delegate.rs:495-512 */
+    uint32_t a = s->walk[wi];
     const sim_view* re = &s->view[(size_t)a * s->Nl + lr];
     if ((re->bits & SIM_VB_KNOWN) && SIM_VB_STATUS(re->bits) == SIM_STATUS_LEFT) {
       PP_GUARD();
       handle_leave_intent(&c, s->subject_of[a], re->ltime + 1, 0);
     }
   }
-  for (uint32_t a = 0; a < s->n_slots; ++a) { /* every other status_ltime as a join intent: delegate.rs:515-526 */
+  for (uint32_t wi = 0; wi < s->n_walk; ++wi) { /* every other status_ltime as a join intent: delegate.rs:515-526 */
+    uint32_t a = s->walk[wi];
     const sim_view* re = &s->view[(size_t)a * s->Nl + lr];
     if ((re->bits & SIM_VB_KNOWN) && SIM_VB_STATUS(re->bits) != SIM_STATUS_LEFT)
       handle_join_intent(&c, s->subject_of[a], re->ltime);
@@ -1177,7 +1185,7 @@ int API(destroy)(osim* s) {
   if (!s) return SIM_EINVAL;
   free(s->rows); free(s->queue); free(s->inbox[0]); free(s->inbox[1]);
   if (s->own_x) { free(s->xsend); free(s->xrecv); }
-  free(s->view); free(s->ering); free(s->qring); free(s->slot_of); free(s->subject_of);
+  free(s->view); free(s->ering); free(s->qring); free(s->slot_of); free(s->subject_of); free(s->walk);
   free(s->base); free(s->ops); free(s->events); free(s->upmap); free(s->qbits); free(s);
   return SIM_OK;
 }
@@ -1212,6 +1220,7 @@ int API(create)(const sim_config* cfg, osim** out) {
   s->qring = (sim_bucket*)calloc((size_t)s->Bq * Nl, sizeof(sim_bucket));
   s->slot_of = (uint32_t*)malloc((size_t)s->N * sizeof(uint32_t));
   s->subject_of = (uint32_t*)malloc((size_t)s->A * sizeof(uint32_t));
+  s->walk = (uint32_t*)malloc((size_t)s->A * sizeof(uint32_t));
   s->base = (sim_view*)calloc(s->N, sizeof(sim_view));
   s->upmap = (uint32_t*)malloc(((size_t)s->N + 31) / 32 * sizeof(uint32_t));
   if (s->upmap) memset(s->upmap, 0xFF, ((size_t)s->N + 31) / 32 * sizeof(uint32_t));
@@ -1220,7 +1229,7 @@ int API(create)(const sim_config* cfg, osim** out) {
   s->q_timeout = 16u * digits10(s->N); /* query.rs:421-427 with query_timeout_mult = 16 (options.rs:518) */
   pp_params(cfg, &s->pp_step, &s->pp_groups);
   if (!s->qbits || !s->upmap || !s->rows || !s->queue || !s->view || !s->ering || !s->qring || !s->slot_of ||
-      !s->subject_of || !s->base || (cfg->shard_count > 1 ? (!s->xsend || !s->xrecv)
+      !s->subject_of || !s->walk || !s->base || (cfg->shard_count > 1 ? (!s->xsend || !s->xrecv)
                                                           : (!s->inbox[0] || !s->inbox[1]))) {
     API(destroy)(s);
     return SIM_ENOMEM;
@@ -1233,9 +1242,9 @@ int API(create)(const sim_config* cfg, osim** out) {
     if (joined) { s->base[i].ltime = 1; s->base[i].bits = vb_make(1, SIM_STATUS_ALIVE, 0, 0, 0, 0); }
   }
   if (s->dense) {
-    s->n_slots = s->N;
+    s->n_slots = s->n_walk = s->N;
     for (uint32_t a = 0; a < s->A; ++a) {
-      s->subject_of[a] = a;
+      s->subject_of[a] = s->walk[a] = a;
       for (size_t l = 0; l < Nl; ++l) s->view[(size_t)a * Nl + l] = s->base[a];
     }
   }
@@ -1263,6 +1272,16 @@ int API(create)(const sim_config* cfg, osim** out) {
 
 int API(set_stream)(osim* s, void* st) { (void)s; (void)st; return SIM_OK; }
 
+static void walk_insert(osim* s, uint32_t a) { /* keep `walk` sorted by subject id */
+  uint32_t pos = s->n_walk++;
+  while (pos > 0 && s->subject_of[s->walk[pos - 1]] > s->subject_of[a]) { s->walk[pos] = s->walk[pos - 1]; --pos; }
+  s->walk[pos] = a;
+}
+static void walk_rebuild(osim* s) {
+  s->n_walk = 0;
+  for (uint32_t subj = 0; subj < s->N; ++subj)
+    if (s->slot_of[subj] != NOSLOT) s->walk[s->n_walk++] = s->slot_of[subj];
+}
 /* active-subject slots (non-dense): allocate at injection time, column := baseline */
 static int ensure_slot(osim* s, uint32_t subject) {
   if (subject >= s->N) return SIM_EINVAL;
@@ -1272,6 +1291,7 @@ static int ensure_slot(osim* s, uint32_t subject) {
   s->slot_of[subject] = a;
   s->subject_of[a] = subject;
   for (size_t l = 0; l < s->Nl; ++l) s->view[(size_t)a * s->Nl + l] = s->base[subject];
+  walk_insert(s, a);
   return SIM_OK;
 }
 
@@ -1280,7 +1300,7 @@ int API(inject)(osim* s, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, 
   if (tick < s->tick) tick = s->tick;
   int rc = SIM_OK;
   switch (op) {
-    case SIM_OP_USER_EVENT: if (!a) return SIM_EINVAL; if (b > 9 * 1024) return SIM_ETOOBIG; break;
+    case SIM_OP_USER_EVENT: if (!a) return SIM_EINVAL; if ((b & 0x7FFFFFFFu) > 9 * 1024) return SIM_ETOOBIG; break; /* bit 31: cc */
     case SIM_OP_QUERY: if (!a) return SIM_EINVAL; break;
     case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: rc = ensure_slot(s, node); break;
     case SIM_OP_FORCE_LEAVE: rc = ensure_slot(s, a); break;
@@ -1316,8 +1336,8 @@ int API(force_leave)(osim* s, uint32_t node, uint32_t subject, int prune) {
   return API(inject)(s, s ? s->tick : 0, SIM_OP_FORCE_LEAVE, node, subject, prune ? 1u : 0u);
 }
 int API(user_event)(osim* s, uint32_t node, uint32_t key, uint32_t len, int cc) {
-  (void)cc;
-  return API(inject)(s, s ? s->tick : 0, SIM_OP_USER_EVENT, node, key, len);
+  /* UserEventMessage.cc (types/user_event/message.rs) travels in the record's flag bits */
+  return API(inject)(s, s ? s->tick : 0, SIM_OP_USER_EVENT, node, key, (len & 0x7FFFFFFFu) | (cc ? 0x80000000u : 0u));
 }
 int API(query)(osim* s, uint32_t node, uint32_t id, uint32_t flags) {
   return API(inject)(s, s ? s->tick : 0, SIM_OP_QUERY, node, id, flags);
@@ -1541,6 +1561,7 @@ int API(restore)(osim* s, const void* buf, size_t bytes) {
   s->prev.V = s->V; s->prev.blk = (s->N / s->V) / s->V; s->prev.M = s->N / s->V;
   s->n_watched = 0;
   for (uint32_t l = 0; l < s->Nl; ++l) s->n_watched += (s->rows[l].flags & SIM_RF_WATCHED) != 0;
+  walk_rebuild(s);
   return SIM_OK;
 }
 
@@ -1590,6 +1611,31 @@ int API(profile_read)(osim* s, double* ms, uint64_t* launches) {
   if (!s || !ms || !launches) return SIM_EINVAL;
   *ms = 0.0;
   *launches = 0;
+  return SIM_OK;
+}
+int API(profile_read_stats)(osim* s, double out_ms[3], uint64_t* launches) {
+  if (!s || !out_ms || !launches) return SIM_EINVAL;
+  out_ms[0] = out_ms[1] = out_ms[2] = 0.0;
+  *launches = 0;
+  return SIM_OK;
+}
+int API(cluster_stats_get)(osim* s, sim_cluster_stats* o) {
+  if (!s || !o) return SIM_EINVAL;
+  memset(o, 0, sizeof *o);
+  for (uint32_t l = 0; l < s->Nl; ++l) {
+    const sim_row* row = &s->rows[l];
+    const sim_record* q = &s->queue[(size_t)l * SIM_Q];
+    uint64_t cnt = 0;
+    o->up += (row->flags & SIM_RF_UP) ? 1u : 0u;
+    for (uint32_t i = 0; i < SIM_Q; ++i)
+      if (q[i].meta != SIM_META_EMPTY) { o->queued[q[i].meta >> 30]++; cnt++; }
+    if (cnt > o->max_queue) o->max_queue = cnt;
+    o->overflow += row->overflow; o->failed += row->n_failed; o->left += row->n_left;
+  }
+  const sim_packet* in = cur_inbox(s);
+  if (in)
+    for (size_t i = 0; i < (size_t)s->f * s->Nl; ++i)
+      for (uint32_t p = 0; p < SIM_P; ++p) o->inbox_records += SIM_META_KIND(in[i].rec[p].meta) != SIM_K_EMPTY;
   return SIM_OK;
 }
 int API(exchange_bytes)(const osim* s, size_t* bytes) {

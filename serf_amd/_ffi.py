@@ -58,6 +58,11 @@ class Stats(C.Structure):
                 ("queue_overflow", C.c_uint32)]
 
 
+class ClusterStats(C.Structure):
+    _fields_ = [("up", C.c_uint64), ("queued", C.c_uint64 * 4), ("overflow", C.c_uint64),
+                ("inbox_records", C.c_uint64), ("failed", C.c_uint64), ("left", C.c_uint64), ("max_queue", C.c_uint64)]
+
+
 class Event(C.Structure):
     _fields_ = [("tick", C.c_uint32), ("observer", C.c_uint32), ("type", C.c_uint32),
                 ("key", C.c_uint32), ("ltime", C.c_uint64)]
@@ -78,7 +83,8 @@ _ARR_DTYPE = {ARR_ROWS: ROW_DTYPE, ARR_QUEUE: REC_DTYPE, ARR_INBOX: REC_DTYPE, A
 ABI_SYMBOLS = ("create", "destroy", "set_stream", "join", "leave", "force_leave", "user_event",
                "query", "inject", "step", "sync", "tick", "members", "stats_get", "watch",
                "drain_events", "state_digest", "dump_state", "convergence", "exchange_bytes",
-               "bind_exchange", "snapshot", "restore", "query_status", "profile", "profile_read", "abi_version", "backend_name")
+               "bind_exchange", "snapshot", "restore", "query_status", "profile", "profile_read", "profile_read_stats", "cluster_stats_get",
+               "abi_version", "backend_name")
 
 
 def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, view_slots=0,
@@ -139,6 +145,8 @@ class SimLib:
             "query_status": (C.c_int, [H, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_int)]),
             "profile": (C.c_int, [H, C.c_int]),
             "profile_read": (C.c_int, [H, C.POINTER(C.c_double), C.POINTER(u64)]),
+            "profile_read_stats": (C.c_int, [H, C.POINTER(C.c_double * 3), C.POINTER(u64)]),
+            "cluster_stats_get": (C.c_int, [H, C.POINTER(ClusterStats)]),
             "abi_version": (u32, []),
             "backend_name": (C.c_char_p, []),
         }
@@ -241,12 +249,14 @@ class Sim:
         self._ck(self.lib.f["state_digest"](self.h, C.byref(d)), "sim_state_digest")
         return tuple(int(x) for x in d)
 
-    def dump(self, which):
+    def dump(self, which, dtype=None):
+        """One state array of the local shard as a structured numpy array (`dtype` overrides the product's record
+        layout: an implementation built with other capacity constants has wider rows / buckets)."""
         n = C.c_size_t()
         self._ck(self.lib.f["dump_state"](self.h, which, None, 0, C.byref(n)), "sim_dump_state")
         buf = np.zeros(n.value, np.uint8)
         self._ck(self.lib.f["dump_state"](self.h, which, buf.ctypes.data, n.value, C.byref(n)), "sim_dump_state")
-        return buf.view(_ARR_DTYPE[which])
+        return buf.view(_ARR_DTYPE[which] if dtype is None else dtype)
 
     def convergence(self, kind, key, ltime):
         seen, up = C.c_uint64(), C.c_uint64()
@@ -279,6 +289,19 @@ class Sim:
         ms, n = C.c_double(), C.c_uint64()
         self._ck(self.lib.f["profile_read"](self.h, C.byref(ms), C.byref(n)), "sim_profile_read")
         return ms.value, n.value
+
+    def profile_read_stats(self):
+        """(sum, min, max) of the timed tick-kernel launches in milliseconds, and their number."""
+        ms, n = (C.c_double * 3)(), C.c_uint64()
+        self._ck(self.lib.f["profile_read_stats"](self.h, C.byref(ms), C.byref(n)), "sim_profile_read_stats")
+        return (ms[0], ms[1], ms[2]), n.value
+
+    def cluster_stats(self):
+        """Load figures summed over the local shard's nodes (queue depths by class, model-bound drops, ...)."""
+        s = ClusterStats()
+        self._ck(self.lib.f["cluster_stats_get"](self.h, C.byref(s)), "sim_cluster_stats_get")
+        return {"up": s.up, "queued": [int(x) for x in s.queued], "overflow": s.overflow,
+                "inbox_records": s.inbox_records, "failed": s.failed, "left": s.left, "max_queue": s.max_queue}
 
     def exchange_bytes(self):
         n = C.c_size_t()

@@ -41,7 +41,10 @@ typedef uint64_t u64;
 #define STAMP_MASK 0x1FFFFFu
 #define BLOCK 256
 #define KEMPTY 0xFFFFFFFFu  // empty sort key
-#define SIM_PEND 24u  // >= SIM_MAX_FANOUT * SIM_P records + SIM_S timers + 1 probe per node and tick
+// broadcasts one node can park in one tick: every received record can ask for one rebroadcast,
+// every suspicion timer can fire (dead) and the probe can fail (suspect)
+#define SIM_PEND (SIM_MAX_FANOUT * SIM_P + SIM_S + 1u)
+static_assert(SIM_PEND == 25u, "pend rows are sized for fan-out 4 x 4 records + 8 timers + 1 probe");
 
 // ------------------------------------------------------------------------------------------------
 // hashing / permutation (same arithmetic as the spec; host and device)
@@ -63,7 +66,7 @@ struct TickP {  // per-tick parameters, passed by value (lands in SGPRs)
   u64 tick;
   u64 loss_base, probe_base, query_base;
   u32 M, mask, shift, feff, V, blk, loss_u32, first;  // first: tick 0 has no inbox yet
-  u32 n_slots;  // view slots allocated so far (the Reaper walks them)
+  u32 n_slots;  // length of d.walk: view slots in use (the Reaper and the push-pull merge walk them)
   u32 zero_;    // always 0 (opaque to the compiler)
   u32 abl;      // -DTICK_ABLATE measurement builds only: parts of the tick to leave out
   u32 mul[3], add[3], imul[3];
@@ -165,6 +168,7 @@ struct Dev {
   uint4* qring;  // [Bq][Nl]
   u32* slot_of;     // [N]
   u32* subject_of;  // [A]
+  u32* walk;        // [n_slots] allocated slots in ascending SUBJECT order (the order of every walk over the view)
   u32* upmap;       // [ceil(N/32)] ground-truth liveness of every node (all shards)
   uint4* qtab;      // [SIM_QT] running queries {qid, origin, deadline, flags}
   u32* qbits;       // [SIM_QT][2][ceil(N/32)] who acked / responded, by global node id
@@ -387,6 +391,7 @@ __device__ static void q_renorm(Node& n, SK sk) {
 // Park a broadcast request; phase 2 of the tick queues them in this order (queue_broadcast order
 // is arrival order, and no handler looks at the queue, so deferring is exact).
 __device__ static inline void pend_push(const Ctx& c, Node& n, const Ins& q) {
+  if (n.npend >= SIM_PEND) { n.overflow++; n.dirty |= DR2; return; }  // cannot happen (SIM_PEND is the per-tick maximum); never write past the array
   c.d.pend[(size_t)n.npend * c.d.Nl + c.l] = make_uint4(q.key, q.wmeta, (u32)q.val, (u32)(q.val >> 32));
   n.npend++;
 }
@@ -868,7 +873,8 @@ __device__ static void reap_run(const Ctx& c, Node& n, u32 n_slots) {
   const Dev& d = c.d;
   u32 now = c.tick, next = 0;
 #pragma unroll 1
-  for (u32 a = 0; a < n_slots; ++a) {
+  for (u32 wi = 0; wi < n_slots; ++wi) {  // in subject order: independent of how the slots were handed out
+    u32 a = d.walk[wi];
     uint4* p = view_slot_ptr(c, a);
     uint4 e = p[0];
     u32 age = (now - SIM_VB_STAMP(e.w)) & STAMP_MASK, timeout;
@@ -1279,7 +1285,7 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
           n.eclock++;
           uint4* p = ering_ptr(c, lt);
           handle_user_event(c, n, a, lt, p, p[0], dirty);
-          ins_set(ins2, a, wire_meta(SIM_K_EVENT, 0, b), lt);
+          ins_set(ins2, a, wire_meta(SIM_K_EVENT, (b >> 31) ? SIM_F_CC : 0u, b & 0x7FFFFFFFu), lt);
         }
         break;
       case SIM_OP_QUERY:  // base.rs:875-942
@@ -1372,7 +1378,8 @@ __device__ static void pp_merge(const Dev& d, const TickP& tp, u32 ll, u32 lr) {
   bool dirty = false;
   if (d.swim) {  // alive as alive, left as dead{from = node}, suspect and dead as suspect
 #pragma unroll 1
-    for (u32 a = 0; a < tp.n_slots; ++a) {
+    for (u32 wi = 0; wi < tp.n_slots; ++wi) {
+      u32 a = d.walk[wi];
       uint4 re = d.view[((size_t)a * d.Nl + lr) * 2];
       if (!(re.w & SIM_VB_KNOWN)) continue;
       if (n.next_seq > 1023u - 64u) q_renorm(n, sk);  // a merge can queue one broadcast per view slot
@@ -1395,7 +1402,8 @@ __device__ static void pp_merge(const Dev& d, const TickP& tp, u32 ll, u32 lr) {
 #pragma unroll 1
   for (u32 pass = 0; pass < 2; ++pass) {  // left members first (at status_ltime + 1), then the join intents
 #pragma unroll 1
-    for (u32 a = 0; a < tp.n_slots; ++a) {
+    for (u32 wi = 0; wi < tp.n_slots; ++wi) {
+      u32 a = d.walk[wi];
       uint4 re = d.view[((size_t)a * d.Nl + lr) * 2];
       if (!(re.w & SIM_VB_KNOWN)) continue;
       bool left = SIM_VB_STATUS(re.w) == SIM_STATUS_LEFT;
@@ -1456,6 +1464,15 @@ __global__ void fill_view_col(uint4* view, size_t Nl, u32 a, uint4 e0, uint4 e1)
     view[((size_t)a * Nl + l) * 2] = e0;
     view[((size_t)a * Nl + l) * 2 + 1] = e1;
   }
+}
+// keep d.walk sorted by subject: shift [pos, count) up by one, put slot a at pos (one thread; slot allocation is rare)
+__global__ void walk_insert_kernel(u32* walk, u32 count, u32 pos, u32 a) {
+  if (threadIdx.x || blockIdx.x) return;
+  for (u32 i = count; i > pos; --i) walk[i] = walk[i - 1];
+  walk[pos] = a;
+}
+__global__ void fill_iota(u32* p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = (u32)i;
 }
 __global__ void init_dense_self(Dev d) {  // new_in's synthetic notify_join(local): self known, Alive @ 0
   for (size_t l = blockIdx.x * (size_t)blockDim.x + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * blockDim.x) {
@@ -1657,6 +1674,29 @@ __global__ void stats_kernel(Dev d, u32 l, sim_stats* o) {
   s.queue_overflow = r2.w;
   *o = s;
 }
+// cluster-wide load figures: out[0] up, [1..4] queue entries by class, [5] overflow, [6] records in flight,
+// [7] failed, [8] left, [9] deepest queue (max)
+__global__ void cluster_stats_kernel(Dev d, const uint4* inbox, u64* out) {
+  u64 a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  u32 mx = 0;
+  for (size_t l = blockIdx.x * (size_t)BLOCK + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * BLOCK) {
+    uint4 r1 = d.R1[l], r2 = d.R2[l];
+    a[0] += (r1.z & SIM_RF_UP) ? 1u : 0u;
+    u32 cnt = __popc(r2.z >> 16);
+    mx = max(mx, cnt);
+    for (u32 q = 0; q < cnt; ++q) {
+      uint4 kq = d.qkeys[(size_t)(q >> 2) * d.Nl + l];
+      u32 k = (q & 3) == 0 ? kq.x : (q & 3) == 1 ? kq.y : (q & 3) == 2 ? kq.z : kq.w;
+      a[1 + (k >> 26)] += 1;
+    }
+    a[5] += r2.w; a[7] += r2.x; a[8] += r2.y;
+    if (inbox)
+      for (u32 k = 0; k < d.f; ++k)
+        for (u32 p = 0; p < SIM_P; ++p) a[6] += SIM_META_KIND(inbox[((size_t)k * d.Nl + l) * 4 + p].y) != SIM_K_EMPTY;
+  }
+  for (int i = 0; i < 9; ++i) block_sum_add(a[i], out + i);
+  atomicMax((unsigned long long*)(out + 9), (unsigned long long)mx);
+}
 __global__ void set_flag_bits(uint4* R1, u32 l, u32 bits) {
   if (threadIdx.x == 0 && blockIdx.x == 0) R1[l].z |= bits;
 }
@@ -1676,6 +1716,7 @@ struct sim_handle {
   u32 dense, n_slots;
   hipStream_t stream;
   std::vector<u32> slot_of, subject_of;
+  std::vector<u32> walk;  // host copy of d.walk
   std::vector<sim_view> base;
   uint4* d_base;  // [N][2]
   std::vector<OpEnt> ops;
@@ -1849,7 +1890,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   DA(d.view, (size_t)d.A * Nl * 2)
   DA(d.ering, (size_t)d.Bev * Nl * 2)
   DA(d.qring, (size_t)d.Bq * Nl * 2)
-  DA(d.slot_of, d.N) DA(d.subject_of, d.A) DA(d.upmap, nup) DA(d.nullcell, 2)
+  DA(d.slot_of, d.N) DA(d.subject_of, d.A) DA(d.walk, d.A) DA(d.upmap, nup) DA(d.nullcell, 2)
   DA(d.qtab, SIM_QT) DA(d.qbits, (size_t)SIM_QT * 2 * nup)
   DA(d.events, (size_t)EV_CAP) DA(d.ev_count, 1)
   DA(h->d_base, (size_t)d.N * 2)
@@ -1886,7 +1927,9 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   fill_view_col<<<grid_for(d.N), BLOCK, 0, s>>>(h->d_base, d.N, 0, e0, e1);  // d_base is one "column" of N entries
   if (h->dense) {
     h->n_slots = d.N;
-    for (u32 i = 0; i < d.N; ++i) h->slot_of[i] = h->subject_of[i] = i;
+    h->walk.resize(d.N);
+    for (u32 i = 0; i < d.N; ++i) h->slot_of[i] = h->subject_of[i] = h->walk[i] = i;
+    fill_iota<<<grid_for(d.N), BLOCK, 0, s>>>(d.walk, d.N);
     if (joined) {
       size_t tot = (size_t)d.A * Nl;
       fill_view_col<<<grid_for(tot), BLOCK, 0, s>>>(d.view, tot, 0, e0, e1);
@@ -1923,6 +1966,12 @@ static int ensure_slot(sim_handle* h, u32 subject) {
   uint4 e0 = make_uint4((u32)b.ltime, (u32)(b.ltime >> 32), b.inc, b.bits);
   uint4 e1 = make_uint4(b.conf[0], b.conf[1], b.conf[2], b.conf[3]);
   fill_view_col<<<grid_for(d.Nl), BLOCK, 0, h->stream>>>(d.view, d.Nl, a, e0, e1);
+  {
+    u32 pos = (u32)h->walk.size();
+    while (pos > 0 && h->subject_of[h->walk[pos - 1]] > subject) --pos;
+    walk_insert_kernel<<<1, 64, 0, h->stream>>>(d.walk, (u32)h->walk.size(), pos, a);
+    h->walk.insert(h->walk.begin() + pos, a);
+  }
   HCHECK(hipMemcpyAsync(d.slot_of + subject, &h->slot_of[subject], 4, hipMemcpyHostToDevice, h->stream));
   HCHECK(hipMemcpyAsync(d.subject_of + a, &h->subject_of[a], 4, hipMemcpyHostToDevice, h->stream));
   return SIM_OK;
@@ -1933,7 +1982,7 @@ int sim_inject(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, uint32_
   if (tick < h->tick) tick = h->tick;
   int rc = SIM_OK;
   switch (op) {
-    case SIM_OP_USER_EVENT: if (!a) return SIM_EINVAL; if (b > 9 * 1024) return SIM_ETOOBIG; break;
+    case SIM_OP_USER_EVENT: if (!a) return SIM_EINVAL; if ((b & 0x7FFFFFFFu) > 9 * 1024) return SIM_ETOOBIG; break;  // bit 31: cc
     case SIM_OP_QUERY: if (!a) return SIM_EINVAL; break;
     case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: rc = ensure_slot(h, node); break;
     case SIM_OP_FORCE_LEAVE: rc = ensure_slot(h, a); break;
@@ -1961,8 +2010,8 @@ int sim_force_leave(sim_handle* h, uint32_t node, uint32_t subject, int prune) {
   return sim_inject(h, h ? h->tick : 0, SIM_OP_FORCE_LEAVE, node, subject, prune ? 1u : 0u);
 }
 int sim_user_event(sim_handle* h, uint32_t node, uint32_t key, uint32_t len, int cc) {
-  (void)cc;
-  return sim_inject(h, h ? h->tick : 0, SIM_OP_USER_EVENT, node, key, len);
+  // UserEventMessage.cc (types/user_event/message.rs) travels in the record's flag bits
+  return sim_inject(h, h ? h->tick : 0, SIM_OP_USER_EVENT, node, key, (len & 0x7FFFFFFFu) | (cc ? 0x80000000u : 0u));
 }
 int sim_query(sim_handle* h, uint32_t node, uint32_t id, uint32_t flags) {
   return sim_inject(h, h ? h->tick : 0, SIM_OP_QUERY, node, id, flags);
@@ -1972,6 +2021,7 @@ int sim_step(sim_handle* h, uint32_t n_ticks) {
   if (!h) return SIM_EINVAL;
   Dev& d = h->d;
   if (d.sharded && !h->bound) return SIM_ESTATE;
+  if (d.sharded && n_ticks > 1) return SIM_EINVAL;  // the caller has to move send -> recv between two ticks
   for (u32 it = 0; it < n_ticks; ++it) {
     TickP tp;
     tickp_make(&tp, &h->cfg, h->tick);
@@ -1979,7 +2029,7 @@ int sim_step(sim_handle* h, uint32_t n_ticks) {
     tp.abl = g_ablate;
 #endif
     for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) tp.prot[k] = h->prev.rot[k];
-    tp.n_slots = h->n_slots;
+    tp.n_slots = (u32)h->walk.size();
     while (h->op_cursor < h->ops.size() && h->ops[h->op_cursor].tick <= h->tick) {
       OpBatch ob;
       memset(&ob, 0, sizeof ob);
@@ -2140,13 +2190,16 @@ int sim_dump_state(sim_handle* h, uint32_t which, void* buf, size_t cap, size_t*
     if (hipMalloc(&tmp, std::max<size_t>(n, 16)) != hipSuccess) return SIM_ENOMEM;
     if (which == SIM_ARR_ROWS) canon_rows_kernel<<<grid_for(Nl), BLOCK, 0, h->stream>>>(d, (u64*)tmp);
     else canon_queue_kernel<<<grid_for(Nl), BLOCK, 0, h->stream>>>(d, (uint4*)tmp);
-    hipError_t e = hipMemcpy(buf, tmp, n, hipMemcpyDeviceToHost);
+    // copy on the handle's stream: a non-blocking stream does not order against the null stream
+    hipError_t e = hipMemcpyAsync(buf, tmp, n, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     (void)hipFree(tmp);
     HCHECK(e);
     return SIM_OK;
   }
   if (!src) { memset(buf, 0, n); return SIM_OK; }
-  HCHECK(hipMemcpy(buf, src, n, hipMemcpyDeviceToHost));
+  HCHECK(hipMemcpyAsync(buf, src, n, hipMemcpyDeviceToHost, h->stream));
+  HCHECK(hipStreamSynchronize(h->stream));
   return SIM_OK;
 }
 
@@ -2214,9 +2267,9 @@ int sim_snapshot(sim_handle* h, void* buf, size_t cap, size_t* bytes) {
     } else if (i == 6) memcpy(o, h->slot_of.data(), n);
     else if (i == 7) memcpy(o, h->subject_of.data(), n);
     else if (i == 8) memcpy(o, h->base.data(), n);
-    else if (i == 9) HCHECK(hipMemcpy(o, d.upmap, n, hipMemcpyDeviceToHost));
-    else if (i == 10) HCHECK(hipMemcpy(o, d.qtab, n, hipMemcpyDeviceToHost));
-    else if (i == 11) HCHECK(hipMemcpy(o, d.qbits, n, hipMemcpyDeviceToHost));
+    else if (i == 9) { HCHECK(hipMemcpyAsync(o, d.upmap, n, hipMemcpyDeviceToHost, h->stream)); HCHECK(hipStreamSynchronize(h->stream)); }
+    else if (i == 10) { HCHECK(hipMemcpyAsync(o, d.qtab, n, hipMemcpyDeviceToHost, h->stream)); HCHECK(hipStreamSynchronize(h->stream)); }
+    else if (i == 11) { HCHECK(hipMemcpyAsync(o, d.qbits, n, hipMemcpyDeviceToHost, h->stream)); HCHECK(hipStreamSynchronize(h->stream)); }
     else if (n) memcpy(o, h->ops.data() + h->op_cursor, n);
     o += n;
   }
@@ -2229,52 +2282,70 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
   snap_header hd;
   memcpy(&hd, buf, sizeof hd);
   if (hd.magic != SNAP_MAGIC || hd.abi != SIM_ABI_VERSION || memcmp(&hd.cfg, &h->cfg, sizeof(sim_config))) return SIM_EINVAL;
-  h->tick = hd.tick;
-  h->n_slots = hd.n_slots;
-  h->ops.assign(hd.n_pending_ops, OpEnt{0, 0, 0, 0, 0});
-  h->op_cursor = 0;
-  for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) h->prev.rot[k] = hd.prev_rot[k];
+  // ---- pass 1: validate the header and every section length before anything is touched ----
+  if (hd.n_slots > d.A) return SIM_EINVAL;                          // reap_run / pp_merge walk a < n_slots
+  if ((size_t)hd.n_pending_ops > bytes / sizeof(OpEnt)) return SIM_EINVAL;  // sizes a host allocation
   size_t len[SNAP_SECTIONS];
   snap_lengths(h, len);
-  const uint8_t* in = (const uint8_t*)buf + sizeof hd;
-  const uint8_t* end = (const uint8_t*)buf + bytes;
+  len[SNAP_SECTIONS - 1] = (size_t)hd.n_pending_ops * sizeof(OpEnt);
+  const uint8_t* sec[SNAP_SECTIONS];
+  {
+    const uint8_t* in = (const uint8_t*)buf + sizeof hd;
+    const uint8_t* end = (const uint8_t*)buf + bytes;
+    for (int i = 0; i < SNAP_SECTIONS; ++i) {
+      uint64_t n;
+      if ((size_t)(end - in) < 8) return SIM_EINVAL;
+      memcpy(&n, in, 8); in += 8;
+      if (n != len[i] || (size_t)(end - in) < n) return SIM_EINVAL;
+      sec[i] = in;
+      in += n;
+    }
+  }
+  uint4* inbox_dst = d.sharded ? d.xrecv : d.inbox[hd.tick & 1];
+  if (len[2] && !inbox_dst) return SIM_ESTATE;  // sharded: bind the exchange buffers first
+  {  // slot maps must be consistent with n_slots (they index the view)
+    const u32* so = (const u32*)sec[6];
+    for (u32 i = 0; i < d.N; ++i)
+      if (so[i] != NOSLOT && so[i] >= (h->dense ? d.A : hd.n_slots)) return SIM_EINVAL;
+  }
+  // ---- pass 2: device copies (the handle's host state is committed only after they succeed) ----
   hipStream_t s = h->stream;
   void* tmp_rows = nullptr;
   void* tmp_queue = nullptr;
-  for (int i = 0; i < SNAP_SECTIONS; ++i) {
-    uint64_t n;
-    if (in + 8 > end) return SIM_EINVAL;
-    memcpy(&n, in, 8); in += 8;
-    if (n != len[i] || in + n > end) return SIM_EINVAL;
-    switch (i) {
-      case 0: if (hipMalloc(&tmp_rows, std::max<size_t>(n, 16)) != hipSuccess) return SIM_ENOMEM;
-              HCHECK(hipMemcpy(tmp_rows, in, n, hipMemcpyHostToDevice)); break;
-      case 1: if (hipMalloc(&tmp_queue, std::max<size_t>(n, 16)) != hipSuccess) return SIM_ENOMEM;
-              HCHECK(hipMemcpy(tmp_queue, in, n, hipMemcpyHostToDevice)); break;
-      case 2: { uint4* dst = d.sharded ? d.xrecv : d.inbox[h->tick & 1];
-                if (n && !dst) return SIM_ESTATE;  // sharded: bind the exchange buffers first
-                if (n) HCHECK(hipMemcpy(dst, in, n, hipMemcpyHostToDevice)); break; }
-      case 3: if (n) HCHECK(hipMemcpy(d.view, in, n, hipMemcpyHostToDevice)); break;
-      case 4: if (n) HCHECK(hipMemcpy(d.ering, in, n, hipMemcpyHostToDevice)); break;
-      case 5: if (n) HCHECK(hipMemcpy(d.qring, in, n, hipMemcpyHostToDevice)); break;
-      case 6: memcpy(h->slot_of.data(), in, n); HCHECK(hipMemcpy(d.slot_of, in, n, hipMemcpyHostToDevice)); break;
-      case 7: memcpy(h->subject_of.data(), in, n); HCHECK(hipMemcpy(d.subject_of, in, n, hipMemcpyHostToDevice)); break;
-      case 8: memcpy(h->base.data(), in, n); HCHECK(hipMemcpy(h->d_base, in, n, hipMemcpyHostToDevice)); break;
-      case 9: HCHECK(hipMemcpy(d.upmap, in, n, hipMemcpyHostToDevice)); break;
-      case 10: HCHECK(hipMemcpy(d.qtab, in, n, hipMemcpyHostToDevice)); break;
-      case 11: HCHECK(hipMemcpy(d.qbits, in, n, hipMemcpyHostToDevice)); break;
-      default: if (n) memcpy(h->ops.data(), in, n); break;
+  int rc = SIM_OK;
+#define RCHECK(x) do { if (rc == SIM_OK && (x) != hipSuccess) rc = SIM_EDEVICE; } while (0)
+  if (hipMalloc(&tmp_rows, std::max<size_t>(len[0], 16)) != hipSuccess) rc = SIM_ENOMEM;
+  if (rc == SIM_OK && hipMalloc(&tmp_queue, std::max<size_t>(len[1], 16)) != hipSuccess) rc = SIM_ENOMEM;
+  auto up = [&](void* dst, int i) { if (len[i]) RCHECK(hipMemcpyAsync(dst, sec[i], len[i], hipMemcpyHostToDevice, s)); };
+  if (rc == SIM_OK) {
+    up(tmp_rows, 0); up(tmp_queue, 1); up(inbox_dst, 2); up(d.view, 3); up(d.ering, 4); up(d.qring, 5);
+    up(d.slot_of, 6); up(d.subject_of, 7); up(h->d_base, 8); up(d.upmap, 9); up(d.qtab, 10); up(d.qbits, 11);
+    // canonical rows / queue -> packed row groups, sort keys + slot-stable payloads
+    RCHECK(hipMemsetAsync(d.R2, 0, (size_t)d.Nl * 16, s));
+    if (rc == SIM_OK) {
+      restore_queue_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, (const uint4*)tmp_queue);
+      restore_rows_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, (const u64*)tmp_rows);
+      RCHECK(hipGetLastError());
     }
-    in += n;
+    RCHECK(hipStreamSynchronize(s));
   }
-  // canonical rows / queue -> packed row groups, sort keys + slot-stable payloads
-  HCHECK(hipMemsetAsync(d.R2, 0, (size_t)d.Nl * 16, s));
-  restore_queue_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, (const uint4*)tmp_queue);
-  restore_rows_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, (const u64*)tmp_rows);
-  hipError_t e = hipStreamSynchronize(s);
-  (void)hipFree(tmp_rows);
-  (void)hipFree(tmp_queue);
-  HCHECK(e);
+#undef RCHECK
+  if (tmp_rows) (void)hipFree(tmp_rows);
+  if (tmp_queue) (void)hipFree(tmp_queue);
+  if (rc != SIM_OK) return rc;
+  h->tick = hd.tick;
+  h->n_slots = hd.n_slots;
+  for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) h->prev.rot[k] = hd.prev_rot[k];
+  memcpy(h->slot_of.data(), sec[6], len[6]);
+  memcpy(h->subject_of.data(), sec[7], len[7]);
+  memcpy(h->base.data(), sec[8], len[8]);
+  h->walk.clear();
+  for (u32 subj = 0; subj < d.N; ++subj)
+    if (h->slot_of[subj] != NOSLOT) h->walk.push_back(h->slot_of[subj]);
+  if (!h->walk.empty()) HCHECK(hipMemcpy(d.walk, h->walk.data(), h->walk.size() * 4, hipMemcpyHostToDevice));
+  h->ops.assign(hd.n_pending_ops, OpEnt{0, 0, 0, 0, 0});
+  if (len[12]) memcpy(h->ops.data(), sec[12], len[12]);
+  h->op_cursor = 0;
   return SIM_OK;
 }
 int sim_query_status(sim_handle* h, uint32_t qid, uint64_t* acks, uint64_t* responses, int* open) {
@@ -2317,6 +2388,47 @@ int sim_profile_read(sim_handle* h, double* ms, uint64_t* launches) {
   *ms = tot;
   *launches = h->prof.size();
   h->prof.clear();
+  return SIM_OK;
+}
+int sim_profile_read_stats(sim_handle* h, double out_ms[3], uint64_t* launches) {
+  if (!h || !out_ms || !launches) return SIM_EINVAL;
+  HCHECK(hipStreamSynchronize(h->stream));
+  double tot = 0.0, mn = 0.0, mx = 0.0;
+  bool first = true;
+  for (auto& pr : h->prof) {
+    float t = 0.f;
+    HCHECK(hipEventElapsedTime(&t, pr.first, pr.second));
+    tot += t;
+    mn = first ? t : std::min<double>(mn, t);
+    mx = first ? t : std::max<double>(mx, t);
+    first = false;
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  out_ms[0] = tot; out_ms[1] = mn; out_ms[2] = mx;
+  *launches = h->prof.size();
+  h->prof.clear();
+  return SIM_OK;
+}
+int sim_cluster_stats_get(sim_handle* h, sim_cluster_stats* out) {
+  if (!h || !out) return SIM_EINVAL;
+  Dev& d = h->d;
+  hipStream_t s = h->stream;
+  u64* scr = nullptr;
+  if (hipMalloc((void**)&scr, 10 * 8) != hipSuccess) return SIM_ENOMEM;
+  u64 r[10];
+  hipError_t e = hipMemsetAsync(scr, 0, 10 * 8, s);
+  if (e == hipSuccess) {
+    // sharded: the packets in flight sit in the receive buffer, [src][k][blk] = f * Nl cells as well
+    cluster_stats_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, cur_inbox(h), scr);
+    e = hipMemcpyAsync(r, scr, sizeof r, hipMemcpyDeviceToHost, s);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(scr);
+  HCHECK(e);
+  out->up = r[0];
+  for (int i = 0; i < 4; ++i) out->queued[i] = r[1 + i];
+  out->overflow = r[5]; out->inbox_records = r[6]; out->failed = r[7]; out->left = r[8]; out->max_queue = r[9];
   return SIM_OK;
 }
 int sim_exchange_bytes(const sim_handle* h, size_t* bytes) {

@@ -62,7 +62,7 @@ struct Options {
   static Options lan(uint32_t n) { return Options(n); }
   static Options wan(uint32_t n) {  // gossip 500 ms, probe 5 s, fan-out 4, suspicion_mult 6 (k capped at 3)
     Options o(n);
-    o.c.fanout = 4; o.c.probe_interval = 10; o.c.suspicion_mult = 5;
+    o.c.fanout = 4; o.c.probe_interval = 10; o.c.suspicion_mult = 6;
     return o;
   }
   Options& with_fanout(uint32_t f) { c.fanout = f; return *this; }

@@ -37,6 +37,7 @@ class ShardedSim:
         self.n = n_nodes
         self.m = n_nodes // self.world
         self.lo = self.rank * self.m
+        self._xt = None  # exchange timing: list of (start, end) event pairs while enabled
 
     def owns(self, node):
         return self.lo <= node < self.lo + self.m
@@ -61,7 +62,39 @@ class ShardedSim:
     def step(self, n_ticks=1):
         for _ in range(n_ticks):
             self.sim.step(1)  # reads self.recv (packets of the previous round), fills self.send
-            dist.all_to_all_single(self.recv, self.send, group=self.group)
+            if self._xt is None:
+                dist.all_to_all_single(self.recv, self.send, group=self.group)
+            else:
+                e0, e1 = self._event(), self._event()
+                e0.record()
+                dist.all_to_all_single(self.recv, self.send, group=self.group)
+                e1.record()
+                self._xt.append((e0, e1))
+
+    # measurement: time of the collective alone (events on the stream it is enqueued on) -------------
+    def _event(self):
+        if self.device.type == "cuda":
+            return torch.cuda.Event(enable_timing=True)
+
+        class _T:  # CPU stand-in (gloo is synchronous)
+            def record(self):
+                import time
+                self.t = time.perf_counter()
+
+            def elapsed_time(self, other):
+                return (other.t - self.t) * 1e3
+        return _T()
+
+    def time_exchange(self, enable):
+        """enable=True: start bracketing every all-to-all with events; enable=False: stop and return the
+        summed milliseconds since it was enabled."""
+        if enable:
+            self._xt = []
+            return 0.0
+        pairs, self._xt = self._xt or [], None
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        return float(sum(a.elapsed_time(b) for a, b in pairs))
 
     def sync(self):
         self.sim.sync()

@@ -21,7 +21,7 @@ def _worker(rank, world, port, q):
 
     try:
         args = bench.parse_args(["--gpus", str(world), "--steps", "20", "--warmup", "10", "--nodes-per-gpu", "2048",
-                                 "--view-slots", "64", "--ring", "32", "--no-cpu-baseline"])
+                                 "--view-slots", "64", "--ring", "32", "--no-cpu-baseline", "--allow-drops"])
         out = bench.run(args, lib=load_oracle(), dev=torch.device("cpu"), backend="gloo")
         q.put((rank, json.dumps(out) if out is not None else "null"))
     except BaseException as e:  # noqa: BLE001

@@ -16,7 +16,7 @@ def pair(oracle, hiplib, n, **kw):
 
 def test_backend_is_hip(hiplib):
     assert hiplib.backend_name() == "hip-gfx950"
-    assert hiplib.abi_version() == 6
+    assert hiplib.abi_version() == 7
 
 
 @pytest.mark.parametrize("swim", [0, 5, 2])
@@ -243,3 +243,27 @@ def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim):
         assert (sum(p[0] for p in parts), sum(p[1] for p in parts), parts[0][2]) == ref.query_status(qop[3])
     tot = [sum(x) for x in zip(*(s.convergence(_ffi.K_LEAVE, next(o for o in ops if o[1] == _ffi.OP_LEAVE)[2], 1) for s in shards))]
     assert tuple(tot) == ref.convergence(_ffi.K_LEAVE, next(o for o in ops if o[1] == _ffi.OP_LEAVE)[2], 1)
+
+
+def test_bench_configuration_64k_digests(oracle, hiplib):
+    # The benchmark's OWN configuration tuple and schedule (bench.workload: fan-out 4, view_slots 1024, rings 512,
+    # probe interval 5, push-pull 150, reaper 75, queue checker 150, evenly spaced operations at the bench rate),
+    # at 64 Ki nodes so that the oracle keeps up: 440 ticks — the pre-roll into the stationary load and beyond, a
+    # push-pull batch (every 225 ticks at this size), Reaper and QueueChecker rounds, suspicion timers firing
+    # (min 96 ticks) — with a digest of every array every 40 ticks, and no model bound hit on either side.
+    import bench
+
+    n = 1 << 16
+    args = bench.parse_args(["--nodes-per-gpu", str(n)])
+    kw, ops = bench.workload(args, n)
+    g, o = pair(oracle, hiplib, n, **kw)
+    sc.apply_schedule(g, ops)
+    sc.apply_schedule(o, ops)
+    for t in range(0, 440, 40):
+        g.step(40)
+        o.step(40)
+        assert g.digest() == o.digest(), f"digest differs after tick {t + 40}"
+    cg, co = g.cluster_stats(), o.cluster_stats()
+    assert cg == co
+    assert cg["overflow"] == 0, "the benchmark workload must stay inside the model bounds"
+    assert cg["failed"] > 0 and cg["left"] > 0, "crashes and leaves were declared (timers fired) within the window"

@@ -47,7 +47,7 @@ def run_case(lib, case):
 
 if __name__ == "__main__":
     lib = load_oracle()
-    doc = {"spec": "DESIGN.md SIMSPEC (ABI 4)", "cases": []}
+    doc = {"spec": f"DESIGN.md SIMSPEC (ABI {lib.abi_version()})", "cases": []}
     for case in CASES:
         doc["cases"].append(dict(case, digests=run_case(lib, case)))
     path = os.path.join(ROOT, "tests", "golden", "digests.json")
