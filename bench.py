@@ -113,7 +113,7 @@ def parse_args(argv=None):
     ap.add_argument("--fanout", type=int, default=4)
     ap.add_argument("--view-slots", type=int, default=1024)
     ap.add_argument("--ring", type=int, default=512)
-    ap.add_argument("--rate", type=float, default=0.4, help="API operations injected per tick (cluster-wide)")
+    ap.add_argument("--rate", type=float, default=0.25, help="API operations injected per tick (cluster-wide)")
     ap.add_argument("--probe-interval", type=int, default=5, help="memberlist probe interval in ticks (0 = SWIM layer off)")
     ap.add_argument("--push-pull-interval", type=int, default=150, help="memberlist push_pull_interval in ticks before log2(N) scaling (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

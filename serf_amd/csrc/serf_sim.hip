@@ -862,6 +862,27 @@ __device__ static inline uint4* lookup_ptr(const Ctx& c, u32 kind, u32 key, u64 
   uint4* p = basep + (row * d.Nl + c.l) * 2;
   return none ? nullptr : p;
 }
+// Row of the state array a record is checked against — view slot of its subject, or ring bucket of its Lamport
+// time — as an 18-bit id (NOROW: nothing to look at).  The staged copy of a record carries it in the bits of
+// `meta` that are zero on the wire ([17:8] and [31:24]), so that the handler loop needs no staged pointers.
+#define NOROW 0x3FFFFu
+__device__ static inline u32 row_pack(u32 row) { return ((row & 0x3FFu) << 8) | ((row >> 10) << 24); }
+__device__ static inline u32 row_unpack(u32 meta) { return ((meta >> 8) & 0x3FFu) | ((meta >> 24) << 10); }
+__device__ static inline u32 lookup_row(const Dev& d, u32 kind, u64 val, u32 slot) {
+  bool isq = kind == SIM_K_QUERY, isring = isq || kind == SIM_K_EVENT;
+  u32 B = isq ? d.Bq : d.Bev, mask = isq ? d.bq_mask : d.bev_mask;
+  u32 idx = (u32)val & mask;
+  if (!(d.bev_mask && d.bq_mask)) idx = ring_idx(val, B, mask);  // uniform: a ring size that is not a power of two
+  bool none = !isring && (kind == SIM_K_EMPTY || slot == NOSLOT);
+  return none ? NOROW : (isring ? idx : slot);
+}
+__device__ static inline uint4* row_ptr(const Ctx& c, u32 kind, u32 row) {
+  const Dev& d = c.d;
+  uint4* basep = kind == SIM_K_QUERY ? d.qring : kind == SIM_K_EVENT ? d.ering : d.view;
+  return basep + ((size_t)row * d.Nl + c.l) * 2;
+}
+// which array a kind's row lives in (view 0, event ring 1, query ring 2), above the 18 row bits: "same entry" test
+__device__ static inline u32 row_tag(u32 kind, u32 row) { return row | ((kind == SIM_K_EVENT ? 1u : kind == SIM_K_QUERY ? 2u : 0u) << 18); }
 // slot of a member record's subject (NOSLOT for other kinds and for ids out of range)
 __device__ static inline u32 slot_load(const Dev& d, u32 kind, u32 key) {
   u32 s = NOSLOT;
@@ -1012,17 +1033,24 @@ static u32 g_ablate = 0;
 #else
 #define ABL(bit) false
 #endif
+// global_load_lds writes LDS behind the compiler's back as far as its s_waitcnt insertion is concerned (it was seen
+// issuing a ds_read of DMA'd data ahead of the vmcnt wait): every consumer waits explicitly.  The asm is a memory
+// barrier for the compiler as well, so no LDS access moves across it.
+#define DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#ifndef TICK_OCC
+#define TICK_OCC 4
+#endif
 template <bool SHARDED, int F>
-__global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur, const uint4* base) {
+__global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, u32 cur, const uint4* base) {
 #ifdef TICK_TIMING
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #endif
-  // LDS staging of the per-node inbox: the packet being delivered, the slot of each record's
-  // subject's entry and the head of that entry (40 KiB per block: exactly 4 blocks per CU)
+  // LDS staging of the per-node inbox: the packet being delivered (each record tagged with the row of the entry
+  // it is checked against) and the head of that entry: 32 KiB per block = exactly 5 blocks per CU.  Phase 2
+  // reuses both planes as the double buffer of the payload gathers.
   __shared__ uint4 lds_r[SIM_P][BLOCK];
   __shared__ uint4 lds_e[SIM_P][BLOCK];
-  __shared__ uint4* lds_p[SIM_P][BLOCK];  // where each record's entry lives (null: nothing to look at)
   const u32 tid = threadIdx.x;
   u32 l = blockIdx.x * BLOCK + threadIdx.x;
   if (l >= d.Nl) return;
@@ -1072,48 +1100,58 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
           // wave-ballot early out: nobody in this wave received anything in packet k
           if (!__any((k0 | k1 | k2 | k3) != SIM_K_EMPTY)) continue;
           if (ABL(64)) { n.dirty |= (k0 ^ k1 ^ k2 ^ k3) & tp.zero_; continue; }
-          lds_r[0][tid] = r0; lds_r[1][tid] = r1; lds_r[2][tid] = r2; lds_r[3][tid] = r3;
           u32 s0 = slot_load(d, k0, r0.x);
           u32 s1 = slot_load(d, k1, r1.x);
           u32 s2 = slot_load(d, k2, r2.x);
           u32 s3 = slot_load(d, k3, r3.x);
           TT(2);
-          uint4* p0 = lookup_ptr(c, k0, r0.x, (u64)r0.z | ((u64)r0.w << 32), s0);
-          uint4* p1 = lookup_ptr(c, k1, r1.x, (u64)r1.z | ((u64)r1.w << 32), s1);
-          uint4* p2 = lookup_ptr(c, k2, r2.x, (u64)r2.z | ((u64)r2.w << 32), s2);
-          uint4* p3 = lookup_ptr(c, k3, r3.x, (u64)r3.z | ((u64)r3.w << 32), s3);
-          lds_p[0][tid] = p0; lds_p[1][tid] = p1; lds_p[2][tid] = p2; lds_p[3][tid] = p3;
-          uint4 e0 = ld4(p0 ? p0 : d.nullcell), e1 = ld4(p1 ? p1 : d.nullcell), e2 = ld4(p2 ? p2 : d.nullcell), e3 = ld4(p3 ? p3 : d.nullcell);
+          u32 w0 = lookup_row(d, k0, (u64)r0.z | ((u64)r0.w << 32), s0);
+          u32 w1 = lookup_row(d, k1, (u64)r1.z | ((u64)r1.w << 32), s1);
+          u32 w2 = lookup_row(d, k2, (u64)r2.z | ((u64)r2.w << 32), s2);
+          u32 w3 = lookup_row(d, k3, (u64)r3.z | ((u64)r3.w << 32), s3);
+          const uint4* p0 = w0 != NOROW ? row_ptr(c, k0, w0) : d.nullcell;
+          const uint4* p1 = w1 != NOROW ? row_ptr(c, k1, w1) : d.nullcell;
+          const uint4* p2 = w2 != NOROW ? row_ptr(c, k2, w2) : d.nullcell;
+          const uint4* p3 = w3 != NOROW ? row_ptr(c, k3, w3) : d.nullcell;
+          // the four heads go from HBM straight into this wave's columns of lds_e (global_load_lds: no VGPR landing
+          // zone, no LDS write instruction), the tagged records through registers into lds_r
+          const u32 wb = tid & ~63u;
+#define HEAD_DMA(i, ptr) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ptr), \
+                                                          (__attribute__((address_space(3))) void*)&lds_e[i][wb], 16, 0, 0)
+          HEAD_DMA(0, p0); HEAD_DMA(1, p1); HEAD_DMA(2, p2); HEAD_DMA(3, p3);
+#undef HEAD_DMA
+          r0.y |= row_pack(w0); r1.y |= row_pack(w1); r2.y |= row_pack(w2); r3.y |= row_pack(w3);
+          lds_r[0][tid] = r0; lds_r[1][tid] = r1; lds_r[2][tid] = r2; lds_r[3][tid] = r3;
           TT(3);
-          lds_e[0][tid] = e0; lds_e[1][tid] = e1; lds_e[2][tid] = e2; lds_e[3][tid] = e3;
           TT(4);
         }
         // phase B: the records in arrival order, one rolled loop = one copy of the handler code.
         // Duplicates, old messages and subjects without a view slot (~95 % of all records) are
         // retired by fast_noop against the staged head; the rest runs the full handlers.  Once a
         // handler of this packet has written state, later heads are re-read (rare).
-        // `wptr`: the one entry a handler of this packet has written so far; `wall`: more than one,
+        // `wtag`: the one entry a handler of this packet has written so far; `wall`: more than one,
         // or the node's own entry as well (refutation) — only then is a staged head stale.
         if (ABL(32)) continue;
-        uint4* wptr = nullptr;
+        u32 wtag = 0xFFFFFFFFu;
         bool wall = false;
+        DMA_WAIT();  // the heads have landed in lds_e
 #pragma unroll 1
         for (u32 p = 0; p < SIM_P; ++p) {
           uint4 r = lds_r[p][tid];
-          u32 kind = SIM_META_KIND(r.y);
-          uint4* ptr = lds_p[p][tid];
+          u32 kind = SIM_META_KIND(r.y), row = row_unpack(r.y), tag = row_tag(kind, row);
+          bool has = row != NOROW;
           uint4 e = lds_e[p][tid];
-          if (ptr && (wall || ptr == wptr)) e = ld4(ptr);
-          bool fast = fast_noop(c, n, kind, r, ptr != nullptr, e);
+          if (has && (wall || tag == wtag)) e = ld4(row_ptr(c, kind, row));
+          bool fast = fast_noop(c, n, kind, r, has, e);
           fast_witness(n, kind, r, fast);
           if (fast) continue;
           Ins ins;
           ins.has = ins.wide = 0;
           bool dirty = false;
-          dispatch(c, n, r, ptr, e, dirty, ins);
+          dispatch(c, n, r, has ? row_ptr(c, kind, row) : nullptr, e, dirty, ins);
           if (dirty) {
-            wall |= ins.wide || (wptr != nullptr && wptr != ptr);
-            wptr = ptr;
+            wall |= ins.wide || (wtag != 0xFFFFFFFFu && wtag != tag);
+            wtag = tag;
           }
           if (ins.has) pend_push(c, n, ins);
         }
@@ -1174,29 +1212,16 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
     }
   }
   TT(8);
-  // ... then every payload gather of the tick in flight at once (one memory round trip, not F) ...
-  // A queue of at most SIM_P entries sends the same records in every round: a record that sits
-  // in the same place as in the previous packet is copied, not gathered again (the gathers are
-  // scattered 16-byte accesses, one address per lane for the texture addresser).
-  uint4 pk[F][SIM_P];
-#pragma unroll
-  for (int k = 0; k < F; ++k) {
-#pragma unroll
-    for (int p = 0; p < (int)SIM_P; ++p) {
-      u32 s = (slots[k] >> (8 * p)) & 0xFFu;
-      bool again = k > 0 && s == ((slots[k > 0 ? k - 1 : 0] >> (8 * p)) & 0xFFu);
-      pk[k][p] = zero;
-      if (again) pk[k][p] = pk[k > 0 ? k - 1 : 0][p];
-      else if (s != 0xFFu && !ABL(8)) pk[k][p] = ld4(&d.qpay[(size_t)s * d.Nl + l]);
-    }
+  // the node's own state is final here: write the dirty row groups and the live key groups back now (the stores
+  // drain behind the gathers below, and ~40 registers are free for the rest of the tick)
+  if (up && !ABL(16)) {
+    node_store(d, l, n);
+    keys_store(d, l, cnt0, n.used, sk);
   }
   TT(9);
-  // ... then the F scatters: packet k goes to the inbox cell of T_k(l)
+  // ... then the F packets: gather the payload records of packet k, push the packet into the inbox cell of T_k(l).
   u32 sx = tp.feff ? sigma(tp, ll) : 0;
-  const bool coop = (blockIdx.x + 1u) * BLOCK <= d.Nl;  // every lane of the block is here
-#pragma unroll
-  for (int k = 0; k < F; ++k) {
-    if ((u32)k >= tp.feff || ABL(4)) break;
+  auto cell_ptr = [&](int k) -> uint4* {
     u32 y = sx + tp.off[k];
     if (y >= tp.M) y -= tp.M;
     u32 t = sigma_inv(tp, y);
@@ -1205,38 +1230,72 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
       b = t / tp.blk;
       h = (g + tp.V - ((b + tp.rot[k]) % tp.V)) % tp.V;
     }
-    uint4* dst;
-    if (SHARDED) dst = d.xsend + (((size_t)h * d.f + k) * tp.blk + (t - b * tp.blk)) * 4;
-    else dst = d.inbox[cur ^ 1] + ((size_t)k * d.Nl + (size_t)h * tp.M + t) * 4;
-    if (coop) {
-      // Four lanes write one 64-byte cell per store instruction (lane i of the quad writes record
-      // i of quad-mate j's packet): the texture addresser sees 64 contiguous bytes per quad and L2
-      // one write per cell instead of four.  The 4x4 transpose goes through this wave's columns of
-      // lds_r (free in phase 2), XOR-swizzled so that neither side has bank conflicts.
-      lds_r[0][tid] = pk[k][0]; lds_r[1][tid ^ 1] = pk[k][1]; lds_r[2][tid ^ 2] = pk[k][2]; lds_r[3][tid ^ 3] = pk[k][3];
-      __builtin_amdgcn_wave_barrier();
-      u32 qi = tid & 3u, qb = tid & ~3u;
+    if (SHARDED) return d.xsend + (((size_t)h * d.f + k) * tp.blk + (t - b * tp.blk)) * 4;
+    return d.inbox[cur ^ 1] + ((size_t)k * d.Nl + (size_t)h * tp.M + t) * 4;
+  };
+  const bool coop = (blockIdx.x + 1u) * BLOCK <= d.Nl;  // every lane of the block is here
+  if (coop) {
+    // Cooperative path.  The 16-byte payload gathers go straight from HBM into LDS (global_load_lds: no VGPR
+    // round trip), double-buffered over the two staging planes, and land in the XOR-swizzled layout the store
+    // side reads: plane p, column c holds record p of lane c ^ p — so lane c fetches for its quad-mate c ^ p,
+    // whose payload slot comes over by DPP.  Then four lanes write one whole 64-byte cell per store instruction
+    // (lane i of a quad writes record i of quad-mate j's packet): the texture addresser sees 64 contiguous bytes
+    // per quad and L2 one write per cell instead of four partial ones.
+    const u32 qi = tid & 3u, qb = tid & ~3u, wb = tid & ~63u;
+    auto issue = [&](int k, uint4 (*buf)[BLOCK]) {
+#pragma unroll
+      for (int p = 0; p < (int)SIM_P; ++p) {
+        u32 mine = (slots[k] >> (8 * p)) & 0xFFu;
+        u32 sl = mine;  // quad_perm: lane ^ 1 = [1,0,3,2], lane ^ 2 = [2,3,0,1], lane ^ 3 = [3,2,1,0]
+        if (p == 1) sl = (u32)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);
+        if (p == 2) sl = (u32)__builtin_amdgcn_mov_dpp((int)mine, 0x4E, 0xF, 0xF, true);
+        if (p == 3) sl = (u32)__builtin_amdgcn_mov_dpp((int)mine, 0x1B, 0xF, 0xF, true);
+        if (sl != 0xFFu && !ABL(8))
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)&d.qpay[(size_t)sl * d.Nl + (l ^ (u32)p)],
+                                           (__attribute__((address_space(3))) void*)&buf[p][wb], 16, 0, 0);
+        else
+          buf[p][tid] = zero;
+      }
+    };
+    auto push = [&](int k, uint4 (*buf)[BLOCK]) {
+      uint4* dst = cell_ptr(k);
       u32 dlo = (u32)(uintptr_t)dst, dhi = (u32)((uintptr_t)dst >> 32);
 #define COOP_STORE(j)                                                                              \
       {                                                                                            \
-        uint4 v = lds_r[qi][(qb + j) ^ qi];                                                        \
+        uint4 v = buf[qi][(qb + j) ^ qi];                                                          \
         u32 lo = (u32)__builtin_amdgcn_mov_dpp((int)dlo, j * 0x55, 0xF, 0xF, true);                \
         u32 hi = (u32)__builtin_amdgcn_mov_dpp((int)dhi, j * 0x55, 0xF, 0xF, true);                \
-        ((uint4*)(((uintptr_t)hi << 32) | lo))[qi] = v;                                            \
+        v4u vv = {v.x, v.y, v.z, v.w};                                                             \
+        ((__attribute__((address_space(1))) v4u*)(((uintptr_t)hi << 32) | lo))[qi] = vv;           \
       }
       COOP_STORE(0) COOP_STORE(1) COOP_STORE(2) COOP_STORE(3)
 #undef COOP_STORE
+    };
+    // two packets per round trip: both gathers in flight (one per staging plane), one wait, eight cell stores
+#pragma unroll
+    for (int k0 = 0; k0 < F; k0 += 2) {
+      if ((u32)k0 >= tp.feff || ABL(4)) break;
+      issue(k0, lds_r);
+      if (k0 + 1 < F && (u32)k0 + 1 < tp.feff) issue(k0 + 1, lds_e);
+      DMA_WAIT();
+      push(k0, lds_r);
+      if (k0 + 1 < F && (u32)k0 + 1 < tp.feff) push(k0 + 1, lds_e);
       __builtin_amdgcn_wave_barrier();
-    } else {
-      dst[0] = pk[k][0]; dst[1] = pk[k][1]; dst[2] = pk[k][2]; dst[3] = pk[k][3];
+    }
+  } else {
+    // ragged last block: plain per-lane gathers and four 16-byte stores per cell
+#pragma unroll
+    for (int k = 0; k < F; ++k) {
+      if ((u32)k >= tp.feff || ABL(4)) break;
+      uint4* dst = cell_ptr(k);
+#pragma unroll
+      for (int p = 0; p < (int)SIM_P; ++p) {
+        u32 sl = (slots[k] >> (8 * p)) & 0xFFu;
+        dst[p] = (sl != 0xFFu && !ABL(8)) ? ld4(&d.qpay[(size_t)sl * d.Nl + l]) : zero;
+      }
     }
   }
   TT(10);
-  if (up && !ABL(16)) {
-    node_store(d, l, n);
-    keys_store(d, l, cnt0, n.used, sk);
-  }
-  TT(11);
 #ifdef TICK_TIMING
   if ((threadIdx.x & 63) == 0)
     for (int i = 0; i < 12; ++i) atomicAdd(&g_tt[i], tacc[i]);
@@ -1759,6 +1818,10 @@ static int cfg_check(const sim_config* c) {
   if (c->shard_rank >= c->shard_count) return SIM_EINVAL;
   if (c->fanout < 1 || c->fanout > SIM_MAX_FANOUT) return SIM_EINVAL;
   if (c->event_ring < 1 || c->query_ring < 1) return SIM_EINVAL;
+  {  // a staged record names its ring bucket / view slot with 18 bits (NOROW = all ones)
+    u32 A = (c->view_slots == 0 || c->view_slots >= c->n_nodes) ? c->n_nodes : c->view_slots;
+    if (A >= NOROW || c->event_ring >= NOROW || c->query_ring >= NOROW) return SIM_EINVAL;
+  }
   if (c->retransmit_mult * h_digits10(c->n_nodes) > 63u) return SIM_EINVAL;
   if (c->probe_interval) {  // suspicion timers name view slots with 16 bits
     u32 A = (c->view_slots == 0 || c->view_slots >= c->n_nodes) ? c->n_nodes : c->view_slots;

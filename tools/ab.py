@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""A/B of builds of the product library on the benchmark workload (run on the GPU box).
+
+usage: python tools/ab.py [--ticks 120] [--rounds 3] [--nodes N] lib1.so lib2.so ...
+
+Every library runs bench.py's configuration and schedule: untimed pre-roll into the stationary load, then `ticks`
+ticks with HIP events around every tick-kernel launch; the libraries alternate `rounds` times (box-to-box and
+minute-to-minute drift is larger than most effects).  All builds implement the same SIMSPEC, so their state digests
+after the run must agree — checked, a variant that computes something else is flagged.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402,F401  (one HIP runtime per process: torch's first)
+
+import bench  # noqa: E402
+from serf_amd import _ffi  # noqa: E402
+
+
+def run_one(path, args, ticks):
+    lib = _ffi.SimLib(path)
+    n = args.nodes_per_gpu
+    kw, ops = bench.workload(args, n)
+    sim = _ffi.Sim(lib, _ffi.make_config(n, **kw))
+    for o in ops:
+        sim.inject(*o)
+    sim.step(args.preroll)
+    sim.sync()
+    sim.profile(1)
+    sim.step(ticks)
+    (tot, mn, mx), cnt = sim.profile_read_stats()
+    sim.profile(0)
+    dig = sim.digest()
+    drops = sim.cluster_stats()["overflow"]
+    sim.close()
+    return tot / cnt * 1e3, mn * 1e3, mx * 1e3, dig, drops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ticks", type=int, default=120)
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--nodes", type=int, default=1 << 20)
+    ap.add_argument("libs", nargs="+")
+    a = ap.parse_args()
+    args = bench.parse_args(["--nodes-per-gpu", str(a.nodes)])
+    res = {p: [] for p in a.libs}
+    digs = {}
+    for r in range(a.rounds):
+        for p in a.libs:
+            mean, mn, mx, dig, drops = run_one(os.path.join(ROOT, p) if not os.path.isabs(p) else p, args, a.ticks)
+            res[p].append(mean)
+            digs[p] = dig
+            print(f"round {r} {p}: {mean:.1f} us/tick (min {mn:.1f} max {mx:.1f}) drops {drops}", flush=True)
+    ref = digs[a.libs[0]]
+    out = {"ticks": a.ticks, "nodes": a.nodes, "results": {}}
+    for p in a.libs:
+        v = sorted(res[p])
+        out["results"][p] = {"us_per_tick_median": v[len(v) // 2], "us_per_tick_all": res[p], "same_digest_as_first": digs[p] == ref}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -5,9 +5,9 @@ after that launch is garbage, so every measurement starts from a fresh run of th
 """
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401  (one HIP runtime per process: torch's first)
 import serf_amd
 from serf_amd import _ffi
-from tests import _scenario as sc
 import bench
 
 lib = _ffi.SimLib(os.path.join(os.path.dirname(serf_amd.LIB_PATH), "libserf_sim_ablate.so"))
@@ -15,14 +15,14 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 MASKS = [(0, "full tick"), (1, "phase 1 only (no queue phase)"), (2, "phase 2 only (no deliver/timers)"),
          (4, "no scatter stores"), (8, "no payload gathers"), (16, "no row/key stores"), (4 | 8 | 16, "no scatter/gather/row stores"),
          (32, "no handler loop"), (64, "records loaded, no lookups, no handlers"), (1 | 64, "row + record loads only"), (1 | 2, "row load/store only")]
-ticks = (120, 121, 122, 123, 124, 150, 151)  # probe phases differ per tick: average over a few
-ops = list(sc.schedule(n, 200, rate=0.4, seed=3, mix=bench.MIX, max_member_subjects=512, even=True))
+ticks = (330, 333, 351)  # inside the benchmark's timed region (stationary load); probe phases differ per tick
+args = bench.parse_args(["--nodes-per-gpu", str(n)])
+kw, ops = bench.workload(args, n)
 res = {}
 for mask, name in MASKS:
     tot = 0.0
     for t in ticks:
-        sim = _ffi.Sim(lib, _ffi.make_config(n, fanout=4, view_slots=1024, event_ring=512, query_ring=512, probe_interval=5,
-                                             push_pull_interval=150, reap_interval=75, queue_check_interval=150))
+        sim = _ffi.Sim(lib, _ffi.make_config(n, **kw))
         for o in ops:
             sim.inject(*o)
         sim.step(t); sim.sync()
