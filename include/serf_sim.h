@@ -215,12 +215,18 @@ typedef struct sim_config {
   uint32_t min_queue_depth;   /* options.rs:514: > 0 => cap = max(2 * members, min)             */
   uint32_t push_pull_interval;/* memberlist push_pull_interval in ticks (lan: 30 s = 150), before its
                                * log2(N) scaling; 0 = no anti-entropy                             */
-  uint32_t reserved0;         /* keeps `seed` 8-byte aligned                                    */
+  uint32_t chunks;            /* C sender chunks per shard for the chunk-wise exchange (0 or 1: one); must divide
+                               * (N / V) / V.  Chunk c = the nodes whose offset inside their N/V/V-node block lies in
+                               * [c, c+1) * (N/V/V/C): their packets for one (destination, slot) form ONE dense slab     */
   uint32_t flags;             /* SIM_CF_*                                                       */
   uint64_t seed;              /* master seed; default 0x5EEDC0DE5E4F0001                        */
 } sim_config;
 
 #define SIM_CF_BASELINE_JOINED 1u /* all nodes known+Alive at status_time 1, clock 2 (config 2-5) */
+#define SIM_CF_RANDOM_FANOUT 2u   /* CPU oracle only (the product returns SIM_EINVAL): gossip targets are memberlist's literal
+                                   * kRandomNodes (uniform, no replacement, skip self — App. B.2) instead of the per-tick
+                                   * bijection; in-degree is then Poisson-like.  Exists to put an error bar on the bijection's
+                                   * effect on rounds-to-99 % (tools/convergence_hist.py --random-fanout) */
 #define SIM_DEFAULT_SEED 0x5EEDC0DE5E4F0001ull
 
 /* Stats — mirrors serf-core/src/serf/api.rs:586-602 (`Stats`) for one simulated node. */

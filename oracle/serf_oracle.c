@@ -75,7 +75,7 @@ static inline uint64_t mix64(uint64_t z) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-enum { STREAM_PERM = 1, STREAM_OFF = 2, STREAM_ROT = 3, STREAM_LOSS = 4, STREAM_PROBE = 5, STREAM_QUERY = 6 };
+enum { STREAM_PERM = 1, STREAM_OFF = 2, STREAM_ROT = 3, STREAM_LOSS = 4, STREAM_PROBE = 5, STREAM_QUERY = 6, STREAM_RFAN = 7, STREAM_RHO = 8 };
 /* sub-draws of the per-(tick, prober) probe stream */
 enum { PD_TARGET = 0, PD_PING = 1, PD_ACK = 2, PD_RELAY0 = 3 /* + 5*j: relay, 4 legs */ };
 static inline uint64_t rng_base(uint64_t seed, uint64_t stream, uint64_t a) {
@@ -88,8 +88,12 @@ static inline uint64_t rng4(uint64_t seed, uint64_t stream, uint64_t a, uint64_t
 typedef struct tickp {
   uint64_t tick;
   uint32_t M, nbits, mask, shift, feff, V, blk;
+  /* fan-out map (SIMSPEC §2.3): C sender chunks, sub = blk / C cells per (chunk, destination, slot) slab, blocks of
+   * B nodes (64, or 1 for small / ragged shards), nbc = V * sub / B blocks per chunk; bmask/bshift: the block
+   * permutation's bit width */
+  uint32_t C, sub, B, nbc, bmask, bshift;
   uint32_t mul[3], add[3], imul[3];
-  uint32_t off[SIM_MAX_FANOUT], rot[SIM_MAX_FANOUT];
+  uint32_t off[SIM_MAX_FANOUT], rot[SIM_MAX_FANOUT], rho[SIM_MAX_FANOUT];
   uint64_t loss_base, probe_base;
   uint32_t loss_u32;
 } tickp;
@@ -115,8 +119,18 @@ static void tickp_make(tickp* p, const sim_config* c, uint64_t tick) {
   if (p->nbits < 1) p->nbits = 1;
   p->mask = p->nbits >= 32 ? 0xFFFFFFFFu : ((1u << p->nbits) - 1u);
   p->shift = (p->nbits + 1) / 2;
+  p->C = c->chunks ? c->chunks : 1;
+  p->sub = p->blk / p->C;
+  p->B = (p->sub % 64u == 0 && (uint64_t)p->V * p->sub / 64u >= 8u) ? 64u : 1u;
+  p->nbc = (uint32_t)((uint64_t)p->V * p->sub / p->B);
+  {
+    uint32_t bb = ceil_log2_u32(p->nbc);
+    if (bb < 1) bb = 1;
+    p->bmask = bb >= 32 ? 0xFFFFFFFFu : ((1u << bb) - 1u);
+    p->bshift = (bb + 1) / 2;
+  }
   p->feff = c->fanout;
-  if (p->M - 1 < p->feff) p->feff = p->M - 1;
+  if (p->nbc - 1 < p->feff) p->feff = p->nbc - 1;
   for (int r = 0; r < 3; ++r) {
     uint64_t w = rng4(c->seed, STREAM_PERM, tick, (uint64_t)r);
     p->mul[r] = (uint32_t)w | 1u;
@@ -125,15 +139,16 @@ static void tickp_make(tickp* p, const sim_config* c, uint64_t tick) {
   }
   for (uint32_t k = 0; k < p->feff; ++k) {
     uint64_t u = rng4(c->seed, STREAM_OFF, tick, k);
-    uint32_t ck = 1u + (uint32_t)(u % (uint64_t)(p->M - 1));
+    uint32_t ck = 1u + (uint32_t)(u % (uint64_t)(p->nbc - 1));
     for (;;) {
       int clash = 0;
       for (uint32_t j = 0; j < k; ++j) clash |= (p->off[j] == ck);
       if (!clash) break;
-      ck = ck % (p->M - 1) + 1u;
+      ck = ck % (p->nbc - 1) + 1u;
     }
     p->off[k] = ck;
     p->rot[k] = (uint32_t)(rng4(c->seed, STREAM_ROT, tick, k) % (uint64_t)p->V);
+    p->rho[k] = (uint32_t)(rng4(c->seed, STREAM_RHO, tick, k) % (uint64_t)p->C);
   }
   p->loss_base = rng_base(c->seed, STREAM_LOSS, tick);
   p->probe_base = rng_base(c->seed, STREAM_PROBE, tick);
@@ -164,15 +179,50 @@ static inline uint32_t sigma_inv(const tickp* p, uint32_t y) {
   do y = perm_fi(p, y); while (y >= p->M);
   return y;
 }
-/* k-th gossip target of the node whose sigma-image is sx, living in shard g. */
-static inline void fan_target(const tickp* p, uint32_t g, uint32_t sx, uint32_t k, uint32_t* h,
-                              uint32_t* lp) {
-  uint32_t y = sx + p->off[k];
-  if (y >= p->M) y -= p->M;
-  uint32_t t = sigma_inv(p, y);
-  uint32_t b = t / p->blk;
-  *lp = t;
-  *h = (g + p->V - ((b + p->rot[k]) % p->V)) % p->V;
+/* the block permutation pi: the same three rounds on the bit width of nbc, cycle-walking into [0, nbc) */
+static inline uint32_t permb_f(const tickp* p, uint32_t x) {
+  x = (x * p->mul[0] + p->add[0]) & p->bmask;
+  x ^= x >> p->bshift;
+  x = (x * p->mul[1] + p->add[1]) & p->bmask;
+  x ^= x >> p->bshift;
+  x = (x * p->mul[2] + p->add[2]) & p->bmask;
+  return x;
+}
+static inline uint32_t permb_fi(const tickp* p, uint32_t y) {
+  y = ((y - p->add[2]) * p->imul[2]) & p->bmask;
+  y ^= y >> p->bshift;
+  y = ((y - p->add[1]) * p->imul[1]) & p->bmask;
+  y ^= y >> p->bshift;
+  y = ((y - p->add[0]) * p->imul[0]) & p->bmask;
+  return y;
+}
+static inline uint32_t pi_f(const tickp* p, uint32_t x) { do x = permb_f(p, x); while (x >= p->nbc); return x; }
+static inline uint32_t pi_inv(const tickp* p, uint32_t y) { do y = permb_fi(p, y); while (y >= p->nbc); return y; }
+/* k-th gossip target of in-shard node ll of shard g (SIMSPEC §2.3): ll = (bb0, s0, r0) by vblock / sub-slab /
+ * offset; the sender's chunk is s0 and its index within the chunk u = bb0 * sub + r0 = (block j, position i).
+ * Block j goes to block pi^-1(pi(j) + off_k) (never itself, a different one per k), positions are XOR-scrambled
+ * inside the block, the sub-slab rotates by rho_k, and the vblock the packet lands in picks the destination shard.
+ * Consequences: a wave of 64 consecutive senders fills 64 consecutive cells (one 4 KiB run), the packets chunk s0
+ * sends to (destination, slot) are one dense slab of `sub` cells, and with B = 1, C = 1 (small or ragged shards) this
+ * is the plain node permutation sigma^-1(sigma(ll) + off_k). */
+static inline void fan_target(const tickp* p, uint32_t g, uint32_t ll, uint32_t k, uint32_t* h, uint32_t* t) {
+  uint32_t bb0 = ll / p->blk, w = ll % p->blk, s0 = w / p->sub, r0 = w % p->sub;
+  uint32_t u = bb0 * p->sub + r0, j = u / p->B, i = u % p->B;
+  uint32_t y = pi_f(p, j) + p->off[k];
+  if (y >= p->nbc) y -= p->nbc;
+  uint32_t j2 = pi_inv(p, y);
+  uint32_t i2 = p->B == 64u ? (i ^ (((y + 1u) * 0x9E3779B1u + k * 0x85EBCA6Bu) >> 26)) : 0u;
+  uint32_t u2 = j2 * p->B + i2, bb = u2 / p->sub, r = u2 % p->sub;
+  uint32_t s = s0 + p->rho[k];
+  if (s >= p->C) s -= p->C;
+  *h = (g + p->V - ((bb + p->rot[k]) % p->V)) % p->V;
+  *t = bb * p->blk + s * p->sub + r;
+}
+/* where, in the sharded exchange buffers ([chunk][peer][slot][sub] cells), the packet for (in-shard target t, slot k)
+ * sits: on the sender's side `peer` is the destination shard and the chunk is the sender's; on the receiver's side
+ * `peer` is the source shard and the chunk is found by undoing the sub-slab rotation */
+static inline size_t xcell(const tickp* p, uint32_t f, uint32_t chunk, uint32_t peer, uint32_t k, uint32_t t) {
+  return (((size_t)chunk * p->V + peer) * f + k) * p->sub + (t % p->sub);
 }
 static inline int pkt_lost(const tickp* p, uint32_t gid, uint32_t k) {
   if (!p->loss_u32) return 0;
@@ -228,6 +278,13 @@ struct sim_handle {
   uint32_t* qbits;      /* [SIM_QT][2][ceil(N/32)]: ack bitmap, response bitmap, by global node id */
   uint32_t qt_cursor, q_timeout;
   uint32_t pp_step, pp_groups; /* push-pull batches: every pp_step ticks one of pp_groups pair classes syncs */
+  /* SIM_CF_RANDOM_FANOUT (oracle only): memberlist's literal kRandomNodes instead of the per-tick bijection.
+   * Packets stay in the SENDER's cell ([k][sender]); rtgt holds each packet's target, (rcsr, rsrc) list every
+   * node's incoming cells in canonical (sender, k) order. */
+  uint32_t rfan;
+  uint32_t* rtgt;  /* [f][Nl] target of the packet in the same cell of the inbox being filled */
+  uint32_t* rcsr;  /* [Nl + 1] */
+  uint32_t* rsrc;  /* [f * Nl] cell indices (k * Nl + sender), grouped by target */
 };
 typedef struct sim_handle osim;
 
@@ -1064,9 +1121,10 @@ static void pp_round(osim* s, const tickp* p) {
 static inline const sim_packet* inbox_cell(const osim* s, uint32_t k, uint32_t l) {
   if (s->cfg.shard_count > 1) { /* sharded: [src shard][k][blk] written by the previous tick */
     const tickp* pp = &s->prev;
-    uint32_t b = l / pp->blk;
+    uint32_t b = l / pp->blk, sl = (l % pp->blk) / pp->sub;
     uint32_t g = (s->cfg.shard_rank + b + pp->rot[k]) % pp->V;
-    return &s->xrecv[((size_t)g * s->f + k) * pp->blk + (l % pp->blk)];
+    uint32_t ch = (sl + pp->C - pp->rho[k]) % pp->C; /* the sender's chunk */
+    return &s->xrecv[xcell(pp, s->f, ch, g, k, l)];
   }
   return &s->inbox[s->tick & 1][(size_t)k * s->Nl + l];
 }
@@ -1082,7 +1140,13 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
   int up = (row->flags & SIM_RF_UP) != 0;
   if (up) {
     if (row->next_seq > 1023u - 64u) queue_renorm(row, q);
-    if (s->tick > 0) {
+    if (s->tick > 0 && s->rfan) { /* variable in-degree: every packet addressed to this node, (sender, k) order */
+      for (uint32_t i = s->rcsr[l]; i < s->rcsr[l + 1]; ++i) {
+        const sim_packet* pk = &s->inbox[s->tick & 1][s->rsrc[i]];
+        for (uint32_t r = 0; r < SIM_P; ++r)
+          if (SIM_META_KIND(pk->rec[r].meta) != SIM_K_EMPTY) dispatch_record(&c, &pk->rec[r]);
+      }
+    } else if (s->tick > 0) {
       for (uint32_t k = 0; k < s->f; ++k) {
         const sim_packet* pk = inbox_cell(s, k, l);
         for (uint32_t r = 0; r < SIM_P; ++r)
@@ -1098,14 +1162,30 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
     uint32_t limit = s->cfg.retransmit_mult * digits10(row->n_known); /* B.1, serf.rs:123-131 */
     for (uint32_t k = 0; k < p->feff; ++k) queue_emit(row, q, limit, &out[k]);
   }
+  if (s->rfan) { /* kRandomNodes (App. B.2): uniform draws, skip self and duplicates, up to 3n tries */
+    uint64_t rb = rng_base(s->cfg.seed, STREAM_RFAN, s->tick);
+    uint32_t chosen[SIM_MAX_FANOUT], nc = 0;
+    for (uint32_t i = 0; i < 3u * s->N && nc < p->feff; ++i) {
+      uint32_t t = (uint32_t)(((mix64(rb ^ ((uint64_t)c.gid * 4096u + i)) >> 32) * (uint64_t)s->N) >> 32);
+      int dup = (t == c.gid);
+      for (uint32_t j = 0; j < nc; ++j) dup |= (chosen[j] == t);
+      if (!dup) chosen[nc++] = t;
+    }
+    for (uint32_t k = 0; k < p->feff; ++k) {
+      size_t cell = (size_t)k * s->Nl + l;
+      if (k >= nc || (up && pkt_lost(p, c.gid, k))) memset(&out[k], 0, sizeof out[k]);
+      s->inbox[(s->tick + 1) & 1][cell] = out[k];
+      s->rtgt[cell] = k < nc ? chosen[k] : NOSLOT;
+    }
+    return;
+  }
   /* push the f packets (empty ones too: every inbox cell is rewritten every tick) */
-  uint32_t sx = p->feff ? sigma(p, ll) : 0;
   for (uint32_t k = 0; k < p->feff; ++k) {
     uint32_t h, lp;
-    fan_target(p, g, sx, k, &h, &lp);
+    fan_target(p, g, ll, k, &h, &lp);
     if (up && pkt_lost(p, c.gid, k)) memset(&out[k], 0, sizeof out[k]);
     if (s->cfg.shard_count > 1)
-      s->xsend[((size_t)h * s->f + k) * p->blk + (lp % p->blk)] = out[k];
+      s->xsend[xcell(p, s->f, (ll % p->blk) / p->sub, h, k, lp)] = out[k];
     else
       s->inbox[(s->tick + 1) & 1][(size_t)k * s->Nl + (size_t)h * p->M + lp] = out[k];
   }
@@ -1125,6 +1205,21 @@ static void step_one(osim* s) {
     int nt = oracle_threads();
 #pragma omp parallel for schedule(static) num_threads(nt) if (s->Nl >= 4096)
     for (uint32_t l = 0; l < s->Nl; ++l) tick_node(s, &p, l);
+  }
+  if (s->rfan) { /* group the cells by target: counting sort, senders ascending within a target */
+    memset(s->rcsr, 0, ((size_t)s->Nl + 1) * sizeof(uint32_t));
+    size_t cells = (size_t)s->f * s->Nl;
+    for (size_t i = 0; i < cells; ++i)
+      if (s->rtgt[i] != NOSLOT) s->rcsr[s->rtgt[i] + 1]++;
+    for (uint32_t l = 0; l < s->Nl; ++l) s->rcsr[l + 1] += s->rcsr[l];
+    uint32_t* fill = (uint32_t*)malloc((size_t)s->Nl * sizeof(uint32_t));
+    memcpy(fill, s->rcsr, (size_t)s->Nl * sizeof(uint32_t));
+    for (uint32_t l = 0; l < s->Nl; ++l)          /* (sender, k) order */
+      for (uint32_t k = 0; k < s->f; ++k) {
+        size_t cell = (size_t)k * s->Nl + l;
+        if (s->rtgt[cell] != NOSLOT) s->rsrc[fill[s->rtgt[cell]]++] = (uint32_t)cell;
+      }
+    free(fill);
   }
   s->prev = p;
   s->tick++;
@@ -1172,6 +1267,7 @@ static int cfg_check(const sim_config* c) {
   if (c->shard_count != 1 && c->shard_count != c->vshards) return SIM_EINVAL;
   if (c->shard_rank >= c->shard_count) return SIM_EINVAL;
   if (c->fanout < 1 || c->fanout > SIM_MAX_FANOUT) return SIM_EINVAL;
+  if (c->chunks > 1 && ((M / c->vshards) % c->chunks || (M / c->vshards) / c->chunks < 1)) return SIM_EINVAL;
   if (c->event_ring < 1 || c->query_ring < 1) return SIM_EINVAL;
   if (c->retransmit_mult * digits10(c->n_nodes) > 63u) return SIM_EINVAL;
   if (c->probe_interval) { /* suspicion timers name view slots with 16 bits */
@@ -1185,7 +1281,7 @@ int API(destroy)(osim* s) {
   if (!s) return SIM_EINVAL;
   free(s->rows); free(s->queue); free(s->inbox[0]); free(s->inbox[1]);
   if (s->own_x) { free(s->xsend); free(s->xrecv); }
-  free(s->view); free(s->ering); free(s->qring); free(s->slot_of); free(s->subject_of); free(s->walk);
+  free(s->view); free(s->ering); free(s->qring); free(s->slot_of); free(s->subject_of); free(s->walk); free(s->rtgt); free(s->rcsr); free(s->rsrc);
   free(s->base); free(s->ops); free(s->events); free(s->upmap); free(s->qbits); free(s);
   return SIM_OK;
 }
@@ -1233,6 +1329,14 @@ int API(create)(const sim_config* cfg, osim** out) {
                                                           : (!s->inbox[0] || !s->inbox[1]))) {
     API(destroy)(s);
     return SIM_ENOMEM;
+  }
+  s->rfan = (cfg->flags & SIM_CF_RANDOM_FANOUT) != 0;
+  if (s->rfan) {
+    if (cfg->shard_count > 1 || cfg->vshards > 1) { API(destroy)(s); return SIM_EINVAL; }
+    s->rtgt = (uint32_t*)malloc((size_t)s->f * Nl * sizeof(uint32_t));
+    s->rcsr = (uint32_t*)calloc((size_t)Nl + 1, sizeof(uint32_t));
+    s->rsrc = (uint32_t*)malloc((size_t)s->f * Nl * sizeof(uint32_t));
+    if (!s->rtgt || !s->rcsr || !s->rsrc) { API(destroy)(s); return SIM_ENOMEM; }
   }
   int joined = (cfg->flags & SIM_CF_BASELINE_JOINED) != 0;
   for (size_t i = 0; i < Nl * SIM_Q; ++i) rec_clear(&s->queue[i]);
@@ -1557,8 +1661,7 @@ int API(restore)(osim* s, const void* buf, size_t bytes) {
     if (n) memcpy((void*)cptr[i], in, n);
     in += n;
   }
-  for (uint32_t k = 0; k < SIM_MAX_FANOUT; ++k) s->prev.rot[k] = h.prev_rot[k];
-  s->prev.V = s->V; s->prev.blk = (s->N / s->V) / s->V; s->prev.M = s->N / s->V;
+  if (s->tick > 0) tickp_make(&s->prev, &s->cfg, s->tick - 1); /* the parameters the packets in flight were sent with */
   s->n_watched = 0;
   for (uint32_t l = 0; l < s->Nl; ++l) s->n_watched += (s->rows[l].flags & SIM_RF_WATCHED) != 0;
   walk_rebuild(s);
@@ -1847,10 +1950,9 @@ int osim_t_targets(osim* s, uint64_t tick, uint32_t gid, uint32_t* out_targets) 
   tickp p;
   tickp_make(&p, &s->cfg, tick);
   uint32_t g = gid / p.M, l = gid % p.M;
-  uint32_t sx = p.feff ? sigma(&p, l) : 0;
   for (uint32_t k = 0; k < p.feff; ++k) {
     uint32_t h, lp;
-    fan_target(&p, g, sx, k, &h, &lp);
+    fan_target(&p, g, l, k, &h, &lp);
     out_targets[k] = h * p.M + lp;
   }
   return (int)p.feff;

@@ -11,7 +11,8 @@ from . import _ffi
 from ._ffi import (Config, Sim, SimError, SimLib, Stats, make_config)  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libserf_sim.so")
+# SERF_SIM_LIB: another build of the same HIP source (tools/ab.py variants, -DTICK_TIMING ...), for measurements
+LIB_PATH = os.environ.get("SERF_SIM_LIB") or os.path.join(_HERE, "csrc", "libserf_sim.so")
 _lib = None
 
 

@@ -55,7 +55,7 @@ __host__ __device__ static inline u64 mix64(u64 z) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-enum { STREAM_PERM = 1, STREAM_OFF = 2, STREAM_ROT = 3, STREAM_LOSS = 4, STREAM_PROBE = 5, STREAM_QUERY = 6 };
+enum { STREAM_PERM = 1, STREAM_OFF = 2, STREAM_ROT = 3, STREAM_LOSS = 4, STREAM_PROBE = 5, STREAM_QUERY = 6, STREAM_RHO = 8 };
 enum { PD_TARGET = 0, PD_PING = 1, PD_ACK = 2, PD_RELAY0 = 3 };
 static inline u64 rng_base(u64 seed, u64 stream, u64 a) {
   return mix64(mix64(seed ^ (stream * 0xD6E8FEB86659FD93ull)) ^ a);
@@ -69,9 +69,13 @@ struct TickP {  // per-tick parameters, passed by value (lands in SGPRs)
   u32 n_slots;  // length of d.walk: view slots in use (the Reaper and the push-pull merge walk them)
   u32 zero_;    // always 0 (opaque to the compiler)
   u32 abl;      // -DTICK_ABLATE measurement builds only: parts of the tick to leave out
+  // fan-out map (SIMSPEC §2.3): C sender chunks, sub = blk / C cells per (chunk, destination, slot) slab, blocks of B
+  // nodes (64, or 1 for small / ragged shards), nbc = V * sub / B blocks per chunk, bmask/bshift: bit width of the
+  // block permutation
+  u32 C, sub, B, nbc, bmask, bshift;
   u32 mul[3], add[3], imul[3];
-  u32 off[SIM_MAX_FANOUT], rot[SIM_MAX_FANOUT];
-  u32 prot[SIM_MAX_FANOUT];  // rot[] of the previous tick (sharded reads)
+  u32 off[SIM_MAX_FANOUT], rot[SIM_MAX_FANOUT], rho[SIM_MAX_FANOUT];
+  u32 prot[SIM_MAX_FANOUT], prho[SIM_MAX_FANOUT];  // rot[] / rho[] of the previous tick (sharded reads)
 };
 
 static u32 modinv32(u32 a) {
@@ -90,7 +94,18 @@ static void tickp_make(TickP* p, const sim_config* c, u64 tick) {
   if (nbits < 1) nbits = 1;
   p->mask = nbits >= 32 ? 0xFFFFFFFFu : ((1u << nbits) - 1u);
   p->shift = (nbits + 1) / 2;
-  p->feff = std::min(c->fanout, p->M - 1);
+  p->C = c->chunks ? c->chunks : 1;
+  p->sub = p->blk / p->C;
+  p->B = (p->sub % 64u == 0 && (u64)p->V * p->sub / 64u >= 8u) ? 64u : 1u;
+  p->nbc = (u32)((u64)p->V * p->sub / p->B);
+  {
+    u32 bb = 0;
+    while (bb < 32 && (1ull << bb) < p->nbc) ++bb;
+    if (bb < 1) bb = 1;
+    p->bmask = bb >= 32 ? 0xFFFFFFFFu : ((1u << bb) - 1u);
+    p->bshift = (bb + 1) / 2;
+  }
+  p->feff = std::min(c->fanout, p->nbc - 1);
   for (int r = 0; r < 3; ++r) {
     u64 w = rng4(c->seed, STREAM_PERM, tick, (u64)r);
     p->mul[r] = (u32)w | 1u;
@@ -99,15 +114,16 @@ static void tickp_make(TickP* p, const sim_config* c, u64 tick) {
   }
   for (u32 k = 0; k < p->feff; ++k) {
     u64 u = rng4(c->seed, STREAM_OFF, tick, k);
-    u32 ck = 1u + (u32)(u % (u64)(p->M - 1));
+    u32 ck = 1u + (u32)(u % (u64)(p->nbc - 1));
     for (;;) {
       bool clash = false;
       for (u32 j = 0; j < k; ++j) clash |= (p->off[j] == ck);
       if (!clash) break;
-      ck = ck % (p->M - 1) + 1u;
+      ck = ck % (p->nbc - 1) + 1u;
     }
     p->off[k] = ck;
     p->rot[k] = (u32)(rng4(c->seed, STREAM_ROT, tick, k) % (u64)p->V);
+    p->rho[k] = (u32)(rng4(c->seed, STREAM_RHO, tick, k) % (u64)p->C);
   }
   p->loss_base = rng_base(c->seed, STREAM_LOSS, tick);
   p->probe_base = rng_base(c->seed, STREAM_PROBE, tick);
@@ -130,6 +146,27 @@ __device__ static inline u32 perm_fi(const TickP& p, u32 y) {
   y = ((y - p.add[1]) * p.imul[1]) & p.mask;
   y ^= y >> p.shift;
   y = ((y - p.add[0]) * p.imul[0]) & p.mask;
+  return y;
+}
+// the block permutation pi of the fan-out map: the same rounds on the bit width of nbc, cycle-walking into [0, nbc)
+__device__ static inline u32 pi_f(const TickP& p, u32 x) {
+  do {
+    x = (x * p.mul[0] + p.add[0]) & p.bmask;
+    x ^= x >> p.bshift;
+    x = (x * p.mul[1] + p.add[1]) & p.bmask;
+    x ^= x >> p.bshift;
+    x = (x * p.mul[2] + p.add[2]) & p.bmask;
+  } while (x >= p.nbc);
+  return x;
+}
+__device__ static inline u32 pi_inv(const TickP& p, u32 y) {
+  do {
+    y = ((y - p.add[2]) * p.imul[2]) & p.bmask;
+    y ^= y >> p.bshift;
+    y = ((y - p.add[1]) * p.imul[1]) & p.bmask;
+    y ^= y >> p.bshift;
+    y = ((y - p.add[0]) * p.imul[0]) & p.bmask;
+  } while (y >= p.nbc);
   return y;
 }
 __device__ static inline u32 sigma(const TickP& p, u32 x) {
@@ -474,7 +511,7 @@ __device__ static inline void erase_member(const Ctx& c, Node& n, uint4* p, cons
   emit_event(c, n, SIM_EV_REAP, subject, 0);
 }
 // handle_node_join_intent: base.rs:1338-1373.  (p, e) = the subject's view entry, e preloaded.
-__device__ static bool handle_join_intent(const Ctx& c, Node& n, u32 subject, u64 ltime, uint4* p, uint4 e, bool& dirty) {
+__device__ static bool handle_join_intent(const Ctx& c, Node& n, u32 subject, u64 ltime, uint4* p, uint4& e, bool& dirty) {
   witness(n, n.clock, ltime, DR0);
   if (!p) return false;
   if (e.w & SIM_VB_KNOWN) {
@@ -497,12 +534,13 @@ __device__ static bool handle_join_intent(const Ctx& c, Node& n, u32 subject, u6
 __device__ static void broadcast_join(const Ctx& c, Node& n, u64 ltime, bool& dirty, Ins& ins) {
   witness(n, n.clock, ltime, DR0);
   uint4* p = view_ptr(c, c.gid);
-  handle_join_intent(c, n, c.gid, ltime, p, p ? p[0] : make_uint4(0, 0, 0, 0), dirty);
+  uint4 own = p ? p[0] : make_uint4(0, 0, 0, 0);
+  handle_join_intent(c, n, c.gid, ltime, p, own, dirty);
   ins.wide = 1;
   ins_set(ins, c.gid, wire_meta(SIM_K_JOIN, 0, 16), ltime);
 }
 // handle_node_leave_intent: base.rs:1442-1572
-__device__ static bool handle_leave_intent(const Ctx& c, Node& n, u32 subject, u64 ltime, bool prune, uint4* p, uint4 e, bool& dirty, Ins& ins) {
+__device__ static bool handle_leave_intent(const Ctx& c, Node& n, u32 subject, u64 ltime, bool prune, uint4* p, uint4& e, bool& dirty, Ins& ins) {
   u32 state = SIM_RF_STATE(n.flags);
   witness(n, n.clock, ltime, DR0);
   if (!p) return false;
@@ -539,7 +577,7 @@ __device__ static bool handle_leave_intent(const Ctx& c, Node& n, u32 subject, u
     e.w = vb_set_status(e.w, SIM_STATUS_LEAVING);
   }
   dirty = true;
-  if (prune && rb) erase_member(c, n, p, e, subject);  // handle_prune: base.rs:1628-1653
+  if (prune && rb) { erase_member(c, n, p, e, subject); e = make_uint4(0, 0, 0, 0); }  // handle_prune: base.rs:1628-1653
   else p[0] = e;
   return rb;
 }
@@ -598,7 +636,7 @@ __device__ static inline bool bucket_add(uint4* p, uint4& b0, u32 key, bool same
   return true;
 }
 // handle_user_event: base.rs:750-837 (quirk U1 kept).  (p, b0) = ring bucket of ltime, preloaded.
-__device__ static bool handle_user_event(const Ctx& c, Node& n, u32 key, u64 ltime, uint4* p, uint4 b0, bool& dirty) {
+__device__ static bool handle_user_event(const Ctx& c, Node& n, u32 key, u64 ltime, uint4* p, uint4& b0, bool& dirty) {
   witness(n, n.eclock, ltime, DR0);
   if (n.flags & SIM_RF_MINTIME) {
     uint4 mn = c.d.R5[c.l];
@@ -610,7 +648,8 @@ __device__ static bool handle_user_event(const Ctx& c, Node& n, u32 key, u64 lti
     bool seen;
     if (!bucket_add(p, b0, key, false, false, n, seen)) return false;
   } else {
-    p[0] = make_uint4((u32)ltime, (u32)(ltime >> 32), key, 0);
+    b0 = make_uint4((u32)ltime, (u32)(ltime >> 32), key, 0);
+    p[0] = b0;
   }
   dirty = true;
   emit_event(c, n, SIM_EV_USER, key, ltime);
@@ -646,7 +685,7 @@ __device__ static void query_respond(const Ctx& c, u32 id, u32 flags) {
   }
 }
 // handle_query, de-dup part: base.rs:972-1073 (quirks Q1, Q2 kept)
-__device__ static bool handle_query(const Ctx& c, Node& n, u32 id, u64 ltime, u32 flags, uint4* p, uint4 b0, bool& dirty) {
+__device__ static bool handle_query(const Ctx& c, Node& n, u32 id, u64 ltime, u32 flags, uint4* p, uint4& b0, bool& dirty) {
   witness(n, n.qclock, ltime, DR1);
   if (n.flags & SIM_RF_MINTIME) {
     uint4 mn = c.d.R5[c.l];
@@ -658,7 +697,8 @@ __device__ static bool handle_query(const Ctx& c, Node& n, u32 id, u64 ltime, u3
     bool seen;
     if (!bucket_add(p, b0, id, E_LTIME(b0) == ltime, true, n, seen)) return false;
   } else {
-    p[0] = make_uint4((u32)ltime, (u32)(ltime >> 32), id, 0);
+    b0 = make_uint4((u32)ltime, (u32)(ltime >> 32), id, 0);
+    p[0] = b0;
   }
   dirty = true;
   query_respond(c, id, flags);
@@ -699,7 +739,7 @@ __device__ static void swim_refute(const Ctx& c, Node& n, u32 accused_inc, Ins& 
   ins.wide = 1;
   ins_set(ins, c.gid, wire_meta(SIM_K_ALIVE, 0, 64), inc);
 }
-__device__ static void swim_alive(const Ctx& c, Node& n, u32 subject, u32 inc, u32 wmeta, uint4* p, uint4 e, bool& dirty, Ins& ins) {
+__device__ static void swim_alive(const Ctx& c, Node& n, u32 subject, u32 inc, u32 wmeta, uint4* p, uint4& e, bool& dirty, Ins& ins) {
   if (!p) return;
   if (subject == c.gid) {
     if (inc <= n.inc) return;
@@ -726,7 +766,7 @@ __device__ static void swim_alive(const Ctx& c, Node& n, u32 subject, u32 inc, u
   p[0] = e;
   dirty = true;
 }
-__device__ static void swim_suspect(const Ctx& c, Node& n, u32 subject, u32 inc, u32 from, u32 wmeta, uint4* p, uint4 e, bool& dirty, Ins& ins) {
+__device__ static void swim_suspect(const Ctx& c, Node& n, u32 subject, u32 inc, u32 from, u32 wmeta, uint4* p, uint4& e, bool& dirty, Ins& ins) {
   const Dev& d = c.d;
   if (!p || !(e.w & SIM_VB_KNOWN)) return;
   if (inc < e.z) return;
@@ -761,7 +801,7 @@ __device__ static void swim_suspect(const Ctx& c, Node& n, u32 subject, u32 inc,
   dirty = true;
   susp_track(c, n, d.slot_of[subject], c.tick + d.T[0]);
 }
-__device__ static void swim_dead(const Ctx& c, Node& n, u32 subject, u32 inc, u32 from, u32 wmeta, uint4* p, uint4 e, bool& dirty, Ins& ins) {
+__device__ static void swim_dead(const Ctx& c, Node& n, u32 subject, u32 inc, u32 from, u32 wmeta, uint4* p, uint4& e, bool& dirty, Ins& ins) {
   if (!p || !(e.w & SIM_VB_KNOWN)) return;
   if (inc < e.z) return;
   u32 old = SIM_VB_SWIM(e.w);
@@ -862,27 +902,6 @@ __device__ static inline uint4* lookup_ptr(const Ctx& c, u32 kind, u32 key, u64 
   uint4* p = basep + (row * d.Nl + c.l) * 2;
   return none ? nullptr : p;
 }
-// Row of the state array a record is checked against — view slot of its subject, or ring bucket of its Lamport
-// time — as an 18-bit id (NOROW: nothing to look at).  The staged copy of a record carries it in the bits of
-// `meta` that are zero on the wire ([17:8] and [31:24]), so that the handler loop needs no staged pointers.
-#define NOROW 0x3FFFFu
-__device__ static inline u32 row_pack(u32 row) { return ((row & 0x3FFu) << 8) | ((row >> 10) << 24); }
-__device__ static inline u32 row_unpack(u32 meta) { return ((meta >> 8) & 0x3FFu) | ((meta >> 24) << 10); }
-__device__ static inline u32 lookup_row(const Dev& d, u32 kind, u64 val, u32 slot) {
-  bool isq = kind == SIM_K_QUERY, isring = isq || kind == SIM_K_EVENT;
-  u32 B = isq ? d.Bq : d.Bev, mask = isq ? d.bq_mask : d.bev_mask;
-  u32 idx = (u32)val & mask;
-  if (!(d.bev_mask && d.bq_mask)) idx = ring_idx(val, B, mask);  // uniform: a ring size that is not a power of two
-  bool none = !isring && (kind == SIM_K_EMPTY || slot == NOSLOT);
-  return none ? NOROW : (isring ? idx : slot);
-}
-__device__ static inline uint4* row_ptr(const Ctx& c, u32 kind, u32 row) {
-  const Dev& d = c.d;
-  uint4* basep = kind == SIM_K_QUERY ? d.qring : kind == SIM_K_EVENT ? d.ering : d.view;
-  return basep + ((size_t)row * d.Nl + c.l) * 2;
-}
-// which array a kind's row lives in (view 0, event ring 1, query ring 2), above the 18 row bits: "same entry" test
-__device__ static inline u32 row_tag(u32 kind, u32 row) { return row | ((kind == SIM_K_EVENT ? 1u : kind == SIM_K_QUERY ? 2u : 0u) << 18); }
 // slot of a member record's subject (NOSLOT for other kinds and for ids out of range)
 __device__ static inline u32 slot_load(const Dev& d, u32 kind, u32 key) {
   u32 s = NOSLOT;
@@ -997,7 +1016,7 @@ __device__ static inline void fast_witness(Node& n, u32 kind, const uint4& r, bo
   n.clock = jl ? lt + 1 : n.clock;
   n.dirty |= ((ev | jl) ? DR0 : 0u) | (qu ? DR1 : 0u);
 }
-__device__ static inline void dispatch(const Ctx& c, Node& n, const uint4& r, uint4* p, const uint4& e, bool& dirty, Ins& ins) {
+__device__ static inline void dispatch(const Ctx& c, Node& n, const uint4& r, uint4* p, uint4& e, bool& dirty, Ins& ins) {
   u32 kind = SIM_META_KIND(r.y), flags = SIM_META_FLAGS(r.y);
   u64 val = (u64)r.z | ((u64)r.w << 32);
   bool rb = false;
@@ -1033,24 +1052,17 @@ static u32 g_ablate = 0;
 #else
 #define ABL(bit) false
 #endif
-// global_load_lds writes LDS behind the compiler's back as far as its s_waitcnt insertion is concerned (it was seen
-// issuing a ds_read of DMA'd data ahead of the vmcnt wait): every consumer waits explicitly.  The asm is a memory
-// barrier for the compiler as well, so no LDS access moves across it.
-#define DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#ifndef TICK_OCC
-#define TICK_OCC 4
-#endif
 template <bool SHARDED, int F>
-__global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, u32 cur, const uint4* base) {
+__global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur, const uint4* base) {
 #ifdef TICK_TIMING
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #endif
-  // LDS staging of the per-node inbox: the packet being delivered (each record tagged with the row of the entry
-  // it is checked against) and the head of that entry: 32 KiB per block = exactly 5 blocks per CU.  Phase 2
-  // reuses both planes as the double buffer of the payload gathers.
+  // LDS staging of the per-node inbox: the packet being delivered, the slot of each record's
+  // subject's entry and the head of that entry (40 KiB per block: exactly 4 blocks per CU)
   __shared__ uint4 lds_r[SIM_P][BLOCK];
   __shared__ uint4 lds_e[SIM_P][BLOCK];
+  __shared__ uint4* lds_p[SIM_P][BLOCK];  // where each record's entry lives (null: nothing to look at)
   const u32 tid = threadIdx.x;
   u32 l = blockIdx.x * BLOCK + threadIdx.x;
   if (l >= d.Nl) return;
@@ -1074,10 +1086,11 @@ __global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, 
     if (!tp.first) {
       // inbox cell of fan-out slot k (sharded: the block of the receive buffer the source shard filled)
       auto cell_of = [&](u32 k) -> const uint4* {
-        if (SHARDED) {
-          u32 b = l / tp.blk;
+        if (SHARDED) {  // [sender chunk][source shard][slot][sub] (oracle xcell)
+          u32 b = l / tp.blk, w = l - b * tp.blk, sl = w / tp.sub;
           u32 src = (d.shard_rank + b + tp.prot[k]) % tp.V;
-          return d.xrecv + (((size_t)src * d.f + k) * tp.blk + (l - b * tp.blk)) * 4;
+          u32 ch = (sl + tp.C - tp.prho[k]) % tp.C;
+          return d.xrecv + ((((size_t)ch * tp.V + src) * d.f + k) * tp.sub + (w - sl * tp.sub)) * 4;
         }
         return d.inbox[cur] + ((size_t)k * d.Nl + l) * 4;
       };
@@ -1100,58 +1113,48 @@ __global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, 
           // wave-ballot early out: nobody in this wave received anything in packet k
           if (!__any((k0 | k1 | k2 | k3) != SIM_K_EMPTY)) continue;
           if (ABL(64)) { n.dirty |= (k0 ^ k1 ^ k2 ^ k3) & tp.zero_; continue; }
+          lds_r[0][tid] = r0; lds_r[1][tid] = r1; lds_r[2][tid] = r2; lds_r[3][tid] = r3;
           u32 s0 = slot_load(d, k0, r0.x);
           u32 s1 = slot_load(d, k1, r1.x);
           u32 s2 = slot_load(d, k2, r2.x);
           u32 s3 = slot_load(d, k3, r3.x);
           TT(2);
-          u32 w0 = lookup_row(d, k0, (u64)r0.z | ((u64)r0.w << 32), s0);
-          u32 w1 = lookup_row(d, k1, (u64)r1.z | ((u64)r1.w << 32), s1);
-          u32 w2 = lookup_row(d, k2, (u64)r2.z | ((u64)r2.w << 32), s2);
-          u32 w3 = lookup_row(d, k3, (u64)r3.z | ((u64)r3.w << 32), s3);
-          const uint4* p0 = w0 != NOROW ? row_ptr(c, k0, w0) : d.nullcell;
-          const uint4* p1 = w1 != NOROW ? row_ptr(c, k1, w1) : d.nullcell;
-          const uint4* p2 = w2 != NOROW ? row_ptr(c, k2, w2) : d.nullcell;
-          const uint4* p3 = w3 != NOROW ? row_ptr(c, k3, w3) : d.nullcell;
-          // the four heads go from HBM straight into this wave's columns of lds_e (global_load_lds: no VGPR landing
-          // zone, no LDS write instruction), the tagged records through registers into lds_r
-          const u32 wb = tid & ~63u;
-#define HEAD_DMA(i, ptr) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ptr), \
-                                                          (__attribute__((address_space(3))) void*)&lds_e[i][wb], 16, 0, 0)
-          HEAD_DMA(0, p0); HEAD_DMA(1, p1); HEAD_DMA(2, p2); HEAD_DMA(3, p3);
-#undef HEAD_DMA
-          r0.y |= row_pack(w0); r1.y |= row_pack(w1); r2.y |= row_pack(w2); r3.y |= row_pack(w3);
-          lds_r[0][tid] = r0; lds_r[1][tid] = r1; lds_r[2][tid] = r2; lds_r[3][tid] = r3;
+          uint4* p0 = lookup_ptr(c, k0, r0.x, (u64)r0.z | ((u64)r0.w << 32), s0);
+          uint4* p1 = lookup_ptr(c, k1, r1.x, (u64)r1.z | ((u64)r1.w << 32), s1);
+          uint4* p2 = lookup_ptr(c, k2, r2.x, (u64)r2.z | ((u64)r2.w << 32), s2);
+          uint4* p3 = lookup_ptr(c, k3, r3.x, (u64)r3.z | ((u64)r3.w << 32), s3);
+          lds_p[0][tid] = p0; lds_p[1][tid] = p1; lds_p[2][tid] = p2; lds_p[3][tid] = p3;
+          uint4 e0 = ld4(p0 ? p0 : d.nullcell), e1 = ld4(p1 ? p1 : d.nullcell), e2 = ld4(p2 ? p2 : d.nullcell), e3 = ld4(p3 ? p3 : d.nullcell);
           TT(3);
+          lds_e[0][tid] = e0; lds_e[1][tid] = e1; lds_e[2][tid] = e2; lds_e[3][tid] = e3;
           TT(4);
         }
         // phase B: the records in arrival order, one rolled loop = one copy of the handler code.
         // Duplicates, old messages and subjects without a view slot (~95 % of all records) are
         // retired by fast_noop against the staged head; the rest runs the full handlers.  Once a
         // handler of this packet has written state, later heads are re-read (rare).
-        // `wtag`: the one entry a handler of this packet has written so far; `wall`: more than one,
+        // `wptr`: the one entry a handler of this packet has written so far; `wall`: more than one,
         // or the node's own entry as well (refutation) — only then is a staged head stale.
         if (ABL(32)) continue;
-        u32 wtag = 0xFFFFFFFFu;
+        uint4* wptr = nullptr;
         bool wall = false;
-        DMA_WAIT();  // the heads have landed in lds_e
 #pragma unroll 1
         for (u32 p = 0; p < SIM_P; ++p) {
           uint4 r = lds_r[p][tid];
-          u32 kind = SIM_META_KIND(r.y), row = row_unpack(r.y), tag = row_tag(kind, row);
-          bool has = row != NOROW;
+          u32 kind = SIM_META_KIND(r.y);
+          uint4* ptr = lds_p[p][tid];
           uint4 e = lds_e[p][tid];
-          if (has && (wall || tag == wtag)) e = ld4(row_ptr(c, kind, row));
-          bool fast = fast_noop(c, n, kind, r, has, e);
+          if (ptr && (wall || ptr == wptr)) e = ld4(ptr);
+          bool fast = fast_noop(c, n, kind, r, ptr != nullptr, e);
           fast_witness(n, kind, r, fast);
           if (fast) continue;
           Ins ins;
           ins.has = ins.wide = 0;
           bool dirty = false;
-          dispatch(c, n, r, has ? row_ptr(c, kind, row) : nullptr, e, dirty, ins);
+          dispatch(c, n, r, ptr, e, dirty, ins);
           if (dirty) {
-            wall |= ins.wide || (wtag != 0xFFFFFFFFu && wtag != tag);
-            wtag = tag;
+            wall |= ins.wide || (wptr != nullptr && wptr != ptr);
+            wptr = ptr;
           }
           if (ins.has) pend_push(c, n, ins);
         }
@@ -1212,90 +1215,88 @@ __global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, 
     }
   }
   TT(8);
-  // the node's own state is final here: write the dirty row groups and the live key groups back now (the stores
-  // drain behind the gathers below, and ~40 registers are free for the rest of the tick)
+  // ... then every payload gather of the tick in flight at once (one memory round trip, not F) ...
+  // A queue of at most SIM_P entries sends the same records in every round: a record that sits
+  // in the same place as in the previous packet is copied, not gathered again (the gathers are
+  // scattered 16-byte accesses, one address per lane for the texture addresser).
+  uint4 pk[F][SIM_P];
+#pragma unroll
+  for (int k = 0; k < F; ++k) {
+#pragma unroll
+    for (int p = 0; p < (int)SIM_P; ++p) {
+      u32 s = (slots[k] >> (8 * p)) & 0xFFu;
+      bool again = k > 0 && s == ((slots[k > 0 ? k - 1 : 0] >> (8 * p)) & 0xFFu);
+      pk[k][p] = zero;
+      if (again) pk[k][p] = pk[k > 0 ? k - 1 : 0][p];
+      else if (s != 0xFFu && !ABL(8)) pk[k][p] = ld4(&d.qpay[(size_t)s * d.Nl + l]);
+    }
+  }
+  TT(9);
+  // ... then the F scatters: packet k goes to the inbox cell of T_k(l) (SIMSPEC §2.3, oracle fan_target).  The sender is
+  // (vblock bb0, sub-slab s0 = its chunk, offset r0); u = its index inside the chunk = (block j, position i).  With
+  // 64-node blocks j is the same for the whole wave: the block permutation runs on the scalar unit, and the wave's 64
+  // packets of one slot land in 64 consecutive cells.
+  u32 bb0 = 0, s0 = 0, r0 = ll;
+  if (tp.V != 1 || tp.C != 1) {
+    bb0 = ll / tp.blk;
+    u32 w = ll - bb0 * tp.blk;
+    s0 = w / tp.sub;
+    r0 = w - s0 * tp.sub;
+  }
+  const u32 uu = bb0 * tp.sub + r0;
+  u32 fj = uu, fi = 0;
+  if (tp.B == 64u) { fj = (u32)__builtin_amdgcn_readfirstlane((int)(uu >> 6)); fi = uu & 63u; }
+  const u32 pj = tp.feff ? pi_f(tp, fj) : 0;
+  const bool coop = (blockIdx.x + 1u) * BLOCK <= d.Nl;  // every lane of the block is here
+#pragma unroll
+  for (int k = 0; k < F; ++k) {
+    if ((u32)k >= tp.feff || ABL(4)) break;
+    u32 y = pj + tp.off[k];
+    if (y >= tp.nbc) y -= tp.nbc;
+    u32 j2 = pi_inv(tp, y);
+    u32 u2 = j2;
+    if (tp.B == 64u) u2 = j2 * 64u + (fi ^ (((y + 1u) * 0x9E3779B1u + (u32)k * 0x85EBCA6Bu) >> 26));
+    u32 bb = 0, r = u2, h = 0;
+    if (tp.V != 1 || tp.C != 1) {
+      bb = u2 / tp.sub;
+      r = u2 - bb * tp.sub;
+      h = (g + tp.V - ((bb + tp.rot[k]) % tp.V)) % tp.V;
+    }
+    u32 sl = s0 + tp.rho[k];
+    if (sl >= tp.C) sl -= tp.C;
+    u32 t = bb * tp.blk + sl * tp.sub + r;
+    uint4* dst;
+    if (SHARDED) dst = d.xsend + ((((size_t)s0 * tp.V + h) * d.f + k) * tp.sub + r) * 4;
+    else dst = d.inbox[cur ^ 1] + ((size_t)k * d.Nl + (size_t)h * tp.M + t) * 4;
+    if (coop) {
+      // Four lanes write one 64-byte cell per store instruction (lane i of the quad writes record
+      // i of quad-mate j's packet): the texture addresser sees 64 contiguous bytes per quad and L2
+      // one write per cell instead of four.  The 4x4 transpose goes through this wave's columns of
+      // lds_r (free in phase 2), XOR-swizzled so that neither side has bank conflicts.
+      lds_r[0][tid] = pk[k][0]; lds_r[1][tid ^ 1] = pk[k][1]; lds_r[2][tid ^ 2] = pk[k][2]; lds_r[3][tid ^ 3] = pk[k][3];
+      __builtin_amdgcn_wave_barrier();
+      u32 qi = tid & 3u, qb = tid & ~3u;
+      u32 dlo = (u32)(uintptr_t)dst, dhi = (u32)((uintptr_t)dst >> 32);
+#define COOP_STORE(j)                                                                              \
+      {                                                                                            \
+        uint4 v = lds_r[qi][(qb + j) ^ qi];                                                        \
+        u32 lo = (u32)__builtin_amdgcn_mov_dpp((int)dlo, j * 0x55, 0xF, 0xF, true);                \
+        u32 hi = (u32)__builtin_amdgcn_mov_dpp((int)dhi, j * 0x55, 0xF, 0xF, true);                \
+        ((uint4*)(((uintptr_t)hi << 32) | lo))[qi] = v;                                            \
+      }
+      COOP_STORE(0) COOP_STORE(1) COOP_STORE(2) COOP_STORE(3)
+#undef COOP_STORE
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      dst[0] = pk[k][0]; dst[1] = pk[k][1]; dst[2] = pk[k][2]; dst[3] = pk[k][3];
+    }
+  }
+  TT(10);
   if (up && !ABL(16)) {
     node_store(d, l, n);
     keys_store(d, l, cnt0, n.used, sk);
   }
-  TT(9);
-  // ... then the F packets: gather the payload records of packet k, push the packet into the inbox cell of T_k(l).
-  u32 sx = tp.feff ? sigma(tp, ll) : 0;
-  auto cell_ptr = [&](int k) -> uint4* {
-    u32 y = sx + tp.off[k];
-    if (y >= tp.M) y -= tp.M;
-    u32 t = sigma_inv(tp, y);
-    u32 b = 0, h = 0;
-    if (tp.V != 1) {
-      b = t / tp.blk;
-      h = (g + tp.V - ((b + tp.rot[k]) % tp.V)) % tp.V;
-    }
-    if (SHARDED) return d.xsend + (((size_t)h * d.f + k) * tp.blk + (t - b * tp.blk)) * 4;
-    return d.inbox[cur ^ 1] + ((size_t)k * d.Nl + (size_t)h * tp.M + t) * 4;
-  };
-  const bool coop = (blockIdx.x + 1u) * BLOCK <= d.Nl;  // every lane of the block is here
-  if (coop) {
-    // Cooperative path.  The 16-byte payload gathers go straight from HBM into LDS (global_load_lds: no VGPR
-    // round trip), double-buffered over the two staging planes, and land in the XOR-swizzled layout the store
-    // side reads: plane p, column c holds record p of lane c ^ p — so lane c fetches for its quad-mate c ^ p,
-    // whose payload slot comes over by DPP.  Then four lanes write one whole 64-byte cell per store instruction
-    // (lane i of a quad writes record i of quad-mate j's packet): the texture addresser sees 64 contiguous bytes
-    // per quad and L2 one write per cell instead of four partial ones.
-    const u32 qi = tid & 3u, qb = tid & ~3u, wb = tid & ~63u;
-    auto issue = [&](int k, uint4 (*buf)[BLOCK]) {
-#pragma unroll
-      for (int p = 0; p < (int)SIM_P; ++p) {
-        u32 mine = (slots[k] >> (8 * p)) & 0xFFu;
-        u32 sl = mine;  // quad_perm: lane ^ 1 = [1,0,3,2], lane ^ 2 = [2,3,0,1], lane ^ 3 = [3,2,1,0]
-        if (p == 1) sl = (u32)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);
-        if (p == 2) sl = (u32)__builtin_amdgcn_mov_dpp((int)mine, 0x4E, 0xF, 0xF, true);
-        if (p == 3) sl = (u32)__builtin_amdgcn_mov_dpp((int)mine, 0x1B, 0xF, 0xF, true);
-        if (sl != 0xFFu && !ABL(8))
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)&d.qpay[(size_t)sl * d.Nl + (l ^ (u32)p)],
-                                           (__attribute__((address_space(3))) void*)&buf[p][wb], 16, 0, 0);
-        else
-          buf[p][tid] = zero;
-      }
-    };
-    auto push = [&](int k, uint4 (*buf)[BLOCK]) {
-      uint4* dst = cell_ptr(k);
-      u32 dlo = (u32)(uintptr_t)dst, dhi = (u32)((uintptr_t)dst >> 32);
-#define COOP_STORE(j)                                                                              \
-      {                                                                                            \
-        uint4 v = buf[qi][(qb + j) ^ qi];                                                          \
-        u32 lo = (u32)__builtin_amdgcn_mov_dpp((int)dlo, j * 0x55, 0xF, 0xF, true);                \
-        u32 hi = (u32)__builtin_amdgcn_mov_dpp((int)dhi, j * 0x55, 0xF, 0xF, true);                \
-        v4u vv = {v.x, v.y, v.z, v.w};                                                             \
-        ((__attribute__((address_space(1))) v4u*)(((uintptr_t)hi << 32) | lo))[qi] = vv;           \
-      }
-      COOP_STORE(0) COOP_STORE(1) COOP_STORE(2) COOP_STORE(3)
-#undef COOP_STORE
-    };
-    // two packets per round trip: both gathers in flight (one per staging plane), one wait, eight cell stores
-#pragma unroll
-    for (int k0 = 0; k0 < F; k0 += 2) {
-      if ((u32)k0 >= tp.feff || ABL(4)) break;
-      issue(k0, lds_r);
-      if (k0 + 1 < F && (u32)k0 + 1 < tp.feff) issue(k0 + 1, lds_e);
-      DMA_WAIT();
-      push(k0, lds_r);
-      if (k0 + 1 < F && (u32)k0 + 1 < tp.feff) push(k0 + 1, lds_e);
-      __builtin_amdgcn_wave_barrier();
-    }
-  } else {
-    // ragged last block: plain per-lane gathers and four 16-byte stores per cell
-#pragma unroll
-    for (int k = 0; k < F; ++k) {
-      if ((u32)k >= tp.feff || ABL(4)) break;
-      uint4* dst = cell_ptr(k);
-#pragma unroll
-      for (int p = 0; p < (int)SIM_P; ++p) {
-        u32 sl = (slots[k] >> (8 * p)) & 0xFFu;
-        dst[p] = (sl != 0xFFu && !ABL(8)) ? ld4(&d.qpay[(size_t)sl * d.Nl + l]) : zero;
-      }
-    }
-  }
-  TT(10);
+  TT(11);
 #ifdef TICK_TIMING
   if ((threadIdx.x & 63) == 0)
     for (int i = 0; i < 12; ++i) atomicAdd(&g_tt[i], tacc[i]);
@@ -1343,7 +1344,8 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
           u64 lt = n.eclock;
           n.eclock++;
           uint4* p = ering_ptr(c, lt);
-          handle_user_event(c, n, a, lt, p, p[0], dirty);
+          uint4 e_ = p[0];
+          handle_user_event(c, n, a, lt, p, e_, dirty);
           ins_set(ins2, a, wire_meta(SIM_K_EVENT, (b >> 31) ? SIM_F_CC : 0u, b & 0x7FFFFFFFu), lt);
         }
         break;
@@ -1351,7 +1353,8 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
         if (up) {
           u64 lt = n.qclock;
           uint4* p = qring_ptr(c, lt);
-          handle_query(c, n, a, lt, b, p, p[0], dirty);
+          uint4 e_ = p[0];
+          handle_query(c, n, a, lt, b, p, e_, dirty);
           ins_set(ins2, a, wire_meta(SIM_K_QUERY, b, 32), lt);
         }
         break;
@@ -1361,7 +1364,8 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
           u64 lt = n.clock;
           n.clock++;
           uint4* p = view_ptr(c, gid);
-          handle_leave_intent(c, n, gid, lt, false, p, p ? p[0] : make_uint4(0, 0, 0, 0), dirty, ins);
+          uint4 e_ = p ? p[0] : make_uint4(0, 0, 0, 0);
+          handle_leave_intent(c, n, gid, lt, false, p, e_, dirty, ins);
           if (has_alive) ins_set(ins2, gid, wire_meta(SIM_K_LEAVE, 0, 16), lt);
         }
         break;
@@ -1369,7 +1373,8 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
         if (up && SIM_RF_STATE(n.flags) == SIM_SERF_LEAVING) {
           if (d.swim) {
             uint4* p = view_ptr(c, gid);
-            swim_dead(c, n, gid, n.inc, gid, wire_meta(SIM_K_DEAD, 0, 32), p, p ? p[0] : make_uint4(0, 0, 0, 0), dirty, ins);
+            uint4 e_ = p ? p[0] : make_uint4(0, 0, 0, 0);
+            swim_dead(c, n, gid, n.inc, gid, wire_meta(SIM_K_DEAD, 0, 32), p, e_, dirty, ins);
           }
           n.flags = (n.flags & ~(3u << 1)) | (SIM_SERF_LEFT << 1);
         }
@@ -1401,7 +1406,8 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
         if (up) {
           u64 lt = n.clock;
           uint4* p = view_ptr(c, a);
-          handle_leave_intent(c, n, a, lt, b != 0, p, p ? p[0] : make_uint4(0, 0, 0, 0), dirty, ins);
+          uint4 e_ = p ? p[0] : make_uint4(0, 0, 0, 0);
+          handle_leave_intent(c, n, a, lt, b != 0, p, e_, dirty, ins);
           if (has_alive) ins_set(ins2, a, wire_meta(SIM_K_LEAVE, b ? SIM_F_PRUNE : 0, 16), lt);
         }
         break;
@@ -1490,7 +1496,8 @@ __device__ static void pp_merge(const Dev& d, const TickP& tp, u32 ll, u32 lr) {
     for (int k = 0; k < (int)SIM_C; ++k) {
       if (!keys[k]) break;
       uint4* p = ering_ptr(c, lt);
-      handle_user_event(c, n, keys[k], lt, p, p[0], dirty);
+      uint4 e_ = p[0];
+      handle_user_event(c, n, keys[k], lt, p, e_, dirty);
     }
   }
   node_store(d, ll, n);
@@ -1817,11 +1824,9 @@ static int cfg_check(const sim_config* c) {
   if (c->shard_count != 1 && c->shard_count != c->vshards) return SIM_EINVAL;
   if (c->shard_rank >= c->shard_count) return SIM_EINVAL;
   if (c->fanout < 1 || c->fanout > SIM_MAX_FANOUT) return SIM_EINVAL;
+  if (c->chunks > 1 && ((M / c->vshards) % c->chunks || (M / c->vshards) / c->chunks < 1)) return SIM_EINVAL;
+  if (c->flags & SIM_CF_RANDOM_FANOUT) return SIM_EINVAL;  // oracle-only comparison mode (variable in-degree)
   if (c->event_ring < 1 || c->query_ring < 1) return SIM_EINVAL;
-  {  // a staged record names its ring bucket / view slot with 18 bits (NOROW = all ones)
-    u32 A = (c->view_slots == 0 || c->view_slots >= c->n_nodes) ? c->n_nodes : c->view_slots;
-    if (A >= NOROW || c->event_ring >= NOROW || c->query_ring >= NOROW) return SIM_EINVAL;
-  }
   if (c->retransmit_mult * h_digits10(c->n_nodes) > 63u) return SIM_EINVAL;
   if (c->probe_interval) {  // suspicion timers name view slots with 16 bits
     u32 A = (c->view_slots == 0 || c->view_slots >= c->n_nodes) ? c->n_nodes : c->view_slots;
@@ -2091,7 +2096,7 @@ int sim_step(sim_handle* h, uint32_t n_ticks) {
 #ifdef TICK_ABLATE
     tp.abl = g_ablate;
 #endif
-    for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) tp.prot[k] = h->prev.rot[k];
+    for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) { tp.prot[k] = h->prev.rot[k]; tp.prho[k] = h->prev.rho[k]; }
     tp.n_slots = (u32)h->walk.size();
     while (h->op_cursor < h->ops.size() && h->ops[h->op_cursor].tick <= h->tick) {
       OpBatch ob;
@@ -2398,7 +2403,7 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
   if (rc != SIM_OK) return rc;
   h->tick = hd.tick;
   h->n_slots = hd.n_slots;
-  for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) h->prev.rot[k] = hd.prev_rot[k];
+  if (hd.tick > 0) tickp_make(&h->prev, &h->cfg, hd.tick - 1);  // the parameters the packets in flight were sent with
   memcpy(h->slot_of.data(), sec[6], len[6]);
   memcpy(h->subject_of.data(), sec[7], len[7]);
   memcpy(h->base.data(), sec[8], len[8]);

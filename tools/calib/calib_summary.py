@@ -23,8 +23,8 @@ def main():
         rows = list(csv.DictReader(open(f)))
         byd = {}
         for r in rows:
-            if "flush_rd" in r["Kernel_Name"]:
-                continue
+            if "flush_rd" in r["Kernel_Name"] or not any(k.rstrip("(") in r["Kernel_Name"] for k in KERNEL_OF.values()):
+                continue  # cache flushes and the runtime's own fill kernels (hipMemset)
             byd.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"], "c": {}})
             byd[int(r["Dispatch_Id"])]["c"].setdefault(r["Counter_Name"], 0.0)
             byd[int(r["Dispatch_Id"])]["c"][r["Counter_Name"]] += float(r["Counter_Value"])
