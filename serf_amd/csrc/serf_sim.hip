@@ -200,9 +200,13 @@ struct Dev {
   uint4* pend;   // [SIM_PEND][Nl] broadcasts requested by the handlers of the running tick, arrival order
   uint4* inbox[2];       // [f][Nl] packets of 4 x uint4 (local mode)
   uint4 *xsend, *xrecv;  // sharded mode: [V][f][blk] packets
-  uint4* view;   // [A][Nl] entries of 2 x uint4 {ltime.lo, ltime.hi, inc, bits}{conf[4]}
-  uint4* ering;  // [Bev][Nl] buckets of 2 x uint4 {ltime.lo, ltime.hi, k0, k1}{k2..k5}
-  uint4* qring;  // [Bq][Nl]
+  // Entries are split into two planes of 16 bytes per (row, node): the HEAD the hot path checks every record against
+  // — view {ltime.lo, ltime.hi, inc, bits}, ring bucket {ltime.lo, ltime.hi, k0, k1} — at arr[row * Nl + l], dense
+  // across the nodes of a wave, and the rarely touched TAIL — view conf[4], bucket k2..k5 — `*tail` uint4s further on.
+  uint4* view;   // [2][A][Nl]
+  uint4* ering;  // [2][Bev][Nl]
+  uint4* qring;  // [2][Bq][Nl]
+  size_t vtail, etail, qtail;  // A * Nl, Bev * Nl, Bq * Nl
   u32* slot_of;     // [N]
   u32* subject_of;  // [A]
   u32* walk;        // [n_slots] allocated slots in ascending SUBJECT order (the order of every walk over the view)
@@ -445,7 +449,7 @@ __device__ static inline u32 vb_set_stamp(u32 b, u32 st) { return (b & 0x7FFu) |
 #define E_LTIME(e) ((u64)(e).x | ((u64)(e).y << 32))
 #define E_SET_LTIME(e, t) ((e).x = (u32)(t), (e).y = (u32)((t) >> 32))
 
-__device__ static inline uint4* view_slot_ptr(const Ctx& c, u32 a) { return c.d.view + ((size_t)a * c.d.Nl + c.l) * 2; }
+__device__ static inline uint4* view_slot_ptr(const Ctx& c, u32 a) { return c.d.view + ((size_t)a * c.d.Nl + c.l); }
 __device__ static inline uint4* view_ptr(const Ctx& c, u32 subject) {
   if (subject >= c.d.N) return nullptr;
   u32 a = c.d.slot_of[subject];
@@ -457,10 +461,10 @@ __device__ static inline u32 ring_idx(u64 lt, u32 B, u32 mask) {
   return (lt >> 32) ? (u32)(lt % B) : ((u32)lt % B);
 }
 __device__ static inline uint4* ering_ptr(const Ctx& c, u64 lt) {
-  return c.d.ering + ((size_t)ring_idx(lt, c.d.Bev, c.d.bev_mask) * c.d.Nl + c.l) * 2;
+  return c.d.ering + ((size_t)ring_idx(lt, c.d.Bev, c.d.bev_mask) * c.d.Nl + c.l);
 }
 __device__ static inline uint4* qring_ptr(const Ctx& c, u64 lt) {
-  return c.d.qring + ((size_t)ring_idx(lt, c.d.Bq, c.d.bq_mask) * c.d.Nl + c.l) * 2;
+  return c.d.qring + ((size_t)ring_idx(lt, c.d.Bq, c.d.bq_mask) * c.d.Nl + c.l);
 }
 
 // Event stream of watched observers (event.rs:325-378); appended in program order per node, the
@@ -505,7 +509,7 @@ __device__ static inline void erase_member(const Ctx& c, Node& n, uint4* p, cons
   if (st == SIM_STATUS_FAILED && n.nfailed) n.nfailed--;
   if (st == SIM_STATUS_LEFT && n.nleft) n.nleft--;
   p[0] = make_uint4(0, 0, 0, 0);
-  p[1] = make_uint4(0, 0, 0, 0);
+  p[c.d.vtail] = make_uint4(0, 0, 0, 0);
   if (n.nknown) n.nknown--;
   n.dirty |= DR1 | DR2;
   emit_event(c, n, SIM_EV_REAP, subject, 0);
@@ -619,20 +623,20 @@ __device__ static void node_leave_e(const Ctx& c, Node& n, uint4& e, u32 subject
     emit_event(c, n, SIM_EV_FAILED, subject, 0);
   }
 }
-__device__ static inline bool bucket_add(uint4* p, uint4& b0, u32 key, bool same_lt, bool check_lt, Node& n, bool& seen) {
+__device__ static inline bool bucket_add(uint4* p, size_t tail, uint4& b0, u32 key, bool same_lt, bool check_lt, Node& n, bool& seen) {
   // returns true when the key was added; `seen` when it was already there (subject to ltime for queries)
   seen = false;
   bool m = !check_lt || same_lt;
   if (m && (b0.z == key || b0.w == key)) { seen = true; return false; }
   if (b0.w == 0) { b0.w = key; p[0] = b0; return true; }
-  uint4 b1 = p[1];
+  uint4 b1 = p[tail];
   if (m && (b1.x == key || b1.y == key || b1.z == key || b1.w == key)) { seen = true; return false; }
   if (b1.x == 0) b1.x = key;
   else if (b1.y == 0) b1.y = key;
   else if (b1.z == 0) b1.z = key;
   else if (b1.w == 0) b1.w = key;
   else { n.overflow++; n.dirty |= DR2; return false; }  // model bound: bucket full => treated as seen
-  p[1] = b1;
+  p[tail] = b1;
   return true;
 }
 // handle_user_event: base.rs:750-837 (quirk U1 kept).  (p, b0) = ring bucket of ltime, preloaded.
@@ -646,7 +650,7 @@ __device__ static bool handle_user_event(const Ctx& c, Node& n, u32 key, u64 lti
   if (cur > B && ltime < cur - B) return false;
   if (b0.z) {  // bucket present: keys[0] != 0
     bool seen;
-    if (!bucket_add(p, b0, key, false, false, n, seen)) return false;
+    if (!bucket_add(p, c.d.etail, b0, key, false, false, n, seen)) return false;
   } else {
     b0 = make_uint4((u32)ltime, (u32)(ltime >> 32), key, 0);
     p[0] = b0;
@@ -695,7 +699,7 @@ __device__ static bool handle_query(const Ctx& c, Node& n, u32 id, u64 ltime, u3
   if (cur > qt && qt < cur - qt) return false;
   if (b0.z) {
     bool seen;
-    if (!bucket_add(p, b0, id, E_LTIME(b0) == ltime, true, n, seen)) return false;
+    if (!bucket_add(p, c.d.qtail, b0, id, E_LTIME(b0) == ltime, true, n, seen)) return false;
   } else {
     b0 = make_uint4((u32)ltime, (u32)(ltime >> 32), id, 0);
     p[0] = b0;
@@ -774,7 +778,7 @@ __device__ static void swim_suspect(const Ctx& c, Node& n, u32 subject, u32 inc,
   if (SIM_VB_SWIM(e.w) == SIM_SWIM_SUSPECT) {  // a timer exists: try to confirm
     u32 k = SIM_VB_NCONF(e.w);
     if (k >= d.kconf) return;
-    uint4 cf = p[1];
+    uint4 cf = p[d.vtail];
     if (cf.x == from) return;
     if (k >= 1 && cf.y == from) return;
     if (k >= 2 && cf.z == from) return;
@@ -782,7 +786,7 @@ __device__ static void swim_suspect(const Ctx& c, Node& n, u32 subject, u32 inc,
     if (k == 0) cf.y = from;
     else if (k == 1) cf.z = from;
     else cf.w = from;
-    p[1] = cf;
+    p[d.vtail] = cf;
     e.w = vb_set_nconf(e.w, k + 1);
     p[0] = e;
     dirty = true;
@@ -797,7 +801,7 @@ __device__ static void swim_suspect(const Ctx& c, Node& n, u32 subject, u32 inc,
   e.z = inc;
   e.w = vb_set_stamp(vb_set_nconf(vb_set_swim(e.w, SIM_SWIM_SUSPECT), 0), c.tick & STAMP_MASK);
   p[0] = e;
-  p[1] = make_uint4(from, 0, 0, 0);
+  p[d.vtail] = make_uint4(from, 0, 0, 0);
   dirty = true;
   susp_track(c, n, d.slot_of[subject], c.tick + d.T[0]);
 }
@@ -899,7 +903,7 @@ __device__ static inline uint4* lookup_ptr(const Ctx& c, u32 kind, u32 key, u64 
   size_t row = isring ? (size_t)idx : (size_t)slot;
   uint4* basep = isring ? ring : d.view;
   bool none = !isring && (kind == SIM_K_EMPTY || slot == NOSLOT);
-  uint4* p = basep + (row * d.Nl + c.l) * 2;
+  uint4* p = basep + (row * d.Nl + c.l);
   return none ? nullptr : p;
 }
 // slot of a member record's subject (NOSLOT for other kinds and for ids out of range)
@@ -926,7 +930,7 @@ __device__ static void reap_run(const Ctx& c, Node& n, u32 n_slots) {
       if (age > timeout) { erase_member(c, n, p, e, d.subject_of[a]); continue; }
     } else if (SIM_VB_INTENT(e.w) && d.intent_timeout) {
       timeout = d.intent_timeout;
-      if (age > timeout) { p[0] = make_uint4(0, 0, 0, 0); p[1] = make_uint4(0, 0, 0, 0); continue; }
+      if (age > timeout) { p[0] = make_uint4(0, 0, 0, 0); p[d.vtail] = make_uint4(0, 0, 0, 0); continue; }
     } else {
       continue;
     }
@@ -1445,7 +1449,7 @@ __device__ static void pp_merge(const Dev& d, const TickP& tp, u32 ll, u32 lr) {
 #pragma unroll 1
     for (u32 wi = 0; wi < tp.n_slots; ++wi) {
       u32 a = d.walk[wi];
-      uint4 re = d.view[((size_t)a * d.Nl + lr) * 2];
+      uint4 re = d.view[(size_t)a * d.Nl + lr];
       if (!(re.w & SIM_VB_KNOWN)) continue;
       if (n.next_seq > 1023u - 64u) q_renorm(n, sk);  // a merge can queue one broadcast per view slot
       u32 subj = d.subject_of[a], sw = SIM_VB_SWIM(re.w), inc = re.z;
@@ -1469,7 +1473,7 @@ __device__ static void pp_merge(const Dev& d, const TickP& tp, u32 ll, u32 lr) {
 #pragma unroll 1
     for (u32 wi = 0; wi < tp.n_slots; ++wi) {
       u32 a = d.walk[wi];
-      uint4 re = d.view[((size_t)a * d.Nl + lr) * 2];
+      uint4 re = d.view[(size_t)a * d.Nl + lr];
       if (!(re.w & SIM_VB_KNOWN)) continue;
       bool left = SIM_VB_STATUS(re.w) == SIM_STATUS_LEFT;
       if (left != (pass == 0)) continue;
@@ -1486,10 +1490,10 @@ __device__ static void pp_merge(const Dev& d, const TickP& tp, u32 ll, u32 lr) {
   }
 #pragma unroll 1
   for (u32 idx = 0; idx < d.Bev; ++idx) {  // replay the remote event buffer: delegate.rs:540-552
-    const uint4* rb = d.ering + ((size_t)idx * d.Nl + lr) * 2;
+    const uint4* rb = d.ering + ((size_t)idx * d.Nl + lr);
     uint4 b0 = rb[0];
     if (!b0.z) continue;
-    uint4 b1 = b0.w ? rb[1] : zero;
+    uint4 b1 = b0.w ? rb[d.etail] : zero;
     u64 lt = E_LTIME(b0);
     u32 keys[SIM_C] = {b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
@@ -1525,10 +1529,30 @@ __global__ void fill_u4(uint4* p, size_t n, uint4 v) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 // column a of the view := the subject's baseline entry
-__global__ void fill_view_col(uint4* view, size_t Nl, u32 a, uint4 e0, uint4 e1) {
+__global__ void fill_view_col(uint4* view, size_t tail, size_t Nl, u32 a, uint4 e0, uint4 e1) {
   for (size_t l = blockIdx.x * (size_t)blockDim.x + threadIdx.x; l < Nl; l += (size_t)gridDim.x * blockDim.x) {
-    view[((size_t)a * Nl + l) * 2] = e0;
-    view[((size_t)a * Nl + l) * 2 + 1] = e1;
+    view[(size_t)a * Nl + l] = e0;
+    view[tail + (size_t)a * Nl + l] = e1;
+  }
+}
+// the per-subject baseline table stays entry-interleaved ([N][2]): it is read by probes and status queries only
+__global__ void fill_base(uint4* base, size_t n, uint4 e0, uint4 e1) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    base[i * 2] = e0;
+    base[i * 2 + 1] = e1;
+  }
+}
+// canonical (interleaved, 32-byte) form of `count` entries starting at entry `first` of a split array, and back
+__global__ void canon_entries_kernel(const uint4* arr, size_t tail, size_t first, size_t count, uint4* out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    out[i * 2] = arr[first + i];
+    out[i * 2 + 1] = arr[tail + first + i];
+  }
+}
+__global__ void uncanon_entries_kernel(uint4* arr, size_t tail, size_t first, size_t count, const uint4* in) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    arr[first + i] = in[i * 2];
+    arr[tail + first + i] = in[i * 2 + 1];
   }
 }
 // keep d.walk sorted by subject: shift [pos, count) up by one, put slot a at pos (one thread; slot allocation is rare)
@@ -1543,7 +1567,7 @@ __global__ void fill_iota(u32* p, size_t n) {
 __global__ void init_dense_self(Dev d) {  // new_in's synthetic notify_join(local): self known, Alive @ 0
   for (size_t l = blockIdx.x * (size_t)blockDim.x + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * blockDim.x) {
     u32 gid = d.shard0 + (u32)l;
-    d.view[((size_t)gid * d.Nl + l) * 2] = make_uint4(0, 0, 0, 1u | (SIM_STATUS_ALIVE << 1));
+    d.view[(size_t)gid * d.Nl + l] = make_uint4(0, 0, 0, 1u | (SIM_STATUS_ALIVE << 1));
   }
 }
 
@@ -1634,6 +1658,16 @@ __global__ void digest_flat(const u64* w, size_t n_words, u64* out) {
   for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < n_words; i += (size_t)gridDim.x * BLOCK) acc += dig(w[i], i);
   block_sum_add(acc, out);
 }
+// digest of a split array in its canonical (interleaved) word order: entry e = words 4e, 4e+1 (head), 4e+2, 4e+3 (tail)
+__global__ void digest_split(const uint4* arr, size_t tail, size_t n_entries, u64* out) {
+  u64 acc = 0;
+  for (size_t e = blockIdx.x * (size_t)BLOCK + threadIdx.x; e < n_entries; e += (size_t)gridDim.x * BLOCK) {
+    uint4 h = arr[e], t = arr[tail + e];
+    acc += dig((u64)h.x | ((u64)h.y << 32), e * 4) + dig((u64)h.z | ((u64)h.w << 32), e * 4 + 1);
+    acc += dig((u64)t.x | ((u64)t.y << 32), e * 4 + 2) + dig((u64)t.z | ((u64)t.w << 32), e * 4 + 3);
+  }
+  block_sum_add(acc, out);
+}
 // running queries: tracker table, then the ack / response bitmaps (canonical order = physical order)
 __global__ void digest_queries(const uint4* qtab, const u32* qbits, size_t n_bits_words, u64* out) {
   u64 acc = 0;
@@ -1693,7 +1727,7 @@ __global__ void digest_rows_queue(Dev d, u64* out_rows, u64* out_queue) {
 __global__ void members_kernel(Dev d, const uint4* base, u32 obs_l, uint8_t* st, u64* lt) {
   for (size_t s = blockIdx.x * (size_t)blockDim.x + threadIdx.x; s < d.N; s += (size_t)gridDim.x * blockDim.x) {
     u32 a = d.slot_of[s];
-    uint4 e = a == NOSLOT ? base[s * 2] : d.view[((size_t)a * d.Nl + obs_l) * 2];
+    uint4 e = a == NOSLOT ? base[s * 2] : d.view[(size_t)a * d.Nl + obs_l];
     bool known = e.w & SIM_VB_KNOWN;
     st[s] = known ? (uint8_t)SIM_VB_STATUS(e.w) : (uint8_t)SIM_STATUS_NONE;
     lt[s] = known ? E_LTIME(e) : 0;
@@ -1706,13 +1740,13 @@ __global__ void convergence_kernel(Dev d, const uint4* base, u32 kind, u32 key, 
     upc++;
     if (kind == SIM_K_JOIN || kind == SIM_K_LEAVE) {
       u32 a = d.slot_of[key];
-      uint4 e = a == NOSLOT ? base[(size_t)key * 2] : d.view[((size_t)a * d.Nl + l) * 2];
+      uint4 e = a == NOSLOT ? base[(size_t)key * 2] : d.view[(size_t)a * d.Nl + l];
       seen += ((e.w & SIM_VB_KNOWN) && E_LTIME(e) >= ltime);
     } else {
       const uint4* ring = kind == SIM_K_EVENT ? d.ering : d.qring;
       u32 B = kind == SIM_K_EVENT ? d.Bev : d.Bq;
-      const uint4* p = ring + ((size_t)(ltime % B) * d.Nl + l) * 2;
-      uint4 b0 = p[0], b1 = p[1];
+      const uint4* p = ring + ((size_t)(ltime % B) * d.Nl + l);
+      uint4 b0 = p[0], b1 = p[kind == SIM_K_EVENT ? d.etail : d.qtail];
       seen += (b0.z == key) | (b0.w == key) | (b1.x == key) | (b1.y == key) | (b1.z == key) | (b1.w == key);
     }
   }
@@ -1924,6 +1958,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   h->dense = (cfg->view_slots == 0 || cfg->view_slots >= d.N);
   d.A = h->dense ? d.N : cfg->view_slots;
   d.Bev = cfg->event_ring; d.Bq = cfg->query_ring; d.f = cfg->fanout;
+  d.vtail = (size_t)d.A * d.Nl; d.etail = (size_t)d.Bev * d.Nl; d.qtail = (size_t)d.Bq * d.Nl;
   d.bev_mask = (d.Bev > 1 && !(d.Bev & (d.Bev - 1))) ? d.Bev - 1 : 0;
   d.bq_mask = (d.Bq > 1 && !(d.Bq & (d.Bq - 1))) ? d.Bq - 1 : 0;
   d.retransmit_mult = cfg->retransmit_mult;
@@ -1992,7 +2027,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   if (joined) { b0.ltime = 1; b0.bits = 1u | (SIM_STATUS_ALIVE << 1); }
   h->base.assign(d.N, b0);
   uint4 e0 = make_uint4((u32)b0.ltime, (u32)(b0.ltime >> 32), b0.inc, b0.bits), e1 = make_uint4(0, 0, 0, 0);
-  fill_view_col<<<grid_for(d.N), BLOCK, 0, s>>>(h->d_base, d.N, 0, e0, e1);  // d_base is one "column" of N entries
+  fill_base<<<grid_for(d.N), BLOCK, 0, s>>>(h->d_base, d.N, e0, e1);
   if (h->dense) {
     h->n_slots = d.N;
     h->walk.resize(d.N);
@@ -2000,7 +2035,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
     fill_iota<<<grid_for(d.N), BLOCK, 0, s>>>(d.walk, d.N);
     if (joined) {
       size_t tot = (size_t)d.A * Nl;
-      fill_view_col<<<grid_for(tot), BLOCK, 0, s>>>(d.view, tot, 0, e0, e1);
+      fill_view_col<<<grid_for(tot), BLOCK, 0, s>>>(d.view, d.vtail, tot, 0, e0, e1);
     } else {
       init_dense_self<<<grid_for(Nl), BLOCK, 0, s>>>(d);
     }
@@ -2033,7 +2068,7 @@ static int ensure_slot(sim_handle* h, u32 subject) {
   const sim_view& b = h->base[subject];
   uint4 e0 = make_uint4((u32)b.ltime, (u32)(b.ltime >> 32), b.inc, b.bits);
   uint4 e1 = make_uint4(b.conf[0], b.conf[1], b.conf[2], b.conf[3]);
-  fill_view_col<<<grid_for(d.Nl), BLOCK, 0, h->stream>>>(d.view, d.Nl, a, e0, e1);
+  fill_view_col<<<grid_for(d.Nl), BLOCK, 0, h->stream>>>(d.view, d.vtail, d.Nl, a, e0, e1);
   {
     u32 pos = (u32)h->walk.size();
     while (pos > 0 && h->subject_of[h->walk[pos - 1]] > subject) --pos;
@@ -2223,9 +2258,9 @@ int sim_state_digest(sim_handle* h, uint64_t out[8]) {
   digest_rows_queue<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, h->d_scratch + 0, h->d_scratch + 1);
   size_t nw;
   if (cur_inbox(h)) { nw = (size_t)d.f * d.Nl * 8; digest_flat<<<grid_for(nw), BLOCK, 0, s>>>((const u64*)cur_inbox(h), nw, h->d_scratch + 2); }
-  nw = (size_t)d.A * d.Nl * 4; digest_flat<<<grid_for(nw), BLOCK, 0, s>>>((const u64*)d.view, nw, h->d_scratch + 3);
-  nw = (size_t)d.Bev * d.Nl * 4; digest_flat<<<grid_for(nw), BLOCK, 0, s>>>((const u64*)d.ering, nw, h->d_scratch + 4);
-  nw = (size_t)d.Bq * d.Nl * 4; digest_flat<<<grid_for(nw), BLOCK, 0, s>>>((const u64*)d.qring, nw, h->d_scratch + 5);
+  digest_split<<<grid_for(d.vtail), BLOCK, 0, s>>>(d.view, d.vtail, d.vtail, h->d_scratch + 3);
+  digest_split<<<grid_for(d.etail), BLOCK, 0, s>>>(d.ering, d.etail, d.etail, h->d_scratch + 4);
+  digest_split<<<grid_for(d.qtail), BLOCK, 0, s>>>(d.qring, d.qtail, d.qtail, h->d_scratch + 5);
   digest_aux<<<grid_for((size_t)d.N + d.N / 32 + 1), BLOCK, 0, s>>>(d.slot_of, d.upmap, d.N, h->d_scratch + 6);
   nw = (size_t)SIM_QT * 2 * (((size_t)d.N + 31) / 32);
   digest_queries<<<grid_for(nw + 2 * SIM_QT), BLOCK, 0, s>>>(d.qtab, d.qbits, nw, h->d_scratch + 7);
@@ -2234,6 +2269,29 @@ int sim_state_digest(sim_handle* h, uint64_t out[8]) {
   return SIM_OK;
 }
 
+// Split arrays (view, rings) <-> their canonical interleaved form, in chunks of at most 64 MiB of device scratch
+static int split_copy(sim_handle* h, uint4* arr, size_t tail, size_t n_entries, void* host, bool download) {
+  const size_t CH = (size_t)1 << 21;  // entries per chunk
+  if (!n_entries) return SIM_OK;
+  uint4* tmp = nullptr;
+  if (hipMalloc((void**)&tmp, std::min(n_entries, CH) * 32) != hipSuccess) return SIM_ENOMEM;
+  hipError_t e = hipSuccess;
+  for (size_t first = 0; first < n_entries && e == hipSuccess; first += CH) {
+    size_t cnt = std::min(CH, n_entries - first);
+    uint8_t* hp = (uint8_t*)host + first * 32;
+    if (download) {
+      canon_entries_kernel<<<grid_for(cnt), BLOCK, 0, h->stream>>>(arr, tail, first, cnt, tmp);
+      e = hipMemcpyAsync(hp, tmp, cnt * 32, hipMemcpyDeviceToHost, h->stream);
+    } else {
+      e = hipMemcpyAsync(tmp, hp, cnt * 32, hipMemcpyHostToDevice, h->stream);
+      if (e == hipSuccess) uncanon_entries_kernel<<<grid_for(cnt), BLOCK, 0, h->stream>>>(arr, tail, first, cnt, tmp);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // tmp is reused by the next chunk
+  }
+  (void)hipFree(tmp);
+  HCHECK(e);
+  return SIM_OK;
+}
 int sim_dump_state(sim_handle* h, uint32_t which, void* buf, size_t cap, size_t* bytes) {
   if (!h || !bytes) return SIM_EINVAL;
   Dev& d = h->d;
@@ -2265,6 +2323,9 @@ int sim_dump_state(sim_handle* h, uint32_t which, void* buf, size_t cap, size_t*
     HCHECK(e);
     return SIM_OK;
   }
+  if (which == SIM_ARR_VIEW) return split_copy(h, d.view, d.vtail, d.vtail, buf, true);
+  if (which == SIM_ARR_ERING) return split_copy(h, d.ering, d.etail, d.etail, buf, true);
+  if (which == SIM_ARR_QRING) return split_copy(h, d.qring, d.qtail, d.qtail, buf, true);
   if (!src) { memset(buf, 0, n); return SIM_OK; }
   HCHECK(hipMemcpyAsync(buf, src, n, hipMemcpyDeviceToHost, h->stream));
   HCHECK(hipStreamSynchronize(h->stream));
@@ -2386,7 +2447,10 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
   if (rc == SIM_OK && hipMalloc(&tmp_queue, std::max<size_t>(len[1], 16)) != hipSuccess) rc = SIM_ENOMEM;
   auto up = [&](void* dst, int i) { if (len[i]) RCHECK(hipMemcpyAsync(dst, sec[i], len[i], hipMemcpyHostToDevice, s)); };
   if (rc == SIM_OK) {
-    up(tmp_rows, 0); up(tmp_queue, 1); up(inbox_dst, 2); up(d.view, 3); up(d.ering, 4); up(d.qring, 5);
+    up(tmp_rows, 0); up(tmp_queue, 1); up(inbox_dst, 2);
+    if (rc == SIM_OK) rc = split_copy(h, d.view, d.vtail, d.vtail, (void*)sec[3], false);
+    if (rc == SIM_OK) rc = split_copy(h, d.ering, d.etail, d.etail, (void*)sec[4], false);
+    if (rc == SIM_OK) rc = split_copy(h, d.qring, d.qtail, d.qtail, (void*)sec[5], false);
     up(d.slot_of, 6); up(d.subject_of, 7); up(h->d_base, 8); up(d.upmap, 9); up(d.qtab, 10); up(d.qbits, 11);
     // canonical rows / queue -> packed row groups, sort keys + slot-stable payloads
     RCHECK(hipMemsetAsync(d.R2, 0, (size_t)d.Nl * 16, s));
