@@ -1056,8 +1056,14 @@ static u32 g_ablate = 0;
 #else
 #define ABL(bit) false
 #endif
+#ifndef TICK_OCC
+#define TICK_OCC 4
+#endif
+#ifndef TICK_PREFETCH4
+#define TICK_PREFETCH4 1  // all four records of the next packet are fetched one packet ahead (measured: -4 %)
+#endif
 template <bool SHARDED, int F>
-__global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur, const uint4* base) {
+__global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, u32 cur, const uint4* base) {
 #ifdef TICK_TIMING
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -1100,6 +1106,9 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
       };
       const uint4* cell = cell_of(0);
       uint4 rn = ld4(cell);  // first record of the next packet, fetched one packet ahead
+#if TICK_PREFETCH4
+      uint4 rn1 = ld4(cell + 1), rn2 = ld4(cell + 2), rn3 = ld4(cell + 3);  // ... and the other three as well
+#endif
       for (u32 k = 0; k < d.f; ++k) {
         // ---- stage the packet in LDS (one 16-byte column per record and lane: conflict-free) ----
         // phase A: the four records, then their four independent lookups — slot map for member
@@ -1107,11 +1116,19 @@ __global__ __launch_bounds__(BLOCK, 4) void tick_kernel(Dev d, TickP tp, u32 cur
         // against.  Everything lands in this lane's LDS cells so that the handler loop below can
         // index it by record number without holding 40 registers across the handlers.
         {
+#if TICK_PREFETCH4
+          uint4 r0 = rn, r1 = rn1, r2 = rn2, r3 = rn3;
+          if (k + 1 < d.f) {
+            cell = cell_of(k + 1);
+            rn = ld4(cell); rn1 = ld4(cell + 1); rn2 = ld4(cell + 2); rn3 = ld4(cell + 3);
+          }
+#else
           uint4 r0 = rn, r1 = ld4(cell + 1), r2 = ld4(cell + 2), r3 = ld4(cell + 3);
           if (k + 1 < d.f) {  // pull the next cell's line towards this CU while this packet is handled
             cell = cell_of(k + 1);
             rn = ld4(cell);
           }
+#endif
           TT(1);
           u32 k0 = SIM_META_KIND(r0.y), k1 = SIM_META_KIND(r1.y), k2 = SIM_META_KIND(r2.y), k3 = SIM_META_KIND(r3.y);
           // wave-ballot early out: nobody in this wave received anything in packet k

@@ -18,8 +18,8 @@ buf = (C.c_ulonglong * 16)()
 lib.dll.sim_debug_timing(buf, 1)
 sim.step(50); sim.sync()
 lib.dll.sim_debug_timing(buf, 1)
-names = ["row load", "cell r1-3 (x4)", "slot_of (x4)", "rows+head DMA issue, records -> LDS (x4)", "(unused)", "head wait + handler loop (x4)",
-         "timers+probe+reaper", "keys+pend inserts", "q_round x4", "row/keys store", "gathers (DMA) + perm + cell stores", "(unused)"]
+names = ["row load", "cell r1-3 (x4)", "slot_of (x4)", "entry ptrs+issue (x4)", "entry heads wait (x4)", "handler loop (x4)", "timers+probe+reaper",
+         "keys+pend inserts", "q_round x4", "payload gather (all)", "perm+store x4", "row/keys store"]
 waves = n // 64 * 50
 tot = sum(buf[:12])
 for i, nm in enumerate(names):
