@@ -119,6 +119,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence", action="store_true", help="skip the rounds-to-99 %% measurement (profiling runs)")
     ap.add_argument("--allow-drops", action="store_true", help="do not fail when the run hit a model bound (overflow > 0)")
+    ap.add_argument("--chunks", type=int, default=2,
+                    help="N > 1: sender chunks per tick; the all-to-all of chunk c travels while chunk c + 1 computes (1 = one exchange after the kernel)")
     return ap.parse_args(argv)
 
 
@@ -156,7 +158,7 @@ def run(args, lib=None, dev=None, backend="nccl"):
         lib = serf_amd.load()
     kw, ops = workload(args, n_total)
     if world > 1:
-        sim = ShardedSim(lib, n_total, dev, **kw)
+        sim = ShardedSim(lib, n_total, dev, chunks=args.chunks, **kw)
     else:
         sim = _ffi.Sim(lib, _ffi.make_config(n_total, **kw))
         if on_gpu:
@@ -182,6 +184,8 @@ def run(args, lib=None, dev=None, backend="nccl"):
         return [int(x) for x in t]
 
     def load_now():  # cluster-wide load: records per packet in flight, queue entries per node, model-bound drops
+        if world > 1:
+            sim.sync()  # the round's exchanges have landed
         cs = raw.cluster_stats()
         inbox, queued, drops, up = allsum([cs["inbox_records"], sum(cs["queued"]), cs["overflow"], cs["up"]])
         return {"records_per_packet": inbox / (args.fanout * n_total), "queued_per_node": queued / n_total,
@@ -213,8 +217,6 @@ def run(args, lib=None, dev=None, backend="nccl"):
     # an event pair costs ~10 us of stream time: time a sample of the launches on long runs, all of them on short ones
     profile_every = 4 if args.steps >= 100 else 1
     raw.profile(profile_every)
-    if world > 1:
-        sim.time_exchange(True)
     barrier()
     # ---- timed: exactly K steps between two barriers.  The launches go to torch's current stream
     # (sim_set_stream above), so one pair of torch events brackets them as well.
@@ -232,8 +234,18 @@ def run(args, lib=None, dev=None, backend="nccl"):
         dt = float(t[0])
     (prof_ms, prof_min, prof_max), prof_n = raw.profile_read_stats()
     raw.profile(False)
-    exchange_ms = sim.time_exchange(False) if world > 1 else None
     load1 = load_now()
+    # N > 1 diagnosis, outside the timed region: the same ticks with every all-to-all bracketed by events and run
+    # synchronously (no overlap) — what one round's exchange costs on its own, next to the kernel
+    exchange_ms, diag_ticks = None, 20
+    if world > 1:
+        barrier()
+        sim.time_exchange(True)
+        td0 = time.perf_counter()
+        step(diag_ticks)
+        barrier()
+        serial_ms = (time.perf_counter() - td0) * 1e3 / diag_ticks
+        exchange_ms = sim.time_exchange(False) / diag_ticks
 
     # ---- second half of the metric: rounds to 99 % convergence, measured after the timed region on
     # fresh user events, one at a time, under the same background load (every rank issues the same
@@ -286,7 +298,8 @@ def run(args, lib=None, dev=None, backend="nccl"):
                                    f"view_slots {args.view_slots}, rings {args.ring}, probe interval {args.probe_interval} ticks, push-pull interval "
                                    f"{args.push_pull_interval} ticks (x log2 scaling), reaper and queue checker on — BASELINE configs[2]; "
                                    f"{args.preroll} untimed pre-roll ticks under the same load before the warm-up (steady state)",
-                       "parallelism": f"node-id range shards x{world}, 1 all_to_all_single/tick" if world > 1 else "single GPU",
+                       "parallelism": (f"node-id range shards x{world}, {args.chunks} chunk-wise all_to_all_single per tick, overlapped with compute"
+                                       if world > 1 else "single GPU"),
                        "preroll": args.preroll,
                        "timed_ticks": [args.preroll + args.warmup, args.preroll + args.warmup + args.steps - 1],
                        "model_bound_drops": load2["drops"],
@@ -311,11 +324,14 @@ def run(args, lib=None, dev=None, backend="nccl"):
         }
         if world > 1:
             xb = raw.exchange_bytes()
-            out["exchange"] = {"exchange_ms": exchange_ms / args.steps, "kernel_ms": kern_s * 1e3,
+            out["exchange"] = {"chunks": sim.chunks, "exchange_ms": exchange_ms, "kernel_ms": kern_s * 1e3,
+                               "serial_ms_per_step": serial_ms, "overlapped_ms_per_step": dt / args.steps * 1e3,
                                "bytes_per_peer": xb // world, "bytes_per_gpu_per_tick": xb,
                                "bytes_leaving_gpu_per_tick": xb // world * (world - 1),
-                               "what": "exchange_ms = mean time of the all_to_all_single of one round (events on the stream around it, rank 0); "
-                                       "kernel_ms = mean tick_kernel launch; they run back to back, ms_per_step ~ their sum"}
+                               "what": f"the timed region runs each tick as {sim.chunks} chunk launches with the all-to-all of chunk c in flight "
+                                       "while chunk c + 1 computes (overlapped_ms_per_step = ms_per_step); exchange_ms and serial_ms_per_step come "
+                                       f"from {diag_ticks} further ticks with the collectives run one after the other between events (rank 0): "
+                                       "exchange_ms = all-to-alls of one round, serial_ms_per_step = that round without overlap"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

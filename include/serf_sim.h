@@ -339,6 +339,18 @@ int sim_convergence(sim_handle* h, uint32_t kind, uint32_t key, uint64_t ltime,
  * moves send -> recv between sim_step(h,1) calls. */
 int sim_exchange_bytes(const sim_handle* h, size_t* bytes);
 int sim_bind_exchange(sim_handle* h, void* send_dev, void* recv_dev);
+/* Chunk-wise exchange (sim_config.chunks = C > 1): the buffers are [C sender chunks][V peers][fanout][N/V/V/C packets],
+ * so chunk c is one contiguous region of bytes_per_chunk bytes with an equal split per peer, complete as soon as the
+ * launch of chunk c has finished — its all-to-all can travel while chunk c + 1 computes.  Because the receive buffer
+ * of round t is still being read by the later chunks of round t + 1 while the first chunks of round t + 1 are
+ * already arriving, the receive side is double-buffered: packets sent during tick t land in recv[t & 1].
+ * A tick is then driven as  sim_step_begin;  for c in 0..C-1: sim_step_chunk(c), <exchange chunk c into recv[t & 1]>;
+ * sim_step_end  — and every exchange of tick t must have completed before sim_step_chunk of tick t + 1. */
+int sim_bind_exchange2(sim_handle* h, void* send_dev, void* recv0_dev, void* recv1_dev);
+int sim_exchange_chunks(const sim_handle* h, uint32_t* chunks, size_t* bytes_per_chunk);
+int sim_step_begin(sim_handle* h);
+int sim_step_chunk(sim_handle* h, uint32_t chunk);
+int sim_step_end(sim_handle* h);
 
 /* Checkpoint / resume of the whole simulated cluster (the reference checkpoints one node's members and
  * clocks, serf-core/src/snapshot.rs:117-126,228-347; here the unit is the simulation).  The image is the

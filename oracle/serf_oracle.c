@@ -248,7 +248,9 @@ struct sim_handle {
   sim_row* rows;        /* [Nl]            */
   sim_record* queue;    /* [Nl][Q], sorted */
   sim_packet* inbox[2]; /* local mode: [f][Nl]; current = tick & 1 */
-  sim_packet *xsend, *xrecv; /* sharded mode: [V][f][blk]          */
+  sim_packet *xsend, *xrecv; /* sharded mode: [C][V][f][sub]; xrecv = rbuf[(tick + 1) & 1] while a tick runs */
+  sim_packet* rbuf[2];       /* packets sent during tick t are received into rbuf[t & 1] */
+  tickp cur; int in_tick;    /* between step_begin and step_end */
   int own_x;
   sim_view* view;       /* [A][Nl]   */
   sim_bucket* ering;    /* [Bev][Nl] */
@@ -1191,21 +1193,33 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
   }
 }
 
-static void step_one(osim* s) {
-  tickp p;
-  tickp_make(&p, &s->cfg, s->tick);
+static void step_begin(osim* s) {
+  tickp* p = &s->cur;
+  tickp_make(p, &s->cfg, s->tick);
+  if (s->cfg.shard_count > 1) s->xrecv = s->rbuf[(s->tick + 1) & 1];
   while (s->op_cursor < s->n_ops && s->ops[s->op_cursor].tick <= s->tick) {
     apply_op(s, &s->ops[s->op_cursor]);
     s->op_cursor++;
   }
-  pp_round(s, &p);
+  pp_round(s, p);
+  s->in_tick = 1;
+}
+/* the nodes of sender chunk c (all of them for c == NOSLOT): V ranges of `sub` consecutive nodes */
+static void step_chunk(osim* s, uint32_t chunk) {
+  const tickp* p = &s->cur;
+  uint32_t cnt = chunk == NOSLOT ? s->Nl : p->V * p->sub;
   if (s->n_watched) {
-    for (uint32_t l = 0; l < s->Nl; ++l) tick_node(s, &p, l);
+    for (uint32_t i = 0; i < cnt; ++i)
+      tick_node(s, p, chunk == NOSLOT ? i : (i / p->sub) * p->blk + chunk * p->sub + i % p->sub);
   } else {
     int nt = oracle_threads();
-#pragma omp parallel for schedule(static) num_threads(nt) if (s->Nl >= 4096)
-    for (uint32_t l = 0; l < s->Nl; ++l) tick_node(s, &p, l);
+#pragma omp parallel for schedule(static) num_threads(nt) if (cnt >= 4096)
+    for (uint32_t i = 0; i < cnt; ++i)
+      tick_node(s, p, chunk == NOSLOT ? i : (i / p->sub) * p->blk + chunk * p->sub + i % p->sub);
   }
+}
+static void step_end(osim* s) {
+  const tickp p = s->cur;
   if (s->rfan) { /* group the cells by target: counting sort, senders ascending within a target */
     memset(s->rcsr, 0, ((size_t)s->Nl + 1) * sizeof(uint32_t));
     size_t cells = (size_t)s->f * s->Nl;
@@ -1223,6 +1237,12 @@ static void step_one(osim* s) {
   }
   s->prev = p;
   s->tick++;
+  s->in_tick = 0;
+}
+static void step_one(osim* s) {
+  step_begin(s);
+  step_chunk(s, NOSLOT); /* chunks are independent within a tick: one pass over all nodes is the same thing */
+  step_end(s);
 }
 
 /* =====================================================================================
@@ -1306,6 +1326,7 @@ int API(create)(const sim_config* cfg, osim** out) {
     size_t cells = (size_t)s->f * s->M;
     s->xsend = (sim_packet*)calloc(cells, sizeof(sim_packet));
     s->xrecv = (sim_packet*)calloc(cells, sizeof(sim_packet));
+    s->rbuf[0] = s->rbuf[1] = s->xrecv;
     s->own_x = 1;
   } else {
     s->inbox[0] = (sim_packet*)calloc((size_t)s->f * Nl, sizeof(sim_packet));
@@ -1531,7 +1552,7 @@ static uint64_t dig_words(const void* p, size_t n_words) {
   return acc;
 }
 static const sim_packet* cur_inbox(const osim* s) {
-  return s->cfg.shard_count > 1 ? s->xrecv : s->inbox[s->tick & 1];
+  return s->cfg.shard_count > 1 ? s->rbuf[(s->tick + 1) & 1] : s->inbox[s->tick & 1];
 }
 int API(state_digest)(osim* s, uint64_t out[8]) {
   if (!s || !out) return SIM_EINVAL;
@@ -1746,13 +1767,43 @@ int API(exchange_bytes)(const osim* s, size_t* bytes) {
   *bytes = s->cfg.shard_count > 1 ? (size_t)s->f * s->M * sizeof(sim_packet) : 0;
   return SIM_OK;
 }
-int API(bind_exchange)(osim* s, void* send, void* recv) {
-  if (!s || s->cfg.shard_count <= 1 || !send || !recv) return SIM_EINVAL;
+int API(bind_exchange2)(osim* s, void* send, void* recv0, void* recv1) {
+  if (!s || s->cfg.shard_count <= 1 || !send || !recv0 || !recv1) return SIM_EINVAL;
   if (s->own_x) { free(s->xsend); free(s->xrecv); s->own_x = 0; }
   s->xsend = (sim_packet*)send;
-  s->xrecv = (sim_packet*)recv;
+  s->rbuf[0] = (sim_packet*)recv0;
+  s->rbuf[1] = (sim_packet*)recv1;
+  s->xrecv = s->rbuf[(s->tick + 1) & 1];
   memset(send, 0, (size_t)s->f * s->M * sizeof(sim_packet));
-  memset(recv, 0, (size_t)s->f * s->M * sizeof(sim_packet));
+  memset(recv0, 0, (size_t)s->f * s->M * sizeof(sim_packet));
+  memset(recv1, 0, (size_t)s->f * s->M * sizeof(sim_packet));
+  return SIM_OK;
+}
+int API(bind_exchange)(osim* s, void* send, void* recv) { return API(bind_exchange2)(s, send, recv, recv); }
+int API(exchange_chunks)(const osim* s, uint32_t* chunks, size_t* bytes_per_chunk) {
+  if (!s || !chunks || !bytes_per_chunk) return SIM_EINVAL;
+  uint32_t C = s->cfg.chunks ? s->cfg.chunks : 1;
+  *chunks = s->cfg.shard_count > 1 ? C : 1;
+  *bytes_per_chunk = s->cfg.shard_count > 1 ? (size_t)s->f * s->M * sizeof(sim_packet) / C : 0;
+  return SIM_OK;
+}
+int API(step_begin)(osim* s) {
+  if (!s) return SIM_EINVAL;
+  if (s->in_tick) return SIM_ESTATE;
+  step_begin(s);
+  return SIM_OK;
+}
+int API(step_chunk)(osim* s, uint32_t chunk) {
+  if (!s) return SIM_EINVAL;
+  if (!s->in_tick) return SIM_ESTATE;
+  if (s->cfg.shard_count <= 1 || chunk >= s->cur.C) return SIM_EINVAL;
+  step_chunk(s, s->cur.C == 1 ? NOSLOT : chunk);
+  return SIM_OK;
+}
+int API(step_end)(osim* s) {
+  if (!s) return SIM_EINVAL;
+  if (!s->in_tick) return SIM_ESTATE;
+  step_end(s);
   return SIM_OK;
 }
 

@@ -84,6 +84,7 @@ ABI_SYMBOLS = ("create", "destroy", "set_stream", "join", "leave", "force_leave"
                "query", "inject", "step", "sync", "tick", "members", "stats_get", "watch",
                "drain_events", "state_digest", "dump_state", "convergence", "exchange_bytes",
                "bind_exchange", "snapshot", "restore", "query_status", "profile", "profile_read", "profile_read_stats", "cluster_stats_get",
+               "bind_exchange2", "exchange_chunks", "step_begin", "step_chunk", "step_end",
                "abi_version", "backend_name")
 
 
@@ -140,6 +141,11 @@ class SimLib:
             "convergence": (C.c_int, [H, u32, u32, u64, C.POINTER(u64), C.POINTER(u64)]),
             "exchange_bytes": (C.c_int, [H, C.POINTER(C.c_size_t)]),
             "bind_exchange": (C.c_int, [H, vp, vp]),
+            "bind_exchange2": (C.c_int, [H, vp, vp, vp]),
+            "exchange_chunks": (C.c_int, [H, C.POINTER(u32), C.POINTER(C.c_size_t)]),
+            "step_begin": (C.c_int, [H]),
+            "step_chunk": (C.c_int, [H, u32]),
+            "step_end": (C.c_int, [H]),
             "snapshot": (C.c_int, [H, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
             "restore": (C.c_int, [H, vp, C.c_size_t]),
             "query_status": (C.c_int, [H, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_int)]),
@@ -307,6 +313,24 @@ class Sim:
         n = C.c_size_t()
         self._ck(self.lib.f["exchange_bytes"](self.h, C.byref(n)), "sim_exchange_bytes")
         return n.value
+
+    def bind_exchange2(self, send_ptr, recv0_ptr, recv1_ptr):
+        self._ck(self.lib.f["bind_exchange2"](self.h, C.c_void_p(send_ptr), C.c_void_p(recv0_ptr), C.c_void_p(recv1_ptr)), "sim_bind_exchange2")
+
+    def exchange_chunks(self):
+        """(number of sender chunks, bytes of one chunk's region of the exchange buffers)."""
+        c, n = C.c_uint32(), C.c_size_t()
+        self._ck(self.lib.f["exchange_chunks"](self.h, C.byref(c), C.byref(n)), "sim_exchange_chunks")
+        return c.value, n.value
+
+    def step_begin(self):
+        self._ck(self.lib.f["step_begin"](self.h), "sim_step_begin")
+
+    def step_chunk(self, chunk):
+        self._ck(self.lib.f["step_chunk"](self.h, chunk), "sim_step_chunk")
+
+    def step_end(self):
+        self._ck(self.lib.f["step_end"](self.h), "sim_step_end")
 
     def bind_exchange(self, send_ptr, recv_ptr):
         self._ck(self.lib.f["bind_exchange"](self.h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr)), "sim_bind_exchange")

@@ -1063,7 +1063,7 @@ static u32 g_ablate = 0;
 #define TICK_PREFETCH4 1  // all four records of the next packet are fetched one packet ahead (measured: -4 %)
 #endif
 template <bool SHARDED, int F>
-__global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, u32 cur, const uint4* base) {
+__global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, u32 cur, const uint4* base, u32 chunk, u32 cnt) {
 #ifdef TICK_TIMING
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -1074,8 +1074,15 @@ __global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, 
   __shared__ uint4 lds_e[SIM_P][BLOCK];
   __shared__ uint4* lds_p[SIM_P][BLOCK];  // where each record's entry lives (null: nothing to look at)
   const u32 tid = threadIdx.x;
-  u32 l = blockIdx.x * BLOCK + threadIdx.x;
-  if (l >= d.Nl) return;
+  // one launch covers `cnt` nodes: the whole shard (chunk == ~0), or sender chunk `chunk` of a sharded run = the nodes
+  // whose offset inside their vblock lies in sub-slab `chunk` (V ranges of `sub` consecutive nodes)
+  const u32 idx = blockIdx.x * BLOCK + threadIdx.x;
+  if (idx >= cnt) return;
+  u32 l = idx;
+  if (SHARDED && chunk != 0xFFFFFFFFu) {
+    u32 b = idx / tp.sub;
+    l = b * tp.blk + chunk * tp.sub + (idx - b * tp.sub);
+  }
 #ifdef TICK_ABLATE
   if (ABL(0xFF00u) && blockIdx.x < 1024u) {  // experiment: stagger the first generation of blocks
     u32 slot = (blockIdx.x >> 8) & 3u, per = (tp.abl >> 8) & 0xFFu;
@@ -1268,7 +1275,7 @@ __global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, 
   u32 fj = uu, fi = 0;
   if (tp.B == 64u) { fj = (u32)__builtin_amdgcn_readfirstlane((int)(uu >> 6)); fi = uu & 63u; }
   const u32 pj = tp.feff ? pi_f(tp, fj) : 0;
-  const bool coop = (blockIdx.x + 1u) * BLOCK <= d.Nl;  // every lane of the block is here
+  const bool coop = (blockIdx.x + 1u) * BLOCK <= cnt;  // every lane of the block is here
 #pragma unroll
   for (int k = 0; k < F; ++k) {
     if ((u32)k >= tp.feff || ABL(4)) break;
@@ -1851,6 +1858,10 @@ struct sim_handle {
   u64 prof_seq;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof;  // one event pair per tick-kernel launch
   u32 pp_step;  // push-pull batches: every pp_step ticks one of PP_GROUPS pair classes synchronises (0 = off)
+  TickP cur_tp;            // parameters of the tick between sim_step_begin and sim_step_end
+  bool in_tick, tick_timed;
+  hipEvent_t tick_ev0;
+  uint4* rbuf[2];          // sharded: packets sent during tick t are received into rbuf[t & 1]
 };
 
 #define HCHECK(x)                                                                        \
@@ -1961,6 +1972,9 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   h->stream = nullptr;
   h->op_cursor = 0;
   h->bound = false;
+  h->in_tick = false;
+  h->tick_timed = false;
+  h->rbuf[0] = h->rbuf[1] = nullptr;
   h->profiling = 0;
   h->prof_seq = 0;
   memset(&h->prev, 0, sizeof h->prev);
@@ -2137,70 +2151,110 @@ int sim_query(sim_handle* h, uint32_t node, uint32_t id, uint32_t flags) {
   return sim_inject(h, h ? h->tick : 0, SIM_OP_QUERY, node, id, flags);
 }
 
+// One tick = sim_step_begin (operations, push-pull batch, tick parameters), one tick-kernel launch per sender chunk
+// (sim_step_chunk; a single launch when there is one chunk or all shards are local), sim_step_end.  sim_step does all
+// of it; a sharded host that wants the exchange of chunk c in flight while chunk c + 1 computes drives the three
+// calls itself (serf_amd/shard.py).
+int sim_step_begin(sim_handle* h) {
+  if (!h) return SIM_EINVAL;
+  Dev& d = h->d;
+  if (h->in_tick || (d.sharded && !h->bound)) return SIM_ESTATE;
+  TickP& tp = h->cur_tp;
+  tickp_make(&tp, &h->cfg, h->tick);
+#ifdef TICK_ABLATE
+  tp.abl = g_ablate;
+#endif
+  for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) { tp.prot[k] = h->prev.rot[k]; tp.prho[k] = h->prev.rho[k]; }
+  tp.n_slots = (u32)h->walk.size();
+  if (d.sharded) d.xrecv = h->rbuf[(h->tick + 1) & 1];  // what was sent during tick - 1
+  while (h->op_cursor < h->ops.size() && h->ops[h->op_cursor].tick <= h->tick) {
+    OpBatch ob;
+    memset(&ob, 0, sizeof ob);
+    while (ob.n < 8 && h->op_cursor < h->ops.size() && h->ops[h->op_cursor].tick <= h->tick) {
+      const OpEnt& e = h->ops[h->op_cursor++];
+      ob.op[ob.n] = e.op; ob.node[ob.n] = e.node; ob.a[ob.n] = e.a; ob.b[ob.n] = e.b;
+      if (e.op == SIM_OP_QUERY) {  // a fresh tracker: who acked / responded starts empty
+        u32 j = e.a % SIM_QT;
+        size_t words = ((size_t)d.N + 31) / 32;
+        ob.c[ob.n] = j;
+        HCHECK(hipMemsetAsync(d.qbits + (size_t)j * 2 * words, 0, 2 * words * 4, h->stream));
+      }
+      ob.n++;
+    }
+    ops_kernel<<<1, 64, 0, h->stream>>>(d, ob, h->tick, d.N > 1 ? 1u : 0u, tp.query_base, h->q_timeout);
+  }
+  if (h->pp_step && h->tick > 0 && h->tick % h->pp_step == 0) {
+    u32 cls = (u32)((h->tick / h->pp_step) % PP_GROUPS);
+    u32 half = tp.M / 2, per_shard = half > cls ? (half - cls + PP_GROUPS - 1) / PP_GROUPS : 0;
+    u32 shards = d.sharded ? 1u : tp.V;
+    if (per_shard) pushpull_kernel<<<(per_shard * shards + 63) / 64, 64, 0, h->stream>>>(d, tp, cls, per_shard, shards);
+  }
+  h->tick_timed = h->profiling && (h->prof_seq++ % h->profiling) == 0;
+  if (h->tick_timed) {
+    HCHECK(hipEventCreate(&h->tick_ev0));
+    HCHECK(hipEventRecord(h->tick_ev0, h->stream));
+  }
+  h->in_tick = true;
+  return SIM_OK;
+}
+static int tick_launch(sim_handle* h, u32 chunk) {
+  Dev& d = h->d;
+  const TickP& tp = h->cur_tp;
+  u32 cnt = chunk == 0xFFFFFFFFu ? d.Nl : tp.V * tp.sub;
+  int grid = (int)((cnt + BLOCK - 1) / BLOCK);
+  u32 cur = (u32)(h->tick & 1);
+#define LAUNCH_TICK(SH, FF) tick_kernel<SH, FF><<<grid, BLOCK, 0, h->stream>>>(d, tp, cur, h->d_base, chunk, cnt)
+  switch (tp.feff + (d.sharded ? 4u : 0u)) {  // one instantiation per fan-out: the drain loop is fully unrolled
+    case 0: case 1: LAUNCH_TICK(false, 1); break;
+    case 2: LAUNCH_TICK(false, 2); break;
+    case 3: LAUNCH_TICK(false, 3); break;
+    case 4: LAUNCH_TICK(false, 4); break;
+    case 5: LAUNCH_TICK(true, 1); break;
+    case 6: LAUNCH_TICK(true, 2); break;
+    case 7: LAUNCH_TICK(true, 3); break;
+    default: LAUNCH_TICK(true, 4); break;
+  }
+#undef LAUNCH_TICK
+  HCHECK(hipGetLastError());
+  return SIM_OK;
+}
+int sim_step_chunk(sim_handle* h, uint32_t chunk) {
+  if (!h) return SIM_EINVAL;
+  if (!h->in_tick) return SIM_ESTATE;
+  if (!h->d.sharded || chunk >= h->cur_tp.C) return SIM_EINVAL;
+  return tick_launch(h, h->cur_tp.C == 1 ? 0xFFFFFFFFu : chunk);
+}
+int sim_step_end(sim_handle* h) {
+  if (!h) return SIM_EINVAL;
+  if (!h->in_tick) return SIM_ESTATE;
+  if (h->tick_timed) {
+    hipEvent_t ev1 = nullptr;
+    HCHECK(hipEventCreate(&ev1));
+    HCHECK(hipEventRecord(ev1, h->stream));
+    h->prof.emplace_back(h->tick_ev0, ev1);
+  }
+  h->prev = h->cur_tp;
+  h->tick++;
+  h->in_tick = false;
+  return SIM_OK;
+}
 int sim_step(sim_handle* h, uint32_t n_ticks) {
   if (!h) return SIM_EINVAL;
   Dev& d = h->d;
   if (d.sharded && !h->bound) return SIM_ESTATE;
   if (d.sharded && n_ticks > 1) return SIM_EINVAL;  // the caller has to move send -> recv between two ticks
   for (u32 it = 0; it < n_ticks; ++it) {
-    TickP tp;
-    tickp_make(&tp, &h->cfg, h->tick);
-#ifdef TICK_ABLATE
-    tp.abl = g_ablate;
-#endif
-    for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) { tp.prot[k] = h->prev.rot[k]; tp.prho[k] = h->prev.rho[k]; }
-    tp.n_slots = (u32)h->walk.size();
-    while (h->op_cursor < h->ops.size() && h->ops[h->op_cursor].tick <= h->tick) {
-      OpBatch ob;
-      memset(&ob, 0, sizeof ob);
-      while (ob.n < 8 && h->op_cursor < h->ops.size() && h->ops[h->op_cursor].tick <= h->tick) {
-        const OpEnt& e = h->ops[h->op_cursor++];
-        ob.op[ob.n] = e.op; ob.node[ob.n] = e.node; ob.a[ob.n] = e.a; ob.b[ob.n] = e.b;
-        if (e.op == SIM_OP_QUERY) {  // a fresh tracker: who acked / responded starts empty
-          u32 j = e.a % SIM_QT;
-          size_t words = ((size_t)d.N + 31) / 32;
-          ob.c[ob.n] = j;
-          HCHECK(hipMemsetAsync(d.qbits + (size_t)j * 2 * words, 0, 2 * words * 4, h->stream));
-        }
-        ob.n++;
-      }
-      ops_kernel<<<1, 64, 0, h->stream>>>(d, ob, h->tick, d.N > 1 ? 1u : 0u, tp.query_base, h->q_timeout);
+    int rc = sim_step_begin(h);
+    if (rc) return rc;
+    if (d.sharded && h->cur_tp.C > 1) {
+      for (u32 c = 0; c < h->cur_tp.C && rc == SIM_OK; ++c) rc = tick_launch(h, c);
+    } else {
+      rc = tick_launch(h, 0xFFFFFFFFu);
     }
-    if (h->pp_step && h->tick > 0 && h->tick % h->pp_step == 0) {
-      u32 cls = (u32)((h->tick / h->pp_step) % PP_GROUPS);
-      u32 half = tp.M / 2, per_shard = half > cls ? (half - cls + PP_GROUPS - 1) / PP_GROUPS : 0;
-      u32 shards = d.sharded ? 1u : tp.V;
-      if (per_shard) pushpull_kernel<<<(per_shard * shards + 63) / 64, 64, 0, h->stream>>>(d, tp, cls, per_shard, shards);
-    }
-    int grid = (int)((d.Nl + BLOCK - 1) / BLOCK);
-    u32 cur = (u32)(h->tick & 1);
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    const bool timed = h->profiling && (h->prof_seq++ % h->profiling) == 0;
-    if (timed) {
-      HCHECK(hipEventCreate(&ev0));
-      HCHECK(hipEventCreate(&ev1));
-      HCHECK(hipEventRecord(ev0, h->stream));
-    }
-#define LAUNCH_TICK(SH, FF) tick_kernel<SH, FF><<<grid, BLOCK, 0, h->stream>>>(d, tp, cur, h->d_base)
-    switch (tp.feff + (d.sharded ? 4u : 0u)) {  // one instantiation per fan-out: the drain loop is fully unrolled
-      case 0: case 1: LAUNCH_TICK(false, 1); break;
-      case 2: LAUNCH_TICK(false, 2); break;
-      case 3: LAUNCH_TICK(false, 3); break;
-      case 4: LAUNCH_TICK(false, 4); break;
-      case 5: LAUNCH_TICK(true, 1); break;
-      case 6: LAUNCH_TICK(true, 2); break;
-      case 7: LAUNCH_TICK(true, 3); break;
-      default: LAUNCH_TICK(true, 4); break;
-    }
-#undef LAUNCH_TICK
-    if (timed) {
-      HCHECK(hipEventRecord(ev1, h->stream));
-      h->prof.emplace_back(ev0, ev1);
-    }
-    h->prev = tp;
-    h->tick++;
+    int rc2 = sim_step_end(h);
+    if (rc) return rc;
+    if (rc2) return rc2;
   }
-  HCHECK(hipGetLastError());
   return SIM_OK;
 }
 int sim_sync(sim_handle* h) {
@@ -2265,7 +2319,7 @@ int sim_drain_events(sim_handle* h, sim_event* out, uint32_t cap, uint32_t* n) {
 }
 
 static const uint4* cur_inbox(const sim_handle* h) {
-  return h->d.sharded ? h->d.xrecv : h->d.inbox[h->tick & 1];
+  return h->d.sharded ? h->rbuf[(h->tick + 1) & 1] : h->d.inbox[h->tick & 1];
 }
 int sim_state_digest(sim_handle* h, uint64_t out[8]) {
   if (!h || !out) return SIM_EINVAL;
@@ -2447,7 +2501,7 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
       in += n;
     }
   }
-  uint4* inbox_dst = d.sharded ? d.xrecv : d.inbox[hd.tick & 1];
+  uint4* inbox_dst = d.sharded ? h->rbuf[(hd.tick + 1) & 1] : d.inbox[hd.tick & 1];
   if (len[2] && !inbox_dst) return SIM_ESTATE;  // sharded: bind the exchange buffers first
   {  // slot maps must be consistent with n_slots (they index the view)
     const u32* so = (const u32*)sec[6];
@@ -2585,14 +2639,25 @@ int sim_exchange_bytes(const sim_handle* h, size_t* bytes) {
   *bytes = h->d.sharded ? (size_t)h->d.f * h->d.M * sizeof(sim_packet) : 0;
   return SIM_OK;
 }
-int sim_bind_exchange(sim_handle* h, void* send, void* recv) {
-  if (!h || !h->d.sharded || !send || !recv) return SIM_EINVAL;
+int sim_bind_exchange2(sim_handle* h, void* send, void* recv0, void* recv1) {
+  if (!h || !h->d.sharded || !send || !recv0 || !recv1) return SIM_EINVAL;
   h->d.xsend = (uint4*)send;
-  h->d.xrecv = (uint4*)recv;
+  h->rbuf[0] = (uint4*)recv0;
+  h->rbuf[1] = (uint4*)recv1;
+  h->d.xrecv = h->rbuf[(h->tick + 1) & 1];
   size_t n = (size_t)h->d.f * h->d.M * sizeof(sim_packet);
   HCHECK(hipMemsetAsync(send, 0, n, h->stream));
-  HCHECK(hipMemsetAsync(recv, 0, n, h->stream));
+  HCHECK(hipMemsetAsync(recv0, 0, n, h->stream));
+  if (recv1 != recv0) HCHECK(hipMemsetAsync(recv1, 0, n, h->stream));
   h->bound = true;
+  return SIM_OK;
+}
+int sim_bind_exchange(sim_handle* h, void* send, void* recv) { return sim_bind_exchange2(h, send, recv, recv); }
+int sim_exchange_chunks(const sim_handle* h, uint32_t* chunks, size_t* bytes_per_chunk) {
+  if (!h || !chunks || !bytes_per_chunk) return SIM_EINVAL;
+  u32 C = h->cfg.chunks ? h->cfg.chunks : 1;
+  *chunks = h->d.sharded ? C : 1;
+  *bytes_per_chunk = h->d.sharded ? (size_t)h->d.f * h->d.M * sizeof(sim_packet) / C : 0;
   return SIM_OK;
 }
 

@@ -1,12 +1,19 @@
-"""Sharded runs: one process per GPU, node-id range partition, ONE all-to-all per gossip round.
+"""Sharded runs: one process per GPU, node-id range partition, the all-to-all of a gossip round overlapped with compute.
 
-Shard g owns nodes [g*M, (g+1)*M).  The tick kernel writes every outgoing packet into a send
-buffer laid out [destination shard][fan-out slot][M/V packets]; because the per-tick fan-out
-bijection assigns each block of M/V consecutive targets of a destination to exactly one source
-shard (DESIGN.md SIMSPEC §2), the exchange is a dense, equal-split
-``torch.distributed.all_to_all_single`` (RCCL over xGMI on MI355X; gloo in the CPU tests) with no
-packing, no counts and no index lists.  The reference has no collective at all (its transport is
-UDP/TCP inside memberlist); this replaces `memberlist.send`-style delivery for the simulation.
+Shard g owns nodes [g*M, (g+1)*M).  The tick kernel writes every outgoing packet into a send buffer laid out
+[sender chunk][destination shard][fan-out slot][M/V/C packets]: the fan-out map (DESIGN.md SIMSPEC §2.3) sends the
+packets of one sender chunk for one (destination, slot) to exactly one dense slab, so
+
+* the exchange is a dense, equal-split ``torch.distributed.all_to_all_single`` (RCCL over xGMI on MI355X; gloo in
+  the CPU tests) with no packing, no counts and no index lists, and
+* with ``chunks = C > 1`` a tick runs as C kernel launches, and the all-to-all of chunk c (1/C of the round's bytes)
+  is issued asynchronously as soon as its launch is enqueued: RCCL's stream waits for that launch only, so the
+  slabs of chunk c travel while chunk c + 1 computes.  Only the last chunk's exchange is exposed.  Every exchange of
+  round t has to be complete before round t + 1 reads it, and the later chunks of round t + 1 still read round t's
+  packets while the first chunks of t + 1 arrive, so the receive side is double-buffered (recv[t & 1]).
+
+The reference has no collective at all (its transport is UDP/TCP inside memberlist); this replaces
+`memberlist.send`-style delivery for the simulation.
 """
 from __future__ import annotations
 
@@ -20,24 +27,26 @@ class ShardedSim:
     """`Serf`-shaped facade over one shard; every rank issues the same API calls (the slot map
     and the op schedule are replicated, each shard applies the ops of the nodes it owns)."""
 
-    def __init__(self, lib: _ffi.SimLib, n_nodes: int, device: torch.device, group=None, **kw):
+    def __init__(self, lib: _ffi.SimLib, n_nodes: int, device: torch.device, group=None, chunks: int = 1, **kw):
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.device = device
-        kw.update(vshards=self.world, shard_rank=self.rank, shard_count=self.world)
+        kw.update(vshards=self.world, shard_rank=self.rank, shard_count=self.world, chunks=chunks if chunks > 1 else 0)
         self.sim = _ffi.Sim(lib, _ffi.make_config(n_nodes, **kw))
         nbytes = self.sim.exchange_bytes()
+        self.chunks, self.chunk_bytes = self.sim.exchange_chunks()
         # plain byte tensors: torch only provides device memory + the collective
         self.send = torch.zeros(nbytes, dtype=torch.uint8, device=device)
-        self.recv = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        self.recv = [torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(2 if self.chunks > 1 else 1)]
         if device.type == "cuda":
             self.sim.set_stream(torch.cuda.current_stream(device).cuda_stream)
-        self.sim.bind_exchange(self.send.data_ptr(), self.recv.data_ptr())
+        self.sim.bind_exchange2(self.send.data_ptr(), self.recv[0].data_ptr(), self.recv[-1].data_ptr())
         self.n = n_nodes
         self.m = n_nodes // self.world
         self.lo = self.rank * self.m
-        self._xt = None  # exchange timing: list of (start, end) event pairs while enabled
+        self._pending = []  # async all-to-alls of the round in flight
+        self._xt = None     # exchange timing: list of (start, end) event pairs while enabled
 
     def owns(self, node):
         return self.lo <= node < self.lo + self.m
@@ -59,17 +68,38 @@ class ShardedSim:
         self.sim.join(node, peer)
 
     # the hot loop -----------------------------------------------------------------------------
+    def _drain(self):
+        """Every exchange of the previous round has landed (and the compute stream knows it)."""
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
     def step(self, n_ticks=1):
         for _ in range(n_ticks):
-            self.sim.step(1)  # reads self.recv (packets of the previous round), fills self.send
-            if self._xt is None:
-                dist.all_to_all_single(self.recv, self.send, group=self.group)
-            else:
-                e0, e1 = self._event(), self._event()
-                e0.record()
-                dist.all_to_all_single(self.recv, self.send, group=self.group)
-                e1.record()
-                self._xt.append((e0, e1))
+            self._drain()
+            if self.chunks == 1:
+                self.sim.step(1)  # reads recv (packets of the previous round), fills send
+                self._exchange(self.recv[0], self.send, False)
+                continue
+            rbuf = self.recv[self.sim.tick & 1]  # packets sent during tick t land in recv[t & 1]
+            self.sim.step_begin()
+            for c in range(self.chunks):
+                self.sim.step_chunk(c)
+                lo = c * self.chunk_bytes
+                self._exchange(rbuf[lo:lo + self.chunk_bytes], self.send[lo:lo + self.chunk_bytes], True)
+            self.sim.step_end()
+
+    def _exchange(self, recv, send, asynchronous):
+        if self._xt is not None:  # measurement mode: bracket the collective with events, no overlap
+            e0, e1 = self._event(), self._event()
+            e0.record()
+            dist.all_to_all_single(recv, send, group=self.group)
+            e1.record()
+            self._xt.append((e0, e1))
+        elif asynchronous:
+            self._pending.append(dist.all_to_all_single(recv, send, group=self.group, async_op=True))
+        else:
+            dist.all_to_all_single(recv, send, group=self.group)
 
     # measurement: time of the collective alone (events on the stream it is enqueued on) -------------
     def _event(self):
@@ -86,8 +116,10 @@ class ShardedSim:
         return _T()
 
     def time_exchange(self, enable):
-        """enable=True: start bracketing every all-to-all with events; enable=False: stop and return the
-        summed milliseconds since it was enabled."""
+        """enable=True: start bracketing every all-to-all with events (the exchanges then run synchronously, one
+        after the other: this measures the collective, not the overlap); enable=False: stop and return the summed
+        milliseconds since it was enabled."""
+        self._drain()
         if enable:
             self._xt = []
             return 0.0
@@ -97,21 +129,25 @@ class ShardedSim:
         return float(sum(a.elapsed_time(b) for a, b in pairs))
 
     def sync(self):
+        self._drain()
         self.sim.sync()
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
 
     def convergence(self, kind, key, ltime):
+        self._drain()
         seen, up = self.sim.convergence(kind, key, ltime)
         t = torch.tensor([seen, up], dtype=torch.int64, device=self.device)
         dist.all_reduce(t, group=self.group)
         return int(t[0]), int(t[1])
 
     def query_status(self, query_id):
+        self._drain()
         acks, resp, is_open = self.sim.query_status(query_id)   # this shard's responders
         t = torch.tensor([acks, resp], dtype=torch.int64, device=self.device)
         dist.all_reduce(t, group=self.group)
         return int(t[0]), int(t[1]), is_open
 
     def close(self):
+        self._drain()
         self.sim.close()

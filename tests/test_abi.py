@@ -18,7 +18,7 @@ HEADER = os.path.join(ROOT, "include", "serf_sim.h")
 def declared_symbols():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|uint32_t|const char\s*\*)\s*(sim_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|uint32_t|const char\s*\*)\s*(sim_[a-z_0-9]+)\s*\(", src)))
 
 
 def test_header_declares_what_the_binding_binds():

@@ -191,39 +191,48 @@ def test_config3_1m_properties(hiplib):
     assert g.dump(_ffi.ARR_QUEUE)["meta"].min() == 0xFFFFFFFF
 
 
-@pytest.mark.parametrize("swim", [0, 4])
-def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim):
-    # BASELINE configs[3] shape (G shards by node-id range, one all-to-all per round), scaled down and
-    # run as 4 handles on ONE GPU: the exchange of serf_amd/shard.py is done with device-to-device
-    # copies (chunk g of shard s's send buffer -> chunk s of shard g's receive buffer), which is what
-    # all_to_all_single does over RCCL.  Every shard is compared with the oracle's matching slice.
+@pytest.mark.parametrize("swim,chunks", [(0, 1), (4, 1), (4, 2), (0, 4)])
+def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim, chunks):
+    # BASELINE configs[3] shape (G shards by node-id range, the round's all-to-all), scaled down and run as 4 handles
+    # on ONE GPU: the exchange of serf_amd/shard.py is done with device-to-device copies (for every sender chunk c:
+    # slab g of shard s's send region c -> slab s of shard g's receive region c), which is what the per-chunk
+    # all_to_all_single does over RCCL.  chunks > 1 drives the tick as sim_step_begin / sim_step_chunk / sim_step_end
+    # with the double-buffered receive side.  Every shard is compared with the oracle's matching slice.
     import torch
 
     n, V, ticks = 2048, 4, 50
     m = n // V
     kw = dict(fanout=4, view_slots=96, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=0.02,
-              push_pull_interval=3 if swim else 0)
+              push_pull_interval=3 if swim else 0, chunks=chunks if chunks > 1 else 0)
     ref = _ffi.Sim(oracle, _ffi.make_config(n, vshards=V, **kw))
     shards, send, recv = [], [], []
     for g in range(V):
         s = _ffi.Sim(hiplib, _ffi.make_config(n, vshards=V, shard_rank=g, shard_count=V, **kw))
         nb = s.exchange_bytes()
         send.append(torch.zeros(nb, dtype=torch.uint8, device="cuda"))
-        recv.append(torch.zeros(nb, dtype=torch.uint8, device="cuda"))
-        s.bind_exchange(send[-1].data_ptr(), recv[-1].data_ptr())
+        recv.append([torch.zeros(nb, dtype=torch.uint8, device="cuda") for _ in range(2)])
+        s.bind_exchange2(send[-1].data_ptr(), recv[-1][0].data_ptr(), recv[-1][1].data_ptr())
+        assert s.exchange_chunks() == (chunks, nb // chunks)
         shards.append(s)
     ops = sc.schedule(n, ticks // 2, rate=0.8, seed=5, max_member_subjects=60)
     for s in shards + [ref]:
         sc.apply_schedule(s, ops)
-    chunk = send[0].numel() // V
+    region = send[0].numel() // chunks
+    slab = region // V
     for t in range(ticks):
         for s in shards:
-            s.step(1)
+            s.step_begin()
+        for c in range(chunks):
+            for s in shards:
+                s.step_chunk(c)
+            for s in shards:
+                s.sync()
+            for g in range(V):          # the all-to-all of chunk c, into the receive buffer of tick t
+                for src in range(V):
+                    recv[g][t & 1][c * region + src * slab:c * region + (src + 1) * slab].copy_(
+                        send[src][c * region + g * slab:c * region + (g + 1) * slab])
         for s in shards:
-            s.sync()
-        for g in range(V):          # the all-to-all
-            for src in range(V):
-                recv[g][src * chunk:(src + 1) * chunk].copy_(send[src][g * chunk:(g + 1) * chunk])
+            s.step_end()
         torch.cuda.synchronize()
         ref.step(1)
         if t % 7 == 0 or t == ticks - 1:

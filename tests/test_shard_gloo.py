@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, n, ticks, swim, q):
+def _worker(rank, world, port, n, ticks, swim, chunks, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -28,8 +28,8 @@ def _worker(rank, world, port, n, ticks, swim, q):
         lib = load_oracle()
         kw = dict(fanout=3, view_slots=64, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=0.02,
                   push_pull_interval=4 if swim else 0)
-        sh = ShardedSim(lib, n, torch.device("cpu"), **kw)
-        ref = _ffi.Sim(lib, _ffi.make_config(n, vshards=world, **kw))  # all shards in one process
+        sh = ShardedSim(lib, n, torch.device("cpu"), chunks=chunks, **kw)
+        ref = _ffi.Sim(lib, _ffi.make_config(n, vshards=world, chunks=chunks if chunks > 1 else 0, **kw))  # all shards in one process
         ops = sc.schedule(n, ticks // 2, rate=0.7, seed=17, max_member_subjects=40)
         for t, op, node, a, b in ops:
             sh.inject(t, op, node, a, b)
@@ -60,17 +60,19 @@ def _worker(rank, world, port, n, ticks, swim, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("swim", [0, 4])
-def test_two_shards_gloo_match_single_process(swim):
+@pytest.mark.parametrize("world,chunks,swim", [(2, 1, 0), (2, 1, 4), (2, 2, 4), (4, 2, 4), (4, 4, 0)])
+def test_shards_gloo_match_single_process(world, chunks, swim):
+    # chunks > 1: the tick runs as `chunks` launches, each followed by the asynchronous all-to-all of its slabs
+    # (double-buffered receive side) — the overlapped path of serf_amd/shard.py
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 300) + swim
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 512, 60, swim, q)) for r in range(2)]
+    port = 29600 + (os.getpid() % 300) + swim + 7 * world + chunks
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 1024, 60, swim, chunks, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(180)
+        p.join(240)
     res = sorted(q.get(timeout=5) for _ in procs)
-    assert res == [(0, "ok"), (1, "ok")], res
+    assert res == [(r, "ok") for r in range(world)], res
