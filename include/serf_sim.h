@@ -218,6 +218,10 @@ typedef struct sim_config {
   uint32_t chunks;            /* C sender chunks per shard for the chunk-wise exchange (0 or 1: one); must divide
                                * (N / V) / V.  Chunk c = the nodes whose offset inside their N/V/V-node block lies in
                                * [c, c+1) * (N/V/V/C): their packets for one (destination, slot) form ONE dense slab     */
+  uint32_t recycle_interval;  /* view-slot recycling pass every this many ticks (0 = never): a subject whose entry
+                               * is the same at every running node and that nothing in flight mentions gives its
+                               * slot back (SIMSPEC §2.6; reference analogue: erase_node! base.rs:499-518)        */
+  uint32_t reserved1;         /* keeps `seed` 8-byte aligned                                    */
   uint32_t flags;             /* SIM_CF_*                                                       */
   uint64_t seed;              /* master seed; default 0x5EEDC0DE5E4F0001                        */
 } sim_config;
@@ -261,7 +265,18 @@ typedef struct sim_cluster_stats {
   uint64_t inbox_records; /* non-empty records in the packets in flight                         */
   uint64_t failed, left;  /* sum of n_failed / n_left                                           */
   uint64_t max_queue;     /* deepest queue of any node                                          */
+  uint64_t ops_dropped;   /* scheduled operations skipped because no view slot was free (model bound; handle-wide) */
+  uint64_t slots_in_use, slots_recycled; /* view slots handed out now / given back so far (handle-wide)  */
 } sim_cluster_stats;
+
+/* One candidate of a view-slot recycling pass (sharded runs: every shard scans its own nodes, the host combines). */
+typedef struct sim_recycle_cand {
+  uint32_t subject, slot;
+  uint32_t flags;          /* 1: not recyclable on this shard; 2: `ref` is valid (the shard has a running node) */
+  uint32_t pad;
+  sim_view ref;            /* the entry the shard's running nodes agree on (conf zeroed)                        */
+} sim_recycle_cand;
+#define SIM_RECYCLE_BATCH 64u
 
 typedef struct sim_handle sim_handle;
 
@@ -348,6 +363,14 @@ int sim_bind_exchange(sim_handle* h, void* send_dev, void* recv_dev);
  * sim_step_end  — and every exchange of tick t must have completed before sim_step_chunk of tick t + 1. */
 int sim_bind_exchange2(sim_handle* h, void* send_dev, void* recv0_dev, void* recv1_dev);
 int sim_exchange_chunks(const sim_handle* h, uint32_t* chunks, size_t* bytes_per_chunk);
+/* View-slot recycling in sharded runs.  A single-process handle runs the pass inside sim_step_begin.  With one shard
+ * per process the verdict needs every shard: when sim_recycle_due() the host calls sim_recycle_scan on every shard
+ * (same candidates everywhere: the slot bookkeeping is replicated), keeps the candidates for which NO shard set flag 1
+ * and all shards that set flag 2 report the same `ref`, and hands that list to sim_recycle_apply on every shard —
+ * before sim_step_begin, which otherwise refuses with SIM_ESTATE. */
+int sim_recycle_due(const sim_handle* h);
+int sim_recycle_scan(sim_handle* h, sim_recycle_cand* out, uint32_t cap, uint32_t* n);
+int sim_recycle_apply(sim_handle* h, const sim_recycle_cand* agreed, uint32_t n);
 int sim_step_begin(sim_handle* h);
 int sim_step_chunk(sim_handle* h, uint32_t chunk);
 int sim_step_end(sim_handle* h);

@@ -258,6 +258,11 @@ struct sim_handle {
   uint32_t* slot_of;    /* [N] global subject -> slot */
   uint32_t* subject_of; /* [A] */
   uint32_t n_slots;
+  uint32_t* alloc_tick; /* [A] tick at which the slot was handed out (recycling takes the oldest first) */
+  uint32_t n_alloc;     /* slots in use */
+  uint64_t ops_dropped; /* operations skipped because their subject found no free view slot (model bound) */
+  uint64_t slots_recycled;
+  uint32_t recycle_at;  /* the tick whose recycling pass has already run (sharded hosts run it before step_begin) */
   uint32_t* walk;       /* [n_walk] allocated slots in ascending SUBJECT order: the order every per-node walk over
                          * the view uses (Reaper, push-pull merge), so that it does not depend on how slots were
                          * handed out (an unbounded run with a dense view walks subjects in id order, too) */
@@ -1193,12 +1198,21 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
   }
 }
 
+static int recycle_due(const osim* s);
+static void recycle_local(osim* s);
+static uint32_t op_subject(const osim* s, uint32_t op, uint32_t node, uint32_t a);
+static int ensure_slot(osim* s, uint32_t subject);
+static const sim_packet* cur_inbox(const osim* s);
 static void step_begin(osim* s) {
   tickp* p = &s->cur;
   tickp_make(p, &s->cfg, s->tick);
   if (s->cfg.shard_count > 1) s->xrecv = s->rbuf[(s->tick + 1) & 1];
+  if (recycle_due(s) && s->cfg.shard_count <= 1) recycle_local(s);
   while (s->op_cursor < s->n_ops && s->ops[s->op_cursor].tick <= s->tick) {
-    apply_op(s, &s->ops[s->op_cursor]);
+    const sim_opent* op = &s->ops[s->op_cursor];
+    uint32_t x = op_subject(s, op->op, op->node, op->a);
+    if (x != NOSLOT && ensure_slot(s, x) != SIM_OK) s->ops_dropped++; /* no free view slot: the operation does not happen */
+    else apply_op(s, op);
     s->op_cursor++;
   }
   pp_round(s, p);
@@ -1301,7 +1315,7 @@ int API(destroy)(osim* s) {
   if (!s) return SIM_EINVAL;
   free(s->rows); free(s->queue); free(s->inbox[0]); free(s->inbox[1]);
   if (s->own_x) { free(s->xsend); free(s->xrecv); }
-  free(s->view); free(s->ering); free(s->qring); free(s->slot_of); free(s->subject_of); free(s->walk); free(s->rtgt); free(s->rcsr); free(s->rsrc);
+  free(s->view); free(s->ering); free(s->qring); free(s->slot_of); free(s->subject_of); free(s->walk); free(s->alloc_tick); free(s->rtgt); free(s->rcsr); free(s->rsrc);
   free(s->base); free(s->ops); free(s->events); free(s->upmap); free(s->qbits); free(s);
   return SIM_OK;
 }
@@ -1338,6 +1352,8 @@ int API(create)(const sim_config* cfg, osim** out) {
   s->slot_of = (uint32_t*)malloc((size_t)s->N * sizeof(uint32_t));
   s->subject_of = (uint32_t*)malloc((size_t)s->A * sizeof(uint32_t));
   s->walk = (uint32_t*)malloc((size_t)s->A * sizeof(uint32_t));
+  s->alloc_tick = (uint32_t*)calloc((size_t)s->A, sizeof(uint32_t));
+  s->recycle_at = 0xFFFFFFFFu;
   s->base = (sim_view*)calloc(s->N, sizeof(sim_view));
   s->upmap = (uint32_t*)malloc(((size_t)s->N + 31) / 32 * sizeof(uint32_t));
   if (s->upmap) memset(s->upmap, 0xFF, ((size_t)s->N + 31) / 32 * sizeof(uint32_t));
@@ -1346,7 +1362,7 @@ int API(create)(const sim_config* cfg, osim** out) {
   s->q_timeout = 16u * digits10(s->N); /* query.rs:421-427 with query_timeout_mult = 16 (options.rs:518) */
   pp_params(cfg, &s->pp_step, &s->pp_groups);
   if (!s->qbits || !s->upmap || !s->rows || !s->queue || !s->view || !s->ering || !s->qring || !s->slot_of ||
-      !s->subject_of || !s->walk || !s->base || (cfg->shard_count > 1 ? (!s->xsend || !s->xrecv)
+      !s->subject_of || !s->walk || !s->alloc_tick || !s->base || (cfg->shard_count > 1 ? (!s->xsend || !s->xrecv)
                                                           : (!s->inbox[0] || !s->inbox[1]))) {
     API(destroy)(s);
     return SIM_ENOMEM;
@@ -1367,7 +1383,7 @@ int API(create)(const sim_config* cfg, osim** out) {
     if (joined) { s->base[i].ltime = 1; s->base[i].bits = vb_make(1, SIM_STATUS_ALIVE, 0, 0, 0, 0); }
   }
   if (s->dense) {
-    s->n_slots = s->n_walk = s->N;
+    s->n_slots = s->n_walk = s->n_alloc = s->N;
     for (uint32_t a = 0; a < s->A; ++a) {
       s->subject_of[a] = s->walk[a] = a;
       for (size_t l = 0; l < Nl; ++l) s->view[(size_t)a * Nl + l] = s->base[a];
@@ -1411,13 +1427,124 @@ static void walk_rebuild(osim* s) {
 static int ensure_slot(osim* s, uint32_t subject) {
   if (subject >= s->N) return SIM_EINVAL;
   if (s->slot_of[subject] != NOSLOT) return SIM_OK;
-  if (s->n_slots >= s->A) return SIM_ENOSLOT;
-  uint32_t a = s->n_slots++;
+  uint32_t a = 0;
+  while (a < s->A && s->subject_of[a] != NOSLOT) ++a; /* the lowest free slot */
+  if (a == s->A) return SIM_ENOSLOT;
+  if (a >= s->n_slots) s->n_slots = a + 1;
+  s->n_alloc++;
   s->slot_of[subject] = a;
   s->subject_of[a] = subject;
+  s->alloc_tick[a] = (uint32_t)s->tick;
   for (size_t l = 0; l < s->Nl; ++l) s->view[(size_t)a * s->Nl + l] = s->base[subject];
   walk_insert(s, a);
   return SIM_OK;
+}
+/* the subject an operation needs a view slot for (NOSLOT: none) — SIMSPEC §2.6 */
+static uint32_t op_subject(const osim* s, uint32_t op, uint32_t node, uint32_t a) {
+  switch (op) {
+    case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: return node;
+    case SIM_OP_FORCE_LEAVE: return a;
+    case SIM_OP_CRASH: case SIM_OP_REVIVE: return s->swim ? node : NOSLOT;
+    default: return NOSLOT;
+  }
+}
+
+/* ---- view-slot recycling (SIMSPEC §2.6): a subject whose entry has settled gives its slot back -------------------
+ * Reference analogue: a member that is forgotten — erase_node! base.rs:499-518, the Reaper base.rs:521-553; here the
+ * per-observer entries of a subject collapse back into ONE baseline entry once every running observer holds the same
+ * one.  Every `recycle_interval` ticks, before the tick's operations, up to SIM_RECYCLE_BATCH of the slots that have
+ * been in use longest (at least one interval) are examined; slot a (subject x) is freed iff, over the running nodes:
+ * all hold the same entry head E (stamp aside), E is settled — forgotten, or known and Alive for serf and memberlist
+ * with nothing buffered —, no queue and no packet in flight
+ * carries a member record about x, and no suspicion timer names slot a.  Then baseline[x] := E and the slot is free;
+ * processes that are down adopt E when they come back. */
+typedef sim_recycle_cand rc_cand;
+static int recycle_due(const osim* s) {
+  uint32_t R = s->cfg.recycle_interval;
+  return R && !s->dense && s->tick > 0 && s->tick % R == 0 && s->recycle_at != (uint32_t)s->tick;
+}
+static uint32_t recycle_candidates(const osim* s, rc_cand* out) {
+  uint32_t n = 0, R = s->cfg.recycle_interval, now = (uint32_t)s->tick;
+  for (uint32_t a = 0; a < s->n_slots; ++a) {
+    if (s->subject_of[a] == NOSLOT || s->alloc_tick[a] + R > now) continue;
+    /* insertion into the batch ordered by (alloc_tick, slot); a ascends, so ties keep slot order */
+    uint32_t pos = n < SIM_RECYCLE_BATCH ? n : SIM_RECYCLE_BATCH;
+    while (pos > 0 && s->alloc_tick[out[pos - 1].slot] > s->alloc_tick[a]) --pos;
+    if (pos >= SIM_RECYCLE_BATCH) continue;
+    uint32_t last = n < SIM_RECYCLE_BATCH ? n : SIM_RECYCLE_BATCH - 1;
+    for (uint32_t i = last; i > pos; --i) out[i] = out[i - 1];
+    memset(&out[pos], 0, sizeof out[pos]);
+    out[pos].slot = a;
+    out[pos].subject = s->subject_of[a];
+    if (n < SIM_RECYCLE_BATCH) ++n;
+  }
+  return n;
+}
+static void recycle_scan(osim* s, rc_cand* c, uint32_t n) {
+  uint8_t* refd = (uint8_t*)calloc(s->N, 1); /* subjects some running node still has a record / timer about */
+  const sim_packet* in = cur_inbox(s);
+  uint32_t l0 = NOSLOT;
+  for (uint32_t l = 0; l < s->Nl; ++l) {
+    const sim_row* row = &s->rows[l];
+    if (!(row->flags & SIM_RF_UP)) continue;
+    if (l0 == NOSLOT) l0 = l;
+    const sim_record* q = &s->queue[(size_t)l * SIM_Q];
+    for (uint32_t i = 0; i < SIM_Q; ++i) {
+      uint32_t kind = SIM_META_KIND(q[i].meta);
+      if (q[i].meta != SIM_META_EMPTY && (kind == SIM_K_JOIN || kind == SIM_K_LEAVE || kind >= SIM_K_ALIVE) && q[i].key < s->N) refd[q[i].key] = 1;
+    }
+    for (uint32_t j = 0; j < SIM_S; ++j)
+      if (row->susp[j] && s->subject_of[row->susp[j] - 1] != NOSLOT) refd[s->subject_of[row->susp[j] - 1]] = 1;
+  }
+  if (in)
+    for (size_t i = 0; i < (size_t)s->f * s->Nl; ++i)
+      for (uint32_t p = 0; p < SIM_P; ++p) {
+        uint32_t kind = SIM_META_KIND(in[i].rec[p].meta);
+        if ((kind == SIM_K_JOIN || kind == SIM_K_LEAVE || kind >= SIM_K_ALIVE) && in[i].rec[p].key < s->N) refd[in[i].rec[p].key] = 1;
+      }
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t a = c[i].slot;
+    c[i].flags = refd[c[i].subject] ? 1u : 0u;
+    if (l0 == NOSLOT) continue;
+    sim_view ref = s->view[(size_t)a * s->Nl + l0];
+    memset(ref.conf, 0, sizeof ref.conf);
+    ref.bits &= 0x7FFu; /* the stamp of a settled entry (when a long-refuted suspicion started) is dead data */
+    c[i].ref = ref;
+    c[i].flags |= 2u;
+    /* settled = forgotten altogether, or known + Alive for serf and for memberlist, nothing buffered or pending */
+    int settled = (ref.bits == 0 && ref.ltime == 0 && ref.inc == 0) ||
+                  ((ref.bits & SIM_VB_KNOWN) && SIM_VB_STATUS(ref.bits) == SIM_STATUS_ALIVE && SIM_VB_SWIM(ref.bits) == SIM_SWIM_ALIVE &&
+                   !SIM_VB_INTENT(ref.bits) && !SIM_VB_NCONF(ref.bits));
+    if (!settled) c[i].flags |= 1u;
+    for (uint32_t l = l0; l < s->Nl && !(c[i].flags & 1u); ++l) {
+      if (!(s->rows[l].flags & SIM_RF_UP)) continue;
+      const sim_view* e = &s->view[(size_t)a * s->Nl + l];
+      if (e->ltime != ref.ltime || e->inc != ref.inc || (e->bits & 0x7FFu) != ref.bits) c[i].flags |= 1u;
+    }
+  }
+  free(refd);
+}
+static void recycle_apply(osim* s, const rc_cand* c, uint32_t n) {
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t x = c[i].subject, a = s->slot_of[x];
+    if (a == NOSLOT) continue;
+    s->base[x] = c[i].ref;
+    s->slot_of[x] = NOSLOT;
+    s->subject_of[a] = NOSLOT;
+    s->n_alloc--;
+    s->slots_recycled++;
+  }
+  while (s->n_slots > 0 && s->subject_of[s->n_slots - 1] == NOSLOT) s->n_slots--;
+  walk_rebuild(s);
+}
+static void recycle_local(osim* s) { /* every shard is in this process: decide here */
+  rc_cand c[SIM_RECYCLE_BATCH];
+  uint32_t n = recycle_candidates(s, c), m = 0;
+  recycle_scan(s, c, n);
+  for (uint32_t i = 0; i < n; ++i)
+    if ((c[i].flags & 3u) == 2u) c[m++] = c[i];
+  recycle_apply(s, c, m);
+  s->recycle_at = (uint32_t)s->tick;
 }
 
 int API(inject)(osim* s, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, uint32_t b) {
@@ -1427,11 +1554,13 @@ int API(inject)(osim* s, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, 
   switch (op) {
     case SIM_OP_USER_EVENT: if (!a) return SIM_EINVAL; if ((b & 0x7FFFFFFFu) > 9 * 1024) return SIM_ETOOBIG; break; /* bit 31: cc */
     case SIM_OP_QUERY: if (!a) return SIM_EINVAL; break;
-    case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: rc = ensure_slot(s, node); break;
-    case SIM_OP_FORCE_LEAVE: rc = ensure_slot(s, a); break;
-    case SIM_OP_CRASH: case SIM_OP_REVIVE: if (s->swim) rc = ensure_slot(s, node); break;
+    case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: case SIM_OP_FORCE_LEAVE: case SIM_OP_CRASH: case SIM_OP_REVIVE: break;
     default: return SIM_EINVAL;
   }
+  if (op == SIM_OP_FORCE_LEAVE && a >= s->N) return SIM_EINVAL;
+  /* an operation that executes now gets its view slot now (and SIM_ENOSLOT if there is none); one scheduled for a
+   * later tick gets it when it executes — and is dropped and counted if none is free then (SIMSPEC §2.6) */
+  if (tick <= s->tick && op_subject(s, op, node, a) != NOSLOT) rc = ensure_slot(s, op_subject(s, op, node, a));
   if (rc) return rc;
   if (s->n_ops == s->cap_ops) {
     s->cap_ops = s->cap_ops ? s->cap_ops * 2 : 64;
@@ -1616,19 +1745,20 @@ typedef struct snap_header {
   sim_config cfg;
   uint64_t tick;
   uint32_t n_slots, n_pending_ops;
-  uint32_t prev_rot[SIM_MAX_FANOUT];
+  uint64_t ops_dropped, slots_recycled;
 } snap_header;
 #define SNAP_MAGIC 0x53465253u /* "SRFS" */
-#define SNAP_SECTIONS 13
+#define SNAP_SECTIONS 14
 static void snap_sections(osim* s, const void* ptr[SNAP_SECTIONS], size_t len[SNAP_SECTIONS]) {
   size_t nup = ((size_t)s->N + 31) / 32;
   const void* p[SNAP_SECTIONS] = {s->rows, s->queue, cur_inbox(s), s->view, s->ering, s->qring, s->slot_of, s->subject_of,
-                                  s->base, s->upmap, s->qtab, s->qbits, s->ops + s->op_cursor};
+                                  s->base, s->upmap, s->qtab, s->qbits, s->ops + s->op_cursor, s->alloc_tick};
   size_t n[SNAP_SECTIONS] = {(size_t)s->Nl * sizeof(sim_row), (size_t)s->Nl * SIM_Q * sizeof(sim_record),
                              (size_t)s->f * s->Nl * sizeof(sim_packet), (size_t)s->A * s->Nl * sizeof(sim_view),
                              (size_t)s->Bev * s->Nl * sizeof(sim_bucket), (size_t)s->Bq * s->Nl * sizeof(sim_bucket),
                              (size_t)s->N * 4, (size_t)s->A * 4, (size_t)s->N * sizeof(sim_view), nup * 4,
-                             sizeof s->qtab, (size_t)SIM_QT * 2 * nup * 4, (s->n_ops - s->op_cursor) * sizeof(sim_opent)};
+                             sizeof s->qtab, (size_t)SIM_QT * 2 * nup * 4, (s->n_ops - s->op_cursor) * sizeof(sim_opent),
+                             (size_t)s->A * 4};
   memcpy(ptr, p, sizeof p);
   memcpy(len, n, sizeof n);
 }
@@ -1645,7 +1775,7 @@ int API(snapshot)(osim* s, void* buf, size_t cap, size_t* bytes) {
   memset(&h, 0, sizeof h);
   h.magic = SNAP_MAGIC; h.abi = SIM_ABI_VERSION; h.cfg = s->cfg; h.tick = s->tick; h.n_slots = s->n_slots;
   h.n_pending_ops = (uint32_t)(s->n_ops - s->op_cursor);
-  for (uint32_t k = 0; k < SIM_MAX_FANOUT; ++k) h.prev_rot[k] = s->prev.rot[k];
+  h.ops_dropped = s->ops_dropped; h.slots_recycled = s->slots_recycled;
   uint8_t* o = (uint8_t*)buf;
   memcpy(o, &h, sizeof h); o += sizeof h;
   for (int i = 0; i < SNAP_SECTIONS; ++i) {
@@ -1664,6 +1794,7 @@ int API(restore)(osim* s, const void* buf, size_t bytes) {
   if (h.magic != SNAP_MAGIC || h.abi != SIM_ABI_VERSION || memcmp(&h.cfg, &s->cfg, sizeof(sim_config))) return SIM_EINVAL;
   s->tick = h.tick;
   s->n_slots = h.n_slots;
+  s->ops_dropped = h.ops_dropped; s->slots_recycled = h.slots_recycled;
   /* the pending schedule first: it sizes the last section */
   s->cap_ops = h.n_pending_ops ? h.n_pending_ops : 1;
   s->ops = (sim_opent*)realloc(s->ops, s->cap_ops * sizeof(sim_opent));
@@ -1686,6 +1817,8 @@ int API(restore)(osim* s, const void* buf, size_t bytes) {
   s->n_watched = 0;
   for (uint32_t l = 0; l < s->Nl; ++l) s->n_watched += (s->rows[l].flags & SIM_RF_WATCHED) != 0;
   walk_rebuild(s);
+  s->n_alloc = s->n_walk;
+  s->recycle_at = 0xFFFFFFFFu;
   return SIM_OK;
 }
 
@@ -1760,6 +1893,7 @@ int API(cluster_stats_get)(osim* s, sim_cluster_stats* o) {
   if (in)
     for (size_t i = 0; i < (size_t)s->f * s->Nl; ++i)
       for (uint32_t p = 0; p < SIM_P; ++p) o->inbox_records += SIM_META_KIND(in[i].rec[p].meta) != SIM_K_EMPTY;
+  o->ops_dropped = s->ops_dropped; o->slots_in_use = s->n_alloc; o->slots_recycled = s->slots_recycled;
   return SIM_OK;
 }
 int API(exchange_bytes)(const osim* s, size_t* bytes) {
@@ -1787,9 +1921,25 @@ int API(exchange_chunks)(const osim* s, uint32_t* chunks, size_t* bytes_per_chun
   *bytes_per_chunk = s->cfg.shard_count > 1 ? (size_t)s->f * s->M * sizeof(sim_packet) / C : 0;
   return SIM_OK;
 }
+int API(recycle_due)(const osim* s) { return s ? recycle_due(s) : SIM_EINVAL; }
+int API(recycle_scan)(osim* s, sim_recycle_cand* out, uint32_t cap, uint32_t* n) {
+  if (!s || !out || !n || cap < SIM_RECYCLE_BATCH) return SIM_EINVAL;
+  if (s->in_tick) return SIM_ESTATE;
+  *n = recycle_candidates(s, out);
+  recycle_scan(s, out, *n);
+  return SIM_OK;
+}
+int API(recycle_apply)(osim* s, const sim_recycle_cand* agreed, uint32_t n) {
+  if (!s || (n && !agreed)) return SIM_EINVAL;
+  if (s->in_tick) return SIM_ESTATE;
+  recycle_apply(s, agreed, n);
+  s->recycle_at = (uint32_t)s->tick;
+  return SIM_OK;
+}
 int API(step_begin)(osim* s) {
   if (!s) return SIM_EINVAL;
   if (s->in_tick) return SIM_ESTATE;
+  if (s->cfg.shard_count > 1 && recycle_due(s)) return SIM_ESTATE; /* the host runs the pass first (it needs every shard) */
   step_begin(s);
   return SIM_OK;
 }

@@ -45,7 +45,7 @@ class Config(C.Structure):
         "event_ring", "query_ring", "retransmit_mult", "probe_interval", "suspicion_mult",
         "suspicion_max_mult", "indirect_checks", "loss_u32", "intent_timeout", "leave_delay",
         "reap_interval", "reconnect_timeout", "tombstone_timeout", "queue_check_interval", "max_queue_depth",
-        "min_queue_depth", "push_pull_interval", "chunks", "flags")] + [("seed", C.c_uint64)]
+        "min_queue_depth", "push_pull_interval", "chunks", "recycle_interval", "reserved1", "flags")] + [("seed", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -60,7 +60,16 @@ class Stats(C.Structure):
 
 class ClusterStats(C.Structure):
     _fields_ = [("up", C.c_uint64), ("queued", C.c_uint64 * 4), ("overflow", C.c_uint64),
-                ("inbox_records", C.c_uint64), ("failed", C.c_uint64), ("left", C.c_uint64), ("max_queue", C.c_uint64)]
+                ("inbox_records", C.c_uint64), ("failed", C.c_uint64), ("left", C.c_uint64), ("max_queue", C.c_uint64),
+                ("ops_dropped", C.c_uint64), ("slots_in_use", C.c_uint64), ("slots_recycled", C.c_uint64)]
+
+
+class RecycleCand(C.Structure):
+    _fields_ = [("subject", C.c_uint32), ("slot", C.c_uint32), ("flags", C.c_uint32), ("pad", C.c_uint32),
+                ("ltime", C.c_uint64), ("inc", C.c_uint32), ("bits", C.c_uint32), ("conf", C.c_uint32 * 4)]
+
+
+RECYCLE_BATCH = 64
 
 
 class Event(C.Structure):
@@ -85,6 +94,7 @@ ABI_SYMBOLS = ("create", "destroy", "set_stream", "join", "leave", "force_leave"
                "drain_events", "state_digest", "dump_state", "convergence", "exchange_bytes",
                "bind_exchange", "snapshot", "restore", "query_status", "profile", "profile_read", "profile_read_stats", "cluster_stats_get",
                "bind_exchange2", "exchange_chunks", "step_begin", "step_chunk", "step_end",
+               "recycle_due", "recycle_scan", "recycle_apply",
                "abi_version", "backend_name")
 
 
@@ -92,7 +102,7 @@ def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, vi
                 event_ring=512, query_ring=512, retransmit_mult=4, probe_interval=0,
                 suspicion_mult=4, suspicion_max_mult=6, indirect_checks=3, loss=0.0,
                 intent_timeout=0, leave_delay=30, reap_interval=0, reconnect_timeout=432000, tombstone_timeout=432000,
-                queue_check_interval=0, max_queue_depth=4096, min_queue_depth=0, push_pull_interval=0, chunks=0,
+                queue_check_interval=0, max_queue_depth=4096, min_queue_depth=0, push_pull_interval=0, chunks=0, recycle_interval=0,
                 flags=CF_BASELINE_JOINED, seed=DEFAULT_SEED):
     cfg = Config()
     cfg.struct_size = C.sizeof(Config)
@@ -104,7 +114,7 @@ def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, vi
     cfg.intent_timeout, cfg.leave_delay, cfg.flags, cfg.seed = intent_timeout, leave_delay, flags, seed
     cfg.reap_interval, cfg.reconnect_timeout, cfg.tombstone_timeout = reap_interval, reconnect_timeout, tombstone_timeout
     cfg.queue_check_interval, cfg.max_queue_depth, cfg.min_queue_depth = queue_check_interval, max_queue_depth, min_queue_depth
-    cfg.push_pull_interval, cfg.chunks = push_pull_interval, chunks
+    cfg.push_pull_interval, cfg.chunks, cfg.recycle_interval = push_pull_interval, chunks, recycle_interval
     return cfg
 
 
@@ -146,6 +156,9 @@ class SimLib:
             "step_begin": (C.c_int, [H]),
             "step_chunk": (C.c_int, [H, u32]),
             "step_end": (C.c_int, [H]),
+            "recycle_due": (C.c_int, [H]),
+            "recycle_scan": (C.c_int, [H, C.POINTER(RecycleCand), u32, C.POINTER(u32)]),
+            "recycle_apply": (C.c_int, [H, C.POINTER(RecycleCand), u32]),
             "snapshot": (C.c_int, [H, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
             "restore": (C.c_int, [H, vp, C.c_size_t]),
             "query_status": (C.c_int, [H, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_int)]),
@@ -307,7 +320,8 @@ class Sim:
         s = ClusterStats()
         self._ck(self.lib.f["cluster_stats_get"](self.h, C.byref(s)), "sim_cluster_stats_get")
         return {"up": s.up, "queued": [int(x) for x in s.queued], "overflow": s.overflow,
-                "inbox_records": s.inbox_records, "failed": s.failed, "left": s.left, "max_queue": s.max_queue}
+                "inbox_records": s.inbox_records, "failed": s.failed, "left": s.left, "max_queue": s.max_queue,
+                "ops_dropped": s.ops_dropped, "slots_in_use": s.slots_in_use, "slots_recycled": s.slots_recycled}
 
     def exchange_bytes(self):
         n = C.c_size_t()
@@ -322,6 +336,22 @@ class Sim:
         c, n = C.c_uint32(), C.c_size_t()
         self._ck(self.lib.f["exchange_chunks"](self.h, C.byref(c), C.byref(n)), "sim_exchange_chunks")
         return c.value, n.value
+
+    def recycle_due(self):
+        return self._ck(self.lib.f["recycle_due"](self.h), "sim_recycle_due") > 0
+
+    def recycle_scan(self):
+        """This shard's verdict on the recycling candidates of the next tick: numpy uint32 array [n, 12] (the
+        sim_recycle_cand records as words), ready for an all-gather."""
+        buf = (RecycleCand * RECYCLE_BATCH)()
+        n = C.c_uint32()
+        self._ck(self.lib.f["recycle_scan"](self.h, buf, RECYCLE_BATCH, C.byref(n)), "sim_recycle_scan")
+        return np.frombuffer(buf, dtype=np.uint32, count=n.value * 12).reshape(n.value, 12).copy()
+
+    def recycle_apply(self, words):
+        words = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1, 12)
+        buf = (RecycleCand * max(1, len(words))).from_buffer_copy(words.tobytes() if len(words) else bytes(C.sizeof(RecycleCand)))
+        self._ck(self.lib.f["recycle_apply"](self.h, buf, len(words)), "sim_recycle_apply")
 
     def step_begin(self):
         self._ck(self.lib.f["step_begin"](self.h), "sim_step_begin")

@@ -1821,6 +1821,52 @@ __global__ void cluster_stats_kernel(Dev d, const uint4* inbox, u64* out) {
   for (int i = 0; i < 9; ++i) block_sum_add(a[i], out + i);
   atomicMax((unsigned long long*)(out + 9), (unsigned long long)mx);
 }
+// single-word / single-entry updates of device tables with the value passed by value (no host buffer to outlive)
+__global__ void poke_u32(u32* p, u32 v) { if (!threadIdx.x && !blockIdx.x) *p = v; }
+__global__ void poke_base(uint4* base, u32 x, uint4 e0, uint4 e1) { if (!threadIdx.x && !blockIdx.x) { base[(size_t)x * 2] = e0; base[(size_t)x * 2 + 1] = e1; } }
+// ---- view-slot recycling scans (SIMSPEC §2.6; oracle recycle_scan) ----
+// subjects that a running node still has a queued record or a suspicion timer about, or that a packet in flight mentions
+__global__ void recycle_refd_kernel(Dev d, const uint4* inbox, uint8_t* refd, u32* first_up) {
+  u32 lo = 0xFFFFFFFFu;
+  for (size_t l = blockIdx.x * (size_t)BLOCK + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * BLOCK) {
+    if (inbox)
+      for (u32 k = 0; k < d.f; ++k)
+        for (u32 p = 0; p < SIM_P; ++p) {
+          uint4 r = inbox[((size_t)k * d.Nl + l) * 4 + p];
+          if (member_kind(SIM_META_KIND(r.y)) && r.x < d.N) refd[r.x] = 1;
+        }
+    uint4 r1 = d.R1[l];
+    if (!(r1.z & SIM_RF_UP)) continue;
+    lo = min(lo, (u32)l);
+    u32 cnt = __popc(d.R2[l].z >> 16);
+    for (u32 q = 0; q < cnt; ++q) {
+      uint4 kq = d.qkeys[(size_t)(q >> 2) * d.Nl + l];
+      u32 k = (q & 3) == 0 ? kq.x : (q & 3) == 1 ? kq.y : (q & 3) == 2 ? kq.z : kq.w;
+      uint4 pay = d.qpay[(size_t)(k & 15u) * d.Nl + l];
+      if (member_kind(SIM_META_KIND(pay.y)) && pay.x < d.N) refd[pay.x] = 1;
+    }
+    const uint16_t* sp = reinterpret_cast<const uint16_t*>(&d.R4[l]);
+    for (u32 j = 0; j < SIM_S; ++j)
+      if (sp[j] && d.subject_of[sp[j] - 1] != NOSLOT) refd[d.subject_of[sp[j] - 1]] = 1;
+  }
+  if (lo != 0xFFFFFFFFu) atomicMin(first_up, lo);
+}
+// candidate c = blockIdx.y: does every running node hold the head the first running node holds?
+__global__ void recycle_view_kernel(Dev d, const u32* cand_slots, const u32* first_up, uint4* out_ref, u32* out_bad) {
+  u32 c = blockIdx.y, a = cand_slots[c], l0 = *first_up;
+  if (l0 == 0xFFFFFFFFu) return;
+  uint4 ref = d.view[(size_t)a * d.Nl + l0];
+  ref.w &= 0x7FFu;  // the stamp of a settled entry is dead data
+  if (!blockIdx.x && !threadIdx.x) out_ref[c] = ref;
+  bool bad = false;
+  for (size_t l = blockIdx.x * (size_t)BLOCK + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * BLOCK) {
+    if (!(d.R1[l].z & SIM_RF_UP)) continue;
+    uint4 e = d.view[(size_t)a * d.Nl + l];
+    e.w &= 0x7FFu;
+    bad |= ne4(e, ref);
+  }
+  if (bad) out_bad[c] = 1;
+}
 __global__ void set_flag_bits(uint4* R1, u32 l, u32 bits) {
   if (threadIdx.x == 0 && blockIdx.x == 0) R1[l].z |= bits;
 }
@@ -1841,6 +1887,10 @@ struct sim_handle {
   hipStream_t stream;
   std::vector<u32> slot_of, subject_of;
   std::vector<u32> walk;  // host copy of d.walk
+  std::vector<u32> alloc_tick;  // [A] tick at which the slot was handed out
+  u32 n_alloc;                  // slots in use
+  u64 ops_dropped, slots_recycled;
+  u32 recycle_at;               // the tick whose recycling pass has already run
   std::vector<sim_view> base;
   uint4* d_base;  // [N][2]
   std::vector<OpEnt> ops;
@@ -1972,6 +2022,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   h->stream = nullptr;
   h->op_cursor = 0;
   h->bound = false;
+  h->n_alloc = 0; h->ops_dropped = h->slots_recycled = 0; h->recycle_at = 0xFFFFFFFFu;
   h->in_tick = false;
   h->tick_timed = false;
   h->rbuf[0] = h->rbuf[1] = nullptr;
@@ -2053,6 +2104,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   // slot map + baseline
   h->slot_of.assign(d.N, NOSLOT);
   h->subject_of.assign(d.A, NOSLOT);
+  h->alloc_tick.assign(d.A, 0);
   sim_view b0;
   memset(&b0, 0, sizeof b0);
   if (joined) { b0.ltime = 1; b0.bits = 1u | (SIM_STATUS_ALIVE << 1); }
@@ -2060,7 +2112,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   uint4 e0 = make_uint4((u32)b0.ltime, (u32)(b0.ltime >> 32), b0.inc, b0.bits), e1 = make_uint4(0, 0, 0, 0);
   fill_base<<<grid_for(d.N), BLOCK, 0, s>>>(h->d_base, d.N, e0, e1);
   if (h->dense) {
-    h->n_slots = d.N;
+    h->n_slots = h->n_alloc = d.N;
     h->walk.resize(d.N);
     for (u32 i = 0; i < d.N; ++i) h->slot_of[i] = h->subject_of[i] = h->walk[i] = i;
     fill_iota<<<grid_for(d.N), BLOCK, 0, s>>>(d.walk, d.N);
@@ -2088,14 +2140,22 @@ int sim_set_stream(sim_handle* h, void* st) {
   return SIM_OK;
 }
 
+static const uint4* cur_inbox(const sim_handle* h);
+static void walk_upload(sim_handle* h) {  // h->walk -> d.walk (synchronous: the host vector changes again later)
+  if (!h->walk.empty()) (void)hipMemcpy(h->d.walk, h->walk.data(), h->walk.size() * 4, hipMemcpyHostToDevice);
+}
 static int ensure_slot(sim_handle* h, u32 subject) {
   Dev& d = h->d;
   if (subject >= d.N) return SIM_EINVAL;
   if (h->slot_of[subject] != NOSLOT) return SIM_OK;
-  if (h->n_slots >= d.A) return SIM_ENOSLOT;
-  u32 a = h->n_slots++;
+  u32 a = 0;
+  while (a < d.A && h->subject_of[a] != NOSLOT) ++a;  // the lowest free slot
+  if (a == d.A) return SIM_ENOSLOT;
+  if (a >= h->n_slots) h->n_slots = a + 1;
+  h->n_alloc++;
   h->slot_of[subject] = a;
   h->subject_of[a] = subject;
+  h->alloc_tick[a] = (u32)h->tick;
   const sim_view& b = h->base[subject];
   uint4 e0 = make_uint4((u32)b.ltime, (u32)(b.ltime >> 32), b.inc, b.bits);
   uint4 e1 = make_uint4(b.conf[0], b.conf[1], b.conf[2], b.conf[3]);
@@ -2106,11 +2166,126 @@ static int ensure_slot(sim_handle* h, u32 subject) {
     walk_insert_kernel<<<1, 64, 0, h->stream>>>(d.walk, (u32)h->walk.size(), pos, a);
     h->walk.insert(h->walk.begin() + pos, a);
   }
-  HCHECK(hipMemcpyAsync(d.slot_of + subject, &h->slot_of[subject], 4, hipMemcpyHostToDevice, h->stream));
-  HCHECK(hipMemcpyAsync(d.subject_of + a, &h->subject_of[a], 4, hipMemcpyHostToDevice, h->stream));
+  poke_u32<<<1, 64, 0, h->stream>>>(d.slot_of + subject, a);
+  poke_u32<<<1, 64, 0, h->stream>>>(d.subject_of + a, subject);
   return SIM_OK;
 }
+// the subject an operation needs a view slot for (NOSLOT: none) — SIMSPEC §2.6
+static u32 op_subject(const sim_handle* h, u32 op, u32 node, u32 a) {
+  switch (op) {
+    case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: return node;
+    case SIM_OP_FORCE_LEAVE: return a;
+    case SIM_OP_CRASH: case SIM_OP_REVIVE: return h->d.swim ? node : NOSLOT;
+    default: return NOSLOT;
+  }
+}
 
+// ---- view-slot recycling (SIMSPEC §2.6; oracle recycle_*) -------------------------------------------------------------
+static bool recycle_is_due(const sim_handle* h) {
+  u32 R = h->cfg.recycle_interval;
+  return R && !h->dense && h->tick > 0 && h->tick % R == 0 && h->recycle_at != (u32)h->tick;
+}
+static u32 recycle_candidates(const sim_handle* h, sim_recycle_cand* out) {
+  u32 n = 0, R = h->cfg.recycle_interval, now = (u32)h->tick;
+  for (u32 a = 0; a < h->n_slots; ++a) {
+    if (h->subject_of[a] == NOSLOT || h->alloc_tick[a] + R > now) continue;
+    u32 pos = n < SIM_RECYCLE_BATCH ? n : SIM_RECYCLE_BATCH;
+    while (pos > 0 && h->alloc_tick[out[pos - 1].slot] > h->alloc_tick[a]) --pos;
+    if (pos >= SIM_RECYCLE_BATCH) continue;
+    u32 last = n < SIM_RECYCLE_BATCH ? n : SIM_RECYCLE_BATCH - 1;
+    for (u32 i = last; i > pos; --i) out[i] = out[i - 1];
+    memset(&out[pos], 0, sizeof out[pos]);
+    out[pos].slot = a;
+    out[pos].subject = h->subject_of[a];
+    if (n < SIM_RECYCLE_BATCH) ++n;
+  }
+  return n;
+}
+static int recycle_scan(sim_handle* h, sim_recycle_cand* c, u32 n) {
+  if (!n) return SIM_OK;
+  Dev& d = h->d;
+  hipStream_t s = h->stream;
+  uint8_t* refd = nullptr;
+  u32* scr = nullptr;  // [0] first running node, [1 .. n] slots, [1 + 64 .. ] bad flags, then the refs (16-byte aligned)
+  if (hipMalloc((void**)&refd, d.N) != hipSuccess) return SIM_ENOMEM;
+  if (hipMalloc((void**)&scr, (4 + 2 * SIM_RECYCLE_BATCH) * 4 + SIM_RECYCLE_BATCH * 16) != hipSuccess) { (void)hipFree(refd); return SIM_ENOMEM; }
+  u32 hs[4 + 2 * SIM_RECYCLE_BATCH];
+  memset(hs, 0, sizeof hs);
+  hs[0] = 0xFFFFFFFFu;
+  for (u32 i = 0; i < n; ++i) hs[4 + i] = c[i].slot;
+  uint4* d_ref = (uint4*)(scr + 4 + 2 * SIM_RECYCLE_BATCH);
+  std::vector<uint8_t> hrefd(d.N);
+  uint4 href[SIM_RECYCLE_BATCH];
+  u32 hbad[SIM_RECYCLE_BATCH];
+  hipError_t e = hipMemsetAsync(refd, 0, d.N, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(scr, hs, sizeof hs, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemsetAsync(d_ref, 0, SIM_RECYCLE_BATCH * 16, s);
+  if (e == hipSuccess) {
+    recycle_refd_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, cur_inbox(h), refd, scr);
+    recycle_view_kernel<<<dim3((unsigned)std::min<size_t>((d.Nl + BLOCK - 1) / BLOCK, 1024), n), BLOCK, 0, s>>>(d, scr + 4, scr, d_ref, scr + 4 + SIM_RECYCLE_BATCH);
+    e = hipMemcpyAsync(hs, scr, sizeof hs, hipMemcpyDeviceToHost, s);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(href, d_ref, sizeof href, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(hrefd.data(), refd, d.N, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(refd);
+  (void)hipFree(scr);
+  HCHECK(e);
+  memcpy(hbad, hs + 4 + SIM_RECYCLE_BATCH, sizeof hbad);
+  for (u32 i = 0; i < n; ++i) {
+    c[i].flags = hrefd[c[i].subject] ? 1u : 0u;
+    if (hs[0] == 0xFFFFFFFFu) continue;  // no running node on this shard
+    memset(&c[i].ref, 0, sizeof c[i].ref);
+    c[i].ref.ltime = (u64)href[i].x | ((u64)href[i].y << 32);
+    c[i].ref.inc = href[i].z;
+    c[i].ref.bits = href[i].w;
+    c[i].flags |= 2u;
+    const sim_view& r = c[i].ref;
+    // settled = forgotten altogether, or known + Alive for serf and for memberlist, nothing buffered or pending
+    bool settled = (r.bits == 0 && r.ltime == 0 && r.inc == 0) ||
+                   ((r.bits & SIM_VB_KNOWN) && SIM_VB_STATUS(r.bits) == SIM_STATUS_ALIVE && SIM_VB_SWIM(r.bits) == SIM_SWIM_ALIVE &&
+                    !SIM_VB_INTENT(r.bits) && !SIM_VB_NCONF(r.bits));
+    if (!settled || hbad[i]) c[i].flags |= 1u;
+  }
+  return SIM_OK;
+}
+static int recycle_apply(sim_handle* h, const sim_recycle_cand* c, u32 n) {
+  Dev& d = h->d;
+  for (u32 i = 0; i < n; ++i) {
+    u32 x = c[i].subject;
+    if (x >= d.N) return SIM_EINVAL;
+    u32 a = h->slot_of[x];
+    if (a == NOSLOT) continue;
+    h->base[x] = c[i].ref;
+    const sim_view& b = h->base[x];
+    poke_base<<<1, 64, 0, h->stream>>>(h->d_base, x, make_uint4((u32)b.ltime, (u32)(b.ltime >> 32), b.inc, b.bits),
+                                        make_uint4(b.conf[0], b.conf[1], b.conf[2], b.conf[3]));
+    poke_u32<<<1, 64, 0, h->stream>>>(d.slot_of + x, NOSLOT);
+    poke_u32<<<1, 64, 0, h->stream>>>(d.subject_of + a, NOSLOT);
+    h->slot_of[x] = NOSLOT;
+    h->subject_of[a] = NOSLOT;
+    h->n_alloc--;
+    h->slots_recycled++;
+  }
+  while (h->n_slots > 0 && h->subject_of[h->n_slots - 1] == NOSLOT) h->n_slots--;
+  h->walk.clear();
+  for (u32 x = 0; x < d.N; ++x)
+    if (h->slot_of[x] != NOSLOT) h->walk.push_back(h->slot_of[x]);
+  HCHECK(hipStreamSynchronize(h->stream));
+  walk_upload(h);
+  return SIM_OK;
+}
+static int recycle_local(sim_handle* h) {  // every shard is in this process: decide here
+  sim_recycle_cand c[SIM_RECYCLE_BATCH];
+  u32 n = recycle_candidates(h, c), m = 0;
+  int rc = recycle_scan(h, c, n);
+  if (rc) return rc;
+  for (u32 i = 0; i < n; ++i)
+    if ((c[i].flags & 3u) == 2u) c[m++] = c[i];
+  rc = recycle_apply(h, c, m);
+  h->recycle_at = (u32)h->tick;
+  return rc;
+}
 int sim_inject(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, uint32_t b) {
   if (!h || node >= h->d.N) return SIM_EINVAL;
   if (tick < h->tick) tick = h->tick;
@@ -2118,11 +2293,13 @@ int sim_inject(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, uint32_
   switch (op) {
     case SIM_OP_USER_EVENT: if (!a) return SIM_EINVAL; if ((b & 0x7FFFFFFFu) > 9 * 1024) return SIM_ETOOBIG; break;  // bit 31: cc
     case SIM_OP_QUERY: if (!a) return SIM_EINVAL; break;
-    case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: rc = ensure_slot(h, node); break;
-    case SIM_OP_FORCE_LEAVE: rc = ensure_slot(h, a); break;
-    case SIM_OP_CRASH: case SIM_OP_REVIVE: if (h->d.swim) rc = ensure_slot(h, node); break;
+    case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: case SIM_OP_FORCE_LEAVE: case SIM_OP_CRASH: case SIM_OP_REVIVE: break;
     default: return SIM_EINVAL;
   }
+  if (op == SIM_OP_FORCE_LEAVE && a >= h->d.N) return SIM_EINVAL;
+  // an operation that executes now gets its view slot now (and SIM_ENOSLOT if there is none); one scheduled for a
+  // later tick gets it when it executes — and is dropped and counted if none is free then (SIMSPEC §2.6)
+  if (tick <= h->tick && op_subject(h, op, node, a) != NOSLOT) rc = ensure_slot(h, op_subject(h, op, node, a));
   if (rc) return rc;
   size_t pos = h->ops.size();
   h->ops.push_back(OpEnt{tick, op, node, a, b});
@@ -2155,23 +2332,43 @@ int sim_query(sim_handle* h, uint32_t node, uint32_t id, uint32_t flags) {
 // (sim_step_chunk; a single launch when there is one chunk or all shards are local), sim_step_end.  sim_step does all
 // of it; a sharded host that wants the exchange of chunk c in flight while chunk c + 1 computes drives the three
 // calls itself (serf_amd/shard.py).
+int sim_recycle_due(const sim_handle* h) { return h ? (recycle_is_due(h) ? 1 : 0) : SIM_EINVAL; }
+int sim_recycle_scan(sim_handle* h, sim_recycle_cand* out, uint32_t cap, uint32_t* n) {
+  if (!h || !out || !n || cap < SIM_RECYCLE_BATCH) return SIM_EINVAL;
+  if (h->in_tick) return SIM_ESTATE;
+  *n = recycle_candidates(h, out);
+  return recycle_scan(h, out, *n);
+}
+int sim_recycle_apply(sim_handle* h, const sim_recycle_cand* agreed, uint32_t n) {
+  if (!h || (n && !agreed)) return SIM_EINVAL;
+  if (h->in_tick) return SIM_ESTATE;
+  int rc = recycle_apply(h, agreed, n);
+  h->recycle_at = (u32)h->tick;
+  return rc;
+}
 int sim_step_begin(sim_handle* h) {
   if (!h) return SIM_EINVAL;
   Dev& d = h->d;
   if (h->in_tick || (d.sharded && !h->bound)) return SIM_ESTATE;
+  if (recycle_is_due(h)) {
+    if (d.sharded) return SIM_ESTATE;  // the host runs the pass first (it needs every shard's verdict)
+    int rc = recycle_local(h);
+    if (rc) return rc;
+  }
   TickP& tp = h->cur_tp;
   tickp_make(&tp, &h->cfg, h->tick);
 #ifdef TICK_ABLATE
   tp.abl = g_ablate;
 #endif
   for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) { tp.prot[k] = h->prev.rot[k]; tp.prho[k] = h->prev.rho[k]; }
-  tp.n_slots = (u32)h->walk.size();
   if (d.sharded) d.xrecv = h->rbuf[(h->tick + 1) & 1];  // what was sent during tick - 1
   while (h->op_cursor < h->ops.size() && h->ops[h->op_cursor].tick <= h->tick) {
     OpBatch ob;
     memset(&ob, 0, sizeof ob);
     while (ob.n < 8 && h->op_cursor < h->ops.size() && h->ops[h->op_cursor].tick <= h->tick) {
       const OpEnt& e = h->ops[h->op_cursor++];
+      u32 x = op_subject(h, e.op, e.node, e.a);
+      if (x != NOSLOT && ensure_slot(h, x) != SIM_OK) { h->ops_dropped++; continue; }  // no free view slot: the operation does not happen
       ob.op[ob.n] = e.op; ob.node[ob.n] = e.node; ob.a[ob.n] = e.a; ob.b[ob.n] = e.b;
       if (e.op == SIM_OP_QUERY) {  // a fresh tracker: who acked / responded starts empty
         u32 j = e.a % SIM_QT;
@@ -2181,8 +2378,9 @@ int sim_step_begin(sim_handle* h) {
       }
       ob.n++;
     }
-    ops_kernel<<<1, 64, 0, h->stream>>>(d, ob, h->tick, d.N > 1 ? 1u : 0u, tp.query_base, h->q_timeout);
+    if (ob.n) ops_kernel<<<1, 64, 0, h->stream>>>(d, ob, h->tick, d.N > 1 ? 1u : 0u, tp.query_base, h->q_timeout);
   }
+  tp.n_slots = (u32)h->walk.size();  // after the operations: they may have taken slots
   if (h->pp_step && h->tick > 0 && h->tick % h->pp_step == 0) {
     u32 cls = (u32)((h->tick / h->pp_step) % PP_GROUPS);
     u32 half = tp.M / 2, per_shard = half > cls ? (half - cls + PP_GROUPS - 1) / PP_GROUPS : 0;
@@ -2425,10 +2623,10 @@ struct snap_header {
   sim_config cfg;
   uint64_t tick;
   uint32_t n_slots, n_pending_ops;
-  uint32_t prev_rot[SIM_MAX_FANOUT];
+  uint64_t ops_dropped, slots_recycled;
 };
 #define SNAP_MAGIC 0x53465253u
-#define SNAP_SECTIONS 13
+#define SNAP_SECTIONS 14
 static void snap_lengths(const sim_handle* h, size_t len[SNAP_SECTIONS]) {
   const Dev& d = h->d;
   size_t nup = ((size_t)d.N + 31) / 32;
@@ -2436,7 +2634,8 @@ static void snap_lengths(const sim_handle* h, size_t len[SNAP_SECTIONS]) {
                              (size_t)d.f * d.Nl * sizeof(sim_packet), (size_t)d.A * d.Nl * sizeof(sim_view),
                              (size_t)d.Bev * d.Nl * sizeof(sim_bucket), (size_t)d.Bq * d.Nl * sizeof(sim_bucket),
                              (size_t)d.N * 4, (size_t)d.A * 4, (size_t)d.N * sizeof(sim_view), nup * 4,
-                             (size_t)SIM_QT * 16, (size_t)SIM_QT * 2 * nup * 4, (h->ops.size() - h->op_cursor) * sizeof(OpEnt)};
+                             (size_t)SIM_QT * 16, (size_t)SIM_QT * 2 * nup * 4, (h->ops.size() - h->op_cursor) * sizeof(OpEnt),
+                             (size_t)d.A * 4};
   memcpy(len, n, sizeof n);
 }
 int sim_snapshot(sim_handle* h, void* buf, size_t cap, size_t* bytes) {
@@ -2453,7 +2652,7 @@ int sim_snapshot(sim_handle* h, void* buf, size_t cap, size_t* bytes) {
   memset(&hd, 0, sizeof hd);
   hd.magic = SNAP_MAGIC; hd.abi = SIM_ABI_VERSION; hd.cfg = h->cfg; hd.tick = h->tick; hd.n_slots = h->n_slots;
   hd.n_pending_ops = (uint32_t)(h->ops.size() - h->op_cursor);
-  for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) hd.prev_rot[k] = h->prev.rot[k];
+  hd.ops_dropped = h->ops_dropped; hd.slots_recycled = h->slots_recycled;
   uint8_t* o = (uint8_t*)buf;
   memcpy(o, &hd, sizeof hd); o += sizeof hd;
   const uint32_t dumps[6] = {SIM_ARR_ROWS, SIM_ARR_QUEUE, SIM_ARR_INBOX, SIM_ARR_VIEW, SIM_ARR_ERING, SIM_ARR_QRING};
@@ -2470,7 +2669,8 @@ int sim_snapshot(sim_handle* h, void* buf, size_t cap, size_t* bytes) {
     else if (i == 9) { HCHECK(hipMemcpyAsync(o, d.upmap, n, hipMemcpyDeviceToHost, h->stream)); HCHECK(hipStreamSynchronize(h->stream)); }
     else if (i == 10) { HCHECK(hipMemcpyAsync(o, d.qtab, n, hipMemcpyDeviceToHost, h->stream)); HCHECK(hipStreamSynchronize(h->stream)); }
     else if (i == 11) { HCHECK(hipMemcpyAsync(o, d.qbits, n, hipMemcpyDeviceToHost, h->stream)); HCHECK(hipStreamSynchronize(h->stream)); }
-    else if (n) memcpy(o, h->ops.data() + h->op_cursor, n);
+    else if (i == 12) { if (n) memcpy(o, h->ops.data() + h->op_cursor, n); }
+    else memcpy(o, h->alloc_tick.data(), n);
     o += n;
   }
   return SIM_OK;
@@ -2487,7 +2687,7 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
   if ((size_t)hd.n_pending_ops > bytes / sizeof(OpEnt)) return SIM_EINVAL;  // sizes a host allocation
   size_t len[SNAP_SECTIONS];
   snap_lengths(h, len);
-  len[SNAP_SECTIONS - 1] = (size_t)hd.n_pending_ops * sizeof(OpEnt);
+  len[12] = (size_t)hd.n_pending_ops * sizeof(OpEnt);
   const uint8_t* sec[SNAP_SECTIONS];
   {
     const uint8_t* in = (const uint8_t*)buf + sizeof hd;
@@ -2548,6 +2748,10 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
   if (!h->walk.empty()) HCHECK(hipMemcpy(d.walk, h->walk.data(), h->walk.size() * 4, hipMemcpyHostToDevice));
   h->ops.assign(hd.n_pending_ops, OpEnt{0, 0, 0, 0, 0});
   if (len[12]) memcpy(h->ops.data(), sec[12], len[12]);
+  memcpy(h->alloc_tick.data(), sec[13], len[13]);
+  h->n_alloc = (u32)h->walk.size();
+  h->ops_dropped = hd.ops_dropped; h->slots_recycled = hd.slots_recycled;
+  h->recycle_at = 0xFFFFFFFFu;
   h->op_cursor = 0;
   return SIM_OK;
 }
@@ -2632,6 +2836,7 @@ int sim_cluster_stats_get(sim_handle* h, sim_cluster_stats* out) {
   out->up = r[0];
   for (int i = 0; i < 4; ++i) out->queued[i] = r[1 + i];
   out->overflow = r[5]; out->inbox_records = r[6]; out->failed = r[7]; out->left = r[8]; out->max_queue = r[9];
+  out->ops_dropped = h->ops_dropped; out->slots_in_use = h->n_alloc; out->slots_recycled = h->slots_recycled;
   return SIM_OK;
 }
 int sim_exchange_bytes(const sim_handle* h, size_t* bytes) {

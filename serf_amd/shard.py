@@ -74,9 +74,35 @@ class ShardedSim:
             w.wait()
         self._pending = []
 
+    def _recycle(self):
+        """View-slot recycling needs every shard's verdict (include/serf_sim.h): scan locally, all-gather, keep the
+        candidates no shard objects to and whose running nodes agree everywhere, apply the same list on every shard."""
+        import numpy as np
+
+        mine = self.sim.recycle_scan()  # [n, 12] uint32 words of sim_recycle_cand; n is the same on every shard
+        n = len(mine)
+        if n == 0:
+            self.sim.recycle_apply(mine)
+            return
+        t = torch.from_numpy(mine.astype(np.int64)).to(self.device)
+        allv = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(allv, t, group=self.group)
+        a = torch.stack(allv).cpu().numpy().astype(np.uint32)  # [world, n, 12]
+        keep = []
+        for i in range(n):
+            flags = a[:, i, 2]
+            if (flags & 1).any() or not (flags & 2).any():
+                continue
+            refs = a[(flags & 2) != 0, i, 4:8]  # ltime.lo, ltime.hi, inc, bits of the shards that have running nodes
+            if (refs == refs[0]).all():
+                keep.append(a[np.nonzero(flags & 2)[0][0], i])
+        self.sim.recycle_apply(np.array(keep, dtype=np.uint32).reshape(-1, 12))
+
     def step(self, n_ticks=1):
         for _ in range(n_ticks):
             self._drain()
+            if self.sim.recycle_due():
+                self._recycle()
             if self.chunks == 1:
                 self.sim.step(1)  # reads recv (packets of the previous round), fills send
                 self._exchange(self.recv[0], self.send, False)

@@ -30,6 +30,11 @@ def pytest_sessionstart(session):
         import shutil
         if shutil.which("hipcc"):
             subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", so, hip])
+    ex = os.path.join(ROOT, "serf_amd", "host", "serf_example")
+    exsrc = os.path.join(ROOT, "serf_amd", "host", "serf_example.cpp")
+    if os.path.exists(so) and _stale(ex, exsrc, os.path.join(ROOT, "serf_amd", "host", "serf.hpp"), hdr):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), "-o", ex, exsrc,
+                               "-L", os.path.dirname(so), "-lserf_sim", "-Wl,-rpath,$ORIGIN/../csrc"])
     osrc = os.path.join(ROOT, "oracle", "serf_oracle.c")
     if _stale(os.path.join(ROOT, "oracle", "liboracle.so"), osrc, hdr):
         subprocess.check_call(["make", "-B", "-C", os.path.join(ROOT, "oracle")])

@@ -276,3 +276,88 @@ def test_bench_configuration_64k_digests(oracle, hiplib):
     assert cg == co
     assert cg["overflow"] == 0, "the benchmark workload must stay inside the model bounds"
     assert cg["failed"] > 0 and cg["left"] > 0, "crashes and leaves were declared (timers fired) within the window"
+
+
+def test_view_slot_recycling_parity(oracle, hiplib):
+    # churn over 4x more subjects than view slots, failure detector on: slots are taken when the operations execute
+    # and given back by the recycling pass (SIMSPEC §2.6) — HIP and oracle agree on every array, on the slot map and
+    # on the bookkeeping, and nothing is dropped
+    from tests.test_recycle import KW, churn_ops
+
+    n = 2048
+    kw = dict(KW, view_slots=24, fanout=4)
+    g, o = pair(oracle, hiplib, n, **kw)
+    ops = churn_ops(n, 100, every=5, down=4)
+    sc.apply_schedule(g, ops)
+    sc.apply_schedule(o, ops)
+    for t in range(0, 700, 10):
+        g.step(10)
+        o.step(10)
+        if g.digest() != o.digest():
+            sc.assert_same_state(g, o, f"tick {t + 10}")
+            raise AssertionError(f"digest differs after tick {t + 10} but the arrays agree")
+    sc.assert_same_state(g, o, "final")
+    cg, co = g.cluster_stats(), o.cluster_stats()
+    assert cg == co
+    assert cg["ops_dropped"] == 0 and cg["slots_recycled"] >= 76 and cg["overflow"] == 0 and cg["up"] == n
+
+
+def test_view_slot_recycling_four_shards_on_one_gpu(oracle, hiplib):
+    # the sharded form of the pass: every shard scans its own nodes (sim_recycle_scan), the host keeps the candidates
+    # all shards agree on, every shard applies the same list (sim_recycle_apply) — against the single-process oracle
+    import torch
+    from tests.test_recycle import KW, churn_ops
+
+    n, V = 2048, 4
+    m = n // V
+    kw = dict(KW, view_slots=24, fanout=4)
+    ref = _ffi.Sim(oracle, _ffi.make_config(n, vshards=V, **kw))
+    shards, send, recv = [], [], []
+    for r in range(V):
+        s = _ffi.Sim(hiplib, _ffi.make_config(n, vshards=V, shard_rank=r, shard_count=V, **kw))
+        nb = s.exchange_bytes()
+        send.append(torch.zeros(nb, dtype=torch.uint8, device="cuda"))
+        recv.append(torch.zeros(nb, dtype=torch.uint8, device="cuda"))
+        s.bind_exchange(send[-1].data_ptr(), recv[-1].data_ptr())
+        shards.append(s)
+    ops = churn_ops(n, 90, every=5, down=4)
+    for s in shards + [ref]:
+        sc.apply_schedule(s, ops)
+    slab = send[0].numel() // V
+    for t in range(600):
+        if shards[0].recycle_due():
+            scans = np.stack([s.recycle_scan() for s in shards])   # [V, n_cand, 12]
+            keep = []
+            for i in range(scans.shape[1]):
+                flags = scans[:, i, 2]
+                if (flags & 1).any() or not (flags & 2).any():
+                    continue
+                refs = scans[(flags & 2) != 0, i, 4:8]
+                if (refs == refs[0]).all():
+                    keep.append(scans[np.nonzero(flags & 2)[0][0], i])
+            for s in shards:
+                s.recycle_apply(np.array(keep, dtype=np.uint32).reshape(-1, 12))
+        for s in shards:
+            s.step(1)
+        for s in shards:
+            s.sync()
+        for r in range(V):
+            for src in range(V):
+                recv[r][src * slab:(src + 1) * slab].copy_(send[src][r * slab:(r + 1) * slab])
+        torch.cuda.synchronize()
+        ref.step(1)
+        if t % 25 == 0 or t == 599:
+            for r, s in enumerate(shards):
+                lo = r * m
+                for which in (_ffi.ARR_ROWS, _ffi.ARR_QUEUE):
+                    a, b = s.dump(which), ref.dump(which)
+                    per = len(b) // n
+                    i = sc.first_diff(a, b[lo * per:(lo + m) * per])
+                    assert i is None, f"shard {r} array {which} element {i} differs at tick {t}"
+                a = s.dump(_ffi.ARR_VIEW).reshape(24, m)
+                b = np.ascontiguousarray(ref.dump(_ffi.ARR_VIEW).reshape(24, n)[:, lo:lo + m])
+                assert a.tobytes() == b.tobytes(), f"shard {r} view differs at tick {t}"
+                assert (s.dump(_ffi.ARR_SLOTMAP) == ref.dump(_ffi.ARR_SLOTMAP)).all()
+    cr = ref.cluster_stats()
+    assert cr["slots_recycled"] >= 66 and cr["ops_dropped"] == 0
+    assert all(s.cluster_stats()["slots_recycled"] == cr["slots_recycled"] for s in shards)
