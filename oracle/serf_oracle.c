@@ -988,7 +988,7 @@ static void apply_op(osim* s, const sim_opent* op) {
       if (!(row->flags & SIM_RF_UP)) break;
       uint64_t lt = row->query_clock;               /* base.rs:904 */
       handle_query(&c, op->a, lt, op->b);           /* base.rs:932 */
-      q_push(&c, op->a, wire_meta(SIM_K_QUERY, op->b, 32), lt); /* base.rs:935-942 */
+      q_push(&c, op->a, wire_meta(SIM_K_QUERY, op->b, 48), lt); /* base.rs:935-942 */
       break;
     }
     case SIM_OP_LEAVE: { /* api.rs:422-460 */

@@ -1383,7 +1383,7 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
           uint4* p = qring_ptr(c, lt);
           uint4 e_ = p[0];
           handle_query(c, n, a, lt, b, p, e_, dirty);
-          ins_set(ins2, a, wire_meta(SIM_K_QUERY, b, 32), lt);
+          ins_set(ins2, a, wire_meta(SIM_K_QUERY, b, 48), lt);
         }
         break;
       case SIM_OP_LEAVE:  // api.rs:422-460

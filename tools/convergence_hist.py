@@ -35,7 +35,8 @@ def main():
     ap.add_argument("--probe-interval", type=int, default=5, help="0 = SWIM layer off")
     ap.add_argument("--push-pull-interval", type=int, default=0)
     ap.add_argument("--churn-frac", type=float, default=0.0, help="fraction of the nodes that crash and come back over the run (needs --probe-interval 0)")
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r01_convergence_hist.json"))
+    ap.add_argument("--recycle-interval", type=int, default=0, help="view-slot recycling pass every this many ticks (SWIM layer on: lets the churn run over more subjects than view slots)")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_convergence_hist.json"))
     args = ap.parse_args()
 
     import numpy as np
@@ -44,7 +45,8 @@ def main():
 
     n = args.nodes
     sim = serf_amd.create(n, fanout=args.fanout, view_slots=args.view_slots, event_ring=512, query_ring=512,
-                          probe_interval=args.probe_interval, push_pull_interval=args.push_pull_interval, loss=args.loss)
+                          probe_interval=args.probe_interval, push_pull_interval=args.push_pull_interval, loss=args.loss,
+                          recycle_interval=args.recycle_interval)
     rng = np.random.default_rng(5)
     total_ticks = args.rumors * args.every + 120
     if args.churn_frac > 0:
@@ -52,7 +54,7 @@ def main():
         n_churn = int(n * args.churn_frac)
         when = np.sort(rng.integers(10, total_ticks - args.down - 10, n_churn))
     else:
-        n_churn = min(total_ticks // args.churn_every, args.view_slots - 8)
+        n_churn = total_ticks // args.churn_every if args.recycle_interval else min(total_ticks // args.churn_every, args.view_slots - 8)
         when = 10 + np.arange(n_churn) * args.churn_every
     churned = rng.choice(n, n_churn, replace=False)
     for t, node in zip(when.tolist(), churned.tolist()):
@@ -85,13 +87,15 @@ def main():
     r = np.array(rounds)
     hist = {int(k): int(v) for k, v in zip(*np.unique(r, return_counts=True))}
     rows = sim.dump(_ffi.ARR_ROWS)
+    cs = sim.cluster_stats()
     out = {
         "config": vars(args), "ticks": total_ticks, "churn_events": int(n_churn), "rumors": int(len(r)),
         "rounds_to_99": {"median": float(np.median(r)), "p90": float(np.percentile(r, 90)), "p99": float(np.percentile(r, 99)),
                          "max": int(r.max()), "not_converged_in_100": int((r > 100).sum())},
         "histogram": hist,
         "refutations": int(rows["inc"].sum()), "nodes_ever_failed_somewhere": int((rows["n_failed"] > 0).sum()),
-        "model_bound_drops": int(rows["overflow"].sum()),
+        "model_bound_drops": int(rows["overflow"].sum()), "ops_dropped_no_slot": int(cs["ops_dropped"]),
+        "view_slots_recycled": int(cs["slots_recycled"]), "view_slots_in_use_at_end": int(cs["slots_in_use"]),
         "wall_s": dt, "member_ticks_per_s_incl_host_polling": n * total_ticks / dt,
     }
     json.dump(out, open(args.out, "w"), indent=1)
