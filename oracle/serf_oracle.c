@@ -2047,7 +2047,7 @@ int osim_t_user_event(osim* s, uint32_t node, uint32_t key, uint64_t ltime) {
 int osim_t_query(osim* s, uint32_t node, uint32_t id, uint64_t ltime, uint32_t flags) {
   TCTX(s, node);
   int rb = handle_query(&c, id, ltime, flags);
-  if (rb) q_push(&c, id, wire_meta(SIM_K_QUERY, flags, 32), ltime);
+  if (rb) q_push(&c, id, wire_meta(SIM_K_QUERY, flags, 48), ltime);
   t_finish(&c);
   return rb;
 }

@@ -123,5 +123,7 @@ def test_query_record_carries_the_codec_length(oracle):
     sim.query(5, 77, _ffi.F_ACK)
     sim.step(1)
     meta = int(sim.dump(_ffi.ARR_QUEUE).reshape(64, _ffi.Q)[5]["meta"][0])
-    q = wire.Query(1, 77, 5, flags=_ffi.F_ACK, relay_factor=0, timeout_ms=16 * 2 * 200)
+    # the simulator prices every query at the length of a representative one (7-digit node id, Lamport time in the
+    # thousands, timeout 16 * 7 gossip intervals); the record's length field is in 16-byte units
+    q = wire.Query(5000, 77, 999999, flags=_ffi.F_ACK, relay_factor=0, timeout_ms=16 * 7 * 200)
     assert 63 - ((meta >> 18) & 63) == (wire.encoded_len(q) + 15) // 16 == 3
