@@ -41,7 +41,8 @@ def workload(args, n_total):
 
     kw = dict(fanout=args.fanout, view_slots=args.view_slots, event_ring=args.ring, query_ring=args.ring,
               probe_interval=args.probe_interval, push_pull_interval=args.push_pull_interval,
-              reap_interval=75, queue_check_interval=150)  # options.rs defaults: reap 15 s, queue check 30 s, timeouts 24 h
+              reap_interval=75, queue_check_interval=150,  # options.rs defaults: reap 15 s, queue check 30 s, timeouts 24 h
+              recycle_interval=args.recycle_interval)
     horizon = args.preroll + args.warmup + args.steps + CONV_RUMOURS * (CONV_MAX_ROUNDS + 1)
     ops = wl.schedule(n_total, horizon, rate=args.rate, seed=3, mix=wl.BENCH_MIX,
                       max_member_subjects=args.view_slots // 2, even=True)
@@ -116,6 +117,7 @@ def parse_args(argv=None):
     ap.add_argument("--rate", type=float, default=0.25, help="API operations injected per tick (cluster-wide)")
     ap.add_argument("--probe-interval", type=int, default=5, help="memberlist probe interval in ticks (0 = SWIM layer off)")
     ap.add_argument("--push-pull-interval", type=int, default=150, help="memberlist push_pull_interval in ticks before log2(N) scaling (0 = off)")
+    ap.add_argument("--recycle-interval", type=int, default=75, help="view-slot recycling pass every this many ticks (0 = never)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence", action="store_true", help="skip the rounds-to-99 %% measurement (profiling runs)")
     ap.add_argument("--allow-drops", action="store_true", help="do not fail when the run hit a model bound (overflow > 0)")
@@ -188,8 +190,10 @@ def run(args, lib=None, dev=None, backend="nccl"):
             sim.sync()  # the round's exchanges have landed
         cs = raw.cluster_stats()
         inbox, queued, drops, up = allsum([cs["inbox_records"], sum(cs["queued"]), cs["overflow"], cs["up"]])
+        # operations skipped for want of a view slot are counted on the (replicated) schedule, the same on every rank
         return {"records_per_packet": inbox / (args.fanout * n_total), "queued_per_node": queued / n_total,
-                "drops": drops, "up": up}
+                "drops": drops + int(cs["ops_dropped"]), "up": up, "slots_in_use": int(cs["slots_in_use"]),
+                "slots_recycled": int(cs["slots_recycled"])}
 
     class _HostEvent:  # CPU stand-in for torch.cuda.Event in the plumbing test
         def __init__(self, enable_timing=True):
@@ -308,7 +312,8 @@ def run(args, lib=None, dev=None, backend="nccl"):
                                 "queued_per_node_start": round(load0["queued_per_node"], 3),
                                 "queued_per_node_end": round(load1["queued_per_node"], 3),
                                 "records_per_packet_preroll_every_40_ticks": trace,
-                                "nodes_up": load1["up"]}},
+                                "nodes_up": load1["up"], "view_slots_in_use": load2["slots_in_use"],
+                                "view_slots_recycled": load2["slots_recycled"]}},
             "rounds_to_99": ({"median": float(np.median(rounds)), "max": int(max(rounds)), "min": int(min(rounds)), "n": len(rounds),
                               "what": "gossip rounds until >= 99 % of running nodes have applied a fresh user event, under the bench load"}
                              if rounds else None),

@@ -368,6 +368,22 @@ int sim_exchange_chunks(const sim_handle* h, uint32_t* chunks, size_t* bytes_per
  * (same candidates everywhere: the slot bookkeeping is replicated), keeps the candidates for which NO shard set flag 1
  * and all shards that set flag 2 report the same `ref`, and hands that list to sim_recycle_apply on every shard —
  * before sim_step_begin, which otherwise refuses with SIM_ESTATE. */
+/* Cross-shard push-pull.  memberlist's pushPull picks ANY peer, so the pairs of a batch come
+ * from a matching over all N nodes and most of them span two shards.  A single-process handle merges them inside
+ * sim_step_begin; with one shard per process, on a batch tick the host runs, AFTER sim_step_begin (the tick's
+ * operations come first) and before the first sim_step_chunk (which refuses with SIM_ESTATE while sim_pp_due):
+ *   sim_pp_plan(h, send1, recv1, &record_bytes)  records this shard sends to / receives from each of the V peers in
+ *                                                round 1; round 2 uses the same counts swapped
+ *   sim_pp_export(h, 1, send); <all-to-all-v>; sim_pp_merge(h, 1, recv)
+ *   sim_pp_export(h, 2, send); <all-to-all-v>; sim_pp_merge(h, 2, recv)
+ * Round 1: the odd-sigma node `b` of every cross pair ships its state (clocks, view heads, event ring: what
+ * SerfDelegate::local_state and memberlist's node list carry, delegate.rs:386-425) to the shard of the even one `a`,
+ * which merges it; in-shard pairs merge both ways.  Round 2: `a` ships its UPDATED state back, `b` merges.  Buffers
+ * are DEVICE memory for the HIP library, grouped by peer shard, records in ascending pair order. */
+int sim_pp_due(const sim_handle* h);
+int sim_pp_plan(sim_handle* h, uint32_t* send1, uint32_t* recv1, size_t* record_bytes);
+int sim_pp_export(sim_handle* h, int round, void* send_dev);
+int sim_pp_merge(sim_handle* h, int round, const void* recv_dev);
 int sim_recycle_due(const sim_handle* h);
 int sim_recycle_scan(sim_handle* h, sim_recycle_cand* out, uint32_t cap, uint32_t* n);
 int sim_recycle_apply(sim_handle* h, const sim_recycle_cand* agreed, uint32_t n);

@@ -92,6 +92,7 @@ typedef struct tickp {
    * B nodes (64, or 1 for small / ragged shards), nbc = V * sub / B blocks per chunk; bmask/bshift: the block
    * permutation's bit width */
   uint32_t C, sub, B, nbc, bmask, bshift;
+  uint32_t N, gmask, gshift; /* push-pull pairs come from a permutation of all N nodes */
   uint32_t mul[3], add[3], imul[3];
   uint32_t off[SIM_MAX_FANOUT], rot[SIM_MAX_FANOUT], rho[SIM_MAX_FANOUT];
   uint64_t loss_base, probe_base;
@@ -119,6 +120,13 @@ static void tickp_make(tickp* p, const sim_config* c, uint64_t tick) {
   if (p->nbits < 1) p->nbits = 1;
   p->mask = p->nbits >= 32 ? 0xFFFFFFFFu : ((1u << p->nbits) - 1u);
   p->shift = (p->nbits + 1) / 2;
+  p->N = c->n_nodes;
+  {
+    uint32_t gb = ceil_log2_u32(p->N);
+    if (gb < 1) gb = 1;
+    p->gmask = gb >= 32 ? 0xFFFFFFFFu : ((1u << gb) - 1u);
+    p->gshift = (gb + 1) / 2;
+  }
   p->C = c->chunks ? c->chunks : 1;
   p->sub = p->blk / p->C;
   p->B = (p->sub % 64u == 0 && (uint64_t)p->V * p->sub / 64u >= 8u) ? 64u : 1u;
@@ -262,6 +270,11 @@ struct sim_handle {
   uint32_t n_alloc;     /* slots in use */
   uint64_t ops_dropped; /* operations skipped because their subject found no free view slot (model bound) */
   uint64_t slots_recycled;
+  uint32_t pp_done_at;  /* the tick whose push-pull batch the sharded host has already run */
+  /* the batch being driven by the sharded host: in-shard pairs, and the cross-shard pairs grouped by peer shard in
+   * ascending pair order — r1: I own the even node `a` (receive b in round 1, send a in round 2); s1: I own `b` */
+  uint32_t pp_n_local, pp_n_r1, pp_n_s1;
+  uint32_t *pp_local_a, *pp_local_b, *pp_r1, *pp_s1;
   uint32_t recycle_at;  /* the tick whose recycling pass has already run (sharded hosts run it before step_begin) */
   uint32_t* walk;       /* [n_walk] allocated slots in ascending SUBJECT order: the order every per-node walk over
                          * the view uses (Reaper, push-pull merge), so that it does not depend on how slots were
@@ -1061,65 +1074,111 @@ static void pp_params(const sim_config* c, uint32_t* step, uint32_t* groups) {
   uint64_t st = iv / PP_GROUPS;
   *step = st < 1 ? 1u : st > 0x7FFFFFFFu ? 0x7FFFFFFFu : (uint32_t)st;
 }
-/* local <- remote: memberlist mergeState, then SerfDelegate::merge_remote_state(is_join = false) */
-static void pp_merge(osim* s, uint32_t ll, uint32_t lr) {
+/* What one side of a push-pull ships to the other (memberlist's node states + SerfDelegate::local_state,
+ * delegate.rs:386-425), as one flat record — the same bytes whether the partner lives in this process or on another
+ * shard (sim_pp_export / sim_pp_merge): 32-byte header {clock, event_clock, query_clock, 0}, the 16-byte heads
+ * {ltime, inc, bits} of the view entries in walk (subject) order, the event ring's buckets. */
+typedef struct pp_head { uint64_t ltime; uint32_t inc, bits; } pp_head;
+static size_t pp_record_bytes(const osim* s) { return 32 + (size_t)s->n_walk * sizeof(pp_head) + (size_t)s->Bev * sizeof(sim_bucket); }
+static void pp_pack(const osim* s, uint32_t l, uint8_t* rec) {
+  const sim_row* r = &s->rows[l];
+  uint64_t hdr[4] = {r->clock, r->event_clock, r->query_clock, 0};
+  memcpy(rec, hdr, 32);
+  pp_head* h = (pp_head*)(rec + 32);
+  for (uint32_t wi = 0; wi < s->n_walk; ++wi) {
+    const sim_view* e = &s->view[(size_t)s->walk[wi] * s->Nl + l];
+    h[wi].ltime = e->ltime; h[wi].inc = e->inc; h[wi].bits = e->bits;
+  }
+  sim_bucket* b = (sim_bucket*)(rec + 32 + (size_t)s->n_walk * sizeof(pp_head));
+  for (uint32_t idx = 0; idx < s->Bev; ++idx) b[idx] = s->ering[(size_t)idx * s->Nl + l];
+}
+/* local <- remote record: memberlist mergeState, then SerfDelegate::merge_remote_state(is_join = false) */
+static void pp_merge(osim* s, uint32_t ll, const uint8_t* rec) {
   nctx c;
   nctx_init(&c, s, ll);
-  const sim_row* rr = &s->rows[lr];
+  uint64_t hdr[4];
+  memcpy(hdr, rec, 32);
+  const pp_head* rh = (const pp_head*)(rec + 32);
+  const sim_bucket* rbk = (const sim_bucket*)(rec + 32 + (size_t)s->n_walk * sizeof(pp_head));
   /* queue ids: renumber whenever fewer than 64 are left, before anything can be queued (a merge can
    * queue one broadcast per view slot) */
 #define PP_GUARD() do { if (c.row->next_seq > 1023u - 64u) queue_renorm(c.row, c.q); } while (0)
   PP_GUARD();
   if (s->swim) { /* mergeState (B.6): alive as alive, left as dead{from = node}, suspect and dead as suspect */
     for (uint32_t wi = 0; wi < s->n_walk; ++wi) {
-      uint32_t a = s->walk[wi];
-      const sim_view* re = &s->view[(size_t)a * s->Nl + lr];
+      const pp_head* re = &rh[wi];
       if (!(re->bits & SIM_VB_KNOWN)) continue;
       PP_GUARD();
-      uint32_t subj = s->subject_of[a], sw = SIM_VB_SWIM(re->bits), inc = re->inc;
+      uint32_t subj = s->subject_of[s->walk[wi]], sw = SIM_VB_SWIM(re->bits), inc = re->inc;
       if (sw == SIM_SWIM_ALIVE) swim_alive(&c, subj, inc, wire_meta(SIM_K_ALIVE, 0, 64));
       else if (sw == SIM_SWIM_LEFT) swim_dead(&c, subj, inc, subj, wire_meta(SIM_K_DEAD, 0, 32));
       else swim_suspect(&c, subj, inc, c.gid, wire_meta(SIM_K_SUSPECT, 0, 32));
     }
   }
-  if (rr->clock > 0) lc_witness(&c.row->clock, rr->clock - 1);                   /* delegate.rs:466-468 */
-  if (rr->event_clock > 0) lc_witness(&c.row->event_clock, rr->event_clock - 1); /* delegate.rs:469-474 */
-  if (rr->query_clock > 0) lc_witness(&c.row->query_clock, rr->query_clock - 1); /* delegate.rs:475-480 */
+  if (hdr[0] > 0) lc_witness(&c.row->clock, hdr[0] - 1);       /* delegate.rs:466-468 */
+  if (hdr[1] > 0) lc_witness(&c.row->event_clock, hdr[1] - 1); /* delegate.rs:469-474 */
+  if (hdr[2] > 0) lc_witness(&c.row->query_clock, hdr[2] - 1); /* delegate.rs:475-480 */
   for (uint32_t wi = 0; wi < s->n_walk; ++wi) { /* left members first, at status_ltime + 1: delegate.rs:495-512 */
-    uint32_t a = s->walk[wi];
-    const sim_view* re = &s->view[(size_t)a * s->Nl + lr];
+    const pp_head* re = &rh[wi];
     if ((re->bits & SIM_VB_KNOWN) && SIM_VB_STATUS(re->bits) == SIM_STATUS_LEFT) {
       PP_GUARD();
-      handle_leave_intent(&c, s->subject_of[a], re->ltime + 1, 0);
+      handle_leave_intent(&c, s->subject_of[s->walk[wi]], re->ltime + 1, 0);
     }
   }
   for (uint32_t wi = 0; wi < s->n_walk; ++wi) { /* every other status_ltime as a join intent: delegate.rs:515-526 */
-    uint32_t a = s->walk[wi];
-    const sim_view* re = &s->view[(size_t)a * s->Nl + lr];
+    const pp_head* re = &rh[wi];
     if ((re->bits & SIM_VB_KNOWN) && SIM_VB_STATUS(re->bits) != SIM_STATUS_LEFT)
-      handle_join_intent(&c, s->subject_of[a], re->ltime);
+      handle_join_intent(&c, s->subject_of[s->walk[wi]], re->ltime);
   }
   for (uint32_t idx = 0; idx < s->Bev; ++idx) { /* replay the remote event buffer: delegate.rs:540-552 */
-    const sim_bucket* rb = &s->ering[(size_t)idx * s->Nl + lr];
+    const sim_bucket* rb = &rbk[idx];
     for (uint32_t k = 0; k < SIM_C && rb->keys[k]; ++k) handle_user_event(&c, rb->keys[k], rb->ltime);
   }
 #undef PP_GUARD
 }
-static void pp_pair(osim* s, const tickp* p, uint32_t g, uint32_t pi) {
-  uint32_t xa = 2 * pi, xb = 2 * pi + 1;
-  if (xb >= p->M) return;
-  uint32_t base = s->cfg.shard_count > 1 ? 0 : g * p->M; /* local index of the shard's first node */
-  uint32_t la = base + sigma_inv(p, xa), lb = base + sigma_inv(p, xb);
-  if (!(s->rows[la].flags & SIM_RF_UP) || !(s->rows[lb].flags & SIM_RF_UP)) return;
-  pp_merge(s, la, lb);
-  pp_merge(s, lb, la);
+/* The pairs of a batch: the tick's matching {sigma_N^-1(2 pi), sigma_N^-1(2 pi + 1)} over ALL N nodes — memberlist's
+ * pushPull picks any peer (App. B.6), whichever shard it lives on — restricted to class pi mod PP_GROUPS.  The node
+ * with the even sigma value (`a`) merges first, then `b` merges a's updated state. */
+static inline uint32_t permg_f(const tickp* p, uint32_t x) {
+  x = (x * p->mul[0] + p->add[0]) & p->gmask;
+  x ^= x >> p->gshift;
+  x = (x * p->mul[1] + p->add[1]) & p->gmask;
+  x ^= x >> p->gshift;
+  x = (x * p->mul[2] + p->add[2]) & p->gmask;
+  return x;
 }
+static inline uint32_t permg_fi(const tickp* p, uint32_t y) {
+  y = ((y - p->add[2]) * p->imul[2]) & p->gmask;
+  y ^= y >> p->gshift;
+  y = ((y - p->add[1]) * p->imul[1]) & p->gmask;
+  y ^= y >> p->gshift;
+  y = ((y - p->add[0]) * p->imul[0]) & p->gmask;
+  return y;
+}
+static inline uint32_t sigma_g_inv(const tickp* p, uint32_t y) { do y = permg_fi(p, y); while (y >= p->N); return y; }
+static int pp_batch_class(const osim* s, uint32_t* cls) {
+  if (!s->pp_step || s->tick == 0 || s->tick % s->pp_step) return 0;
+  *cls = (uint32_t)((s->tick / s->pp_step) % s->pp_groups);
+  return 1;
+}
+static int pp_both_up(const osim* s, uint32_t ga, uint32_t gb) { return up_of(s, ga) && up_of(s, gb); } /* a TCP exchange needs both ends */
 static void pp_round(osim* s, const tickp* p) {
-  if (!s->pp_step || s->tick == 0 || s->tick % s->pp_step) return;
-  uint32_t cls = (uint32_t)((s->tick / s->pp_step) % s->pp_groups);
-  uint32_t shards = s->cfg.shard_count > 1 ? 1 : p->V;
-  for (uint32_t g = 0; g < shards; ++g)
-    for (uint32_t pi = cls; 2 * pi + 1 < p->M; pi += s->pp_groups) pp_pair(s, p, g, pi);
+  uint32_t cls;
+  if (!pp_batch_class(s, &cls)) return;
+  if (s->cfg.shard_count > 1) {
+    if (s->pp_done_at == (uint32_t)s->tick) return; /* the host drove it (sim_pp_plan / export / merge) */
+    /* in-shard pairs only would be a different protocol: the sharded host has to run the exchange */
+    return;
+  }
+  size_t rb = pp_record_bytes(s);
+  uint8_t* rec = (uint8_t*)malloc(rb);
+  for (uint32_t pi = cls; 2 * (uint64_t)pi + 1 < p->N; pi += s->pp_groups) {
+    uint32_t ga = sigma_g_inv(p, 2 * pi), gb = sigma_g_inv(p, 2 * pi + 1);
+    if (!pp_both_up(s, ga, gb)) continue;
+    pp_pack(s, gb, rec); pp_merge(s, ga, rec);
+    pp_pack(s, ga, rec); pp_merge(s, gb, rec);
+  }
+  free(rec);
 }
 
 /* =====================================================================================
@@ -1315,7 +1374,7 @@ int API(destroy)(osim* s) {
   if (!s) return SIM_EINVAL;
   free(s->rows); free(s->queue); free(s->inbox[0]); free(s->inbox[1]);
   if (s->own_x) { free(s->xsend); free(s->xrecv); }
-  free(s->view); free(s->ering); free(s->qring); free(s->slot_of); free(s->subject_of); free(s->walk); free(s->alloc_tick); free(s->rtgt); free(s->rcsr); free(s->rsrc);
+  free(s->view); free(s->ering); free(s->qring); free(s->slot_of); free(s->subject_of); free(s->walk); free(s->alloc_tick); free(s->pp_local_a); free(s->pp_local_b); free(s->pp_r1); free(s->pp_s1); free(s->rtgt); free(s->rcsr); free(s->rsrc);
   free(s->base); free(s->ops); free(s->events); free(s->upmap); free(s->qbits); free(s);
   return SIM_OK;
 }
@@ -1354,6 +1413,7 @@ int API(create)(const sim_config* cfg, osim** out) {
   s->walk = (uint32_t*)malloc((size_t)s->A * sizeof(uint32_t));
   s->alloc_tick = (uint32_t*)calloc((size_t)s->A, sizeof(uint32_t));
   s->recycle_at = 0xFFFFFFFFu;
+  s->pp_done_at = 0xFFFFFFFFu;
   s->base = (sim_view*)calloc(s->N, sizeof(sim_view));
   s->upmap = (uint32_t*)malloc(((size_t)s->N + 31) / 32 * sizeof(uint32_t));
   if (s->upmap) memset(s->upmap, 0xFF, ((size_t)s->N + 31) / 32 * sizeof(uint32_t));
@@ -1599,7 +1659,14 @@ int API(query)(osim* s, uint32_t node, uint32_t id, uint32_t flags) {
 
 int API(step)(osim* s, uint32_t n) {
   if (!s) return SIM_EINVAL;
-  for (uint32_t i = 0; i < n; ++i) step_one(s);
+  for (uint32_t i = 0; i < n; ++i) {
+    if (s->cfg.shard_count > 1) { /* needs the host between begin and end when a cross-shard push-pull batch is due */
+      uint32_t cls;
+      if (recycle_due(s)) return SIM_ESTATE;
+      if (pp_batch_class(s, &cls) && s->pp_done_at != (uint32_t)s->tick) return SIM_ESTATE;
+    }
+    step_one(s);
+  }
   return SIM_OK;
 }
 int API(sync)(osim* s) { return s ? SIM_OK : SIM_EINVAL; }
@@ -1819,6 +1886,7 @@ int API(restore)(osim* s, const void* buf, size_t bytes) {
   walk_rebuild(s);
   s->n_alloc = s->n_walk;
   s->recycle_at = 0xFFFFFFFFu;
+  s->pp_done_at = 0xFFFFFFFFu;
   return SIM_OK;
 }
 
@@ -1921,6 +1989,76 @@ int API(exchange_chunks)(const osim* s, uint32_t* chunks, size_t* bytes_per_chun
   *bytes_per_chunk = s->cfg.shard_count > 1 ? (size_t)s->f * s->M * sizeof(sim_packet) / C : 0;
   return SIM_OK;
 }
+/* ---- cross-shard push-pull, driven by the sharded host (include/serf_sim.h) ---- */
+int API(pp_due)(const osim* s) {
+  uint32_t cls;
+  if (!s) return SIM_EINVAL;
+  return s->cfg.shard_count > 1 && pp_batch_class(s, &cls) && s->pp_done_at != (uint32_t)s->tick;
+}
+int API(pp_plan)(osim* s, uint32_t* send1, uint32_t* recv1, size_t* record_bytes) {
+  uint32_t cls;
+  if (!s || !send1 || !recv1 || !record_bytes) return SIM_EINVAL;
+  if (!s->in_tick || s->cfg.shard_count <= 1 || !pp_batch_class(s, &cls)) return SIM_ESTATE; /* after sim_step_begin: the tick's operations come first */
+  tickp p;
+  tickp_make(&p, &s->cfg, s->tick);
+  uint32_t V = s->V, me = s->cfg.shard_rank, M = s->M;
+  memset(send1, 0, V * sizeof(uint32_t));
+  memset(recv1, 0, V * sizeof(uint32_t));
+  free(s->pp_local_a); free(s->pp_local_b); free(s->pp_r1); free(s->pp_s1);
+  size_t cap = (size_t)s->N / (2 * s->pp_groups) + 2;
+  s->pp_local_a = (uint32_t*)malloc(cap * 4); s->pp_local_b = (uint32_t*)malloc(cap * 4);
+  s->pp_r1 = (uint32_t*)malloc(cap * 4); s->pp_s1 = (uint32_t*)malloc(cap * 4);
+  s->pp_n_local = s->pp_n_r1 = s->pp_n_s1 = 0;
+  for (int pass = 0; pass < 2; ++pass) { /* pass 0 counts per peer, pass 1 fills the peer-grouped lists */
+    uint32_t *off_r = (uint32_t*)calloc(V + 1, 4), *off_s = (uint32_t*)calloc(V + 1, 4);
+    if (pass == 1)
+      for (uint32_t h = 0; h < V; ++h) { off_r[h + 1] = off_r[h] + recv1[h]; off_s[h + 1] = off_s[h] + send1[h]; }
+    for (uint32_t pi = cls; 2 * (uint64_t)pi + 1 < p.N; pi += s->pp_groups) {
+      uint32_t ga = sigma_g_inv(&p, 2 * pi), gb = sigma_g_inv(&p, 2 * pi + 1);
+      if (!pp_both_up(s, ga, gb)) continue;
+      uint32_t oa = ga / M, ob = gb / M;
+      if (oa == me && ob == me) {
+        if (pass == 1) { s->pp_local_a[s->pp_n_local] = ga - s->shard0; s->pp_local_b[s->pp_n_local++] = gb - s->shard0; }
+      } else if (oa == me) {
+        if (pass == 0) recv1[ob]++; else s->pp_r1[off_r[ob]++] = ga - s->shard0;
+      } else if (ob == me) {
+        if (pass == 0) send1[oa]++; else s->pp_s1[off_s[oa]++] = gb - s->shard0;
+      }
+    }
+    if (pass == 1) { s->pp_n_r1 = off_r[V - 1] ; s->pp_n_s1 = off_s[V - 1]; /* = totals after the fill */ }
+    free(off_r); free(off_s);
+  }
+  s->pp_n_r1 = 0; s->pp_n_s1 = 0;
+  for (uint32_t h = 0; h < V; ++h) { s->pp_n_r1 += recv1[h]; s->pp_n_s1 += send1[h]; }
+  *record_bytes = pp_record_bytes(s);
+  return SIM_OK;
+}
+int API(pp_export)(osim* s, int round, void* send) {
+  if (!s || (round != 1 && round != 2)) return SIM_EINVAL;
+  size_t rb = pp_record_bytes(s);
+  const uint32_t* list = round == 1 ? s->pp_s1 : s->pp_r1;
+  uint32_t n = round == 1 ? s->pp_n_s1 : s->pp_n_r1;
+  if (n && !send) return SIM_EINVAL;
+  for (uint32_t i = 0; i < n; ++i) pp_pack(s, list[i], (uint8_t*)send + (size_t)i * rb);
+  return SIM_OK;
+}
+int API(pp_merge)(osim* s, int round, const void* recv) {
+  if (!s || (round != 1 && round != 2)) return SIM_EINVAL;
+  size_t rb = pp_record_bytes(s);
+  if (round == 1) {
+    uint8_t* rec = (uint8_t*)malloc(rb);
+    for (uint32_t i = 0; i < s->pp_n_local; ++i) {
+      pp_pack(s, s->pp_local_b[i], rec); pp_merge(s, s->pp_local_a[i], rec);
+      pp_pack(s, s->pp_local_a[i], rec); pp_merge(s, s->pp_local_b[i], rec);
+    }
+    free(rec);
+    for (uint32_t i = 0; i < s->pp_n_r1; ++i) pp_merge(s, s->pp_r1[i], (const uint8_t*)recv + (size_t)i * rb);
+  } else {
+    for (uint32_t i = 0; i < s->pp_n_s1; ++i) pp_merge(s, s->pp_s1[i], (const uint8_t*)recv + (size_t)i * rb);
+    s->pp_done_at = (uint32_t)s->tick;
+  }
+  return SIM_OK;
+}
 int API(recycle_due)(const osim* s) { return s ? recycle_due(s) : SIM_EINVAL; }
 int API(recycle_scan)(osim* s, sim_recycle_cand* out, uint32_t cap, uint32_t* n) {
   if (!s || !out || !n || cap < SIM_RECYCLE_BATCH) return SIM_EINVAL;
@@ -1940,6 +2078,7 @@ int API(step_begin)(osim* s) {
   if (!s) return SIM_EINVAL;
   if (s->in_tick) return SIM_ESTATE;
   if (s->cfg.shard_count > 1 && recycle_due(s)) return SIM_ESTATE; /* the host runs the pass first (it needs every shard) */
+
   step_begin(s);
   return SIM_OK;
 }
@@ -1947,6 +2086,7 @@ int API(step_chunk)(osim* s, uint32_t chunk) {
   if (!s) return SIM_EINVAL;
   if (!s->in_tick) return SIM_ESTATE;
   if (s->cfg.shard_count <= 1 || chunk >= s->cur.C) return SIM_EINVAL;
+  if (API(pp_due)(s) > 0) return SIM_ESTATE; /* the push-pull batch of this tick comes first (its pairs span shards: the host runs it) */
   step_chunk(s, s->cur.C == 1 ? NOSLOT : chunk);
   return SIM_OK;
 }

@@ -94,7 +94,7 @@ ABI_SYMBOLS = ("create", "destroy", "set_stream", "join", "leave", "force_leave"
                "drain_events", "state_digest", "dump_state", "convergence", "exchange_bytes",
                "bind_exchange", "snapshot", "restore", "query_status", "profile", "profile_read", "profile_read_stats", "cluster_stats_get",
                "bind_exchange2", "exchange_chunks", "step_begin", "step_chunk", "step_end",
-               "recycle_due", "recycle_scan", "recycle_apply",
+               "recycle_due", "recycle_scan", "recycle_apply", "pp_due", "pp_plan", "pp_export", "pp_merge",
                "abi_version", "backend_name")
 
 
@@ -156,6 +156,10 @@ class SimLib:
             "step_begin": (C.c_int, [H]),
             "step_chunk": (C.c_int, [H, u32]),
             "step_end": (C.c_int, [H]),
+            "pp_due": (C.c_int, [H]),
+            "pp_plan": (C.c_int, [H, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_size_t)]),
+            "pp_export": (C.c_int, [H, C.c_int, vp]),
+            "pp_merge": (C.c_int, [H, C.c_int, vp]),
             "recycle_due": (C.c_int, [H]),
             "recycle_scan": (C.c_int, [H, C.POINTER(RecycleCand), u32, C.POINTER(u32)]),
             "recycle_apply": (C.c_int, [H, C.POINTER(RecycleCand), u32]),
@@ -336,6 +340,21 @@ class Sim:
         c, n = C.c_uint32(), C.c_size_t()
         self._ck(self.lib.f["exchange_chunks"](self.h, C.byref(c), C.byref(n)), "sim_exchange_chunks")
         return c.value, n.value
+
+    def pp_due(self):
+        return self._ck(self.lib.f["pp_due"](self.h), "sim_pp_due") > 0
+
+    def pp_plan(self, n_shards):
+        """(records to send to each peer in round 1, records to receive from each peer, bytes per record)."""
+        snd, rcv, rb = (C.c_uint32 * n_shards)(), (C.c_uint32 * n_shards)(), C.c_size_t()
+        self._ck(self.lib.f["pp_plan"](self.h, snd, rcv, C.byref(rb)), "sim_pp_plan")
+        return list(snd), list(rcv), rb.value
+
+    def pp_export(self, rnd, send_ptr):
+        self._ck(self.lib.f["pp_export"](self.h, rnd, C.c_void_p(send_ptr)), "sim_pp_export")
+
+    def pp_merge(self, rnd, recv_ptr):
+        self._ck(self.lib.f["pp_merge"](self.h, rnd, C.c_void_p(recv_ptr)), "sim_pp_merge")
 
     def recycle_due(self):
         return self._ck(self.lib.f["recycle_due"](self.h), "sim_recycle_due") > 0

@@ -73,6 +73,7 @@ struct TickP {  // per-tick parameters, passed by value (lands in SGPRs)
   // nodes (64, or 1 for small / ragged shards), nbc = V * sub / B blocks per chunk, bmask/bshift: bit width of the
   // block permutation
   u32 C, sub, B, nbc, bmask, bshift;
+  u32 N, gmask, gshift;  // push-pull pairs come from a permutation of all N nodes
   u32 mul[3], add[3], imul[3];
   u32 off[SIM_MAX_FANOUT], rot[SIM_MAX_FANOUT], rho[SIM_MAX_FANOUT];
   u32 prot[SIM_MAX_FANOUT], prho[SIM_MAX_FANOUT];  // rot[] / rho[] of the previous tick (sharded reads)
@@ -94,6 +95,14 @@ static void tickp_make(TickP* p, const sim_config* c, u64 tick) {
   if (nbits < 1) nbits = 1;
   p->mask = nbits >= 32 ? 0xFFFFFFFFu : ((1u << nbits) - 1u);
   p->shift = (nbits + 1) / 2;
+  p->N = c->n_nodes;
+  {
+    u32 gb = 0;
+    while (gb < 32 && (1ull << gb) < p->N) ++gb;
+    if (gb < 1) gb = 1;
+    p->gmask = gb >= 32 ? 0xFFFFFFFFu : ((1u << gb) - 1u);
+    p->gshift = (gb + 1) / 2;
+  }
   p->C = c->chunks ? c->chunks : 1;
   p->sub = p->blk / p->C;
   p->B = (p->sub % 64u == 0 && (u64)p->V * p->sub / 64u >= 8u) ? 64u : 1u;
@@ -167,6 +176,17 @@ __device__ static inline u32 pi_inv(const TickP& p, u32 y) {
     y ^= y >> p.bshift;
     y = ((y - p.add[0]) * p.imul[0]) & p.bmask;
   } while (y >= p.nbc);
+  return y;
+}
+// the permutation of all N nodes the push-pull matching comes from (host and device: the sharded host plans with it)
+__host__ __device__ static inline u32 sigma_g_inv(const TickP& p, u32 y) {
+  do {
+    y = ((y - p.add[2]) * p.imul[2]) & p.gmask;
+    y ^= y >> p.gshift;
+    y = ((y - p.add[1]) * p.imul[1]) & p.gmask;
+    y ^= y >> p.gshift;
+    y = ((y - p.add[0]) * p.imul[0]) & p.gmask;
+  } while (y >= p.N);
   return y;
 }
 __device__ static inline u32 sigma(const TickP& p, u32 x) {
@@ -1458,8 +1478,35 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
 // and happens once per (scaled interval / PP_GROUPS) ticks: off the per-tick critical path.
 // ------------------------------------------------------------------------------------------------
 #define PP_GROUPS 8u
+// What one side of a push-pull ships to the other (memberlist's node states + SerfDelegate::local_state,
+// delegate.rs:386-425): the three clocks, the 16-byte heads of the view entries in walk (subject) order, the event
+// ring.  The partner's copy is read either in place (it lives on this shard) or from a flat record a remote shard
+// exported (sim_pp_export): [0] {clock, event_clock} [1] {query_clock, 0} [2 .. 2+ns) heads [..] Bev x {head, tail}.
+struct PPLocal {
+  const Dev& d;
+  u32 lr;
+  __device__ void clocks(u64& c, u64& e, u64& q) const {
+    uint4 r0 = d.R0[lr], r1 = d.R1[lr];
+    c = (u64)r0.x | ((u64)r0.y << 32); e = (u64)r0.z | ((u64)r0.w << 32); q = (u64)r1.x | ((u64)r1.y << 32);
+  }
+  __device__ uint4 head(u32 wi) const { return d.view[(size_t)d.walk[wi] * d.Nl + lr]; }
+  __device__ uint4 bucket_head(u32 idx) const { return d.ering[(size_t)idx * d.Nl + lr]; }
+  __device__ uint4 bucket_tail(u32 idx) const { return d.ering[d.etail + (size_t)idx * d.Nl + lr]; }
+};
+struct PPRecord {
+  const uint4* rec;
+  u32 ns;
+  __device__ void clocks(u64& c, u64& e, u64& q) const {
+    uint4 r0 = rec[0], r1 = rec[1];
+    c = (u64)r0.x | ((u64)r0.y << 32); e = (u64)r0.z | ((u64)r0.w << 32); q = (u64)r1.x | ((u64)r1.y << 32);
+  }
+  __device__ uint4 head(u32 wi) const { return rec[2 + wi]; }
+  __device__ uint4 bucket_head(u32 idx) const { return rec[2 + ns + 2 * (size_t)idx]; }
+  __device__ uint4 bucket_tail(u32 idx) const { return rec[2 + ns + 2 * (size_t)idx + 1]; }
+};
 // local <- remote: memberlist mergeState, then merge_remote_state(is_join = false)
-__device__ static void pp_merge(const Dev& d, const TickP& tp, u32 ll, u32 lr) {
+template <class Remote>
+__device__ static void pp_merge(const Dev& d, const TickP& tp, u32 ll, const Remote& rm) {
   Ctx c{d, ll, d.shard0 + ll, (u32)tp.tick, tp.query_base};
   Node n;
   node_load(d, ll, n);
@@ -1473,7 +1520,7 @@ __device__ static void pp_merge(const Dev& d, const TickP& tp, u32 ll, u32 lr) {
 #pragma unroll 1
     for (u32 wi = 0; wi < tp.n_slots; ++wi) {
       u32 a = d.walk[wi];
-      uint4 re = d.view[(size_t)a * d.Nl + lr];
+      uint4 re = rm.head(wi);
       if (!(re.w & SIM_VB_KNOWN)) continue;
       if (n.next_seq > 1023u - 64u) q_renorm(n, sk);  // a merge can queue one broadcast per view slot
       u32 subj = d.subject_of[a], sw = SIM_VB_SWIM(re.w), inc = re.z;
@@ -1487,8 +1534,8 @@ __device__ static void pp_merge(const Dev& d, const TickP& tp, u32 ll, u32 lr) {
       if (ins.has) q_insert(c, n, sk, ins.key, ins.wmeta, ins.val);
     }
   }
-  uint4 r0 = d.R0[lr], r1 = d.R1[lr];
-  u64 rclock = (u64)r0.x | ((u64)r0.y << 32), reclock = (u64)r0.z | ((u64)r0.w << 32), rqclock = (u64)r1.x | ((u64)r1.y << 32);
+  u64 rclock, reclock, rqclock;
+  rm.clocks(rclock, reclock, rqclock);
   if (rclock > 0) witness(n, n.clock, rclock - 1, DR0);     // delegate.rs:466-480
   if (reclock > 0) witness(n, n.eclock, reclock - 1, DR0);
   if (rqclock > 0) witness(n, n.qclock, rqclock - 1, DR1);
@@ -1497,7 +1544,7 @@ __device__ static void pp_merge(const Dev& d, const TickP& tp, u32 ll, u32 lr) {
 #pragma unroll 1
     for (u32 wi = 0; wi < tp.n_slots; ++wi) {
       u32 a = d.walk[wi];
-      uint4 re = d.view[(size_t)a * d.Nl + lr];
+      uint4 re = rm.head(wi);
       if (!(re.w & SIM_VB_KNOWN)) continue;
       bool left = SIM_VB_STATUS(re.w) == SIM_STATUS_LEFT;
       if (left != (pass == 0)) continue;
@@ -1514,10 +1561,9 @@ __device__ static void pp_merge(const Dev& d, const TickP& tp, u32 ll, u32 lr) {
   }
 #pragma unroll 1
   for (u32 idx = 0; idx < d.Bev; ++idx) {  // replay the remote event buffer: delegate.rs:540-552
-    const uint4* rb = d.ering + ((size_t)idx * d.Nl + lr);
-    uint4 b0 = rb[0];
+    uint4 b0 = rm.bucket_head(idx);
     if (!b0.z) continue;
-    uint4 b1 = b0.w ? rb[d.etail] : zero;
+    uint4 b1 = b0.w ? rm.bucket_tail(idx) : zero;
     u64 lt = E_LTIME(b0);
     u32 keys[SIM_C] = {b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
@@ -1531,16 +1577,47 @@ __device__ static void pp_merge(const Dev& d, const TickP& tp, u32 ll, u32 lr) {
   node_store(d, ll, n);
   keys_store(d, ll, cnt0, n.used, sk);
 }
-__global__ void pushpull_kernel(Dev d, TickP tp, u32 cls, u32 per_shard, u32 shards) {
+// The pairs of a batch: the tick's matching {sigma_N^-1(2 pi), sigma_N^-1(2 pi + 1)} over ALL N nodes — memberlist's
+// pushPull picks any peer (App. B.6), whichever shard it lives on — restricted to class pi mod PP_GROUPS.  The node
+// with the even sigma value merges first, then the other merges its updated state.  This kernel: every shard local.
+__global__ void pushpull_kernel(Dev d, TickP tp, u32 cls, u32 n_pairs) {
   u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= per_shard * shards) return;
-  u32 g = j / per_shard, pi = cls + (j - g * per_shard) * PP_GROUPS;
-  if (2 * pi + 1 >= tp.M) return;
-  u32 base = d.sharded ? 0u : g * tp.M;
-  u32 la = base + sigma_inv(tp, 2 * pi), lb = base + sigma_inv(tp, 2 * pi + 1);
-  if (!(d.R1[la].z & SIM_RF_UP) || !(d.R1[lb].z & SIM_RF_UP)) return;  // a TCP exchange needs both ends
-  pp_merge(d, tp, la, lb);
-  pp_merge(d, tp, lb, la);
+  if (j >= n_pairs) return;
+  u32 pi = cls + j * PP_GROUPS;
+  if (2 * (u64)pi + 1 >= tp.N) return;
+  u32 la = sigma_g_inv(tp, 2 * pi), lb = sigma_g_inv(tp, 2 * pi + 1);
+  if (!up_of(d, la) || !up_of(d, lb)) return;  // a TCP exchange needs both ends
+  pp_merge(d, tp, la, PPLocal{d, lb});
+  pp_merge(d, tp, lb, PPLocal{d, la});
+}
+// sharded runs (host-planned, sim_pp_*): the in-shard pairs ...
+__global__ void pp_local_kernel(Dev d, TickP tp, const u32* la, const u32* lb, u32 n) {
+  u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  pp_merge(d, tp, la[j], PPLocal{d, lb[j]});
+  pp_merge(d, tp, lb[j], PPLocal{d, la[j]});
+}
+// ... the records this shard ships (one block per record: `ns` view heads + the event ring) ...
+__global__ void pp_export_kernel(Dev d, const u32* list, u32 ns, uint4* out, size_t rec_u4) {
+  u32 l = list[blockIdx.x];
+  uint4* o = out + (size_t)blockIdx.x * rec_u4;
+  for (size_t i = threadIdx.x; i < rec_u4; i += blockDim.x) {
+    uint4 v;
+    if (i == 0) v = d.R0[l];
+    else if (i == 1) { uint4 r1 = d.R1[l]; v = make_uint4(r1.x, r1.y, 0, 0); }
+    else if (i < 2 + (size_t)ns) v = d.view[(size_t)d.walk[i - 2] * d.Nl + l];
+    else {
+      size_t k = i - 2 - ns;
+      v = d.ering[((k & 1) ? d.etail : 0) + (k >> 1) * d.Nl + l];
+    }
+    o[i] = v;
+  }
+}
+// ... and the merges from the records it received
+__global__ void pp_cross_kernel(Dev d, TickP tp, const u32* list, u32 n, const uint4* recs, size_t rec_u4) {
+  u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  pp_merge(d, tp, list[j], PPRecord{recs + (size_t)j * rec_u4, tp.n_slots});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1891,6 +1968,11 @@ struct sim_handle {
   u32 n_alloc;                  // slots in use
   u64 ops_dropped, slots_recycled;
   u32 recycle_at;               // the tick whose recycling pass has already run
+  u32 pp_done_at;               // the tick whose push-pull batch the sharded host has already run
+  // the batch being driven by the sharded host: in-shard pairs, and the cross-shard pairs grouped by peer shard in
+  // ascending pair order — r1: this shard owns the even node `a` (receives b in round 1, sends a in round 2); s1: owns `b`
+  std::vector<u32> pp_local_a, pp_local_b, pp_r1, pp_s1;
+  u32* d_pp;                    // the four lists on the device, back to back
   std::vector<sim_view> base;
   uint4* d_base;  // [N][2]
   std::vector<OpEnt> ops;
@@ -2002,6 +2084,7 @@ int sim_destroy(sim_handle* h) {
   if (!h) return SIM_EINVAL;
   (void)hipStreamSynchronize(h->stream);
   for (auto& pr : h->prof) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  if (h->d_pp) (void)hipFree(h->d_pp);
   for (void* p : h->allocs) (void)hipFree(p);
   delete h;
   return SIM_OK;
@@ -2023,6 +2106,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   h->op_cursor = 0;
   h->bound = false;
   h->n_alloc = 0; h->ops_dropped = h->slots_recycled = 0; h->recycle_at = 0xFFFFFFFFu;
+  h->pp_done_at = 0xFFFFFFFFu; h->d_pp = nullptr;
   h->in_tick = false;
   h->tick_timed = false;
   h->rbuf[0] = h->rbuf[1] = nullptr;
@@ -2332,6 +2416,97 @@ int sim_query(sim_handle* h, uint32_t node, uint32_t id, uint32_t flags) {
 // (sim_step_chunk; a single launch when there is one chunk or all shards are local), sim_step_end.  sim_step does all
 // of it; a sharded host that wants the exchange of chunk c in flight while chunk c + 1 computes drives the three
 // calls itself (serf_amd/shard.py).
+// ---- cross-shard push-pull, driven by the sharded host (include/serf_sim.h; oracle pp_plan / pp_export / pp_merge) ----
+static bool pp_batch_class(const sim_handle* h, u32* cls) {
+  if (!h->pp_step || h->tick == 0 || h->tick % h->pp_step) return false;
+  *cls = (u32)((h->tick / h->pp_step) % PP_GROUPS);
+  return true;
+}
+int sim_pp_due(const sim_handle* h) {
+  u32 cls;
+  if (!h) return SIM_EINVAL;
+  return (h->d.sharded && pp_batch_class(h, &cls) && h->pp_done_at != (u32)h->tick) ? 1 : 0;
+}
+int sim_pp_plan(sim_handle* h, uint32_t* send1, uint32_t* recv1, size_t* record_bytes) {
+  u32 cls;
+  if (!h || !send1 || !recv1 || !record_bytes) return SIM_EINVAL;
+  if (!h->in_tick || !h->d.sharded || !pp_batch_class(h, &cls)) return SIM_ESTATE;  // after sim_step_begin: the tick's operations come first
+  Dev& d = h->d;
+  const TickP& tp = h->cur_tp;
+  const u32 V = d.V, me = d.shard_rank, M = d.M;
+  std::vector<u32> up(((size_t)d.N + 31) / 32);  // ground-truth liveness after this tick's operations
+  HCHECK(hipMemcpyAsync(up.data(), d.upmap, up.size() * 4, hipMemcpyDeviceToHost, h->stream));
+  HCHECK(hipStreamSynchronize(h->stream));
+  auto is_up = [&](u32 g) { return (up[g >> 5] >> (g & 31)) & 1u; };
+  for (u32 v = 0; v < V; ++v) send1[v] = recv1[v] = 0;
+  h->pp_local_a.clear(); h->pp_local_b.clear();
+  std::vector<std::vector<u32>> r1(V), s1(V);
+  for (u32 pi = cls; 2 * (u64)pi + 1 < tp.N; pi += PP_GROUPS) {
+    u32 ga = sigma_g_inv(tp, 2 * pi), gb = sigma_g_inv(tp, 2 * pi + 1);
+    if (!is_up(ga) || !is_up(gb)) continue;
+    u32 oa = ga / M, ob = gb / M;
+    if (oa == me && ob == me) { h->pp_local_a.push_back(ga - d.shard0); h->pp_local_b.push_back(gb - d.shard0); }
+    else if (oa == me) r1[ob].push_back(ga - d.shard0);
+    else if (ob == me) s1[oa].push_back(gb - d.shard0);
+  }
+  h->pp_r1.clear(); h->pp_s1.clear();
+  for (u32 v = 0; v < V; ++v) {
+    recv1[v] = (u32)r1[v].size(); send1[v] = (u32)s1[v].size();
+    h->pp_r1.insert(h->pp_r1.end(), r1[v].begin(), r1[v].end());
+    h->pp_s1.insert(h->pp_s1.end(), s1[v].begin(), s1[v].end());
+  }
+  // the four lists on the device: local a | local b | r1 | s1
+  size_t tot = h->pp_local_a.size() * 2 + h->pp_r1.size() + h->pp_s1.size();
+  if (h->d_pp) { (void)hipFree(h->d_pp); h->d_pp = nullptr; }
+  if (tot) {
+    if (hipMalloc((void**)&h->d_pp, tot * 4) != hipSuccess) return SIM_ENOMEM;
+    std::vector<u32> all;
+    all.reserve(tot);
+    all.insert(all.end(), h->pp_local_a.begin(), h->pp_local_a.end());
+    all.insert(all.end(), h->pp_local_b.begin(), h->pp_local_b.end());
+    all.insert(all.end(), h->pp_r1.begin(), h->pp_r1.end());
+    all.insert(all.end(), h->pp_s1.begin(), h->pp_s1.end());
+    HCHECK(hipMemcpy(h->d_pp, all.data(), tot * 4, hipMemcpyHostToDevice));
+  }
+  *record_bytes = (2 + (size_t)tp.n_slots + 2 * (size_t)d.Bev) * 16;
+  return SIM_OK;
+}
+int sim_pp_export(sim_handle* h, int round, void* send) {
+  if (!h || (round != 1 && round != 2)) return SIM_EINVAL;
+  if (!h->in_tick || !h->d.sharded) return SIM_ESTATE;
+  Dev& d = h->d;
+  const TickP& tp = h->cur_tp;
+  size_t nl = h->pp_local_a.size();
+  const u32* list = h->d_pp + 2 * nl + (round == 1 ? h->pp_r1.size() : 0);
+  u32 n = (u32)(round == 1 ? h->pp_s1.size() : h->pp_r1.size());
+  if (!n) return SIM_OK;
+  if (!send) return SIM_EINVAL;
+  size_t rec_u4 = 2 + (size_t)tp.n_slots + 2 * (size_t)d.Bev;
+  pp_export_kernel<<<n, 256, 0, h->stream>>>(d, list, tp.n_slots, (uint4*)send, rec_u4);
+  HCHECK(hipGetLastError());
+  return SIM_OK;
+}
+int sim_pp_merge(sim_handle* h, int round, const void* recv) {
+  if (!h || (round != 1 && round != 2)) return SIM_EINVAL;
+  if (!h->in_tick || !h->d.sharded) return SIM_ESTATE;
+  Dev& d = h->d;
+  const TickP& tp = h->cur_tp;
+  size_t nl = h->pp_local_a.size();
+  size_t rec_u4 = 2 + (size_t)tp.n_slots + 2 * (size_t)d.Bev;
+  if (round == 1) {
+    if (nl) pp_local_kernel<<<(unsigned)((nl + 63) / 64), 64, 0, h->stream>>>(d, tp, h->d_pp, h->d_pp + nl, (u32)nl);
+    u32 n = (u32)h->pp_r1.size();
+    if (n && !recv) return SIM_EINVAL;
+    if (n) pp_cross_kernel<<<(n + 63) / 64, 64, 0, h->stream>>>(d, tp, h->d_pp + 2 * nl, n, (const uint4*)recv, rec_u4);
+  } else {
+    u32 n = (u32)h->pp_s1.size();
+    if (n && !recv) return SIM_EINVAL;
+    if (n) pp_cross_kernel<<<(n + 63) / 64, 64, 0, h->stream>>>(d, tp, h->d_pp + 2 * nl + h->pp_r1.size(), n, (const uint4*)recv, rec_u4);
+    h->pp_done_at = (u32)h->tick;
+  }
+  HCHECK(hipGetLastError());
+  return SIM_OK;
+}
 int sim_recycle_due(const sim_handle* h) { return h ? (recycle_is_due(h) ? 1 : 0) : SIM_EINVAL; }
 int sim_recycle_scan(sim_handle* h, sim_recycle_cand* out, uint32_t cap, uint32_t* n) {
   if (!h || !out || !n || cap < SIM_RECYCLE_BATCH) return SIM_EINVAL;
@@ -2381,11 +2556,10 @@ int sim_step_begin(sim_handle* h) {
     if (ob.n) ops_kernel<<<1, 64, 0, h->stream>>>(d, ob, h->tick, d.N > 1 ? 1u : 0u, tp.query_base, h->q_timeout);
   }
   tp.n_slots = (u32)h->walk.size();  // after the operations: they may have taken slots
-  if (h->pp_step && h->tick > 0 && h->tick % h->pp_step == 0) {
+  if (!d.sharded && h->pp_step && h->tick > 0 && h->tick % h->pp_step == 0) {  // (sharded: the host runs the batch, sim_pp_*)
     u32 cls = (u32)((h->tick / h->pp_step) % PP_GROUPS);
-    u32 half = tp.M / 2, per_shard = half > cls ? (half - cls + PP_GROUPS - 1) / PP_GROUPS : 0;
-    u32 shards = d.sharded ? 1u : tp.V;
-    if (per_shard) pushpull_kernel<<<(per_shard * shards + 63) / 64, 64, 0, h->stream>>>(d, tp, cls, per_shard, shards);
+    u32 half = tp.N / 2, n_pairs = half > cls ? (half - cls + PP_GROUPS - 1) / PP_GROUPS : 0;
+    if (n_pairs) pushpull_kernel<<<(n_pairs + 63) / 64, 64, 0, h->stream>>>(d, tp, cls, n_pairs);
   }
   h->tick_timed = h->profiling && (h->prof_seq++ % h->profiling) == 0;
   if (h->tick_timed) {
@@ -2420,6 +2594,7 @@ int sim_step_chunk(sim_handle* h, uint32_t chunk) {
   if (!h) return SIM_EINVAL;
   if (!h->in_tick) return SIM_ESTATE;
   if (!h->d.sharded || chunk >= h->cur_tp.C) return SIM_EINVAL;
+  if (sim_pp_due(h) > 0) return SIM_ESTATE;  // the push-pull batch of this tick comes first (its pairs span shards: the host runs it)
   return tick_launch(h, h->cur_tp.C == 1 ? 0xFFFFFFFFu : chunk);
 }
 int sim_step_end(sim_handle* h) {
@@ -2442,6 +2617,7 @@ int sim_step(sim_handle* h, uint32_t n_ticks) {
   if (d.sharded && !h->bound) return SIM_ESTATE;
   if (d.sharded && n_ticks > 1) return SIM_EINVAL;  // the caller has to move send -> recv between two ticks
   for (u32 it = 0; it < n_ticks; ++it) {
+    if (sim_pp_due(h) > 0) return SIM_ESTATE;  // needs the host between begin and end (cross-shard push-pull batch)
     int rc = sim_step_begin(h);
     if (rc) return rc;
     if (d.sharded && h->cur_tp.C > 1) {
@@ -2752,6 +2928,7 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
   h->n_alloc = (u32)h->walk.size();
   h->ops_dropped = hd.ops_dropped; h->slots_recycled = hd.slots_recycled;
   h->recycle_at = 0xFFFFFFFFu;
+  h->pp_done_at = 0xFFFFFFFFu;
   h->op_cursor = 0;
   return SIM_OK;
 }

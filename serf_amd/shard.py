@@ -98,17 +98,37 @@ class ShardedSim:
                 keep.append(a[np.nonzero(flags & 2)[0][0], i])
         self.sim.recycle_apply(np.array(keep, dtype=np.uint32).reshape(-1, 12))
 
+    def _push_pull(self):
+        """A push-pull batch whose pairs span shards (include/serf_sim.h): two rounds of pack -> all-to-all-v -> merge."""
+        snd, rcv, rb = self.sim.pp_plan(self.world)
+        for rnd in (1, 2):
+            out_counts, in_counts = (snd, rcv) if rnd == 1 else (rcv, snd)
+            send = torch.empty(max(1, sum(out_counts) * rb), dtype=torch.uint8, device=self.device)
+            recv = torch.empty(max(1, sum(in_counts) * rb), dtype=torch.uint8, device=self.device)
+            self.sim.pp_export(rnd, send.data_ptr())
+            if self.device.type == "cuda":
+                self.sim.sync()
+            dist.all_to_all_single(recv[:sum(in_counts) * rb], send[:sum(out_counts) * rb],
+                                   output_split_sizes=[c * rb for c in in_counts], input_split_sizes=[c * rb for c in out_counts],
+                                   group=self.group)
+            self.sim.pp_merge(rnd, recv.data_ptr())
+        if self.device.type == "cuda":
+            self.sim.sync()  # the buffers go away with this frame
+
     def step(self, n_ticks=1):
         for _ in range(n_ticks):
             self._drain()
             if self.sim.recycle_due():
                 self._recycle()
+            rbuf = self.recv[self.sim.tick & 1] if self.chunks > 1 else self.recv[0]  # packets sent during tick t land in recv[t & 1]
+            self.sim.step_begin()  # the tick's operations
+            if self.sim.pp_due():
+                self._push_pull()
             if self.chunks == 1:
-                self.sim.step(1)  # reads recv (packets of the previous round), fills send
+                self.sim.step_chunk(0)  # reads recv (packets of the previous round), fills send
+                self.sim.step_end()
                 self._exchange(self.recv[0], self.send, False)
                 continue
-            rbuf = self.recv[self.sim.tick & 1]  # packets sent during tick t land in recv[t & 1]
-            self.sim.step_begin()
             for c in range(self.chunks):
                 self.sim.step_chunk(c)
                 lo = c * self.chunk_bytes

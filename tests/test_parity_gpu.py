@@ -191,6 +191,39 @@ def test_config3_1m_properties(hiplib):
     assert g.dump(_ffi.ARR_QUEUE)["meta"].min() == 0xFFFFFFFF
 
 
+def _push_pull_on_one_gpu(shards):
+    """The cross-shard push-pull batch of serf_amd/shard.py with device-to-device copies standing in for the
+    all-to-all-v: two rounds of sim_pp_export -> move every (source, destination) slice -> sim_pp_merge."""
+    import torch
+
+    V = len(shards)
+    plans = [s.pp_plan(V) for s in shards]           # (send1[V], recv1[V], record_bytes)
+    rb = plans[0][2]
+    for rnd in (1, 2):
+        outc = [p[0] if rnd == 1 else p[1] for p in plans]
+        inc = [p[1] if rnd == 1 else p[0] for p in plans]
+        send = [torch.zeros(max(1, sum(c) * rb), dtype=torch.uint8, device="cuda") for c in outc]
+        recv = [torch.zeros(max(1, sum(c) * rb), dtype=torch.uint8, device="cuda") for c in inc]
+        for g, s in enumerate(shards):
+            s.pp_export(rnd, send[g].data_ptr())
+        for s in shards:
+            s.sync()
+        for src in range(V):
+            so = 0
+            for dst in range(V):
+                n = outc[src][dst] * rb
+                assert outc[src][dst] == inc[dst][src]
+                ro = sum(inc[dst][:src]) * rb
+                if n:
+                    recv[dst][ro:ro + n].copy_(send[src][so:so + n])
+                so += n
+        torch.cuda.synchronize()
+        for g, s in enumerate(shards):
+            s.pp_merge(rnd, recv[g].data_ptr())
+        for s in shards:
+            s.sync()
+
+
 @pytest.mark.parametrize("swim,chunks", [(0, 1), (4, 1), (4, 2), (0, 4)])
 def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim, chunks):
     # BASELINE configs[3] shape (G shards by node-id range, the round's all-to-all), scaled down and run as 4 handles
@@ -222,6 +255,8 @@ def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim, chunks):
     for t in range(ticks):
         for s in shards:
             s.step_begin()
+        if shards[0].pp_due():
+            _push_pull_on_one_gpu(shards)
         for c in range(chunks):
             for s in shards:
                 s.step_chunk(c)
@@ -338,7 +373,12 @@ def test_view_slot_recycling_four_shards_on_one_gpu(oracle, hiplib):
             for s in shards:
                 s.recycle_apply(np.array(keep, dtype=np.uint32).reshape(-1, 12))
         for s in shards:
-            s.step(1)
+            s.step_begin()
+        if shards[0].pp_due():
+            _push_pull_on_one_gpu(shards)
+        for s in shards:
+            s.step_chunk(0)
+            s.step_end()
         for s in shards:
             s.sync()
         for r in range(V):

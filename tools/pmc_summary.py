@@ -41,13 +41,14 @@ def main():
             out["counters"][name] = sum(vals) / len(vals)
     c = out["counters"]
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-        # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 FETCH_SIZE counts wide coalesced streams at 1/2
+        # FETCH_SIZE / WRITE_SIZE are in KiB.  Calibrated on this kernel's access shapes (tools/calib,
+        # profiles/r02_hbm_counter_calibration.json): TCC_EA0_RDREQ counts 128-byte requests and FETCH_SIZE prices them
+        # at 64 B, so every read pattern is reported at exactly 1/2; WRITE_SIZE is exact.
         out["hbm_read_bytes_raw"] = c["FETCH_SIZE"] * 1024
-        out["hbm_read_bytes_x2"] = c["FETCH_SIZE"] * 2048
+        out["hbm_read_bytes"] = c["FETCH_SIZE"] * 2048
         out["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024
-        out["hbm_bytes_per_launch"] = out["hbm_read_bytes_x2"] + out["hbm_write_bytes"]
-        out["note"] = ("hbm_bytes_per_launch = 2*FETCH_SIZE KiB + WRITE_SIZE KiB (guide: gfx950 FETCH_SIZE reports 1/2 of a wide "
-                       "coalesced read stream; WRITE_SIZE uncalibrated). Upper bound for partly scattered 32B/64B reads.")
+        out["hbm_bytes_per_launch"] = out["hbm_read_bytes"] + out["hbm_write_bytes"]
+        out["calibration"] = "reads = 2 x FETCH_SIZE (measured factor 0.500 for 16-B loads at 16/32/64-B lane stride and 64-B cells), writes = WRITE_SIZE (factor 1.000): profiles/r02_hbm_counter_calibration.json"
     json.dump(out, sys.stdout, indent=1)
     print()
 

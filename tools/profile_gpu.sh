@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-convergence $*"   # bench.py defaults: 300 timed ticks after 60 warm-up ticks
+ARGS="--no-cpu-baseline --no-convergence $*"   # bench.py defaults: 320 pre-roll ticks, then 300 timed ticks after 60 warm-up ticks
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
 grep '"metric"' $OUT/trace.log > $OUT/bench_traced.json
 i=0
