@@ -315,7 +315,10 @@ def run(args, lib=None, dev=None, backend="nccl"):
                                 "nodes_up": load1["up"], "view_slots_in_use": load2["slots_in_use"],
                                 "view_slots_recycled": load2["slots_recycled"]}},
             "rounds_to_99": ({"median": float(np.median(rounds)), "max": int(max(rounds)), "min": int(min(rounds)), "n": len(rounds),
-                              "what": "gossip rounds until >= 99 % of running nodes have applied a fresh user event, under the bench load"}
+                              "what": "gossip rounds until >= 99 % of running nodes have applied a fresh user event, under the bench load",
+                              "fanout_model": "per-tick bijection (every node receives exactly `fanout` packets per round); memberlist's literal "
+                                              "kRandomNodes (Poisson-like in-degree) needs one round more: 10 vs 9 at 64 Ki nodes, 12 vs 11 at "
+                                              "1 Mi (CPU oracle, 1 000 rumours each, profiles/r02_fanout_model_*.json)"}
                              if rounds else None),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,

@@ -20,6 +20,14 @@
  *     reference's code; no reference test pins their counts (query_deduplicate, event.rs:995-1073,
  *     pins the de-duplication by sender, which the per-sender bit reproduces).
  *   - whole-cluster behaviour is frozen in tests/golden/digests.json (made by tools/make_golden.py).
+ *   - the model's capacity bounds (SIM_Q / SIM_C / SIM_S, view slots) are separated from the protocol:
+ *     `make liboracle_unbounded.so` builds this same source with the bounds out of reach, and
+ *     tests/test_oracle_unbounded.py shows that a bounded run with overflow == 0 is the unbounded run.
+ *   - SIM_CF_RANDOM_FANOUT (this library only): memberlist's literal kRandomNodes instead of the per-tick
+ *     bijection, to put an error bar on the fan-out model (tests/fanout_model_hist.py).
+ *   - view-slot recycling, the chunk-structured fan-out map and the cross-shard push-pull records are
+ *     simulator constructions (DESIGN.md SIMSPEC §2.3, §2.6, §2.10): defined here and in the HIP library,
+ *     nothing in the reference to pin them to beyond the handlers they call.
  *
  * Build: make -C oracle   (gcc -O3 -march=x86-64-v2 -std=c11 -fopenmp -lm)
  */
