@@ -32,6 +32,10 @@ extern "C" {
 #define SIM_ABI_VERSION 7u
 
 #define SIM_P 4u  /* piggyback records per gossip packet (64-byte packet)             */
+#define SIM_PKT_BYTES 1400u /* byte budget of a gossip packet: memberlist's UDP payload limit (lan() and wan()); a packet
+                             * takes records in drain order while they fit it (delegate.rs:317-384 `limit`, App. B.1
+                             * get_broadcasts) — and at most SIM_P of them.  Lengths count in 16-byte units.            */
+#define SIM_PKT_UNITS (SIM_PKT_BYTES / 16u)
 /* The three capacity bounds of the model.  The product is built with exactly these values; the oracle can ALSO be
  * built with far larger ones (oracle/Makefile: liboracle_unbounded.so) so that a test can show that a bounded run
  * which never hit a bound (overflow == 0) is identical to the run without the bounds

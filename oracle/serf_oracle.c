@@ -439,17 +439,25 @@ static void q_push(nctx* c, uint32_t key, uint32_t wmeta, uint64_t val) {
   while (i > 0 && q[i - 1].meta > r.meta) { q[i] = q[i - 1]; --i; }
   q[i] = r;
 }
-/* get_broadcasts for one packet (B.1 with a record-count budget of SIM_P): the first P entries
- * in drain order; transmits+1; drop at the retransmit limit; re-insert. */
+/* get_broadcasts for one packet (B.1; serf's three queues share what memberlist's own broadcasts leave of `limit`,
+ * delegate.rs:328-383 — one running byte budget over the class-ordered pool): walk the entries in drain order
+ * (class, then transmit tier, largest first within a tier) and take every one that still fits SIM_PKT_UNITS, at most
+ * SIM_P of them — an entry that does not fit is skipped, a smaller one further on may; transmits+1; drop at the
+ * retransmit limit; re-insert. */
 static void queue_emit(sim_row* row, sim_record* q, uint32_t limit, sim_packet* out) {
   (void)row;
   memset(out, 0, sizeof *out);
-  for (uint32_t p = 0; p < SIM_P; ++p) {
-    sim_record* r = &q[p];
+  uint32_t free_u = SIM_PKT_UNITS, cnt = 0;
+  for (uint32_t i = 0; i < SIM_Q && cnt < SIM_P; ++i) {
+    sim_record* r = &q[i];
     if (r->meta == SIM_META_EMPTY) break;
-    out->rec[p].key = r->key;
-    out->rec[p].meta = r->meta & SIM_META_WIRE_MASK;
-    out->rec[p].val = r->val;
+    uint32_t len = SIM_META_LEN64(r->meta);
+    if (len > free_u) continue;
+    free_u -= len;
+    out->rec[cnt].key = r->key;
+    out->rec[cnt].meta = r->meta & SIM_META_WIRE_MASK;
+    out->rec[cnt].val = r->val;
+    cnt++;
     uint32_t t = SIM_META_TRANSMITS(r->meta) + 1;
     if (t >= limit) rec_clear(r);
     else r->meta = (r->meta & ~(0x3Fu << 24)) | (t << 24);

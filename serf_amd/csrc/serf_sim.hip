@@ -400,10 +400,53 @@ __device__ static void q_insert(const Ctx& c, Node& n, SK sk, u32 key, u32 wmeta
   if (sk[0] > k32) sk[0] = k32;
 }
 
-// get_broadcasts for one packet: the first SIM_P entries in drain order, transmits+1, drop at the
-// retransmit limit, then restore the sorted order (4-sort + bitonic merge on 32-bit keys).
-// Returns the payload slots of the emitted entries, 0xFF where there is none.
+// bitonic sort network on the 16 sort keys (ascending)
+__device__ static inline void sort16(SK sk) {
+#pragma unroll
+  for (int k = 2; k <= (int)SIM_Q; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int i = 0; i < (int)SIM_Q; ++i) {
+        int l = i ^ j;
+        if (l > i) {
+          bool up = (i & k) == 0;
+          u32 lo = min(sk[i], sk[l]), hi = max(sk[i], sk[l]);
+          sk[i] = up ? lo : hi;
+          sk[l] = up ? hi : lo;
+        }
+      }
+    }
+  }
+}
+// get_broadcasts for one packet (App. B.1; delegate.rs:317-384 `limit`): entries in drain order, every one that still
+// fits the packet's byte budget (SIM_PKT_UNITS 16-byte units), at most SIM_P of them; transmits+1, drop at the
+// retransmit limit, then restore the sorted order.  Returns the payload slots of the emitted entries, 0xFF where there
+// is none.  Nearly always the first SIM_P entries fit together (records are tens of bytes): that case keeps the cheap
+// 4-sort + bitonic merge; only when some lane of the wave holds large user events does the wave take the general walk.
 __device__ static inline u32 q_round(Node& n, SK sk, u32 limit) {
+  u32 head_units = 0;
+#pragma unroll
+  for (int p = 0; p < (int)SIM_P; ++p) head_units += sk[p] != KEMPTY ? 63u - ((sk[p] >> 14) & 63u) : 0u;
+  if (__any(head_units > SIM_PKT_UNITS)) {
+    u32 free_u = SIM_PKT_UNITS, cnt = 0, slots = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < (int)SIM_Q; ++i) {
+      u32 k = sk[i], len = 63u - ((k >> 14) & 63u);
+      bool take = (k != KEMPTY) & (cnt < SIM_P) & (len <= free_u);
+      u32 t = ((k >> 20) & 63u) + 1u;
+      bool drop = t >= limit;
+      if (take) {
+        free_u -= len;
+        slots = (slots & ~(0xFFu << (8 * cnt))) | ((k & 15u) << (8 * cnt));
+        cnt++;
+        if (drop) { n.used &= ~(1u << (k & 15u)); n.dirty |= DR2; }
+        sk[i] = drop ? KEMPTY : k + (1u << 20);
+      }
+    }
+    sort16(sk);
+    return slots;
+  }
   u32 a[SIM_P], slots = 0;
 #pragma unroll
   for (int p = 0; p < (int)SIM_P; ++p) {
@@ -978,24 +1021,9 @@ __device__ static void queue_check(const Ctx& c, Node& n, SK sk) {
       if (drop) { n.used &= ~(1u << (sk[i] & 15u)); sk[i] = KEMPTY; --cnt; changed = true; }
     }
   }
-  if (__any(changed)) {  // re-sort (bitonic sort network on 16 keys)
+  if (__any(changed)) {  // re-sort
     n.dirty |= changed ? DR2 : 0u;
-#pragma unroll
-    for (int k = 2; k <= (int)SIM_Q; k <<= 1) {
-#pragma unroll
-      for (int j = k >> 1; j > 0; j >>= 1) {
-#pragma unroll
-        for (int i = 0; i < (int)SIM_Q; ++i) {
-          int l = i ^ j;
-          if (l > i) {
-            bool up = (i & k) == 0;
-            u32 lo = min(sk[i], sk[l]), hi = max(sk[i], sk[l]);
-            sk[i] = up ? lo : hi;
-            sk[l] = up ? hi : lo;
-          }
-        }
-      }
-    }
+    sort16(sk);
   }
 }
 

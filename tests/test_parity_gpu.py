@@ -401,3 +401,38 @@ def test_view_slot_recycling_four_shards_on_one_gpu(oracle, hiplib):
     cr = ref.cluster_stats()
     assert cr["slots_recycled"] >= 66 and cr["ops_dropped"] == 0
     assert all(s.cluster_stats()["slots_recycled"] == cr["slots_recycled"] for s in shards)
+
+
+def test_packet_byte_budget_mixed_sizes(oracle, hiplib):
+    # user events of 16 .. 528 framed bytes at a rate that keeps several large ones queued: packets fill up by BYTES
+    # (1 400) before they fill up by records, the general selection walk and the full re-sort run — every array, every tick
+    n = 1024
+    g, o = pair(oracle, hiplib, n, fanout=4, view_slots=32, event_ring=64, query_ring=16, probe_interval=3, loss=0.01)
+    rng = np.random.default_rng(77)
+    key = 1
+    for t in range(60):
+        for _ in range(int(rng.integers(1, 4))):
+            node = int(rng.integers(0, n))
+            size = int(rng.choice([16, 40, 300, 480, 528]))
+            for s in (g, o):
+                s.inject(t, _ffi.OP_USER_EVENT, node, key, size)
+            key += 1
+        if t % 9 == 0:
+            node = int(rng.integers(0, n))
+            for s in (g, o):
+                s.inject(t, _ffi.OP_QUERY, node, key, _ffi.F_ACK)
+            key += 1
+    hit = False
+    for t in range(110):
+        g.step(1)
+        o.step(1)
+        if g.digest() != o.digest():
+            sc.assert_same_state(g, o, f"tick {t}")
+            raise AssertionError(f"digest differs after tick {t} but the arrays agree")
+        if t % 10 == 0:
+            sc.assert_same_state(g, o, f"tick {t}")
+            q = o.dump(_ffi.ARR_QUEUE).reshape(n, _ffi.Q)
+            lens = np.where(q["meta"] != 0xFFFFFFFF, 63 - ((q["meta"] >> 18) & 63), 0)
+            hit |= bool((np.sort(lens, axis=1)[:, -4:].sum(axis=1) > 87).any())
+    assert hit, "scenario should put more than 1 400 bytes of events at the head of some queue"
+    sc.assert_same_state(g, o, "final")
