@@ -436,3 +436,23 @@ def test_packet_byte_budget_mixed_sizes(oracle, hiplib):
             hit |= bool((np.sort(lens, axis=1)[:, -4:].sum(axis=1) > 87).any())
     assert hit, "scenario should put more than 1 400 bytes of events at the head of some queue"
     sc.assert_same_state(g, o, "final")
+
+
+def test_bench_configuration_1m_digests(oracle, hiplib):
+    # the benchmark's configuration and schedule at its FULL size (1 Mi nodes, view_slots 1024, rings 512: 66 GB on
+    # the device, ~64 GiB of mostly untouched address space on the host) for the first 120 ticks — through the first
+    # recycling pass, Reaper round and a dozen operations — digests of every array every 40 ticks
+    import bench
+
+    n = 1 << 20
+    args = bench.parse_args(["--nodes-per-gpu", str(n)])
+    kw, ops = bench.workload(args, n)
+    g, o = pair(oracle, hiplib, n, **kw)
+    sc.apply_schedule(g, ops)
+    sc.apply_schedule(o, ops)
+    for t in range(0, 120, 40):
+        g.step(40)
+        o.step(40)
+        assert g.digest() == o.digest(), f"digest differs after tick {t + 40}"
+    cg, co = g.cluster_stats(), o.cluster_stats()
+    assert cg == co and cg["overflow"] == 0 and cg["ops_dropped"] == 0
