@@ -29,7 +29,7 @@ extern "C" {
 
 /* ------------------------------------------------------------------ constants */
 
-#define SIM_ABI_VERSION 7u
+#define SIM_ABI_VERSION 8u
 
 #define SIM_P 4u  /* piggyback records per gossip packet (64-byte packet)             */
 #define SIM_PKT_BYTES 1400u /* byte budget of a gossip packet: memberlist's UDP payload limit (lan() and wan()); a packet
@@ -84,7 +84,9 @@ enum sim_event_type {
   SIM_EV_JOIN = 0,
   SIM_EV_LEAVE = 1,
   SIM_EV_FAILED = 2,
-  SIM_EV_UPDATE = 3, /* reserved: tags/meta are off the simulated path, handle_node_update (base.rs:1576-1624) never fires */
+  SIM_EV_UPDATE = 3, /* key = node, ltime = its new incarnation: handle_node_update (base.rs:1576-1624) after a
+                        SIM_OP_SET_TAGS elsewhere.  Fires for alive messages only; a push-pull that delivers the
+                        same news does not carry the meta in this model and stays silent */
   SIM_EV_REAP = 4,
   SIM_EV_USER = 5,
   SIM_EV_QUERY = 6
@@ -111,6 +113,18 @@ enum sim_kind {
 #define SIM_QT 256u           /* running-query table, direct-mapped by query_id % SIM_QT (a newer query with the
                                * same residue takes the entry over: model bound)                 */
 #define SIM_F_CC 1u           /* UserEventMessage.cc (coalesce)           */
+#define SIM_F_META 1u         /* ALIVE: the node's meta (tags) differs from what its previous incarnation carried:
+                               * a receiver that already knew the node alive gets notify_update (SIM_EV_UPDATE)     */
+/* QueryParam.filters (types/filter.rs; should_process_query, query.rs:439-521): per running query one entry next to
+ * the tracker, {query id, number of ids, tag-class mask, 0, ids[SIM_QF_IDS]} (16 words).  Filter::Id lists up to
+ * SIM_QF_IDS node ids.  Filter::Tag is a regular expression over a tag's value: string work the host does once per
+ * query, not per node — every node carries a TAG CLASS (0..31; class 0 = "no tags", which no tag filter matches,
+ * query.rs:475-477/509-511), the host evaluates each tag filter against the (at most 31) distinct tag sets and
+ * hands over the AND of the masks of matching classes.  A node processes the query iff its id is in the id list (when
+ * there is one) and its class is in the mask (when there is one). */
+#define SIM_QF_IDS 12u
+#define SIM_QF_WORDS 16u
+#define SIM_TAG_CLASSES 32u
 
 /*
  * 16-byte piggyback record — the unit carried in packets and held in queues.
@@ -293,7 +307,14 @@ enum sim_op {
   SIM_OP_FORCE_LEAVE = 5,/* a = subject, b = prune                                api.rs:505  */
   SIM_OP_CRASH = 6,      /* ground truth: process stops (tests `shutdown()` a node, event.rs:112) */
   SIM_OP_REVIVE = 7,     /* ground truth: process resumes with its old state                   */
-  SIM_OP_LEAVE_FINISH = 8/* internal: memberlist.leave + state = Left (api.rs:462-497)         */
+  SIM_OP_LEAVE_FINISH = 8,/* internal: memberlist.leave + state = Left (api.rs:462-497)        */
+  SIM_OP_SET_TAGS = 9,   /* a = tag class (< SIM_TAG_CLASSES): Serf::set_tags, api.rs:219 — stores the tags and
+                            triggers memberlist.update_node (incarnation + 1, an alive broadcast)      */
+  SIM_OP_QUERY_FILTER_ID = 10,  /* a = query id, b = a node id to add to the query's Filter::Id (`node` is not used);
+                                   scheduled BEFORE the SIM_OP_QUERY it belongs to.  A 13th id does not fit: the
+                                   operation is dropped and counted in ops_dropped (model bound)                  */
+  SIM_OP_QUERY_FILTER_TAGS = 11 /* a = query id, b = mask of the tag classes one Filter::Tag matches (ANDed into
+                                   the query's mask); BEFORE the SIM_OP_QUERY, like the ids                       */
 };
 
 /* ------------------------------------------------------------------ entry points */
@@ -315,6 +336,18 @@ int sim_force_leave(sim_handle* h, uint32_t node, uint32_t subject, int prune);
 int sim_user_event(sim_handle* h, uint32_t node, uint32_t event_key, uint32_t encoded_len, int coalesce);
 /* flags: SIM_F_NO_BROADCAST | SIM_F_ACK | SIM_F_RESPOND, and QueryParam.relay_factor (0..7) in bits [10:8]. */
 int sim_query(sim_handle* h, uint32_t node, uint32_t query_id, uint32_t flags);
+/* The same with QueryParam.filters (query.rs:439-521): ids[n_ids] is the Filter::Id list (n_ids <= SIM_QF_IDS, else
+ * SIM_ETOOBIG; NULL / 0 = none), tag_mask the AND of the Filter::Tag class masks (0xFFFFFFFF = no tag filter).  Nodes the
+ * filters exclude still rebroadcast the query the first time they see it (base.rs:1063-1073) but neither ack, respond
+ * nor see the event.  Shorthand for SIM_OP_QUERY_FILTER_* + SIM_OP_QUERY at the next tick. */
+int sim_query_filtered(sim_handle* h, uint32_t node, uint32_t query_id, uint32_t flags, const uint32_t* ids, uint32_t n_ids,
+                       uint32_t tag_mask);
+/* Serf::set_tags (api.rs:219) in the tag-class model above, applied at the start of the next tick. */
+int sim_set_tags(sim_handle* h, uint32_t node, uint32_t tag_class);
+/* The tags the nodes [first, first + count) were STARTED with (Options::with_tags, options.rs; read by the filter at
+ * query.rs:465/499): classes[i] < SIM_TAG_CLASSES, written straight into the table — no update_node, no gossip, no view
+ * slot.  Every shard of a sharded run makes the same call. */
+int sim_init_tags(sim_handle* h, uint32_t first, uint32_t count, const uint8_t* classes);
 /* Churn / packet-loss / kill / revive schedule: run `op` on `node` at the start of tick `tick`
  * (reference analogue: MessageDropper delegate.rs:42-45 and tests that shutdown() a node). */
 int sim_inject(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, uint32_t b);

@@ -304,6 +304,8 @@ struct sim_handle {
   /* running queries (QueryCore.responses, serf.rs:152-160): who acked / responded, per tracked query */
   struct { uint32_t qid, origin, deadline, flags; } qtab[SIM_QT];
   uint32_t* qbits;      /* [SIM_QT][2][ceil(N/32)]: ack bitmap, response bitmap, by global node id */
+  uint32_t qfilt[SIM_QT][SIM_QF_WORDS]; /* the running queries' filters {qid, n_ids, tag mask, 0, ids[SIM_QF_IDS]} */
+  uint8_t* tagclass;    /* [N] every node's tag class (replicated on every shard, like liveness) */
   uint32_t qt_cursor, q_timeout;
   uint32_t pp_step, pp_groups; /* push-pull batches: every pp_step ticks one of pp_groups pair classes syncs */
   /* SIM_CF_RANDOM_FANOUT (oracle only): memberlist's literal kRandomNodes instead of the per-tick bijection.
@@ -688,6 +690,19 @@ static void query_respond(nctx* c, uint32_t id, uint32_t flags) {
   }
 }
 
+/* should_process_query (query.rs:439-521): every filter of the query has to match.  Filter::Id = the node's id is in
+ * the list; Filter::Tag (a regular expression over one tag's value) is evaluated by the host against the distinct tag
+ * sets once per query and arrives as a mask of matching tag classes (include/serf_sim.h, SIM_QF_*). */
+static int query_should_process(const osim* s, uint32_t gid, uint32_t id) {
+  const uint32_t* f = s->qfilt[id % SIM_QT];
+  if (f[0] != id) return 1; /* no filters on record for this query */
+  if (f[2] != 0xFFFFFFFFu && !((f[2] >> s->tagclass[gid]) & 1u)) return 0; /* query.rs:463-481 */
+  if (!f[1]) return 1;
+  for (uint32_t i = 0; i < f[1]; ++i)
+    if (f[4 + i] == gid) return 1; /* query.rs:448-461 */
+  return 0;
+}
+
 /* handle_query (de-dup + rebroadcast decision): base.rs:972-1073.
  * Quirk Q1 (age test uses the ring length, base.rs:1012-1014) and quirk Q2 (bucket ltime not
  * updated, base.rs:1027-1036) are reproduced. */
@@ -712,6 +727,8 @@ static int handle_query(nctx* c, uint32_t id, uint64_t ltime, uint32_t flags) {
     b->ltime = ltime;
     b->keys[0] = id;
   }
+  if (!query_should_process(s, c->gid, id)) /* base.rs:1062-1073: filtered out, but seen for the first time: rebroadcast */
+    return (flags & SIM_F_NO_BROADCAST) ? 0 : 1;
   query_respond(c, id, flags);            /* base.rs:1075-1124 */
   emit_event(c, SIM_EV_QUERY, id, ltime); /* base.rs:1126-1151 */
   return (flags & SIM_F_NO_BROADCAST) ? 0 : 1; /* base.rs:1062-1073 */
@@ -751,15 +768,16 @@ static void susp_track(nctx* c, uint32_t slot, uint32_t deadline) {
   if (!row->susp_next || deadline < row->susp_next) row->susp_next = deadline;
 }
 /* refute (memberlist state.go `refute`): bump the incarnation past the accusation, gossip alive */
-static void swim_refute(nctx* c, uint32_t accused_inc) {
+static void swim_refute_f(nctx* c, uint32_t accused_inc, uint32_t flags) {
   uint32_t inc = c->row->inc + 1;
   if (accused_inc >= inc) inc = accused_inc + 1;
   c->row->inc = inc;
   sim_view* e = view_at(c->s, c->l, c->gid);
   if (e) e->inc = inc;
   aw_delta(c->row, +1);
-  q_push(c, c->gid, wire_meta(SIM_K_ALIVE, 0, 64), inc);
+  q_push(c, c->gid, wire_meta(SIM_K_ALIVE, flags, 64), inc);
 }
+static void swim_refute(nctx* c, uint32_t accused_inc) { swim_refute_f(c, accused_inc, 0); }
 /* aliveNode (B.4) */
 static void swim_alive(nctx* c, uint32_t subject, uint32_t inc, uint32_t wmeta) {
   sim_view* e = view_at(c->s, c->l, subject);
@@ -784,6 +802,7 @@ static void swim_alive(nctx* c, uint32_t subject, uint32_t inc, uint32_t wmeta) 
   e->bits = vb_set_nconf(vb_set_swim(e->bits, SIM_SWIM_ALIVE), 0);
   q_push(c, subject, wmeta, inc);
   if (old == SIM_SWIM_DEAD || old == SIM_SWIM_LEFT) handle_node_join(c, subject);
+  else if (wmeta & SIM_F_META) emit_event(c, SIM_EV_UPDATE, subject, inc); /* notify_update -> handle_node_update, base.rs:1576-1624 */
 }
 /* suspectNode (B.4) + suspicion.Confirm (B.5) */
 static void swim_suspect(nctx* c, uint32_t subject, uint32_t inc, uint32_t from, uint32_t wmeta) {
@@ -990,6 +1009,7 @@ static void apply_op(osim* s, const sim_opent* op) {
   /* ground-truth liveness is replicated on every shard (probes read it, B.3) */
   if (op->op == SIM_OP_CRASH) up_set(s, op->node, 0);
   if (op->op == SIM_OP_REVIVE || op->op == SIM_OP_JOIN) up_set(s, op->node, 1);
+  if (op->op == SIM_OP_SET_TAGS) s->tagclass[op->node] = (uint8_t)op->a; /* api.rs:227: store the tags */
   if (op->op == SIM_OP_QUERY) { /* base.rs:905-930: register the QueryResponse before sending (every shard counts its own nodes) */
     uint32_t j = op->a % SIM_QT;
     size_t words = ((size_t)s->N + 31) / 32;
@@ -1059,6 +1079,12 @@ static void apply_op(osim* s, const sim_opent* op) {
       handle_leave_intent(&c, op->a, lt, (int)op->b); /* base.rs:463 */
       if (has_alive_members(s))                     /* base.rs:466 */
         q_push(&c, op->a, wire_meta(SIM_K_LEAVE, op->b ? SIM_F_PRUNE : 0, 16), lt);
+      break;
+    }
+    case SIM_OP_SET_TAGS: { /* api.rs:219-235: memberlist.update_node = next incarnation + an alive broadcast */
+      if (!(row->flags & SIM_RF_UP) || !s->swim) break;
+      swim_refute_f(&c, row->inc, SIM_F_META);
+      aw_delta(row, -1); /* not an accusation */
       break;
     }
     case SIM_OP_CRASH: row->flags &= ~SIM_RF_UP; break;
@@ -1285,10 +1311,22 @@ static void step_begin(osim* s) {
   if (recycle_due(s) && s->cfg.shard_count <= 1) recycle_local(s);
   while (s->op_cursor < s->n_ops && s->ops[s->op_cursor].tick <= s->tick) {
     const sim_opent* op = &s->ops[s->op_cursor];
+    s->op_cursor++;
+    if (op->op == SIM_OP_QUERY_FILTER_ID || op->op == SIM_OP_QUERY_FILTER_TAGS || op->op == SIM_OP_QUERY) {
+      /* QueryParam.filters (query.rs:439-521; base.rs:875-903 builds them into the message): the query's filter entry
+       * is started by the first filter operation that names the query, kept by its SIM_OP_QUERY, and replaced by
+       * whatever names another query with the same residue */
+      uint32_t* f = s->qfilt[op->a % SIM_QT];
+      if (f[0] != op->a) { memset(f, 0, sizeof s->qfilt[0]); f[0] = op->a; f[2] = 0xFFFFFFFFu; }
+      if (op->op == SIM_OP_QUERY_FILTER_ID) {
+        if (f[1] == SIM_QF_IDS) s->ops_dropped++; /* model bound: the id does not fit */
+        else f[4 + f[1]++] = op->b;
+      } else if (op->op == SIM_OP_QUERY_FILTER_TAGS) f[2] &= op->b;
+      if (op->op != SIM_OP_QUERY) continue;
+    }
     uint32_t x = op_subject(s, op->op, op->node, op->a);
     if (x != NOSLOT && ensure_slot(s, x) != SIM_OK) s->ops_dropped++; /* no free view slot: the operation does not happen */
     else apply_op(s, op);
-    s->op_cursor++;
   }
   pp_round(s, p);
   s->in_tick = 1;
@@ -1391,7 +1429,7 @@ int API(destroy)(osim* s) {
   free(s->rows); free(s->queue); free(s->inbox[0]); free(s->inbox[1]);
   if (s->own_x) { free(s->xsend); free(s->xrecv); }
   free(s->view); free(s->ering); free(s->qring); free(s->slot_of); free(s->subject_of); free(s->walk); free(s->alloc_tick); free(s->pp_local_a); free(s->pp_local_b); free(s->pp_r1); free(s->pp_s1); free(s->rtgt); free(s->rcsr); free(s->rsrc);
-  free(s->base); free(s->ops); free(s->events); free(s->upmap); free(s->qbits); free(s);
+  free(s->base); free(s->ops); free(s->events); free(s->upmap); free(s->qbits); free(s->tagclass); free(s);
   return SIM_OK;
 }
 
@@ -1435,6 +1473,7 @@ int API(create)(const sim_config* cfg, osim** out) {
   if (s->upmap) memset(s->upmap, 0xFF, ((size_t)s->N + 31) / 32 * sizeof(uint32_t));
   swim_params(cfg, &s->swim, &s->k_conf, s->T);
   s->qbits = (uint32_t*)calloc((size_t)SIM_QT * 2 * (((size_t)s->N + 31) / 32), sizeof(uint32_t));
+  s->tagclass = (uint8_t*)calloc(s->N, 1);
   s->q_timeout = 16u * digits10(s->N); /* query.rs:421-427 with query_timeout_mult = 16 (options.rs:518) */
   pp_params(cfg, &s->pp_step, &s->pp_groups);
   if (!s->qbits || !s->upmap || !s->rows || !s->queue || !s->view || !s->ering || !s->qring || !s->slot_of ||
@@ -1520,7 +1559,7 @@ static uint32_t op_subject(const osim* s, uint32_t op, uint32_t node, uint32_t a
   switch (op) {
     case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: return node;
     case SIM_OP_FORCE_LEAVE: return a;
-    case SIM_OP_CRASH: case SIM_OP_REVIVE: return s->swim ? node : NOSLOT;
+    case SIM_OP_CRASH: case SIM_OP_REVIVE: case SIM_OP_SET_TAGS: return s->swim ? node : NOSLOT;
     default: return NOSLOT;
   }
 }
@@ -1631,6 +1670,9 @@ int API(inject)(osim* s, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, 
     case SIM_OP_USER_EVENT: if (!a) return SIM_EINVAL; if ((b & 0x7FFFFFFFu) > 9 * 1024) return SIM_ETOOBIG; break; /* bit 31: cc */
     case SIM_OP_QUERY: if (!a) return SIM_EINVAL; break;
     case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: case SIM_OP_FORCE_LEAVE: case SIM_OP_CRASH: case SIM_OP_REVIVE: break;
+    case SIM_OP_SET_TAGS: if (a >= SIM_TAG_CLASSES) return SIM_EINVAL; break;
+    case SIM_OP_QUERY_FILTER_ID: if (!a || b >= s->N) return SIM_EINVAL; break;
+    case SIM_OP_QUERY_FILTER_TAGS: if (!a) return SIM_EINVAL; break;
     default: return SIM_EINVAL;
   }
   if (op == SIM_OP_FORCE_LEAVE && a >= s->N) return SIM_EINVAL;
@@ -1671,6 +1713,27 @@ int API(user_event)(osim* s, uint32_t node, uint32_t key, uint32_t len, int cc) 
 }
 int API(query)(osim* s, uint32_t node, uint32_t id, uint32_t flags) {
   return API(inject)(s, s ? s->tick : 0, SIM_OP_QUERY, node, id, flags);
+}
+/* QueryParam.filters (query.rs:37-93; built into the message at base.rs:875-903) */
+int API(query_filtered)(osim* s, uint32_t node, uint32_t id, uint32_t flags, const uint32_t* ids, uint32_t n_ids, uint32_t tag_mask) {
+  if (!s || !id || node >= s->N || (n_ids && !ids)) return SIM_EINVAL;
+  if (n_ids > SIM_QF_IDS) return SIM_ETOOBIG;
+  for (uint32_t i = 0; i < n_ids; ++i)
+    if (ids[i] >= s->N) return SIM_EINVAL;
+  int rc = SIM_OK;
+  for (uint32_t i = 0; i < n_ids && rc == SIM_OK; ++i) rc = API(inject)(s, s->tick, SIM_OP_QUERY_FILTER_ID, node, id, ids[i]);
+  if (rc == SIM_OK && tag_mask != 0xFFFFFFFFu) rc = API(inject)(s, s->tick, SIM_OP_QUERY_FILTER_TAGS, node, id, tag_mask);
+  return rc ? rc : API(inject)(s, s->tick, SIM_OP_QUERY, node, id, flags);
+}
+int API(init_tags)(osim* s, uint32_t first, uint32_t count, const uint8_t* classes) {
+  if (!s || !classes || first > s->N || count > s->N - first) return SIM_EINVAL;
+  for (uint32_t i = 0; i < count; ++i)
+    if (classes[i] >= SIM_TAG_CLASSES) return SIM_EINVAL;
+  memcpy(s->tagclass + first, classes, count);
+  return SIM_OK;
+}
+int API(set_tags)(osim* s, uint32_t node, uint32_t tag_class) {
+  return API(inject)(s, s ? s->tick : 0, SIM_OP_SET_TAGS, node, tag_class, 0);
 }
 
 int API(step)(osim* s, uint32_t n) {
@@ -1792,7 +1855,12 @@ int API(state_digest)(osim* s, uint64_t out[8]) {
       acc += dig((uint64_t)s->qtab[j].qid | ((uint64_t)s->qtab[j].origin << 32), (uint64_t)j * 2);
       acc += dig((uint64_t)s->qtab[j].deadline | ((uint64_t)s->qtab[j].flags << 32), (uint64_t)j * 2 + 1);
     }
-    for (size_t i = 0; i < (size_t)SIM_QT * 2 * words; ++i) acc += dig((uint64_t)s->qbits[i], 2 * SIM_QT + (uint64_t)i);
+    uint64_t at = 2 * SIM_QT;
+    for (size_t i = 0; i < (size_t)SIM_QT * 2 * words; ++i) acc += dig((uint64_t)s->qbits[i], at + i);
+    at += (uint64_t)SIM_QT * 2 * words; /* then the filters, word by word, and the tag classes, byte by byte */
+    for (size_t i = 0; i < (size_t)SIM_QT * SIM_QF_WORDS; ++i) acc += dig((uint64_t)((const uint32_t*)s->qfilt)[i], at + i);
+    at += (uint64_t)SIM_QT * SIM_QF_WORDS;
+    for (uint32_t i = 0; i < s->N; ++i) acc += dig((uint64_t)s->tagclass[i], at + i);
     out[7] = acc;
   }
   return SIM_OK;
@@ -1819,9 +1887,9 @@ int API(dump_state)(osim* s, uint32_t which, void* buf, size_t cap, size_t* byte
 
 /* =====================================================================================
  * Checkpoint / resume (include/serf_sim.h sim_snapshot / sim_restore): canonical image.
- * header, then 13 sections, each = u64 byte count + payload, in this order:
+ * header, then 16 sections, each = u64 byte count + payload, in this order:
  * rows, queue, inbox, view, event ring, query ring, slot_of, subject_of, baseline, liveness bitmap,
- * running-query table, running-query bitmaps, pending operations.
+ * running-query table, running-query bitmaps, pending operations, slot allocation ticks, query filters, tag classes.
  * ===================================================================================== */
 typedef struct snap_header {
   uint32_t magic, abi;
@@ -1831,17 +1899,18 @@ typedef struct snap_header {
   uint64_t ops_dropped, slots_recycled;
 } snap_header;
 #define SNAP_MAGIC 0x53465253u /* "SRFS" */
-#define SNAP_SECTIONS 14
+#define SNAP_SECTIONS 16
 static void snap_sections(osim* s, const void* ptr[SNAP_SECTIONS], size_t len[SNAP_SECTIONS]) {
   size_t nup = ((size_t)s->N + 31) / 32;
   const void* p[SNAP_SECTIONS] = {s->rows, s->queue, cur_inbox(s), s->view, s->ering, s->qring, s->slot_of, s->subject_of,
-                                  s->base, s->upmap, s->qtab, s->qbits, s->ops + s->op_cursor, s->alloc_tick};
+                                  s->base, s->upmap, s->qtab, s->qbits, s->ops + s->op_cursor, s->alloc_tick,
+                                  s->qfilt, s->tagclass};
   size_t n[SNAP_SECTIONS] = {(size_t)s->Nl * sizeof(sim_row), (size_t)s->Nl * SIM_Q * sizeof(sim_record),
                              (size_t)s->f * s->Nl * sizeof(sim_packet), (size_t)s->A * s->Nl * sizeof(sim_view),
                              (size_t)s->Bev * s->Nl * sizeof(sim_bucket), (size_t)s->Bq * s->Nl * sizeof(sim_bucket),
                              (size_t)s->N * 4, (size_t)s->A * 4, (size_t)s->N * sizeof(sim_view), nup * 4,
                              sizeof s->qtab, (size_t)SIM_QT * 2 * nup * 4, (s->n_ops - s->op_cursor) * sizeof(sim_opent),
-                             (size_t)s->A * 4};
+                             (size_t)s->A * 4, sizeof s->qfilt, (size_t)s->N};
   memcpy(ptr, p, sizeof p);
   memcpy(len, n, sizeof n);
 }

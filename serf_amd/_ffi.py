@@ -23,8 +23,12 @@ _ERR = {EINVAL: "SIM_EINVAL", ENOMEM: "SIM_ENOMEM", EDEVICE: "SIM_EDEVICE", ENOS
 STATUS_NONE, STATUS_ALIVE, STATUS_LEAVING, STATUS_LEFT, STATUS_FAILED = 0, 1, 2, 3, 4
 # enum sim_kind
 K_JOIN, K_LEAVE, K_EVENT, K_QUERY, K_ALIVE, K_SUSPECT, K_DEAD = 1, 2, 3, 4, 5, 6, 7
+# enum sim_event_type (event.rs:263-279, 367-378)
+EV_JOIN, EV_LEAVE, EV_FAILED, EV_UPDATE, EV_REAP, EV_USER, EV_QUERY = range(7)
 # enum sim_op
 OP_USER_EVENT, OP_QUERY, OP_LEAVE, OP_JOIN, OP_FORCE_LEAVE, OP_CRASH, OP_REVIVE, OP_LEAVE_FINISH = 1, 2, 3, 4, 5, 6, 7, 8
+OP_SET_TAGS, OP_QUERY_FILTER_ID, OP_QUERY_FILTER_TAGS = 9, 10, 11
+QF_IDS, TAG_CLASSES, NO_TAG_FILTER = 12, 32, 0xFFFFFFFF
 # enum sim_array
 ARR_ROWS, ARR_QUEUE, ARR_INBOX, ARR_VIEW, ARR_ERING, ARR_QRING, ARR_SLOTMAP = range(7)
 # enum sim_swim_state (memberlist node state)
@@ -95,7 +99,7 @@ ABI_SYMBOLS = ("create", "destroy", "set_stream", "join", "leave", "force_leave"
                "bind_exchange", "snapshot", "restore", "query_status", "profile", "profile_read", "profile_read_stats", "cluster_stats_get",
                "bind_exchange2", "exchange_chunks", "step_begin", "step_chunk", "step_end",
                "recycle_due", "recycle_scan", "recycle_apply", "pp_due", "pp_plan", "pp_export", "pp_merge",
-               "abi_version", "backend_name")
+               "query_filtered", "set_tags", "init_tags", "abi_version", "backend_name")
 
 
 def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, view_slots=0,
@@ -138,6 +142,9 @@ class SimLib:
             "force_leave": (C.c_int, [H, u32, u32, C.c_int]),
             "user_event": (C.c_int, [H, u32, u32, u32, C.c_int]),
             "query": (C.c_int, [H, u32, u32, u32]),
+            "query_filtered": (C.c_int, [H, u32, u32, u32, C.POINTER(u32), u32, u32]),
+            "set_tags": (C.c_int, [H, u32, u32]),
+            "init_tags": (C.c_int, [H, u32, u32, vp]),
             "inject": (C.c_int, [H, u64, u32, u32, u32, u32]),
             "step": (C.c_int, [H, u32]),
             "sync": (C.c_int, [H]),
@@ -226,11 +233,28 @@ class Sim:
     def user_event(self, node, key, encoded_len=32, coalesce=False):
         self._ck(self.lib.f["user_event"](self.h, node, key, encoded_len, int(coalesce)), "sim_user_event")
 
-    def query(self, node, query_id, flags=0):
-        self._ck(self.lib.f["query"](self.h, node, query_id, flags), "sim_query")
+    def query(self, node, query_id, flags=0, ids=None, tag_mask=NO_TAG_FILTER):
+        """Serf::query (api.rs:304).  ids / tag_mask = QueryParam.filters in the form the ABI takes them
+        (serf_amd.filters.TagTable.compile turns Filter::Id / Filter::Tag lists into this pair)."""
+        if ids is None and tag_mask == NO_TAG_FILTER:
+            self._ck(self.lib.f["query"](self.h, node, query_id, flags), "sim_query")
+            return
+        ids = list(ids or [])
+        arr = (C.c_uint32 * max(1, len(ids)))(*ids)
+        self._ck(self.lib.f["query_filtered"](self.h, node, query_id, flags, arr, len(ids), tag_mask), "sim_query_filtered")
+
+    def set_tags(self, node, tag_class):
+        """Serf::set_tags (api.rs:219) in the tag-class model (include/serf_sim.h)."""
+        self._ck(self.lib.f["set_tags"](self.h, node, tag_class), "sim_set_tags")
 
     def inject(self, tick, op, node, a=0, b=0):
         self._ck(self.lib.f["inject"](self.h, tick, op, node, a, b), "sim_inject")
+
+    def init_tags(self, classes, first=0):
+        """Options::with_tags for the nodes [first, first + len(classes)): start-up tags, no gossip."""
+        import numpy as np
+        arr = np.ascontiguousarray(classes, dtype=np.uint8)
+        self._ck(self.lib.f["init_tags"](self.h, first, len(arr), arr.ctypes.data), "sim_init_tags")
 
     def set_stream(self, stream_ptr):
         self._ck(self.lib.f["set_stream"](self.h, C.c_void_p(stream_ptr)), "sim_set_stream")

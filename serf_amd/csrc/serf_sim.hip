@@ -231,7 +231,8 @@ struct Dev {
   u32* subject_of;  // [A]
   u32* walk;        // [n_slots] allocated slots in ascending SUBJECT order (the order of every walk over the view)
   u32* upmap;       // [ceil(N/32)] ground-truth liveness of every node (all shards)
-  uint4* qtab;      // [SIM_QT] running queries {qid, origin, deadline, flags}
+  uint4* qtab;      // [SIM_QT] running queries {qid, origin, deadline, flags}; then [SIM_QT][4] their filters
+                    // {qid, n_ids, tag mask, 0, ids[12]} (QFILT); then [N] bytes, every node's tag class (TAGCLASS)
   u32* qbits;       // [SIM_QT][2][ceil(N/32)] who acked / responded, by global node id
   uint4* nullcell;  // 2 x uint4 of zeros: where the prefetch of a record without a lookup points
   sim_event* events;
@@ -722,6 +723,23 @@ __device__ static bool handle_user_event(const Ctx& c, Node& n, u32 key, u64 lti
   emit_event(c, n, SIM_EV_USER, key, ltime);
   return true;
 }
+#define QFILT(d) ((d).qtab + SIM_QT)
+#define TAGCLASS(d) (reinterpret_cast<uint8_t*>((d).qtab + SIM_QT + SIM_QT * (SIM_QF_WORDS / 4)))
+#define QTAB_U4(n) ((size_t)SIM_QT + (size_t)SIM_QT * (SIM_QF_WORDS / 4) + ((size_t)(n) + 15) / 16)
+// should_process_query (query.rs:439-521): every filter must match — the node's id is in the Filter::Id list, its tag
+// class is in the mask the host made of the Filter::Tag expressions (include/serf_sim.h).  Rare path: runs once per
+// (node, query), after the de-dup.
+__device__ static bool query_should_process(const Dev& d, u32 gid, u32 id) {
+  const uint4* f = QFILT(d) + (size_t)(id % SIM_QT) * (SIM_QF_WORDS / 4);
+  uint4 h = f[0];
+  if (h.x != id) return true;  // no filters on record for this query
+  if (h.z != 0xFFFFFFFFu && !((h.z >> TAGCLASS(d)[gid]) & 1u)) return false;
+  if (!h.y) return true;
+  const u32* ids = reinterpret_cast<const u32*>(f + 1);
+  for (u32 i = 0; i < h.y; ++i)
+    if (ids[i] == gid) return true;
+  return false;
+}
 // Responder half of handle_query (base.rs:1075-1154) and origin half (base.rs:1158-1204,
 // query.rs:240-303) — see oracle query_respond: one bit per (running query, node) for acks, one for
 // responses; the counts are popcounts taken when somebody asks (no hot atomic counter).
@@ -768,6 +786,8 @@ __device__ static bool handle_query(const Ctx& c, Node& n, u32 id, u64 ltime, u3
     p[0] = b0;
   }
   dirty = true;
+  // base.rs:1062-1073: a node the filters exclude still rebroadcasts what it sees for the first time
+  if (!query_should_process(c.d, c.gid, id)) return !(flags & SIM_F_NO_BROADCAST);
   query_respond(c, id, flags);
   emit_event(c, n, SIM_EV_QUERY, id, ltime);
   return !(flags & SIM_F_NO_BROADCAST);
@@ -830,6 +850,7 @@ __device__ static void swim_alive(const Ctx& c, Node& n, u32 subject, u32 inc, u
   e.w = vb_set_nconf(vb_set_swim(e.w, SIM_SWIM_ALIVE), 0);
   ins_set(ins, subject, wmeta, inc);
   if (old == SIM_SWIM_DEAD || old == SIM_SWIM_LEFT) node_join_e(c, n, e, subject);
+  else if (wmeta & SIM_F_META) emit_event(c, n, SIM_EV_UPDATE, subject, inc);  // notify_update -> handle_node_update, base.rs:1576-1624
   p[0] = e;
   dirty = true;
 }
@@ -1400,6 +1421,7 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
     if (op == SIM_OP_REVIVE || op == SIM_OP_JOIN) up_set(d, gid, true);
     // base.rs:905-930: the QueryResponse is registered before the query goes out (every shard counts its own nodes)
     if (op == SIM_OP_QUERY) d.qtab[ob.c[i]] = make_uint4(ob.a[i], gid, (u32)tick + q_timeout, ob.b[i]);
+    if (op == SIM_OP_SET_TAGS) TAGCLASS(d)[gid] = (uint8_t)ob.a[i];  // replicated like liveness: a table the host fills
     if (gid < d.shard0 || gid >= d.shard0 + d.Nl) continue;
     u32 l = gid - d.shard0;
     Ctx c{d, l, gid, (u32)tick, qbase};
@@ -1485,6 +1507,13 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
           uint4 e_ = p ? p[0] : make_uint4(0, 0, 0, 0);
           handle_leave_intent(c, n, a, lt, b != 0, p, e_, dirty, ins);
           if (has_alive) ins_set(ins2, a, wire_meta(SIM_K_LEAVE, b ? SIM_F_PRUNE : 0, 16), lt);
+        }
+        break;
+      case SIM_OP_SET_TAGS:  // api.rs:219-235: memberlist.update_node = next incarnation + an alive broadcast
+        if (up && d.swim) {
+          swim_refute(c, n, n.inc, ins);
+          ins.wmeta |= SIM_F_META;  // the meta differs from the one the previous incarnation carried
+          aw_delta(n, -1);  // not an accusation
         }
         break;
       case SIM_OP_CRASH: n.flags &= ~SIM_RF_UP; break;
@@ -1798,18 +1827,31 @@ __global__ void digest_split(const uint4* arr, size_t tail, size_t n_entries, u6
   block_sum_add(acc, out);
 }
 // running queries: tracker table, then the ack / response bitmaps (canonical order = physical order)
-__global__ void digest_queries(const uint4* qtab, const u32* qbits, size_t n_bits_words, u64* out) {
+// ... then the filters (32-bit words) and the tag classes (bytes)
+__global__ void digest_queries(const uint4* qtab, const u32* qbits, size_t n_bits_words, u32 N, u64* out) {
   u64 acc = 0;
-  for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < 2 * SIM_QT + n_bits_words; i += (size_t)gridDim.x * BLOCK) {
-    if (i < 2 * SIM_QT) {
+  const size_t n0 = 2 * SIM_QT, n1 = n0 + n_bits_words, n2 = n1 + (size_t)SIM_QT * SIM_QF_WORDS, n3 = n2 + N;
+  const u32* filt = reinterpret_cast<const u32*>(qtab + SIM_QT);
+  const uint8_t* tags = reinterpret_cast<const uint8_t*>(qtab + SIM_QT + SIM_QT * (SIM_QF_WORDS / 4));
+  for (size_t i = blockIdx.x * (size_t)BLOCK + threadIdx.x; i < n3; i += (size_t)gridDim.x * BLOCK) {
+    if (i < n0) {
       uint4 t = qtab[i >> 1];
       u64 w = (i & 1) ? ((u64)t.z | ((u64)t.w << 32)) : ((u64)t.x | ((u64)t.y << 32));
       acc += dig(w, i);
+    } else if (i < n1) {
+      acc += dig((u64)qbits[i - n0], i);
+    } else if (i < n2) {
+      acc += dig((u64)filt[i - n1], i);
     } else {
-      acc += dig((u64)qbits[i - 2 * SIM_QT], i);
+      acc += dig((u64)tags[i - n2], i);
     }
   }
   block_sum_add(acc, out);
+}
+// one filter entry, by value (the host keeps the table and is its only writer)
+struct QFiltEnt { uint4 w[SIM_QF_WORDS / 4]; };
+__global__ void qfilt_set_kernel(uint4* dst, QFiltEnt e) {
+  if (threadIdx.x < SIM_QF_WORDS / 4 && !blockIdx.x) dst[threadIdx.x] = e.w[threadIdx.x];
 }
 __global__ void query_count_kernel(const u32* bits, size_t words, u64* out /*[2]*/) {
   u64 a = 0, r = 0;
@@ -2014,6 +2056,7 @@ struct sim_handle {
   bool bound;
   int device;
   u32 qt_cursor, q_timeout;  // running-query trackers (SIM_QT, round robin); query timeout in ticks
+  std::vector<u32> qfilt;    // [SIM_QT][SIM_QF_WORDS] host copy of the query filters (the host is their only writer)
   u32 profiling;  // 0 = off, n = HIP events around every n-th tick-kernel launch
   u64 prof_seq;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof;  // one event pair per tick-kernel launch
@@ -2188,7 +2231,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   DA(d.ering, (size_t)d.Bev * Nl * 2)
   DA(d.qring, (size_t)d.Bq * Nl * 2)
   DA(d.slot_of, d.N) DA(d.subject_of, d.A) DA(d.walk, d.A) DA(d.upmap, nup) DA(d.nullcell, 2)
-  DA(d.qtab, SIM_QT) DA(d.qbits, (size_t)SIM_QT * 2 * nup)
+  DA(d.qtab, QTAB_U4(d.N)) DA(d.qbits, (size_t)SIM_QT * 2 * nup)
   DA(d.events, (size_t)EV_CAP) DA(d.ev_count, 1)
   DA(h->d_base, (size_t)d.N * 2)
   DA(h->d_scratch, 16)
@@ -2203,7 +2246,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   HCHECK(zero(d.qpay, (size_t)SIM_Q * Nl * 16));
   HCHECK(zero(d.ev_count, 4));
   HCHECK(zero(d.nullcell, 32));
-  HCHECK(zero(d.qtab, SIM_QT * 16)); HCHECK(zero(d.qbits, (size_t)SIM_QT * 2 * nup * 4));
+  HCHECK(zero(d.qtab, QTAB_U4(d.N) * 16)); HCHECK(zero(d.qbits, (size_t)SIM_QT * 2 * nup * 4));
   if (!d.sharded) { HCHECK(zero(d.inbox[0], (size_t)d.f * Nl * 64)); HCHECK(zero(d.inbox[1], (size_t)d.f * Nl * 64)); }
   HCHECK(zero(d.view, (size_t)d.A * Nl * 32));
   HCHECK(zero(d.ering, (size_t)d.Bev * Nl * 32));
@@ -2217,6 +2260,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   h->slot_of.assign(d.N, NOSLOT);
   h->subject_of.assign(d.A, NOSLOT);
   h->alloc_tick.assign(d.A, 0);
+  h->qfilt.assign((size_t)SIM_QT * SIM_QF_WORDS, 0);
   sim_view b0;
   memset(&b0, 0, sizeof b0);
   if (joined) { b0.ltime = 1; b0.bits = 1u | (SIM_STATUS_ALIVE << 1); }
@@ -2287,7 +2331,7 @@ static u32 op_subject(const sim_handle* h, u32 op, u32 node, u32 a) {
   switch (op) {
     case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: return node;
     case SIM_OP_FORCE_LEAVE: return a;
-    case SIM_OP_CRASH: case SIM_OP_REVIVE: return h->d.swim ? node : NOSLOT;
+    case SIM_OP_CRASH: case SIM_OP_REVIVE: case SIM_OP_SET_TAGS: return h->d.swim ? node : NOSLOT;
     default: return NOSLOT;
   }
 }
@@ -2406,6 +2450,9 @@ int sim_inject(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, uint32_
     case SIM_OP_USER_EVENT: if (!a) return SIM_EINVAL; if ((b & 0x7FFFFFFFu) > 9 * 1024) return SIM_ETOOBIG; break;  // bit 31: cc
     case SIM_OP_QUERY: if (!a) return SIM_EINVAL; break;
     case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: case SIM_OP_FORCE_LEAVE: case SIM_OP_CRASH: case SIM_OP_REVIVE: break;
+    case SIM_OP_SET_TAGS: if (a >= SIM_TAG_CLASSES) return SIM_EINVAL; break;
+    case SIM_OP_QUERY_FILTER_ID: if (!a || b >= h->d.N) return SIM_EINVAL; break;
+    case SIM_OP_QUERY_FILTER_TAGS: if (!a) return SIM_EINVAL; break;
     default: return SIM_EINVAL;
   }
   if (op == SIM_OP_FORCE_LEAVE && a >= h->d.N) return SIM_EINVAL;
@@ -2438,6 +2485,28 @@ int sim_user_event(sim_handle* h, uint32_t node, uint32_t key, uint32_t len, int
 }
 int sim_query(sim_handle* h, uint32_t node, uint32_t id, uint32_t flags) {
   return sim_inject(h, h ? h->tick : 0, SIM_OP_QUERY, node, id, flags);
+}
+int sim_query_filtered(sim_handle* h, uint32_t node, uint32_t id, uint32_t flags, const uint32_t* ids, uint32_t n_ids, uint32_t tag_mask) {
+  if (!h || !id || node >= h->d.N || (n_ids && !ids)) return SIM_EINVAL;
+  if (n_ids > SIM_QF_IDS) return SIM_ETOOBIG;
+  for (u32 i = 0; i < n_ids; ++i)
+    if (ids[i] >= h->d.N) return SIM_EINVAL;
+  int rc = SIM_OK;
+  for (u32 i = 0; i < n_ids && rc == SIM_OK; ++i) rc = sim_inject(h, h->tick, SIM_OP_QUERY_FILTER_ID, node, id, ids[i]);
+  if (rc == SIM_OK && tag_mask != 0xFFFFFFFFu) rc = sim_inject(h, h->tick, SIM_OP_QUERY_FILTER_TAGS, node, id, tag_mask);
+  return rc ? rc : sim_inject(h, h->tick, SIM_OP_QUERY, node, id, flags);
+}
+int sim_init_tags(sim_handle* h, uint32_t first, uint32_t count, const uint8_t* classes) {
+  if (!h || !classes || first > h->d.N || count > h->d.N - first) return SIM_EINVAL;
+  for (u32 i = 0; i < count; ++i)
+    if (classes[i] >= SIM_TAG_CLASSES) return SIM_EINVAL;
+  if (!count) return SIM_OK;
+  HCHECK(hipMemcpyAsync(TAGCLASS(h->d) + first, classes, count, hipMemcpyHostToDevice, h->stream));
+  HCHECK(hipStreamSynchronize(h->stream));  // the caller's buffer is free again when this returns
+  return SIM_OK;
+}
+int sim_set_tags(sim_handle* h, uint32_t node, uint32_t tag_class) {
+  return sim_inject(h, h ? h->tick : 0, SIM_OP_SET_TAGS, node, tag_class, 0);
 }
 
 // One tick = sim_step_begin (operations, push-pull batch, tick parameters), one tick-kernel launch per sender chunk
@@ -2570,6 +2639,23 @@ int sim_step_begin(sim_handle* h) {
     memset(&ob, 0, sizeof ob);
     while (ob.n < 8 && h->op_cursor < h->ops.size() && h->ops[h->op_cursor].tick <= h->tick) {
       const OpEnt& e = h->ops[h->op_cursor++];
+      if (e.op == SIM_OP_QUERY_FILTER_ID || e.op == SIM_OP_QUERY_FILTER_TAGS || e.op == SIM_OP_QUERY) {
+        // the query's filter entry: started by the first filter operation that names the query, kept by its
+        // SIM_OP_QUERY, replaced by whatever names another query with the same residue
+        u32* f = h->qfilt.data() + (size_t)(e.a % SIM_QT) * SIM_QF_WORDS;
+        bool changed = false;
+        if (f[0] != e.a) { memset(f, 0, SIM_QF_WORDS * 4); f[0] = e.a; f[2] = 0xFFFFFFFFu; changed = true; }
+        if (e.op == SIM_OP_QUERY_FILTER_ID) {
+          if (f[1] == SIM_QF_IDS) { h->ops_dropped++; continue; }  // model bound: the id does not fit
+          f[4 + f[1]++] = e.b; changed = true;
+        } else if (e.op == SIM_OP_QUERY_FILTER_TAGS) { f[2] &= e.b; changed = true; }
+        if (changed) {
+          QFiltEnt qe;
+          memcpy(&qe, f, sizeof qe);
+          qfilt_set_kernel<<<1, 64, 0, h->stream>>>(QFILT(d) + (size_t)(e.a % SIM_QT) * (SIM_QF_WORDS / 4), qe);
+        }
+        if (e.op != SIM_OP_QUERY) continue;
+      }
       u32 x = op_subject(h, e.op, e.node, e.a);
       if (x != NOSLOT && ensure_slot(h, x) != SIM_OK) { h->ops_dropped++; continue; }  // no free view slot: the operation does not happen
       ob.op[ob.n] = e.op; ob.node[ob.n] = e.node; ob.a[ob.n] = e.a; ob.b[ob.n] = e.b;
@@ -2736,7 +2822,7 @@ int sim_state_digest(sim_handle* h, uint64_t out[8]) {
   digest_split<<<grid_for(d.qtail), BLOCK, 0, s>>>(d.qring, d.qtail, d.qtail, h->d_scratch + 5);
   digest_aux<<<grid_for((size_t)d.N + d.N / 32 + 1), BLOCK, 0, s>>>(d.slot_of, d.upmap, d.N, h->d_scratch + 6);
   nw = (size_t)SIM_QT * 2 * (((size_t)d.N + 31) / 32);
-  digest_queries<<<grid_for(nw + 2 * SIM_QT), BLOCK, 0, s>>>(d.qtab, d.qbits, nw, h->d_scratch + 7);
+  digest_queries<<<grid_for(nw + 2 * SIM_QT + SIM_QT * SIM_QF_WORDS + d.N), BLOCK, 0, s>>>(d.qtab, d.qbits, nw, d.N, h->d_scratch + 7);
   HCHECK(hipMemcpyAsync(out, h->d_scratch, 8 * 8, hipMemcpyDeviceToHost, s));
   HCHECK(hipStreamSynchronize(s));
   return SIM_OK;
@@ -2830,7 +2916,7 @@ struct snap_header {
   uint64_t ops_dropped, slots_recycled;
 };
 #define SNAP_MAGIC 0x53465253u
-#define SNAP_SECTIONS 14
+#define SNAP_SECTIONS 16
 static void snap_lengths(const sim_handle* h, size_t len[SNAP_SECTIONS]) {
   const Dev& d = h->d;
   size_t nup = ((size_t)d.N + 31) / 32;
@@ -2839,7 +2925,7 @@ static void snap_lengths(const sim_handle* h, size_t len[SNAP_SECTIONS]) {
                              (size_t)d.Bev * d.Nl * sizeof(sim_bucket), (size_t)d.Bq * d.Nl * sizeof(sim_bucket),
                              (size_t)d.N * 4, (size_t)d.A * 4, (size_t)d.N * sizeof(sim_view), nup * 4,
                              (size_t)SIM_QT * 16, (size_t)SIM_QT * 2 * nup * 4, (h->ops.size() - h->op_cursor) * sizeof(OpEnt),
-                             (size_t)d.A * 4};
+                             (size_t)d.A * 4, (size_t)SIM_QT * SIM_QF_WORDS * 4, (size_t)d.N};
   memcpy(len, n, sizeof n);
 }
 int sim_snapshot(sim_handle* h, void* buf, size_t cap, size_t* bytes) {
@@ -2874,7 +2960,9 @@ int sim_snapshot(sim_handle* h, void* buf, size_t cap, size_t* bytes) {
     else if (i == 10) { HCHECK(hipMemcpyAsync(o, d.qtab, n, hipMemcpyDeviceToHost, h->stream)); HCHECK(hipStreamSynchronize(h->stream)); }
     else if (i == 11) { HCHECK(hipMemcpyAsync(o, d.qbits, n, hipMemcpyDeviceToHost, h->stream)); HCHECK(hipStreamSynchronize(h->stream)); }
     else if (i == 12) { if (n) memcpy(o, h->ops.data() + h->op_cursor, n); }
-    else memcpy(o, h->alloc_tick.data(), n);
+    else if (i == 13) memcpy(o, h->alloc_tick.data(), n);
+    else if (i == 14) memcpy(o, h->qfilt.data(), n);
+    else { HCHECK(hipMemcpyAsync(o, TAGCLASS(d), n, hipMemcpyDeviceToHost, h->stream)); HCHECK(hipStreamSynchronize(h->stream)); }
     o += n;
   }
   return SIM_OK;
@@ -2912,6 +3000,10 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
     for (u32 i = 0; i < d.N; ++i)
       if (so[i] != NOSLOT && so[i] >= (h->dense ? d.A : hd.n_slots)) return SIM_EINVAL;
   }
+  for (u32 j = 0; j < SIM_QT; ++j)  // the kernel loops over n_ids and shifts by the class
+    if (((const u32*)sec[14])[(size_t)j * SIM_QF_WORDS + 1] > SIM_QF_IDS) return SIM_EINVAL;
+  for (u32 i = 0; i < d.N; ++i)
+    if (sec[15][i] >= SIM_TAG_CLASSES) return SIM_EINVAL;
   // ---- pass 2: device copies (the handle's host state is committed only after they succeed) ----
   hipStream_t s = h->stream;
   void* tmp_rows = nullptr;
@@ -2927,6 +3019,7 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
     if (rc == SIM_OK) rc = split_copy(h, d.ering, d.etail, d.etail, (void*)sec[4], false);
     if (rc == SIM_OK) rc = split_copy(h, d.qring, d.qtail, d.qtail, (void*)sec[5], false);
     up(d.slot_of, 6); up(d.subject_of, 7); up(h->d_base, 8); up(d.upmap, 9); up(d.qtab, 10); up(d.qbits, 11);
+    up(QFILT(d), 14); up(TAGCLASS(d), 15);
     // canonical rows / queue -> packed row groups, sort keys + slot-stable payloads
     RCHECK(hipMemsetAsync(d.R2, 0, (size_t)d.Nl * 16, s));
     if (rc == SIM_OK) {
@@ -2953,6 +3046,7 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
   h->ops.assign(hd.n_pending_ops, OpEnt{0, 0, 0, 0, 0});
   if (len[12]) memcpy(h->ops.data(), sec[12], len[12]);
   memcpy(h->alloc_tick.data(), sec[13], len[13]);
+  memcpy(h->qfilt.data(), sec[14], len[14]);
   h->n_alloc = (u32)h->walk.size();
   h->ops_dropped = hd.ops_dropped; h->slots_recycled = hd.slots_recycled;
   h->recycle_at = 0xFFFFFFFFu;

@@ -58,8 +58,14 @@ class ShardedSim:
     def user_event(self, node, key, encoded_len=32):
         self.sim.user_event(node, key, encoded_len)
 
-    def query(self, node, qid, flags=0):
-        self.sim.query(node, qid, flags)
+    def query(self, node, qid, flags=0, ids=None, tag_mask=_ffi.NO_TAG_FILTER):
+        self.sim.query(node, qid, flags, ids, tag_mask)
+
+    def set_tags(self, node, tag_class):
+        self.sim.set_tags(node, tag_class)
+
+    def init_tags(self, classes, first=0):
+        self.sim.init_tags(classes, first)
 
     def leave(self, node):
         self.sim.leave(node)

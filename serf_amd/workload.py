@@ -61,6 +61,31 @@ def schedule(n_nodes, n_ticks, rate, seed=1234, mix=(0.5, 0.15, 0.15, 0.1, 0.1),
     return ops
 
 
+def with_filters(ops, n_nodes, seed=5, p=0.6, tag_changes=0, n_ticks=None):
+    """QueryParam.filters and Serf::set_tags on top of a schedule (its own random stream: the base schedule is kept).
+    With probability `p` a query gets filters — a Filter::Id list of 1..12 nodes, a tag-class mask, or both — as
+    SIM_OP_QUERY_FILTER_* operations right before it; `tag_changes` SIM_OP_SET_TAGS are spread over the first
+    `n_ticks` ticks.  Returns (ops, classes): `classes` = the start-up tag class of every node (Sim.init_tags)."""
+    rng = np.random.default_rng(seed)
+    classes = rng.integers(0, 8, n_nodes).astype(np.uint8)   # class 0 = no tags
+    out = []
+    for o in ops:
+        if o[1] == _ffi.OP_QUERY and rng.random() < p:
+            t, _, node, qid, _ = o
+            how = int(rng.integers(0, 3))
+            if how != 1:
+                for x in rng.choice(n_nodes, int(rng.integers(1, _ffi.QF_IDS + 1)), replace=False).tolist():
+                    out.append((t, _ffi.OP_QUERY_FILTER_ID, node, qid, int(x)))
+            if how != 0:
+                out.append((t, _ffi.OP_QUERY_FILTER_TAGS, node, qid, int(rng.integers(0, 256)) & ~1))
+        out.append(o)
+    last = n_ticks if n_ticks is not None else (max(o[0] for o in ops) + 1 if ops else 1)
+    for _ in range(tag_changes):
+        out.append((int(rng.integers(0, last)), _ffi.OP_SET_TAGS, int(rng.integers(0, n_nodes)), int(rng.integers(0, 8)), 0))
+    out.sort(key=lambda o: o[0])
+    return out, classes
+
+
 def apply_schedule(sim, ops):
     for t, op, node, a, b in ops:
         sim.inject(t, op, node, a, b)

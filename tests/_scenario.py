@@ -4,7 +4,7 @@ import numpy as np
 from serf_amd import _ffi
 
 
-from serf_amd.workload import apply_schedule, schedule  # noqa: E402,F401  (moved into the package: bench.py uses it)
+from serf_amd.workload import apply_schedule, schedule, with_filters  # noqa: E402,F401  (moved into the package: bench.py uses it)
 
 
 ARRAYS = (_ffi.ARR_ROWS, _ffi.ARR_QUEUE, _ffi.ARR_INBOX, _ffi.ARR_VIEW, _ffi.ARR_ERING, _ffi.ARR_QRING, _ffi.ARR_SLOTMAP)

@@ -31,6 +31,10 @@ def _worker(rank, world, port, n, ticks, swim, chunks, q):
         sh = ShardedSim(lib, n, torch.device("cpu"), chunks=chunks, **kw)
         ref = _ffi.Sim(lib, _ffi.make_config(n, vshards=world, chunks=chunks if chunks > 1 else 0, **kw))  # all shards in one process
         ops = sc.schedule(n, ticks // 2, rate=0.7, seed=17, max_member_subjects=40)
+        # query filters and tag classes are replicated tables: every shard applies the same operations
+        ops, classes = sc.with_filters(ops, n, tag_changes=6 if swim else 0)
+        sh.init_tags(classes)
+        ref.init_tags(classes)
         for t, op, node, a, b in ops:
             sh.inject(t, op, node, a, b)
             ref.inject(t, op, node, a, b)
