@@ -85,6 +85,10 @@ class Serf {
   // api.rs:241 — `name`/`payload` identity is a 32-bit key, `encoded_len` its wire size in bytes
   inline void user_event(uint32_t event_key, uint32_t encoded_len = 32, bool coalesce = true);
   inline void query(uint32_t query_id, uint32_t flags = 0);                   // api.rs:304
+  // QueryParam.filters (query.rs:37-93, should_process_query query.rs:439-521): `ids` = Filter::Id (at most
+  // SIM_QF_IDS), `tag_mask` = the AND of the Filter::Tag masks over tag classes (0xFFFFFFFF = no tag filter)
+  inline void query(uint32_t query_id, uint32_t flags, const std::vector<uint32_t>& ids, uint32_t tag_mask = 0xFFFFFFFFu);
+  inline void set_tags(uint32_t tag_class);                                   // api.rs:219
   struct QueryStatus { uint64_t acks, responses; bool open; };                // QueryResponse, query.rs:117-303
   inline QueryStatus query_status(uint32_t query_id) const;
   inline void join(uint32_t peer);                                            // api.rs:318
@@ -104,6 +108,10 @@ class Cluster {
  public:
   explicit Cluster(const Options& o) : n_(o.c.n_nodes) { check(sim_create(&o.c, &h_), "sim_create"); }
   ~Cluster() { if (h_) sim_destroy(h_); }
+  // Options::with_tags for every node at once (start-up tags; include/serf_sim.h sim_init_tags)
+  void init_tags(const std::vector<uint8_t>& classes, uint32_t first = 0) {
+    check(sim_init_tags(h_, first, (uint32_t)classes.size(), classes.data()), "sim_init_tags");
+  }
   Cluster(const Cluster&) = delete;
   Cluster& operator=(const Cluster&) = delete;
   Serf node(uint32_t id) { return Serf(this, id); }
@@ -159,6 +167,10 @@ inline Stats Serf::stats() const {
 }
 inline void Serf::user_event(uint32_t key, uint32_t len, bool cc) { check(sim_user_event(c_->raw(), id_, key, len, cc), "sim_user_event"); }
 inline void Serf::query(uint32_t qid, uint32_t flags) { check(sim_query(c_->raw(), id_, qid, flags), "sim_query"); }
+inline void Serf::query(uint32_t qid, uint32_t flags, const std::vector<uint32_t>& ids, uint32_t tag_mask) {
+  check(sim_query_filtered(c_->raw(), id_, qid, flags, ids.data(), (uint32_t)ids.size(), tag_mask), "sim_query_filtered");
+}
+inline void Serf::set_tags(uint32_t tag_class) { check(sim_set_tags(c_->raw(), id_, tag_class), "sim_set_tags"); }
 inline Serf::QueryStatus Serf::query_status(uint32_t qid) const {
   QueryStatus st{0, 0, false};
   int open = 0;

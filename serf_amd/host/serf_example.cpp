@@ -18,6 +18,15 @@ int main(int argc, char** argv) {
     uint32_t rounds = 0;
     while (cl.convergence(SIM_K_EVENT, 42, 1) < 0.99 && rounds < 200) { cl.step(); ++rounds; }
     printf("user event reached 99%% of %u nodes after %u rounds\n", n, rounds);
+    // a query only the "web" nodes (tag class 1: every fourth node) answer, and of those only three by id
+    std::vector<uint8_t> classes(n);
+    for (uint32_t i = 0; i < n; ++i) classes[i] = i % 4 == 0 ? 1 : 2;
+    cl.init_tags(classes);
+    s7.query(/*query_id=*/7, SIM_F_ACK, /*ids=*/{0, 4, 5}, /*tag_mask=*/1u << 1);
+    cl.step(60);
+    serf::Serf::QueryStatus qs = s7.query_status(7);
+    printf("filtered query: %llu acks (nodes 0 and 4: id listed and class 1)\n", (unsigned long long)qs.acks);
+    if (qs.acks != 2) return 1;
     cl.step(1500);
     serf::Stats st = s0.stats();
     printf("node 0: members %u failed %u left %u, clocks %llu/%llu/%llu\n", st.members, st.failed, st.left,
