@@ -150,10 +150,25 @@ typedef struct sim_record {
 #define SIM_META_SEQ(m) (1023u - (((m) >> 8) & 0x3FFu))
 #define SIM_META_LEN64(m) (63u - (((m) >> 18) & 0x3Fu))
 
-/* 64-byte gossip packet: SIM_P records, empty records have meta == 0 on the wire. */
+/* 48-byte gossip packet: SIM_P records in their 12-byte WIRE form, stored field by field.  A record on the wire needs
+ * its key (32 bits), 48 bits of value — a Lamport time or an incarnation; for SUSPECT / DEAD the incarnation (24 bits)
+ * and the accuser `from` (24 bits) — and 14 bits of meta (len64, kind, flags: SIM_META_WIRE_MASK squeezed together);
+ * class, transmits and queue id never travel.  Packets are half of the tick's HBM traffic: 48 instead
+ * of 64 bytes is an eighth of all bytes moved.  Model bounds: Lamport times below 2^48, incarnations and node ids
+ * below 2^24.  An empty record is all zero (kind 0). */
 typedef struct sim_packet {
-  sim_record rec[SIM_P];
+  uint32_t key[SIM_P];
+  uint32_t val_lo[SIM_P];   /* value bits 31..0                                    */
+  uint32_t hi_meta[SIM_P];  /* [31:16] value bits 47..32   [13:8] 63-len64   [7:4] kind   [3:0] flags */
 } sim_packet;
+#define SIM_WIRE_TWO_PART(kind) ((kind) == SIM_K_SUSPECT || (kind) == SIM_K_DEAD)
+/* sim_record.val -> the 48 bits that travel, and back */
+#define SIM_WIRE_VAL48(kind, val) \
+  (SIM_WIRE_TWO_PART(kind) ? (((val) & 0xFFFFFFull) | ((((val) >> 32) & 0xFFFFFFull) << 24)) : ((val) & 0xFFFFFFFFFFFFull))
+#define SIM_WIRE_VAL(kind, v48) (SIM_WIRE_TWO_PART(kind) ? (((v48) & 0xFFFFFFull) | (((v48) >> 24) << 32)) : (v48))
+/* sim_record.meta (wire bits) -> the 14 bits that travel, and back */
+#define SIM_WIRE_META14(meta) (((((meta) >> 18) & 0x3Fu) << 8) | ((meta) & 0xFFu))
+#define SIM_WIRE_META(m14) (((((m14) >> 8) & 0x3Fu) << 18) | ((m14) & 0xFFu))
 
 /*
  * 32-byte per-(observer, subject-slot) view entry.
@@ -285,6 +300,8 @@ typedef struct sim_cluster_stats {
   uint64_t max_queue;     /* deepest queue of any node                                          */
   uint64_t ops_dropped;   /* scheduled operations skipped because no view slot was free (model bound; handle-wide) */
   uint64_t slots_in_use, slots_recycled; /* view slots handed out now / given back so far (handle-wide)  */
+  uint64_t events_lost;   /* watched nodes' events that did not fit the device log (it holds 2^20 events between two
+                             sim_drain_events calls; the CPU oracle's log grows and never loses any)             */
 } sim_cluster_stats;
 
 /* One candidate of a view-slot recycling pass (sharded runs: every shard scans its own nodes, the host combines). */
@@ -366,7 +383,10 @@ int sim_tick(const sim_handle* h, uint64_t* tick);
 int sim_members(sim_handle* h, uint32_t observer, uint8_t* out_status, uint64_t* out_ltime, uint32_t cap);
 /* Serf::stats (api.rs:150-183). */
 int sim_stats_get(sim_handle* h, uint32_t node, sim_stats* out);
-/* Event stream (EventSubscriber, event.rs:430-491) for watched observers. */
+/* Event stream (EventSubscriber, event.rs:430-491) for watched observers.  sim_drain_events hands over at most `cap`
+ * events in (tick, observer) order and keeps the rest for the next call.  The device log is bounded (2^20 events
+ * between two drains): what does not fit is dropped and counted in sim_cluster_stats.events_lost — drain often
+ * enough, or watch fewer nodes. */
 int sim_watch(sim_handle* h, uint32_t observer);
 int sim_drain_events(sim_handle* h, sim_event* out, uint32_t cap, uint32_t* n);
 

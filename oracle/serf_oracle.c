@@ -446,6 +446,24 @@ static void q_push(nctx* c, uint32_t key, uint32_t wmeta, uint64_t val) {
  * (class, then transmit tier, largest first within a tier) and take every one that still fits SIM_PKT_UNITS, at most
  * SIM_P of them — an entry that does not fit is skipped, a smaller one further on may; transmits+1; drop at the
  * retransmit limit; re-insert. */
+/* a record into / out of slot i of a packet (include/serf_sim.h: 12-byte wire form) */
+static inline void pk_put(sim_packet* pk, uint32_t i, uint32_t key, uint32_t meta, uint64_t val) {
+  uint32_t kind = SIM_META_KIND(meta);
+  uint64_t v48 = SIM_WIRE_VAL48(kind, val);
+  pk->key[i] = key;
+  pk->val_lo[i] = (uint32_t)v48;
+  pk->hi_meta[i] = ((uint32_t)(v48 >> 32) << 16) | SIM_WIRE_META14(meta);
+}
+static inline uint32_t pk_kind(const sim_packet* pk, uint32_t i) { return (pk->hi_meta[i] >> 4) & 0xFu; }
+static inline sim_record pk_get(const sim_packet* pk, uint32_t i) {
+  sim_record r;
+  uint32_t hm = pk->hi_meta[i];
+  uint64_t v48 = (uint64_t)pk->val_lo[i] | ((uint64_t)(hm >> 16) << 32);
+  r.key = pk->key[i];
+  r.meta = SIM_WIRE_META(hm & 0x3FFFu);
+  r.val = SIM_WIRE_VAL(SIM_META_KIND(r.meta), v48);
+  return r;
+}
 static void queue_emit(sim_row* row, sim_record* q, uint32_t limit, sim_packet* out) {
   (void)row;
   memset(out, 0, sizeof *out);
@@ -456,9 +474,7 @@ static void queue_emit(sim_row* row, sim_record* q, uint32_t limit, sim_packet* 
     uint32_t len = SIM_META_LEN64(r->meta);
     if (len > free_u) continue;
     free_u -= len;
-    out->rec[cnt].key = r->key;
-    out->rec[cnt].meta = r->meta & SIM_META_WIRE_MASK;
-    out->rec[cnt].val = r->val;
+    pk_put(out, cnt, r->key, r->meta & SIM_META_WIRE_MASK, r->val);
     cnt++;
     uint32_t t = SIM_META_TRANSMITS(r->meta) + 1;
     if (t >= limit) rec_clear(r);
@@ -1252,13 +1268,13 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
       for (uint32_t i = s->rcsr[l]; i < s->rcsr[l + 1]; ++i) {
         const sim_packet* pk = &s->inbox[s->tick & 1][s->rsrc[i]];
         for (uint32_t r = 0; r < SIM_P; ++r)
-          if (SIM_META_KIND(pk->rec[r].meta) != SIM_K_EMPTY) dispatch_record(&c, &pk->rec[r]);
+          if (pk_kind(pk, r) != SIM_K_EMPTY) { sim_record rec = pk_get(pk, r); dispatch_record(&c, &rec); }
       }
     } else if (s->tick > 0) {
       for (uint32_t k = 0; k < s->f; ++k) {
         const sim_packet* pk = inbox_cell(s, k, l);
         for (uint32_t r = 0; r < SIM_P; ++r)
-          if (SIM_META_KIND(pk->rec[r].meta) != SIM_K_EMPTY) dispatch_record(&c, &pk->rec[r]);
+          if (pk_kind(pk, r) != SIM_K_EMPTY) { sim_record rec = pk_get(pk, r); dispatch_record(&c, &rec); }
       }
     }
     if (s->swim) {
@@ -1614,8 +1630,8 @@ static void recycle_scan(osim* s, rc_cand* c, uint32_t n) {
   if (in)
     for (size_t i = 0; i < (size_t)s->f * s->Nl; ++i)
       for (uint32_t p = 0; p < SIM_P; ++p) {
-        uint32_t kind = SIM_META_KIND(in[i].rec[p].meta);
-        if ((kind == SIM_K_JOIN || kind == SIM_K_LEAVE || kind >= SIM_K_ALIVE) && in[i].rec[p].key < s->N) refd[in[i].rec[p].key] = 1;
+        uint32_t kind = pk_kind(&in[i], p);
+        if ((kind == SIM_K_JOIN || kind == SIM_K_LEAVE || kind >= SIM_K_ALIVE) && in[i].key[p] < s->N) refd[in[i].key[p]] = 1;
       }
   for (uint32_t i = 0; i < n; ++i) {
     uint32_t a = c[i].slot;
@@ -1834,7 +1850,7 @@ int API(state_digest)(osim* s, uint64_t out[8]) {
   memset(out, 0, 8 * sizeof(uint64_t));
   out[0] = dig_words(s->rows, (size_t)s->Nl * sizeof(sim_row) / 8);
   out[1] = dig_words(s->queue, (size_t)s->Nl * SIM_Q * 2);
-  out[2] = dig_words(cur_inbox(s), (size_t)s->f * s->Nl * 8);
+  out[2] = dig_words(cur_inbox(s), (size_t)s->f * s->Nl * (sizeof(sim_packet) / 8));
   out[3] = dig_words(s->view, (size_t)s->A * s->Nl * 4);
   out[4] = dig_words(s->ering, (size_t)s->Bev * s->Nl * 4);
   out[5] = dig_words(s->qring, (size_t)s->Bq * s->Nl * 4);
@@ -2045,8 +2061,9 @@ int API(cluster_stats_get)(osim* s, sim_cluster_stats* o) {
   const sim_packet* in = cur_inbox(s);
   if (in)
     for (size_t i = 0; i < (size_t)s->f * s->Nl; ++i)
-      for (uint32_t p = 0; p < SIM_P; ++p) o->inbox_records += SIM_META_KIND(in[i].rec[p].meta) != SIM_K_EMPTY;
+      for (uint32_t p = 0; p < SIM_P; ++p) o->inbox_records += pk_kind(&in[i], p) != SIM_K_EMPTY;
   o->ops_dropped = s->ops_dropped; o->slots_in_use = s->n_alloc; o->slots_recycled = s->slots_recycled;
+  o->events_lost = 0; /* the log grows (emit_event) */
   return SIM_OK;
 }
 int API(exchange_bytes)(const osim* s, size_t* bytes) {

@@ -65,7 +65,8 @@ class Stats(C.Structure):
 class ClusterStats(C.Structure):
     _fields_ = [("up", C.c_uint64), ("queued", C.c_uint64 * 4), ("overflow", C.c_uint64),
                 ("inbox_records", C.c_uint64), ("failed", C.c_uint64), ("left", C.c_uint64), ("max_queue", C.c_uint64),
-                ("ops_dropped", C.c_uint64), ("slots_in_use", C.c_uint64), ("slots_recycled", C.c_uint64)]
+                ("ops_dropped", C.c_uint64), ("slots_in_use", C.c_uint64), ("slots_recycled", C.c_uint64),
+                ("events_lost", C.c_uint64)]
 
 
 class RecycleCand(C.Structure):
@@ -87,9 +88,10 @@ ROW_DTYPE = np.dtype([("clock", "<u8"), ("event_clock", "<u8"), ("query_clock", 
                       ("next_seq", "<u4"), ("overflow", "<u4"), ("susp_next", "<u4"),
                       ("awareness", "<u4"), ("reap_next", "<u4"), ("susp", "<u2", (8,))])
 REC_DTYPE = np.dtype([("key", "<u4"), ("meta", "<u4"), ("val", "<u8")])
+PACKET_DTYPE = np.dtype([("key", "<u4", (4,)), ("val_lo", "<u4", (4,)), ("hi_meta", "<u4", (4,))])  # 12-byte wire records
 VIEW_DTYPE = np.dtype([("ltime", "<u8"), ("inc", "<u4"), ("bits", "<u4"), ("conf", "<u4", (4,))])
 BUCKET_DTYPE = np.dtype([("ltime", "<u8"), ("keys", "<u4", (CKEYS,))])
-_ARR_DTYPE = {ARR_ROWS: ROW_DTYPE, ARR_QUEUE: REC_DTYPE, ARR_INBOX: REC_DTYPE, ARR_VIEW: VIEW_DTYPE,
+_ARR_DTYPE = {ARR_ROWS: ROW_DTYPE, ARR_QUEUE: REC_DTYPE, ARR_INBOX: PACKET_DTYPE, ARR_VIEW: VIEW_DTYPE,
               ARR_ERING: BUCKET_DTYPE, ARR_QRING: BUCKET_DTYPE, ARR_SLOTMAP: np.dtype("<u4")}
 
 # every symbol include/serf_sim.h declares (without prefix)
@@ -349,7 +351,8 @@ class Sim:
         self._ck(self.lib.f["cluster_stats_get"](self.h, C.byref(s)), "sim_cluster_stats_get")
         return {"up": s.up, "queued": [int(x) for x in s.queued], "overflow": s.overflow,
                 "inbox_records": s.inbox_records, "failed": s.failed, "left": s.left, "max_queue": s.max_queue,
-                "ops_dropped": s.ops_dropped, "slots_in_use": s.slots_in_use, "slots_recycled": s.slots_recycled}
+                "ops_dropped": s.ops_dropped, "slots_in_use": s.slots_in_use, "slots_recycled": s.slots_recycled,
+                "events_lost": s.events_lost}
 
     def exchange_bytes(self):
         n = C.c_size_t()

@@ -4,7 +4,7 @@
 //   1. streams its packed row (three 16-byte groups: the 3 Lamport clocks, SerfState bits and
 //      counters, queue bookkeeping; a fourth group with the memberlist fields when the SWIM layer
 //      is on) and the 16 sort keys of its TransmitLimitedQueue out of HBM,
-//   2. reads the fan-out packets addressed to it (inbox[k][node], 64 B each), four records at a
+//   2. reads the fan-out packets addressed to it (inbox[k][node], 48 B each: 12-byte wire records), four records at a
 //      time, first issuing the four independent de-dup lookups of a packet (slot map -> view
 //      column entry, or event/query ring bucket) and only then running the handlers in arrival
 //      order, so a packet costs two memory round trips instead of eight,
@@ -218,7 +218,7 @@ struct Dev {
   uint4* qkeys;  // [4][Nl]  the 16 sort keys of a node's queue, ascending, 4 per uint4
   uint4* qpay;   // [Q][Nl]  slot-stable wire records {key, wire meta, val.lo, val.hi}
   uint4* pend;   // [SIM_PEND][Nl] broadcasts requested by the handlers of the running tick, arrival order
-  uint4* inbox[2];       // [f][Nl] packets of 4 x uint4 (local mode)
+  uint4* inbox[2];       // [f][Nl] packets of 3 x uint4: keys, value low words, value high bits + meta (local mode)
   uint4 *xsend, *xrecv;  // sharded mode: [V][f][blk] packets
   // Entries are split into two planes of 16 bytes per (row, node): the HEAD the hot path checks every record against
   // — view {ltime.lo, ltime.hi, inc, bits}, ring bucket {ltime.lo, ltime.hi, k0, k1} — at arr[row * Nl + l], dense
@@ -1128,9 +1128,21 @@ static u32 g_ablate = 0;
 #ifndef TICK_OCC
 #define TICK_OCC 4
 #endif
-#ifndef TICK_PREFETCH4
-#define TICK_PREFETCH4 1  // all four records of the next packet are fetched one packet ahead (measured: -4 %)
-#endif
+// A record between its 16-byte working form {key, wire meta, val} and its 12 bytes in a packet (include/serf_sim.h
+// sim_packet: key, value bits 31..0, value bits 47..32 | len64 | kind | flags; SUSPECT / DEAD carry inc : 24 | from : 24)
+#define PK_U4 3u  // a packet cell is three uint4: the four keys, the four low words, the four high words
+__device__ static inline uint4 wire_unpack(u32 key, u32 lo, u32 hm) {
+  u32 meta = (((hm >> 8) & 0x3Fu) << 18) | (hm & 0xFFu), hi = hm >> 16;
+  bool two = ((hm >> 5) & 7u) == 3u;  // kind 6 or 7
+  return make_uint4(key, meta, two ? (lo & 0xFFFFFFu) : lo, two ? ((lo >> 24) | (hi << 8)) : hi);
+}
+__device__ static inline void wire_pack(const uint4& r, u32& key, u32& lo, u32& hm) {
+  bool two = ((r.y >> 5) & 7u) == 3u;
+  key = r.x;
+  lo = two ? ((r.z & 0xFFFFFFu) | (r.w << 24)) : r.z;
+  hm = ((two ? (r.w >> 8) : r.w) << 16) | (((r.y >> 18) & 0x3Fu) << 8) | (r.y & 0xFFu);
+}
+__device__ static inline u32 pk_word(const uint4& v, u32 p) { return p == 0 ? v.x : p == 1 ? v.y : p == 2 ? v.z : v.w; }
 template <bool SHARDED, int F>
 __global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, u32 cur, const uint4* base, u32 chunk, u32 cnt) {
 #ifdef TICK_TIMING
@@ -1176,15 +1188,13 @@ __global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, 
           u32 b = l / tp.blk, w = l - b * tp.blk, sl = w / tp.sub;
           u32 src = (d.shard_rank + b + tp.prot[k]) % tp.V;
           u32 ch = (sl + tp.C - tp.prho[k]) % tp.C;
-          return d.xrecv + ((((size_t)ch * tp.V + src) * d.f + k) * tp.sub + (w - sl * tp.sub)) * 4;
+          return d.xrecv + ((((size_t)ch * tp.V + src) * d.f + k) * tp.sub + (w - sl * tp.sub)) * PK_U4;
         }
-        return d.inbox[cur] + ((size_t)k * d.Nl + l) * 4;
+        return d.inbox[cur] + ((size_t)k * d.Nl + l) * PK_U4;
       };
       const uint4* cell = cell_of(0);
-      uint4 rn = ld4(cell);  // first record of the next packet, fetched one packet ahead
-#if TICK_PREFETCH4
-      uint4 rn1 = ld4(cell + 1), rn2 = ld4(cell + 2), rn3 = ld4(cell + 3);  // ... and the other three as well
-#endif
+      // the next packet (keys, low words, high words), fetched one packet ahead
+      uint4 rn = ld4(cell), rn1 = ld4(cell + 1), rn2 = ld4(cell + 2);
       for (u32 k = 0; k < d.f; ++k) {
         // ---- stage the packet in LDS (one 16-byte column per record and lane: conflict-free) ----
         // phase A: the four records, then their four independent lookups — slot map for member
@@ -1192,23 +1202,17 @@ __global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, 
         // against.  Everything lands in this lane's LDS cells so that the handler loop below can
         // index it by record number without holding 40 registers across the handlers.
         {
-#if TICK_PREFETCH4
-          uint4 r0 = rn, r1 = rn1, r2 = rn2, r3 = rn3;
+          const uint4 ck = rn, cl = rn1, ch = rn2;
           if (k + 1 < d.f) {
             cell = cell_of(k + 1);
-            rn = ld4(cell); rn1 = ld4(cell + 1); rn2 = ld4(cell + 2); rn3 = ld4(cell + 3);
+            rn = ld4(cell); rn1 = ld4(cell + 1); rn2 = ld4(cell + 2);
           }
-#else
-          uint4 r0 = rn, r1 = ld4(cell + 1), r2 = ld4(cell + 2), r3 = ld4(cell + 3);
-          if (k + 1 < d.f) {  // pull the next cell's line towards this CU while this packet is handled
-            cell = cell_of(k + 1);
-            rn = ld4(cell);
-          }
-#endif
           TT(1);
+          // wave-ballot early out: nobody in this wave received anything in packet k (an empty record is all zero)
+          if (!__any(((ch.x | ch.y | ch.z | ch.w) & 0xF0u) != 0)) continue;
+          uint4 r0 = wire_unpack(ck.x, cl.x, ch.x), r1 = wire_unpack(ck.y, cl.y, ch.y);
+          uint4 r2 = wire_unpack(ck.z, cl.z, ch.z), r3 = wire_unpack(ck.w, cl.w, ch.w);
           u32 k0 = SIM_META_KIND(r0.y), k1 = SIM_META_KIND(r1.y), k2 = SIM_META_KIND(r2.y), k3 = SIM_META_KIND(r3.y);
-          // wave-ballot early out: nobody in this wave received anything in packet k
-          if (!__any((k0 | k1 | k2 | k3) != SIM_K_EMPTY)) continue;
           if (ABL(64)) { n.dirty |= (k0 ^ k1 ^ k2 ^ k3) & tp.zero_; continue; }
           lds_r[0][tid] = r0; lds_r[1][tid] = r1; lds_r[2][tid] = r2; lds_r[3][tid] = r3;
           u32 s0 = slot_load(d, k0, r0.x);
@@ -1363,29 +1367,32 @@ __global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, 
     if (sl >= tp.C) sl -= tp.C;
     u32 t = bb * tp.blk + sl * tp.sub + r;
     uint4* dst;
-    if (SHARDED) dst = d.xsend + ((((size_t)s0 * tp.V + h) * d.f + k) * tp.sub + r) * 4;
-    else dst = d.inbox[cur ^ 1] + ((size_t)k * d.Nl + (size_t)h * tp.M + t) * 4;
+    if (SHARDED) dst = d.xsend + ((((size_t)s0 * tp.V + h) * d.f + k) * tp.sub + r) * PK_U4;
+    else dst = d.inbox[cur ^ 1] + ((size_t)k * d.Nl + (size_t)h * tp.M + t) * PK_U4;
+    uint4 wk, wl, wh;  // the packet in its wire form
+    wire_pack(pk[k][0], wk.x, wl.x, wh.x); wire_pack(pk[k][1], wk.y, wl.y, wh.y);
+    wire_pack(pk[k][2], wk.z, wl.z, wh.z); wire_pack(pk[k][3], wk.w, wl.w, wh.w);
     if (coop) {
-      // Four lanes write one 64-byte cell per store instruction (lane i of the quad writes record
-      // i of quad-mate j's packet): the texture addresser sees 64 contiguous bytes per quad and L2
-      // one write per cell instead of four.  The 4x4 transpose goes through this wave's columns of
-      // lds_r (free in phase 2), XOR-swizzled so that neither side has bank conflicts.
-      lds_r[0][tid] = pk[k][0]; lds_r[1][tid ^ 1] = pk[k][1]; lds_r[2][tid ^ 2] = pk[k][2]; lds_r[3][tid ^ 3] = pk[k][3];
+      // Three lanes of a quad write one 48-byte cell per store instruction (lane i < 3 writes part i of quad-mate
+      // j's packet): the texture addresser sees 48 contiguous bytes per quad and L2 one write per cell instead of
+      // three.  The transpose goes through this wave's columns of lds_r (free in phase 2), XOR-swizzled so that
+      // neither side has bank conflicts.
+      lds_r[0][tid] = wk; lds_r[1][tid ^ 1] = wl; lds_r[2][tid ^ 2] = wh;
       __builtin_amdgcn_wave_barrier();
-      u32 qi = tid & 3u, qb = tid & ~3u;
+      u32 qi = tid & 3u, qb = tid & ~3u, part = qi < 3u ? qi : 2u;  // the fourth lane of a quad has nothing to write
       u32 dlo = (u32)(uintptr_t)dst, dhi = (u32)((uintptr_t)dst >> 32);
 #define COOP_STORE(j)                                                                              \
       {                                                                                            \
-        uint4 v = lds_r[qi][(qb + j) ^ qi];                                                        \
+        uint4 v = lds_r[part][(qb + j) ^ part];                                                    \
         u32 lo = (u32)__builtin_amdgcn_mov_dpp((int)dlo, j * 0x55, 0xF, 0xF, true);                \
         u32 hi = (u32)__builtin_amdgcn_mov_dpp((int)dhi, j * 0x55, 0xF, 0xF, true);                \
-        ((uint4*)(((uintptr_t)hi << 32) | lo))[qi] = v;                                            \
+        if (qi < 3u) ((uint4*)(((uintptr_t)hi << 32) | lo))[qi] = v;                               \
       }
       COOP_STORE(0) COOP_STORE(1) COOP_STORE(2) COOP_STORE(3)
 #undef COOP_STORE
       __builtin_amdgcn_wave_barrier();
     } else {
-      dst[0] = pk[k][0]; dst[1] = pk[k][1]; dst[2] = pk[k][2]; dst[3] = pk[k][3];
+      dst[0] = wk; dst[1] = wl; dst[2] = wh;
     }
   }
   TT(10);
@@ -1963,7 +1970,7 @@ __global__ void cluster_stats_kernel(Dev d, const uint4* inbox, u64* out) {
     a[5] += r2.w; a[7] += r2.x; a[8] += r2.y;
     if (inbox)
       for (u32 k = 0; k < d.f; ++k)
-        for (u32 p = 0; p < SIM_P; ++p) a[6] += SIM_META_KIND(inbox[((size_t)k * d.Nl + l) * 4 + p].y) != SIM_K_EMPTY;
+        for (u32 p = 0; p < SIM_P; ++p) a[6] += SIM_META_KIND(pk_word(inbox[((size_t)k * d.Nl + l) * PK_U4 + 2], p)) != SIM_K_EMPTY;
   }
   for (int i = 0; i < 9; ++i) block_sum_add(a[i], out + i);
   atomicMax((unsigned long long*)(out + 9), (unsigned long long)mx);
@@ -1979,8 +1986,9 @@ __global__ void recycle_refd_kernel(Dev d, const uint4* inbox, uint8_t* refd, u3
     if (inbox)
       for (u32 k = 0; k < d.f; ++k)
         for (u32 p = 0; p < SIM_P; ++p) {
-          uint4 r = inbox[((size_t)k * d.Nl + l) * 4 + p];
-          if (member_kind(SIM_META_KIND(r.y)) && r.x < d.N) refd[r.x] = 1;
+          const uint4* cellp = inbox + ((size_t)k * d.Nl + l) * PK_U4;
+          u32 key = pk_word(cellp[0], p);
+          if (member_kind(SIM_META_KIND(pk_word(cellp[2], p))) && key < d.N) refd[key] = 1;
         }
     uint4 r1 = d.R1[l];
     if (!(r1.z & SIM_RF_UP)) continue;
@@ -2037,6 +2045,7 @@ struct sim_handle {
   std::vector<u32> alloc_tick;  // [A] tick at which the slot was handed out
   u32 n_alloc;                  // slots in use
   u64 ops_dropped, slots_recycled;
+  u64 events_lost;              // events the bounded device log dropped (counted when they are drained)
   u32 recycle_at;               // the tick whose recycling pass has already run
   u32 pp_done_at;               // the tick whose push-pull batch the sharded host has already run
   // the batch being driven by the sharded host: in-shard pairs, and the cross-shard pairs grouped by peer shard in
@@ -2226,7 +2235,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   }
   DA(d.R0, Nl) DA(d.R1, Nl) DA(d.R2, Nl) DA(d.R3, Nl) DA(d.R4, Nl) DA(d.R5, Nl)
   DA(d.qkeys, 4 * Nl) DA(d.qpay, (size_t)SIM_Q * Nl) DA(d.pend, (size_t)SIM_PEND * Nl)
-  if (!d.sharded) { DA(d.inbox[0], (size_t)d.f * Nl * 4) DA(d.inbox[1], (size_t)d.f * Nl * 4) }
+  if (!d.sharded) { DA(d.inbox[0], (size_t)d.f * Nl * PK_U4) DA(d.inbox[1], (size_t)d.f * Nl * PK_U4) }
   DA(d.view, (size_t)d.A * Nl * 2)
   DA(d.ering, (size_t)d.Bev * Nl * 2)
   DA(d.qring, (size_t)d.Bq * Nl * 2)
@@ -2247,7 +2256,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   HCHECK(zero(d.ev_count, 4));
   HCHECK(zero(d.nullcell, 32));
   HCHECK(zero(d.qtab, QTAB_U4(d.N) * 16)); HCHECK(zero(d.qbits, (size_t)SIM_QT * 2 * nup * 4));
-  if (!d.sharded) { HCHECK(zero(d.inbox[0], (size_t)d.f * Nl * 64)); HCHECK(zero(d.inbox[1], (size_t)d.f * Nl * 64)); }
+  if (!d.sharded) { HCHECK(zero(d.inbox[0], (size_t)d.f * Nl * sizeof(sim_packet))); HCHECK(zero(d.inbox[1], (size_t)d.f * Nl * sizeof(sim_packet))); }
   HCHECK(zero(d.view, (size_t)d.A * Nl * 32));
   HCHECK(zero(d.ering, (size_t)d.Bev * Nl * 32));
   HCHECK(zero(d.qring, (size_t)d.Bq * Nl * 32));
@@ -2789,7 +2798,7 @@ int sim_drain_events(sim_handle* h, sim_event* out, uint32_t cap, uint32_t* n) {
   HCHECK(hipStreamSynchronize(h->stream));
   u32 cnt = 0;
   HCHECK(hipMemcpy(&cnt, d.ev_count, 4, hipMemcpyDeviceToHost));
-  if (cnt > d.ev_cap) cnt = d.ev_cap;
+  if (cnt > d.ev_cap) { h->events_lost += cnt - d.ev_cap; cnt = d.ev_cap; }
   std::vector<sim_event> ev(cnt);
   if (cnt) HCHECK(hipMemcpy(ev.data(), d.events, (size_t)cnt * sizeof(sim_event), hipMemcpyDeviceToHost));
   // per node the log is in program order; across nodes the oracle's order is (tick, observer)
@@ -2816,7 +2825,7 @@ int sim_state_digest(sim_handle* h, uint64_t out[8]) {
   HCHECK(hipMemsetAsync(h->d_scratch, 0, 16 * 8, s));
   digest_rows_queue<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, h->d_scratch + 0, h->d_scratch + 1);
   size_t nw;
-  if (cur_inbox(h)) { nw = (size_t)d.f * d.Nl * 8; digest_flat<<<grid_for(nw), BLOCK, 0, s>>>((const u64*)cur_inbox(h), nw, h->d_scratch + 2); }
+  if (cur_inbox(h)) { nw = (size_t)d.f * d.Nl * (sizeof(sim_packet) / 8); digest_flat<<<grid_for(nw), BLOCK, 0, s>>>((const u64*)cur_inbox(h), nw, h->d_scratch + 2); }
   digest_split<<<grid_for(d.vtail), BLOCK, 0, s>>>(d.view, d.vtail, d.vtail, h->d_scratch + 3);
   digest_split<<<grid_for(d.etail), BLOCK, 0, s>>>(d.ering, d.etail, d.etail, h->d_scratch + 4);
   digest_split<<<grid_for(d.qtail), BLOCK, 0, s>>>(d.qring, d.qtail, d.qtail, h->d_scratch + 5);
@@ -3129,6 +3138,8 @@ int sim_cluster_stats_get(sim_handle* h, sim_cluster_stats* out) {
     cluster_stats_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, cur_inbox(h), scr);
     e = hipMemcpyAsync(r, scr, sizeof r, hipMemcpyDeviceToHost, s);
   }
+  u32 evc = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&evc, d.ev_count, 4, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   (void)hipFree(scr);
   HCHECK(e);
@@ -3136,6 +3147,7 @@ int sim_cluster_stats_get(sim_handle* h, sim_cluster_stats* out) {
   for (int i = 0; i < 4; ++i) out->queued[i] = r[1 + i];
   out->overflow = r[5]; out->inbox_records = r[6]; out->failed = r[7]; out->left = r[8]; out->max_queue = r[9];
   out->ops_dropped = h->ops_dropped; out->slots_in_use = h->n_alloc; out->slots_recycled = h->slots_recycled;
+  out->events_lost = h->events_lost + (evc > d.ev_cap ? evc - d.ev_cap : 0);
   return SIM_OK;
 }
 int sim_exchange_bytes(const sim_handle* h, size_t* bytes) {

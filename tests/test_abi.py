@@ -49,9 +49,9 @@ def test_struct_layouts_match_the_header(tmp_path):
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(prog)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(_ffi.Config), C.sizeof(_ffi.Stats), C.sizeof(_ffi.Event), _ffi.ROW_DTYPE.itemsize,
-            _ffi.REC_DTYPE.itemsize, _ffi.VIEW_DTYPE.itemsize, _ffi.BUCKET_DTYPE.itemsize, 4 * _ffi.REC_DTYPE.itemsize]
+            _ffi.REC_DTYPE.itemsize, _ffi.VIEW_DTYPE.itemsize, _ffi.BUCKET_DTYPE.itemsize, _ffi.PACKET_DTYPE.itemsize]
     assert got == want
-    assert got[3:] == [96, 16, 32, 32, 64]
+    assert got[3:] == [96, 16, 32, 32, 48]
 
 
 def test_product_has_no_cpu_fallback(hiplib):

@@ -503,3 +503,39 @@ def test_query_filters_and_tags_parity(oracle, hiplib, n, swim):
     g2.step(79)
     o2.step(79)
     assert g2.digest() == o2.digest() == g.digest()
+
+
+def test_event_log_overflow_is_counted(oracle, hiplib):
+    """The device event log holds 2^20 events between two drains (include/serf_sim.h): what does not fit is counted in
+    cluster_stats.events_lost, never silently clipped.  2048 watched nodes x 640 user events = 1.3 M events."""
+    n = 2048
+    kw = dict(fanout=4, view_slots=0, event_ring=1024, query_ring=8, retransmit_mult=2)
+    g, o = pair(oracle, hiplib, n, **kw)
+    for s in (g, o):
+        for w in range(n):
+            s.watch(w)
+        for i in range(640):     # one origin, one event per tick: within the queue's capacity, distinct Lamport times
+            s.inject(i, _ffi.OP_USER_EVENT, 3, 1 + i, 32)
+        s.step(680)
+    assert g.digest() == o.digest()
+    assert o.cluster_stats()["overflow"] == 0
+
+    def drain_all(s):
+        tot = 0
+        while True:
+            ev = s.drain_events(1 << 18)
+            tot += len(ev)
+            if not ev:
+                return tot
+    lost = g.cluster_stats()["events_lost"]      # readable before the drain
+    total_o, total_g = drain_all(o), drain_all(g)
+    assert n * 640 - 100 < total_o <= n * 640 and total_o > 1 << 20   # a handful of (node, event) pairs are missed by gossip
+    assert total_g == 1 << 20 and lost == total_o - total_g
+    assert g.cluster_stats()["events_lost"] == lost and o.cluster_stats()["events_lost"] == 0
+    g.step(5)       # the log works again after the overflow
+    o.step(5)
+    g.inject(0, _ffi.OP_USER_EVENT, 3, 5000, 32)
+    o.inject(0, _ffi.OP_USER_EVENT, 3, 5000, 32)
+    g.step(20)
+    o.step(20)
+    assert g.drain_events(1 << 18) == o.drain_events(1 << 18)
