@@ -1079,15 +1079,14 @@ __device__ static inline bool fast_noop(const Ctx& c, const Node& n, u32 kind, c
   bool swim_fast = !d.swim | !has | ((kind == SIM_K_ALIVE) ? alive_fast : sd_fast);
   return (isring & ring_fast) | (isjl & jl_fast) | (isswim & swim_fast) | !(isring | isjl | isswim);
 }
-__device__ static inline void fast_witness(Node& n, u32 kind, const uint4& r, bool apply) {
+// A record can be retired without a handler when it is a no-op (fast_noop) that does not even advance the Lamport
+// clock it witnesses (it has been seen before: the common duplicate).  The property survives whatever the handlers of
+// earlier records do to the node — clocks and incarnations only grow — as long as they leave the record's own entry alone.
+__device__ static inline bool fast_retire(const Ctx& c, const Node& n, u32 kind, const uint4& r, bool has, const uint4& e) {
   u64 lt = (u64)r.z | ((u64)r.w << 32);
-  bool ev = apply & (kind == SIM_K_EVENT) & (lt >= n.eclock);
-  bool qu = apply & (kind == SIM_K_QUERY) & (lt >= n.qclock);
-  bool jl = apply & ((kind - SIM_K_JOIN) < 2u) & (lt >= n.clock);
-  n.eclock = ev ? lt + 1 : n.eclock;
-  n.qclock = qu ? lt + 1 : n.qclock;
-  n.clock = jl ? lt + 1 : n.clock;
-  n.dirty |= ((ev | jl) ? DR0 : 0u) | (qu ? DR1 : 0u);
+  bool adv = ((kind == SIM_K_EVENT) & (lt >= n.eclock)) | ((kind == SIM_K_QUERY) & (lt >= n.qclock)) |
+             (((kind - SIM_K_JOIN) < 2u) & (lt >= n.clock));
+  return fast_noop(c, n, kind, r, has, e) & !adv;
 }
 __device__ static inline void dispatch(const Ctx& c, Node& n, const uint4& r, uint4* p, uint4& e, bool& dirty, Ins& ins) {
   u32 kind = SIM_META_KIND(r.y), flags = SIM_META_FLAGS(r.y);
@@ -1196,6 +1195,7 @@ __global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, 
       // the next packet (keys, low words, high words), fetched one packet ahead
       uint4 rn = ld4(cell), rn1 = ld4(cell + 1), rn2 = ld4(cell + 2);
       for (u32 k = 0; k < d.f; ++k) {
+        u32 slow;  // records of this packet that need a handler
         // ---- stage the packet in LDS (one 16-byte column per record and lane: conflict-free) ----
         // phase A: the four records, then their four independent lookups — slot map for member
         // records, then the 16-byte head of the view entry / ring bucket each record is checked
@@ -1228,36 +1228,45 @@ __global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, 
           uint4 e0 = ld4(p0 ? p0 : d.nullcell), e1 = ld4(p1 ? p1 : d.nullcell), e2 = ld4(p2 ? p2 : d.nullcell), e3 = ld4(p3 ? p3 : d.nullcell);
           TT(3);
           lds_e[0][tid] = e0; lds_e[1][tid] = e1; lds_e[2][tid] = e2; lds_e[3][tid] = e3;
+          // classify all four against the state as it is now: straight-line, no state is touched
+          slow = (fast_retire(c, n, k0, r0, p0 != nullptr, e0) ? 0u : 1u) | (fast_retire(c, n, k1, r1, p1 != nullptr, e1) ? 0u : 2u) |
+                 (fast_retire(c, n, k2, r2, p2 != nullptr, e2) ? 0u : 4u) | (fast_retire(c, n, k3, r3, p3 != nullptr, e3) ? 0u : 8u);
           TT(4);
         }
-        // phase B: the records in arrival order, one rolled loop = one copy of the handler code.
-        // Duplicates, old messages and subjects without a view slot (~95 % of all records) are
-        // retired by fast_noop against the staged head; the rest runs the full handlers.  Once a
-        // handler of this packet has written state, later heads are re-read (rare).
+        // phase B: the records that need a handler, in arrival order, one rolled loop = one copy of the handler code.
+        // Duplicates, old messages and subjects without a view slot (~95 % of all records) were retired by
+        // fast_retire above: they change nothing, not even a clock, so it does not matter that they were judged
+        // before the handlers of earlier records ran — EXCEPT when such a handler writes the entry a later
+        // record was judged against (a pruned member, a first alive before a suspect ...): that record is looked at
+        // again.  Every lane walks its own list, so a wave runs the handlers as many times as its busiest lane has
+        // work (once or twice per packet), not once per record position.
         // `wptr`: the one entry a handler of this packet has written so far; `wall`: more than one,
         // or the node's own entry as well (refutation) — only then is a staged head stale.
         if (ABL(32)) continue;
         uint4* wptr = nullptr;
         bool wall = false;
 #pragma unroll 1
-        for (u32 p = 0; p < SIM_P; ++p) {
-          uint4 r = lds_r[p][tid];
-          u32 kind = SIM_META_KIND(r.y);
-          uint4* ptr = lds_p[p][tid];
-          uint4 e = lds_e[p][tid];
-          if (ptr && (wall || ptr == wptr)) e = ld4(ptr);
-          bool fast = fast_noop(c, n, kind, r, ptr != nullptr, e);
-          fast_witness(n, kind, r, fast);
-          if (fast) continue;
-          Ins ins;
-          ins.has = ins.wide = 0;
-          bool dirty = false;
-          dispatch(c, n, r, ptr, e, dirty, ins);
-          if (dirty) {
-            wall |= ins.wide || (wptr != nullptr && wptr != ptr);
-            wptr = ptr;
+        while (__any(slow != 0)) {
+          if (slow) {
+            u32 p = (u32)__ffs((int)slow) - 1u;
+            slow &= slow - 1u;
+            uint4 r = lds_r[p][tid];
+            uint4* ptr = lds_p[p][tid];
+            uint4 e = lds_e[p][tid];
+            if (ptr && (wall || ptr == wptr)) e = ld4(ptr);
+            Ins ins;
+            ins.has = ins.wide = 0;
+            bool dirty = false;
+            dispatch(c, n, r, ptr, e, dirty, ins);
+            if (dirty) {
+#pragma unroll 1
+              for (u32 q = p + 1; q < SIM_P; ++q)
+                if (ins.wide || (ptr && lds_p[q][tid] == ptr)) slow |= 1u << q;
+              wall |= ins.wide || (wptr != nullptr && wptr != ptr);
+              wptr = ptr;
+            }
+            if (ins.has) pend_push(c, n, ins);
           }
-          if (ins.has) pend_push(c, n, ins);
         }
         TT(5);
       }
@@ -1316,21 +1325,17 @@ __global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, 
     }
   }
   TT(8);
-  // ... then every payload gather of the tick in flight at once (one memory round trip, not F) ...
-  // A queue of at most SIM_P entries sends the same records in every round: a record that sits
-  // in the same place as in the previous packet is copied, not gathered again (the gathers are
-  // scattered 16-byte accesses, one address per lane for the texture addresser).
-  uint4 pk[F][SIM_P];
+  // ... then the payload of the first packet (four gathers in flight; a lane with nothing to fetch reads the zero cell:
+  // a load inside a branch gets its own s_waitcnt, i.e. its own round trip).  A queue of at most SIM_P entries sends
+  // the same records in every round, so packet k + 1 is packet k except where another payload slot moved into a
+  // position — those are gathered while packet k is being stored, behind a wave-uniform branch that is rarely taken.
+  // (Holding all F packets in registers at once — 64 VGPRs — made the compiler spill every gather as it arrived:
+  // sixteen round trips, one after the other.)
+  uint4 pkc[SIM_P];
 #pragma unroll
-  for (int k = 0; k < F; ++k) {
-#pragma unroll
-    for (int p = 0; p < (int)SIM_P; ++p) {
-      u32 s = (slots[k] >> (8 * p)) & 0xFFu;
-      bool again = k > 0 && s == ((slots[k > 0 ? k - 1 : 0] >> (8 * p)) & 0xFFu);
-      pk[k][p] = zero;
-      if (again) pk[k][p] = pk[k > 0 ? k - 1 : 0][p];
-      else if (s != 0xFFu && !ABL(8)) pk[k][p] = ld4(&d.qpay[(size_t)s * d.Nl + l]);
-    }
+  for (int p = 0; p < (int)SIM_P; ++p) {
+    u32 s = (slots[0] >> (8 * p)) & 0xFFu;
+    pkc[p] = ld4((s != 0xFFu && !ABL(8)) ? &d.qpay[(size_t)s * d.Nl + l] : d.nullcell);
   }
   TT(9);
   // ... then the F scatters: packet k goes to the inbox cell of T_k(l) (SIMSPEC §2.3, oracle fan_target).  The sender is
@@ -1352,6 +1357,25 @@ __global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, 
 #pragma unroll
   for (int k = 0; k < F; ++k) {
     if ((u32)k >= tp.feff || ABL(4)) break;
+    // the payloads packet k + 1 does not share with packet k, in flight while packet k goes out
+    uint4 pkn[SIM_P];
+    bool fetch = false;
+    if (k + 1 < F) {
+#pragma unroll
+      for (int p = 0; p < (int)SIM_P; ++p) {
+        u32 s = (slots[k + 1] >> (8 * p)) & 0xFFu;
+        fetch |= s != 0xFFu && s != ((slots[k] >> (8 * p)) & 0xFFu);
+      }
+      fetch = __any(fetch && !ABL(8));
+      if (fetch) {
+#pragma unroll
+        for (int p = 0; p < (int)SIM_P; ++p) {
+          u32 s = (slots[k + 1] >> (8 * p)) & 0xFFu;
+          bool again = s == ((slots[k] >> (8 * p)) & 0xFFu);
+          pkn[p] = ld4((s != 0xFFu && !again) ? &d.qpay[(size_t)s * d.Nl + l] : d.nullcell);
+        }
+      }
+    }
     u32 y = pj + tp.off[k];
     if (y >= tp.nbc) y -= tp.nbc;
     u32 j2 = pi_inv(tp, y);
@@ -1370,8 +1394,17 @@ __global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, 
     if (SHARDED) dst = d.xsend + ((((size_t)s0 * tp.V + h) * d.f + k) * tp.sub + r) * PK_U4;
     else dst = d.inbox[cur ^ 1] + ((size_t)k * d.Nl + (size_t)h * tp.M + t) * PK_U4;
     uint4 wk, wl, wh;  // the packet in its wire form
-    wire_pack(pk[k][0], wk.x, wl.x, wh.x); wire_pack(pk[k][1], wk.y, wl.y, wh.y);
-    wire_pack(pk[k][2], wk.z, wl.z, wh.z); wire_pack(pk[k][3], wk.w, wl.w, wh.w);
+    wire_pack(pkc[0], wk.x, wl.x, wh.x); wire_pack(pkc[1], wk.y, wl.y, wh.y);
+    wire_pack(pkc[2], wk.z, wl.z, wh.z); wire_pack(pkc[3], wk.w, wl.w, wh.w);
+    if (k + 1 < F) {  // packet k + 1: what stays in place is kept, what moved in was fetched, an empty position is zero
+#pragma unroll
+      for (int p = 0; p < (int)SIM_P; ++p) {
+        u32 s = (slots[k + 1] >> (8 * p)) & 0xFFu;
+        bool again = s == ((slots[k] >> (8 * p)) & 0xFFu);
+        if (fetch) { if (!again) pkc[p] = pkn[p]; }
+        else if (s == 0xFFu) pkc[p] = zero;
+      }
+    }
     if (coop) {
       // Three lanes of a quad write one 48-byte cell per store instruction (lane i < 3 writes part i of quad-mate
       // j's packet): the texture addresser sees 48 contiguous bytes per quad and L2 one write per cell instead of
