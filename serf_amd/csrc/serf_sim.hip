@@ -977,15 +977,24 @@ __device__ static inline bool member_kind(u32 kind) {
 // address of the state a record is checked against (null: nothing to look at)
 // Branch-free on the per-lane values (divergent branches cost scalar exec-mask work on every
 // record): the ring index and the view address are both formed, then selected by kind.
-__device__ static inline uint4* lookup_ptr(const Ctx& c, u32 kind, u32 key, u64 val, u32 slot) {
+// The three plane bases, pinned in scalar registers at kernel entry.  Without this the compiler turns
+// `isring ? (isq ? d.qring : d.ering) : d.view` into ONE per-lane load from the kernel-argument segment at a selected
+// offset: a global-memory round trip between the slot lookup and the head load of every packet.
+// (The same happens to a struct of the three pointers — it goes to scratch and is indexed there — so the rings travel
+// as byte distances from the view plane: differences of pinned values are not loads and cannot be folded into one.)
+__device__ static inline u64 pin_uniform(const void* p) {
+  u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(uintptr_t)p), hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)((uintptr_t)p >> 32));
+  return ((u64)hi << 32) | lo;
+}
+__device__ static inline uint4* lookup_ptr(const Ctx& c, u64 vbase, u64 eoff, u64 qoff, u32 kind, u32 key, u64 val, u32 slot) {
   const Dev& d = c.d;
   bool isq = kind == SIM_K_QUERY, isring = isq || kind == SIM_K_EVENT;
   u32 B = isq ? d.Bq : d.Bev, mask = isq ? d.bq_mask : d.bev_mask;
   u32 idx = (u32)val & mask;
   if (!(d.bev_mask && d.bq_mask)) idx = ring_idx(val, B, mask);  // uniform: a ring size that is not a power of two
-  uint4* ring = isq ? d.qring : d.ering;
   size_t row = isring ? (size_t)idx : (size_t)slot;
-  uint4* basep = isring ? ring : d.view;
+  // (through a global-address-space pointer: a bare integer -> pointer cast would make every access FLAT)
+  uint4* basep = (uint4*)(__attribute__((address_space(1))) uint4*)(vbase + (isring ? (isq ? qoff : eoff) : 0ull));
   bool none = !isring && (kind == SIM_K_EMPTY || slot == NOSLOT);
   uint4* p = basep + (row * d.Nl + c.l);
   return none ? nullptr : p;
@@ -1173,7 +1182,22 @@ __global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, 
   // V == 1 (one shard holds everything) is wave-uniform: no divisions by run-time values on that path
   u32 g = tp.V == 1 ? 0u : gid / tp.M, ll = gid - g * tp.M;
   Ctx c{d, l, gid, (u32)tp.tick, tp.query_base};
+  const u64 vbase = pin_uniform(d.view), eoff = pin_uniform(d.ering) - vbase, qoff = pin_uniform(d.qring) - vbase;
   const uint4 zero = make_uint4(0, 0, 0, 0);
+  // inbox cell of fan-out slot k (sharded: the block of the receive buffer the source shard filled)
+  auto cell_of = [&](u32 k) -> const uint4* {
+    if (SHARDED) {  // [sender chunk][source shard][slot][sub] (oracle xcell)
+      u32 b = l / tp.blk, w = l - b * tp.blk, sl = w / tp.sub;
+      u32 src = (d.shard_rank + b + tp.prot[k]) % tp.V;
+      u32 ch = (sl + tp.C - tp.prho[k]) % tp.C;
+      return d.xrecv + ((((size_t)ch * tp.V + src) * d.f + k) * tp.sub + (w - sl * tp.sub)) * PK_U4;
+    }
+    return d.inbox[cur] + ((size_t)k * d.Nl + l) * PK_U4;
+  };
+  // The first packet is requested together with the node's row (it does not depend on it: a node that turns out to be
+  // down has loaded 48 bytes for nothing), every further one a packet ahead: keys, low words, high words.
+  const uint4* cell = tp.first ? d.nullcell : cell_of(0);
+  uint4 rn = ld4(cell), rn1 = ld4(tp.first ? cell : cell + 1), rn2 = ld4(tp.first ? cell : cell + 2);
   Node n;
   node_load(d, l, n);
   bool up = n.flags & SIM_RF_UP;
@@ -1181,19 +1205,6 @@ __global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, 
   // ---- phase 1: deliver.  The queue is not touched: handlers park their broadcasts in d.pend.
   if (up && !ABL(2)) {
     if (!tp.first) {
-      // inbox cell of fan-out slot k (sharded: the block of the receive buffer the source shard filled)
-      auto cell_of = [&](u32 k) -> const uint4* {
-        if (SHARDED) {  // [sender chunk][source shard][slot][sub] (oracle xcell)
-          u32 b = l / tp.blk, w = l - b * tp.blk, sl = w / tp.sub;
-          u32 src = (d.shard_rank + b + tp.prot[k]) % tp.V;
-          u32 ch = (sl + tp.C - tp.prho[k]) % tp.C;
-          return d.xrecv + ((((size_t)ch * tp.V + src) * d.f + k) * tp.sub + (w - sl * tp.sub)) * PK_U4;
-        }
-        return d.inbox[cur] + ((size_t)k * d.Nl + l) * PK_U4;
-      };
-      const uint4* cell = cell_of(0);
-      // the next packet (keys, low words, high words), fetched one packet ahead
-      uint4 rn = ld4(cell), rn1 = ld4(cell + 1), rn2 = ld4(cell + 2);
       for (u32 k = 0; k < d.f; ++k) {
         u32 slow;  // records of this packet that need a handler
         // ---- stage the packet in LDS (one 16-byte column per record and lane: conflict-free) ----
@@ -1220,10 +1231,10 @@ __global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, 
           u32 s2 = slot_load(d, k2, r2.x);
           u32 s3 = slot_load(d, k3, r3.x);
           TT(2);
-          uint4* p0 = lookup_ptr(c, k0, r0.x, (u64)r0.z | ((u64)r0.w << 32), s0);
-          uint4* p1 = lookup_ptr(c, k1, r1.x, (u64)r1.z | ((u64)r1.w << 32), s1);
-          uint4* p2 = lookup_ptr(c, k2, r2.x, (u64)r2.z | ((u64)r2.w << 32), s2);
-          uint4* p3 = lookup_ptr(c, k3, r3.x, (u64)r3.z | ((u64)r3.w << 32), s3);
+          uint4* p0 = lookup_ptr(c, vbase, eoff, qoff, k0, r0.x, (u64)r0.z | ((u64)r0.w << 32), s0);
+          uint4* p1 = lookup_ptr(c, vbase, eoff, qoff, k1, r1.x, (u64)r1.z | ((u64)r1.w << 32), s1);
+          uint4* p2 = lookup_ptr(c, vbase, eoff, qoff, k2, r2.x, (u64)r2.z | ((u64)r2.w << 32), s2);
+          uint4* p3 = lookup_ptr(c, vbase, eoff, qoff, k3, r3.x, (u64)r3.z | ((u64)r3.w << 32), s3);
           lds_p[0][tid] = p0; lds_p[1][tid] = p1; lds_p[2][tid] = p2; lds_p[3][tid] = p3;
           uint4 e0 = ld4(p0 ? p0 : d.nullcell), e1 = ld4(p1 ? p1 : d.nullcell), e2 = ld4(p2 ? p2 : d.nullcell), e3 = ld4(p3 ? p3 : d.nullcell);
           TT(3);
@@ -1251,7 +1262,7 @@ __global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, 
             u32 p = (u32)__ffs((int)slow) - 1u;
             slow &= slow - 1u;
             uint4 r = lds_r[p][tid];
-            uint4* ptr = lds_p[p][tid];
+            uint4* ptr = (uint4*)(__attribute__((address_space(1))) uint4*)lds_p[p][tid];  // (global, not flat, accesses in the handlers)
             uint4 e = lds_e[p][tid];
             if (ptr && (wall || ptr == wptr)) e = ld4(ptr);
             Ins ins;
