@@ -40,6 +40,12 @@ typedef uint64_t u64;
 #define NOSLOT 0xFFFFFFFFu
 #define STAMP_MASK 0x1FFFFFu
 #define BLOCK 256
+// The tick kernel runs one wave per block: nothing in it is shared between waves (LDS staging is per lane, the
+// transposes per quad), and the smaller the unit the scheduler hands out, the shorter the tail at the end of a launch
+// in which 16 384 waves go through 4 096 slots (measured: 256 -> 64 threads per block = -2.4 %).
+#ifndef TBLOCK
+#define TBLOCK 64
+#endif
 #define KEMPTY 0xFFFFFFFFu  // empty sort key
 // broadcasts one node can park in one tick: every received record can ask for one rebroadcast,
 // every suspicion timer can fire (dead) and the probe can fail (suspect)
@@ -1152,20 +1158,20 @@ __device__ static inline void wire_pack(const uint4& r, u32& key, u32& lo, u32& 
 }
 __device__ static inline u32 pk_word(const uint4& v, u32 p) { return p == 0 ? v.x : p == 1 ? v.y : p == 2 ? v.z : v.w; }
 template <bool SHARDED, int F>
-__global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, u32 cur, const uint4* base, u32 chunk, u32 cnt) {
+__global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, u32 cur, const uint4* base, u32 chunk, u32 cnt) {
 #ifdef TICK_TIMING
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #endif
   // LDS staging of the per-node inbox: the packet being delivered, the slot of each record's
-  // subject's entry and the head of that entry (40 KiB per block: exactly 4 blocks per CU)
-  __shared__ uint4 lds_r[SIM_P][BLOCK];
-  __shared__ uint4 lds_e[SIM_P][BLOCK];
-  __shared__ uint4* lds_p[SIM_P][BLOCK];  // where each record's entry lives (null: nothing to look at)
+  // subject's entry and the head of that entry (10 KiB per wave: 16 waves per CU = all of its 160 KiB)
+  __shared__ uint4 lds_r[SIM_P][TBLOCK];
+  __shared__ uint4 lds_e[SIM_P][TBLOCK];
+  __shared__ uint4* lds_p[SIM_P][TBLOCK];  // where each record's entry lives (null: nothing to look at)
   const u32 tid = threadIdx.x;
   // one launch covers `cnt` nodes: the whole shard (chunk == ~0), or sender chunk `chunk` of a sharded run = the nodes
   // whose offset inside their vblock lies in sub-slab `chunk` (V ranges of `sub` consecutive nodes)
-  const u32 idx = blockIdx.x * BLOCK + threadIdx.x;
+  const u32 idx = blockIdx.x * TBLOCK + threadIdx.x;
   if (idx >= cnt) return;
   u32 l = idx;
   if (SHARDED && chunk != 0xFFFFFFFFu) {
@@ -1364,7 +1370,7 @@ __global__ __launch_bounds__(BLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, 
   u32 fj = uu, fi = 0;
   if (tp.B == 64u) { fj = (u32)__builtin_amdgcn_readfirstlane((int)(uu >> 6)); fi = uu & 63u; }
   const u32 pj = tp.feff ? pi_f(tp, fj) : 0;
-  const bool coop = (blockIdx.x + 1u) * BLOCK <= cnt;  // every lane of the block is here
+  const bool coop = (blockIdx.x + 1u) * TBLOCK <= cnt;  // every lane of the block is here
 #pragma unroll
   for (int k = 0; k < F; ++k) {
     if ((u32)k >= tp.feff || ABL(4)) break;
@@ -2740,9 +2746,9 @@ static int tick_launch(sim_handle* h, u32 chunk) {
   Dev& d = h->d;
   const TickP& tp = h->cur_tp;
   u32 cnt = chunk == 0xFFFFFFFFu ? d.Nl : tp.V * tp.sub;
-  int grid = (int)((cnt + BLOCK - 1) / BLOCK);
+  int grid = (int)((cnt + TBLOCK - 1) / TBLOCK);
   u32 cur = (u32)(h->tick & 1);
-#define LAUNCH_TICK(SH, FF) tick_kernel<SH, FF><<<grid, BLOCK, 0, h->stream>>>(d, tp, cur, h->d_base, chunk, cnt)
+#define LAUNCH_TICK(SH, FF) tick_kernel<SH, FF><<<grid, TBLOCK, 0, h->stream>>>(d, tp, cur, h->d_base, chunk, cnt)
   switch (tp.feff + (d.sharded ? 4u : 0u)) {  // one instantiation per fan-out: the drain loop is fully unrolled
     case 0: case 1: LAUNCH_TICK(false, 1); break;
     case 2: LAUNCH_TICK(false, 2); break;
