@@ -324,7 +324,7 @@ def run(args, lib=None, dev=None, backend="nccl"):
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": "tick_kernel", "kernel_ms": kern_s * 1e3,
                          "kernel_ms_min": prof_min, "kernel_ms_max": prof_max, "kernel_launches": int(prof_n),
-                         "kernel_timing": f"HIP events around every {profile_every}{'th' if profile_every > 1 else 'st'} tick_kernel launch of the timed region, on its stream",
+                         "kernel_timing": f"HIP event pair on every {profile_every}{'th' if profile_every > 1 else 'st'} tick_kernel dispatch of the timed region (hipExtLaunchKernelGGL start/stop events, on the launch stream)",
                          "stream_ms_per_step": ev_ms / args.steps, "b_tick_bytes": bt,
                          "achieved_revised": args.nodes_per_gpu * bt2 / kern_s / 1e9, "b_tick_layout_bytes": bt2,
                          "traffic_over_algorithmic": (traffic / (args.nodes_per_gpu * bt)) if traffic else None,

@@ -24,6 +24,7 @@
 // There is deliberately no CPU fallback in this file: without a usable HIP device sim_create
 // returns SIM_EDEVICE.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -2121,7 +2122,7 @@ struct sim_handle {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof;  // one event pair per tick-kernel launch
   u32 pp_step;  // push-pull batches: every pp_step ticks one of PP_GROUPS pair classes synchronises (0 = off)
   TickP cur_tp;            // parameters of the tick between sim_step_begin and sim_step_end
-  bool in_tick, tick_timed;
+  bool in_tick, tick_timed, tick_bracket;
   hipEvent_t tick_ev0;
   uint4* rbuf[2];          // sharded: packets sent during tick t are received into rbuf[t & 1]
 };
@@ -2734,8 +2735,13 @@ int sim_step_begin(sim_handle* h) {
     u32 half = tp.N / 2, n_pairs = half > cls ? (half - cls + PP_GROUPS - 1) / PP_GROUPS : 0;
     if (n_pairs) pushpull_kernel<<<(n_pairs + 63) / 64, 64, 0, h->stream>>>(d, tp, cls, n_pairs);
   }
+  // Timing of the tick's launch(es) with HIP events.  One launch per tick: the pair rides on the dispatch itself
+  // (hipExtLaunchKernelGGL: start / stop = the kernel's own begin and end, no barrier packets in the stream — two
+  // hipEventRecord calls around every launch cost 10 us of stream time each tick).  Several chunk launches per tick
+  // (sharded, C > 1): the pair brackets them with hipEventRecord.
   h->tick_timed = h->profiling && (h->prof_seq++ % h->profiling) == 0;
-  if (h->tick_timed) {
+  h->tick_bracket = h->tick_timed && d.sharded && tp.C > 1;
+  if (h->tick_bracket) {
     HCHECK(hipEventCreate(&h->tick_ev0));
     HCHECK(hipEventRecord(h->tick_ev0, h->stream));
   }
@@ -2748,7 +2754,18 @@ static int tick_launch(sim_handle* h, u32 chunk) {
   u32 cnt = chunk == 0xFFFFFFFFu ? d.Nl : tp.V * tp.sub;
   int grid = (int)((cnt + TBLOCK - 1) / TBLOCK);
   u32 cur = (u32)(h->tick & 1);
-#define LAUNCH_TICK(SH, FF) tick_kernel<SH, FF><<<grid, TBLOCK, 0, h->stream>>>(d, tp, cur, h->d_base, chunk, cnt)
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->tick_timed && !h->tick_bracket) {
+    HCHECK(hipEventCreate(&e0));
+    HCHECK(hipEventCreate(&e1));
+    h->prof.emplace_back(e0, e1);
+  }
+#define LAUNCH_TICK(SH, FF)                                                                                              \
+  do {                                                                                                                   \
+    if (e0) hipExtLaunchKernelGGL((tick_kernel<SH, FF>), dim3(grid), dim3(TBLOCK), 0, h->stream, e0, e1, 0, d, tp, cur, \
+                                  (const uint4*)h->d_base, chunk, cnt);                                                  \
+    else tick_kernel<SH, FF><<<grid, TBLOCK, 0, h->stream>>>(d, tp, cur, h->d_base, chunk, cnt);                         \
+  } while (0)
   switch (tp.feff + (d.sharded ? 4u : 0u)) {  // one instantiation per fan-out: the drain loop is fully unrolled
     case 0: case 1: LAUNCH_TICK(false, 1); break;
     case 2: LAUNCH_TICK(false, 2); break;
@@ -2773,7 +2790,7 @@ int sim_step_chunk(sim_handle* h, uint32_t chunk) {
 int sim_step_end(sim_handle* h) {
   if (!h) return SIM_EINVAL;
   if (!h->in_tick) return SIM_ESTATE;
-  if (h->tick_timed) {
+  if (h->tick_bracket) {
     hipEvent_t ev1 = nullptr;
     HCHECK(hipEventCreate(&ev1));
     HCHECK(hipEventRecord(ev1, h->stream));
