@@ -165,7 +165,7 @@ __device__ static inline u32 perm_fi(const TickP& p, u32 y) {
   return y;
 }
 // the block permutation pi of the fan-out map: the same rounds on the bit width of nbc, cycle-walking into [0, nbc)
-__device__ static inline u32 pi_f(const TickP& p, u32 x) {
+__host__ __device__ static inline u32 pi_f(const TickP& p, u32 x) {
   do {
     x = (x * p.mul[0] + p.add[0]) & p.bmask;
     x ^= x >> p.bshift;
@@ -175,7 +175,7 @@ __device__ static inline u32 pi_f(const TickP& p, u32 x) {
   } while (x >= p.nbc);
   return x;
 }
-__device__ static inline u32 pi_inv(const TickP& p, u32 y) {
+__host__ __device__ static inline u32 pi_inv(const TickP& p, u32 y) {
   do {
     y = ((y - p.add[2]) * p.imul[2]) & p.bmask;
     y ^= y >> p.bshift;
@@ -184,6 +184,39 @@ __device__ static inline u32 pi_inv(const TickP& p, u32 y) {
     y = ((y - p.add[0]) * p.imul[0]) & p.bmask;
   } while (y >= p.nbc);
   return y;
+}
+// The fan-out map in its general (per-node) form, both directions (SIMSPEC §2.3, oracle fan_target).  A node is
+// (shard g, in-shard index ll); ll = (vblock bb0, sub-slab s0, offset r0).  The tick kernel evaluates the same map
+// with the block permutation on the scalar unit; these are what the support kernels (and the host-side test hook) use.
+#define SEL4(i, a, b, c, d) ((i) == 0 ? (a) : (i) == 1 ? (b) : (i) == 2 ? (c) : (d))
+__host__ __device__ static inline u32 fan_scramble(u32 y, u32 k) { return ((y + 1u) * 0x9E3779B1u + k * 0x85EBCA6Bu) >> 26; }
+__host__ __device__ static inline void fan_target_g(const TickP& p, u32 g, u32 ll, u32 k, u32& h, u32& t) {
+  u32 bb0 = ll / p.blk, w = ll - bb0 * p.blk, s0 = w / p.sub, r0 = w - s0 * p.sub;
+  u32 u = bb0 * p.sub + r0, j = u / p.B, i = u - j * p.B;
+  u32 y = pi_f(p, j) + p.off[k];
+  if (y >= p.nbc) y -= p.nbc;
+  u32 j2 = pi_inv(p, y);
+  u32 i2 = p.B == 64u ? (i ^ fan_scramble(y, k)) : 0u;
+  u32 u2 = j2 * p.B + i2, bb = u2 / p.sub, r = u2 - bb * p.sub;
+  u32 s = s0 + p.rho[k];
+  if (s >= p.C) s -= p.C;
+  h = (g + p.V - ((bb + p.rot[k]) % p.V)) % p.V;
+  t = bb * p.blk + s * p.sub + r;
+}
+// the node whose k-th packet lands at (shard h, in-shard index t): the inverse of fan_target_g in (g, ll) for fixed k
+// (off_k, rot_k, rho_k = p.off[k], p.rot[k], p.rho[k]: picked by the caller, a kernel must not index its arguments dynamically)
+#define PICK4(a, k) SEL4(k, (a)[0], (a)[1], (a)[2], (a)[3])
+__host__ __device__ __attribute__((always_inline)) static inline void fan_source_g(const TickP& p, u32 off_k, u32 rot_k, u32 rho_k, u32 h, u32 t, u32 k, u32& g, u32& ll) {
+  u32 bb = t / p.blk, w = t - bb * p.blk, s = w / p.sub, r = w - s * p.sub;
+  u32 u2 = bb * p.sub + r, j2 = u2 / p.B, i2 = u2 - j2 * p.B;
+  u32 y = pi_f(p, j2);
+  u32 yy = y >= off_k ? y - off_k : y + p.nbc - off_k;
+  u32 j = pi_inv(p, yy);
+  u32 i = p.B == 64u ? (i2 ^ fan_scramble(y, k)) : 0u;
+  u32 u = j * p.B + i, bb0 = u / p.sub, r0 = u - bb0 * p.sub;
+  u32 s0 = s >= rho_k ? s - rho_k : s + p.C - rho_k;
+  g = (h + (bb + rot_k) % p.V) % p.V;
+  ll = bb0 * p.blk + s0 * p.sub + r0;
 }
 // the permutation of all N nodes the push-pull matching comes from (host and device: the sharded host plans with it)
 __host__ __device__ static inline u32 sigma_g_inv(const TickP& p, u32 y) {
@@ -225,7 +258,13 @@ struct Dev {
   uint4* qkeys;  // [4][Nl]  the 16 sort keys of a node's queue, ascending, 4 per uint4
   uint4* qpay;   // [Q][Nl]  slot-stable wire records {key, wire meta, val.lo, val.hi}
   uint4* pend;   // [SIM_PEND][Nl] broadcasts requested by the handlers of the running tick, arrival order
-  uint4* inbox[2];       // [f][Nl] packets of 3 x uint4: keys, value low words, value high bits + meta (local mode)
+  // Local mode: what a node sent, kept at the SENDER (SIMSPEC §2.3 read from the other end).  A node's f packets of one
+  // tick are nearly always the same packet (a queue of at most SIM_P entries sends the same records f times), so it
+  // writes each DISTINCT packet once — obox[j][sender], 3 x uint4: keys, value low words, value high bits + meta — and
+  // one word omap[sender] = for every fan-out slot the index j of the cell that holds its packet (0xFF: nothing sent
+  // or lost).  The receiver of slot k looks up its sender (the inverse of the map) and fetches the cell.
+  uint4* obox[2];        // [f][Nl] cells, double buffered by tick parity
+  u32* omap[2];          // [Nl]
   uint4 *xsend, *xrecv;  // sharded mode: [V][f][blk] packets
   // Entries are split into two planes of 16 bytes per (row, node): the HEAD the hot path checks every record against
   // — view {ltime.lo, ltime.hi, inc, bits}, ring bucket {ltime.lo, ltime.hi, k0, k1} — at arr[row * Nl + l], dense
@@ -1119,7 +1158,6 @@ __device__ static inline void dispatch(const Ctx& c, Node& n, const uint4& r, ui
   }
   if (rb) ins_set(ins, r.x, r.y, val);  // re-queue the original message unchanged (delegate.rs:294-300)
 }
-#define SEL4(i, a, b, c, d) ((i) == 0 ? (a) : (i) == 1 ? (b) : (i) == 2 ? (c) : (d))
 __device__ static inline uint4 sel4(u32 i, const uint4& a, const uint4& b, const uint4& c, const uint4& d) {
   return make_uint4(SEL4(i, a.x, b.x, c.x, d.x), SEL4(i, a.y, b.y, c.y, d.y), SEL4(i, a.z, b.z, c.z, d.z), SEL4(i, a.w, b.w, c.w, d.w));
 }
@@ -1158,8 +1196,9 @@ __device__ static inline void wire_pack(const uint4& r, u32& key, u32& lo, u32& 
   hm = ((two ? (r.w >> 8) : r.w) << 16) | (((r.y >> 18) & 0x3Fu) << 8) | (r.y & 0xFFu);
 }
 __device__ static inline u32 pk_word(const uint4& v, u32 p) { return p == 0 ? v.x : p == 1 ? v.y : p == 2 ? v.z : v.w; }
-template <bool SHARDED, int F>
-__global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, u32 cur, const uint4* base, u32 chunk, u32 cnt) {
+// (B64: local mode with 64-node blocks — the sharded instantiations read tp.B at run time and pass false)
+template <bool SHARDED, int F, bool B64>
+__global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, TickP ptp, u32 cur, const uint4* base, u32 chunk, u32 cnt) {
 #ifdef TICK_TIMING
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -1191,27 +1230,86 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
   Ctx c{d, l, gid, (u32)tp.tick, tp.query_base};
   const u64 vbase = pin_uniform(d.view), eoff = pin_uniform(d.ering) - vbase, qoff = pin_uniform(d.qring) - vbase;
   const uint4 zero = make_uint4(0, 0, 0, 0);
-  // inbox cell of fan-out slot k (sharded: the block of the receive buffer the source shard filled)
-  auto cell_of = [&](u32 k) -> const uint4* {
+  // Local mode: the packet of fan-out slot k is fetched from its sender (Dev::obox).  The receiver is (vblock rbb,
+  // sub-slab rs, offset rr); the senders of a wave's 64 consecutive receivers are the 64 nodes of ONE block (the map of
+  // the PREVIOUS tick, `ptp`, run backwards: block pi^-1(pi(j2) - off_k), positions XOR-scrambled), so the block
+  // permutation runs on the scalar unit and the wave reads one 3 KiB run.
+  // (B64, 64-node blocks: pi(j2) and the four sender blocks are wave-uniform and pinned in SGPRs; small or ragged
+  // shards, B = 1, work the four senders out once through the general per-node form of the map.)
+  u32 ry = 0, sj0 = 0, sj1 = 0, sj2 = 0, sj3 = 0;
+  if (!SHARDED && B64 && tp.feff) {
+    u32 ru2 = ll;  // index inside the receiving chunk: (vblock, offset)
+    if (tp.V != 1 || tp.C != 1) {
+      u32 rbb = ll / tp.blk, w = ll - rbb * tp.blk;
+      ru2 = rbb * tp.sub + w % tp.sub;
+    }
+    ry = (u32)__builtin_amdgcn_readfirstlane((int)pi_f(ptp, (u32)__builtin_amdgcn_readfirstlane((int)(ru2 >> 6))));
+    auto blk_of = [&](u32 k) __attribute__((always_inline)) -> u32 {
+      if (k >= tp.feff) return 0u;
+      u32 yy = ry >= ptp.off[k] ? ry - ptp.off[k] : ry + tp.nbc - ptp.off[k];
+      return (u32)__builtin_amdgcn_readfirstlane((int)pi_inv(ptp, yy));
+    };
+    sj0 = blk_of(0); sj1 = blk_of(1); sj2 = blk_of(2); sj3 = blk_of(3);
+  }
+  if (!SHARDED && !B64) {
+#pragma unroll 1
+    for (u32 k = 0; k < tp.feff; ++k) {
+      u32 gs, sl;
+      fan_source_g(ptp, PICK4(ptp.off, k), PICK4(ptp.rot, k), PICK4(ptp.rho, k), g, ll, k, gs, sl);
+      u32 v = gs * tp.M + sl;
+      if (k == 0) sj0 = v; else if (k == 1) sj1 = v; else if (k == 2) sj2 = v; else sj3 = v;
+    }
+  }
+  auto src_of = [&](u32 k) __attribute__((always_inline)) -> u32 {  // local index of the node whose k-th packet is addressed to this one
+    if (!B64) return SEL4(k, sj0, sj1, sj2, sj3);
+    u32 u = SEL4(k, sj0, sj1, sj2, sj3) * 64u + ((ll & 63u) ^ fan_scramble(ry, k));
+    if (tp.V == 1 && tp.C == 1) return u;
+    u32 rbb = ll / tp.blk, w = ll - rbb * tp.blk, rs = w / tp.sub;
+    u32 bb0 = u / tp.sub, r0 = u - bb0 * tp.sub;
+    u32 rho = PICK4(ptp.rho, k), s0 = rs >= rho ? rs - rho : rs + tp.C - rho;
+    u32 gs = (g + (rbb + PICK4(ptp.rot, k)) % tp.V) % tp.V;
+    return gs * tp.M + bb0 * tp.blk + s0 * tp.sub + r0;
+  };
+  u32 jw = 0xFFFFFFFFu;  // local mode: byte k = which of its cells the sender of slot k put that packet in
+  // cell of fan-out slot k (sharded: the block of the receive buffer the source shard filled)
+  auto cell_of = [&](u32 k) __attribute__((always_inline)) -> const uint4* {
     if (SHARDED) {  // [sender chunk][source shard][slot][sub] (oracle xcell)
       u32 b = l / tp.blk, w = l - b * tp.blk, sl = w / tp.sub;
       u32 src = (d.shard_rank + b + tp.prot[k]) % tp.V;
       u32 ch = (sl + tp.C - tp.prho[k]) % tp.C;
       return d.xrecv + ((((size_t)ch * tp.V + src) * d.f + k) * tp.sub + (w - sl * tp.sub)) * PK_U4;
     }
-    return d.inbox[cur] + ((size_t)k * d.Nl + l) * PK_U4;
+    u32 jb = (jw >> (8u * k)) & 0xFFu;
+    return jb == 0xFFu ? d.nullcell : d.obox[cur] + ((size_t)jb * d.Nl + src_of(k)) * PK_U4;
   };
   // The first packet is requested together with the node's row (it does not depend on it: a node that turns out to be
-  // down has loaded 48 bytes for nothing), every further one a packet ahead: keys, low words, high words.
-  const uint4* cell = tp.first ? d.nullcell : cell_of(0);
-  uint4 rn = ld4(cell), rn1 = ld4(tp.first ? cell : cell + 1), rn2 = ld4(tp.first ? cell : cell + 2);
+  // down has loaded 48 bytes for nothing), every further one a packet ahead: keys, low words, high words.  Local mode:
+  // together with the four senders' map words; a sender's first packet can only be in its cell 0, so that cell is
+  // requested before the map word is known and dropped if the word says "nothing sent".
+  const uint4* cell;
+  u32 om0 = 0xFFFFFFFFu, om1 = 0xFFFFFFFFu, om2 = 0xFFFFFFFFu, om3 = 0xFFFFFFFFu;
+  if (SHARDED) cell = tp.first ? d.nullcell : cell_of(0);
+  else {
+    const u32* om = d.omap[cur];
+    u32 s0 = src_of(0);
+    cell = tp.feff ? d.obox[cur] + (size_t)s0 * PK_U4 : d.nullcell;
+    if (tp.feff > 0) om0 = om[s0];
+    if (tp.feff > 1) om1 = om[src_of(1)];
+    if (tp.feff > 2) om2 = om[src_of(2)];
+    if (tp.feff > 3) om3 = om[src_of(3)];
+  }
+  uint4 rn = ld4(cell), rn1 = ld4((SHARDED && tp.first) ? cell : cell + 1), rn2 = ld4((SHARDED && tp.first) ? cell : cell + 2);
   Node n;
   node_load(d, l, n);
+  if (!SHARDED) {
+    jw = (om0 & 0xFFu) | (om1 & 0xFF00u) | (om2 & 0xFF0000u) | (om3 & 0xFF000000u);
+    if ((jw & 0xFFu) == 0xFFu) rn = rn1 = rn2 = zero;
+  }
   bool up = n.flags & SIM_RF_UP;
   TT(0);
   // ---- phase 1: deliver.  The queue is not touched: handlers park their broadcasts in d.pend.
   if (up && !ABL(2)) {
-    if (!tp.first) {
+    if (!SHARDED || !tp.first) {
       for (u32 k = 0; k < d.f; ++k) {
         u32 slow;  // records of this packet that need a handler
         // ---- stage the packet in LDS (one 16-byte column per record and lane: conflict-free) ----
@@ -1361,7 +1459,7 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
   // 64-node blocks j is the same for the whole wave: the block permutation runs on the scalar unit, and the wave's 64
   // packets of one slot land in 64 consecutive cells.
   u32 bb0 = 0, s0 = 0, r0 = ll;
-  if (tp.V != 1 || tp.C != 1) {
+  if (SHARDED && (tp.V != 1 || tp.C != 1)) {
     bb0 = ll / tp.blk;
     u32 w = ll - bb0 * tp.blk;
     s0 = w / tp.sub;
@@ -1369,9 +1467,11 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
   }
   const u32 uu = bb0 * tp.sub + r0;
   u32 fj = uu, fi = 0;
-  if (tp.B == 64u) { fj = (u32)__builtin_amdgcn_readfirstlane((int)(uu >> 6)); fi = uu & 63u; }
-  const u32 pj = tp.feff ? pi_f(tp, fj) : 0;
+  if (SHARDED && tp.B == 64u) { fj = (u32)__builtin_amdgcn_readfirstlane((int)(uu >> 6)); fi = uu & 63u; }
+  const u32 pj = (SHARDED && tp.feff) ? pi_f(tp, fj) : 0;
   const bool coop = (blockIdx.x + 1u) * TBLOCK <= cnt;  // every lane of the block is here
+  // local mode: which of this node's cells holds the packet of every slot (0xFF: nothing sent), distinct packets so far
+  u32 jout = 0xFFFFFFFFu, ndist = 0;
 #pragma unroll
   for (int k = 0; k < F; ++k) {
     if ((u32)k >= tp.feff || ABL(4)) break;
@@ -1394,26 +1494,41 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
         }
       }
     }
-    u32 y = pj + tp.off[k];
-    if (y >= tp.nbc) y -= tp.nbc;
-    u32 j2 = pi_inv(tp, y);
-    u32 u2 = j2;
-    if (tp.B == 64u) u2 = j2 * 64u + (fi ^ (((y + 1u) * 0x9E3779B1u + (u32)k * 0x85EBCA6Bu) >> 26));
-    u32 bb = 0, r = u2, h = 0;
-    if (tp.V != 1 || tp.C != 1) {
-      bb = u2 / tp.sub;
-      r = u2 - bb * tp.sub;
-      h = (g + tp.V - ((bb + tp.rot[k]) % tp.V)) % tp.V;
-    }
-    u32 sl = s0 + tp.rho[k];
-    if (sl >= tp.C) sl -= tp.C;
-    u32 t = bb * tp.blk + sl * tp.sub + r;
     uint4* dst;
-    if (SHARDED) dst = d.xsend + ((((size_t)s0 * tp.V + h) * d.f + k) * tp.sub + r) * PK_U4;
-    else dst = d.inbox[cur ^ 1] + ((size_t)k * d.Nl + (size_t)h * tp.M + t) * PK_U4;
+    bool wr = true;  // this lane has a cell to write for slot k
+    if (SHARDED) {
+      u32 y = pj + tp.off[k];
+      if (y >= tp.nbc) y -= tp.nbc;
+      u32 j2 = pi_inv(tp, y);
+      u32 u2 = j2;
+      if (tp.B == 64u) u2 = j2 * 64u + (fi ^ fan_scramble(y, (u32)k));
+      u32 bb = 0, r = u2, h = 0;
+      if (tp.V != 1 || tp.C != 1) {
+        bb = u2 / tp.sub;
+        r = u2 - bb * tp.sub;
+        h = (g + tp.V - ((bb + tp.rot[k]) % tp.V)) % tp.V;
+      }
+      dst = d.xsend + ((((size_t)s0 * tp.V + h) * d.f + k) * tp.sub + r) * PK_U4;
+    } else {
+      // the same payload slots in the same positions = the same packet (payloads do not change while the queue
+      // drains; transmit counts do not travel): point at the cell that already holds it
+      u32 j = 0xFFu;
+      wr = slots[k] != 0xFFFFFFFFu;
+      if (wr) {
+#pragma unroll
+        for (int q = k - 1; q >= 0; --q)
+          if (slots[q] == slots[k]) { j = (jout >> (8 * q)) & 0xFFu; wr = false; }
+        if (wr) j = ndist++;
+      }
+      jout = (jout & ~(0xFFu << (8 * k))) | (j << (8 * k));
+      dst = d.obox[cur ^ 1] + ((size_t)j * d.Nl + l) * PK_U4;
+    }
+    const bool store = SHARDED || __any(wr);  // (wave-uniform)
     uint4 wk, wl, wh;  // the packet in its wire form
-    wire_pack(pkc[0], wk.x, wl.x, wh.x); wire_pack(pkc[1], wk.y, wl.y, wh.y);
-    wire_pack(pkc[2], wk.z, wl.z, wh.z); wire_pack(pkc[3], wk.w, wl.w, wh.w);
+    if (store) {
+      wire_pack(pkc[0], wk.x, wl.x, wh.x); wire_pack(pkc[1], wk.y, wl.y, wh.y);
+      wire_pack(pkc[2], wk.z, wl.z, wh.z); wire_pack(pkc[3], wk.w, wl.w, wh.w);
+    }
     if (k + 1 < F) {  // packet k + 1: what stays in place is kept, what moved in was fetched, an empty position is zero
 #pragma unroll
       for (int p = 0; p < (int)SIM_P; ++p) {
@@ -1423,29 +1538,31 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
         else if (s == 0xFFu) pkc[p] = zero;
       }
     }
+    if (!store) continue;
     if (coop) {
       // Three lanes of a quad write one 48-byte cell per store instruction (lane i < 3 writes part i of quad-mate
       // j's packet): the texture addresser sees 48 contiguous bytes per quad and L2 one write per cell instead of
       // three.  The transpose goes through this wave's columns of lds_r (free in phase 2), XOR-swizzled so that
-      // neither side has bank conflicts.
+      // neither side has bank conflicts.  A lane without a cell to write hands its quad a null address.
       lds_r[0][tid] = wk; lds_r[1][tid ^ 1] = wl; lds_r[2][tid ^ 2] = wh;
       __builtin_amdgcn_wave_barrier();
       u32 qi = tid & 3u, qb = tid & ~3u, part = qi < 3u ? qi : 2u;  // the fourth lane of a quad has nothing to write
-      u32 dlo = (u32)(uintptr_t)dst, dhi = (u32)((uintptr_t)dst >> 32);
+      u32 dlo = wr ? (u32)(uintptr_t)dst : 0u, dhi = wr ? (u32)((uintptr_t)dst >> 32) : 0u;
 #define COOP_STORE(j)                                                                              \
       {                                                                                            \
         uint4 v = lds_r[part][(qb + j) ^ part];                                                    \
         u32 lo = (u32)__builtin_amdgcn_mov_dpp((int)dlo, j * 0x55, 0xF, 0xF, true);                \
         u32 hi = (u32)__builtin_amdgcn_mov_dpp((int)dhi, j * 0x55, 0xF, 0xF, true);                \
-        if (qi < 3u) ((uint4*)(((uintptr_t)hi << 32) | lo))[qi] = v;                               \
+        if (qi < 3u && (SHARDED || (lo | hi) != 0u)) ((uint4*)(((uintptr_t)hi << 32) | lo))[qi] = v; \
       }
       COOP_STORE(0) COOP_STORE(1) COOP_STORE(2) COOP_STORE(3)
 #undef COOP_STORE
       __builtin_amdgcn_wave_barrier();
-    } else {
+    } else if (wr) {
       dst[0] = wk; dst[1] = wl; dst[2] = wh;
     }
   }
+  if (!SHARDED && !ABL(4)) d.omap[cur ^ 1][l] = jout;
   TT(10);
   if (up && !ABL(16)) {
     node_store(d, l, n);
@@ -2073,6 +2190,45 @@ __global__ void recycle_view_kernel(Dev d, const u32* cand_slots, const u32* fir
   }
   if (bad) out_bad[c] = 1;
 }
+// Local mode, off the hot path: Dev::obox / omap (packets kept at their senders) <-> the canonical receiver-indexed
+// inbox[k][node].  `p` = the parameters of the tick the packets were sent in; `valid` = 0 at tick 0 (nothing in flight).
+__global__ void materialize_kernel(Dev d, TickP p, u32 cur, u32 valid, uint4* out) {
+  size_t n = (size_t)d.f * d.Nl;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    u32 k = (u32)(i / d.Nl), l = (u32)(i - (size_t)k * d.Nl);
+    uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a;
+    if (valid && k < p.feff) {
+      u32 h = l / p.M, t = l - h * p.M, g, ll;
+      fan_source_g(p, PICK4(p.off, k), PICK4(p.rot, k), PICK4(p.rho, k), h, t, k, g, ll);
+      u32 s = g * p.M + ll;
+      u32 jb = (d.omap[cur][s] >> (8u * k)) & 0xFFu;
+      if (jb != 0xFFu) {
+        const uint4* cp = d.obox[cur] + ((size_t)jb * d.Nl + s) * PK_U4;
+        a = cp[0]; b = cp[1]; c = cp[2];
+      }
+    }
+    out[i * PK_U4] = a; out[i * PK_U4 + 1] = b; out[i * PK_U4 + 2] = c;
+  }
+}
+__global__ void unmaterialize_kernel(Dev d, TickP p, u32 cur, u32 valid, const uint4* in) {
+  for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < d.Nl; s += (size_t)gridDim.x * blockDim.x) {
+    u32 jw = 0xFFFFFFFFu;
+    if (valid) {
+      u32 g = (u32)s / p.M, ll = (u32)s - g * p.M;
+      for (u32 k = 0; k < p.feff; ++k) {
+        u32 h, t;
+        fan_target_g(p, g, ll, k, h, t);
+        const uint4* cp = in + ((size_t)k * d.Nl + (size_t)h * p.M + t) * PK_U4;
+        uint4 a = cp[0], b = cp[1], c = cp[2];
+        if (((c.x | c.y | c.z | c.w) & 0xF0u) == 0) continue;  // no record in it
+        uint4* op = d.obox[cur] + ((size_t)k * d.Nl + s) * PK_U4;
+        op[0] = a; op[1] = b; op[2] = c;
+        jw = (jw & ~(0xFFu << (8u * k))) | (k << (8u * k));
+      }
+    }
+    d.omap[cur][s] = jw;
+  }
+}
 __global__ void set_flag_bits(uint4* R1, u32 l, u32 bits) {
   if (threadIdx.x == 0 && blockIdx.x == 0) R1[l].z |= bits;
 }
@@ -2125,6 +2281,10 @@ struct sim_handle {
   bool in_tick, tick_timed, tick_bracket;
   hipEvent_t tick_ev0;
   uint4* rbuf[2];          // sharded: packets sent during tick t are received into rbuf[t & 1]
+  // local mode: the packets in flight in their canonical receiver-indexed form inbox[k][node] (what the oracle keeps,
+  // what dumps, digests and images hold), produced from Dev::obox on demand; mat_tick = the tick it was made for
+  uint4* inbox_mat;
+  u64 mat_tick;
 };
 
 #define HCHECK(x)                                                                        \
@@ -2286,11 +2446,16 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   }
   DA(d.R0, Nl) DA(d.R1, Nl) DA(d.R2, Nl) DA(d.R3, Nl) DA(d.R4, Nl) DA(d.R5, Nl)
   DA(d.qkeys, 4 * Nl) DA(d.qpay, (size_t)SIM_Q * Nl) DA(d.pend, (size_t)SIM_PEND * Nl)
-  if (!d.sharded) { DA(d.inbox[0], (size_t)d.f * Nl * PK_U4) DA(d.inbox[1], (size_t)d.f * Nl * PK_U4) }
+  h->inbox_mat = nullptr;
+  h->mat_tick = ~0ull;
+  if (!d.sharded) {
+    DA(d.obox[0], (size_t)d.f * Nl * PK_U4) DA(d.obox[1], (size_t)d.f * Nl * PK_U4) DA(d.omap[0], Nl) DA(d.omap[1], Nl)
+    DA(h->inbox_mat, (size_t)d.f * Nl * PK_U4)
+  }
   DA(d.view, (size_t)d.A * Nl * 2)
   DA(d.ering, (size_t)d.Bev * Nl * 2)
   DA(d.qring, (size_t)d.Bq * Nl * 2)
-  DA(d.slot_of, d.N) DA(d.subject_of, d.A) DA(d.walk, d.A) DA(d.upmap, nup) DA(d.nullcell, 2)
+  DA(d.slot_of, d.N) DA(d.subject_of, d.A) DA(d.walk, d.A) DA(d.upmap, nup) DA(d.nullcell, 4)
   DA(d.qtab, QTAB_U4(d.N)) DA(d.qbits, (size_t)SIM_QT * 2 * nup)
   DA(d.events, (size_t)EV_CAP) DA(d.ev_count, 1)
   DA(h->d_base, (size_t)d.N * 2)
@@ -2305,9 +2470,12 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   HCHECK(zero(d.R2, Nl * 16)); HCHECK(zero(d.R3, Nl * 16)); HCHECK(zero(d.R4, Nl * 16)); HCHECK(zero(d.R5, Nl * 16));
   HCHECK(zero(d.qpay, (size_t)SIM_Q * Nl * 16));
   HCHECK(zero(d.ev_count, 4));
-  HCHECK(zero(d.nullcell, 32));
+  HCHECK(zero(d.nullcell, 64));
   HCHECK(zero(d.qtab, QTAB_U4(d.N) * 16)); HCHECK(zero(d.qbits, (size_t)SIM_QT * 2 * nup * 4));
-  if (!d.sharded) { HCHECK(zero(d.inbox[0], (size_t)d.f * Nl * sizeof(sim_packet))); HCHECK(zero(d.inbox[1], (size_t)d.f * Nl * sizeof(sim_packet))); }
+  if (!d.sharded) {  // nothing has been sent yet
+    HCHECK(zero(d.obox[0], (size_t)d.f * Nl * sizeof(sim_packet))); HCHECK(zero(d.obox[1], (size_t)d.f * Nl * sizeof(sim_packet)));
+    HCHECK(hipMemsetAsync(d.omap[0], 0xFF, Nl * 4, s)); HCHECK(hipMemsetAsync(d.omap[1], 0xFF, Nl * 4, s));
+  }
   HCHECK(zero(d.view, (size_t)d.A * Nl * 32));
   HCHECK(zero(d.ering, (size_t)d.Bev * Nl * 32));
   HCHECK(zero(d.qring, (size_t)d.Bq * Nl * 32));
@@ -2356,7 +2524,7 @@ int sim_set_stream(sim_handle* h, void* st) {
   return SIM_OK;
 }
 
-static const uint4* cur_inbox(const sim_handle* h);
+static const uint4* cur_inbox(sim_handle* h);
 static void walk_upload(sim_handle* h) {  // h->walk -> d.walk (synchronous: the host vector changes again later)
   if (!h->walk.empty()) (void)hipMemcpy(h->d.walk, h->walk.data(), h->walk.size() * 4, hipMemcpyHostToDevice);
 }
@@ -2751,6 +2919,7 @@ int sim_step_begin(sim_handle* h) {
 static int tick_launch(sim_handle* h, u32 chunk) {
   Dev& d = h->d;
   const TickP& tp = h->cur_tp;
+  const TickP& ptp = h->tick ? h->prev : h->cur_tp;  // the map the packets in flight were sent with (tick 0: none are)
   u32 cnt = chunk == 0xFFFFFFFFu ? d.Nl : tp.V * tp.sub;
   int grid = (int)((cnt + TBLOCK - 1) / TBLOCK);
   u32 cur = (u32)(h->tick & 1);
@@ -2760,22 +2929,24 @@ static int tick_launch(sim_handle* h, u32 chunk) {
     HCHECK(hipEventCreate(&e1));
     h->prof.emplace_back(e0, e1);
   }
-#define LAUNCH_TICK(SH, FF)                                                                                              \
+#define LAUNCH_TICK(SH, FF, BB)                                                                                          \
   do {                                                                                                                   \
-    if (e0) hipExtLaunchKernelGGL((tick_kernel<SH, FF>), dim3(grid), dim3(TBLOCK), 0, h->stream, e0, e1, 0, d, tp, cur, \
+    if (e0) hipExtLaunchKernelGGL((tick_kernel<SH, FF, BB>), dim3(grid), dim3(TBLOCK), 0, h->stream, e0, e1, 0, d, tp, ptp, cur, \
                                   (const uint4*)h->d_base, chunk, cnt);                                                  \
-    else tick_kernel<SH, FF><<<grid, TBLOCK, 0, h->stream>>>(d, tp, cur, h->d_base, chunk, cnt);                         \
+    else tick_kernel<SH, FF, BB><<<grid, TBLOCK, 0, h->stream>>>(d, tp, ptp, cur, h->d_base, chunk, cnt);                \
   } while (0)
+#define LAUNCH_LOCAL(FF) do { if (tp.B == 64u) LAUNCH_TICK(false, FF, true); else LAUNCH_TICK(false, FF, false); } while (0)
   switch (tp.feff + (d.sharded ? 4u : 0u)) {  // one instantiation per fan-out: the drain loop is fully unrolled
-    case 0: case 1: LAUNCH_TICK(false, 1); break;
-    case 2: LAUNCH_TICK(false, 2); break;
-    case 3: LAUNCH_TICK(false, 3); break;
-    case 4: LAUNCH_TICK(false, 4); break;
-    case 5: LAUNCH_TICK(true, 1); break;
-    case 6: LAUNCH_TICK(true, 2); break;
-    case 7: LAUNCH_TICK(true, 3); break;
-    default: LAUNCH_TICK(true, 4); break;
+    case 0: case 1: LAUNCH_LOCAL(1); break;
+    case 2: LAUNCH_LOCAL(2); break;
+    case 3: LAUNCH_LOCAL(3); break;
+    case 4: LAUNCH_LOCAL(4); break;
+    case 5: LAUNCH_TICK(true, 1, false); break;
+    case 6: LAUNCH_TICK(true, 2, false); break;
+    case 7: LAUNCH_TICK(true, 3, false); break;
+    default: LAUNCH_TICK(true, 4, false); break;
   }
+#undef LAUNCH_LOCAL
 #undef LAUNCH_TICK
   HCHECK(hipGetLastError());
   return SIM_OK;
@@ -2882,8 +3053,18 @@ int sim_drain_events(sim_handle* h, sim_event* out, uint32_t cap, uint32_t* n) {
   return SIM_OK;
 }
 
-static const uint4* cur_inbox(const sim_handle* h) {
-  return h->d.sharded ? h->rbuf[(h->tick + 1) & 1] : h->d.inbox[h->tick & 1];
+// The packets in flight, receiver-indexed ([f][Nl] cells).  Sharded: the receive buffer.  Local mode: Dev::obox turned
+// inside out on h->stream (every user launches on that stream afterwards); the map is the one of the tick they were sent in.
+static const uint4* cur_inbox(sim_handle* h) {
+  if (h->d.sharded) return h->rbuf[(h->tick + 1) & 1];
+  if (h->mat_tick != h->tick) {
+    const Dev& d = h->d;
+    TickP p;
+    tickp_make(&p, &h->cfg, h->tick ? h->tick - 1 : 0);
+    materialize_kernel<<<grid_for((size_t)d.f * d.Nl), BLOCK, 0, h->stream>>>(d, p, (u32)(h->tick & 1), h->tick ? 1u : 0u, h->inbox_mat);
+    h->mat_tick = h->tick;
+  }
+  return h->inbox_mat;
 }
 int sim_state_digest(sim_handle* h, uint64_t out[8]) {
   if (!h || !out) return SIM_EINVAL;
@@ -3069,7 +3250,7 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
       in += n;
     }
   }
-  uint4* inbox_dst = d.sharded ? h->rbuf[(hd.tick + 1) & 1] : d.inbox[hd.tick & 1];
+  uint4* inbox_dst = d.sharded ? h->rbuf[(hd.tick + 1) & 1] : h->inbox_mat;
   if (len[2] && !inbox_dst) return SIM_ESTATE;  // sharded: bind the exchange buffers first
   {  // slot maps must be consistent with n_slots (they index the view)
     const u32* so = (const u32*)sec[6];
@@ -3101,6 +3282,11 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
     if (rc == SIM_OK) {
       restore_queue_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, (const uint4*)tmp_queue);
       restore_rows_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, (const u64*)tmp_rows);
+      if (!d.sharded) {  // the packets in flight go back to their senders (one cell per slot)
+        TickP p;
+        tickp_make(&p, &h->cfg, hd.tick ? hd.tick - 1 : 0);
+        unmaterialize_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, p, (u32)(hd.tick & 1), hd.tick ? 1u : 0u, h->inbox_mat);
+      }
       RCHECK(hipGetLastError());
     }
     RCHECK(hipStreamSynchronize(s));
@@ -3110,6 +3296,7 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
   if (tmp_queue) (void)hipFree(tmp_queue);
   if (rc != SIM_OK) return rc;
   h->tick = hd.tick;
+  h->mat_tick = d.sharded ? ~0ull : hd.tick;  // the image's inbox section is what sits in inbox_mat
   h->n_slots = hd.n_slots;
   if (hd.tick > 0) tickp_make(&h->prev, &h->cfg, hd.tick - 1);  // the parameters the packets in flight were sent with
   memcpy(h->slot_of.data(), sec[6], len[6]);
@@ -3242,6 +3429,23 @@ int sim_exchange_chunks(const sim_handle* h, uint32_t* chunks, size_t* bytes_per
   *chunks = h->d.sharded ? C : 1;
   *bytes_per_chunk = h->d.sharded ? (size_t)h->d.f * h->d.M * sizeof(sim_packet) / C : 0;
   return SIM_OK;
+}
+
+// Test hook (host arithmetic only, no device): the fan-out map of `tick` for global node `gid` — its targets and the
+// nodes whose packets land on it, both through the general forms the support kernels use.  Returns feff.
+int sim_t_fanmap(const sim_config* cfg, uint64_t tick, uint32_t gid, uint32_t* targets, uint32_t* sources) {
+  if (!cfg || !targets || !sources || !cfg->vshards || gid >= cfg->n_nodes) return SIM_EINVAL;
+  TickP p;
+  tickp_make(&p, cfg, tick);
+  u32 g = gid / p.M, ll = gid - g * p.M;
+  for (u32 k = 0; k < p.feff; ++k) {
+    u32 h, t, sg, sl;
+    fan_target_g(p, g, ll, k, h, t);
+    targets[k] = h * p.M + t;
+    fan_source_g(p, p.off[k], p.rot[k], p.rho[k], g, ll, k, sg, sl);
+    sources[k] = sg * p.M + sl;
+  }
+  return (int)p.feff;
 }
 
 }  // extern "C"

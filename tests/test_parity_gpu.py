@@ -44,6 +44,34 @@ def test_full_state_every_tick_small(oracle, hiplib, n, fanout, dense, swim):
     sc.assert_same_state(g, o, f"n={n} final")
 
 
+@pytest.mark.parametrize("n,vshards,chunks,fanout", [(4096, 4, 2, 4), (2048, 4, 0, 4), (4096, 1, 0, 3), (640, 2, 0, 2), (8192, 2, 2, 4)])
+def test_packets_kept_at_the_sender_virtual_shards_and_chunks(oracle, hiplib, n, vshards, chunks, fanout):
+    # One handle, every shape of the fan-out map (virtual shards, sender chunks, 64-node blocks and the B = 1
+    # fallback): the product keeps each DISTINCT packet once at its sender and the receiver fetches it through the
+    # map's inverse; the canonical inbox (dump, digest) is turned inside out from that on demand.  Packet loss and a
+    # load that makes the four packets of a node differ exercise the map word; a checkpoint taken in the middle goes
+    # through the image's receiver-indexed inbox and back to the senders.
+    kw = dict(fanout=fanout, vshards=vshards, chunks=chunks, view_slots=64, event_ring=16, query_ring=8, loss=0.03,
+              probe_interval=4, push_pull_interval=10, leave_delay=6)
+    g, o = pair(oracle, hiplib, n, **kw)
+    ops = sc.schedule(n, 50, rate=2.0, seed=n + vshards, max_member_subjects=30)
+    sc.apply_schedule(g, ops)
+    sc.apply_schedule(o, ops)
+    for t in range(70):
+        g.step(1)
+        o.step(1)
+        assert g.digest() == o.digest(), f"digest differs after tick {t}"
+        if t % 9 == 0:
+            sc.assert_same_state(g, o, f"tick {t}")
+        if t == 33:  # resume both from the HIP image
+            img = g.snapshot()
+            g.close()
+            g = _ffi.Sim(hiplib, _ffi.make_config(n, **kw))
+            g.restore(img)
+            assert g.digest() == o.digest(), "restored image differs"
+    sc.assert_same_state(g, o, "final")
+
+
 def test_packet_loss_and_overload(oracle, hiplib):
     # 5 % packet loss and an injection rate above the protocol's capacity => queue overflow paths
     g, o = pair(oracle, hiplib, 512, fanout=3, view_slots=128, event_ring=8, query_ring=8, loss=0.05)
