@@ -25,10 +25,12 @@ def b_tick_v0(f):
     return 2 * 64 + 2 * 16 * 16 + 2 * f * 4 * 16 + 4 * (f + 2)
 
 
-# the same accounting for the frozen layout: rows + (sort keys r/w + payload gathers)
-# + packets written once and read once + one slot-map word and one 16-byte head per received record
+# the same accounting for the frozen layout
 def b_tick_layout(f):
-    return 2 * 64 + (2 * 16 * 4 + f * 4 * 16) + 2 * f * 4 * 16 + f * 4 * (4 + 16)
+    # rows r/w; sort keys r/w + the payload gathers of ONE packet (a node's f packets of a tick are the same packet);
+    # that packet written once (48-byte cell + the map word) and fetched by its f receivers; one slot-map word and one
+    # 16-byte head per received record
+    return 2 * 64 + (2 * 16 * 4 + 4 * 16) + (48 + 4) + f * (48 + 4) + f * 4 * (4 + 16)
 
 
 PMC_TRAFFIC = ("profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json")  # newest first
@@ -121,6 +123,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence", action="store_true", help="skip the rounds-to-99 %% measurement (profiling runs)")
     ap.add_argument("--allow-drops", action="store_true", help="do not fail when the run hit a model bound (overflow > 0)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N > 1 run (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (with --backend gloo; RCCL refuses two ranks on one device)")
     ap.add_argument("--chunks", type=int, default=2,
                     help="N > 1: sender chunks per tick; the all-to-all of chunk c travels while chunk c + 1 computes (1 = one exchange after the kernel)")
     return ap.parse_args(argv)
@@ -145,6 +150,8 @@ def run(args, lib=None, dev=None, backend="nccl"):
     if on_gpu:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+        if getattr(args, "single_device", False):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -352,7 +359,8 @@ def run(args, lib=None, dev=None, backend="nccl"):
 
 
 def main():
-    run(parse_args())
+    args = parse_args()
+    run(args, backend=args.backend)
 
 
 if __name__ == "__main__":

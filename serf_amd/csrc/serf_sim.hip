@@ -4,7 +4,9 @@
 //   1. streams its packed row (three 16-byte groups: the 3 Lamport clocks, SerfState bits and
 //      counters, queue bookkeeping; a fourth group with the memberlist fields when the SWIM layer
 //      is on) and the 16 sort keys of its TransmitLimitedQueue out of HBM,
-//   2. reads the fan-out packets addressed to it (inbox[k][node], 48 B each: 12-byte wire records), four records at a
+//   2. reads the fan-out packets addressed to it (48 B each: 12-byte wire records) — on one GPU it FETCHES them from
+//      their senders through the inverse of the fan-out map (a sender keeps one copy of each distinct packet, step 6),
+//      in a sharded run from the exchange buffer — four records at a
 //      time, first issuing the four independent de-dup lookups of a packet (slot map -> view
 //      column entry, or event/query ring bucket) and only then running the handlers in arrival
 //      order, so a packet costs two memory round trips instead of eight,
@@ -16,9 +18,11 @@
 //      in 32 bits, sorted by min/max networks — while the 16-byte records themselves never move
 //      (slot-stable payload array), drains `fanout` packets of SIM_P records
 //      (delegate.rs:317-384, memberlist-core App. B.1) and
-//   6. pushes each packet into the inbox cell of the peer chosen by this tick's fixed-point-free
-//      pseudo-random bijection — exactly one writer per cell, so no atomics and no ordering
-//      ambiguity (DESIGN.md SIMSPEC).
+//   6. sends packet k to the peer chosen by this tick's fixed-point-free pseudo-random bijection — every node
+//      receives exactly one packet per slot, so no atomics and no ordering ambiguity (DESIGN.md SIMSPEC).  One GPU:
+//      a node's f packets of a tick are nearly always the SAME packet, so it writes each distinct packet once, next
+//      to itself, plus a map word (slot -> cell), and the receivers come and get it (step 2): a quarter of the packet
+//      writes.  Sharded: the packets go into the exchange buffer, one dense slab per (destination, slot).
 // Integer / byte work only: the roofline is HBM bandwidth, there is nothing for MFMA to do.
 //
 // There is deliberately no CPU fallback in this file: without a usable HIP device sim_create
