@@ -1294,19 +1294,22 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
   u32 om0 = 0xFFFFFFFFu, om1 = 0xFFFFFFFFu, om2 = 0xFFFFFFFFu, om3 = 0xFFFFFFFFu;
   if (SHARDED) cell = tp.first ? d.nullcell : cell_of(0);
   else {
+    // (the four senders first, then the four loads back to back from selected addresses: a load inside a branch gets
+    // its own s_waitcnt — four round trips before the row was even asked for)
     const u32* om = d.omap[cur];
-    u32 s0 = src_of(0);
+    const u32* none = reinterpret_cast<const u32*>(d.nullcell);
+    const u32 s0 = src_of(0), s1 = src_of(1), s2 = src_of(2), s3 = src_of(3);
+    const u32 *a0 = tp.feff > 0 ? om + s0 : none, *a1 = tp.feff > 1 ? om + s1 : none;
+    const u32 *a2 = tp.feff > 2 ? om + s2 : none, *a3 = tp.feff > 3 ? om + s3 : none;
     cell = tp.feff ? d.obox[cur] + (size_t)s0 * PK_U4 : d.nullcell;
-    if (tp.feff > 0) om0 = om[s0];
-    if (tp.feff > 1) om1 = om[src_of(1)];
-    if (tp.feff > 2) om2 = om[src_of(2)];
-    if (tp.feff > 3) om3 = om[src_of(3)];
+    om0 = *a0; om1 = *a1; om2 = *a2; om3 = *a3;
   }
   uint4 rn = ld4(cell), rn1 = ld4((SHARDED && tp.first) ? cell : cell + 1), rn2 = ld4((SHARDED && tp.first) ? cell : cell + 2);
   Node n;
   node_load(d, l, n);
   if (!SHARDED) {
-    jw = (om0 & 0xFFu) | (om1 & 0xFF00u) | (om2 & 0xFF0000u) | (om3 & 0xFF000000u);
+    jw = (tp.feff > 0 ? om0 & 0xFFu : 0xFFu) | (tp.feff > 1 ? om1 & 0xFF00u : 0xFF00u) |
+         (tp.feff > 2 ? om2 & 0xFF0000u : 0xFF0000u) | (tp.feff > 3 ? om3 & 0xFF000000u : 0xFF000000u);
     if ((jw & 0xFFu) == 0xFFu) rn = rn1 = rn2 = zero;
   }
   bool up = n.flags & SIM_RF_UP;
@@ -1422,12 +1425,21 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
   u32 sk[SIM_Q];
   u32 cnt0 = __popc(n.used);
   if (up) {
+    // the first two parked broadcasts travel with the sort keys (one round trip instead of up to three; a lane with
+    // nothing parked reads the zero cell: a load inside a branch gets its own s_waitcnt)
+    uint4 pq0 = ld4(n.npend > 0 ? &d.pend[l] : d.nullcell), pq1 = ld4(n.npend > 1 ? &d.pend[(size_t)d.Nl + l] : d.nullcell);
     keys_load(d, l, cnt0, sk);
     if (n.next_seq > 1023u - 64u) q_renorm(n, sk);
+    if (__any(n.npend > 0)) {
+      if (n.npend > 0) q_insert(c, n, sk, pq0.x, pq0.y, (u64)pq0.z | ((u64)pq0.w << 32));
+      if (__any(n.npend > 1)) {
+        if (n.npend > 1) q_insert(c, n, sk, pq1.x, pq1.y, (u64)pq1.z | ((u64)pq1.w << 32));
 #pragma unroll 1
-    for (u32 i = 0; i < n.npend; ++i) {
-      uint4 q = ld4(&d.pend[(size_t)i * d.Nl + l]);
-      q_insert(c, n, sk, q.x, q.y, (u64)q.z | ((u64)q.w << 32));
+        for (u32 i = 2; i < n.npend; ++i) {
+          uint4 q = ld4(&d.pend[(size_t)i * d.Nl + l]);
+          q_insert(c, n, sk, q.x, q.y, (u64)q.z | ((u64)q.w << 32));
+        }
+      }
     }
     if (d.queue_check_interval && ((u32)tp.tick + (gid >> 6)) % d.queue_check_interval == 0) queue_check(c, n, sk);
   }
@@ -2152,9 +2164,26 @@ __global__ void poke_u32(u32* p, u32 v) { if (!threadIdx.x && !blockIdx.x) *p = 
 __global__ void poke_base(uint4* base, u32 x, uint4 e0, uint4 e1) { if (!threadIdx.x && !blockIdx.x) { base[(size_t)x * 2] = e0; base[(size_t)x * 2 + 1] = e1; } }
 // ---- view-slot recycling scans (SIMSPEC §2.6; oracle recycle_scan) ----
 // subjects that a running node still has a queued record or a suspicion timer about, or that a packet in flight mentions
-__global__ void recycle_refd_kernel(Dev d, const uint4* inbox, uint8_t* refd, u32* first_up) {
+// (packets in flight: sharded, the receive buffer `inbox`; local mode, inbox == null and the cells the senders kept —
+// every cell a map word points at is delivered to somebody, so the set of subjects is the same)
+__global__ void recycle_refd_kernel(Dev d, const uint4* inbox, u32 cur, uint8_t* refd, u32* first_up) {
   u32 lo = 0xFFFFFFFFu;
   for (size_t l = blockIdx.x * (size_t)BLOCK + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * BLOCK) {
+    if (!inbox && !d.sharded) {
+      u32 jw = d.omap[cur][l];
+      for (u32 k = 0; k < d.f; ++k) {
+        u32 jb = (jw >> (8u * k)) & 0xFFu;
+        bool again = jb == 0xFFu;
+        for (u32 q = 0; q < k; ++q) again |= ((jw >> (8u * q)) & 0xFFu) == jb;
+        if (again) continue;
+        const uint4* cellp = d.obox[cur] + ((size_t)jb * d.Nl + l) * PK_U4;
+        uint4 ck = cellp[0], ch = cellp[2];
+        for (u32 p = 0; p < SIM_P; ++p) {
+          u32 key = pk_word(ck, p);
+          if (member_kind(SIM_META_KIND(pk_word(ch, p))) && key < d.N) refd[key] = 1;
+        }
+      }
+    }
     if (inbox)
       for (u32 k = 0; k < d.f; ++k)
         for (u32 p = 0; p < SIM_P; ++p) {
@@ -2609,7 +2638,7 @@ static int recycle_scan(sim_handle* h, sim_recycle_cand* c, u32 n) {
   if (e == hipSuccess) e = hipMemcpyAsync(scr, hs, sizeof hs, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) e = hipMemsetAsync(d_ref, 0, SIM_RECYCLE_BATCH * 16, s);
   if (e == hipSuccess) {
-    recycle_refd_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, cur_inbox(h), refd, scr);
+    recycle_refd_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, d.sharded ? cur_inbox(h) : nullptr, (u32)(h->tick & 1), refd, scr);
     recycle_view_kernel<<<dim3((unsigned)std::min<size_t>((d.Nl + BLOCK - 1) / BLOCK, 1024), n), BLOCK, 0, s>>>(d, scr + 4, scr, d_ref, scr + 4 + SIM_RECYCLE_BATCH);
     e = hipMemcpyAsync(hs, scr, sizeof hs, hipMemcpyDeviceToHost, s);
   }
