@@ -34,7 +34,7 @@ traffic = {
                    "(profiles/r02_hbm_counter_calibration.json): TCC_EA0_RDREQ counts 128-byte requests, FETCH_SIZE prices "
                    "them at 64 B (factor 0.500 for every read pattern); WRITE_SIZE exact (factor 1.000)",
     "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python bench.py --no-cpu-baseline "
-              "--no-convergence --steps 20 --warmup 5` (tools/profile_gpu.sh r02c, tools/gpu/call20.sh: the driver's command "
+              "--no-convergence --steps 20 --warmup 5` (tools/profile_gpu.sh r02d, tools/gpu/call22.sh: the driver's command "
               "line), mean over the 20 timed launches",
     "algorithmic_bytes_per_launch_v0": algo, "traffic_over_algorithmic": (read + write) / algo,
 }
