@@ -72,6 +72,43 @@ def test_packets_kept_at_the_sender_virtual_shards_and_chunks(oracle, hiplib, n,
     sc.assert_same_state(g, o, "final")
 
 
+@pytest.mark.parametrize("seed", list(range(48)))
+def test_random_configurations(oracle, hiplib, seed):
+    # a seeded sweep over the configuration space (size — ragged sizes included —, fan-out, virtual shards and chunks,
+    # view slots or dense views, ring sizes that are and are not powers of two, loss, load from idle to overload,
+    # SWIM / push-pull / reaper / queue checker / recycling on or off): digests after every tick, every array at the end
+    rng = np.random.default_rng(1000 + seed)
+    v = int(rng.choice([1, 1, 2, 4]))
+    c = int(rng.choice([0, 0, 2, 4])) if v > 1 or rng.random() < 0.3 else 0
+    unit = v * v * max(c, 1)
+    n = int(rng.choice([96, 200, 512, 1000, 2048, 4096, 8192]))
+    n = max(unit, n // unit * unit) if (v > 1 or c) else n  # shards and chunks need equal slabs
+    dense = n <= 600 and rng.random() < 0.4
+    swim = int(rng.choice([0, 2, 3, 5]))
+    kw = dict(fanout=int(rng.integers(1, 5)), vshards=v, chunks=c, view_slots=0 if dense else int(rng.choice([16, 48, 64])),
+              event_ring=int(rng.choice([8, 12, 16, 64])), query_ring=int(rng.choice([8, 10, 32])), leave_delay=int(rng.integers(3, 9)),
+              loss=float(rng.choice([0.0, 0.0, 0.02, 0.1])), probe_interval=swim, reap_interval=int(rng.choice([0, 5, 11])) if swim else 0,
+              reconnect_timeout=20, tombstone_timeout=30, intent_timeout=15,
+              queue_check_interval=int(rng.choice([0, 7])), min_queue_depth=int(rng.choice([0, 2])),
+              push_pull_interval=int(rng.choice([0, 4, 9])), recycle_interval=int(rng.choice([0, 6])) if not dense else 0)
+    try:
+        g, o = pair(oracle, hiplib, n, **kw)
+    except _ffi.SimError:
+        pytest.skip(f"configuration rejected by both sides: n={n} {kw}")
+    rate = float(rng.choice([0.2, 0.8, 2.5]))
+    ops = sc.schedule(n, 40, rate=rate, seed=seed, max_member_subjects=12 if not dense else min(n // 2, 30))
+    sc.apply_schedule(g, ops)
+    sc.apply_schedule(o, ops)
+    for t in range(64):
+        g.step(1)
+        o.step(1)
+        if g.digest() != o.digest():
+            sc.assert_same_state(g, o, f"seed {seed} n={n} {kw} tick {t}")
+            raise AssertionError(f"digest differs after tick {t} but the arrays agree")
+    sc.assert_same_state(g, o, f"seed {seed} final")
+    assert g.cluster_stats()["ops_dropped"] == o.cluster_stats()["ops_dropped"]
+
+
 def test_packet_loss_and_overload(oracle, hiplib):
     # 5 % packet loss and an injection rate above the protocol's capacity => queue overflow paths
     g, o = pair(oracle, hiplib, 512, fanout=3, view_slots=128, event_ring=8, query_ring=8, loss=0.05)
