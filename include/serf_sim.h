@@ -395,7 +395,10 @@ int sim_drain_events(sim_handle* h, sim_event* out, uint32_t cap, uint32_t* n);
  * [0] rows [1] queues [2] inbox [3] view [4] event ring [5] query ring [6] ops/aux [7] reserved */
 int sim_state_digest(sim_handle* h, uint64_t out[8]);
 /* Raw dump of one state array of the local shard (host buffer).  which = enum sim_array.
- * Call with buf == NULL to get the size in *bytes. */
+ * Call with buf == NULL to get the size in *bytes.  SIM_ARR_INBOX is the canonical form of the packets in flight:
+ * inbox[k][node] = the packet `node` is about to receive in fan-out slot k ([fanout][local nodes] sim_packet).  An
+ * implementation is free to keep them otherwise — the HIP library keeps one copy of each distinct packet at its SENDER
+ * (DESIGN.md sections 2.3, 3) — as long as the dump, the digest and the image are this form. */
 enum sim_array { SIM_ARR_ROWS = 0, SIM_ARR_QUEUE = 1, SIM_ARR_INBOX = 2, SIM_ARR_VIEW = 3,
                  SIM_ARR_ERING = 4, SIM_ARR_QRING = 5, SIM_ARR_SLOTMAP = 6 };
 int sim_dump_state(sim_handle* h, uint32_t which, void* buf, size_t cap_bytes, size_t* bytes);
