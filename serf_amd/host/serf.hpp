@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/serf_sim.h"
+#include "wire.hpp"
 
 namespace serf {
 
@@ -82,7 +83,13 @@ class Serf {
   inline std::vector<Member> members() const;                                 // api.rs:136
   inline Stats stats() const;                                                 // api.rs:150
   inline size_t num_members() const { return stats().members; }               // api.rs:188
-  // api.rs:241 — `name`/`payload` identity is a 32-bit key, `encoded_len` its wire size in bytes
+  // api.rs:241-299 with the reference's arguments: the size checks before and after encoding (UserEventLimitTooLarge /
+  // UserEventTooLarge / RawUserEventTooLarge, error.rs:247-259 -> SIM_ETOOBIG), the message priced by the codec
+  // (`encoded_message_len`, wire.hpp) at the node's current event clock; the simulator is told the 32-bit identity of
+  // (name, payload) and the framed length.  `max_user_event_size` = options.rs:528 (512), hard limit serf.rs:44 (9 KiB).
+  inline void user_event(const std::string& name, const std::vector<uint8_t>& payload, bool coalesce,
+                         size_t max_user_event_size = 512);
+  // the same with the identity and the length worked out by the caller
   inline void user_event(uint32_t event_key, uint32_t encoded_len = 32, bool coalesce = true);
   inline void query(uint32_t query_id, uint32_t flags = 0);                   // api.rs:304
   // QueryParam.filters (query.rs:37-93, should_process_query query.rs:439-521): `ids` = Filter::Id (at most
@@ -166,6 +173,16 @@ inline Stats Serf::stats() const {
   return s;
 }
 inline void Serf::user_event(uint32_t key, uint32_t len, bool cc) { check(sim_user_event(c_->raw(), id_, key, len, cc), "sim_user_event"); }
+inline void Serf::user_event(const std::string& name, const std::vector<uint8_t>& payload, bool cc, size_t max_user_event_size) {
+  constexpr size_t USER_EVENT_SIZE_LIMIT = 9 * 1024;  // serf.rs:44
+  size_t before = name.size() + payload.size();
+  if (before > max_user_event_size) throw Error(SIM_ETOOBIG, "user event exceeds configured limit before encoding");
+  if (before > USER_EVENT_SIZE_LIMIT) throw Error(SIM_ETOOBIG, "user event exceeds sane limit before encoding");
+  wire::Bytes nm(name.begin(), name.end());
+  size_t len = wire::user_event_len(stats().event_time, nm, payload, cc);
+  if (len > max_user_event_size || len > USER_EVENT_SIZE_LIMIT) throw Error(SIM_ETOOBIG, "encoded user event exceeds limit");
+  user_event(wire::event_key(nm, payload), (uint32_t)len, cc);
+}
 inline void Serf::query(uint32_t qid, uint32_t flags) { check(sim_query(c_->raw(), id_, qid, flags), "sim_query"); }
 inline void Serf::query(uint32_t qid, uint32_t flags, const std::vector<uint32_t>& ids, uint32_t tag_mask) {
   check(sim_query_filtered(c_->raw(), id_, qid, flags, ids.data(), (uint32_t)ids.size(), tag_mask), "sim_query_filtered");
