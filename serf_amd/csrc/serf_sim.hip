@@ -1326,22 +1326,27 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
         // index it by record number without holding 40 registers across the handlers.
         {
           const uint4 ck = rn, cl = rn1, ch = rn2;
-          if (k + 1 < d.f) {
-            cell = cell_of(k + 1);
-            rn = ld4(cell); rn1 = ld4(cell + 1); rn2 = ld4(cell + 2);
-          }
+          // The next packet is requested right BEHIND this packet's slot-map loads (which need only the keys and the
+          // kinds, straight from the wire words), not before them: vmcnt counts in issue order, so a prefetch issued first
+          // is waited for by the slot-map wait — an HBM round trip where an L2 one would do, and the heads' round trip
+          // on top; issued behind the slot-map loads it travels together with the head loads.
+          // (its address is worked out up here: what that needs may come back from scratch, and a scratch reload
+          // between two loads makes the second wait for the first)
+          cell = k + 1 < d.f ? cell_of(k + 1) : d.nullcell;
+          auto prefetch = [&]() __attribute__((always_inline)) { rn = ld4(cell); rn1 = ld4(cell + 1); rn2 = ld4(cell + 2); };
           TT(1);
           // wave-ballot early out: nobody in this wave received anything in packet k (an empty record is all zero)
-          if (!__any(((ch.x | ch.y | ch.z | ch.w) & 0xF0u) != 0)) continue;
+          if (!__any(((ch.x | ch.y | ch.z | ch.w) & 0xF0u) != 0)) { prefetch(); continue; }
+          u32 k0 = SIM_META_KIND(ch.x), k1 = SIM_META_KIND(ch.y), k2 = SIM_META_KIND(ch.z), k3 = SIM_META_KIND(ch.w);
+          if (ABL(64)) { n.dirty |= (k0 ^ k1 ^ k2 ^ k3) & tp.zero_; prefetch(); continue; }
+          u32 s0 = slot_load(d, k0, ck.x);
+          u32 s1 = slot_load(d, k1, ck.y);
+          u32 s2 = slot_load(d, k2, ck.z);
+          u32 s3 = slot_load(d, k3, ck.w);
+          prefetch();
           uint4 r0 = wire_unpack(ck.x, cl.x, ch.x), r1 = wire_unpack(ck.y, cl.y, ch.y);
           uint4 r2 = wire_unpack(ck.z, cl.z, ch.z), r3 = wire_unpack(ck.w, cl.w, ch.w);
-          u32 k0 = SIM_META_KIND(r0.y), k1 = SIM_META_KIND(r1.y), k2 = SIM_META_KIND(r2.y), k3 = SIM_META_KIND(r3.y);
-          if (ABL(64)) { n.dirty |= (k0 ^ k1 ^ k2 ^ k3) & tp.zero_; continue; }
           lds_r[0][tid] = r0; lds_r[1][tid] = r1; lds_r[2][tid] = r2; lds_r[3][tid] = r3;
-          u32 s0 = slot_load(d, k0, r0.x);
-          u32 s1 = slot_load(d, k1, r1.x);
-          u32 s2 = slot_load(d, k2, r2.x);
-          u32 s3 = slot_load(d, k3, r3.x);
           TT(2);
           uint4* p0 = lookup_ptr(c, vbase, eoff, qoff, k0, r0.x, (u64)r0.z | ((u64)r0.w << 32), s0);
           uint4* p1 = lookup_ptr(c, vbase, eoff, qoff, k1, r1.x, (u64)r1.z | ((u64)r1.w << 32), s1);
