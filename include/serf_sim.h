@@ -31,7 +31,7 @@ extern "C" {
 
 #define SIM_ABI_VERSION 8u
 
-#define SIM_P 4u  /* piggyback records per gossip packet (64-byte packet)             */
+#define SIM_P 4u  /* piggyback records per packet PAGE (48-byte cell: 4 records x 12 wire bytes) */
 #define SIM_PKT_BYTES 1400u /* byte budget of a gossip packet: memberlist's UDP payload limit (lan() and wan()); a packet
                              * takes records in drain order while they fit it (delegate.rs:317-384 `limit`, App. B.1
                              * get_broadcasts) — and at most SIM_P of them.  Lengths count in 16-byte units.            */
@@ -116,7 +116,8 @@ enum sim_kind {
 #define SIM_F_META 1u         /* ALIVE: the node's meta (tags) differs from what its previous incarnation carried:
                                * a receiver that already knew the node alive gets notify_update (SIM_EV_UPDATE)     */
 /* QueryParam.filters (types/filter.rs; should_process_query, query.rs:439-521): per running query one entry next to
- * the tracker, {query id, number of ids, tag-class mask, 0, ids[SIM_QF_IDS]} (16 words).  Filter::Id lists up to
+ * the tracker, {query id, number of ids, tag-class mask, sealed, ids[SIM_QF_IDS]} (16 words; `sealed` = 1 once the
+ * entry's SIM_OP_QUERY has been consumed: a later filter or query operation under the same id starts a fresh entry).  Filter::Id lists up to
  * SIM_QF_IDS node ids.  Filter::Tag is a regular expression over a tag's value: string work the host does once per
  * query, not per node — every node carries a TAG CLASS (0..31; class 0 = "no tags", which no tag filter matches,
  * query.rs:475-477/509-511), the host evaluates each tag filter against the (at most 31) distinct tag sets and

@@ -1333,11 +1333,14 @@ static void step_begin(osim* s) {
        * is started by the first filter operation that names the query, kept by its SIM_OP_QUERY, and replaced by
        * whatever names another query with the same residue */
       uint32_t* f = s->qfilt[op->a % SIM_QT];
-      if (f[0] != op->a) { memset(f, 0, sizeof s->qfilt[0]); f[0] = op->a; f[2] = 0xFFFFFFFFu; }
+      /* word 3 bit 0: sealed — the entry's SIM_OP_QUERY has been consumed; whatever names the id again starts afresh
+       * (a query re-issued under an old id must not inherit the old filters) */
+      if (f[0] != op->a || (f[3] & 1u)) { memset(f, 0, sizeof s->qfilt[0]); f[0] = op->a; f[2] = 0xFFFFFFFFu; }
       if (op->op == SIM_OP_QUERY_FILTER_ID) {
         if (f[1] == SIM_QF_IDS) s->ops_dropped++; /* model bound: the id does not fit */
         else f[4 + f[1]++] = op->b;
       } else if (op->op == SIM_OP_QUERY_FILTER_TAGS) f[2] &= op->b;
+      else f[3] |= 1u;
       if (op->op != SIM_OP_QUERY) continue;
     }
     uint32_t x = op_subject(s, op->op, op->node, op->a);
@@ -1433,6 +1436,7 @@ static int cfg_check(const sim_config* c) {
   if (c->chunks > 1 && ((M / c->vshards) % c->chunks || (M / c->vshards) / c->chunks < 1)) return SIM_EINVAL;
   if (c->event_ring < 1 || c->query_ring < 1) return SIM_EINVAL;
   if (c->retransmit_mult * digits10(c->n_nodes) > 63u) return SIM_EINVAL;
+  if (c->n_nodes > (1u << 24)) return SIM_EINVAL; /* SUSPECT / DEAD carry the accuser's id in 24 bits on the wire (sim_packet) */
   if (c->probe_interval) { /* suspicion timers name view slots with 16 bits */
     uint32_t A = (c->view_slots == 0 || c->view_slots >= c->n_nodes) ? c->n_nodes : c->view_slots;
     if (A > 65534u) return SIM_EINVAL;
@@ -1932,6 +1936,7 @@ static void snap_sections(osim* s, const void* ptr[SNAP_SECTIONS], size_t len[SN
 }
 int API(snapshot)(osim* s, void* buf, size_t cap, size_t* bytes) {
   if (!s || !bytes) return SIM_EINVAL;
+  if (s->in_tick) return SIM_ESTATE;
   const void* ptr[SNAP_SECTIONS];
   size_t len[SNAP_SECTIONS], tot = sizeof(snap_header);
   snap_sections(s, ptr, len);

@@ -2351,6 +2351,7 @@ static int cfg_check(const sim_config* c) {
   if (c->flags & SIM_CF_RANDOM_FANOUT) return SIM_EINVAL;  // oracle-only comparison mode (variable in-degree)
   if (c->event_ring < 1 || c->query_ring < 1) return SIM_EINVAL;
   if (c->retransmit_mult * h_digits10(c->n_nodes) > 63u) return SIM_EINVAL;
+  if (c->n_nodes > (1u << 24)) return SIM_EINVAL;  // SUSPECT / DEAD carry the accuser's id in 24 bits on the wire (sim_packet)
   if (c->probe_interval) {  // suspicion timers name view slots with 16 bits
     u32 A = (c->view_slots == 0 || c->view_slots >= c->n_nodes) ? c->n_nodes : c->view_slots;
     if (A > 65534u) return SIM_EINVAL;
@@ -2708,20 +2709,27 @@ static int recycle_local(sim_handle* h) {  // every shard is in this process: de
   h->recycle_at = (u32)h->tick;
   return rc;
 }
-int sim_inject(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, uint32_t b) {
-  if (!h || node >= h->d.N) return SIM_EINVAL;
-  if (tick < h->tick) tick = h->tick;
-  int rc = SIM_OK;
+// what an operation's arguments have to satisfy before it may reach ops_kernel (sim_inject, and every pending operation
+// of an image being restored)
+static int op_validate(u32 N, u32 op, u32 node, u32 a, u32 b) {
+  if (node >= N) return SIM_EINVAL;
   switch (op) {
     case SIM_OP_USER_EVENT: if (!a) return SIM_EINVAL; if ((b & 0x7FFFFFFFu) > 9 * 1024) return SIM_ETOOBIG; break;  // bit 31: cc
     case SIM_OP_QUERY: if (!a) return SIM_EINVAL; break;
-    case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: case SIM_OP_FORCE_LEAVE: case SIM_OP_CRASH: case SIM_OP_REVIVE: break;
+    case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: case SIM_OP_CRASH: case SIM_OP_REVIVE: break;
+    case SIM_OP_FORCE_LEAVE: if (a >= N) return SIM_EINVAL; break;
     case SIM_OP_SET_TAGS: if (a >= SIM_TAG_CLASSES) return SIM_EINVAL; break;
-    case SIM_OP_QUERY_FILTER_ID: if (!a || b >= h->d.N) return SIM_EINVAL; break;
+    case SIM_OP_QUERY_FILTER_ID: if (!a || b >= N) return SIM_EINVAL; break;
     case SIM_OP_QUERY_FILTER_TAGS: if (!a) return SIM_EINVAL; break;
     default: return SIM_EINVAL;
   }
-  if (op == SIM_OP_FORCE_LEAVE && a >= h->d.N) return SIM_EINVAL;
+  return SIM_OK;
+}
+int sim_inject(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, uint32_t b) {
+  if (!h) return SIM_EINVAL;
+  if (tick < h->tick) tick = h->tick;
+  int rc = op_validate(h->d.N, op, node, a, b);
+  if (rc) return rc;
   // an operation that executes now gets its view slot now (and SIM_ENOSLOT if there is none); one scheduled for a
   // later tick gets it when it executes — and is dropped and counted if none is free then (SIMSPEC §2.6)
   if (tick <= h->tick && op_subject(h, op, node, a) != NOSLOT) rc = ensure_slot(h, op_subject(h, op, node, a));
@@ -2906,15 +2914,17 @@ int sim_step_begin(sim_handle* h) {
     while (ob.n < 8 && h->op_cursor < h->ops.size() && h->ops[h->op_cursor].tick <= h->tick) {
       const OpEnt& e = h->ops[h->op_cursor++];
       if (e.op == SIM_OP_QUERY_FILTER_ID || e.op == SIM_OP_QUERY_FILTER_TAGS || e.op == SIM_OP_QUERY) {
-        // the query's filter entry: started by the first filter operation that names the query, kept by its
-        // SIM_OP_QUERY, replaced by whatever names another query with the same residue
+        // the query's filter entry: started by the first filter operation that names the query, SEALED by its
+        // SIM_OP_QUERY (word 3), replaced by whatever names another query with the same residue — or the same id again
+        // once the entry is sealed: a query issued a second time under an id starts from no filters
         u32* f = h->qfilt.data() + (size_t)(e.a % SIM_QT) * SIM_QF_WORDS;
         bool changed = false;
-        if (f[0] != e.a) { memset(f, 0, SIM_QF_WORDS * 4); f[0] = e.a; f[2] = 0xFFFFFFFFu; changed = true; }
+        if (f[0] != e.a || (f[3] & 1u)) { memset(f, 0, SIM_QF_WORDS * 4); f[0] = e.a; f[2] = 0xFFFFFFFFu; changed = true; }
         if (e.op == SIM_OP_QUERY_FILTER_ID) {
           if (f[1] == SIM_QF_IDS) { h->ops_dropped++; continue; }  // model bound: the id does not fit
           f[4 + f[1]++] = e.b; changed = true;
         } else if (e.op == SIM_OP_QUERY_FILTER_TAGS) { f[2] &= e.b; changed = true; }
+        else { f[3] |= 1u; changed = true; }
         if (changed) {
           QFiltEnt qe;
           memcpy(&qe, f, sizeof qe);
@@ -3225,6 +3235,7 @@ static void snap_lengths(const sim_handle* h, size_t len[SNAP_SECTIONS]) {
 }
 int sim_snapshot(sim_handle* h, void* buf, size_t cap, size_t* bytes) {
   if (!h || !bytes) return SIM_EINVAL;
+  if (h->in_tick) return SIM_ESTATE;  // between sim_step_begin and sim_step_end the state is half a tick ahead of `tick`
   Dev& d = h->d;
   size_t len[SNAP_SECTIONS], tot = sizeof(snap_header);
   snap_lengths(h, len);
@@ -3290,10 +3301,22 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
   }
   uint4* inbox_dst = d.sharded ? h->rbuf[(hd.tick + 1) & 1] : h->inbox_mat;
   if (len[2] && !inbox_dst) return SIM_ESTATE;  // sharded: bind the exchange buffers first
-  {  // slot maps must be consistent with n_slots (they index the view)
+  {  // slot maps must be consistent with n_slots (they index the view) and with each other (the recycling scan and
+     // ensure_slot go from a slot to its subject and back)
     const u32* so = (const u32*)sec[6];
+    const u32* sj = (const u32*)sec[7];
     for (u32 i = 0; i < d.N; ++i)
-      if (so[i] != NOSLOT && so[i] >= (h->dense ? d.A : hd.n_slots)) return SIM_EINVAL;
+      if (so[i] != NOSLOT && (so[i] >= (h->dense ? d.A : hd.n_slots) || sj[so[i]] != i)) return SIM_EINVAL;
+    for (u32 a = 0; a < d.A; ++a)
+      if (sj[a] != NOSLOT && (sj[a] >= d.N || so[sj[a]] != a)) return SIM_EINVAL;
+  }
+  {  // the pending schedule goes straight to ops_kernel: the same checks sim_inject applies
+    const OpEnt* po = (const OpEnt*)sec[12];
+    for (u32 i = 0; i < hd.n_pending_ops; ++i) {
+      OpEnt e;
+      memcpy(&e, po + i, sizeof e);
+      if (op_validate(d.N, e.op, e.node, e.a, e.b) != SIM_OK) return SIM_EINVAL;
+    }
   }
   for (u32 j = 0; j < SIM_QT; ++j)  // the kernel loops over n_ids and shifts by the class
     if (((const u32*)sec[14])[(size_t)j * SIM_QF_WORDS + 1] > SIM_QF_IDS) return SIM_EINVAL;

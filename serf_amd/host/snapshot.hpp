@@ -107,9 +107,10 @@ class Snapshotter {
     uint64_t last_seen = clock_time ? clock_time - 1 : 0;
     if (last_seen > last_clock_) { last_clock_ = last_seen; put_clock_record(buf_, CLOCK, last_seen); }
   }
-  void leave() {  // snapshot.rs:562-580
+  void leave() {  // snapshot.rs:562-580: the record is always appended; only the live set depends on rejoin_after_leave
     left_ = true;
-    if (!rejoin_after_leave_) buf_.push_back(LEAVE);
+    if (!rejoin_after_leave_) alive_.clear();
+    buf_.push_back(LEAVE);
   }
   // events of Cluster::drain_events() of this observer, in order; `clock_time` = the observer's Stats.member_time
   void feed(const std::vector<sim_event>& events, uint64_t clock_time) {

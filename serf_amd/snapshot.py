@@ -88,10 +88,12 @@ class Snapshotter:
             self.buf += _clock_record(CLOCK, last_seen)
 
     def leave(self):
-        """snapshot.rs:562-580: the node is leaving; nothing is recorded afterwards."""
+        """snapshot.rs:562-580 (handle_leave): the Leave record is ALWAYS appended; only forgetting the live nodes
+        depends on `rejoin_after_leave` ("if we plan to re-join, keep our state").  Nothing is recorded afterwards."""
         self.left = True
         if not self.rejoin_after_leave:
-            self.buf += bytes([LEAVE])
+            self.alive.clear()
+        self.buf += bytes([LEAVE])
 
     def feed(self, events, clock_time: int):
         """Events of sim_drain_events — (tick, observer, type, key, ltime) — of this observer, in order; `clock_time`

@@ -171,3 +171,21 @@ def test_filters_and_tags_survive_a_checkpoint(oracle):
     assert b.digest() == a.digest()
     assert drive(a) == drive(b)
     assert a.query_status(12)[0] > 0
+
+
+def test_query_id_reused_does_not_inherit_filters(oracle):
+    """A filter entry is sealed by its SIM_OP_QUERY: issuing a query again under an id that was used before starts from
+    no filters (`sim_query(id)` after `sim_query_filtered(id)` was silently filtered)."""
+    n = 64
+    sim = _ffi.Sim(oracle, _ffi.make_config(n, **KW))
+    sim.step(1)
+    sim.query(0, 77, ACK, ids=[1, 2], tag_mask=_ffi.NO_TAG_FILTER)
+    sim.step(30)
+    assert sim.query_status(77)[0] == 2
+    sim.query(3, 77, ACK)  # same id, no filters this time
+    sim.step(30)
+    assert sim.query_status(77)[0] == n
+    sim.query(4, 77, ACK, ids=[9])  # and a third time with another list: not appended to the first one
+    sim.step(30)
+    assert sim.query_status(77)[0] == 1
+    sim.close()

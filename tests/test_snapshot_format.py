@@ -52,15 +52,24 @@ def test_snapshoter_leave():
     s = kat_stream(False)
     s.leave()
     s.user_event(99)  # "stop recording events after a leave is issued": leaves no record
-    assert s.bytes()[-1] == snap.LEAVE
+    assert s.bytes()[-1] == snap.LEAVE and s.alive == set()
+    assert s.compact() == snap._clock_record(snap.CLOCK, s.last_clock) + snap._clock_record(snap.EVENT_CLOCK, s.last_event_clock) + \
+        snap._clock_record(snap.QUERY_CLOCK, s.last_query_clock)  # compaction after a leave re-emits no live node
+    s = kat_stream(False)
+    s.leave()
     r = snap.replay(s.bytes())
     assert r.alive_nodes == set() and (r.last_clock, r.last_event_clock, r.last_query_clock) == (0, 0, 0)
 
 
 def test_snapshoter_leave_rejoin():
-    # :389-493: with rejoin_after_leave the leave leaves no trace
+    # :389-493: with rejoin_after_leave the Leave record is still written (handle_leave, snapshot.rs:562-580, appends it
+    # unconditionally) but the state is kept, and a replay that plans to rejoin skips the record
     s = kat_stream(True)
     s.leave()
+    assert s.bytes()[-1] == snap.LEAVE and s.alive == {7}
+    # the same file replayed by a process that does NOT plan to come back: the record clears everything
+    r0 = snap.replay(s.bytes(), rejoin_after_leave=False)
+    assert r0.alive_nodes == set() and (r0.last_clock, r0.last_event_clock, r0.last_query_clock) == (0, 0, 0)
     r = snap.replay(s.bytes(), rejoin_after_leave=True)
     assert (r.last_clock, r.last_event_clock, r.last_query_clock) == (100, 42, 50) and r.alive_nodes == {7}
     # and a Leave record written by a process that did NOT plan to come back is ignored by one that does
