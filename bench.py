@@ -5,15 +5,24 @@ A "step" is one gossip tick of every simulated node.  N=1: BASELINE.json configs
 (1 Mi nodes, fan-out 4, HBM-roofline report).  N>1: one shard of 1 Mi nodes per GPU (weak
 scaling), the round's RCCL all-to-all issued chunk-wise and overlapped with compute.  Prints ONE JSON line on rank 0.
 
-The timed region is steady state by construction: run() first rolls the cluster forward
-`--preroll` untimed ticks under the same constant load (rumours live ~20 ticks, suspicion timers
-120+ ticks at this size, so a cold cluster is nearly idle), then does the `--warmup` and `--steps`
-the contract asks for.  The figure therefore does not depend on --steps / --warmup.
+`python bench.py --gpus N` without a launcher (WORLD_SIZE unset) starts its N ranks itself (one process per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set for them, rendezvous on 127.0.0.1) and supervises them: a rank that dies
+or a run that stops making progress is torn down, retried once with `--chunks 1`, and reported as a JSON line with an
+"error" field instead of a hang.  Under `python -m torch.distributed.run … bench.py --gpus N` it is a plain rank.
+
+The timed region is steady state by construction: run() first rolls the cluster forward `--preroll` untimed ticks
+under the same constant load (rumours live ~20 ticks, suspicion timers 120+ ticks at this size, so a cold cluster is
+nearly idle), then does the `--warmup` and `--steps` the contract asks for.  The operation schedule has a fixed horizon
+and the convergence window starts at a fixed tick, so neither member-ticks/s nor rounds-to-99 % depend on
+--steps / --warmup.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -21,8 +30,8 @@ sys.path.insert(0, ROOT)
 
 
 # SURVEY.md §8d algorithmic bytes per member-tick (v0 layout): 2R + 2QE + 2fPE + 4(f+2)
-def b_tick_v0(f):
-    return 2 * 64 + 2 * 16 * 16 + 2 * f * 4 * 16 + 4 * (f + 2)
+def b_tick_v0(f, p=4):
+    return 2 * 64 + 2 * 16 * 16 + 2 * f * p * 16 + 4 * (f + 2)
 
 
 # the same accounting for the frozen layout
@@ -33,8 +42,20 @@ def b_tick_layout(f):
     return 2 * 64 + (2 * 16 * 4 + 4 * 16) + (48 + 4) + f * (48 + 4) + f * 4 * (4 + 16)
 
 
-PMC_TRAFFIC = ("profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json")  # newest first
-CONV_RUMOURS, CONV_MAX_ROUNDS = 8, 60
+PMC_TRAFFIC = ("profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")  # newest first
+KERNEL_SOURCE = os.path.join("serf_amd", "csrc", "serf_sim.hip")
+# rounds-to-99 %: every user event the workload issues in CONV_WINDOW ticks starting CONV_OFFSET ticks after the
+# pre-roll (at most CONV_RUMOURS of them), each followed for at most CONV_MAX_ROUNDS rounds
+CONV_RUMOURS, CONV_MAX_ROUNDS, CONV_OFFSET, CONV_WINDOW = 64, 60, 400, 480
+
+
+def conv_start_tick(args):
+    return args.preroll + max(CONV_OFFSET, args.warmup + args.steps)
+
+
+def horizon(args):
+    h = conv_start_tick(args) + CONV_WINDOW + CONV_MAX_ROUNDS + 1
+    return (h + 39) // 40 * 40
 
 
 def workload(args, n_total):
@@ -45,17 +66,45 @@ def workload(args, n_total):
               probe_interval=args.probe_interval, push_pull_interval=args.push_pull_interval,
               reap_interval=75, queue_check_interval=150,  # options.rs defaults: reap 15 s, queue check 30 s, timeouts 24 h
               recycle_interval=args.recycle_interval)
-    horizon = args.preroll + args.warmup + args.steps + CONV_RUMOURS * (CONV_MAX_ROUNDS + 1)
-    ops = wl.schedule(n_total, horizon, rate=args.rate, seed=3, mix=wl.BENCH_MIX,
+    if getattr(args, "pkt_records", 4) != 4:
+        kw["pkt_records"] = args.pkt_records
+    ops = wl.schedule(n_total, horizon(args), rate=args.rate, seed=3, mix=wl.BENCH_MIX,
                       max_member_subjects=args.view_slots // 2, even=True)
     return kw, ops
 
 
-def cpu_baseline(args, seconds_budget=60.0):
-    """The CPU oracle ("port") on the SAME configuration and schedule as the N=1 GPU run (rank 0 only): the same
-    pre-roll, then a bounded number of timed ticks on all cores and a few on one thread.  When the host cannot hold
-    the configuration (it needs ~64 KiB of address space per node, a fraction of it resident) it falls back to a
-    smaller cluster and says so."""
+def kernel_source_sha16():
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, KERNEL_SOURCE), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def measured_traffic():
+    """HBM bytes per tick-kernel launch from the newest committed PMC profile — valid only for the kernel source it was
+    measured on (the profile records the source's hash; a file without one is treated as stale)."""
+    sha = kernel_source_sha16()
+    for rel in PMC_TRAFFIC:
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        try:
+            doc = json.load(open(path))
+        except Exception:
+            continue
+        prov = {"from_file": rel, "measured_at_commit": doc.get("commit"), "kernel_source_sha16": doc.get("kernel_source_sha16"),
+                "kernel_source_sha16_now": sha, "workload": doc.get("workload"), "calibration": doc.get("calibration")}
+        prov["matches_this_kernel"] = bool(sha and doc.get("kernel_source_sha16") == sha)
+        return doc.get("hbm_bytes_per_launch"), prov
+    return None, None
+
+
+def cpu_baseline(args, parity_tick, seconds_budget=240.0):
+    """The CPU oracle ("port") on the SAME configuration and schedule as the N=1 GPU run (rank 0 only): rolled through
+    the same ticks up to `parity_tick` (= the first timed tick of the GPU run), where its state digest is taken for the
+    parity block, then a bounded number of timed ticks on all cores and a few on one thread.  When the host cannot hold
+    the configuration (it needs ~64 KiB of address space per node, a fraction of it resident) it falls back to a smaller
+    cluster, says so, and the parity block is void."""
     from serf_amd import _ffi
 
     lib = _ffi.SimLib(os.path.join(ROOT, "oracle", "liboracle.so"), prefix="osim_")  # test infrastructure: the checker, timed
@@ -76,11 +125,15 @@ def cpu_baseline(args, seconds_budget=60.0):
     cores = int(lib.dll.osim_t_threads())
     t0 = time.perf_counter()
     rolled = 0
-    target = args.preroll + args.warmup
-    while rolled < target and time.perf_counter() - t0 < seconds_budget:  # untimed, like the GPU run's pre-roll
-        sim.step(5)
-        rolled += 5
+    while rolled < parity_tick:  # untimed, like the GPU run's pre-roll + warm-up — never shortened
+        k = min(5, parity_tick - rolled)
+        sim.step(k)
+        rolled += k
+        if time.perf_counter() - t0 > seconds_budget:
+            raise SystemExit(f"bench.py: the CPU oracle needed more than {seconds_budget:.0f} s for {rolled} of {parity_tick} pre-roll ticks "
+                             "on this host — cpu_baseline would not be timing the GPU's ticks; rerun with --no-cpu-baseline or a smaller --preroll")
     t_roll = time.perf_counter() - t0
+    digest = sim.digest() if n == args.nodes_per_gpu else None
     ticks_all, ticks_one = 32, 8
     t1 = time.perf_counter()
     done = 0
@@ -102,7 +155,7 @@ def cpu_baseline(args, seconds_budget=60.0):
             "single_thread_value": n * done1 / dt1,
             "sample": f"same configuration and schedule as the GPU run{note}: {n} nodes, view_slots {args.view_slots}, rings {args.ring}, "
                       f"fan-out {args.fanout}; {rolled} untimed pre-roll ticks ({t_roll:.1f} s), then ticks {rolled}..{rolled + done - 1} timed on "
-                      f"{cores} threads (OpenMP over nodes) and {done1} more on one thread; model_bound_drops {drops}"}
+                      f"{cores} threads (OpenMP over nodes) and {done1} more on one thread; model_bound_drops {drops}"}, digest
 
 
 def parse_args(argv=None):
@@ -117,6 +170,7 @@ def parse_args(argv=None):
     ap.add_argument("--view-slots", type=int, default=1024)
     ap.add_argument("--ring", type=int, default=512)
     ap.add_argument("--rate", type=float, default=0.25, help="API operations injected per tick (cluster-wide)")
+    ap.add_argument("--pkt-records", type=int, default=4, help="records a gossip packet can carry (4, 8, 12 or 16: pages of 4)")
     ap.add_argument("--probe-interval", type=int, default=5, help="memberlist probe interval in ticks (0 = SWIM layer off)")
     ap.add_argument("--push-pull-interval", type=int, default=150, help="memberlist push_pull_interval in ticks before log2(N) scaling (0 = off)")
     ap.add_argument("--recycle-interval", type=int, default=75, help="view-slot recycling pass every this many ticks (0 = never)")
@@ -128,7 +182,33 @@ def parse_args(argv=None):
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (with --backend gloo; RCCL refuses two ranks on one device)")
     ap.add_argument("--chunks", type=int, default=2,
                     help="N > 1: sender chunks per tick; the all-to-all of chunk c travels while chunk c + 1 computes (1 = one exchange after the kernel)")
+    ap.add_argument("--watchdog", type=float, default=120.0,
+                    help="N > 1: seconds without progress after which a rank gives up (a JSON line with \"error\" on rank 0, exit code 3)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched N > 1 run: seconds the supervisor waits for its ranks")
     return ap.parse_args(argv)
+
+
+class Progress:
+    """Heartbeat of a rank: every phase of run() touches it; a watchdog thread ends the process when it goes stale
+    (a collective that never completes would otherwise hang the whole job without a word)."""
+
+    def __init__(self, limit, rank, meta):
+        self.t, self.what, self.limit, self.rank, self.meta, self.done = time.monotonic(), "start", limit, rank, meta, False
+        if limit > 0:
+            threading.Thread(target=self._watch, daemon=True).start()
+
+    def __call__(self, what):
+        self.t, self.what = time.monotonic(), what
+
+    def _watch(self):
+        while not self.done:
+            time.sleep(1.0)
+            if not self.done and time.monotonic() - self.t > self.limit:
+                if self.rank == 0:
+                    print(json.dumps(dict(self.meta, error=f"no progress for {self.limit:.0f} s in phase '{self.what}' (collective hung?)",
+                                          value=None)), flush=True)
+                sys.stderr.write(f"bench.py rank {self.rank}: watchdog: stuck in '{self.what}'\n")
+                os._exit(3)
 
 
 def run(args, lib=None, dev=None, backend="nccl"):
@@ -147,6 +227,8 @@ def run(args, lib=None, dev=None, backend="nccl"):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     on_gpu = dev is None
+    progress = Progress(args.watchdog if world > 1 else 0.0, rank,
+                        {"metric": "member-ticks/sec", "unit": "member-ticks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup})
     if on_gpu:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
@@ -156,6 +238,7 @@ def run(args, lib=None, dev=None, backend="nccl"):
         dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        progress("init_process_group")
         if on_gpu:
             dist.init_process_group(backend, device_id=dev)
         else:
@@ -166,6 +249,7 @@ def run(args, lib=None, dev=None, backend="nccl"):
     if lib is None:
         lib = serf_amd.load()
     kw, ops = workload(args, n_total)
+    progress("create")
     if world > 1:
         sim = ShardedSim(lib, n_total, dev, chunks=args.chunks, **kw)
     else:
@@ -173,7 +257,15 @@ def run(args, lib=None, dev=None, backend="nccl"):
         if on_gpu:
             sim.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     raw = sim.sim if world > 1 else sim
-    step = sim.step
+
+    def step(k):
+        # (a heartbeat every few ticks: a long pre-roll is progress, a stuck collective is not)
+        while k > 0:
+            j = min(k, 20)
+            sim.step(j)
+            progress(f"step (tick {raw.tick})")
+            k -= j
+
     for t, op, node, a, b in ops:
         sim.inject(t, op, node, a, b)
 
@@ -184,6 +276,7 @@ def run(args, lib=None, dev=None, backend="nccl"):
             torch.cuda.synchronize()
         else:
             raw.sync()
+        progress("barrier")
 
     def allsum(vals):
         if world == 1:
@@ -192,15 +285,22 @@ def run(args, lib=None, dev=None, backend="nccl"):
         dist.all_reduce(t)
         return [int(x) for x in t]
 
+    def allmax(v):
+        if world == 1:
+            return int(v)
+        t = torch.tensor([int(v)], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t[0])
+
     def load_now():  # cluster-wide load: records per packet in flight, queue entries per node, model-bound drops
         if world > 1:
             sim.sync()  # the round's exchanges have landed
         cs = raw.cluster_stats()
-        inbox, queued, drops, up = allsum([cs["inbox_records"], sum(cs["queued"]), cs["overflow"], cs["up"]])
+        inbox, queued, drops, up, mxq = allsum([cs["inbox_records"], sum(cs["queued"]), cs["overflow"], cs["up"], 0])
         # operations skipped for want of a view slot are counted on the (replicated) schedule, the same on every rank
         return {"records_per_packet": inbox / (args.fanout * n_total), "queued_per_node": queued / n_total,
                 "drops": drops + int(cs["ops_dropped"]), "up": up, "slots_in_use": int(cs["slots_in_use"]),
-                "slots_recycled": int(cs["slots_recycled"])}
+                "slots_recycled": int(cs["slots_recycled"]), "max_queue": allmax(cs["max_queue"])}
 
     class _HostEvent:  # CPU stand-in for torch.cuda.Event in the plumbing test
         def __init__(self, enable_timing=True):
@@ -225,6 +325,11 @@ def run(args, lib=None, dev=None, backend="nccl"):
     step(args.warmup)
     barrier()
     load0 = load_now()
+    # parity block: the state the timed region starts from, digested (all 8 arrays); rank 0's cpu_baseline() rolls the
+    # oracle through the same schedule to the same tick and compares
+    parity_tick = args.preroll + args.warmup
+    want_parity = world == 1 and not args.no_cpu_baseline
+    gpu_digest = raw.digest() if want_parity else None
     # an event pair costs ~10 us of stream time: time a sample of the launches on long runs, all of them on short ones
     profile_every = 4 if args.steps >= 100 else 1
     raw.profile(profile_every)
@@ -234,7 +339,7 @@ def run(args, lib=None, dev=None, backend="nccl"):
     t0 = time.perf_counter()
     ev0, ev1 = Event(enable_timing=True), Event(enable_timing=True)
     ev0.record()
-    step(args.steps)
+    sim.step(args.steps)
     ev1.record()
     barrier()
     dt = time.perf_counter() - t0
@@ -258,28 +363,37 @@ def run(args, lib=None, dev=None, backend="nccl"):
         serial_ms = (time.perf_counter() - td0) * 1e3 / diag_ticks
         exchange_ms = sim.time_exchange(False) / diag_ticks
 
-    # ---- second half of the metric: rounds to 99 % convergence, measured after the timed region on
-    # fresh user events, one at a time, under the same background load (every rank issues the same
-    # calls; the originator's rank reads the Lamport time the event is going to get)
-    rng = np.random.default_rng(99)
-    rounds = []
-    for i in range(0 if args.no_convergence else CONV_RUMOURS):
-        node, key = int(rng.integers(0, n_total)), 0x7F000000 + i
-        owner = node // args.nodes_per_gpu
-        lt = raw.stats(node).event_time if owner == rank else 0
-        if world > 1:
-            t = torch.tensor([lt], dtype=torch.int64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            lt = int(t[0])
-        sim.user_event(node, key, 64)
-        got = None
-        for r in range(1, CONV_MAX_ROUNDS + 1):
+    # ---- second half of the metric: rounds to 99 % convergence of the workload's OWN user events (no extra load),
+    # every one issued in a fixed window of ticks, all outstanding ones polled with one launch per tick
+    rounds, conv_first, conv_last = [], None, None
+    if not args.no_convergence:
+        c0 = conv_start_tick(args)
+        step(c0 - raw.tick)
+        evs = [(t, node, a) for (t, op, node, a, b) in ops if op == _ffi.OP_USER_EVENT and c0 <= t < c0 + CONV_WINDOW][:CONV_RUMOURS]
+        by_tick = {}
+        for t, node, key in evs:
+            by_tick.setdefault(t, []).append((node, key))
+        outstanding = {}  # key -> (ltime, tick issued)
+        last = (max(by_tick) if by_tick else c0) + CONV_MAX_ROUNDS
+        while raw.tick <= last and (outstanding or raw.tick <= (max(by_tick) if by_tick else c0)):
+            t = raw.tick
+            bump = {}
+            for node, key in by_tick.get(t, ()):  # the Lamport time the event is going to get: its origin's event clock now
+                owner = node // args.nodes_per_gpu
+                lt = allmax(raw.stats(node).event_time if owner == rank else 0) + bump.get(node, 0)
+                bump[node] = bump.get(node, 0) + 1
+                outstanding[key] = (lt, t)
             step(1)
-            seen, up = sim.convergence(_ffi.K_EVENT, key, lt)
-            if seen * 100 >= up * 99:
-                got = r
-                break
-        rounds.append(got if got is not None else CONV_MAX_ROUNDS + 1)
+            keys = list(outstanding)
+            if keys:
+                seen, up = sim.convergence_many([(_ffi.K_EVENT, k, outstanding[k][0]) for k in keys])
+                for k, s in zip(keys, seen):
+                    r = raw.tick - outstanding[k][1]
+                    if s * 100 >= up * 99 or r > CONV_MAX_ROUNDS:
+                        rounds.append(r)
+                        del outstanding[k]
+        rounds += [CONV_MAX_ROUNDS + 1] * len(outstanding)
+        conv_first, conv_last = c0, raw.tick
     load2 = load_now()
     out = None
     if rank == 0:
@@ -288,17 +402,16 @@ def run(args, lib=None, dev=None, backend="nccl"):
         # dominant kernel = tick_kernel: one launch per tick; HIP events around the launches of the timed
         # region (sim_profile); ev_ms (everything on the stream, ops + push-pull included) for reference
         kern_s = prof_ms / 1e3 / max(1, prof_n) if prof_ms > 0 else ev_ms / 1e3 / args.steps  # (the oracle behind a CPU test has no kernel)
-        achieved = args.nodes_per_gpu * bt / kern_s / 1e9
-        traffic, traffic_src, traffic_cal = None, None, None
-        for rel in PMC_TRAFFIC:
-            if os.path.exists(os.path.join(ROOT, rel)):
-                try:
-                    doc = json.load(open(os.path.join(ROOT, rel)))
-                    traffic, traffic_src = doc.get("hbm_bytes_per_launch"), rel
-                    traffic_cal = doc.get("calibration")
-                    break
-                except Exception:
-                    pass
+        algorithmic = args.nodes_per_gpu * bt / kern_s / 1e9
+        layout = args.nodes_per_gpu * bt2 / kern_s / 1e9
+        traffic, prov = measured_traffic()
+        default_load = args.pkt_records == 4 and args.rate == 0.25 and args.nodes_per_gpu == 1 << 20 and world == 1
+        if traffic and prov["matches_this_kernel"] and default_load:
+            achieved, basis = traffic / kern_s / 1e9, "HBM bytes per launch measured with rocprofv3 PMC counters on this kernel source (roofline.traffic)"
+        else:
+            traffic = None  # a figure measured on another kernel source (or another load) is not this run's traffic
+            achieved, basis = layout, ("bytes per member-tick of the frozen layout (roofline.layout; no PMC measurement of this kernel source "
+                                       "and load is on file)")
         out = {
             "metric": "member-ticks/sec", "value": value, "unit": "member-ticks/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -306,41 +419,48 @@ def run(args, lib=None, dev=None, backend="nccl"):
             "data": "synthetic",
             "config": {"workload": f"{n_total} nodes ({args.nodes_per_gpu}/GPU), fan-out {args.fanout}, "
                                    f"{args.rate} API ops/tick evenly spaced, mix (0.55, 0.2, 0.15, 0.05, 0.05) of (user event, query, leave, crash+remove, crash+revive), "
+                                   f"{args.pkt_records} records per packet, "
                                    f"view_slots {args.view_slots}, rings {args.ring}, probe interval {args.probe_interval} ticks, push-pull interval "
                                    f"{args.push_pull_interval} ticks (x log2 scaling), reaper and queue checker on — BASELINE configs[2]; "
                                    f"{args.preroll} untimed pre-roll ticks under the same load before the warm-up (steady state)",
                        "parallelism": (f"node-id range shards x{world}, {args.chunks} chunk-wise all_to_all_single per tick, overlapped with compute"
                                        if world > 1 else "single GPU"),
-                       "departure_from_survey_8d": "SURVEY.md §8d config 3 asks for 1 024 active rumours: a packet carries SIM_P = 4 records "
-                                                   "(the survey's own P), so a node rebroadcasts f*P/limit = 16/28 = 0.57 records per tick and the "
-                                                   f"cluster sustains about that many new rumours per tick; the bench injects {args.rate} operations "
-                                                   "(~0.41 rumours) per tick = 72 % of it, ~10-15 rumours live at any time, zero model-bound drops "
-                                                   "(DESIGN.md §7)",
-                       "preroll": args.preroll,
+                       "preroll": args.preroll, "schedule_horizon": horizon(args),
                        "timed_ticks": [args.preroll + args.warmup, args.preroll + args.warmup + args.steps - 1],
                        "model_bound_drops": load2["drops"],
                        "load": {"records_per_packet_start": round(load0["records_per_packet"], 3),
                                 "records_per_packet_end": round(load1["records_per_packet"], 3),
                                 "queued_per_node_start": round(load0["queued_per_node"], 3),
                                 "queued_per_node_end": round(load1["queued_per_node"], 3),
+                                "deepest_queue": load1["max_queue"],
                                 "records_per_packet_preroll_every_40_ticks": trace,
                                 "nodes_up": load1["up"], "view_slots_in_use": load2["slots_in_use"],
                                 "view_slots_recycled": load2["slots_recycled"]}},
-            "rounds_to_99": ({"median": float(np.median(rounds)), "max": int(max(rounds)), "min": int(min(rounds)), "n": len(rounds),
-                              "what": "gossip rounds until >= 99 % of running nodes have applied a fresh user event, under the bench load",
+            "rounds_to_99": ({"median": float(np.median(rounds)), "p90": float(np.percentile(rounds, 90)), "max": int(max(rounds)),
+                              "min": int(min(rounds)), "mean": float(np.mean(rounds)), "n": len(rounds),
+                              "histogram": {str(r): int(c) for r, c in zip(*np.unique(rounds, return_counts=True))},
+                              "window_ticks": [conv_first, conv_last],
+                              "what": "gossip rounds until >= 99 % of running nodes have applied a user event, for every user event the workload itself "
+                                      f"issues in ticks [{conv_first}, {conv_first + CONV_WINDOW}) (a fixed window: independent of --steps / --warmup), "
+                                      "all outstanding events polled once per tick (sim_convergence_many)",
                               "fanout_model": "per-tick bijection (every node receives exactly `fanout` packets per round); memberlist's literal "
                                               "kRandomNodes (Poisson-like in-degree) needs one round more: 10 vs 9 at 64 Ki nodes, 12 vs 11 at "
                                               "1 Mi (CPU oracle, 1 000 rumours each, profiles/r02_fanout_model_*.json)"}
                              if rounds else None),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "frac": achieved / 8000.0, "traffic": traffic, "achieved_from": basis,
                          "kernel": "tick_kernel", "kernel_ms": kern_s * 1e3,
                          "kernel_ms_min": prof_min, "kernel_ms_max": prof_max, "kernel_launches": int(prof_n),
                          "kernel_timing": f"HIP event pair on every {profile_every}{'th' if profile_every > 1 else 'st'} tick_kernel dispatch of the timed region (hipExtLaunchKernelGGL start/stop events, on the launch stream)",
-                         "stream_ms_per_step": ev_ms / args.steps, "b_tick_bytes": bt,
-                         "achieved_revised": args.nodes_per_gpu * bt2 / kern_s / 1e9, "b_tick_layout_bytes": bt2,
+                         "stream_ms_per_step": ev_ms / args.steps,
+                         # SURVEY.md §8d's v0 figure — the formula the contract prices `achieved` with; it counts 4 copies
+                         # of every packet, which this kernel does not write, so it overstates the bytes on the pins
+                         "algorithmic": {"b_tick_bytes": bt, "achieved": algorithmic, "frac": algorithmic / 8000.0,
+                                         "what": "SURVEY.md §8d B_tick(f) = 2R + 2QE + 2fPE + 4(f+2) x nodes / kernel time"},
+                         "layout": {"b_tick_bytes": bt2, "achieved": layout, "frac": layout / 8000.0,
+                                    "what": "the same accounting for the frozen layout (DESIGN.md §4): packets kept at the sender"},
                          "traffic_over_algorithmic": (traffic / (args.nodes_per_gpu * bt)) if traffic else None,
-                         "traffic_source": traffic_src, "traffic_calibration": traffic_cal},
+                         "traffic_provenance": prov},
         }
         if world > 1:
             xb = raw.exchange_bytes()
@@ -352,19 +472,85 @@ def run(args, lib=None, dev=None, backend="nccl"):
                                        "while chunk c + 1 computes (overlapped_ms_per_step = ms_per_step); exchange_ms and serial_ms_per_step come "
                                        f"from {diag_ticks} further ticks with the collectives run one after the other between events (rank 0): "
                                        "exchange_ms = all-to-alls of one round, serial_ms_per_step = that round without overlap"}
+            out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                  "collective_library": ("RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version())
+                                                         if on_gpu and backend == "nccl" else backend)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            progress("cpu_baseline")
+            out["cpu_baseline"], cpu_digest = cpu_baseline(args, parity_tick)
+            if cpu_digest is None:
+                out["parity"] = {"tick": parity_tick, "digest_match": None, "why": "the host could not hold the configuration: oracle ran a smaller cluster"}
+            else:
+                out["parity"] = {"tick": parity_tick, "digest_match": tuple(cpu_digest) == tuple(gpu_digest), "arrays": 8,
+                                 "what": "sim_state_digest of the GPU run right before the timed region (rows, queues, packets in flight, views, "
+                                         "both rings, slot map + liveness, query tables) against the CPU oracle rolled through the same "
+                                         "schedule to the same tick (oracle/liboracle.so, the checker)",
+                                 "gpu": [f"{x:016x}" for x in gpu_digest], "oracle": [f"{x:016x}" for x in cpu_digest]}
         print(json.dumps(out), flush=True)
+    progress.done = True
     if world > 1:
         dist.destroy_process_group()
+    if out is not None and out.get("parity", {}).get("digest_match") is False:
+        raise SystemExit("bench.py: the GPU state at the first timed tick differs from the CPU oracle's — result invalid")
     if load2["drops"] and not args.allow_drops:
         # a run that hit a model bound is not a run of the protocol the parity tests cover: refuse it
         raise SystemExit(f"bench.py: model bound hit ({load2['drops']} drops: queue slots / bucket keys / timers) — result invalid")
     return out
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks, wait, tear down on failure; one retry with
+    `--chunks 1` (one synchronous exchange per tick: the simplest schedule) before giving up with an error line."""
+    import socket
+
+    def attempt(extra):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            # rank 0 inherits stdout (its JSON line is the result); the others keep stderr only
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(sys.argv[0])] + argv + extra, env=env,
+                                          stdout=None if r == 0 else subprocess.DEVNULL))
+        deadline = time.monotonic() + args.launch_timeout
+        rc, why = 0, ""
+        while True:
+            codes = [p.poll() for p in procs]
+            if any(c not in (None, 0) for c in codes):
+                rc, why = next(c for c in codes if c not in (None, 0)), f"rank {next(i for i, c in enumerate(codes) if c not in (None, 0))} exited with a failure"
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                rc, why = 124, f"ranks still running after {args.launch_timeout:.0f} s"
+                break
+            time.sleep(0.2)
+        for p in procs:  # our own children, by handle
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        return rc, why
+
+    rc, why = attempt([])
+    if rc and args.chunks > 1:
+        sys.stderr.write(f"bench.py: {why} (exit code {rc}); retrying with --chunks 1\n")
+        rc, why = attempt(["--chunks", "1"])
+    if rc:
+        print(json.dumps({"metric": "member-ticks/sec", "value": None, "unit": "member-ticks/s", "n_gpus": args.gpus, "steps": args.steps,
+                          "warmup": args.warmup, "error": f"{why} (exit code {rc}), also with --chunks 1"}), flush=True)
+    return rc
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
     run(args, backend=args.backend)
 
 

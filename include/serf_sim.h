@@ -29,7 +29,7 @@ extern "C" {
 
 /* ------------------------------------------------------------------ constants */
 
-#define SIM_ABI_VERSION 8u
+#define SIM_ABI_VERSION 9u
 
 #define SIM_P 4u  /* piggyback records per packet PAGE (48-byte cell: 4 records x 12 wire bytes) */
 #define SIM_PKT_BYTES 1400u /* byte budget of a gossip packet: memberlist's UDP payload limit (lan() and wan()); a packet
@@ -408,6 +408,13 @@ int sim_dump_state(sim_handle* h, uint32_t which, void* buf, size_t cap_bytes, s
  * number of up nodes (rounds-to-99 % = first tick with seen >= 0.99 * up). */
 int sim_convergence(sim_handle* h, uint32_t kind, uint32_t key, uint64_t ltime,
                     uint64_t* seen, uint64_t* up);
+
+/* The same for n <= SIM_CONV_MAX rumours in ONE pass over the nodes (bench.py follows every user event of its workload
+ * through a window of ticks: one launch per tick instead of one per rumour and tick): seen[i] for (kinds[i], keys[i],
+ * ltimes[i]); `up` is the common denominator. */
+#define SIM_CONV_MAX 64u
+int sim_convergence_many(sim_handle* h, uint32_t n, const uint32_t* kinds, const uint32_t* keys, const uint64_t* ltimes,
+                         uint64_t* seen, uint64_t* up);
 
 /* Sharded mode (shard_count == V > 1): the tick kernel writes outgoing packets into `send` and
  * reads incoming ones from `recv`, both DEVICE buffers of sim_exchange_bytes() bytes laid out as

@@ -2025,6 +2025,19 @@ int API(convergence)(osim* s, uint32_t kind, uint32_t key, uint64_t ltime, uint6
   return SIM_OK;
 }
 
+int API(convergence_many)(osim* s, uint32_t n, const uint32_t* kinds, const uint32_t* keys, const uint64_t* ltimes,
+                          uint64_t* seen, uint64_t* up) {
+  if (!s || !up || n > SIM_CONV_MAX || (n && (!kinds || !keys || !ltimes || !seen))) return SIM_EINVAL;
+  *up = 0;
+  for (uint32_t l = 0; l < s->Nl; ++l) *up += (s->rows[l].flags & SIM_RF_UP) != 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    uint64_t u;
+    int rc = API(convergence)(s, kinds[i], keys[i], ltimes[i], &seen[i], &u);
+    if (rc) return rc;
+  }
+  return SIM_OK;
+}
+
 int API(query_status)(osim* s, uint32_t qid, uint64_t* acks, uint64_t* responses, int* open) {
   if (!s || !acks || !responses || !open || !qid) return SIM_EINVAL;
   uint32_t j = qid % SIM_QT;

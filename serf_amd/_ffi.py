@@ -97,7 +97,7 @@ _ARR_DTYPE = {ARR_ROWS: ROW_DTYPE, ARR_QUEUE: REC_DTYPE, ARR_INBOX: PACKET_DTYPE
 # every symbol include/serf_sim.h declares (without prefix)
 ABI_SYMBOLS = ("create", "destroy", "set_stream", "join", "leave", "force_leave", "user_event",
                "query", "inject", "step", "sync", "tick", "members", "stats_get", "watch",
-               "drain_events", "state_digest", "dump_state", "convergence", "exchange_bytes",
+               "drain_events", "state_digest", "dump_state", "convergence", "convergence_many", "exchange_bytes",
                "bind_exchange", "snapshot", "restore", "query_status", "profile", "profile_read", "profile_read_stats", "cluster_stats_get",
                "bind_exchange2", "exchange_chunks", "step_begin", "step_chunk", "step_end",
                "recycle_due", "recycle_scan", "recycle_apply", "pp_due", "pp_plan", "pp_export", "pp_merge",
@@ -158,6 +158,7 @@ class SimLib:
             "state_digest": (C.c_int, [H, C.POINTER(u64 * 8)]),
             "dump_state": (C.c_int, [H, u32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
             "convergence": (C.c_int, [H, u32, u32, u64, C.POINTER(u64), C.POINTER(u64)]),
+            "convergence_many": (C.c_int, [H, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
             "exchange_bytes": (C.c_int, [H, C.POINTER(C.c_size_t)]),
             "bind_exchange": (C.c_int, [H, vp, vp]),
             "bind_exchange2": (C.c_int, [H, vp, vp, vp]),
@@ -311,6 +312,16 @@ class Sim:
         seen, up = C.c_uint64(), C.c_uint64()
         self._ck(self.lib.f["convergence"](self.h, kind, key, ltime, C.byref(seen), C.byref(up)), "sim_convergence")
         return seen.value, up.value
+
+    def convergence_many(self, rumours):
+        """([seen_i], up) for a list of up to 64 (kind, key, ltime) in one pass over the nodes."""
+        n = len(rumours)
+        kinds = (C.c_uint32 * max(1, n))(*[r[0] for r in rumours])
+        keys = (C.c_uint32 * max(1, n))(*[r[1] for r in rumours])
+        lts = (C.c_uint64 * max(1, n))(*[r[2] for r in rumours])
+        seen, up = (C.c_uint64 * max(1, n))(), C.c_uint64()
+        self._ck(self.lib.f["convergence_many"](self.h, n, kinds, keys, lts, seen, C.byref(up)), "sim_convergence_many")
+        return [int(x) for x in seen[:n]], up.value
 
     def snapshot(self):
         """Canonical image of the whole simulated cluster (bytes); restores into any implementation of the ABI."""

@@ -2120,6 +2120,47 @@ __global__ void convergence_kernel(Dev d, const uint4* base, u32 kind, u32 key, 
   block_sum_add(seen, out);
   block_sum_add(upc, out + 1);
 }
+// the same for up to SIM_CONV_MAX rumours in one pass: out[0] = running nodes, out[1 + i] = those that have applied rumour i
+struct ConvSet { u32 n; u32 kind[SIM_CONV_MAX], key[SIM_CONV_MAX]; u64 ltime[SIM_CONV_MAX]; };
+__global__ void convergence_many_kernel(Dev d, const uint4* base, ConvSet cs, u64* out) {
+  __shared__ u32 cnt[SIM_CONV_MAX + 1];
+  for (u32 i = threadIdx.x; i <= SIM_CONV_MAX; i += BLOCK) cnt[i] = 0;
+  __syncthreads();
+  const size_t rounds = ((size_t)d.Nl + (size_t)gridDim.x * BLOCK - 1) / ((size_t)gridDim.x * BLOCK);
+  for (size_t it = 0; it < rounds; ++it) {  // whole waves stay together: the ballots below need every lane
+    size_t l = (it * gridDim.x + blockIdx.x) * (size_t)BLOCK + threadIdx.x;
+    bool up = l < d.Nl && (d.R1[l].z & SIM_RF_UP);
+    u64 m = __ballot(up);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt[0], (u32)__popcll(m));
+    for (u32 i = 0; i < cs.n; ++i) {
+      bool hit = false;
+      if (up) {
+        u32 kind = cs.kind[i], key = cs.key[i];
+        u64 ltime = cs.ltime[i];
+        if (kind == SIM_K_JOIN || kind == SIM_K_LEAVE) {
+          u32 a = d.slot_of[key];
+          uint4 e = a == NOSLOT ? base[(size_t)key * 2] : d.view[(size_t)a * d.Nl + l];
+          hit = (e.w & SIM_VB_KNOWN) && E_LTIME(e) >= ltime;
+        } else {
+          const uint4* ring = kind == SIM_K_EVENT ? d.ering : d.qring;
+          u32 B = kind == SIM_K_EVENT ? d.Bev : d.Bq;
+          const uint4* p = ring + ((size_t)(ltime % B) * d.Nl + l);
+          uint4 b0 = p[0];
+          hit = (b0.z == key) | (b0.w == key);
+          if (!hit && b0.w) {  // the tail plane only when the head is full and does not hold the key
+            uint4 b1 = p[kind == SIM_K_EVENT ? d.etail : d.qtail];
+            hit = (b1.x == key) | (b1.y == key) | (b1.z == key) | (b1.w == key);
+          }
+        }
+      }
+      u64 hm = __ballot(hit);
+      if ((threadIdx.x & 63) == 0 && hm) atomicAdd(&cnt[1 + i], (u32)__popcll(hm));
+    }
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i <= cs.n; i += BLOCK)
+    if (cnt[i]) atomicAdd((unsigned long long*)(out + i), (unsigned long long)cnt[i]);
+}
 __global__ void stats_kernel(Dev d, u32 l, sim_stats* o) {
   if (threadIdx.x || blockIdx.x) return;
   sim_stats s;
@@ -3209,6 +3250,36 @@ int sim_convergence(sim_handle* h, uint32_t kind, uint32_t key, uint64_t ltime, 
   HCHECK(hipStreamSynchronize(s));
   *seen = r[0];
   *up = r[1];
+  return SIM_OK;
+}
+
+int sim_convergence_many(sim_handle* h, uint32_t n, const uint32_t* kinds, const uint32_t* keys, const uint64_t* ltimes,
+                         uint64_t* seen, uint64_t* up) {
+  if (!h || !up || n > SIM_CONV_MAX || (n && (!kinds || !keys || !ltimes || !seen))) return SIM_EINVAL;
+  Dev& d = h->d;
+  ConvSet cs;
+  memset(&cs, 0, sizeof cs);
+  cs.n = n;
+  for (u32 i = 0; i < n; ++i) {
+    if (kinds[i] == SIM_K_JOIN || kinds[i] == SIM_K_LEAVE) { if (keys[i] >= d.N) return SIM_EINVAL; }
+    else if (kinds[i] != SIM_K_EVENT && kinds[i] != SIM_K_QUERY) return SIM_EINVAL;
+    else if (!keys[i]) return SIM_EINVAL;
+    cs.kind[i] = kinds[i]; cs.key[i] = keys[i]; cs.ltime[i] = ltimes[i];
+  }
+  hipStream_t s = h->stream;
+  u64* scr = nullptr;
+  if (hipMalloc((void**)&scr, (SIM_CONV_MAX + 1) * 8) != hipSuccess) return SIM_ENOMEM;
+  u64 r[SIM_CONV_MAX + 1];
+  hipError_t e = hipMemsetAsync(scr, 0, sizeof r, s);
+  if (e == hipSuccess) {
+    convergence_many_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, h->d_base, cs, scr);
+    e = hipMemcpyAsync(r, scr, sizeof r, hipMemcpyDeviceToHost, s);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(scr);
+  HCHECK(e);
+  *up = r[0];
+  for (u32 i = 0; i < n; ++i) seen[i] = r[1 + i];
   return SIM_OK;
 }
 

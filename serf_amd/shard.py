@@ -193,6 +193,13 @@ class ShardedSim:
         dist.all_reduce(t, group=self.group)
         return int(t[0]), int(t[1])
 
+    def convergence_many(self, rumours):
+        self._drain()
+        seen, up = self.sim.convergence_many(rumours)
+        t = torch.tensor(list(seen) + [up], dtype=torch.int64, device=self.device)
+        dist.all_reduce(t, group=self.group)
+        return [int(x) for x in t[:-1]], int(t[-1])
+
     def query_status(self, query_id):
         self._drain()
         acks, resp, is_open = self.sim.query_status(query_id)   # this shard's responders
