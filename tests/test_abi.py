@@ -30,7 +30,7 @@ def test_hip_library_exports_every_declared_symbol():
     dll = C.CDLL(lib.path)
     for sym in declared_symbols():
         assert hasattr(dll, sym), f"{sym} missing from {lib.path}"
-    assert lib.backend_name() == "hip-gfx950" and lib.abi_version() == 8
+    assert lib.backend_name() == "hip-gfx950" and lib.abi_version() == 9
 
 
 def test_oracle_exports_the_same_interface(oracle):
