@@ -37,7 +37,7 @@ def test_oracle_exports_the_same_interface(oracle):
     dll = C.CDLL(oracle.path)
     for sym in declared_symbols():
         assert hasattr(dll, "o" + sym), f"o{sym} missing from the oracle"
-    assert oracle.backend_name() == "cpu-oracle" and oracle.abi_version() == 8
+    assert oracle.backend_name() == "cpu-oracle" and oracle.abi_version() == 9
 
 
 def test_struct_layouts_match_the_header(tmp_path):
