@@ -1,0 +1,112 @@
+"""SURVEY.md §8f.3 / §8f.4 over the PRODUCT: the reference-format per-node snapshot (serf_amd/snapshot.py <- snapshot.rs),
+the event coalescers (serf_amd/coalesce.py <- coalesce/*.rs) and the codec's message lengths (serf_amd/wire.py <-
+types/*.rs) fed from what the HIP library itself drains and queues — the same scenarios the CPU tests run over the oracle
+(tests/test_snapshot_format.py, tests/test_coalesce.py, tests/test_wire.py, tests/test_byte_budget.py), with the oracle
+run beside the GPU as the checker."""
+import pytest
+
+from serf_amd import _ffi, snapshot as snap, wire
+from serf_amd.coalesce import MemberEventCoalescer, UserEventCoalescer, coalesce_loop
+
+pytestmark = pytest.mark.gpu
+
+
+def both(oracle, hiplib, n, **kw):
+    return _ffi.Sim(hiplib, _ffi.make_config(n, **kw)), _ffi.Sim(oracle, _ffi.make_config(n, **kw))
+
+
+def test_snapshot_of_a_node_simulated_on_the_gpu(oracle, hiplib):
+    # tests/test_snapshot_format.py::test_snapshot_of_a_simulated_node, events drained from the HIP library
+    n, obs = 128, 5
+    g, o = both(oracle, hiplib, n, fanout=3, view_slots=0, probe_interval=2, suspicion_mult=3, suspicion_max_mult=2, leave_delay=4)
+    for s in (g, o):
+        s.watch(obs)
+        s.inject(2, _ffi.OP_CRASH, 40)
+        s.inject(3, _ffi.OP_USER_EVENT, 9, 0xAB, 40)
+        s.inject(5, _ffi.OP_QUERY, 11, 77, _ffi.F_ACK)
+        s.inject(6, _ffi.OP_LEAVE, 60)
+        s.inject(11, _ffi.OP_LEAVE_FINISH, 60)
+        s.inject(16, _ffi.OP_CRASH, 60)
+        s.inject(60, _ffi.OP_JOIN, 60)
+        s.step(160)
+    eg, eo = g.drain_events(), o.drain_events()
+    assert eg == eo and len(eg) >= 5
+    events = [e for e in eg if e[1] == obs]
+    kinds = [e[2] for e in events]
+    assert snap.EV_FAILED in kinds and snap.EV_LEAVE in kinds and snap.EV_JOIN in kinds and snap.EV_USER in kinds and snap.EV_QUERY in kinds
+    sg, so = snap.snapshot_of(g, obs, events), snap.snapshot_of(o, obs, events)
+    assert sg.bytes() == so.bytes(), "the file a node simulated on the GPU would write is the oracle's, byte for byte"
+    r = snap.replay(sg.bytes())
+    st = g.stats(obs)
+    assert r.last_clock == st.member_time - 1
+    assert r.last_event_clock == max(e[4] for e in events if e[2] == snap.EV_USER)
+    assert r.last_query_clock == max(e[4] for e in events if e[2] == snap.EV_QUERY)
+    assert 60 in r.alive_nodes and 40 not in r.alive_nodes
+    status, _ = g.members(obs)
+    assert status[60] == _ffi.STATUS_ALIVE and status[40] == _ffi.STATUS_FAILED
+    c = snap.replay(sg.compact())
+    assert (c.alive_nodes, c.last_clock, c.last_event_clock, c.last_query_clock) == (r.alive_nodes, r.last_clock, r.last_event_clock, r.last_query_clock)
+    # leave (snapshot.rs:562-580): the record is written, the state forgotten, and a replay starts from nothing
+    sg.leave()
+    assert snap.replay(sg.bytes()).alive_nodes == set()
+
+
+def test_coalescers_over_the_gpus_event_stream(oracle, hiplib):
+    # tests/test_coalesce.py::test_coalescing_a_simulated_clusters_member_events + user events with the cc flag
+    g, o = both(oracle, hiplib, 64, fanout=3, probe_interval=5, leave_delay=8)
+    for s in (g, o):
+        s.watch(3)
+        s.inject(1, _ffi.OP_CRASH, 20)
+        s.step(1)
+        s.leave(30)
+        for i, (key, cc) in enumerate([(0x10, True), (0x11, True), (0x10, True), (0x12, False)]):
+            s.inject(40 + 30 * i, _ffi.OP_USER_EVENT, 7 + i, key, wire.user_event_len(1, b"deploy", b"v%d" % i, cc=cc) | (0x80000000 if cc else 0))
+        s.step(400)
+    raw = [e for e in g.drain_events() if e[1] == 3]
+    assert raw == [e for e in o.drain_events() if e[1] == 3]
+    members = [e for e in raw if e[2] in (_ffi.EV_LEAVE, _ffi.EV_FAILED)]
+    assert sorted((e[2], e[3]) for e in members) == [(_ffi.EV_LEAVE, 30), (_ffi.EV_FAILED, 20)]
+    out = coalesce_loop(members, MemberEventCoalescer(), coalesce_period=1000, quiescent_period=1000, end_tick=2000)
+    assert {ty: m for _, _, ty, m in out} == {_ffi.EV_LEAVE: [30], _ffi.EV_FAILED: [20]}
+    users = [e for e in raw if e[2] == _ffi.EV_USER]
+    assert len(users) == 4
+    # coalesce/user.rs: per event NAME only the newest Lamport time survives a window; an event that did not ask to be
+    # coalesced passes straight through.  The simulator's event key stands for (name, payload): key = name here.
+    uc = UserEventCoalescer(name_of=lambda key: key, is_cc=lambda ev: ev[3] != 0x12)
+    out = coalesce_loop(users, uc, coalesce_period=1000, quiescent_period=1000, end_tick=2000)
+    assert [e[3] for e in out if e[3] == 0x12] == [0x12] and out[0][3] == 0x12, "not coalesced: delivered at once"
+    kept = [e for e in out if e[3] != 0x12]
+    assert sorted(e[3] for e in kept) == [0x10, 0x11]
+    assert [e[4] for e in kept if e[3] == 0x10] == [max(e[4] for e in users if e[3] == 0x10)]
+
+
+def test_codec_lengths_ride_the_gpus_queue_and_byte_budget(oracle, hiplib):
+    # tests/test_wire.py::test_user_event_through_the_simulator and tests/test_byte_budget.py on the HIP library: the
+    # host prices the message with the codec, the record carries the length, the packet fills up by BYTES
+    def transmits(sim, node):
+        q = sim.dump(_ffi.ARR_QUEUE).reshape(sim.n, _ffi.Q)[node]
+        return {int(r["key"]): (int(r["meta"]) >> 24) & 63 for r in q if r["meta"] != 0xFFFFFFFF}
+
+    g, o = both(oracle, hiplib, 64, fanout=3, view_slots=8)
+    name, payload = b"deploy", b"v1.2.3" * 20
+    nbytes = wire.user_event_len(1, name, payload, cc=True)
+    big = wire.user_event_len(1, b"deploy", b"x" * 506)       # the largest event the default limit allows: 528 bytes framed
+    for s in (g, o):
+        s.user_event(3, 0xBEEF, nbytes, coalesce=True)
+        for key in (101, 102, 103):
+            s.user_event(0, key, big)
+        s.user_event(0, 104, 16)
+        s.query(5, 77, _ffi.F_ACK)
+        s.step(1)
+    qg = g.dump(_ffi.ARR_QUEUE).reshape(64, _ffi.Q)
+    assert (qg == o.dump(_ffi.ARR_QUEUE).reshape(64, _ffi.Q)).all()
+    meta = int(qg[3]["meta"][0])
+    assert 63 - ((meta >> 18) & 63) == (nbytes + 15) // 16 and (meta >> 4) & 15 == _ffi.K_EVENT and meta & 1
+    qm = int(qg[5]["meta"][0])
+    ref_q = wire.Query(5000, 77, 999999, flags=_ffi.F_ACK, relay_factor=0, timeout_ms=16 * 7 * 200)
+    assert 63 - ((qm >> 18) & 63) == (wire.encoded_len(ref_q) + 15) // 16 == 3
+    # three 528-byte events do not share a 1 400-byte packet: 103 + 102 go, 101 is skipped, 104 still fits ...
+    assert transmits(g, 0) == transmits(o, 0) == {101: 2, 102: 2, 103: 2, 104: 3}
+    g.step(30)
+    o.step(30)
+    assert g.digest() == o.digest()

@@ -354,6 +354,96 @@ def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim, chunks):
     assert tuple(tot) == ref.convergence(_ffi.K_LEAVE, next(o for o in ops if o[1] == _ffi.OP_LEAVE)[2], 1)
 
 
+def test_sharded_kernel_b64_four_shards_of_64k_on_one_gpu(oracle, hiplib):
+    """the SHARDED instantiation of the tick kernel with 64-node blocks, at a shard size near the
+    bench's — 4 handles x 64 Ki nodes on one GPU, 2 sender chunks (2 x 512 blocks per shard and tick: tp.B == 64, the
+    block permutation on the scalar unit, chunk launches, double-buffered receive side), failure detector on, cross-shard
+    push-pull batches, view-slot recycling with the all-shard verdict, packet loss — against the single-process oracle's
+    slices: rows and queues every 25 ticks, views and rings at three checkpoints, for 160 ticks."""
+    import torch
+    from tests.test_recycle import churn_ops
+
+    V, m, chunks, ticks = 4, 1 << 16, 2, 200
+    n = V * m
+    kw = dict(fanout=4, view_slots=48, event_ring=32, query_ring=16, leave_delay=6, probe_interval=5, loss=0.01,
+              suspicion_mult=3, suspicion_max_mult=2, push_pull_interval=2, recycle_interval=40, chunks=chunks)
+    ref = _ffi.Sim(oracle, _ffi.make_config(n, vshards=V, **kw))
+    shards, send, recv = [], [], []
+    for g in range(V):
+        s = _ffi.Sim(hiplib, _ffi.make_config(n, vshards=V, shard_rank=g, shard_count=V, **kw))
+        nb = s.exchange_bytes()
+        send.append(torch.zeros(nb, dtype=torch.uint8, device="cuda"))
+        recv.append([torch.zeros(nb, dtype=torch.uint8, device="cuda") for _ in range(2)])
+        s.bind_exchange2(send[-1].data_ptr(), recv[-1][0].data_ptr(), recv[-1][1].data_ptr())
+        assert s.exchange_chunks() == (chunks, nb // chunks)
+        shards.append(s)
+    # user events, queries and short crash + revive pairs, plus five nodes that stay down for 100 ticks: long enough to be
+    # suspected, confirmed and declared failed (timeout 81 .. 162 ticks here), to refute when they come back, and for their
+    # view slots to be recycled afterwards
+    ops = sc.schedule(n, 160, rate=0.2, seed=11, mix=(0.6, 0.25, 0.0, 0.0, 0.15), max_member_subjects=12) + \
+        churn_ops(n, 5, every=9, down=100, seed=8, start=3)
+    ops.sort(key=lambda o: o[0])
+    for s in shards + [ref]:
+        sc.apply_schedule(s, ops)
+    region = send[0].numel() // chunks
+    slab = region // V
+    n_pp = n_rec = max_failed = 0
+    for t in range(ticks):
+        if shards[0].recycle_due():
+            n_rec += 1
+            scans = np.stack([s.recycle_scan() for s in shards])
+            keep = []
+            for i in range(scans.shape[1]):
+                flags = scans[:, i, 2]
+                if (flags & 1).any() or not (flags & 2).any():
+                    continue
+                refs = scans[(flags & 2) != 0, i, 4:8]
+                if (refs == refs[0]).all():
+                    keep.append(scans[np.nonzero(flags & 2)[0][0], i])
+            for s in shards:
+                s.recycle_apply(np.array(keep, dtype=np.uint32).reshape(-1, 12))
+        for s in shards:
+            s.step_begin()
+        if shards[0].pp_due():
+            n_pp += 1
+            _push_pull_on_one_gpu(shards)
+        for c in range(chunks):
+            for s in shards:
+                s.step_chunk(c)
+            for s in shards:
+                s.sync()
+            for g in range(V):
+                for src in range(V):
+                    recv[g][t & 1][c * region + src * slab:c * region + (src + 1) * slab].copy_(
+                        send[src][c * region + g * slab:c * region + (g + 1) * slab])
+        for s in shards:
+            s.step_end()
+        torch.cuda.synchronize()
+        ref.step(1)
+        if t % 25 == 0 or t == ticks - 1:
+            deep = t in (50, 125, ticks - 1)
+            max_failed = max(max_failed, ref.cluster_stats()["failed"])
+            rrows, rq = ref.dump(_ffi.ARR_ROWS), ref.dump(_ffi.ARR_QUEUE)
+            big = {w: ref.dump(w) for w in (_ffi.ARR_VIEW, _ffi.ARR_ERING, _ffi.ARR_QRING)} if deep else {}
+            for g, s in enumerate(shards):
+                lo = g * m
+                i = sc.first_diff(s.dump(_ffi.ARR_ROWS), rrows[lo:lo + m])
+                assert i is None, f"shard {g} row {i} differs at tick {t}"
+                i = sc.first_diff(s.dump(_ffi.ARR_QUEUE), rq[lo * _ffi.Q:(lo + m) * _ffi.Q])
+                assert i is None, f"shard {g} queue entry {i} differs at tick {t}"
+                for which, rows in ((_ffi.ARR_VIEW, 48), (_ffi.ARR_ERING, 32), (_ffi.ARR_QRING, 16)):
+                    if deep:
+                        a = s.dump(which).reshape(rows, m)
+                        b = np.ascontiguousarray(big[which].reshape(rows, n)[:, lo:lo + m])
+                        assert a.tobytes() == b.tobytes(), f"shard {g} array {which} differs at tick {t}"
+                assert (s.dump(_ffi.ARR_SLOTMAP) == ref.dump(_ffi.ARR_SLOTMAP)).all()
+    cr = ref.cluster_stats()
+    assert n_pp >= 3 and n_rec >= 3 and cr["slots_recycled"] >= 3, (n_pp, n_rec, cr)
+    assert max_failed > n, "suspicion timers fired: the nodes that stayed down were declared failed inside the window"
+    assert sum(s.cluster_stats()["overflow"] for s in shards) == cr["overflow"]
+    assert all(s.cluster_stats()["slots_recycled"] == cr["slots_recycled"] for s in shards)
+
+
 def test_bench_configuration_64k_digests(oracle, hiplib):
     # The benchmark's OWN configuration tuple and schedule (bench.workload: fan-out 4, view_slots 1024, rings 512,
     # probe interval 5, push-pull 150, reaper 75, queue checker 150, evenly spaced operations at the bench rate),

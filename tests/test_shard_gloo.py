@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, n, ticks, swim, chunks, q):
+def _worker(rank, world, port, n, ticks, swim, chunks, q, jitter=0.0):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -24,6 +24,29 @@ def _worker(rank, world, port, n, ticks, swim, chunks, q):
     from tests._oracle import load_oracle
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if jitter:
+        # every collective is issued, and every asynchronous one is waited for, after a random per-rank delay: the ranks
+        # drift apart by whole chunks, which is what four processes sharing one GPU did in the round-2 hang
+        # (profiles/r02_shard_processes_check.txt) — if ShardedSim's bookkeeping (_drain, the double-buffered receive
+        # side, the push-pull and recycling collectives between the chunk exchanges) depended on timing, it shows here
+        import random
+        import time
+        rnd = random.Random(1000 + rank)
+        real = dist.all_to_all_single
+
+        class _Late:
+            def __init__(self, w):
+                self.w = w
+
+            def wait(self):
+                time.sleep(rnd.random() * jitter)
+                return self.w.wait()
+
+        def late(*a, **k):
+            time.sleep(rnd.random() * jitter)
+            w = real(*a, **k)
+            return _Late(w) if k.get("async_op") else w
+        dist.all_to_all_single = late
     try:
         lib = load_oracle()
         kw = dict(fanout=3, view_slots=64, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=0.02,
@@ -64,8 +87,9 @@ def _worker(rank, world, port, n, ticks, swim, chunks, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,chunks,swim", [(2, 1, 0), (2, 1, 4), (2, 2, 4), (4, 2, 4), (4, 4, 0)])
-def test_shards_gloo_match_single_process(world, chunks, swim):
+@pytest.mark.parametrize("world,chunks,swim,n,jitter", [(2, 1, 0, 1024, 0), (2, 1, 4, 1024, 0), (2, 2, 4, 1024, 0), (4, 2, 4, 1024, 0),
+                                                        (4, 4, 0, 1024, 0), (4, 4, 4, 4096, 0.004)])
+def test_shards_gloo_match_single_process(world, chunks, swim, n, jitter):
     # chunks > 1: the tick runs as `chunks` launches, each followed by the asynchronous all-to-all of its slabs
     # (double-buffered receive side) — the overlapped path of serf_amd/shard.py
     import torch.multiprocessing as mp
@@ -73,7 +97,9 @@ def test_shards_gloo_match_single_process(world, chunks, swim):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29600 + (os.getpid() % 300) + swim + 7 * world + chunks
-    procs = [ctx.Process(target=_worker, args=(r, world, port, 1024, 60, swim, chunks, q)) for r in range(world)]
+    # (the last case is the configuration that stalled on one GPU in round 2 — world 4, 4 chunks, SWIM and push-pull
+    # batches, 4 096 nodes — here with CPU tensors and every collective randomly delayed)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, 60, swim, chunks, q, jitter)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
