@@ -881,6 +881,9 @@ static void swim_timers(nctx* c) {
     uint32_t a = row->susp[j];
     if (!a) continue;
     sim_view* e = &s->view[(size_t)(a - 1) * s->Nl + c->l];
+    /* a timer on a slot that was recycled while this process was down (recycling looks at running nodes only, §2.6):
+     * the subject is back at its baseline entry, there is nothing left to time */
+    if (s->subject_of[a - 1] == NOSLOT) { row->susp[j] = 0; continue; }
     if (SIM_VB_SWIM(e->bits) != SIM_SWIM_SUSPECT) { row->susp[j] = 0; continue; }
     uint32_t age = (now - SIM_VB_STAMP(e->bits)) & STAMP_MASK;
     uint32_t T = s->T[SIM_VB_NCONF(e->bits)];

@@ -973,7 +973,9 @@ __device__ static void swim_timer_j(const Ctx& c, Node& n, u32 j, u32& next, Ins
   if (!a) return;
   uint4* p = view_slot_ptr(c, a - 1);
   uint4 e = p[0];
-  if (SIM_VB_SWIM(e.w) != SIM_SWIM_SUSPECT) {
+  // (a slot that was recycled while this process was down: its subject is back at the baseline entry and
+  // subject_of[] says NOSLOT — which must not be used as a subject: slot_of[NOSLOT] is 16 GiB past the table)
+  if (d.subject_of[a - 1] == NOSLOT || SIM_VB_SWIM(e.w) != SIM_SWIM_SUSPECT) {
     sp[j] = 0;
     return;
   }

@@ -492,6 +492,23 @@ def test_view_slot_recycling_parity(oracle, hiplib):
     assert cg["ops_dropped"] == 0 and cg["slots_recycled"] >= 76 and cg["overflow"] == 0 and cg["up"] == n
 
 
+def test_timer_on_a_slot_recycled_while_its_holder_was_down(oracle, hiplib):
+    # tests/test_recycle.py, same name: a node comes back holding a suspicion timer on a view slot that lost its subject
+    # while the node was down — the kernel once used subject_of[slot] = NOSLOT as a subject (a memory fault at scale)
+    from tests.test_recycle import KW, stale_timer_ops
+
+    n = 512
+    g, o = pair(oracle, hiplib, n, **dict(KW, view_slots=8))
+    for s in (g, o):
+        sc.apply_schedule(s, stale_timer_ops())
+    for t in range(130):
+        g.step(1)
+        o.step(1)
+        assert g.digest() == o.digest(), f"digest differs after tick {t}"
+    sc.assert_same_state(g, o, "final")
+    assert g.cluster_stats() == o.cluster_stats()
+
+
 def test_view_slot_recycling_four_shards_on_one_gpu(oracle, hiplib):
     # the sharded form of the pass: every shard scans its own nodes (sim_recycle_scan), the host keeps the candidates
     # all shards agree on, every shard applies the same list (sim_recycle_apply) — against the single-process oracle

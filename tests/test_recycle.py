@@ -145,3 +145,31 @@ def test_sharded_recycling_matches_single_process():
         p.join(240)
     res = sorted(q.get(timeout=5) for _ in procs)
     assert res == [(0, "ok"), (1, "ok")], res
+
+
+def stale_timer_ops(x=100, y=200):
+    """Y goes down and is suspected by everybody; X goes down holding a suspicion timer on Y; Y comes back, refutes, its
+    entry settles and its view slot is recycled; X comes back BEFORE the slot is handed out again: its timer names a slot
+    that has no subject any more."""
+    return [(5, _ffi.OP_CRASH, y, 0, 0), (22, _ffi.OP_CRASH, x, 0, 0), (26, _ffi.OP_REVIVE, y, 0, 0), (90, _ffi.OP_REVIVE, x, 0, 0)]
+
+
+def test_timer_on_a_slot_recycled_while_its_holder_was_down(oracle):
+    # round 3: found by the 4 x 64 Ki sharded GPU test — the HIP path used subject_of[slot] = NOSLOT as a subject
+    # (slot_of[0xFFFFFFFF]); the rule now, in both implementations: such a timer is dropped
+    n, x, y = 512, 100, 200
+    sim = _ffi.Sim(oracle, _ffi.make_config(n, **dict(KW, view_slots=8)))
+    for o in stale_timer_ops(x, y):
+        sim.inject(*o)
+    sim.step(22)
+    rows = sim.dump(_ffi.ARR_ROWS)
+    slot_y = int(sim.dump(_ffi.ARR_SLOTMAP)[y])
+    assert slot_y + 1 in rows["susp"][x], "X holds a timer on Y when it goes down"
+    sim.step(68)
+    assert int(sim.dump(_ffi.ARR_SLOTMAP)[y]) == 0xFFFFFFFF, "Y's slot was recycled while X was down"
+    assert slot_y + 1 in sim.dump(_ffi.ARR_ROWS)["susp"][x], "X is down: nobody touched its timers"
+    sim.step(12)   # X is back (tick 90) and has looked at its timers
+    assert slot_y + 1 not in sim.dump(_ffi.ARR_ROWS)["susp"][x]
+    st, _ = sim.members(x)
+    assert st[y] == _ffi.STATUS_ALIVE, "X sees Y through the baseline entry the recycling pass left"
+    assert sim.cluster_stats()["up"] == n
