@@ -36,6 +36,8 @@ extern "C" {
                              * takes records in drain order while they fit it (delegate.rs:317-384 `limit`, App. B.1
                              * get_broadcasts) — and at most SIM_P of them.  Lengths count in 16-byte units.            */
 #define SIM_PKT_UNITS (SIM_PKT_BYTES / 16u)
+#define SIM_PAGES_MAX 4u        /* pages of SIM_P records in one packet                            */
+#define SIM_PKT_RECORDS_MAX (SIM_P * SIM_PAGES_MAX)
 /* The three capacity bounds of the model.  The product is built with exactly these values; the oracle can ALSO be
  * built with far larger ones (oracle/Makefile: liboracle_unbounded.so) so that a test can show that a bounded run
  * which never hit a bound (overflow == 0) is identical to the run without the bounds
@@ -151,7 +153,8 @@ typedef struct sim_record {
 #define SIM_META_SEQ(m) (1023u - (((m) >> 8) & 0x3FFu))
 #define SIM_META_LEN64(m) (63u - (((m) >> 18) & 0x3Fu))
 
-/* 48-byte gossip packet: SIM_P records in their 12-byte WIRE form, stored field by field.  A record on the wire needs
+/* 48-byte gossip packet PAGE: SIM_P records in their 12-byte WIRE form, stored field by field (a packet is
+ * sim_config.pkt_records / SIM_P of them, records in order, unused positions and pages zero).  A record on the wire needs
  * its key (32 bits), 48 bits of value — a Lamport time or an incarnation; for SUSPECT / DEAD the incarnation (24 bits)
  * and the accuser `from` (24 bits) — and 14 bits of meta (len64, kind, flags: SIM_META_WIRE_MASK squeezed together);
  * class, transmits and queue id never travel.  Packets are half of the tick's HBM traffic: 48 instead
@@ -255,7 +258,11 @@ typedef struct sim_config {
   uint32_t recycle_interval;  /* view-slot recycling pass every this many ticks (0 = never): a subject whose entry
                                * is the same at every running node and that nothing in flight mentions gives its
                                * slot back (SIMSPEC §2.6; reference analogue: erase_node! base.rs:499-518)        */
-  uint32_t reserved1;         /* keeps `seed` 8-byte aligned                                    */
+  uint32_t pkt_records;       /* records a gossip packet can carry: 0 (= 4), 4, 8, 12 or 16 — a packet is up to
+                               * SIM_PAGES_MAX pages of SIM_P records, filled in drain order under the byte budget
+                               * SIM_PKT_BYTES (delegate.rs:317-384; App. B.1 get_broadcasts).  With 4 the record
+                               * budget binds first for small messages; with 16 = SIM_Q a packet can carry the whole
+                               * queue and only the byte budget is left                           */
   uint32_t flags;             /* SIM_CF_*                                                       */
   uint64_t seed;              /* master seed; default 0x5EEDC0DE5E4F0001                        */
 } sim_config;
@@ -397,7 +404,8 @@ int sim_drain_events(sim_handle* h, sim_event* out, uint32_t cap, uint32_t* n);
 int sim_state_digest(sim_handle* h, uint64_t out[8]);
 /* Raw dump of one state array of the local shard (host buffer).  which = enum sim_array.
  * Call with buf == NULL to get the size in *bytes.  SIM_ARR_INBOX is the canonical form of the packets in flight:
- * inbox[k][node] = the packet `node` is about to receive in fan-out slot k ([fanout][local nodes] sim_packet).  An
+ * inbox[k * PG + pg][node] = page pg of the packet `node` is about to receive in fan-out slot k ([fanout * PG][local
+ * nodes] sim_packet, PG = pkt_records / SIM_P pages per packet).  An
  * implementation is free to keep them otherwise — the HIP library keeps one copy of each distinct packet at its SENDER
  * (DESIGN.md sections 2.3, 3) — as long as the dump, the digest and the image are this form. */
 enum sim_array { SIM_ARR_ROWS = 0, SIM_ARR_QUEUE = 1, SIM_ARR_INBOX = 2, SIM_ARR_VIEW = 3,

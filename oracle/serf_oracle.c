@@ -259,11 +259,12 @@ typedef struct sim_opent {
 struct sim_handle {
   sim_config cfg;
   uint32_t N, V, M, Nl, A, Bev, Bq, f, dense, shard0; /* Nl local nodes; shard0 = first global id */
+  uint32_t P, PG, fp; /* records a packet can carry (sim_config.pkt_records), its pages of SIM_P records, fp = f * PG cells per node */
   uint64_t tick;
   tickp prev; /* parameters of the tick that produced the current inbox (sharded reads) */
   sim_row* rows;        /* [Nl]            */
   sim_record* queue;    /* [Nl][Q], sorted */
-  sim_packet* inbox[2]; /* local mode: [f][Nl]; current = tick & 1 */
+  sim_packet* inbox[2]; /* local mode: [f * PG][Nl] pages, cell (k, pg, node) at (k * PG + pg) * Nl + node; current = tick & 1 */
   sim_packet *xsend, *xrecv; /* sharded mode: [C][V][f][sub]; xrecv = rbuf[(tick + 1) & 1] while a tick runs */
   sim_packet* rbuf[2];       /* packets sent during tick t are received into rbuf[t & 1] */
   tickp cur; int in_tick;    /* between step_begin and step_end */
@@ -444,8 +445,8 @@ static void q_push(nctx* c, uint32_t key, uint32_t wmeta, uint64_t val) {
 /* get_broadcasts for one packet (B.1; serf's three queues share what memberlist's own broadcasts leave of `limit`,
  * delegate.rs:328-383 — one running byte budget over the class-ordered pool): walk the entries in drain order
  * (class, then transmit tier, largest first within a tier) and take every one that still fits SIM_PKT_UNITS, at most
- * SIM_P of them — an entry that does not fit is skipped, a smaller one further on may; transmits+1; drop at the
- * retransmit limit; re-insert. */
+ * P = sim_config.pkt_records of them (4 .. 16: a packet is up to 4 pages of SIM_P records) — an entry that does not fit
+ * is skipped, a smaller one further on may; transmits+1; drop at the retransmit limit; re-insert. */
 /* a record into / out of slot i of a packet (include/serf_sim.h: 12-byte wire form) */
 static inline void pk_put(sim_packet* pk, uint32_t i, uint32_t key, uint32_t meta, uint64_t val) {
   uint32_t kind = SIM_META_KIND(meta);
@@ -464,17 +465,17 @@ static inline sim_record pk_get(const sim_packet* pk, uint32_t i) {
   r.val = SIM_WIRE_VAL(SIM_META_KIND(r.meta), v48);
   return r;
 }
-static void queue_emit(sim_row* row, sim_record* q, uint32_t limit, sim_packet* out) {
+static void queue_emit(sim_row* row, sim_record* q, uint32_t limit, uint32_t P, sim_packet* out /* [PG] pages */) {
   (void)row;
-  memset(out, 0, sizeof *out);
+  memset(out, 0, (size_t)((P + SIM_P - 1) / SIM_P) * sizeof *out);
   uint32_t free_u = SIM_PKT_UNITS, cnt = 0;
-  for (uint32_t i = 0; i < SIM_Q && cnt < SIM_P; ++i) {
+  for (uint32_t i = 0; i < SIM_Q && cnt < P; ++i) {
     sim_record* r = &q[i];
     if (r->meta == SIM_META_EMPTY) break;
     uint32_t len = SIM_META_LEN64(r->meta);
     if (len > free_u) continue;
     free_u -= len;
-    pk_put(out, cnt, r->key, r->meta & SIM_META_WIRE_MASK, r->val);
+    pk_put(&out[cnt / SIM_P], cnt % SIM_P, r->key, r->meta & SIM_META_WIRE_MASK, r->val);
     cnt++;
     uint32_t t = SIM_META_TRANSMITS(r->meta) + 1;
     if (t >= limit) rec_clear(r);
@@ -1245,15 +1246,15 @@ static void pp_round(osim* s, const tickp* p) {
 /* =====================================================================================
  * The tick (DESIGN.md SIMSPEC §4)
  * ===================================================================================== */
-static inline const sim_packet* inbox_cell(const osim* s, uint32_t k, uint32_t l) {
-  if (s->cfg.shard_count > 1) { /* sharded: [src shard][k][blk] written by the previous tick */
+static inline const sim_packet* inbox_cell(const osim* s, uint32_t k, uint32_t pg, uint32_t l) {
+  if (s->cfg.shard_count > 1) { /* sharded: [src shard][k * PG + pg][blk] written by the previous tick */
     const tickp* pp = &s->prev;
     uint32_t b = l / pp->blk, sl = (l % pp->blk) / pp->sub;
     uint32_t g = (s->cfg.shard_rank + b + pp->rot[k]) % pp->V;
     uint32_t ch = (sl + pp->C - pp->rho[k]) % pp->C; /* the sender's chunk */
-    return &s->xrecv[xcell(pp, s->f, ch, g, k, l)];
+    return &s->xrecv[xcell(pp, s->fp, ch, g, k * s->PG + pg, l)];
   }
-  return &s->inbox[s->tick & 1][(size_t)k * s->Nl + l];
+  return &s->inbox[s->tick & 1][((size_t)k * s->PG + pg) * s->Nl + l];
 }
 
 static void tick_node(osim* s, const tickp* p, uint32_t l) {
@@ -1262,23 +1263,28 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
   sim_row* row = c.row;
   sim_record* q = &s->queue[(size_t)l * SIM_Q];
   uint32_t g = c.gid / p->M, ll = c.gid % p->M;
-  sim_packet out[SIM_MAX_FANOUT];
+  sim_packet out[SIM_MAX_FANOUT][SIM_PAGES_MAX];
   memset(out, 0, sizeof out);
+  const uint32_t PG = s->PG;
   int up = (row->flags & SIM_RF_UP) != 0;
   if (up) {
     if (row->next_seq > 1023u - 64u) queue_renorm(row, q);
     if (s->tick > 0 && s->rfan) { /* variable in-degree: every packet addressed to this node, (sender, k) order */
-      for (uint32_t i = s->rcsr[l]; i < s->rcsr[l + 1]; ++i) {
-        const sim_packet* pk = &s->inbox[s->tick & 1][s->rsrc[i]];
-        for (uint32_t r = 0; r < SIM_P; ++r)
-          if (pk_kind(pk, r) != SIM_K_EMPTY) { sim_record rec = pk_get(pk, r); dispatch_record(&c, &rec); }
+      for (uint32_t i = s->rcsr[l]; i < s->rcsr[l + 1]; ++i) { /* rsrc: k * Nl + sender */
+        uint32_t k = s->rsrc[i] / s->Nl, snd = s->rsrc[i] % s->Nl;
+        for (uint32_t pg = 0; pg < PG; ++pg) {
+          const sim_packet* pk = &s->inbox[s->tick & 1][((size_t)k * PG + pg) * s->Nl + snd];
+          for (uint32_t r = 0; r < SIM_P; ++r)
+            if (pk_kind(pk, r) != SIM_K_EMPTY) { sim_record rec = pk_get(pk, r); dispatch_record(&c, &rec); }
+        }
       }
     } else if (s->tick > 0) {
-      for (uint32_t k = 0; k < s->f; ++k) {
-        const sim_packet* pk = inbox_cell(s, k, l);
-        for (uint32_t r = 0; r < SIM_P; ++r)
-          if (pk_kind(pk, r) != SIM_K_EMPTY) { sim_record rec = pk_get(pk, r); dispatch_record(&c, &rec); }
-      }
+      for (uint32_t k = 0; k < s->f; ++k)
+        for (uint32_t pg = 0; pg < PG; ++pg) { /* a packet's records in order: page 0 first */
+          const sim_packet* pk = inbox_cell(s, k, pg, l);
+          for (uint32_t r = 0; r < SIM_P; ++r)
+            if (pk_kind(pk, r) != SIM_K_EMPTY) { sim_record rec = pk_get(pk, r); dispatch_record(&c, &rec); }
+        }
     }
     if (s->swim) {
       swim_timers(&c);
@@ -1287,7 +1293,7 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
     reap_run(&c);
     queue_check(&c);
     uint32_t limit = s->cfg.retransmit_mult * digits10(row->n_known); /* B.1, serf.rs:123-131 */
-    for (uint32_t k = 0; k < p->feff; ++k) queue_emit(row, q, limit, &out[k]);
+    for (uint32_t k = 0; k < p->feff; ++k) queue_emit(row, q, limit, s->P, out[k]);
   }
   if (s->rfan) { /* kRandomNodes (App. B.2): uniform draws, skip self and duplicates, up to 3n tries */
     uint64_t rb = rng_base(s->cfg.seed, STREAM_RFAN, s->tick);
@@ -1300,8 +1306,8 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
     }
     for (uint32_t k = 0; k < p->feff; ++k) {
       size_t cell = (size_t)k * s->Nl + l;
-      if (k >= nc || (up && pkt_lost(p, c.gid, k))) memset(&out[k], 0, sizeof out[k]);
-      s->inbox[(s->tick + 1) & 1][cell] = out[k];
+      if (k >= nc || (up && pkt_lost(p, c.gid, k))) memset(out[k], 0, sizeof out[k]);
+      for (uint32_t pg = 0; pg < PG; ++pg) s->inbox[(s->tick + 1) & 1][((size_t)k * PG + pg) * s->Nl + l] = out[k][pg];
       s->rtgt[cell] = k < nc ? chosen[k] : NOSLOT;
     }
     return;
@@ -1310,11 +1316,13 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
   for (uint32_t k = 0; k < p->feff; ++k) {
     uint32_t h, lp;
     fan_target(p, g, ll, k, &h, &lp);
-    if (up && pkt_lost(p, c.gid, k)) memset(&out[k], 0, sizeof out[k]);
-    if (s->cfg.shard_count > 1)
-      s->xsend[xcell(p, s->f, (ll % p->blk) / p->sub, h, k, lp)] = out[k];
-    else
-      s->inbox[(s->tick + 1) & 1][(size_t)k * s->Nl + (size_t)h * p->M + lp] = out[k];
+    if (up && pkt_lost(p, c.gid, k)) memset(out[k], 0, sizeof out[k]);
+    for (uint32_t pg = 0; pg < PG; ++pg) {
+      if (s->cfg.shard_count > 1)
+        s->xsend[xcell(p, s->fp, (ll % p->blk) / p->sub, h, k * PG + pg, lp)] = out[k][pg];
+      else
+        s->inbox[(s->tick + 1) & 1][((size_t)k * PG + pg) * s->Nl + (size_t)h * p->M + lp] = out[k][pg];
+    }
   }
 }
 
@@ -1438,6 +1446,7 @@ static int cfg_check(const sim_config* c) {
   if (c->fanout < 1 || c->fanout > SIM_MAX_FANOUT) return SIM_EINVAL;
   if (c->chunks > 1 && ((M / c->vshards) % c->chunks || (M / c->vshards) / c->chunks < 1)) return SIM_EINVAL;
   if (c->event_ring < 1 || c->query_ring < 1) return SIM_EINVAL;
+  if (c->pkt_records && (c->pkt_records % SIM_P || c->pkt_records > SIM_PKT_RECORDS_MAX)) return SIM_EINVAL;
   if (c->retransmit_mult * digits10(c->n_nodes) > 63u) return SIM_EINVAL;
   if (c->n_nodes > (1u << 24)) return SIM_EINVAL; /* SUSPECT / DEAD carry the accuser's id in 24 bits on the wire (sim_packet) */
   if (c->probe_interval) { /* suspicion timers name view slots with 16 bits */
@@ -1469,18 +1478,21 @@ int API(create)(const sim_config* cfg, osim** out) {
   s->dense = (cfg->view_slots == 0 || cfg->view_slots >= s->N);
   s->A = s->dense ? s->N : cfg->view_slots;
   s->Bev = cfg->event_ring; s->Bq = cfg->query_ring; s->f = cfg->fanout;
+  s->P = cfg->pkt_records ? cfg->pkt_records : SIM_P;
+  s->PG = s->P / SIM_P;
+  s->fp = s->f * s->PG;
   size_t Nl = s->Nl;
   s->rows = (sim_row*)calloc(Nl, sizeof(sim_row));
   s->queue = (sim_record*)malloc(Nl * SIM_Q * sizeof(sim_record));
   if (cfg->shard_count > 1) {
-    size_t cells = (size_t)s->f * s->M;
+    size_t cells = (size_t)s->fp * s->M;
     s->xsend = (sim_packet*)calloc(cells, sizeof(sim_packet));
     s->xrecv = (sim_packet*)calloc(cells, sizeof(sim_packet));
     s->rbuf[0] = s->rbuf[1] = s->xrecv;
     s->own_x = 1;
   } else {
-    s->inbox[0] = (sim_packet*)calloc((size_t)s->f * Nl, sizeof(sim_packet));
-    s->inbox[1] = (sim_packet*)calloc((size_t)s->f * Nl, sizeof(sim_packet));
+    s->inbox[0] = (sim_packet*)calloc((size_t)s->fp * Nl, sizeof(sim_packet));
+    s->inbox[1] = (sim_packet*)calloc((size_t)s->fp * Nl, sizeof(sim_packet));
   }
   s->view = (sim_view*)calloc((size_t)s->A * Nl, sizeof(sim_view));
   s->ering = (sim_bucket*)calloc((size_t)s->Bev * Nl, sizeof(sim_bucket));
@@ -1635,7 +1647,7 @@ static void recycle_scan(osim* s, rc_cand* c, uint32_t n) {
       if (row->susp[j] && s->subject_of[row->susp[j] - 1] != NOSLOT) refd[s->subject_of[row->susp[j] - 1]] = 1;
   }
   if (in)
-    for (size_t i = 0; i < (size_t)s->f * s->Nl; ++i)
+    for (size_t i = 0; i < (size_t)s->fp * s->Nl; ++i)
       for (uint32_t p = 0; p < SIM_P; ++p) {
         uint32_t kind = pk_kind(&in[i], p);
         if ((kind == SIM_K_JOIN || kind == SIM_K_LEAVE || kind >= SIM_K_ALIVE) && in[i].key[p] < s->N) refd[in[i].key[p]] = 1;
@@ -1857,7 +1869,7 @@ int API(state_digest)(osim* s, uint64_t out[8]) {
   memset(out, 0, 8 * sizeof(uint64_t));
   out[0] = dig_words(s->rows, (size_t)s->Nl * sizeof(sim_row) / 8);
   out[1] = dig_words(s->queue, (size_t)s->Nl * SIM_Q * 2);
-  out[2] = dig_words(cur_inbox(s), (size_t)s->f * s->Nl * (sizeof(sim_packet) / 8));
+  out[2] = dig_words(cur_inbox(s), (size_t)s->fp * s->Nl * (sizeof(sim_packet) / 8));
   out[3] = dig_words(s->view, (size_t)s->A * s->Nl * 4);
   out[4] = dig_words(s->ering, (size_t)s->Bev * s->Nl * 4);
   out[5] = dig_words(s->qring, (size_t)s->Bq * s->Nl * 4);
@@ -1894,7 +1906,7 @@ int API(dump_state)(osim* s, uint32_t which, void* buf, size_t cap, size_t* byte
   switch (which) {
     case SIM_ARR_ROWS: src = s->rows; n = (size_t)s->Nl * sizeof(sim_row); break;
     case SIM_ARR_QUEUE: src = s->queue; n = (size_t)s->Nl * SIM_Q * sizeof(sim_record); break;
-    case SIM_ARR_INBOX: src = cur_inbox(s); n = (size_t)s->f * s->Nl * sizeof(sim_packet); break;
+    case SIM_ARR_INBOX: src = cur_inbox(s); n = (size_t)s->fp * s->Nl * sizeof(sim_packet); break;
     case SIM_ARR_VIEW: src = s->view; n = (size_t)s->A * s->Nl * sizeof(sim_view); break;
     case SIM_ARR_ERING: src = s->ering; n = (size_t)s->Bev * s->Nl * sizeof(sim_bucket); break;
     case SIM_ARR_QRING: src = s->qring; n = (size_t)s->Bq * s->Nl * sizeof(sim_bucket); break;
@@ -1929,7 +1941,7 @@ static void snap_sections(osim* s, const void* ptr[SNAP_SECTIONS], size_t len[SN
                                   s->base, s->upmap, s->qtab, s->qbits, s->ops + s->op_cursor, s->alloc_tick,
                                   s->qfilt, s->tagclass};
   size_t n[SNAP_SECTIONS] = {(size_t)s->Nl * sizeof(sim_row), (size_t)s->Nl * SIM_Q * sizeof(sim_record),
-                             (size_t)s->f * s->Nl * sizeof(sim_packet), (size_t)s->A * s->Nl * sizeof(sim_view),
+                             (size_t)s->fp * s->Nl * sizeof(sim_packet), (size_t)s->A * s->Nl * sizeof(sim_view),
                              (size_t)s->Bev * s->Nl * sizeof(sim_bucket), (size_t)s->Bq * s->Nl * sizeof(sim_bucket),
                              (size_t)s->N * 4, (size_t)s->A * 4, (size_t)s->N * sizeof(sim_view), nup * 4,
                              sizeof s->qtab, (size_t)SIM_QT * 2 * nup * 4, (s->n_ops - s->op_cursor) * sizeof(sim_opent),
@@ -2081,7 +2093,7 @@ int API(cluster_stats_get)(osim* s, sim_cluster_stats* o) {
   }
   const sim_packet* in = cur_inbox(s);
   if (in)
-    for (size_t i = 0; i < (size_t)s->f * s->Nl; ++i)
+    for (size_t i = 0; i < (size_t)s->fp * s->Nl; ++i)
       for (uint32_t p = 0; p < SIM_P; ++p) o->inbox_records += pk_kind(&in[i], p) != SIM_K_EMPTY;
   o->ops_dropped = s->ops_dropped; o->slots_in_use = s->n_alloc; o->slots_recycled = s->slots_recycled;
   o->events_lost = 0; /* the log grows (emit_event) */
@@ -2089,7 +2101,7 @@ int API(cluster_stats_get)(osim* s, sim_cluster_stats* o) {
 }
 int API(exchange_bytes)(const osim* s, size_t* bytes) {
   if (!s || !bytes) return SIM_EINVAL;
-  *bytes = s->cfg.shard_count > 1 ? (size_t)s->f * s->M * sizeof(sim_packet) : 0;
+  *bytes = s->cfg.shard_count > 1 ? (size_t)s->fp * s->M * sizeof(sim_packet) : 0;
   return SIM_OK;
 }
 int API(bind_exchange2)(osim* s, void* send, void* recv0, void* recv1) {
@@ -2099,9 +2111,9 @@ int API(bind_exchange2)(osim* s, void* send, void* recv0, void* recv1) {
   s->rbuf[0] = (sim_packet*)recv0;
   s->rbuf[1] = (sim_packet*)recv1;
   s->xrecv = s->rbuf[(s->tick + 1) & 1];
-  memset(send, 0, (size_t)s->f * s->M * sizeof(sim_packet));
-  memset(recv0, 0, (size_t)s->f * s->M * sizeof(sim_packet));
-  memset(recv1, 0, (size_t)s->f * s->M * sizeof(sim_packet));
+  memset(send, 0, (size_t)s->fp * s->M * sizeof(sim_packet));
+  memset(recv0, 0, (size_t)s->fp * s->M * sizeof(sim_packet));
+  memset(recv1, 0, (size_t)s->fp * s->M * sizeof(sim_packet));
   return SIM_OK;
 }
 int API(bind_exchange)(osim* s, void* send, void* recv) { return API(bind_exchange2)(s, send, recv, recv); }
@@ -2109,7 +2121,7 @@ int API(exchange_chunks)(const osim* s, uint32_t* chunks, size_t* bytes_per_chun
   if (!s || !chunks || !bytes_per_chunk) return SIM_EINVAL;
   uint32_t C = s->cfg.chunks ? s->cfg.chunks : 1;
   *chunks = s->cfg.shard_count > 1 ? C : 1;
-  *bytes_per_chunk = s->cfg.shard_count > 1 ? (size_t)s->f * s->M * sizeof(sim_packet) / C : 0;
+  *bytes_per_chunk = s->cfg.shard_count > 1 ? (size_t)s->fp * s->M * sizeof(sim_packet) / C : 0;
   return SIM_OK;
 }
 /* ---- cross-shard push-pull, driven by the sharded host (include/serf_sim.h) ---- */

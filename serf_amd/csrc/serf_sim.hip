@@ -53,9 +53,7 @@ typedef uint64_t u64;
 #endif
 #define KEMPTY 0xFFFFFFFFu  // empty sort key
 // broadcasts one node can park in one tick: every received record can ask for one rebroadcast,
-// every suspicion timer can fire (dead) and the probe can fail (suspect)
-#define SIM_PEND (SIM_MAX_FANOUT * SIM_P + SIM_S + 1u)
-static_assert(SIM_PEND == 25u, "pend rows are sized for fan-out 4 x 4 records + 8 timers + 1 probe");
+// every suspicion timer can fire (dead) and the probe can fail (suspect): Dev::npend = fanout * pkt_records + SIM_S + 1
 
 // ------------------------------------------------------------------------------------------------
 // hashing / permutation (same arithmetic as the spec; host and device)
@@ -261,13 +259,13 @@ struct Dev {
   uint4* R5;  // {event_min.lo, event_min.hi, query_min.lo, query_min.hi} (read when SIM_RF_MINTIME)
   uint4* qkeys;  // [4][Nl]  the 16 sort keys of a node's queue, ascending, 4 per uint4
   uint4* qpay;   // [Q][Nl]  slot-stable wire records {key, wire meta, val.lo, val.hi}
-  uint4* pend;   // [SIM_PEND][Nl] broadcasts requested by the handlers of the running tick, arrival order
+  uint4* pend;   // [npend][Nl] broadcasts requested by the handlers of the running tick, arrival order
   // Local mode: what a node sent, kept at the SENDER (SIMSPEC §2.3 read from the other end).  A node's f packets of one
   // tick are nearly always the same packet (a queue of at most SIM_P entries sends the same records f times), so it
   // writes each DISTINCT packet once — obox[j][sender], 3 x uint4: keys, value low words, value high bits + meta — and
   // one word omap[sender] = for every fan-out slot the index j of the cell that holds its packet (0xFF: nothing sent
   // or lost).  The receiver of slot k looks up its sender (the inverse of the map) and fetches the cell.
-  uint4* obox[2];        // [f][Nl] cells, double buffered by tick parity
+  uint4* obox[2];        // [f * PG][Nl] cells (pages), double buffered by tick parity
   u32* omap[2];          // [Nl]
   uint4 *xsend, *xrecv;  // sharded mode: [V][f][blk] packets
   // Entries are split into two planes of 16 bytes per (row, node): the HEAD the hot path checks every record against
@@ -289,6 +287,8 @@ struct Dev {
   u32* ev_count;
   u32 ev_cap;
   u32 N, Nl, M, V, A, Bev, Bq, f, shard0, shard_rank, sharded, retransmit_mult;
+  u32 P, PG, fp;  // records a packet can carry (sim_config.pkt_records), its pages of SIM_P records, fp = f * PG cells per node
+  u32 npend;      // rows of `pend`: f * P + SIM_S + 1
   u32 bev_mask, bq_mask;  // B - 1 when B is a power of two (> 1), else 0
   u32 swim, PI, kconf, ic, T[SIM_MAX_CONF];
   u32 loss_u32;
@@ -525,6 +525,29 @@ __device__ static inline u32 q_round(Node& n, SK sk, u32 limit) {
   return slots;
 }
 
+// get_broadcasts for a packet of up to P records (P <= SIM_Q: sim_config.pkt_records > SIM_P): the same walk without
+// the four-record shortcut.  The payload slots of the taken entries come back as nibbles, in drain order.
+__device__ static inline void q_round_mp(Node& n, SK sk, u32 limit, u32 P, u64& nib, u32& cnt) {
+  u32 free_u = SIM_PKT_UNITS, c = 0;
+  u64 nb = 0;
+#pragma unroll
+  for (int i = 0; i < (int)SIM_Q; ++i) {
+    u32 k = sk[i], len = 63u - ((k >> 14) & 63u);
+    bool take = (k != KEMPTY) & (c < P) & (len <= free_u);
+    bool drop = ((k >> 20) & 63u) + 1u >= limit;
+    if (take) {
+      free_u -= len;
+      nb |= (u64)(k & 15u) << (4u * c);
+      c++;
+      if (drop) { n.used &= ~(1u << (k & 15u)); n.dirty |= DR2; }
+      sk[i] = drop ? KEMPTY : k + (1u << 20);
+    }
+  }
+  sort16(sk);
+  nib = nb;
+  cnt = c;
+}
+
 // rare: renumber the queue ids when the 10-bit id space is nearly used up (order-preserving)
 __device__ static void q_renorm(Node& n, SK sk) {
   u32 o[SIM_Q], cnt = 0;
@@ -546,7 +569,7 @@ __device__ static void q_renorm(Node& n, SK sk) {
 // Park a broadcast request; phase 2 of the tick queues them in this order (queue_broadcast order
 // is arrival order, and no handler looks at the queue, so deferring is exact).
 __device__ static inline void pend_push(const Ctx& c, Node& n, const Ins& q) {
-  if (n.npend >= SIM_PEND) { n.overflow++; n.dirty |= DR2; return; }  // cannot happen (SIM_PEND is the per-tick maximum); never write past the array
+  if (n.npend >= c.d.npend) { n.overflow++; n.dirty |= DR2; return; }  // cannot happen (npend is the per-tick maximum); never write past the array
   c.d.pend[(size_t)n.npend * c.d.Nl + c.l] = make_uint4(q.key, q.wmeta, (u32)q.val, (u32)(q.val >> 32));
   n.npend++;
 }
@@ -1203,7 +1226,9 @@ __device__ static inline void wire_pack(const uint4& r, u32& key, u32& lo, u32& 
 }
 __device__ static inline u32 pk_word(const uint4& v, u32 p) { return p == 0 ? v.x : p == 1 ? v.y : p == 2 ? v.z : v.w; }
 // (B64: local mode with 64-node blocks — the sharded instantiations read tp.B at run time and pass false)
-template <bool SHARDED, int F, bool B64>
+// (MP: packets of more than one page, sim_config.pkt_records > SIM_P: the deliver loop walks the pages of a packet, the
+//  drain takes up to d.P entries per packet; with MP = false all of that folds back to the one-page kernel)
+template <bool SHARDED, int F, bool B64, bool MP>
 __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, TickP ptp, u32 cur, const uint4* base, u32 chunk, u32 cnt) {
 #ifdef TICK_TIMING
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1276,17 +1301,29 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
     u32 gs = (g + (rbb + PICK4(ptp.rot, k)) % tp.V) % tp.V;
     return gs * tp.M + bb0 * tp.blk + s0 * tp.sub + r0;
   };
-  u32 jw = 0xFFFFFFFFu;  // local mode: byte k = which of its cells the sender of slot k put that packet in
-  // cell of fan-out slot k (sharded: the block of the receive buffer the source shard filled)
-  auto cell_of = [&](u32 k) __attribute__((always_inline)) -> const uint4* {
-    if (SHARDED) {  // [sender chunk][source shard][slot][sub] (oracle xcell)
+  // local mode: byte k = where the sender of slot k put that packet: first page << 2 | pages - 1 (0xFF: nothing sent)
+  u32 jw = 0xFFFFFFFFu;
+  // page pg of the packet of fan-out slot k (sharded: the block of the receive buffer the source shard filled)
+  auto cell_of = [&](u32 k, u32 pg) __attribute__((always_inline)) -> const uint4* {
+    if (SHARDED) {  // [sender chunk][source shard][slot * PG + page][sub] (oracle xcell)
       u32 b = l / tp.blk, w = l - b * tp.blk, sl = w / tp.sub;
       u32 src = (d.shard_rank + b + tp.prot[k]) % tp.V;
       u32 ch = (sl + tp.C - tp.prho[k]) % tp.C;
-      return d.xrecv + ((((size_t)ch * tp.V + src) * d.f + k) * tp.sub + (w - sl * tp.sub)) * PK_U4;
+      return d.xrecv + ((((size_t)ch * tp.V + src) * d.fp + (MP ? k * d.PG + pg : k)) * tp.sub + (w - sl * tp.sub)) * PK_U4;
     }
     u32 jb = (jw >> (8u * k)) & 0xFFu;
-    return jb == 0xFFu ? d.nullcell : d.obox[cur] + ((size_t)jb * d.Nl + src_of(k)) * PK_U4;
+    bool none = jb == 0xFFu || (MP && pg > (jb & 3u));
+    return none ? d.nullcell : d.obox[cur] + ((size_t)((jb >> 2) + (MP ? pg : 0u)) * d.Nl + src_of(k)) * PK_U4;
+  };
+  // pages the wave walks for slot k: the most any of its lanes received (a lane with fewer reads the zero cell)
+  auto wave_np = [&](u32 k) __attribute__((always_inline)) -> u32 {
+    if (!MP) return 1u;
+    if (SHARDED) return d.PG;
+    u32 jb = (jw >> (8u * k)) & 0xFFu, np = jb == 0xFFu ? 0u : (jb & 3u) + 1u, w = 1u;
+    if (__any(np >= 2u)) w = 2u;
+    if (__any(np >= 3u)) w = 3u;
+    if (__any(np >= 4u)) w = 4u;
+    return w;
   };
   // The first packet is requested together with the node's row (it does not depend on it: a node that turns out to be
   // down has loaded 48 bytes for nothing), every further one a packet ahead: keys, low words, high words.  Local mode:
@@ -1294,7 +1331,7 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
   // requested before the map word is known and dropped if the word says "nothing sent".
   const uint4* cell;
   u32 om0 = 0xFFFFFFFFu, om1 = 0xFFFFFFFFu, om2 = 0xFFFFFFFFu, om3 = 0xFFFFFFFFu;
-  if (SHARDED) cell = tp.first ? d.nullcell : cell_of(0);
+  if (SHARDED) cell = tp.first ? d.nullcell : cell_of(0, 0);
   else {
     // (the four senders first, then the four loads back to back from selected addresses: a load inside a branch gets
     // its own s_waitcnt — four round trips before the row was even asked for)
@@ -1319,8 +1356,14 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
   // ---- phase 1: deliver.  The queue is not touched: handlers park their broadcasts in d.pend.
   if (up && !ABL(2)) {
     if (!SHARDED || !tp.first) {
-      for (u32 k = 0; k < d.f; ++k) {
-        u32 slow;  // records of this packet that need a handler
+      // the pages of the f packets, in order: packet k's page 0, 1, ... then packet k + 1 (one page each unless MP)
+      u32 k = 0, pg = 0, wnp = wave_np(0);
+      while (k < d.f) {
+        if (MP) {
+          if (++pg >= wnp) { ++k; pg = 0; if (k < d.f) wnp = wave_np(k); }
+        } else ++k;
+        // from here on (k, pg) is the page AFTER the one being delivered (whose three words are in rn, rn1, rn2)
+        u32 slow;  // records of this page that need a handler
         // ---- stage the packet in LDS (one 16-byte column per record and lane: conflict-free) ----
         // phase A: the four records, then their four independent lookups — slot map for member
         // records, then the 16-byte head of the view entry / ring bucket each record is checked
@@ -1334,7 +1377,7 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
           // on top; issued behind the slot-map loads it travels together with the head loads.
           // (its address is worked out up here: what that needs may come back from scratch, and a scratch reload
           // between two loads makes the second wait for the first)
-          cell = k + 1 < d.f ? cell_of(k + 1) : d.nullcell;
+          cell = k < d.f ? cell_of(k, pg) : d.nullcell;
           auto prefetch = [&]() __attribute__((always_inline)) { rn = ld4(cell); rn1 = ld4(cell + 1); rn2 = ld4(cell + 2); };
           TT(1);
           // wave-ballot early out: nobody in this wave received anything in packet k (an empty record is all zero)
@@ -1452,6 +1495,120 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
   }
   TT(7);
   u32 limit = up ? d.retransmit_mult * digits10(n.nknown) : 0;
+  const bool coop = (blockIdx.x + 1u) * TBLOCK <= cnt;  // every lane of the block is here
+  // One 48-byte cell per lane that has one (`wr`), written quad-cooperatively when the whole wave is here:
+  // three lanes of a quad write one whole cell per store instruction (lane i < 3 writes part i of quad-mate
+  // j's packet): the texture addresser sees 48 contiguous bytes per quad and L2 one write per cell instead of
+  // three.  The transpose goes through this wave's columns of lds_r (free in phase 2), XOR-swizzled so that
+  // neither side has bank conflicts.  A lane without a cell to write hands its quad a null address.
+  auto store_cell = [&](uint4* dst, bool wr, const uint4& wk, const uint4& wl, const uint4& wh) __attribute__((always_inline)) {
+    if (coop) {
+      lds_r[0][tid] = wk; lds_r[1][tid ^ 1] = wl; lds_r[2][tid ^ 2] = wh;
+      __builtin_amdgcn_wave_barrier();
+      u32 qi = tid & 3u, qb = tid & ~3u, part = qi < 3u ? qi : 2u;  // the fourth lane of a quad has nothing to write
+      u32 dlo = wr ? (u32)(uintptr_t)dst : 0u, dhi = wr ? (u32)((uintptr_t)dst >> 32) : 0u;
+#define COOP_STORE(j)                                                                              \
+      {                                                                                            \
+        uint4 v = lds_r[part][(qb + j) ^ part];                                                    \
+        u32 lo = (u32)__builtin_amdgcn_mov_dpp((int)dlo, j * 0x55, 0xF, 0xF, true);                \
+        u32 hi = (u32)__builtin_amdgcn_mov_dpp((int)dhi, j * 0x55, 0xF, 0xF, true);                \
+        if (qi < 3u && (lo | hi) != 0u) ((uint4*)(((uintptr_t)hi << 32) | lo))[qi] = v;           \
+      }
+      COOP_STORE(0) COOP_STORE(1) COOP_STORE(2) COOP_STORE(3)
+#undef COOP_STORE
+      __builtin_amdgcn_wave_barrier();
+    } else if (wr) {
+      dst[0] = wk; dst[1] = wl; dst[2] = wh;
+    }
+  };
+  if (MP) {
+    // ---- packets of up to d.P records (pages of SIM_P): drain, then every DISTINCT packet page by page ----
+    u64 nib[F];
+    u32 cn[F];
+#pragma unroll
+    for (int k = 0; k < F; ++k) {
+      nib[k] = 0; cn[k] = 0;
+      if (up && (u32)k < tp.feff) {
+        u64 nb; u32 c;
+        q_round_mp(n, sk, limit, d.P, nb, c);
+        bool lost = tp.loss_u32 && (u32)(mix64(tp.loss_base ^ ((u64)gid * 4u + k)) >> 32) < tp.loss_u32;
+        if (!lost) { nib[k] = nb; cn[k] = c; }
+      }
+    }
+    u32 bb0 = 0, s0 = 0, r0 = ll;
+    if (SHARDED && (tp.V != 1 || tp.C != 1)) {
+      bb0 = ll / tp.blk;
+      u32 w = ll - bb0 * tp.blk;
+      s0 = w / tp.sub;
+      r0 = w - s0 * tp.sub;
+    }
+    const u32 uu = bb0 * tp.sub + r0;
+    u32 fj = uu, fi = 0;
+    if (SHARDED && tp.B == 64u) { fj = (u32)__builtin_amdgcn_readfirstlane((int)(uu >> 6)); fi = uu & 63u; }
+    const u32 pj = (SHARDED && tp.feff) ? pi_f(tp, fj) : 0;
+    u32 jout = 0xFFFFFFFFu, used = 0;  // local mode: the map word, pages handed out so far
+#pragma unroll
+    for (int k = 0; k < F; ++k) {
+      if ((u32)k >= tp.feff) break;
+      const bool has = cn[k] != 0u;  // (nothing queued, or the packet was lost: no cell)
+      const u32 np = (cn[k] + SIM_P - 1u) / SIM_P;
+      u32 first = 0;
+      bool isnew = SHARDED;
+      uint4* dbase;  // page 0 of this packet's cells; page pg is pstride uint4s further on
+      size_t pstride;
+      if (SHARDED) {
+        u32 y = pj + tp.off[k];
+        if (y >= tp.nbc) y -= tp.nbc;
+        u32 j2 = pi_inv(tp, y);
+        u32 u2 = j2;
+        if (tp.B == 64u) u2 = j2 * 64u + (fi ^ fan_scramble(y, (u32)k));
+        u32 bb = 0, r = u2, h = 0;
+        if (tp.V != 1 || tp.C != 1) {
+          bb = u2 / tp.sub;
+          r = u2 - bb * tp.sub;
+          h = (g + tp.V - ((bb + tp.rot[k]) % tp.V)) % tp.V;
+        }
+        dbase = d.xsend + ((((size_t)s0 * tp.V + h) * d.fp + (size_t)k * d.PG) * tp.sub + r) * PK_U4;
+        pstride = (size_t)tp.sub * PK_U4;
+      } else {
+        u32 jenc = 0xFFu;
+        if (has) {
+          isnew = true;
+#pragma unroll
+          for (int q = k - 1; q >= 0; --q)
+            if (cn[q] == cn[k] && nib[q] == nib[k]) { jenc = (jout >> (8 * q)) & 0xFFu; isnew = false; }
+          if (isnew) { first = used; used += np; jenc = (first << 2) | (np - 1u); }
+        }
+        jout = (jout & ~(0xFFu << (8 * k))) | (jenc << (8 * k));
+        dbase = d.obox[cur ^ 1] + ((size_t)first * d.Nl + l) * PK_U4;
+        pstride = (size_t)d.Nl * PK_U4;
+      }
+      u32 wmax = SHARDED ? d.PG : 0u;  // pages the wave writes for this slot (uniform)
+      if (!SHARDED) {
+        if (__any(isnew)) wmax = 1u;
+        if (__any(isnew && np >= 2u)) wmax = 2u;
+        if (__any(isnew && np >= 3u)) wmax = 3u;
+        if (__any(isnew && np >= 4u)) wmax = 4u;
+      }
+#pragma unroll 1
+      for (u32 pgi = 0; pgi < wmax; ++pgi) {
+        const bool wr = SHARDED || (isnew && pgi < np);
+        uint4 pk[SIM_P];
+#pragma unroll
+        for (int p = 0; p < (int)SIM_P; ++p) {
+          u32 idx = 4u * pgi + (u32)p;
+          bool valid = has && isnew && idx < cn[k];
+          u32 sl = (u32)(nib[k] >> (4u * (idx & 15u))) & 15u;
+          pk[p] = ld4(valid ? &d.qpay[(size_t)sl * d.Nl + l] : d.nullcell);
+        }
+        uint4 wk, wl, wh;
+        wire_pack(pk[0], wk.x, wl.x, wh.x); wire_pack(pk[1], wk.y, wl.y, wh.y);
+        wire_pack(pk[2], wk.z, wl.z, wh.z); wire_pack(pk[3], wk.w, wl.w, wh.w);
+        store_cell(dbase + (size_t)pgi * pstride, wr, wk, wl, wh);
+      }
+    }
+    if (!SHARDED) d.omap[cur ^ 1][l] = jout;
+  } else {
   // all F drain rounds first (pure register work on the sort keys) ...
   u32 slots[F];
 #pragma unroll
@@ -1492,7 +1649,6 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
   u32 fj = uu, fi = 0;
   if (SHARDED && tp.B == 64u) { fj = (u32)__builtin_amdgcn_readfirstlane((int)(uu >> 6)); fi = uu & 63u; }
   const u32 pj = (SHARDED && tp.feff) ? pi_f(tp, fj) : 0;
-  const bool coop = (blockIdx.x + 1u) * TBLOCK <= cnt;  // every lane of the block is here
   // local mode: which of this node's cells holds the packet of every slot (0xFF: nothing sent), distinct packets so far
   u32 jout = 0xFFFFFFFFu, ndist = 0;
 #pragma unroll
@@ -1540,10 +1696,10 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
       if (wr) {
 #pragma unroll
         for (int q = k - 1; q >= 0; --q)
-          if (slots[q] == slots[k]) { j = (jout >> (8 * q)) & 0xFFu; wr = false; }
+          if (slots[q] == slots[k]) { j = ((jout >> (8 * q)) & 0xFFu) >> 2; wr = false; }
         if (wr) j = ndist++;
       }
-      jout = (jout & ~(0xFFu << (8 * k))) | (j << (8 * k));
+      jout = (jout & ~(0xFFu << (8 * k))) | ((j == 0xFFu ? 0xFFu : j << 2) << (8 * k));  // first page << 2 | pages - 1
       dst = d.obox[cur ^ 1] + ((size_t)j * d.Nl + l) * PK_U4;
     }
     const bool store = SHARDED || __any(wr);  // (wave-uniform)
@@ -1562,30 +1718,10 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
       }
     }
     if (!store) continue;
-    if (coop) {
-      // Three lanes of a quad write one 48-byte cell per store instruction (lane i < 3 writes part i of quad-mate
-      // j's packet): the texture addresser sees 48 contiguous bytes per quad and L2 one write per cell instead of
-      // three.  The transpose goes through this wave's columns of lds_r (free in phase 2), XOR-swizzled so that
-      // neither side has bank conflicts.  A lane without a cell to write hands its quad a null address.
-      lds_r[0][tid] = wk; lds_r[1][tid ^ 1] = wl; lds_r[2][tid ^ 2] = wh;
-      __builtin_amdgcn_wave_barrier();
-      u32 qi = tid & 3u, qb = tid & ~3u, part = qi < 3u ? qi : 2u;  // the fourth lane of a quad has nothing to write
-      u32 dlo = wr ? (u32)(uintptr_t)dst : 0u, dhi = wr ? (u32)((uintptr_t)dst >> 32) : 0u;
-#define COOP_STORE(j)                                                                              \
-      {                                                                                            \
-        uint4 v = lds_r[part][(qb + j) ^ part];                                                    \
-        u32 lo = (u32)__builtin_amdgcn_mov_dpp((int)dlo, j * 0x55, 0xF, 0xF, true);                \
-        u32 hi = (u32)__builtin_amdgcn_mov_dpp((int)dhi, j * 0x55, 0xF, 0xF, true);                \
-        if (qi < 3u && (SHARDED || (lo | hi) != 0u)) ((uint4*)(((uintptr_t)hi << 32) | lo))[qi] = v; \
-      }
-      COOP_STORE(0) COOP_STORE(1) COOP_STORE(2) COOP_STORE(3)
-#undef COOP_STORE
-      __builtin_amdgcn_wave_barrier();
-    } else if (wr) {
-      dst[0] = wk; dst[1] = wl; dst[2] = wh;
-    }
+    store_cell(dst, wr, wk, wl, wh);
   }
   if (!SHARDED && !ABL(4)) d.omap[cur ^ 1][l] = jout;
+  }
   TT(10);
   if (up && !ABL(16)) {
     node_store(d, l, n);
@@ -2201,7 +2337,7 @@ __global__ void cluster_stats_kernel(Dev d, const uint4* inbox, u64* out) {
     }
     a[5] += r2.w; a[7] += r2.x; a[8] += r2.y;
     if (inbox)
-      for (u32 k = 0; k < d.f; ++k)
+      for (u32 k = 0; k < d.fp; ++k)
         for (u32 p = 0; p < SIM_P; ++p) a[6] += SIM_META_KIND(pk_word(inbox[((size_t)k * d.Nl + l) * PK_U4 + 2], p)) != SIM_K_EMPTY;
   }
   for (int i = 0; i < 9; ++i) block_sum_add(a[i], out + i);
@@ -2220,20 +2356,22 @@ __global__ void recycle_refd_kernel(Dev d, const uint4* inbox, u32 cur, uint8_t*
     if (!inbox && !d.sharded) {
       u32 jw = d.omap[cur][l];
       for (u32 k = 0; k < d.f; ++k) {
-        u32 jb = (jw >> (8u * k)) & 0xFFu;
+        u32 jb = (jw >> (8u * k)) & 0xFFu;  // first page << 2 | pages - 1
         bool again = jb == 0xFFu;
         for (u32 q = 0; q < k; ++q) again |= ((jw >> (8u * q)) & 0xFFu) == jb;
         if (again) continue;
-        const uint4* cellp = d.obox[cur] + ((size_t)jb * d.Nl + l) * PK_U4;
-        uint4 ck = cellp[0], ch = cellp[2];
-        for (u32 p = 0; p < SIM_P; ++p) {
-          u32 key = pk_word(ck, p);
-          if (member_kind(SIM_META_KIND(pk_word(ch, p))) && key < d.N) refd[key] = 1;
+        for (u32 pg = 0; pg <= (jb & 3u); ++pg) {
+          const uint4* cellp = d.obox[cur] + ((size_t)((jb >> 2) + pg) * d.Nl + l) * PK_U4;
+          uint4 ck = cellp[0], ch = cellp[2];
+          for (u32 p = 0; p < SIM_P; ++p) {
+            u32 key = pk_word(ck, p);
+            if (member_kind(SIM_META_KIND(pk_word(ch, p))) && key < d.N) refd[key] = 1;
+          }
         }
       }
     }
     if (inbox)
-      for (u32 k = 0; k < d.f; ++k)
+      for (u32 k = 0; k < d.fp; ++k)
         for (u32 p = 0; p < SIM_P; ++p) {
           const uint4* cellp = inbox + ((size_t)k * d.Nl + l) * PK_U4;
           u32 key = pk_word(cellp[0], p);
@@ -2274,17 +2412,17 @@ __global__ void recycle_view_kernel(Dev d, const u32* cand_slots, const u32* fir
 // Local mode, off the hot path: Dev::obox / omap (packets kept at their senders) <-> the canonical receiver-indexed
 // inbox[k][node].  `p` = the parameters of the tick the packets were sent in; `valid` = 0 at tick 0 (nothing in flight).
 __global__ void materialize_kernel(Dev d, TickP p, u32 cur, u32 valid, uint4* out) {
-  size_t n = (size_t)d.f * d.Nl;
+  size_t n = (size_t)d.fp * d.Nl;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    u32 k = (u32)(i / d.Nl), l = (u32)(i - (size_t)k * d.Nl);
+    u32 kk = (u32)(i / d.Nl), l = (u32)(i - (size_t)kk * d.Nl), k = kk / d.PG, pg = kk - k * d.PG;
     uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a;
     if (valid && k < p.feff) {
       u32 h = l / p.M, t = l - h * p.M, g, ll;
       fan_source_g(p, PICK4(p.off, k), PICK4(p.rot, k), PICK4(p.rho, k), h, t, k, g, ll);
       u32 s = g * p.M + ll;
-      u32 jb = (d.omap[cur][s] >> (8u * k)) & 0xFFu;
-      if (jb != 0xFFu) {
-        const uint4* cp = d.obox[cur] + ((size_t)jb * d.Nl + s) * PK_U4;
+      u32 jb = (d.omap[cur][s] >> (8u * k)) & 0xFFu;  // first page << 2 | pages - 1
+      if (jb != 0xFFu && pg <= (jb & 3u)) {
+        const uint4* cp = d.obox[cur] + ((size_t)((jb >> 2) + pg) * d.Nl + s) * PK_U4;
         a = cp[0]; b = cp[1]; c = cp[2];
       }
     }
@@ -2296,15 +2434,18 @@ __global__ void unmaterialize_kernel(Dev d, TickP p, u32 cur, u32 valid, const u
     u32 jw = 0xFFFFFFFFu;
     if (valid) {
       u32 g = (u32)s / p.M, ll = (u32)s - g * p.M;
-      for (u32 k = 0; k < p.feff; ++k) {
-        u32 h, t;
+      for (u32 k = 0; k < p.feff; ++k) {  // every slot gets its own pages k * PG ...: an image does not say which packets were the same
+        u32 h, t, np = 0;
         fan_target_g(p, g, ll, k, h, t);
-        const uint4* cp = in + ((size_t)k * d.Nl + (size_t)h * p.M + t) * PK_U4;
-        uint4 a = cp[0], b = cp[1], c = cp[2];
-        if (((c.x | c.y | c.z | c.w) & 0xF0u) == 0) continue;  // no record in it
-        uint4* op = d.obox[cur] + ((size_t)k * d.Nl + s) * PK_U4;
-        op[0] = a; op[1] = b; op[2] = c;
-        jw = (jw & ~(0xFFu << (8u * k))) | (k << (8u * k));
+        for (u32 pg = 0; pg < d.PG; ++pg) {
+          const uint4* cp = in + ((size_t)(k * d.PG + pg) * d.Nl + (size_t)h * p.M + t) * PK_U4;
+          uint4 a = cp[0], b = cp[1], c = cp[2];
+          if (((c.x | c.y | c.z | c.w) & 0xF0u) == 0) break;  // no record in it: pages fill up in order
+          uint4* op = d.obox[cur] + ((size_t)(k * d.PG + pg) * d.Nl + s) * PK_U4;
+          op[0] = a; op[1] = b; op[2] = c;
+          np = pg + 1;
+        }
+        if (np) jw = (jw & ~(0xFFu << (8u * k))) | ((((k * d.PG) << 2) | (np - 1u)) << (8u * k));
       }
     }
     d.omap[cur][s] = jw;
@@ -2393,6 +2534,7 @@ static int cfg_check(const sim_config* c) {
   if (c->chunks > 1 && ((M / c->vshards) % c->chunks || (M / c->vshards) / c->chunks < 1)) return SIM_EINVAL;
   if (c->flags & SIM_CF_RANDOM_FANOUT) return SIM_EINVAL;  // oracle-only comparison mode (variable in-degree)
   if (c->event_ring < 1 || c->query_ring < 1) return SIM_EINVAL;
+  if (c->pkt_records && (c->pkt_records % SIM_P || c->pkt_records > SIM_PKT_RECORDS_MAX)) return SIM_EINVAL;
   if (c->retransmit_mult * h_digits10(c->n_nodes) > 63u) return SIM_EINVAL;
   if (c->n_nodes > (1u << 24)) return SIM_EINVAL;  // SUSPECT / DEAD carry the accuser's id in 24 bits on the wire (sim_packet)
   if (c->probe_interval) {  // suspicion timers name view slots with 16 bits
@@ -2497,6 +2639,10 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   h->dense = (cfg->view_slots == 0 || cfg->view_slots >= d.N);
   d.A = h->dense ? d.N : cfg->view_slots;
   d.Bev = cfg->event_ring; d.Bq = cfg->query_ring; d.f = cfg->fanout;
+  d.P = cfg->pkt_records ? cfg->pkt_records : SIM_P;
+  d.PG = d.P / SIM_P;
+  d.fp = d.f * d.PG;
+  d.npend = d.f * d.P + SIM_S + 1u;
   d.vtail = (size_t)d.A * d.Nl; d.etail = (size_t)d.Bev * d.Nl; d.qtail = (size_t)d.Bq * d.Nl;
   d.bev_mask = (d.Bev > 1 && !(d.Bev & (d.Bev - 1))) ? d.Bev - 1 : 0;
   d.bq_mask = (d.Bq > 1 && !(d.Bq & (d.Bq - 1))) ? d.Bq - 1 : 0;
@@ -2527,12 +2673,12 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
     return rc;                                       \
   }
   DA(d.R0, Nl) DA(d.R1, Nl) DA(d.R2, Nl) DA(d.R3, Nl) DA(d.R4, Nl) DA(d.R5, Nl)
-  DA(d.qkeys, 4 * Nl) DA(d.qpay, (size_t)SIM_Q * Nl) DA(d.pend, (size_t)SIM_PEND * Nl)
+  DA(d.qkeys, 4 * Nl) DA(d.qpay, (size_t)SIM_Q * Nl) DA(d.pend, (size_t)d.npend * Nl)
   h->inbox_mat = nullptr;
   h->mat_tick = ~0ull;
   if (!d.sharded) {
-    DA(d.obox[0], (size_t)d.f * Nl * PK_U4) DA(d.obox[1], (size_t)d.f * Nl * PK_U4) DA(d.omap[0], Nl) DA(d.omap[1], Nl)
-    DA(h->inbox_mat, (size_t)d.f * Nl * PK_U4)
+    DA(d.obox[0], (size_t)d.fp * Nl * PK_U4) DA(d.obox[1], (size_t)d.fp * Nl * PK_U4) DA(d.omap[0], Nl) DA(d.omap[1], Nl)
+    DA(h->inbox_mat, (size_t)d.fp * Nl * PK_U4)
   }
   DA(d.view, (size_t)d.A * Nl * 2)
   DA(d.ering, (size_t)d.Bev * Nl * 2)
@@ -2555,7 +2701,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   HCHECK(zero(d.nullcell, 64));
   HCHECK(zero(d.qtab, QTAB_U4(d.N) * 16)); HCHECK(zero(d.qbits, (size_t)SIM_QT * 2 * nup * 4));
   if (!d.sharded) {  // nothing has been sent yet
-    HCHECK(zero(d.obox[0], (size_t)d.f * Nl * sizeof(sim_packet))); HCHECK(zero(d.obox[1], (size_t)d.f * Nl * sizeof(sim_packet)));
+    HCHECK(zero(d.obox[0], (size_t)d.fp * Nl * sizeof(sim_packet))); HCHECK(zero(d.obox[1], (size_t)d.fp * Nl * sizeof(sim_packet)));
     HCHECK(hipMemsetAsync(d.omap[0], 0xFF, Nl * 4, s)); HCHECK(hipMemsetAsync(d.omap[1], 0xFF, Nl * 4, s));
   }
   HCHECK(zero(d.view, (size_t)d.A * Nl * 32));
@@ -3020,12 +3166,13 @@ static int tick_launch(sim_handle* h, u32 chunk) {
     HCHECK(hipEventCreate(&e1));
     h->prof.emplace_back(e0, e1);
   }
-#define LAUNCH_TICK(SH, FF, BB)                                                                                          \
+#define LAUNCH_TICK_(SH, FF, BB, PP)                                                                                     \
   do {                                                                                                                   \
-    if (e0) hipExtLaunchKernelGGL((tick_kernel<SH, FF, BB>), dim3(grid), dim3(TBLOCK), 0, h->stream, e0, e1, 0, d, tp, ptp, cur, \
+    if (e0) hipExtLaunchKernelGGL((tick_kernel<SH, FF, BB, PP>), dim3(grid), dim3(TBLOCK), 0, h->stream, e0, e1, 0, d, tp, ptp, cur, \
                                   (const uint4*)h->d_base, chunk, cnt);                                                  \
-    else tick_kernel<SH, FF, BB><<<grid, TBLOCK, 0, h->stream>>>(d, tp, ptp, cur, h->d_base, chunk, cnt);                \
+    else tick_kernel<SH, FF, BB, PP><<<grid, TBLOCK, 0, h->stream>>>(d, tp, ptp, cur, h->d_base, chunk, cnt);            \
   } while (0)
+#define LAUNCH_TICK(SH, FF, BB) do { if (d.PG > 1u) LAUNCH_TICK_(SH, FF, BB, true); else LAUNCH_TICK_(SH, FF, BB, false); } while (0)
 #define LAUNCH_LOCAL(FF) do { if (tp.B == 64u) LAUNCH_TICK(false, FF, true); else LAUNCH_TICK(false, FF, false); } while (0)
   switch (tp.feff + (d.sharded ? 4u : 0u)) {  // one instantiation per fan-out: the drain loop is fully unrolled
     case 0: case 1: LAUNCH_LOCAL(1); break;
@@ -3039,6 +3186,7 @@ static int tick_launch(sim_handle* h, u32 chunk) {
   }
 #undef LAUNCH_LOCAL
 #undef LAUNCH_TICK
+#undef LAUNCH_TICK_
   HCHECK(hipGetLastError());
   return SIM_OK;
 }
@@ -3152,7 +3300,7 @@ static const uint4* cur_inbox(sim_handle* h) {
     const Dev& d = h->d;
     TickP p;
     tickp_make(&p, &h->cfg, h->tick ? h->tick - 1 : 0);
-    materialize_kernel<<<grid_for((size_t)d.f * d.Nl), BLOCK, 0, h->stream>>>(d, p, (u32)(h->tick & 1), h->tick ? 1u : 0u, h->inbox_mat);
+    materialize_kernel<<<grid_for((size_t)d.fp * d.Nl), BLOCK, 0, h->stream>>>(d, p, (u32)(h->tick & 1), h->tick ? 1u : 0u, h->inbox_mat);
     h->mat_tick = h->tick;
   }
   return h->inbox_mat;
@@ -3164,7 +3312,7 @@ int sim_state_digest(sim_handle* h, uint64_t out[8]) {
   HCHECK(hipMemsetAsync(h->d_scratch, 0, 16 * 8, s));
   digest_rows_queue<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, h->d_scratch + 0, h->d_scratch + 1);
   size_t nw;
-  if (cur_inbox(h)) { nw = (size_t)d.f * d.Nl * (sizeof(sim_packet) / 8); digest_flat<<<grid_for(nw), BLOCK, 0, s>>>((const u64*)cur_inbox(h), nw, h->d_scratch + 2); }
+  if (cur_inbox(h)) { nw = (size_t)d.fp * d.Nl * (sizeof(sim_packet) / 8); digest_flat<<<grid_for(nw), BLOCK, 0, s>>>((const u64*)cur_inbox(h), nw, h->d_scratch + 2); }
   digest_split<<<grid_for(d.vtail), BLOCK, 0, s>>>(d.view, d.vtail, d.vtail, h->d_scratch + 3);
   digest_split<<<grid_for(d.etail), BLOCK, 0, s>>>(d.ering, d.etail, d.etail, h->d_scratch + 4);
   digest_split<<<grid_for(d.qtail), BLOCK, 0, s>>>(d.qring, d.qtail, d.qtail, h->d_scratch + 5);
@@ -3207,7 +3355,7 @@ int sim_dump_state(sim_handle* h, uint32_t which, void* buf, size_t cap, size_t*
   switch (which) {
     case SIM_ARR_ROWS: n = Nl * sizeof(sim_row); break;
     case SIM_ARR_QUEUE: n = Nl * SIM_Q * sizeof(sim_record); break;
-    case SIM_ARR_INBOX: src = cur_inbox(h); n = (size_t)d.f * Nl * sizeof(sim_packet); break;
+    case SIM_ARR_INBOX: src = cur_inbox(h); n = (size_t)d.fp * Nl * sizeof(sim_packet); break;
     case SIM_ARR_VIEW: src = d.view; n = (size_t)d.A * Nl * sizeof(sim_view); break;
     case SIM_ARR_ERING: src = d.ering; n = (size_t)d.Bev * Nl * sizeof(sim_bucket); break;
     case SIM_ARR_QRING: src = d.qring; n = (size_t)d.Bq * Nl * sizeof(sim_bucket); break;
@@ -3299,7 +3447,7 @@ static void snap_lengths(const sim_handle* h, size_t len[SNAP_SECTIONS]) {
   const Dev& d = h->d;
   size_t nup = ((size_t)d.N + 31) / 32;
   size_t n[SNAP_SECTIONS] = {(size_t)d.Nl * sizeof(sim_row), (size_t)d.Nl * SIM_Q * sizeof(sim_record),
-                             (size_t)d.f * d.Nl * sizeof(sim_packet), (size_t)d.A * d.Nl * sizeof(sim_view),
+                             (size_t)d.fp * d.Nl * sizeof(sim_packet), (size_t)d.A * d.Nl * sizeof(sim_view),
                              (size_t)d.Bev * d.Nl * sizeof(sim_bucket), (size_t)d.Bq * d.Nl * sizeof(sim_bucket),
                              (size_t)d.N * 4, (size_t)d.A * 4, (size_t)d.N * sizeof(sim_view), nup * 4,
                              (size_t)SIM_QT * 16, (size_t)SIM_QT * 2 * nup * 4, (h->ops.size() - h->op_cursor) * sizeof(OpEnt),
@@ -3540,7 +3688,7 @@ int sim_cluster_stats_get(sim_handle* h, sim_cluster_stats* out) {
 }
 int sim_exchange_bytes(const sim_handle* h, size_t* bytes) {
   if (!h || !bytes) return SIM_EINVAL;
-  *bytes = h->d.sharded ? (size_t)h->d.f * h->d.M * sizeof(sim_packet) : 0;
+  *bytes = h->d.sharded ? (size_t)h->d.fp * h->d.M * sizeof(sim_packet) : 0;
   return SIM_OK;
 }
 int sim_bind_exchange2(sim_handle* h, void* send, void* recv0, void* recv1) {
@@ -3549,7 +3697,7 @@ int sim_bind_exchange2(sim_handle* h, void* send, void* recv0, void* recv1) {
   h->rbuf[0] = (uint4*)recv0;
   h->rbuf[1] = (uint4*)recv1;
   h->d.xrecv = h->rbuf[(h->tick + 1) & 1];
-  size_t n = (size_t)h->d.f * h->d.M * sizeof(sim_packet);
+  size_t n = (size_t)h->d.fp * h->d.M * sizeof(sim_packet);
   HCHECK(hipMemsetAsync(send, 0, n, h->stream));
   HCHECK(hipMemsetAsync(recv0, 0, n, h->stream));
   if (recv1 != recv0) HCHECK(hipMemsetAsync(recv1, 0, n, h->stream));
@@ -3561,7 +3709,7 @@ int sim_exchange_chunks(const sim_handle* h, uint32_t* chunks, size_t* bytes_per
   if (!h || !chunks || !bytes_per_chunk) return SIM_EINVAL;
   u32 C = h->cfg.chunks ? h->cfg.chunks : 1;
   *chunks = h->d.sharded ? C : 1;
-  *bytes_per_chunk = h->d.sharded ? (size_t)h->d.f * h->d.M * sizeof(sim_packet) / C : 0;
+  *bytes_per_chunk = h->d.sharded ? (size_t)h->d.fp * h->d.M * sizeof(sim_packet) / C : 0;
   return SIM_OK;
 }
 

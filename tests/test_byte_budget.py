@@ -31,3 +31,32 @@ def test_small_records_are_unaffected(oracle):
     t = transmits_by_key(sim, 0)
     # five 3-unit events, four per packet, fewest transmits first: 12 transmits spread 3,3,2,2,2
     assert sorted(t.values()) == [2, 2, 2, 3, 3] and sum(t.values()) == 12
+
+
+def test_paged_packet_fills_up_by_bytes_not_by_records(oracle):
+    # pkt_records = 16: the cell could hold the whole queue, the 1 400-byte budget is what binds — sixteen 96-byte events
+    # (6 units each: 16 x 6 = 96 > 87 units) go out fourteen at a time ("so the byte budget is the
+    # one that binds")
+    sim = _ffi.Sim(oracle, _ffi.make_config(64, fanout=3, view_slots=8, pkt_records=16))
+    for key in range(1, 17):
+        sim.user_event(0, key, 96)
+    sim.step(1)
+    t = transmits_by_key(sim, 0)
+    assert len(t) == 16 and sum(t.values()) == 3 * 14 and set(t.values()) == {2, 3}
+    pk = sim.dump(_ffi.ARR_INBOX).reshape(3, 4, 64)     # [slot][page][node]: what went out, receiver-indexed
+    per_packet = ((pk["hi_meta"] >> 4) & 15 != 0).sum(axis=(1, 3))   # records per (slot, receiver)
+    assert sorted(per_packet[per_packet > 0].tolist()) == [14, 14, 14]
+    # small messages: the whole queue in every packet (16 x 1 unit)
+    sim = _ffi.Sim(oracle, _ffi.make_config(64, fanout=3, view_slots=8, pkt_records=16))
+    for key in range(1, 17):
+        sim.user_event(0, key, 16)
+    sim.step(1)
+    assert set(transmits_by_key(sim, 0).values()) == {3}
+
+
+def test_record_budget_of_a_one_page_packet_still_binds_first(oracle):
+    sim = _ffi.Sim(oracle, _ffi.make_config(64, fanout=3, view_slots=8, pkt_records=4))
+    for key in range(1, 17):
+        sim.user_event(0, key, 16)
+    sim.step(1)
+    assert sum(transmits_by_key(sim, 0).values()) == 3 * 4

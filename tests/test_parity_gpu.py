@@ -109,6 +109,84 @@ def test_random_configurations(oracle, hiplib, seed):
     assert g.cluster_stats()["ops_dropped"] == o.cluster_stats()["ops_dropped"]
 
 
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_configurations_paged_packets(oracle, hiplib, seed):
+    # the same sweep with packets of 8, 12 and 16 records (sim_config.pkt_records: pages of 4 records)
+    # at loads that fill the extra pages — the multi-page instantiation of the tick kernel (page walk on the receiving
+    # side, the general drain + page-by-page cell stores on the sending side, sender-kept pages and the map word's
+    # first-page / page-count encoding), virtual shards and chunks included; a checkpoint in the middle goes through the
+    # canonical paged inbox and back
+    rng = np.random.default_rng(5000 + seed)
+    v = int(rng.choice([1, 1, 2, 4]))
+    c = int(rng.choice([0, 0, 2, 4])) if v > 1 or rng.random() < 0.3 else 0
+    unit = v * v * max(c, 1)
+    n = int(rng.choice([96, 200, 512, 1000, 2048, 4096, 8192]))
+    n = max(unit, n // unit * unit) if (v > 1 or c) else n
+    dense = n <= 600 and rng.random() < 0.4
+    swim = int(rng.choice([0, 2, 3, 5]))
+    kw = dict(fanout=int(rng.integers(1, 5)), vshards=v, chunks=c, view_slots=0 if dense else int(rng.choice([16, 48, 64])),
+              event_ring=int(rng.choice([8, 12, 16, 64])), query_ring=int(rng.choice([8, 10, 32])), leave_delay=int(rng.integers(3, 9)),
+              loss=float(rng.choice([0.0, 0.0, 0.02, 0.1])), probe_interval=swim, reap_interval=int(rng.choice([0, 5, 11])) if swim else 0,
+              reconnect_timeout=20, tombstone_timeout=30, intent_timeout=15,
+              queue_check_interval=int(rng.choice([0, 7])), min_queue_depth=int(rng.choice([0, 2])),
+              push_pull_interval=int(rng.choice([0, 4, 9])), recycle_interval=int(rng.choice([0, 6])) if not dense else 0,
+              pkt_records=int(rng.choice([8, 12, 16])))
+    try:
+        g, o = pair(oracle, hiplib, n, **kw)
+    except _ffi.SimError:
+        pytest.skip(f"configuration rejected by both sides: n={n} {kw}")
+    rate = float(rng.choice([0.8, 2.5, 5.0]))
+    ops = sc.schedule(n, 40, rate=rate, seed=seed, max_member_subjects=12 if not dense else min(n // 2, 30))
+    sc.apply_schedule(g, ops)
+    sc.apply_schedule(o, ops)
+    g2 = o2 = None
+    for t in range(64):
+        g.step(1)
+        o.step(1)
+        if g.digest() != o.digest():
+            sc.assert_same_state(g, o, f"seed {seed} n={n} {kw} tick {t}")
+            raise AssertionError(f"digest differs after tick {t} but the arrays agree")
+        if t == 30 and seed % 3 == 0:
+            gi, oi = g.snapshot(), o.snapshot()
+            assert bytes(gi) == bytes(oi)
+            g2, o2 = pair(oracle, hiplib, n, **kw)
+            g2.restore(oi)
+            o2.restore(gi)
+    sc.assert_same_state(g, o, f"seed {seed} final")
+    if g2 is not None:
+        g2.step(33)
+        o2.step(33)
+        assert g2.digest() == o2.digest() == g.digest()
+    pk = o.dump(_ffi.ARR_INBOX)
+    assert pk.shape[0] == kw["fanout"] * (kw["pkt_records"] // 4) * n
+
+
+def test_paged_packets_carry_the_whole_queue(oracle, hiplib):
+    # what the pages are for: with pkt_records = 16 = SIM_Q a packet carries every queued record (delegate.rs:317-384
+    # fills by bytes: tens of small messages), so a burst of rumours reaches everybody without waiting for a turn in a
+    # 4-record packet — and pages beyond the first really are used
+    n = 4096
+    kw = dict(fanout=4, view_slots=32, event_ring=64, query_ring=16, probe_interval=5)
+    res = {}
+    for P in (4, 16):
+        g, o = pair(oracle, hiplib, n, pkt_records=P, **kw)
+        for s in (g, o):
+            for i in range(12):   # twelve user events from twelve nodes in one tick
+                s.inject(2, _ffi.OP_USER_EVENT, 100 + 7 * i, 500 + i, 40)
+        used = 0
+        for t in range(40):
+            g.step(1)
+            o.step(1)
+            assert g.digest() == o.digest(), f"P={P}: digest differs after tick {t}"
+            if P == 16 and t == 12:
+                pk = g.dump(_ffi.ARR_INBOX).reshape(4, 4, n)   # [slot][page][node]
+                used = int(((pk["hi_meta"][:, 1:, :, :] >> 4) & 15 != 0).sum())
+        seen = [g.convergence(_ffi.K_EVENT, 500 + i, 1)[0] for i in range(12)]
+        res[P] = (sum(x >= n * 99 // 100 for x in seen), g.cluster_stats()["overflow"], used)
+        sc.assert_same_state(g, o, f"P={P} final")
+    assert res[16][0] == 12 and res[16][1] == 0 and res[16][2] > 0, res
+
+
 def test_packet_loss_and_overload(oracle, hiplib):
     # 5 % packet loss and an injection rate above the protocol's capacity => queue overflow paths
     g, o = pair(oracle, hiplib, 512, fanout=3, view_slots=128, event_ring=8, query_ring=8, loss=0.05)
@@ -289,8 +367,8 @@ def _push_pull_on_one_gpu(shards):
             s.sync()
 
 
-@pytest.mark.parametrize("swim,chunks", [(0, 1), (4, 1), (4, 2), (0, 4)])
-def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim, chunks):
+@pytest.mark.parametrize("swim,chunks,pkt", [(0, 1, 0), (4, 1, 0), (4, 2, 0), (0, 4, 0), (4, 2, 8), (0, 1, 16)])
+def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim, chunks, pkt):
     # BASELINE configs[3] shape (G shards by node-id range, the round's all-to-all), scaled down and run as 4 handles
     # on ONE GPU: the exchange of serf_amd/shard.py is done with device-to-device copies (for every sender chunk c:
     # slab g of shard s's send region c -> slab s of shard g's receive region c), which is what the per-chunk
@@ -301,7 +379,7 @@ def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim, chunks):
     n, V, ticks = 2048, 4, 50
     m = n // V
     kw = dict(fanout=4, view_slots=96, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=0.02,
-              push_pull_interval=3 if swim else 0, chunks=chunks if chunks > 1 else 0)
+              push_pull_interval=3 if swim else 0, chunks=chunks if chunks > 1 else 0, pkt_records=pkt)   # pkt: paged packets in the exchange buffers
     ref = _ffi.Sim(oracle, _ffi.make_config(n, vshards=V, **kw))
     shards, send, recv = [], [], []
     for g in range(V):
@@ -312,7 +390,7 @@ def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim, chunks):
         s.bind_exchange2(send[-1].data_ptr(), recv[-1][0].data_ptr(), recv[-1][1].data_ptr())
         assert s.exchange_chunks() == (chunks, nb // chunks)
         shards.append(s)
-    ops = sc.schedule(n, ticks // 2, rate=0.8, seed=5, max_member_subjects=60)
+    ops = sc.schedule(n, ticks // 2, rate=0.8 if not pkt else 3.0, seed=5, max_member_subjects=60)
     for s in shards + [ref]:
         sc.apply_schedule(s, ops)
     region = send[0].numel() // chunks

@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, n, ticks, swim, chunks, q, jitter=0.0):
+def _worker(rank, world, port, n, ticks, swim, chunks, q, jitter=0.0, pkt=0):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -50,10 +50,10 @@ def _worker(rank, world, port, n, ticks, swim, chunks, q, jitter=0.0):
     try:
         lib = load_oracle()
         kw = dict(fanout=3, view_slots=64, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=0.02,
-                  push_pull_interval=4 if swim else 0)
+                  push_pull_interval=4 if swim else 0, pkt_records=pkt)
         sh = ShardedSim(lib, n, torch.device("cpu"), chunks=chunks, **kw)
         ref = _ffi.Sim(lib, _ffi.make_config(n, vshards=world, chunks=chunks if chunks > 1 else 0, **kw))  # all shards in one process
-        ops = sc.schedule(n, ticks // 2, rate=0.7, seed=17, max_member_subjects=40)
+        ops = sc.schedule(n, ticks // 2, rate=0.7 if not pkt else 3.0, seed=17, max_member_subjects=40)
         # query filters and tag classes are replicated tables: every shard applies the same operations
         ops, classes = sc.with_filters(ops, n, tag_changes=6 if swim else 0)
         sh.init_tags(classes)
@@ -87,9 +87,9 @@ def _worker(rank, world, port, n, ticks, swim, chunks, q, jitter=0.0):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,chunks,swim,n,jitter", [(2, 1, 0, 1024, 0), (2, 1, 4, 1024, 0), (2, 2, 4, 1024, 0), (4, 2, 4, 1024, 0),
-                                                        (4, 4, 0, 1024, 0), (4, 4, 4, 4096, 0.004)])
-def test_shards_gloo_match_single_process(world, chunks, swim, n, jitter):
+@pytest.mark.parametrize("world,chunks,swim,n,jitter,pkt", [(2, 1, 0, 1024, 0, 0), (2, 1, 4, 1024, 0, 0), (2, 2, 4, 1024, 0, 0), (4, 2, 4, 1024, 0, 0),
+                                                            (4, 4, 0, 1024, 0, 0), (4, 4, 4, 4096, 0.004, 0), (2, 2, 4, 1024, 0, 16)])
+def test_shards_gloo_match_single_process(world, chunks, swim, n, jitter, pkt):
     # chunks > 1: the tick runs as `chunks` launches, each followed by the asynchronous all-to-all of its slabs
     # (double-buffered receive side) — the overlapped path of serf_amd/shard.py
     import torch.multiprocessing as mp
@@ -99,7 +99,7 @@ def test_shards_gloo_match_single_process(world, chunks, swim, n, jitter):
     port = 29600 + (os.getpid() % 300) + swim + 7 * world + chunks
     # (the last case is the configuration that stalled on one GPU in round 2 — world 4, 4 chunks, SWIM and push-pull
     # batches, 4 096 nodes — here with CPU tensors and every collective randomly delayed)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, 60, swim, chunks, q, jitter)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, 60, swim, chunks, q, jitter, pkt)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
