@@ -171,8 +171,8 @@ def test_paged_packets_carry_the_whole_queue(oracle, hiplib):
     for P in (4, 16):
         g, o = pair(oracle, hiplib, n, pkt_records=P, **kw)
         for s in (g, o):
-            for i in range(12):   # twelve user events from twelve nodes in one tick
-                s.inject(2, _ffi.OP_USER_EVENT, 100 + 7 * i, 500 + i, 40)
+            for i in range(12):   # twelve user events from one node in one tick (Lamport times 1 .. 12)
+                s.inject(2, _ffi.OP_USER_EVENT, 100, 500 + i, 40)
         used = 0
         for t in range(40):
             g.step(1)
@@ -181,10 +181,11 @@ def test_paged_packets_carry_the_whole_queue(oracle, hiplib):
             if P == 16 and t == 12:
                 pk = g.dump(_ffi.ARR_INBOX).reshape(4, 4, n)   # [slot][page][node]
                 used = int(((pk["hi_meta"][:, 1:, :, :] >> 4) & 15 != 0).sum())
-        seen = [g.convergence(_ffi.K_EVENT, 500 + i, 1)[0] for i in range(12)]
+        seen = [g.convergence(_ffi.K_EVENT, 500 + i, 1 + i)[0] for i in range(12)]
         res[P] = (sum(x >= n * 99 // 100 for x in seen), g.cluster_stats()["overflow"], used)
         sc.assert_same_state(g, o, f"P={P} final")
     assert res[16][0] == 12 and res[16][1] == 0 and res[16][2] > 0, res
+    assert res[4][0] <= 12 and res[4][2] == 0
 
 
 def test_packet_loss_and_overload(oracle, hiplib):
