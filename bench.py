@@ -158,6 +158,44 @@ def cpu_baseline(args, parity_tick, seconds_budget=240.0):
                       f"{cores} threads (OpenMP over nodes) and {done1} more on one thread; model_bound_drops {drops}"}, digest
 
 
+def second_load(args, lib, dev, torch):
+    """N = 1 only, after the headline run: the same cluster with packets of 16 records (= SIM_Q: a packet carries the
+    whole queue, only the 1 400-byte budget is left) under the heaviest evenly spaced load that still stays inside the
+    model bounds — measured the same way (pre-roll, warm-up, HIP events around the launches), reported next to the
+    headline ("report both loads")."""
+    import copy
+
+    from serf_amd import _ffi
+
+    a2 = copy.copy(args)
+    a2.pkt_records, a2.rate, a2.warmup, a2.steps = 16, args.second_rate, 20, 100
+    kw, ops = workload(a2, args.nodes_per_gpu)
+    sim = _ffi.Sim(lib, _ffi.make_config(args.nodes_per_gpu, **kw))
+    sim.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    for o in ops:
+        sim.inject(*o)
+    sim.step(a2.preroll + a2.warmup)
+    sim.sync()
+    sim.profile(1)
+    t0 = time.perf_counter()
+    sim.step(a2.steps)
+    sim.sync()
+    dt = time.perf_counter() - t0
+    (ms, mn, mx), cnt = sim.profile_read_stats()
+    sim.profile(0)
+    cs = sim.cluster_stats()
+    out = {"pkt_records": 16, "rate": a2.rate, "steps": a2.steps, "value": args.nodes_per_gpu * a2.steps / dt, "unit": "member-ticks/s",
+           "ms_per_step": dt / a2.steps * 1e3, "kernel_ms": ms / max(1, cnt), "kernel_ms_min": mn, "kernel_ms_max": mx,
+           "model_bound_drops": int(cs["overflow"]) + int(cs["ops_dropped"]),
+           "records_per_packet": round(cs["inbox_records"] / (args.fanout * args.nodes_per_gpu), 3),
+           "queued_per_node": round(sum(cs["queued"]) / args.nodes_per_gpu, 3), "deepest_queue": int(cs["max_queue"]),
+           "what": f"same cluster and mix, {a2.rate} API ops/tick, 16 records per packet (the whole 16-slot queue per packet: the byte budget of "
+                   "1 400 B is the only packet bound left); above this rate the 6-key ring buckets and the 16-slot pooled queue — model "
+                   "bounds, counted — start to drop (DESIGN.md §7)"}
+    sim.close()
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,6 +212,8 @@ def parse_args(argv=None):
     ap.add_argument("--probe-interval", type=int, default=5, help="memberlist probe interval in ticks (0 = SWIM layer off)")
     ap.add_argument("--push-pull-interval", type=int, default=150, help="memberlist push_pull_interval in ticks before log2(N) scaling (0 = off)")
     ap.add_argument("--recycle-interval", type=int, default=75, help="view-slot recycling pass every this many ticks (0 = never)")
+    ap.add_argument("--second-rate", type=float, default=0.4, help="API operations per tick of the second measured load (16 records per packet)")
+    ap.add_argument("--no-second-load", action="store_true", help="skip the second measured load (N = 1: 16 records per packet at --second-rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence", action="store_true", help="skip the rounds-to-99 %% measurement (profiling runs)")
     ap.add_argument("--allow-drops", action="store_true", help="do not fail when the run hit a model bound (overflow > 0)")
@@ -475,6 +515,10 @@ def run(args, lib=None, dev=None, backend="nccl"):
             out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                   "collective_library": ("RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version())
                                                          if on_gpu and backend == "nccl" else backend)}
+        if world == 1 and on_gpu and not args.no_second_load and args.pkt_records == 4:
+            progress("second load")
+            raw.close()  # both clusters do not fit next to each other (66 GB each at 1 Mi nodes)
+            out["second_load"] = second_load(args, lib, dev, torch)
         if world == 1 and not args.no_cpu_baseline:
             progress("cpu_baseline")
             out["cpu_baseline"], cpu_digest = cpu_baseline(args, parity_tick)

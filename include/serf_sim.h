@@ -338,8 +338,11 @@ enum sim_op {
   SIM_OP_QUERY_FILTER_ID = 10,  /* a = query id, b = a node id to add to the query's Filter::Id (`node` is not used);
                                    scheduled BEFORE the SIM_OP_QUERY it belongs to.  A 13th id does not fit: the
                                    operation is dropped and counted in ops_dropped (model bound)                  */
-  SIM_OP_QUERY_FILTER_TAGS = 11 /* a = query id, b = mask of the tag classes one Filter::Tag matches (ANDed into
+  SIM_OP_QUERY_FILTER_TAGS = 11,/* a = query id, b = mask of the tag classes one Filter::Tag matches (ANDed into
                                    the query's mask); BEFORE the SIM_OP_QUERY, like the ids                       */
+  SIM_OP_DELIVER = 12           /* internal (sim_inject_record / sim_deliver_message): `node` receives one record from
+                                   outside the simulated cluster — SerfDelegate::notify_message (delegate.rs:157-315) for
+                                   the serf kinds, memberlist's alive / suspect / dead handling for its own              */
 };
 
 /* ------------------------------------------------------------------ entry points */
@@ -376,6 +379,35 @@ int sim_init_tags(sim_handle* h, uint32_t first, uint32_t count, const uint8_t* 
 /* Churn / packet-loss / kill / revive schedule: run `op` on `node` at the start of tick `tick`
  * (reference analogue: MessageDropper delegate.rs:42-45 and tests that shutdown() a node). */
 int sim_inject(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, uint32_t b);
+
+/* ---- the byte boundary of the delegate: SerfDelegate::notify_message(buf) (delegate.rs:157-163) and
+ * SerfDelegate::broadcast_messages(..) -> Bytes (delegate.rs:317-384) are byte interfaces.  A message is the reference's
+ * own encoding — one type byte, the body length as a varint, the body (types/message.rs:397-428; join.rs:123-158,
+ * leave.rs:138-195, user_event/message.rs:205-272, query.rs:404-527); node ids are decimal strings; the bits of
+ * memberlist-proto's tag bytes are an UPSTREAM-RECALL assumption (serf_amd/wire.py).
+ *
+ * sim_inject_record: at the start of tick `tick`, `node` receives `rec` (key, wire bits of meta, val) as if it had come
+ *   in a packet: the handler runs, a rebroadcast is queued.  A member record whose subject finds no view slot is
+ *   dropped and counted like an operation (ops_dropped).
+ * sim_deliver_message: decode ONE framed serf message (Join, Leave, UserEvent, Query) from buf[0 .. len) and
+ *   sim_inject_record it for the next tick; *consumed (may be NULL) = bytes used, so a caller can walk a packet of several
+ *   messages.  A user event is identified by the 32-bit FNV-1a key of (name, payload) (serf_amd/host/wire.hpp
+ *   event_key) and its content is remembered for sim_peek_packet; QueryFlag bits are mapped (ACK 1 -> SIM_F_ACK,
+ *   NO_BROADCAST 2 -> SIM_F_NO_BROADCAST); Filter::Id lists are installed for the query, a Filter::Tag is refused with
+ *   SIM_EINVAL (tag expressions are evaluated by the host: sim_query_filtered).  SIM_EINVAL for anything malformed.
+ * sim_user_event_bytes: Serf::user_event(name, payload, coalesce) (api.rs:241-299) with the bytes themselves: checks
+ *   name + payload <= 512 (SIM_ETOOBIG), derives key and encoded length with the codec, remembers the content.
+ * sim_peek_packet: the serf messages of the packet `node` sent in fan-out slot k during the LAST tick — what
+ *   broadcast_messages handed memberlist for that packet — encoded back to back, in packet order (memberlist's own
+ *   alive / suspect / dead records, which travel in the same simulated packet, are not serf messages and are left out;
+ *   memberlist's compound framing is memberlist-proto and is not emitted).  A user event whose content the library
+ *   was never told (sim_user_event with a bare key) is encoded with the name "#<key in hex>" and no payload; a query with
+ *   the name "#q" and the tracker's origin and relay factor when it is still running.  buf == NULL returns the size. */
+int sim_inject_record(sim_handle* h, uint64_t tick, uint32_t node, const sim_record* rec);
+int sim_deliver_message(sim_handle* h, uint32_t node, const uint8_t* buf, size_t len, size_t* consumed);
+int sim_user_event_bytes(sim_handle* h, uint32_t node, const uint8_t* name, size_t name_len, const uint8_t* payload,
+                         size_t payload_len, int coalesce);
+int sim_peek_packet(sim_handle* h, uint32_t node, uint32_t k, uint8_t* buf, size_t cap, size_t* len);
 
 /* The hot loop: n_ticks gossip intervals for every node.  Replaces, per node and tick:
  * SerfDelegate::notify_message (delegate.rs:157-315), the handlers it dispatches to

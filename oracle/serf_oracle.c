@@ -254,6 +254,7 @@ static inline int pkt_lost(const tickp* p, uint32_t gid, uint32_t k) {
 typedef struct sim_opent {
   uint64_t tick;
   uint32_t op, node, a, b;
+  uint64_t val; /* SIM_OP_DELIVER: the record's value (a = key, b = wire bits of meta); 0 otherwise */
 } sim_opent;
 
 struct sim_handle {
@@ -316,6 +317,10 @@ struct sim_handle {
   uint32_t* rtgt;  /* [f][Nl] target of the packet in the same cell of the inbox being filled */
   uint32_t* rcsr;  /* [Nl + 1] */
   uint32_t* rsrc;  /* [f * Nl] cell indices (k * Nl + sender), grouped by target */
+  /* content of the user events the library was told in bytes (sim_deliver_message, sim_user_event_bytes): key ->
+   * name, payload — what sim_peek_packet encodes */
+  struct evreg { uint32_t key, nlen, plen; uint8_t* bytes; } *evreg;
+  size_t n_evreg, cap_evreg;
 };
 typedef struct sim_handle osim;
 
@@ -1025,6 +1030,7 @@ static void nctx_init(nctx* c, osim* s, uint32_t l) {
 }
 static int has_alive_members(const osim* s) { return s->N > 1; } /* base.rs:346-359, bulk form */
 
+static void dispatch_record(nctx* c, const sim_record* r);
 static void apply_op(osim* s, const sim_opent* op) {
   /* ground-truth liveness is replicated on every shard (probes read it, B.3) */
   if (op->op == SIM_OP_CRASH) up_set(s, op->node, 0);
@@ -1109,6 +1115,13 @@ static void apply_op(osim* s, const sim_opent* op) {
     }
     case SIM_OP_CRASH: row->flags &= ~SIM_RF_UP; break;
     case SIM_OP_REVIVE: row->flags |= SIM_RF_UP; break;
+    case SIM_OP_DELIVER: /* a record from outside the cluster: notify_message (delegate.rs:157-315) / memberlist's own handling */
+      if (row->flags & SIM_RF_UP) {
+        sim_record r;
+        r.key = op->a; r.meta = op->b; r.val = op->val;
+        dispatch_record(&c, &r);
+      }
+      break;
     default: break;
   }
   (void)q;
@@ -1328,7 +1341,7 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
 
 static int recycle_due(const osim* s);
 static void recycle_local(osim* s);
-static uint32_t op_subject(const osim* s, uint32_t op, uint32_t node, uint32_t a);
+static uint32_t op_subject(const osim* s, uint32_t op, uint32_t node, uint32_t a, uint32_t b);
 static int ensure_slot(osim* s, uint32_t subject);
 static const sim_packet* cur_inbox(const osim* s);
 static void step_begin(osim* s) {
@@ -1354,7 +1367,7 @@ static void step_begin(osim* s) {
       else f[3] |= 1u;
       if (op->op != SIM_OP_QUERY) continue;
     }
-    uint32_t x = op_subject(s, op->op, op->node, op->a);
+    uint32_t x = op_subject(s, op->op, op->node, op->a, op->b);
     if (x != NOSLOT && ensure_slot(s, x) != SIM_OK) s->ops_dropped++; /* no free view slot: the operation does not happen */
     else apply_op(s, op);
   }
@@ -1458,6 +1471,8 @@ static int cfg_check(const sim_config* c) {
 
 int API(destroy)(osim* s) {
   if (!s) return SIM_EINVAL;
+  for (size_t i = 0; i < s->n_evreg; ++i) free(s->evreg[i].bytes);
+  free(s->evreg);
   free(s->rows); free(s->queue); free(s->inbox[0]); free(s->inbox[1]);
   if (s->own_x) { free(s->xsend); free(s->xrecv); }
   free(s->view); free(s->ering); free(s->qring); free(s->slot_of); free(s->subject_of); free(s->walk); free(s->alloc_tick); free(s->pp_local_a); free(s->pp_local_b); free(s->pp_r1); free(s->pp_s1); free(s->rtgt); free(s->rcsr); free(s->rsrc);
@@ -1590,11 +1605,16 @@ static int ensure_slot(osim* s, uint32_t subject) {
   return SIM_OK;
 }
 /* the subject an operation needs a view slot for (NOSLOT: none) — SIMSPEC §2.6 */
-static uint32_t op_subject(const osim* s, uint32_t op, uint32_t node, uint32_t a) {
+static uint32_t op_subject(const osim* s, uint32_t op, uint32_t node, uint32_t a, uint32_t b) {
   switch (op) {
     case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: return node;
     case SIM_OP_FORCE_LEAVE: return a;
     case SIM_OP_CRASH: case SIM_OP_REVIVE: case SIM_OP_SET_TAGS: return s->swim ? node : NOSLOT;
+    case SIM_OP_DELIVER: { /* a member record from outside is about subject `a` */
+      uint32_t kind = SIM_META_KIND(b);
+      if (kind == SIM_K_JOIN || kind == SIM_K_LEAVE) return a;
+      return (kind >= SIM_K_ALIVE && s->swim) ? a : NOSLOT;
+    }
     default: return NOSLOT;
   }
 }
@@ -1697,11 +1717,19 @@ static void recycle_local(osim* s) { /* every shard is in this process: decide h
   s->recycle_at = (uint32_t)s->tick;
 }
 
-int API(inject)(osim* s, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, uint32_t b) {
+int API(user_event)(osim* s, uint32_t node, uint32_t key, uint32_t len, int cc);
+static int inject_val(osim* s, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, uint32_t b, uint64_t val) {
   if (!s || node >= s->N) return SIM_EINVAL;
   if (tick < s->tick) tick = s->tick;
   int rc = SIM_OK;
   switch (op) {
+    case SIM_OP_DELIVER: {
+      uint32_t kind = SIM_META_KIND(b);
+      if (kind < SIM_K_JOIN || kind > SIM_K_DEAD || (b & ~SIM_META_WIRE_MASK)) return SIM_EINVAL;
+      if (kind == SIM_K_EVENT || kind == SIM_K_QUERY) { if (!a) return SIM_EINVAL; }
+      else if (a >= s->N) return SIM_EINVAL;
+      break;
+    }
     case SIM_OP_USER_EVENT: if (!a) return SIM_EINVAL; if ((b & 0x7FFFFFFFu) > 9 * 1024) return SIM_ETOOBIG; break; /* bit 31: cc */
     case SIM_OP_QUERY: if (!a) return SIM_EINVAL; break;
     case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: case SIM_OP_FORCE_LEAVE: case SIM_OP_CRASH: case SIM_OP_REVIVE: break;
@@ -1713,7 +1741,7 @@ int API(inject)(osim* s, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, 
   if (op == SIM_OP_FORCE_LEAVE && a >= s->N) return SIM_EINVAL;
   /* an operation that executes now gets its view slot now (and SIM_ENOSLOT if there is none); one scheduled for a
    * later tick gets it when it executes — and is dropped and counted if none is free then (SIMSPEC §2.6) */
-  if (tick <= s->tick && op_subject(s, op, node, a) != NOSLOT) rc = ensure_slot(s, op_subject(s, op, node, a));
+  if (tick <= s->tick && op_subject(s, op, node, a, b) != NOSLOT) rc = ensure_slot(s, op_subject(s, op, node, a, b));
   if (rc) return rc;
   if (s->n_ops == s->cap_ops) {
     s->cap_ops = s->cap_ops ? s->cap_ops * 2 : 64;
@@ -1724,7 +1752,233 @@ int API(inject)(osim* s, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, 
   size_t pos = s->n_ops;
   while (pos > s->op_cursor && s->ops[pos - 1].tick > tick) { s->ops[pos] = s->ops[pos - 1]; --pos; }
   s->ops[pos].tick = tick; s->ops[pos].op = op; s->ops[pos].node = node; s->ops[pos].a = a; s->ops[pos].b = b;
+  s->ops[pos].val = val;
   s->n_ops++;
+  return SIM_OK;
+}
+int API(inject)(osim* s, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, uint32_t b) {
+  if (op == SIM_OP_DELIVER) return SIM_EINVAL; /* needs a value: sim_inject_record */
+  return inject_val(s, tick, op, node, a, b, 0);
+}
+
+/* ---- the byte boundary of the delegate (include/serf_sim.h): the reference's message encoding restated in C — framing
+ * types/message.rs:397-428; join.rs:123-158; leave.rs:138-195; user_event/message.rs:205-272; query.rs:404-527; tag byte =
+ * (tag << 3) | wire type with wire types byte 0, varint 1, length-delimited 2 (UPSTREAM-RECALL, as serf_amd/wire.py) ---- */
+int API(inject_record)(osim* s, uint64_t tick, uint32_t node, const sim_record* rec) {
+  if (!s || !rec) return SIM_EINVAL;
+  return inject_val(s, tick, SIM_OP_DELIVER, node, rec->key, rec->meta & SIM_META_WIRE_MASK, rec->val);
+}
+typedef struct { const uint8_t* p; size_t n, off; int bad; } rdr;
+static uint64_t rd_varint(rdr* r) {
+  uint64_t v = 0;
+  for (unsigned shift = 0; shift < 70; shift += 7) {
+    if (r->off >= r->n) { r->bad = 1; return 0; }
+    uint8_t b = r->p[r->off++];
+    if (shift < 64) v |= (uint64_t)(b & 0x7F) << shift;
+    if (!(b & 0x80)) return v;
+  }
+  r->bad = 1;
+  return 0;
+}
+static rdr rd_ld(rdr* r) {
+  rdr o = {NULL, 0, 0, 0};
+  uint64_t n = rd_varint(r);
+  if (r->bad || n > r->n - r->off) { r->bad = 1; return o; }
+  o.p = r->p + r->off; o.n = (size_t)n;
+  r->off += (size_t)n;
+  return o;
+}
+static int parse_node_id(rdr d, uint32_t* gid) { /* a simulated node id travels as the decimal string of its number */
+  uint64_t v = 0;
+  if (!d.n) return 0;
+  for (size_t i = 0; i < d.n; ++i) {
+    if (d.p[i] < '0' || d.p[i] > '9') return 0;
+    v = v * 10 + (uint64_t)(d.p[i] - '0');
+    if (v > 0xFFFFFFFFull) return 0;
+  }
+  *gid = (uint32_t)v;
+  return 1;
+}
+static uint32_t event_key_of(const uint8_t* name, size_t nlen, const uint8_t* payload, size_t plen) {
+  uint32_t h = 2166136261u; /* FNV-1a over name, 0xFF, payload; never 0 (serf_amd/host/wire.hpp event_key) */
+  for (size_t i = 0; i < nlen; ++i) h = (h ^ name[i]) * 16777619u;
+  h = (h ^ 0xFFu) * 16777619u;
+  for (size_t i = 0; i < plen; ++i) h = (h ^ payload[i]) * 16777619u;
+  return h ? h : 1u;
+}
+static size_t varint_len(uint64_t v) { size_t n = 1; while (v >= 0x80) { v >>= 7; ++n; } return n; }
+static size_t user_event_wire_len(uint64_t ltime, size_t nlen, size_t plen, int cc) {
+  size_t body = 1 + varint_len(ltime) + (cc ? 2 : 0) + (nlen ? 1 + varint_len(nlen) + nlen : 0) + (plen ? 1 + varint_len(plen) + plen : 0);
+  return 1 + varint_len(body) + body;
+}
+static int evreg_put(osim* s, uint32_t key, const uint8_t* name, size_t nlen, const uint8_t* payload, size_t plen) {
+  for (size_t i = 0; i < s->n_evreg; ++i)
+    if (s->evreg[i].key == key) return SIM_OK; /* the first content under a key stays (a collision is a model bound) */
+  if (s->n_evreg == s->cap_evreg) {
+    s->cap_evreg = s->cap_evreg ? s->cap_evreg * 2 : 16;
+    s->evreg = (struct evreg*)realloc(s->evreg, s->cap_evreg * sizeof *s->evreg);
+    if (!s->evreg) return SIM_ENOMEM;
+  }
+  struct evreg* e = &s->evreg[s->n_evreg++];
+  e->key = key; e->nlen = (uint32_t)nlen; e->plen = (uint32_t)plen;
+  e->bytes = (uint8_t*)malloc(nlen + plen + 1);
+  if (!e->bytes) return SIM_ENOMEM;
+  if (nlen) memcpy(e->bytes, name, nlen);
+  if (plen) memcpy(e->bytes + nlen, payload, plen);
+  return SIM_OK;
+}
+int API(user_event_bytes)(osim* s, uint32_t node, const uint8_t* name, size_t nlen, const uint8_t* payload, size_t plen, int cc) {
+  if (!s || (nlen && !name) || (plen && !payload)) return SIM_EINVAL;
+  if (nlen + plen > 512) return SIM_ETOOBIG; /* api.rs:246-262 user_event_size_limit */
+  uint32_t key = event_key_of(name, nlen, payload, plen);
+  int rc = evreg_put(s, key, name, nlen, payload, plen);
+  if (rc) return rc;
+  /* the length is priced at Lamport time 1 (one varint byte): what Serf::user_event in serf_amd/host/serf.hpp does */
+  return API(user_event)(s, node, key, (uint32_t)user_event_wire_len(1, nlen, plen, cc), cc);
+}
+int API(deliver_message)(osim* s, uint32_t node, const uint8_t* buf, size_t len, size_t* consumed) {
+  if (!s || !buf || !len || node >= s->N) return SIM_EINVAL;
+  rdr r = {buf, len, 0, 0};
+  uint8_t tb = r.p[r.off++];
+  if ((tb & 7) != 2) return SIM_EINVAL; /* the type byte is length-delimited */
+  uint32_t tag = tb >> 3;
+  rdr body = rd_ld(&r);
+  if (r.bad) return SIM_EINVAL;
+  size_t used = r.off;
+  uint64_t ltime = 0, flags = 0, qid = 0;
+  uint32_t id = 0, have_id = 0, prune = 0, cc = 0, n_fid = 0, fids[SIM_QF_IDS];
+  rdr name = {NULL, 0, 0, 0}, payload = {NULL, 0, 0, 0};
+  while (body.off < body.n && !body.bad) {
+    uint8_t fb = body.p[body.off++];
+    uint32_t wt = fb & 7, ft = fb >> 3;
+    uint64_t v = 0;
+    rdr d = {NULL, 0, 0, 0};
+    if (tag == 5 && ft == 6) { if (body.off >= body.n) return SIM_EINVAL; v = body.p[body.off++]; } /* relay_factor: one raw byte (query.rs:484-490) */
+    else if (wt == 1) v = rd_varint(&body);
+    else if (wt == 0) { if (body.off >= body.n) return SIM_EINVAL; v = body.p[body.off++]; }
+    else if (wt == 2) d = rd_ld(&body);
+    else return SIM_EINVAL;
+    if (body.bad) return SIM_EINVAL;
+    switch (tag) {
+      case 2: /* JoinMessage: ltime 1, id 2 */
+        if (ft == 1) ltime = v; else if (ft == 2) have_id = parse_node_id(d, &id);
+        break;
+      case 1: /* LeaveMessage: ltime 1, prune 2, id 3 */
+        if (ft == 1) ltime = v; else if (ft == 2) prune = v != 0; else if (ft == 3) have_id = parse_node_id(d, &id);
+        break;
+      case 4: /* UserEventMessage: ltime 1, cc 2, name 3, payload 4 */
+        if (ft == 1) ltime = v; else if (ft == 2) cc = v != 0; else if (ft == 3) name = d; else if (ft == 4) payload = d;
+        break;
+      case 5: /* QueryMessage: ltime 1, id 2, from 3, filters 4, flags 5, relay_factor 6, timeout 7, name 8, payload 9 */
+        if (ft == 1) ltime = v; else if (ft == 2) qid = v; else if (ft == 5) flags = v;
+        else if (ft == 4) { /* Filter (types/filter.rs:176-262): Id = (id_byte <id, length-delimited>)*, Tag = tag_byte <TagFilter> */
+          rdr f = d;
+          while (f.off < f.n) {
+            uint8_t kb = f.p[f.off++];
+            if ((kb >> 3) != 1) return SIM_EINVAL; /* FILTER_TAG_TAG: a tag expression, evaluated by the host (sim_query_filtered) */
+            rdr one = rd_ld(&f);
+            uint32_t g;
+            if (f.bad || !parse_node_id(one, &g) || g >= s->N || n_fid == SIM_QF_IDS) return SIM_EINVAL;
+            fids[n_fid++] = g;
+          }
+        }
+        break;
+      default: return SIM_EINVAL; /* not a message of the simulated path */
+    }
+  }
+  if (body.bad) return SIM_EINVAL;
+  sim_record rec;
+  memset(&rec, 0, sizeof rec);
+  rec.val = ltime;
+  uint32_t wlen = (uint32_t)used;
+  int rc = SIM_OK;
+  if (tag == 2 || tag == 1) {
+    if (!have_id || id >= s->N) return SIM_EINVAL;
+    rec.key = id;
+    rec.meta = wire_meta(tag == 2 ? SIM_K_JOIN : SIM_K_LEAVE, prune ? SIM_F_PRUNE : 0, wlen);
+  } else if (tag == 4) {
+    rec.key = event_key_of(name.p, name.n, payload.p, payload.n);
+    rec.meta = wire_meta(SIM_K_EVENT, cc ? SIM_F_CC : 0, wlen);
+    rc = evreg_put(s, rec.key, name.p, name.n, payload.p, payload.n);
+  } else {
+    if (!qid || qid > 0xFFFFFFFFull) return SIM_EINVAL;
+    rec.key = (uint32_t)qid;
+    rec.meta = wire_meta(SIM_K_QUERY, ((flags & 1) ? SIM_F_ACK : 0) | ((flags & 2) ? SIM_F_NO_BROADCAST : 0), 48); /* every query is priced at 48 B */
+    for (uint32_t i = 0; i < n_fid && rc == SIM_OK; ++i) rc = inject_val(s, s->tick, SIM_OP_QUERY_FILTER_ID, node, rec.key, fids[i], 0);
+  }
+  if (rc == SIM_OK) rc = API(inject_record)(s, s->tick, node, &rec);
+  if (rc == SIM_OK && consumed) *consumed = used;
+  return rc;
+}
+/* encoder side */
+typedef struct { uint8_t* p; size_t cap, n; } wtr;
+static void w_byte(wtr* w, uint8_t b) { if (w->p && w->n < w->cap) w->p[w->n] = b; w->n++; }
+static void w_varint(wtr* w, uint64_t v) { for (;;) { uint8_t b = v & 0x7F; v >>= 7; if (v) w_byte(w, b | 0x80); else { w_byte(w, b); return; } } }
+static void w_bytes(wtr* w, const uint8_t* p, size_t n) { for (size_t i = 0; i < n; ++i) w_byte(w, p[i]); }
+static void w_ld(wtr* w, const uint8_t* p, size_t n) { w_varint(w, n); w_bytes(w, p, n); }
+static size_t dec_str(uint32_t v, uint8_t out[12]) { int n = snprintf((char*)out, 12, "%u", v); return (size_t)n; }
+static void w_message(wtr* w, uint32_t tag, const uint8_t* body, size_t n) { w_byte(w, (uint8_t)((tag << 3) | 2)); w_ld(w, body, n); }
+int API(peek_packet)(osim* s, uint32_t node, uint32_t k, uint8_t* buf, size_t cap, size_t* len) {
+  if (!s || !len || k >= s->f) return SIM_EINVAL;
+  if (node < s->shard0 || node >= s->shard0 + s->Nl || s->rfan || s->in_tick) return SIM_EINVAL;
+  wtr w = {buf, buf ? cap : 0, 0};
+  if (s->tick > 0 && k < s->prev.feff) {
+    const tickp* p = &s->prev; /* the map the packets in flight were sent with */
+    uint32_t g = node / p->M, ll = node % p->M, h, lp;
+    fan_target(p, g, ll, k, &h, &lp);
+    for (uint32_t pg = 0; pg < s->PG; ++pg) {
+      const sim_packet* pk = s->cfg.shard_count > 1
+          ? &s->xsend[xcell(p, s->fp, (ll % p->blk) / p->sub, h, k * s->PG + pg, lp)]
+          : &s->inbox[s->tick & 1][((size_t)k * s->PG + pg) * s->Nl + (size_t)h * p->M + lp];
+      for (uint32_t r = 0; r < SIM_P; ++r) {
+        uint32_t kind = pk_kind(pk, r);
+        if (kind == SIM_K_EMPTY || kind >= SIM_K_ALIVE) continue; /* memberlist's own records are not serf messages */
+        sim_record rec = pk_get(pk, r);
+        uint8_t body[1200], ids[12];
+        wtr b = {body, sizeof body, 0};
+        uint32_t flags = SIM_META_FLAGS(rec.meta);
+        w_byte(&b, (1 << 3) | 1); w_varint(&b, rec.val); /* ltime: tag 1 in every message */
+        if (kind == SIM_K_JOIN) {
+          w_byte(&b, (2 << 3) | 2); w_ld(&b, ids, dec_str(rec.key, ids));
+          w_message(&w, 2, body, b.n);
+        } else if (kind == SIM_K_LEAVE) {
+          if (flags & SIM_F_PRUNE) { w_byte(&b, (2 << 3) | 0); w_byte(&b, 1); }
+          w_byte(&b, (3 << 3) | 2); w_ld(&b, ids, dec_str(rec.key, ids));
+          w_message(&w, 1, body, b.n);
+        } else if (kind == SIM_K_EVENT) {
+          const struct evreg* e = NULL;
+          for (size_t i = 0; i < s->n_evreg; ++i) if (s->evreg[i].key == rec.key) e = &s->evreg[i];
+          if (flags & SIM_F_CC) { w_byte(&b, (2 << 3) | 0); w_byte(&b, 1); }
+          if (e) {
+            if (e->nlen) { w_byte(&b, (3 << 3) | 2); w_ld(&b, e->bytes, e->nlen); }
+            if (e->plen) { w_byte(&b, (4 << 3) | 2); w_ld(&b, e->bytes + e->nlen, e->plen); }
+          } else {
+            char nm[16];
+            int n = snprintf(nm, sizeof nm, "#%08x", rec.key);
+            w_byte(&b, (3 << 3) | 2); w_ld(&b, (const uint8_t*)nm, (size_t)n);
+          }
+          w_message(&w, 4, body, b.n);
+        } else { /* query */
+          uint32_t j = rec.key % SIM_QT, origin = 0, relay = 0;
+          if (s->qtab[j].qid == rec.key) { origin = s->qtab[j].origin; relay = (s->qtab[j].flags >> 8) & 7u; }
+          uint8_t nb[32];
+          wtr nw = {nb, sizeof nb, 0}; /* Node{id: tag 1, addr: tag 2 (6 bytes)} as serf_amd/wire.py encode_node */
+          w_byte(&nw, (1 << 3) | 2); w_ld(&nw, ids, dec_str(origin, ids));
+          uint8_t addr[6] = {10, (uint8_t)(origin >> 16), (uint8_t)(origin >> 8), (uint8_t)origin, (uint8_t)(7946 >> 8), (uint8_t)(7946 & 0xFF)};
+          w_byte(&nw, (2 << 3) | 2); w_ld(&nw, addr, 6);
+          w_byte(&b, (2 << 3) | 1); w_varint(&b, rec.key);
+          w_byte(&b, (3 << 3) | 2); w_ld(&b, nb, nw.n);
+          w_byte(&b, (5 << 3) | 1); w_varint(&b, ((flags & SIM_F_ACK) ? 1u : 0u) | ((flags & SIM_F_NO_BROADCAST) ? 2u : 0u));
+          w_byte(&b, (6 << 3) | 1); w_byte(&b, (uint8_t)relay);
+          w_byte(&b, (7 << 3) | 1); w_varint(&b, (uint64_t)s->q_timeout * 200u); /* gossip intervals of 200 ms */
+          w_byte(&b, (8 << 3) | 2); w_ld(&b, (const uint8_t*)"#q", 2);
+          w_message(&w, 5, body, b.n);
+        }
+      }
+    }
+  }
+  *len = w.n;
+  if (buf && w.n > cap) return SIM_ERANGE;
   return SIM_OK;
 }
 

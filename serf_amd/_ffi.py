@@ -27,7 +27,7 @@ K_JOIN, K_LEAVE, K_EVENT, K_QUERY, K_ALIVE, K_SUSPECT, K_DEAD = 1, 2, 3, 4, 5, 6
 EV_JOIN, EV_LEAVE, EV_FAILED, EV_UPDATE, EV_REAP, EV_USER, EV_QUERY = range(7)
 # enum sim_op
 OP_USER_EVENT, OP_QUERY, OP_LEAVE, OP_JOIN, OP_FORCE_LEAVE, OP_CRASH, OP_REVIVE, OP_LEAVE_FINISH = 1, 2, 3, 4, 5, 6, 7, 8
-OP_SET_TAGS, OP_QUERY_FILTER_ID, OP_QUERY_FILTER_TAGS = 9, 10, 11
+OP_SET_TAGS, OP_QUERY_FILTER_ID, OP_QUERY_FILTER_TAGS, OP_DELIVER = 9, 10, 11, 12
 QF_IDS, TAG_CLASSES, NO_TAG_FILTER = 12, 32, 0xFFFFFFFF
 # enum sim_array
 ARR_ROWS, ARR_QUEUE, ARR_INBOX, ARR_VIEW, ARR_ERING, ARR_QRING, ARR_SLOTMAP = range(7)
@@ -101,7 +101,8 @@ ABI_SYMBOLS = ("create", "destroy", "set_stream", "join", "leave", "force_leave"
                "bind_exchange", "snapshot", "restore", "query_status", "profile", "profile_read", "profile_read_stats", "cluster_stats_get",
                "bind_exchange2", "exchange_chunks", "step_begin", "step_chunk", "step_end",
                "recycle_due", "recycle_scan", "recycle_apply", "pp_due", "pp_plan", "pp_export", "pp_merge",
-               "query_filtered", "set_tags", "init_tags", "abi_version", "backend_name")
+               "query_filtered", "set_tags", "init_tags", "inject_record", "deliver_message", "user_event_bytes", "peek_packet",
+               "abi_version", "backend_name")
 
 
 def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, view_slots=0,
@@ -181,6 +182,10 @@ class SimLib:
             "profile_read": (C.c_int, [H, C.POINTER(C.c_double), C.POINTER(u64)]),
             "profile_read_stats": (C.c_int, [H, C.POINTER(C.c_double * 3), C.POINTER(u64)]),
             "cluster_stats_get": (C.c_int, [H, C.POINTER(ClusterStats)]),
+            "inject_record": (C.c_int, [H, u64, u32, vp]),
+            "deliver_message": (C.c_int, [H, u32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+            "user_event_bytes": (C.c_int, [H, u32, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]),
+            "peek_packet": (C.c_int, [H, u32, u32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
             "abi_version": (u32, []),
             "backend_name": (C.c_char_p, []),
         }
@@ -259,6 +264,31 @@ class Sim:
         import numpy as np
         arr = np.ascontiguousarray(classes, dtype=np.uint8)
         self._ck(self.lib.f["init_tags"](self.h, first, len(arr), arr.ctypes.data), "sim_init_tags")
+
+    # ---- the byte boundary of the delegate (delegate.rs:157-163, 317-384) ----
+    def inject_record(self, tick, node, key, meta, val):
+        """`node` receives the record (key, wire bits of meta, val) at the start of tick `tick` as if it came in a packet."""
+        rec = np.zeros(1, REC_DTYPE)
+        rec["key"], rec["meta"], rec["val"] = key, meta, val
+        self._ck(self.lib.f["inject_record"](self.h, tick, node, rec.ctypes.data), "sim_inject_record")
+
+    def deliver_message(self, node, data: bytes):
+        """SerfDelegate::notify_message(buf): one framed serf message in the reference's encoding; returns bytes consumed."""
+        used = C.c_size_t()
+        self._ck(self.lib.f["deliver_message"](self.h, node, data, len(data), C.byref(used)), "sim_deliver_message")
+        return used.value
+
+    def user_event_bytes(self, node, name: bytes, payload: bytes, coalesce=False):
+        """Serf::user_event(name, payload, coalesce) (api.rs:241-299) with the bytes themselves."""
+        self._ck(self.lib.f["user_event_bytes"](self.h, node, name, len(name), payload, len(payload), int(coalesce)), "sim_user_event_bytes")
+
+    def peek_packet(self, node, k) -> bytes:
+        """SerfDelegate::broadcast_messages as bytes: the serf messages of the packet `node` sent in slot k last tick."""
+        n = C.c_size_t()
+        self._ck(self.lib.f["peek_packet"](self.h, node, k, None, 0, C.byref(n)), "sim_peek_packet")
+        buf = np.zeros(max(1, n.value), np.uint8)
+        self._ck(self.lib.f["peek_packet"](self.h, node, k, buf.ctypes.data, n.value, C.byref(n)), "sim_peek_packet")
+        return buf[:n.value].tobytes()
 
     def set_stream(self, stream_ptr):
         self._ck(self.lib.f["set_stream"](self.h, C.c_void_p(stream_ptr)), "sim_set_stream")

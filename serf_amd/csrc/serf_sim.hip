@@ -38,6 +38,8 @@
 #include <vector>
 
 #include "../../include/serf_sim.h"
+#include "../host/wire.hpp"  // the reference's message encoding (host side only: sim_deliver_message / sim_peek_packet)
+#include <unordered_map>
 
 typedef uint32_t u32;
 typedef uint64_t u64;
@@ -522,6 +524,37 @@ __device__ static inline u32 q_round(Node& n, SK sk, u32 limit) {
   }
 #pragma unroll
   for (int i = 0; i < (int)SIM_Q; ++i) sk[i] = s[i];
+  return slots;
+}
+
+// The same round for a wave in which no lane holds more than 8 entries (sk[8 ..] all empty — the caller checks it with a
+// ballot; at the benchmark load the deepest queue is 7): the four re-keyed head entries merge with four others, a
+// 12-exchange network instead of 32.
+__device__ static inline u32 q_round8(Node& n, SK sk, u32 limit) {
+  u32 head_units = 0;
+#pragma unroll
+  for (int p = 0; p < (int)SIM_P; ++p) head_units += sk[p] != KEMPTY ? 63u - ((sk[p] >> 14) & 63u) : 0u;
+  if (__any(head_units > SIM_PKT_UNITS)) return q_round(n, sk, limit);  // large messages: the general walk
+  u32 a[SIM_P], slots = 0;
+#pragma unroll
+  for (int p = 0; p < (int)SIM_P; ++p) {
+    u32 k = sk[p];
+    bool valid = k != KEMPTY;
+    bool drop = ((k >> 20) & 63u) + 1u >= limit;
+    slots |= (valid ? (k & 15u) : 0xFFu) << (8 * p);
+    if (valid && drop) { n.used &= ~(1u << (k & 15u)); n.dirty |= DR2; }
+    a[p] = valid ? (drop ? KEMPTY : k + (1u << 20)) : k;
+  }
+  cas32(a[0], a[1]); cas32(a[2], a[3]); cas32(a[0], a[2]); cas32(a[1], a[3]); cas32(a[1], a[2]);
+  u32 s[8] = {sk[4], sk[5], sk[6], sk[7], a[3], a[2], a[1], a[0]};  // ascending, then descending: bitonic
+#pragma unroll
+  for (int dd = 4; dd >= 1; dd >>= 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if ((i & dd) == 0) cas32(s[i], s[i + dd]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sk[i] = s[i];
   return slots;
 }
 
@@ -1611,11 +1644,16 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
   } else {
   // all F drain rounds first (pure register work on the sort keys) ...
   u32 slots[F];
+#ifdef TICK_NO_ROUND8
+  const bool small = false;
+#else
+  const bool small = !__any(up && sk[8] != KEMPTY);  // (wave-uniform) nobody holds more than 8 entries
+#endif
 #pragma unroll
   for (int k = 0; k < F; ++k) {
     slots[k] = 0xFFFFFFFFu;
     if (up && (u32)k < tp.feff) {
-      u32 s = q_round(n, sk, limit);
+      u32 s = small ? q_round8(n, sk, limit) : q_round(n, sk, limit);
       bool lost = tp.loss_u32 && (u32)(mix64(tp.loss_base ^ ((u64)gid * 4u + k)) >> 32) < tp.loss_u32;
       if (!lost) slots[k] = s;
     }
@@ -1741,6 +1779,7 @@ struct OpBatch {
   u32 n;
   u32 op[8], node[8], a[8], b[8];
   u32 c[8];  // SIM_OP_QUERY: tracker index
+  u64 val[8];  // SIM_OP_DELIVER: the record's value
 };
 __device__ static inline void up_set(const Dev& d, u32 gid, bool up) {
   u32 w = d.upmap[gid >> 5];
@@ -1852,6 +1891,17 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
         break;
       case SIM_OP_CRASH: n.flags &= ~SIM_RF_UP; break;
       case SIM_OP_REVIVE: n.flags |= SIM_RF_UP; break;
+      case SIM_OP_DELIVER:  // a record from outside the cluster: notify_message (delegate.rs:157-315) / memberlist's own handling
+        if (up) {
+          u64 val = ob.val[i];
+          uint4 r = make_uint4(a, b, (u32)val, (u32)(val >> 32));
+          u32 kind = SIM_META_KIND(b);
+          u64 vbase = (u64)(uintptr_t)d.view;
+          uint4* p = lookup_ptr(c, vbase, (u64)(uintptr_t)d.ering - vbase, (u64)(uintptr_t)d.qring - vbase, kind, a, val, slot_load(d, kind, a));
+          uint4 e_ = p ? p[0] : make_uint4(0, 0, 0, 0);
+          dispatch(c, n, r, p, e_, dirty, ins);
+        }
+        break;
       default: break;
     }
     if (ins.has) q_insert(c, n, sk, ins.key, ins.wmeta, ins.val);
@@ -2461,6 +2511,7 @@ __global__ void set_flag_bits(uint4* R1, u32 l, u32 bits) {
 struct OpEnt {
   u64 tick;
   u32 op, node, a, b;
+  u64 val;  // SIM_OP_DELIVER: the record's value (a = key, b = wire bits of meta); 0 otherwise
 };
 
 struct sim_handle {
@@ -2495,6 +2546,9 @@ struct sim_handle {
   int device;
   u32 qt_cursor, q_timeout;  // running-query trackers (SIM_QT, round robin); query timeout in ticks
   std::vector<u32> qfilt;    // [SIM_QT][SIM_QF_WORDS] host copy of the query filters (the host is their only writer)
+  // content of the user events the library was told in bytes (sim_deliver_message, sim_user_event_bytes): what
+  // sim_peek_packet encodes for their keys
+  std::unordered_map<u32, std::pair<serf::wire::Bytes, serf::wire::Bytes>> evreg;
   u32 profiling;  // 0 = off, n = HIP events around every n-th tick-kernel launch
   u64 prof_seq;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof;  // one event pair per tick-kernel launch
@@ -2783,11 +2837,16 @@ static int ensure_slot(sim_handle* h, u32 subject) {
   return SIM_OK;
 }
 // the subject an operation needs a view slot for (NOSLOT: none) — SIMSPEC §2.6
-static u32 op_subject(const sim_handle* h, u32 op, u32 node, u32 a) {
+static u32 op_subject(const sim_handle* h, u32 op, u32 node, u32 a, u32 b) {
   switch (op) {
     case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: return node;
     case SIM_OP_FORCE_LEAVE: return a;
     case SIM_OP_CRASH: case SIM_OP_REVIVE: case SIM_OP_SET_TAGS: return h->d.swim ? node : NOSLOT;
+    case SIM_OP_DELIVER: {  // a member record from outside is about subject `a`
+      u32 kind = SIM_META_KIND(b);
+      if (kind == SIM_K_JOIN || kind == SIM_K_LEAVE) return a;
+      return (kind >= SIM_K_ALIVE && h->d.swim) ? a : NOSLOT;
+    }
     default: return NOSLOT;
   }
 }
@@ -2910,23 +2969,98 @@ static int op_validate(u32 N, u32 op, u32 node, u32 a, u32 b) {
     case SIM_OP_SET_TAGS: if (a >= SIM_TAG_CLASSES) return SIM_EINVAL; break;
     case SIM_OP_QUERY_FILTER_ID: if (!a || b >= N) return SIM_EINVAL; break;
     case SIM_OP_QUERY_FILTER_TAGS: if (!a) return SIM_EINVAL; break;
+    case SIM_OP_DELIVER: {
+      u32 kind = SIM_META_KIND(b);
+      if (kind < SIM_K_JOIN || kind > SIM_K_DEAD || (b & ~SIM_META_WIRE_MASK)) return SIM_EINVAL;
+      if (kind == SIM_K_EVENT || kind == SIM_K_QUERY) { if (!a) return SIM_EINVAL; }
+      else if (a >= N) return SIM_EINVAL;
+      break;
+    }
     default: return SIM_EINVAL;
   }
   return SIM_OK;
 }
-int sim_inject(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, uint32_t b) {
+static int inject_val(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, uint32_t b, uint64_t val) {
   if (!h) return SIM_EINVAL;
   if (tick < h->tick) tick = h->tick;
   int rc = op_validate(h->d.N, op, node, a, b);
   if (rc) return rc;
   // an operation that executes now gets its view slot now (and SIM_ENOSLOT if there is none); one scheduled for a
   // later tick gets it when it executes — and is dropped and counted if none is free then (SIMSPEC §2.6)
-  if (tick <= h->tick && op_subject(h, op, node, a) != NOSLOT) rc = ensure_slot(h, op_subject(h, op, node, a));
+  if (tick <= h->tick && op_subject(h, op, node, a, b) != NOSLOT) rc = ensure_slot(h, op_subject(h, op, node, a, b));
   if (rc) return rc;
   size_t pos = h->ops.size();
-  h->ops.push_back(OpEnt{tick, op, node, a, b});
+  h->ops.push_back(OpEnt{tick, op, node, a, b, val});
   while (pos > h->op_cursor && h->ops[pos - 1].tick > tick) { std::swap(h->ops[pos], h->ops[pos - 1]); --pos; }
   return SIM_OK;
+}
+int sim_inject(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, uint32_t b) {
+  if (op == SIM_OP_DELIVER) return SIM_EINVAL;  // needs a value: sim_inject_record
+  return inject_val(h, tick, op, node, a, b, 0);
+}
+// ---- the byte boundary of the delegate (include/serf_sim.h; oracle: the same entry points with its own C codec) ----
+int sim_inject_record(sim_handle* h, uint64_t tick, uint32_t node, const sim_record* rec) {
+  if (!h || !rec) return SIM_EINVAL;
+  return inject_val(h, tick, SIM_OP_DELIVER, node, rec->key, rec->meta & SIM_META_WIRE_MASK, rec->val);
+}
+int sim_user_event_bytes(sim_handle* h, uint32_t node, const uint8_t* name, size_t nlen, const uint8_t* payload, size_t plen, int cc) {
+  if (!h || (nlen && !name) || (plen && !payload)) return SIM_EINVAL;
+  if (nlen + plen > 512) return SIM_ETOOBIG;  // api.rs:246-262 user_event_size_limit
+  namespace w = serf::wire;
+  w::Bytes nm(name, name + nlen), pl(payload, payload + plen);
+  u32 key = w::event_key(nm, pl);
+  h->evreg.emplace(key, std::make_pair(nm, pl));  // the first content under a key stays
+  return sim_user_event(h, node, key, (uint32_t)w::user_event_len(1, nm, pl, cc != 0), cc);
+}
+int sim_deliver_message(sim_handle* h, uint32_t node, const uint8_t* buf, size_t len, size_t* consumed) {
+  if (!h || !buf || !len || node >= h->d.N) return SIM_EINVAL;
+  namespace w = serf::wire;
+  try {
+    w::Bytes in(buf, buf + len);
+    size_t used = 0;
+    auto [tag, body] = w::unframe(in, used);
+    sim_record rec;
+    memset(&rec, 0, sizeof rec);
+    int rc = SIM_OK;
+    if (tag == w::JOIN) {
+      w::Join m = w::decode_join(body);
+      if (m.id >= h->d.N) return SIM_EINVAL;
+      rec.key = m.id; rec.val = m.ltime; rec.meta = wire_meta(SIM_K_JOIN, 0, (u32)used);
+    } else if (tag == w::LEAVE) {
+      w::Leave m = w::decode_leave(body);
+      if (m.id >= h->d.N) return SIM_EINVAL;
+      rec.key = m.id; rec.val = m.ltime; rec.meta = wire_meta(SIM_K_LEAVE, m.prune ? SIM_F_PRUNE : 0, (u32)used);
+    } else if (tag == w::USER_EVENT) {
+      w::UserEvent m = w::decode_user_event(body);
+      rec.key = w::event_key(m.name, m.payload); rec.val = m.ltime;
+      rec.meta = wire_meta(SIM_K_EVENT, m.cc ? SIM_F_CC : 0, (u32)used);
+      h->evreg.emplace(rec.key, std::make_pair(m.name, m.payload));
+    } else if (tag == w::QUERY) {
+      w::Query m = w::decode_query(body);
+      if (!m.id) return SIM_EINVAL;
+      rec.key = m.id; rec.val = m.ltime;
+      rec.meta = wire_meta(SIM_K_QUERY, ((m.flags & 1u) ? SIM_F_ACK : 0u) | ((m.flags & 2u) ? SIM_F_NO_BROADCAST : 0u), 48);  // every query is priced at 48 B
+      std::vector<u32> ids;
+      for (const w::Bytes& f : m.filters) {  // types/filter.rs:176-262: Id = (id_byte <id>)*, Tag = tag_byte <TagFilter>
+        size_t off = 0;
+        while (off < f.size()) {
+          if ((f[off++] >> 3) != 1) return SIM_EINVAL;  // a tag expression: evaluated by the host (sim_query_filtered)
+          u32 g = w::parse_node_id(w::read_ld(f, off));
+          if (g >= h->d.N || ids.size() == SIM_QF_IDS) return SIM_EINVAL;
+          ids.push_back(g);
+        }
+      }
+      for (u32 g : ids)
+        if ((rc = inject_val(h, h->tick, SIM_OP_QUERY_FILTER_ID, node, rec.key, g, 0)) != SIM_OK) return rc;
+    } else {
+      return SIM_EINVAL;  // not a message of the simulated path
+    }
+    rc = sim_inject_record(h, h->tick, node, &rec);
+    if (rc == SIM_OK && consumed) *consumed = used;
+    return rc;
+  } catch (const std::exception&) {
+    return SIM_EINVAL;
+  }
 }
 int sim_join(sim_handle* h, uint32_t node, uint32_t peer) { return sim_inject(h, h ? h->tick : 0, SIM_OP_JOIN, node, peer, 0); }
 int sim_leave(sim_handle* h, uint32_t node) {
@@ -3121,9 +3255,9 @@ int sim_step_begin(sim_handle* h) {
         }
         if (e.op != SIM_OP_QUERY) continue;
       }
-      u32 x = op_subject(h, e.op, e.node, e.a);
+      u32 x = op_subject(h, e.op, e.node, e.a, e.b);
       if (x != NOSLOT && ensure_slot(h, x) != SIM_OK) { h->ops_dropped++; continue; }  // no free view slot: the operation does not happen
-      ob.op[ob.n] = e.op; ob.node[ob.n] = e.node; ob.a[ob.n] = e.a; ob.b[ob.n] = e.b;
+      ob.op[ob.n] = e.op; ob.node[ob.n] = e.node; ob.a[ob.n] = e.a; ob.b[ob.n] = e.b; ob.val[ob.n] = e.val;
       if (e.op == SIM_OP_QUERY) {  // a fresh tracker: who acked / responded starts empty
         u32 j = e.a % SIM_QT;
         size_t words = ((size_t)d.N + 31) / 32;
@@ -3400,6 +3534,63 @@ int sim_convergence(sim_handle* h, uint32_t kind, uint32_t key, uint64_t ltime, 
   HCHECK(hipStreamSynchronize(s));
   *seen = r[0];
   *up = r[1];
+  return SIM_OK;
+}
+
+int sim_peek_packet(sim_handle* h, uint32_t node, uint32_t k, uint8_t* buf, size_t cap, size_t* len) {
+  if (!h || !len || k >= h->d.f) return SIM_EINVAL;
+  Dev& d = h->d;
+  if (node < d.shard0 || node >= d.shard0 + d.Nl || h->in_tick) return SIM_EINVAL;
+  namespace w = serf::wire;
+  w::Bytes out;
+  const TickP& p = h->prev;  // the map the packets in flight were sent with
+  if (h->tick > 0 && k < p.feff) {
+    u32 g = node / p.M, ll = node - g * p.M, hh, lp;
+    fan_target_g(p, g, ll, k, hh, lp);
+    std::vector<sim_packet> pages(d.PG);
+    const uint4* src = d.sharded ? d.xsend : cur_inbox(h);
+    for (u32 pg = 0; pg < d.PG; ++pg) {
+      size_t cell = d.sharded ? ((((size_t)((ll % p.blk) / p.sub) * p.V + hh) * d.fp + (size_t)k * d.PG + pg) * p.sub + lp % p.sub)
+                              : (((size_t)k * d.PG + pg) * d.Nl + (size_t)hh * p.M + lp);
+      HCHECK(hipMemcpyAsync(&pages[pg], src + cell * PK_U4, sizeof(sim_packet), hipMemcpyDeviceToHost, h->stream));
+    }
+    HCHECK(hipStreamSynchronize(h->stream));
+    for (u32 pg = 0; pg < d.PG; ++pg)
+      for (u32 r = 0; r < SIM_P; ++r) {
+        const sim_packet& pk = pages[pg];
+        u32 hm = pk.hi_meta[r], kind = (hm >> 4) & 15u, flags = hm & 15u;
+        if (kind == SIM_K_EMPTY || kind >= SIM_K_ALIVE) continue;  // memberlist's own records are not serf messages
+        u64 ltime = (u64)pk.val_lo[r] | ((u64)(hm >> 16) << 32);
+        w::Bytes m;
+        if (kind == SIM_K_JOIN) {
+          w::Join j; j.ltime = ltime; j.id = pk.key[r];
+          m = w::encode_message(j);
+        } else if (kind == SIM_K_LEAVE) {
+          w::Leave l; l.ltime = ltime; l.id = pk.key[r]; l.prune = flags & SIM_F_PRUNE;
+          m = w::encode_message(l);
+        } else if (kind == SIM_K_EVENT) {
+          w::UserEvent e; e.ltime = ltime; e.cc = flags & SIM_F_CC;
+          auto it = h->evreg.find(pk.key[r]);
+          if (it != h->evreg.end()) { e.name = it->second.first; e.payload = it->second.second; }
+          else { char nm[16]; int n = snprintf(nm, sizeof nm, "#%08x", pk.key[r]); e.name.assign(nm, nm + n); }
+          m = w::encode_message(e);
+        } else {
+          w::Query q; q.ltime = ltime; q.id = pk.key[r];
+          q.flags = ((flags & SIM_F_ACK) ? 1u : 0u) | ((flags & SIM_F_NO_BROADCAST) ? 2u : 0u);
+          uint4 tj;
+          HCHECK(hipMemcpy(&tj, d.qtab + pk.key[r] % SIM_QT, sizeof tj, hipMemcpyDeviceToHost));
+          if (tj.x == pk.key[r]) { q.from_node = tj.y; q.relay_factor = (uint8_t)((tj.w >> 8) & 7u); }
+          q.timeout_ms = (u64)h->q_timeout * 200u;  // gossip intervals of 200 ms
+          q.name = {'#', 'q'};
+          m = w::encode_message(q);
+        }
+        out.insert(out.end(), m.begin(), m.end());
+      }
+  }
+  *len = out.size();
+  if (!buf) return SIM_OK;
+  if (out.size() > cap) return SIM_ERANGE;
+  if (!out.empty()) memcpy(buf, out.data(), out.size());
   return SIM_OK;
 }
 

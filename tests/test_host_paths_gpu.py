@@ -110,3 +110,56 @@ def test_codec_lengths_ride_the_gpus_queue_and_byte_budget(oracle, hiplib):
     g.step(30)
     o.step(30)
     assert g.digest() == o.digest()
+
+
+def test_byte_boundary_of_the_delegate_on_the_gpu(oracle, hiplib):
+    # tests/test_bridge.py on the HIP library: deliver(encode(x)) == inject_record(x); the packet bytes the C++ codec
+    # (serf_amd/host/wire.hpp, inside the library) writes are the oracle's C codec's, byte for byte; a packet peeked
+    # from one cluster and delivered to a node of another reproduces its rumours
+    from tests.test_bridge import KW, deliver_all, event_key, inject_all
+
+    n = 256
+    ga, gb = _ffi.Sim(hiplib, _ffi.make_config(n, **KW)), _ffi.Sim(hiplib, _ffi.make_config(n, **KW))
+    oa = _ffi.Sim(oracle, _ffi.make_config(n, **KW))
+    deliver_all(ga)
+    deliver_all(oa)
+    inject_all(gb)
+    for t in range(30):
+        for s in (ga, gb, oa):
+            s.step(1)
+        assert ga.digest() == gb.digest() == oa.digest(), f"tick {t}"
+    c, co = both(oracle, hiplib, n, **KW)
+    for s in (c, co):
+        s.user_event_bytes(5, b"restart", b"now", True)
+        s.user_event(5, 0xABCDEF01, 40)
+        s.query(5, 91, _ffi.F_ACK | (2 << 8))
+        s.leave(5)
+        s.step(2)
+    for node in (5, 17, 200):
+        for k in range(3):
+            assert c.peek_packet(node, k) == co.peek_packet(node, k)
+    raw = c.peek_packet(5, 0)
+    assert len(raw) > 40
+    d, do = both(oracle, hiplib, n, **KW)
+    for s in (d, do):
+        off = 0
+        while off < len(raw):
+            off += s.deliver_message(100, raw[off:])
+        s.step(25)
+    assert d.digest() == do.digest()
+    assert d.convergence(_ffi.K_EVENT, event_key(b"restart", b"now"), 1) == (n, n)
+    assert d.convergence(_ffi.K_QUERY, 91, 1) == (n, n)
+    # paged packets: sixteen records of one packet come out as sixteen messages
+    e, eo = both(oracle, hiplib, n, pkt_records=16, **KW)
+    for s in (e, eo):
+        for i in range(14):
+            s.user_event_bytes(9, b"ev%d" % i, b"", False)
+        s.step(1)
+    r1, r2 = e.peek_packet(9, 1), eo.peek_packet(9, 1)
+    assert r1 == r2
+    names, off = [], 0
+    while off < len(r1):
+        m, used = wire.decode_message(r1[off:])
+        off += used
+        names.append(m.name)
+    assert sorted(names) == sorted(b"ev%d" % i for i in range(14))
