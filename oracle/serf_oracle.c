@@ -2600,6 +2600,22 @@ int osim_t_swim_dead(osim* s, uint32_t node, uint32_t subject, uint32_t inc, uin
   return SIM_OK;
 }
 int osim_t_swim_timers(osim* s, uint32_t node) { TCTX(s, node); swim_timers(&c); return SIM_OK; }
+/* pure functions of the memberlist half, for the UPSTREAM-RECALL known-answer tests (tests/test_memberlist_kat.py) */
+uint32_t osim_t_retransmit_limit(uint32_t retransmit_mult, uint32_t n) { return retransmit_mult * digits10(n); } /* util.go retransmitLimit */
+uint32_t osim_t_push_pull_scale(uint32_t n) { /* util.go pushPullScale, as a multiplier of the interval */
+  sim_config c;
+  memset(&c, 0, sizeof c);
+  c.n_nodes = n; c.push_pull_interval = PP_GROUPS; /* step = interval * mult / PP_GROUPS = mult */
+  uint32_t step, groups;
+  pp_params(&c, &step, &groups);
+  return step;
+}
+uint32_t osim_t_awareness(const int* deltas, uint32_t n, uint32_t* scores) { /* awareness.go ApplyDelta / GetHealthScore */
+  sim_row row;
+  memset(&row, 0, sizeof row);
+  for (uint32_t i = 0; i < n; ++i) { aw_delta(&row, deltas[i]); if (scores) scores[i] = row.awareness; }
+  return row.awareness;
+}
 int osim_t_swim_params(osim* s, uint32_t* k, uint32_t* T) {
   if (!s) return SIM_EINVAL;
   *k = s->k_conf;
