@@ -340,6 +340,9 @@ enum sim_op {
                                    operation is dropped and counted in ops_dropped (model bound)                  */
   SIM_OP_QUERY_FILTER_TAGS = 11,/* a = query id, b = mask of the tag classes one Filter::Tag matches (ANDed into
                                    the query's mask); BEFORE the SIM_OP_QUERY, like the ids                       */
+  SIM_OP_SUSPECT = 13,          /* internal: `node` suspects a = target (from = node) — a probe that failed on a target without
+                                   a view slot in the previous tick (SIMSPEC §2.7: the suspicion is taken up one tick late,
+                                   once the target has its slot); scheduled by the library / by sim_suspect_requests' caller */
   SIM_OP_DELIVER = 12           /* internal (sim_inject_record / sim_deliver_message): `node` receives one record from
                                    outside the simulated cluster — SerfDelegate::notify_message (delegate.rs:157-315) for
                                    the serf kinds, memberlist's alive / suspect / dead handling for its own              */
@@ -492,6 +495,17 @@ int sim_pp_due(const sim_handle* h);
 int sim_pp_plan(sim_handle* h, uint32_t* send1, uint32_t* recv1, size_t* record_bytes);
 int sim_pp_export(sim_handle* h, int round, void* send_dev);
 int sim_pp_merge(sim_handle* h, int round, const void* recv_dev);
+/* Probes that failed on a target WITHOUT a view slot during the tick that just ended (only with packet loss: a target
+ * that is really down got its slot when it crashed).  The prober cannot hold that suspicion yet: the pair goes on the
+ * tick's request list and is replayed at the next tick as SIM_OP_SUSPECT (after that tick's scheduled operations, in
+ * ascending prober order), which gives the target its slot first.  A single-process handle does this by itself in
+ * sim_step_end.  With one shard per process the host calls sim_suspect_requests on every shard after sim_step_end —
+ * out[2 i] = prober, out[2 i + 1] = target, sorted by prober; the call empties the list —, gathers the lists, and injects
+ * sim_inject(h, tick, SIM_OP_SUSPECT, prober, target, 0) for the merged list, ascending by prober, on EVERY shard
+ * (serf_amd/shard.py).  More than SIM_SUSPECT_REQ_MAX requests in one tick on one shard: all of them are dropped and
+ * counted in ops_dropped (model bound). */
+#define SIM_SUSPECT_REQ_MAX 4096u
+int sim_suspect_requests(sim_handle* h, uint32_t* out, uint32_t cap_pairs, uint32_t* n_pairs);
 int sim_recycle_due(const sim_handle* h);
 int sim_recycle_scan(sim_handle* h, sim_recycle_cand* out, uint32_t cap, uint32_t* n);
 int sim_recycle_apply(sim_handle* h, const sim_recycle_cand* agreed, uint32_t n);

@@ -319,6 +319,10 @@ struct sim_handle {
   uint32_t* rsrc;  /* [f * Nl] cell indices (k * Nl + sender), grouped by target */
   /* content of the user events the library was told in bytes (sim_deliver_message, sim_user_event_bytes): key ->
    * name, payload — what sim_peek_packet encodes */
+  /* probes of the running tick that failed on a target without a view slot: (prober, target) pairs, appended by
+   * tick_node (any thread), turned into SIM_OP_SUSPECT operations of the next tick by step_end (SIMSPEC §2.7) */
+  uint32_t* sreq;      /* [SIM_SUSPECT_REQ_MAX][2] */
+  uint32_t sreq_n;     /* requests made (may exceed the capacity: then all are dropped) */
   struct evreg { uint32_t key, nlen, plen; uint8_t* bytes; } *evreg;
   size_t n_evreg, cap_evreg;
 };
@@ -937,7 +941,11 @@ static void swim_probe(nctx* c, const tickp* p) {
   }
   if (ok) { aw_delta(c->row, -1); return; }
   aw_delta(c->row, +1);
-  if (!e) { c->row->overflow++; return; } /* model bound: no view slot to hold the suspicion */
+  if (!e) { /* no view slot to hold the suspicion yet: taken up next tick, once the target has one (SIM_OP_SUSPECT) */
+    uint32_t i = __atomic_fetch_add(&s->sreq_n, 1u, __ATOMIC_RELAXED);
+    if (i < SIM_SUSPECT_REQ_MAX) { s->sreq[2 * i] = c->gid; s->sreq[2 * i + 1] = t; }
+    return;
+  }
   swim_suspect(c, t, e->inc, c->gid, wire_meta(SIM_K_SUSPECT, 0, 32));
 }
 
@@ -1115,6 +1123,12 @@ static void apply_op(osim* s, const sim_opent* op) {
     }
     case SIM_OP_CRASH: row->flags &= ~SIM_RF_UP; break;
     case SIM_OP_REVIVE: row->flags |= SIM_RF_UP; break;
+    case SIM_OP_SUSPECT: /* the suspicion of a probe that failed last tick on a then slot-less target (swim_probe) */
+      if ((row->flags & SIM_RF_UP) && s->swim) {
+        sim_view* e = view_at(s, l, op->a);
+        if (e) swim_suspect(&c, op->a, e->inc, c.gid, wire_meta(SIM_K_SUSPECT, 0, 32));
+      }
+      break;
     case SIM_OP_DELIVER: /* a record from outside the cluster: notify_message (delegate.rs:157-315) / memberlist's own handling */
       if (row->flags & SIM_RF_UP) {
         sim_record r;
@@ -1339,6 +1353,8 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
   }
 }
 
+int API(suspect_requests)(osim* s, uint32_t* out, uint32_t cap_pairs, uint32_t* n_pairs);
+static int inject_val(osim* s, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, uint32_t b, uint64_t val);
 static int recycle_due(const osim* s);
 static void recycle_local(osim* s);
 static uint32_t op_subject(const osim* s, uint32_t op, uint32_t node, uint32_t a, uint32_t b);
@@ -1408,6 +1424,11 @@ static void step_end(osim* s) {
   s->prev = p;
   s->tick++;
   s->in_tick = 0;
+  if (s->cfg.shard_count <= 1 && s->sreq_n) { /* every shard is here: replay the tick's slot-less suspicions next tick */
+    uint32_t buf[2 * SIM_SUSPECT_REQ_MAX], n = 0;
+    API(suspect_requests)(s, buf, SIM_SUSPECT_REQ_MAX, &n);
+    for (uint32_t i = 0; i < n; ++i) inject_val(s, s->tick, SIM_OP_SUSPECT, buf[2 * i], buf[2 * i + 1], 0, 0);
+  }
 }
 static void step_one(osim* s) {
   step_begin(s);
@@ -1471,6 +1492,7 @@ static int cfg_check(const sim_config* c) {
 
 int API(destroy)(osim* s) {
   if (!s) return SIM_EINVAL;
+  free(s->sreq);
   for (size_t i = 0; i < s->n_evreg; ++i) free(s->evreg[i].bytes);
   free(s->evreg);
   free(s->rows); free(s->queue); free(s->inbox[0]); free(s->inbox[1]);
@@ -1524,6 +1546,7 @@ int API(create)(const sim_config* cfg, osim** out) {
   swim_params(cfg, &s->swim, &s->k_conf, s->T);
   s->qbits = (uint32_t*)calloc((size_t)SIM_QT * 2 * (((size_t)s->N + 31) / 32), sizeof(uint32_t));
   s->tagclass = (uint8_t*)calloc(s->N, 1);
+  s->sreq = (uint32_t*)malloc((size_t)SIM_SUSPECT_REQ_MAX * 2 * sizeof(uint32_t));
   s->q_timeout = 16u * digits10(s->N); /* query.rs:421-427 with query_timeout_mult = 16 (options.rs:518) */
   pp_params(cfg, &s->pp_step, &s->pp_groups);
   if (!s->qbits || !s->upmap || !s->rows || !s->queue || !s->view || !s->ering || !s->qring || !s->slot_of ||
@@ -1610,6 +1633,7 @@ static uint32_t op_subject(const osim* s, uint32_t op, uint32_t node, uint32_t a
     case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: return node;
     case SIM_OP_FORCE_LEAVE: return a;
     case SIM_OP_CRASH: case SIM_OP_REVIVE: case SIM_OP_SET_TAGS: return s->swim ? node : NOSLOT;
+    case SIM_OP_SUSPECT: return s->swim ? a : NOSLOT;
     case SIM_OP_DELIVER: { /* a member record from outside is about subject `a` */
       uint32_t kind = SIM_META_KIND(b);
       if (kind == SIM_K_JOIN || kind == SIM_K_LEAVE) return a;
@@ -1723,6 +1747,7 @@ static int inject_val(osim* s, uint64_t tick, uint32_t op, uint32_t node, uint32
   if (tick < s->tick) tick = s->tick;
   int rc = SIM_OK;
   switch (op) {
+    case SIM_OP_SUSPECT: if (a >= s->N) return SIM_EINVAL; break;
     case SIM_OP_DELIVER: {
       uint32_t kind = SIM_META_KIND(b);
       if (kind < SIM_K_JOIN || kind > SIM_K_DEAD || (b & ~SIM_META_WIRE_MASK)) return SIM_EINVAL;
@@ -1741,7 +1766,9 @@ static int inject_val(osim* s, uint64_t tick, uint32_t op, uint32_t node, uint32
   if (op == SIM_OP_FORCE_LEAVE && a >= s->N) return SIM_EINVAL;
   /* an operation that executes now gets its view slot now (and SIM_ENOSLOT if there is none); one scheduled for a
    * later tick gets it when it executes — and is dropped and counted if none is free then (SIMSPEC §2.6) */
-  if (tick <= s->tick && op_subject(s, op, node, a, b) != NOSLOT) rc = ensure_slot(s, op_subject(s, op, node, a, b));
+  /* (a SIM_OP_SUSPECT always takes its slot when it executes: it is scheduled by the library / the sharded host, and a
+   * full view must count it as dropped the same way in both) */
+  if (op != SIM_OP_SUSPECT && tick <= s->tick && op_subject(s, op, node, a, b) != NOSLOT) rc = ensure_slot(s, op_subject(s, op, node, a, b));
   if (rc) return rc;
   if (s->n_ops == s->cap_ops) {
     s->cap_ops = s->cap_ops ? s->cap_ops * 2 : 64;
@@ -2446,6 +2473,22 @@ int API(pp_merge)(osim* s, int round, const void* recv) {
     for (uint32_t i = 0; i < s->pp_n_s1; ++i) pp_merge(s, s->pp_s1[i], (const uint8_t*)recv + (size_t)i * rb);
     s->pp_done_at = (uint32_t)s->tick;
   }
+  return SIM_OK;
+}
+static int sreq_cmp(const void* a, const void* b) {
+  uint32_t x = ((const uint32_t*)a)[0], y = ((const uint32_t*)b)[0];
+  return x < y ? -1 : x > y;
+}
+int API(suspect_requests)(osim* s, uint32_t* out, uint32_t cap_pairs, uint32_t* n_pairs) {
+  if (!s || !n_pairs || s->in_tick) return SIM_EINVAL;
+  uint32_t n = s->sreq_n;
+  s->sreq_n = 0;
+  *n_pairs = 0;
+  if (n > SIM_SUSPECT_REQ_MAX) { s->ops_dropped += n; return SIM_OK; } /* model bound: the whole tick's list is dropped */
+  if (n > cap_pairs || (n && !out)) return SIM_ERANGE;
+  qsort(s->sreq, n, 2 * sizeof(uint32_t), sreq_cmp); /* a node probes once per tick: probers are distinct */
+  memcpy(out, s->sreq, (size_t)n * 2 * sizeof(uint32_t));
+  *n_pairs = n;
   return SIM_OK;
 }
 int API(recycle_due)(const osim* s) { return s ? recycle_due(s) : SIM_EINVAL; }

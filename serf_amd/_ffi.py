@@ -27,7 +27,8 @@ K_JOIN, K_LEAVE, K_EVENT, K_QUERY, K_ALIVE, K_SUSPECT, K_DEAD = 1, 2, 3, 4, 5, 6
 EV_JOIN, EV_LEAVE, EV_FAILED, EV_UPDATE, EV_REAP, EV_USER, EV_QUERY = range(7)
 # enum sim_op
 OP_USER_EVENT, OP_QUERY, OP_LEAVE, OP_JOIN, OP_FORCE_LEAVE, OP_CRASH, OP_REVIVE, OP_LEAVE_FINISH = 1, 2, 3, 4, 5, 6, 7, 8
-OP_SET_TAGS, OP_QUERY_FILTER_ID, OP_QUERY_FILTER_TAGS, OP_DELIVER = 9, 10, 11, 12
+OP_SET_TAGS, OP_QUERY_FILTER_ID, OP_QUERY_FILTER_TAGS, OP_DELIVER, OP_SUSPECT = 9, 10, 11, 12, 13
+SUSPECT_REQ_MAX = 4096
 QF_IDS, TAG_CLASSES, NO_TAG_FILTER = 12, 32, 0xFFFFFFFF
 # enum sim_array
 ARR_ROWS, ARR_QUEUE, ARR_INBOX, ARR_VIEW, ARR_ERING, ARR_QRING, ARR_SLOTMAP = range(7)
@@ -101,7 +102,7 @@ ABI_SYMBOLS = ("create", "destroy", "set_stream", "join", "leave", "force_leave"
                "bind_exchange", "snapshot", "restore", "query_status", "profile", "profile_read", "profile_read_stats", "cluster_stats_get",
                "bind_exchange2", "exchange_chunks", "step_begin", "step_chunk", "step_end",
                "recycle_due", "recycle_scan", "recycle_apply", "pp_due", "pp_plan", "pp_export", "pp_merge",
-               "query_filtered", "set_tags", "init_tags", "inject_record", "deliver_message", "user_event_bytes", "peek_packet",
+               "query_filtered", "set_tags", "init_tags", "inject_record", "deliver_message", "user_event_bytes", "peek_packet", "suspect_requests",
                "abi_version", "backend_name")
 
 
@@ -186,6 +187,7 @@ class SimLib:
             "deliver_message": (C.c_int, [H, u32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
             "user_event_bytes": (C.c_int, [H, u32, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]),
             "peek_packet": (C.c_int, [H, u32, u32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+            "suspect_requests": (C.c_int, [H, vp, u32, C.POINTER(u32)]),
             "abi_version": (u32, []),
             "backend_name": (C.c_char_p, []),
         }
@@ -424,6 +426,14 @@ class Sim:
 
     def pp_merge(self, rnd, recv_ptr):
         self._ck(self.lib.f["pp_merge"](self.h, rnd, C.c_void_p(recv_ptr)), "sim_pp_merge")
+
+    def suspect_requests(self):
+        """(prober, target) pairs of the probes that failed on a slot-less target in the tick just ended, sorted by
+        prober (sharded hosts: gather, merge, inject OP_SUSPECT on every shard); empties the shard's list."""
+        buf = np.zeros((SUSPECT_REQ_MAX, 2), np.uint32)
+        n = C.c_uint32()
+        self._ck(self.lib.f["suspect_requests"](self.h, buf.ctypes.data, SUSPECT_REQ_MAX, C.byref(n)), "sim_suspect_requests")
+        return buf[:n.value].copy()
 
     def recycle_due(self):
         return self._ck(self.lib.f["recycle_due"](self.h), "sim_recycle_due") > 0

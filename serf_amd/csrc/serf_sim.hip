@@ -285,6 +285,7 @@ struct Dev {
                     // {qid, n_ids, tag mask, 0, ids[12]} (QFILT); then [N] bytes, every node's tag class (TAGCLASS)
   u32* qbits;       // [SIM_QT][2][ceil(N/32)] who acked / responded, by global node id
   uint4* nullcell;  // 2 x uint4 of zeros: where the prefetch of a record without a lookup points
+  u32* sreq;        // [1 + 2 * SIM_SUSPECT_REQ_MAX]: count, then the (prober, target) pairs of the tick's slot-less failed probes
   sim_event* events;
   u32* ev_count;
   u32 ev_cap;
@@ -1073,7 +1074,11 @@ __device__ static void swim_probe(const Ctx& c, Node& n, const TickP& tp, const 
   }
   if (ok) { aw_delta(n, -1); return; }
   aw_delta(n, +1);
-  if (!p) { n.overflow++; n.dirty |= DR2; return; }  // model bound: no view slot to hold the suspicion
+  if (!p) {  // no view slot to hold the suspicion yet: taken up next tick, once the target has one (SIM_OP_SUSPECT)
+    u32 i = atomicAdd(d.sreq, 1u);
+    if (i < SIM_SUSPECT_REQ_MAX) { d.sreq[1 + 2 * i] = c.gid; d.sreq[2 + 2 * i] = t; }
+    return;
+  }
   bool dirty = false;
   swim_suspect(c, n, t, e.z, c.gid, wire_meta(SIM_K_SUSPECT, 0, 32), p, e, dirty, ins);
 }
@@ -1891,6 +1896,15 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
         break;
       case SIM_OP_CRASH: n.flags &= ~SIM_RF_UP; break;
       case SIM_OP_REVIVE: n.flags |= SIM_RF_UP; break;
+      case SIM_OP_SUSPECT:  // the suspicion of a probe that failed last tick on a then slot-less target (swim_probe)
+        if (up && d.swim) {
+          uint4* p = view_ptr(c, a);
+          if (p) {
+            uint4 e_ = p[0];
+            swim_suspect(c, n, a, e_.z, gid, wire_meta(SIM_K_SUSPECT, 0, 32), p, e_, dirty, ins);
+          }
+        }
+        break;
       case SIM_OP_DELIVER:  // a record from outside the cluster: notify_message (delegate.rs:157-315) / memberlist's own handling
         if (up) {
           u64 val = ob.val[i];
@@ -2737,7 +2751,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   DA(d.view, (size_t)d.A * Nl * 2)
   DA(d.ering, (size_t)d.Bev * Nl * 2)
   DA(d.qring, (size_t)d.Bq * Nl * 2)
-  DA(d.slot_of, d.N) DA(d.subject_of, d.A) DA(d.walk, d.A) DA(d.upmap, nup) DA(d.nullcell, 4)
+  DA(d.slot_of, d.N) DA(d.subject_of, d.A) DA(d.walk, d.A) DA(d.upmap, nup) DA(d.nullcell, 4) DA(d.sreq, 1 + 2 * SIM_SUSPECT_REQ_MAX)
   DA(d.qtab, QTAB_U4(d.N)) DA(d.qbits, (size_t)SIM_QT * 2 * nup)
   DA(d.events, (size_t)EV_CAP) DA(d.ev_count, 1)
   DA(h->d_base, (size_t)d.N * 2)
@@ -2753,6 +2767,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   HCHECK(zero(d.qpay, (size_t)SIM_Q * Nl * 16));
   HCHECK(zero(d.ev_count, 4));
   HCHECK(zero(d.nullcell, 64));
+  HCHECK(zero(d.sreq, 4));
   HCHECK(zero(d.qtab, QTAB_U4(d.N) * 16)); HCHECK(zero(d.qbits, (size_t)SIM_QT * 2 * nup * 4));
   if (!d.sharded) {  // nothing has been sent yet
     HCHECK(zero(d.obox[0], (size_t)d.fp * Nl * sizeof(sim_packet))); HCHECK(zero(d.obox[1], (size_t)d.fp * Nl * sizeof(sim_packet)));
@@ -2842,6 +2857,7 @@ static u32 op_subject(const sim_handle* h, u32 op, u32 node, u32 a, u32 b) {
     case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: return node;
     case SIM_OP_FORCE_LEAVE: return a;
     case SIM_OP_CRASH: case SIM_OP_REVIVE: case SIM_OP_SET_TAGS: return h->d.swim ? node : NOSLOT;
+    case SIM_OP_SUSPECT: return h->d.swim ? a : NOSLOT;
     case SIM_OP_DELIVER: {  // a member record from outside is about subject `a`
       u32 kind = SIM_META_KIND(b);
       if (kind == SIM_K_JOIN || kind == SIM_K_LEAVE) return a;
@@ -2969,6 +2985,7 @@ static int op_validate(u32 N, u32 op, u32 node, u32 a, u32 b) {
     case SIM_OP_SET_TAGS: if (a >= SIM_TAG_CLASSES) return SIM_EINVAL; break;
     case SIM_OP_QUERY_FILTER_ID: if (!a || b >= N) return SIM_EINVAL; break;
     case SIM_OP_QUERY_FILTER_TAGS: if (!a) return SIM_EINVAL; break;
+    case SIM_OP_SUSPECT: if (a >= N) return SIM_EINVAL; break;
     case SIM_OP_DELIVER: {
       u32 kind = SIM_META_KIND(b);
       if (kind < SIM_K_JOIN || kind > SIM_K_DEAD || (b & ~SIM_META_WIRE_MASK)) return SIM_EINVAL;
@@ -2987,7 +3004,9 @@ static int inject_val(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, 
   if (rc) return rc;
   // an operation that executes now gets its view slot now (and SIM_ENOSLOT if there is none); one scheduled for a
   // later tick gets it when it executes — and is dropped and counted if none is free then (SIMSPEC §2.6)
-  if (tick <= h->tick && op_subject(h, op, node, a, b) != NOSLOT) rc = ensure_slot(h, op_subject(h, op, node, a, b));
+  // (a SIM_OP_SUSPECT always takes its slot when it executes: it is scheduled by the library / the sharded host, and a
+  // full view must count it as dropped the same way in both)
+  if (op != SIM_OP_SUSPECT && tick <= h->tick && op_subject(h, op, node, a, b) != NOSLOT) rc = ensure_slot(h, op_subject(h, op, node, a, b));
   if (rc) return rc;
   size_t pos = h->ops.size();
   h->ops.push_back(OpEnt{tick, op, node, a, b, val});
@@ -3343,6 +3362,36 @@ int sim_step_end(sim_handle* h) {
   h->prev = h->cur_tp;
   h->tick++;
   h->in_tick = false;
+  // Slot-less failed probes of this tick (possible only with packet loss: a target that is really down has a slot): every
+  // shard is here, replay them next tick.  Costs one stream synchronisation per tick — only in runs with SWIM and loss.
+  if (!h->d.sharded && h->d.swim && h->d.loss_u32) {
+    static thread_local std::vector<u32> buf(2 * SIM_SUSPECT_REQ_MAX);
+    u32 n = 0;
+    int rc = sim_suspect_requests(h, buf.data(), SIM_SUSPECT_REQ_MAX, &n);
+    if (rc) return rc;
+    for (u32 i = 0; i < n; ++i)
+      if ((rc = inject_val(h, h->tick, SIM_OP_SUSPECT, buf[2 * i], buf[2 * i + 1], 0, 0)) != SIM_OK) return rc;
+  }
+  return SIM_OK;
+}
+int sim_suspect_requests(sim_handle* h, uint32_t* out, uint32_t cap_pairs, uint32_t* n_pairs) {
+  if (!h || !n_pairs || h->in_tick) return SIM_EINVAL;
+  *n_pairs = 0;
+  if (!h->d.swim || !h->d.loss_u32) return SIM_OK;  // nothing can have been requested
+  u32 n = 0;
+  HCHECK(hipMemcpyAsync(&n, h->d.sreq, 4, hipMemcpyDeviceToHost, h->stream));
+  HCHECK(hipStreamSynchronize(h->stream));
+  if (!n) return SIM_OK;
+  HCHECK(hipMemsetAsync(h->d.sreq, 0, 4, h->stream));
+  if (n > SIM_SUSPECT_REQ_MAX) { h->ops_dropped += n; return SIM_OK; }  // model bound: the whole tick's list is dropped
+  if (n > cap_pairs || !out) return SIM_ERANGE;
+  HCHECK(hipMemcpyAsync(out, h->d.sreq + 1, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+  HCHECK(hipStreamSynchronize(h->stream));
+  std::vector<std::pair<u32, u32>> v(n);
+  for (u32 i = 0; i < n; ++i) v[i] = {out[2 * i], out[2 * i + 1]};
+  std::sort(v.begin(), v.end());  // a node probes once per tick: probers are distinct
+  for (u32 i = 0; i < n; ++i) { out[2 * i] = v[i].first; out[2 * i + 1] = v[i].second; }
+  *n_pairs = n;
   return SIM_OK;
 }
 int sim_step(sim_handle* h, uint32_t n_ticks) {

@@ -45,6 +45,8 @@ class ShardedSim:
         self.n = n_nodes
         self.m = n_nodes // self.world
         self.lo = self.rank * self.m
+        # slot-less failed probes (possible only with the SWIM layer on and packet loss): gathered after every tick
+        self._poll_suspects = bool(kw.get("probe_interval", 0)) and kw.get("loss", 0.0) > 0
         self._pending = []  # async all-to-alls of the round in flight
         self._xt = None     # exchange timing: list of (start, end) event pairs while enabled
 
@@ -121,6 +123,26 @@ class ShardedSim:
         if self.device.type == "cuda":
             self.sim.sync()  # the buffers go away with this frame
 
+    def _suspicions(self):
+        """Probes that failed on a target without a view slot (include/serf_sim.h sim_suspect_requests): every shard's
+        list of the tick just ended, merged in ascending prober order, becomes SIM_OP_SUSPECT operations of the next
+        tick on EVERY shard (the schedule and the slot map are replicated)."""
+        mine = self.sim.suspect_requests().astype("int64")
+        cnt = torch.tensor([len(mine)], dtype=torch.int64, device=self.device)
+        cnts = [torch.zeros_like(cnt) for _ in range(self.world)]
+        dist.all_gather(cnts, cnt, group=self.group)
+        mx = max(int(c[0]) for c in cnts)
+        if mx == 0:
+            return
+        pad = torch.zeros((mx, 2), dtype=torch.int64)
+        pad[:len(mine)] = torch.from_numpy(mine)
+        pad = pad.to(self.device)
+        allp = [torch.zeros_like(pad) for _ in range(self.world)]
+        dist.all_gather(allp, pad, group=self.group)
+        pairs = sorted((int(p[i][0]), int(p[i][1])) for p, c in zip((x.cpu() for x in allp), cnts) for i in range(int(c[0])))
+        for prober, target in pairs:
+            self.sim.inject(self.sim.tick, _ffi.OP_SUSPECT, prober, target, 0)
+
     def step(self, n_ticks=1):
         for _ in range(n_ticks):
             self._drain()
@@ -134,12 +156,14 @@ class ShardedSim:
                 self.sim.step_chunk(0)  # reads recv (packets of the previous round), fills send
                 self.sim.step_end()
                 self._exchange(self.recv[0], self.send, False)
-                continue
-            for c in range(self.chunks):
-                self.sim.step_chunk(c)
-                lo = c * self.chunk_bytes
-                self._exchange(rbuf[lo:lo + self.chunk_bytes], self.send[lo:lo + self.chunk_bytes], True)
-            self.sim.step_end()
+            else:
+                for c in range(self.chunks):
+                    self.sim.step_chunk(c)
+                    lo = c * self.chunk_bytes
+                    self._exchange(rbuf[lo:lo + self.chunk_bytes], self.send[lo:lo + self.chunk_bytes], True)
+                self.sim.step_end()
+            if self._poll_suspects:
+                self._suspicions()
 
     def _exchange(self, recv, send, asynchronous):
         if self._xt is not None:  # measurement mode: bracket the collective with events, no overlap

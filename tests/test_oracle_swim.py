@@ -444,3 +444,30 @@ def test_query_relays_rescue_lost_acks(oracle):
         assert got[relay] <= seen <= n
     assert 0.35 * n < got[0] < 0.65 * n          # one lossy leg: about half arrive
     assert got[3] > got[0] + 0.15 * n            # 1 - 0.5 * (1 - 0.25)^3 ~ 0.79
+
+
+def test_false_suspicion_of_a_slotless_node_is_taken_up_one_tick_late(oracle):
+    """SIMSPEC §2.7 (round 3): with packet loss a probe can fail on a LIVE node that has no view slot.  The prober cannot
+    hold the suspicion in that tick; the pair goes on the tick's request list and comes back as SIM_OP_SUSPECT in the
+    next tick, which gives the target its slot first — the suspicion then runs its course: gossip, the target refutes
+    (incarnation + 1), everybody is back to alive, the slot is recycled.  Nothing is counted as a model-bound drop."""
+    n = 2048
+    kw = dict(fanout=3, view_slots=32, event_ring=16, query_ring=8, probe_interval=3, suspicion_mult=4, suspicion_max_mult=3,
+              loss=0.02, indirect_checks=2, recycle_interval=20, push_pull_interval=10)
+    sim = _ffi.Sim(oracle, _ffi.make_config(n, **kw))
+    for w in range(0, n, 64):
+        sim.watch(w)
+    seen_slots = refuted = 0
+    for t in range(600):
+        sim.step(1)
+        if t % 20 == 0:
+            seen_slots = max(seen_slots, sim.cluster_stats()["slots_in_use"])
+    cs = sim.cluster_stats()
+    rows = sim.dump(_ffi.ARR_ROWS)
+    refuted = int((rows["inc"] > 0).sum())
+    assert seen_slots > 0 and cs["slots_recycled"] > 0, "false suspicions took view slots and gave them back"
+    assert refuted > 0, "suspected live nodes refuted with a higher incarnation"
+    assert cs["overflow"] == 0 and cs["ops_dropped"] == 0, cs
+    assert cs["failed"] == 0 and cs["up"] == n, "nobody was declared dead: the refutation beats the suspicion timeout"
+    ev = sim.drain_events()
+    assert not [e for e in ev if e[2] == _ffi.EV_FAILED]
