@@ -52,7 +52,9 @@ extern "C" {
 #define SIM_MAX_FANOUT 4u
 #define SIM_MAX_CONF 4u /* conf[0] = node that started the suspicion, conf[1..3] = confirmers (k <= 3) */
 #ifndef SIM_S
-#define SIM_S 8u        /* suspicion timers a node can track at once (16-bit view slots) */
+#define SIM_S 16u       /* suspicion timers a node can track at once (16-bit view slots).  At 1 Mi nodes under 1 % packet
+                         * loss there are always two or three FALSE suspicions in flight (0.26 failed probes per tick,
+                         * each alive for the ~8 ticks its refutation takes) next to the real ones: 8 was too tight   */
 #endif
 #define SIM_MAX_AWARENESS 7u /* memberlist awareness_max_multiplier - 1 (lan: 8)      */
 
@@ -201,7 +203,7 @@ typedef struct sim_bucket {
   uint32_t keys[SIM_C];
 } sim_bucket;
 
-/* 96-byte per-node row: the node's own (non-view) state.  serf.rs:133-169 (`SerfCore`): three
+/* 112-byte per-node row: the node's own (non-view) state.  serf.rs:133-169 (`SerfCore`): three
  * Lamport clocks, EventCore/QueryCore min_time, SerfState; plus memberlist's incarnation,
  * awareness and the suspicion timers it is running (memberlist-core). */
 typedef struct sim_row {

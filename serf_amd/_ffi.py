@@ -87,7 +87,7 @@ ROW_DTYPE = np.dtype([("clock", "<u8"), ("event_clock", "<u8"), ("query_clock", 
                       ("event_min", "<u8"), ("query_min", "<u8"), ("flags", "<u4"), ("inc", "<u4"),
                       ("n_known", "<u4"), ("n_failed", "<u4"), ("n_left", "<u4"),
                       ("next_seq", "<u4"), ("overflow", "<u4"), ("susp_next", "<u4"),
-                      ("awareness", "<u4"), ("reap_next", "<u4"), ("susp", "<u2", (8,))])
+                      ("awareness", "<u4"), ("reap_next", "<u4"), ("susp", "<u2", (16,))])
 REC_DTYPE = np.dtype([("key", "<u4"), ("meta", "<u4"), ("val", "<u8")])
 PACKET_DTYPE = np.dtype([("key", "<u4", (4,)), ("val_lo", "<u4", (4,)), ("hi_meta", "<u4", (4,))])  # 12-byte wire records
 VIEW_DTYPE = np.dtype([("ltime", "<u8"), ("inc", "<u4"), ("bits", "<u4"), ("conf", "<u4", (4,))])

@@ -257,7 +257,7 @@ struct Dev {
   uint4* R1;  // {query_clock.lo, query_clock.hi, flags, n_known}
   uint4* R2;  // {n_failed, n_left, next_seq | used-slot mask << 16, overflow}
   uint4* R3;  // {incarnation, susp_next, awareness, reap_next}          (memberlist layer / Reaper)
-  uint4* R4;  // susp[8] x u16: view slot + 1 of each running suspicion timer (memberlist layer)
+  uint4* R4;  // [Nl][2]: susp[16] x u16, view slot + 1 of each running suspicion timer (memberlist layer; rare paths only)
   uint4* R5;  // {event_min.lo, event_min.hi, query_min.lo, query_min.hi} (read when SIM_RF_MINTIME)
   uint4* qkeys;  // [4][Nl]  the 16 sort keys of a node's queue, ascending, 4 per uint4
   uint4* qpay;   // [Q][Nl]  slot-stable wire records {key, wire meta, val.lo, val.hi}
@@ -906,9 +906,10 @@ __device__ static inline void aw_delta(Node& n, int dlt) {
   n.awareness = a < 0 ? 0u : a > (int)SIM_MAX_AWARENESS ? SIM_MAX_AWARENESS : (u32)a;
   n.dirty |= DR3;
 }
-// R4 holds SIM_S = 8 sixteen-bit entries: view slot + 1 of each running suspicion timer (rare paths:
+// R4 holds SIM_S = 16 sixteen-bit entries per node (two uint4): view slot + 1 of each running suspicion timer (rare paths:
 // plain 2-byte accesses)
-__device__ static inline uint16_t* susp_of(const Ctx& c) { return reinterpret_cast<uint16_t*>(&c.d.R4[c.l]); }
+static_assert(SIM_S == 16u, "R4 is laid out as two uint4 per node");
+__device__ static inline uint16_t* susp_of(const Ctx& c) { return reinterpret_cast<uint16_t*>(&c.d.R4[2 * (size_t)c.l]); }
 __device__ static inline void susp_forget(const Ctx& c, u32 slot) {
   uint16_t* sp = susp_of(c);
   for (u32 j = 0; j < SIM_S; ++j)
@@ -2128,8 +2129,10 @@ __global__ void init_dense_self(Dev d) {  // new_in's synthetic notify_join(loca
 }
 
 // canonical sim_row (12 x u64 words) of node l
-__device__ static inline void canon_row(const Dev& d, size_t l, u64 (&w)[12]) {
-  uint4 r0 = d.R0[l], r1 = d.R1[l], r2 = d.R2[l], r3 = d.R3[l], r4 = d.R4[l], r5 = d.R5[l];
+#define ROW_W 14  // u64 words of a canonical sim_row
+static_assert(sizeof(sim_row) == ROW_W * 8, "canonical row");
+__device__ static inline void canon_row(const Dev& d, size_t l, u64 (&w)[ROW_W]) {
+  uint4 r0 = d.R0[l], r1 = d.R1[l], r2 = d.R2[l], r3 = d.R3[l], r4 = d.R4[2 * l], r4b = d.R4[2 * l + 1], r5 = d.R5[l];
   w[0] = (u64)r0.x | ((u64)r0.y << 32);
   w[1] = (u64)r0.z | ((u64)r0.w << 32);
   w[2] = (u64)r1.x | ((u64)r1.y << 32);
@@ -2142,6 +2145,8 @@ __device__ static inline void canon_row(const Dev& d, size_t l, u64 (&w)[12]) {
   w[9] = (u64)r3.z | ((u64)r3.w << 32);              // awareness, reap_next
   w[10] = (u64)r4.x | ((u64)r4.y << 32);
   w[11] = (u64)r4.z | ((u64)r4.w << 32);
+  w[12] = (u64)r4b.x | ((u64)r4b.y << 32);
+  w[13] = (u64)r4b.z | ((u64)r4b.w << 32);
 }
 // canonical sim_record i (drain order) of node l
 __device__ static inline uint4 canon_qrec(const Dev& d, size_t l, u32 i, u32 cnt) {
@@ -2153,9 +2158,9 @@ __device__ static inline uint4 canon_qrec(const Dev& d, size_t l, u32 i, u32 cnt
 }
 __global__ void canon_rows_kernel(Dev d, u64* out) {
   for (size_t l = blockIdx.x * (size_t)blockDim.x + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * blockDim.x) {
-    u64 w[12];
+    u64 w[ROW_W];
     canon_row(d, l, w);
-    for (int i = 0; i < 12; ++i) out[l * 12 + i] = w[i];
+    for (int i = 0; i < ROW_W; ++i) out[l * ROW_W + i] = w[i];
   }
 }
 __global__ void canon_queue_kernel(Dev d, uint4* out) {
@@ -2166,15 +2171,16 @@ __global__ void canon_queue_kernel(Dev d, uint4* out) {
 }
 
 // ---- checkpoint / resume: canonical image -> physical layout ----------------------------------------
-__global__ void restore_rows_kernel(Dev d, const u64* in /* [Nl][12] canonical sim_row */) {
+__global__ void restore_rows_kernel(Dev d, const u64* in /* [Nl][ROW_W] canonical sim_row */) {
   for (size_t l = blockIdx.x * (size_t)blockDim.x + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * blockDim.x) {
-    const u64* w = in + l * 12;
+    const u64* w = in + l * ROW_W;
     u32 used = d.R2[l].z >> 16;  // set by restore_queue_kernel, which runs first
     d.R0[l] = make_uint4((u32)w[0], (u32)(w[0] >> 32), (u32)w[1], (u32)(w[1] >> 32));
     d.R1[l] = make_uint4((u32)w[2], (u32)(w[2] >> 32), (u32)w[5], (u32)w[6]);
     d.R2[l] = make_uint4((u32)(w[6] >> 32), (u32)w[7], ((u32)(w[7] >> 32) & 0xFFFFu) | (used << 16), (u32)w[8]);
     d.R3[l] = make_uint4((u32)(w[5] >> 32), (u32)(w[8] >> 32), (u32)w[9], (u32)(w[9] >> 32));
-    d.R4[l] = make_uint4((u32)w[10], (u32)(w[10] >> 32), (u32)w[11], (u32)(w[11] >> 32));
+    d.R4[2 * l] = make_uint4((u32)w[10], (u32)(w[10] >> 32), (u32)w[11], (u32)(w[11] >> 32));
+    d.R4[2 * l + 1] = make_uint4((u32)w[12], (u32)(w[12] >> 32), (u32)w[13], (u32)(w[13] >> 32));
     d.R5[l] = make_uint4((u32)w[3], (u32)(w[3] >> 32), (u32)w[4], (u32)(w[4] >> 32));
   }
 }
@@ -2279,9 +2285,9 @@ __global__ void digest_aux(const u32* slot_of, const u32* upmap, u32 N, u64* out
 __global__ void digest_rows_queue(Dev d, u64* out_rows, u64* out_queue) {
   u64 ar = 0, aq = 0;
   for (size_t l = blockIdx.x * (size_t)BLOCK + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * BLOCK) {
-    u64 w[12];
+    u64 w[ROW_W];
     canon_row(d, l, w);
-    for (int i = 0; i < 12; ++i) ar += dig(w[i], l * 12 + i);
+    for (int i = 0; i < ROW_W; ++i) ar += dig(w[i], l * ROW_W + i);
     u32 cnt = __popc(d.R2[l].z >> 16);
     for (u32 q = 0; q < SIM_Q; ++q) {
       uint4 e = canon_qrec(d, l, q, cnt);
@@ -2451,7 +2457,7 @@ __global__ void recycle_refd_kernel(Dev d, const uint4* inbox, u32 cur, uint8_t*
       uint4 pay = d.qpay[(size_t)(k & 15u) * d.Nl + l];
       if (member_kind(SIM_META_KIND(pay.y)) && pay.x < d.N) refd[pay.x] = 1;
     }
-    const uint16_t* sp = reinterpret_cast<const uint16_t*>(&d.R4[l]);
+    const uint16_t* sp = reinterpret_cast<const uint16_t*>(&d.R4[2 * l]);
     for (u32 j = 0; j < SIM_S; ++j)
       if (sp[j] && d.subject_of[sp[j] - 1] != NOSLOT) refd[d.subject_of[sp[j] - 1]] = 1;
   }
@@ -2740,7 +2746,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
     sim_destroy(h);                                  \
     return rc;                                       \
   }
-  DA(d.R0, Nl) DA(d.R1, Nl) DA(d.R2, Nl) DA(d.R3, Nl) DA(d.R4, Nl) DA(d.R5, Nl)
+  DA(d.R0, Nl) DA(d.R1, Nl) DA(d.R2, Nl) DA(d.R3, Nl) DA(d.R4, 2 * Nl) DA(d.R5, Nl)
   DA(d.qkeys, 4 * Nl) DA(d.qpay, (size_t)SIM_Q * Nl) DA(d.pend, (size_t)d.npend * Nl)
   h->inbox_mat = nullptr;
   h->mat_tick = ~0ull;
@@ -2763,7 +2769,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   bool joined = cfg->flags & SIM_CF_BASELINE_JOINED;
   hipStream_t s = h->stream;
   auto zero = [&](void* p, size_t bytes) { return hipMemsetAsync(p, 0, bytes, s); };
-  HCHECK(zero(d.R2, Nl * 16)); HCHECK(zero(d.R3, Nl * 16)); HCHECK(zero(d.R4, Nl * 16)); HCHECK(zero(d.R5, Nl * 16));
+  HCHECK(zero(d.R2, Nl * 16)); HCHECK(zero(d.R3, Nl * 16)); HCHECK(zero(d.R4, Nl * 32)); HCHECK(zero(d.R5, Nl * 16));
   HCHECK(zero(d.qpay, (size_t)SIM_Q * Nl * 16));
   HCHECK(zero(d.ev_count, 4));
   HCHECK(zero(d.nullcell, 64));

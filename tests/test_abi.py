@@ -51,7 +51,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     want = [C.sizeof(_ffi.Config), C.sizeof(_ffi.Stats), C.sizeof(_ffi.Event), _ffi.ROW_DTYPE.itemsize,
             _ffi.REC_DTYPE.itemsize, _ffi.VIEW_DTYPE.itemsize, _ffi.BUCKET_DTYPE.itemsize, _ffi.PACKET_DTYPE.itemsize]
     assert got == want
-    assert got[3:] == [96, 16, 32, 32, 48]
+    assert got[3:] == [112, 16, 32, 32, 48]
 
 
 def test_product_has_no_cpu_fallback(hiplib):

@@ -79,7 +79,7 @@ def test_suspect_confirm_and_timer(oracle):
     assert (v["swim"], v["nconf"], v["conf"][0], v["stamp"]) == (SW_SUSPECT, 0, 5, 100)
     assert v["status"] == ALIVE         # serf only hears about it when the node is declared dead
     row = sim.dump(_ffi.ARR_ROWS)[0]
-    assert row["susp_next"] == 100 + T[0] and list(row["susp"]).count(0) == 7
+    assert row["susp_next"] == 100 + T[0] and list(row["susp"]).count(0) == 15
     assert s1.queue_kinds() == [_ffi.K_SUSPECT]
     s1.suspect(9, 0, 5)                 # same accuser again: not a confirmation
     assert s1.view(9)["nconf"] == 0

@@ -2,7 +2,7 @@
 
 The simulator bounds what the reference leaves unbounded: SIM_Q = 16 pooled queue slots (reference: three queues
 of up to 4096 entries, options.rs:513, serf.rs:142-144), SIM_C = 6 keys per de-dup ring bucket (reference: a Vec,
-base.rs:783-813), SIM_S = 8 suspicion timers per node, and `view_slots` active subjects instead of a member map
+base.rs:783-813), SIM_S = 16 suspicion timers per node, and `view_slots` active subjects instead of a member map
 per node.  Every time one of those bounds bites, `sim_row.overflow` is incremented.  The claim the benchmark and
 the parity tests rest on is:  a bounded run with overflow == 0 IS the unbounded run.
 
@@ -49,7 +49,7 @@ def raw(sim, which, dtype):
 
 def compare(b, u, n, A, Bev, Bq, what):
     """b: bounded sim (view_slots = A), u: unbounded sim (dense)."""
-    rb, ru = raw(b, _ffi.ARR_ROWS, row_dtype(8)), raw(u, _ffi.ARR_ROWS, row_dtype(US))
+    rb, ru = raw(b, _ffi.ARR_ROWS, row_dtype(16)), raw(u, _ffi.ARR_ROWS, row_dtype(US))
     assert rb["overflow"].sum() == 0, f"{what}: the bounded run hit a bound — pick a lighter scenario"
     assert ru["overflow"].sum() == 0
     for f in rb.dtype.names:
@@ -63,7 +63,7 @@ def compare(b, u, n, A, Bev, Bq, what):
             subj_of[a] = s_
     sb = rb["susp"].astype(np.int64)
     tb = np.where(sb > 0, subj_of[np.maximum(sb - 1, 0)] + 1, 0)
-    assert (tb == ru["susp"][:, :8]).all() and (ru["susp"][:, 8:] == 0).all(), f"{what}: suspicion timer lists differ"
+    assert (tb == ru["susp"][:, :16]).all() and (ru["susp"][:, 16:] == 0).all(), f"{what}: suspicion timer lists differ"
     qb = b.dump(_ffi.ARR_QUEUE).reshape(n, _ffi.Q)
     qu = u.dump(_ffi.ARR_QUEUE).reshape(n, UQ)
     assert qb.tobytes() == np.ascontiguousarray(qu[:, :_ffi.Q]).tobytes(), f"{what}: queues differ"
@@ -105,7 +105,7 @@ def test_zero_overflow_run_equals_unbounded_run(oracle, unbounded, n, fanout, sw
         u.step(every)
         compare(b, u, n, A, Bev, Bq, f"n={n} swim={swim} tick {t + every}")
     assert b.drain_events() == u.drain_events()
-    rows = raw(b, _ffi.ARR_ROWS, row_dtype(8))
+    rows = raw(b, _ffi.ARR_ROWS, row_dtype(16))
     if swim:
         assert rows["n_failed"].sum() + rows["n_left"].sum() > 0, "scenario should exercise the failure detector"
 
@@ -121,7 +121,7 @@ def test_overflow_is_what_separates_them(oracle, unbounded):
         sc.apply_schedule(s, ops)
     b.step(60)
     u.step(60)
-    rb, ru = raw(b, _ffi.ARR_ROWS, row_dtype(8)), raw(u, _ffi.ARR_ROWS, row_dtype(US))
+    rb, ru = raw(b, _ffi.ARR_ROWS, row_dtype(16)), raw(u, _ffi.ARR_ROWS, row_dtype(US))
     assert rb["overflow"].sum() > 0 and ru["overflow"].sum() == 0
     assert u.cluster_stats()["max_queue"] > _ffi.Q or (rb["event_clock"] != ru["event_clock"]).any() or \
         b.dump(_ffi.ARR_INBOX).tobytes() != u.dump(_ffi.ARR_INBOX).tobytes()
