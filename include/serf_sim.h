@@ -266,6 +266,11 @@ typedef struct sim_config {
                                * budget binds first for small messages; with 16 = SIM_Q a packet can carry the whole
                                * queue and only the byte budget is left                           */
   uint32_t flags;             /* SIM_CF_*                                                       */
+  uint32_t gossip_to_the_dead;/* memberlist gossip_to_the_dead_time in ticks (lan: 30 s = 150; App. B.2): a node whose
+                               * view says the target of one of its packets has been dead / left for longer does not
+                               * gossip to it (kRandomNodes would not have picked it) — here: that packet is not sent,
+                               * the transmits are spent all the same.  0 = every node stays a gossip target          */
+  uint32_t reserved2;         /* keeps `seed` 8-byte aligned                                    */
   uint64_t seed;              /* master seed; default 0x5EEDC0DE5E4F0001                        */
 } sim_config;
 
@@ -274,6 +279,9 @@ typedef struct sim_config {
                                    * kRandomNodes (uniform, no replacement, skip self — App. B.2) instead of the per-tick
                                    * bijection; in-degree is then Poisson-like.  Exists to put an error bar on the bijection's
                                    * effect on rounds-to-99 % (tools/convergence_hist.py --random-fanout) */
+#define SIM_CF_AWARENESS_PROBE 4u  /* memberlist scales its probe interval by the node's health score (awareness, state.go
+                                   * probeNode: ScaleTimeout): a node with score s probes in every (s + 1)-th round of its
+                                   * group's probe phase instead of every round (App. B.3)                              */
 #define SIM_DEFAULT_SEED 0x5EEDC0DE5E4F0001ull
 
 /* Stats — mirrors serf-core/src/serf/api.rs:586-602 (`Stats`) for one simulated node. */

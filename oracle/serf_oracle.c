@@ -922,6 +922,8 @@ static void swim_probe(nctx* c, const tickp* p) {
   /* probe phase: the 64 nodes of an id-aligned group share it (one wavefront on the GPU), groups
    * are staggered over the probe interval like memberlist's randomly started probe tickers */
   if (s->N < 2 || ((uint32_t)s->tick + (c->gid >> 6)) % PI) return;
+  /* SIM_CF_AWARENESS_PROBE: the probe interval scales with the health score (memberlist probeNode: ScaleTimeout) */
+  if ((s->cfg.flags & SIM_CF_AWARENESS_PROBE) && (((uint32_t)s->tick + (c->gid >> 6)) / PI) % (c->row->awareness + 1u)) return;
   uint32_t t = draw_below(probe_draw(p, c->gid, PD_TARGET), s->N - 1);
   if (t >= c->gid) ++t; /* uniform over the other N-1 nodes */
   sim_view* e = view_at(s, c->l, t);
@@ -1284,6 +1286,17 @@ static inline const sim_packet* inbox_cell(const osim* s, uint32_t k, uint32_t p
   return &s->inbox[s->tick & 1][((size_t)k * s->PG + pg) * s->Nl + l];
 }
 
+/* gossip_to_the_dead_time (App. B.2): does this node's view say that `target` has been dead / left for longer than that? */
+static int gossip_skips(osim* s, uint32_t l, uint32_t target) {
+  uint32_t G = s->cfg.gossip_to_the_dead;
+  if (!G) return 0;
+  const sim_view* e = view_at(s, l, target);
+  if (!e) e = &s->base[target];
+  if (!(e->bits & SIM_VB_KNOWN)) return 0;
+  uint32_t sw = SIM_VB_SWIM(e->bits);
+  if (sw != SIM_SWIM_DEAD && sw != SIM_SWIM_LEFT) return 0;
+  return (((uint32_t)s->tick - SIM_VB_STAMP(e->bits)) & STAMP_MASK) > G;
+}
 static void tick_node(osim* s, const tickp* p, uint32_t l) {
   nctx c;
   nctx_init(&c, s, l);
@@ -1333,7 +1346,7 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
     }
     for (uint32_t k = 0; k < p->feff; ++k) {
       size_t cell = (size_t)k * s->Nl + l;
-      if (k >= nc || (up && pkt_lost(p, c.gid, k))) memset(out[k], 0, sizeof out[k]);
+      if (k >= nc || (up && (pkt_lost(p, c.gid, k) || gossip_skips(s, l, chosen[k])))) memset(out[k], 0, sizeof out[k]);
       for (uint32_t pg = 0; pg < PG; ++pg) s->inbox[(s->tick + 1) & 1][((size_t)k * PG + pg) * s->Nl + l] = out[k][pg];
       s->rtgt[cell] = k < nc ? chosen[k] : NOSLOT;
     }
@@ -1343,7 +1356,7 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
   for (uint32_t k = 0; k < p->feff; ++k) {
     uint32_t h, lp;
     fan_target(p, g, ll, k, &h, &lp);
-    if (up && pkt_lost(p, c.gid, k)) memset(out[k], 0, sizeof out[k]);
+    if (up && (pkt_lost(p, c.gid, k) || gossip_skips(s, l, h * p->M + lp))) memset(out[k], 0, sizeof out[k]);
     for (uint32_t pg = 0; pg < PG; ++pg) {
       if (s->cfg.shard_count > 1)
         s->xsend[xcell(p, s->fp, (ll % p->blk) / p->sub, h, k * PG + pg, lp)] = out[k][pg];

@@ -295,6 +295,8 @@ struct Dev {
   u32 bev_mask, bq_mask;  // B - 1 when B is a power of two (> 1), else 0
   u32 swim, PI, kconf, ic, T[SIM_MAX_CONF];
   u32 loss_u32;
+  u32 aw_probe;  // SIM_CF_AWARENESS_PROBE
+  u32 gttd;      // gossip_to_the_dead in ticks (0 = off)
   u32 r3on;  // R3 is live: SWIM layer or Reaper configured
   u32 reap_interval, reconnect_timeout, tombstone_timeout, intent_timeout;
   u32 queue_check_interval, max_queue_depth, min_queue_depth;
@@ -1056,6 +1058,8 @@ __device__ static inline bool leg_lost(const TickP& tp, u32 gid, u32 j) {
 __device__ static inline bool up_of(const Dev& d, u32 gid) { return (d.upmap[gid >> 5] >> (gid & 31)) & 1u; }
 __device__ static void swim_probe(const Ctx& c, Node& n, const TickP& tp, const uint4* base, Ins& ins) {
   const Dev& d = c.d;
+  // SIM_CF_AWARENESS_PROBE: the probe interval scales with the health score (memberlist probeNode: ScaleTimeout)
+  if (d.aw_probe && ((c.tick + (c.gid >> 6)) / d.PI) % (n.awareness + 1u)) return;
   u32 t = draw_below(probe_draw(tp, c.gid, PD_TARGET), d.N - 1);
   if (t >= c.gid) ++t;
   uint4* p = view_ptr(c, t);
@@ -1534,6 +1538,18 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
   }
   TT(7);
   u32 limit = up ? d.retransmit_mult * digits10(n.nknown) : 0;
+  // gossip_to_the_dead_time (App. B.2; oracle gossip_skips): this node's view says the target of its packet k has been dead
+  // or left for longer than that — the packet is not sent (off unless configured: the general per-node form of the map)
+  auto gossip_skips = [&](u32 k) __attribute__((always_inline)) -> bool {
+    if (!d.gttd) return false;
+    u32 hh, tt;
+    fan_target_g(tp, g, ll, k, hh, tt);
+    u32 target = hh * tp.M + tt;
+    const uint4* vp = view_ptr(c, target);
+    uint4 e = vp ? vp[0] : base[(size_t)target * 2];
+    u32 sw = SIM_VB_SWIM(e.w);
+    return (e.w & SIM_VB_KNOWN) && (sw == SIM_SWIM_DEAD || sw == SIM_SWIM_LEFT) && ((((u32)tp.tick - SIM_VB_STAMP(e.w)) & STAMP_MASK) > d.gttd);
+  };
   const bool coop = (blockIdx.x + 1u) * TBLOCK <= cnt;  // every lane of the block is here
   // One 48-byte cell per lane that has one (`wr`), written quad-cooperatively when the whole wave is here:
   // three lanes of a quad write one whole cell per store instruction (lane i < 3 writes part i of quad-mate
@@ -1570,7 +1586,7 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
       if (up && (u32)k < tp.feff) {
         u64 nb; u32 c;
         q_round_mp(n, sk, limit, d.P, nb, c);
-        bool lost = tp.loss_u32 && (u32)(mix64(tp.loss_base ^ ((u64)gid * 4u + k)) >> 32) < tp.loss_u32;
+        bool lost = (tp.loss_u32 && (u32)(mix64(tp.loss_base ^ ((u64)gid * 4u + k)) >> 32) < tp.loss_u32) || gossip_skips((u32)k);
         if (!lost) { nib[k] = nb; cn[k] = c; }
       }
     }
@@ -1660,7 +1676,7 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
     slots[k] = 0xFFFFFFFFu;
     if (up && (u32)k < tp.feff) {
       u32 s = small ? q_round8(n, sk, limit) : q_round(n, sk, limit);
-      bool lost = tp.loss_u32 && (u32)(mix64(tp.loss_base ^ ((u64)gid * 4u + k)) >> 32) < tp.loss_u32;
+      bool lost = (tp.loss_u32 && (u32)(mix64(tp.loss_base ^ ((u64)gid * 4u + k)) >> 32) < tp.loss_u32) || gossip_skips((u32)k);
       if (!lost) slots[k] = s;
     }
   }
@@ -2730,6 +2746,8 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   d.min_queue_depth = cfg->min_queue_depth;
   d.r3on = d.swim || d.reap_interval;
   d.loss_u32 = cfg->loss_u32;
+  d.aw_probe = (cfg->flags & SIM_CF_AWARENESS_PROBE) ? 1u : 0u;
+  d.gttd = cfg->gossip_to_the_dead;
   h->qt_cursor = 0;
   h->q_timeout = 16u * h_digits10(cfg->n_nodes);  // query.rs:421-427, query_timeout_mult = 16 (options.rs:518)
   h->pp_step = 0;

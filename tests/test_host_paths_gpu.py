@@ -163,3 +163,28 @@ def test_byte_boundary_of_the_delegate_on_the_gpu(oracle, hiplib):
         off += used
         names.append(m.name)
     assert sorted(names) == sorted(b"ev%d" % i for i in range(14))
+
+
+def test_memberlist_flags_on_the_gpu(oracle, hiplib):
+    # tests/test_oracle_swim.py::test_gossip_to_the_dead_time and ::test_awareness_scales_the_probe_interval on the HIP
+    # library, the oracle beside it tick by tick
+    n = 512
+    kw = dict(fanout=3, view_slots=32, event_ring=16, query_ring=8, probe_interval=2, suspicion_mult=4, suspicion_max_mult=2)
+    for gttd, want in ((0, _ffi.STATUS_ALIVE), (1, _ffi.STATUS_FAILED)):
+        g, o = both(oracle, hiplib, n, gossip_to_the_dead=gttd, **kw)
+        for s in (g, o):
+            s.inject(3, _ffi.OP_CRASH, 10)
+            s.inject(32, _ffi.OP_REVIVE, 10)
+        for t in range(120):
+            g.step(1)
+            o.step(1)
+            assert g.digest() == o.digest(), f"gossip_to_the_dead {gttd}: tick {t}"
+        assert int(g.members(200)[0][10]) == want
+    g, o = both(oracle, hiplib, 1024, awareness_probe=True, **dict(kw, suspicion_mult=6, suspicion_max_mult=3))
+    for s in (g, o):
+        for x in range(100, 1000, 45):
+            s.inject(2, _ffi.OP_CRASH, x)
+    for t in range(80):
+        g.step(1)
+        o.step(1)
+        assert g.digest() == o.digest(), f"awareness probe: tick {t}"

@@ -471,3 +471,52 @@ def test_false_suspicion_of_a_slotless_node_is_taken_up_one_tick_late(oracle):
     assert cs["failed"] == 0 and cs["up"] == n, "nobody was declared dead: the refutation beats the suspicion timeout"
     ev = sim.drain_events()
     assert not [e for e in ev if e[2] == _ffi.EV_FAILED]
+
+
+def test_gossip_to_the_dead_time(oracle):
+    """memberlist gossip_to_the_dead_time (App. B.2; sim_config.gossip_to_the_dead): a node keeps gossiping to a member it
+    believes dead for that long and no longer — the window in which a node that was wrongly declared dead (here: one that
+    comes back right after the declaration) still hears its obituary and refutes.  Node 10 goes down at tick 3, is declared
+    dead around tick 24 - 30 and resumes at tick 32 with its old state: with the window open it refutes and is alive
+    again; with a one-tick window nobody talks to it any more and it stays failed (no push-pull in this run)."""
+    n = 512
+    kw = dict(fanout=3, view_slots=32, event_ring=16, query_ring=8, probe_interval=2, suspicion_mult=4, suspicion_max_mult=2)
+    res = {}
+    for g in (0, 1):
+        sim = _ffi.Sim(oracle, _ffi.make_config(n, gossip_to_the_dead=g, **kw))
+        sim.inject(3, _ffi.OP_CRASH, 10)
+        sim.inject(32, _ffi.OP_REVIVE, 10)
+        sim.step(120)
+        st, _ = sim.members(200)
+        res[g] = (int(st[10]), int(sim.dump(_ffi.ARR_ROWS)["inc"][10]), sim.cluster_stats()["overflow"])
+    assert res[0] == (_ffi.STATUS_ALIVE, 1, 0), res
+    assert res[1] == (_ffi.STATUS_FAILED, 0, 0), res
+
+
+def test_awareness_scales_the_probe_interval(oracle):
+    """SIM_CF_AWARENESS_PROBE (memberlist probeNode: probe interval = ScaleTimeout(ProbeInterval) = (score + 1) x): a node
+    with health score s probes only in every (s + 1)-th round of its group's probe phase.  In a run with crashes only, a
+    node's score changes exactly when it probes (awareness_test.go: -1 on success, +1 on failure)."""
+    n, PI = 1024, 2
+    kw = dict(fanout=3, view_slots=32, event_ring=16, query_ring=8, probe_interval=PI, suspicion_mult=6, suspicion_max_mult=3)
+    traj = {}
+    for flag in (False, True):
+        sim = _ffi.Sim(oracle, _ffi.make_config(n, awareness_probe=flag, **kw))
+        for x in range(100, 1000, 45):      # twenty nodes down: one probe in fifty fails
+            sim.inject(2, _ffi.OP_CRASH, x)
+        prev = sim.dump(_ffi.ARR_ROWS)["awareness"].astype(np.int64)
+        sums, moved = [], 0
+        for t in range(60):
+            sim.step(1)                     # executes tick t
+            aw = sim.dump(_ffi.ARR_ROWS)["awareness"].astype(np.int64)
+            ch = np.nonzero(aw != prev)[0]
+            if flag:
+                rounds = (t + (ch >> 6)) // PI
+                assert ((t + (ch >> 6)) % PI == 0).all()
+                assert (rounds % (prev[ch] + 1) == 0).all(), f"tick {t}: a node with score s probed outside every (s+1)-th round"
+            moved += len(ch)
+            sums.append(int(aw.sum()))
+            prev = aw
+        traj[flag] = sums
+        assert moved > 20
+    assert traj[True] != traj[False] and sum(traj[True]) >= sum(traj[False]), "degraded nodes recover more slowly when they probe less often"
