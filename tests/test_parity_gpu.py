@@ -339,6 +339,15 @@ def test_config3_1m_properties(hiplib):
     assert g.dump(_ffi.ARR_QUEUE)["meta"].min() == 0xFFFFFFFF
 
 
+def _suspicions_on_one_gpu(shards):
+    """serf_amd/shard.py ShardedSim._suspicions for hand-driven shards: every shard's slot-less failed probes of the tick
+    just ended, merged in ascending prober order, become SIM_OP_SUSPECT operations of the next tick on every shard."""
+    pairs = sorted((int(a), int(b)) for s in shards for a, b in s.suspect_requests())
+    for s in shards:
+        for prober, target in pairs:
+            s.inject(s.tick, _ffi.OP_SUSPECT, prober, target, 0)
+
+
 def _push_pull_on_one_gpu(shards):
     """The cross-shard push-pull batch of serf_amd/shard.py with device-to-device copies standing in for the
     all-to-all-v: two rounds of sim_pp_export -> move every (source, destination) slice -> sim_pp_merge."""
@@ -416,6 +425,7 @@ def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim, chunks, pkt
                         send[src][c * region + g * slab:c * region + (g + 1) * slab])
         for s in shards:
             s.step_end()
+        _suspicions_on_one_gpu(shards)
         torch.cuda.synchronize()
         ref.step(1)
         if t % 7 == 0 or t == ticks - 1:
@@ -501,6 +511,7 @@ def test_sharded_kernel_b64_four_shards_of_64k_on_one_gpu(oracle, hiplib):
                         send[src][c * region + g * slab:c * region + (g + 1) * slab])
         for s in shards:
             s.step_end()
+        _suspicions_on_one_gpu(shards)
         torch.cuda.synchronize()
         ref.step(1)
         if t % 25 == 0 or t == ticks - 1:
@@ -634,6 +645,7 @@ def test_view_slot_recycling_four_shards_on_one_gpu(oracle, hiplib):
         for s in shards:
             s.step_chunk(0)
             s.step_end()
+        _suspicions_on_one_gpu(shards)
         for s in shards:
             s.sync()
         for r in range(V):
