@@ -321,8 +321,12 @@ struct sim_handle {
    * name, payload — what sim_peek_packet encodes */
   /* probes of the running tick that failed on a target without a view slot: (prober, target) pairs, appended by
    * tick_node (any thread), turned into SIM_OP_SUSPECT operations of the next tick by step_end (SIMSPEC §2.7) */
-  uint32_t* sreq;      /* [SIM_SUSPECT_REQ_MAX][2] */
+  uint32_t* sreq;      /* [SIM_SUSPECT_REQ_MAX][2] requests of the running tick */
   uint32_t sreq_n;     /* requests made (may exceed the capacity: then all are dropped) */
+  uint32_t* sreq_prev; /* the previous tick's requests, sorted by prober: replayed as operations of the NEXT tick, i.e. two
+                        * ticks after the probe (the HIP library reads its device list with one tick of lag, so that
+                        * no tick has to wait for the one before it) */
+  uint32_t sreq_prev_n;
   struct evreg { uint32_t key, nlen, plen; uint8_t* bytes; } *evreg;
   size_t n_evreg, cap_evreg;
 };
@@ -1373,7 +1377,17 @@ static void recycle_local(osim* s);
 static uint32_t op_subject(const osim* s, uint32_t op, uint32_t node, uint32_t a, uint32_t b);
 static int ensure_slot(osim* s, uint32_t subject);
 static const sim_packet* cur_inbox(const osim* s);
+static int sreq_cmp(const void* a, const void* b);
+static void sreq_rotate(osim* s) { /* the finished tick's list becomes the previous one */
+  uint32_t n = s->sreq_n;
+  s->sreq_n = 0;
+  if (n > SIM_SUSPECT_REQ_MAX) { s->ops_dropped += n; n = 0; } /* model bound: the whole tick's list is dropped */
+  qsort(s->sreq, n, 2 * sizeof(uint32_t), sreq_cmp); /* a node probes once per tick: probers are distinct */
+  memcpy(s->sreq_prev, s->sreq, (size_t)n * 2 * sizeof(uint32_t));
+  s->sreq_prev_n = n;
+}
 static void step_begin(osim* s) {
+  sreq_rotate(s);
   tickp* p = &s->cur;
   tickp_make(p, &s->cfg, s->tick);
   if (s->cfg.shard_count > 1) s->xrecv = s->rbuf[(s->tick + 1) & 1];
@@ -1437,10 +1451,9 @@ static void step_end(osim* s) {
   s->prev = p;
   s->tick++;
   s->in_tick = 0;
-  if (s->cfg.shard_count <= 1 && s->sreq_n) { /* every shard is here: replay the tick's slot-less suspicions next tick */
-    uint32_t buf[2 * SIM_SUSPECT_REQ_MAX], n = 0;
-    API(suspect_requests)(s, buf, SIM_SUSPECT_REQ_MAX, &n);
-    for (uint32_t i = 0; i < n; ++i) inject_val(s, s->tick, SIM_OP_SUSPECT, buf[2 * i], buf[2 * i + 1], 0, 0);
+  if (s->cfg.shard_count <= 1 && s->sreq_prev_n) { /* every shard is here: replay the PREVIOUS tick's slot-less suspicions next tick */
+    for (uint32_t i = 0; i < s->sreq_prev_n; ++i) inject_val(s, s->tick, SIM_OP_SUSPECT, s->sreq_prev[2 * i], s->sreq_prev[2 * i + 1], 0, 0);
+    s->sreq_prev_n = 0;
   }
 }
 static void step_one(osim* s) {
@@ -1505,7 +1518,7 @@ static int cfg_check(const sim_config* c) {
 
 int API(destroy)(osim* s) {
   if (!s) return SIM_EINVAL;
-  free(s->sreq);
+  free(s->sreq); free(s->sreq_prev);
   for (size_t i = 0; i < s->n_evreg; ++i) free(s->evreg[i].bytes);
   free(s->evreg);
   free(s->rows); free(s->queue); free(s->inbox[0]); free(s->inbox[1]);
@@ -1560,6 +1573,7 @@ int API(create)(const sim_config* cfg, osim** out) {
   s->qbits = (uint32_t*)calloc((size_t)SIM_QT * 2 * (((size_t)s->N + 31) / 32), sizeof(uint32_t));
   s->tagclass = (uint8_t*)calloc(s->N, 1);
   s->sreq = (uint32_t*)malloc((size_t)SIM_SUSPECT_REQ_MAX * 2 * sizeof(uint32_t));
+  s->sreq_prev = (uint32_t*)malloc((size_t)SIM_SUSPECT_REQ_MAX * 2 * sizeof(uint32_t));
   s->q_timeout = 16u * digits10(s->N); /* query.rs:421-427 with query_timeout_mult = 16 (options.rs:518) */
   pp_params(cfg, &s->pp_step, &s->pp_groups);
   if (!s->qbits || !s->upmap || !s->rows || !s->queue || !s->view || !s->ering || !s->qring || !s->slot_of ||
@@ -1732,6 +1746,17 @@ static void recycle_scan(osim* s, rc_cand* c, uint32_t n) {
   free(refd);
 }
 static void recycle_apply(osim* s, const rc_cand* c, uint32_t n) {
+  { /* a candidate that was examined and could not go to the back of the line: it is looked at again one interval from now,
+     * after the others — otherwise 64 entries that stay unsettled for long (a straggler waiting for its push-pull, a node
+     * that is down) would be the only ones ever examined */
+    rc_cand ex[SIM_RECYCLE_BATCH];
+    uint32_t ne = recycle_candidates(s, ex);
+    for (uint32_t j = 0; j < ne; ++j) {
+      int agreed = 0;
+      for (uint32_t i = 0; i < n; ++i) agreed |= (c[i].subject == ex[j].subject);
+      if (!agreed) s->alloc_tick[ex[j].slot] = (uint32_t)s->tick;
+    }
+  }
   for (uint32_t i = 0; i < n; ++i) {
     uint32_t x = c[i].subject, a = s->slot_of[x];
     if (a == NOSLOT) continue;
@@ -2246,6 +2271,12 @@ static void snap_sections(osim* s, const void* ptr[SNAP_SECTIONS], size_t len[SN
 int API(snapshot)(osim* s, void* buf, size_t cap, size_t* bytes) {
   if (!s || !bytes) return SIM_EINVAL;
   if (s->in_tick) return SIM_ESTATE;
+  if (s->cfg.shard_count <= 1 && (s->sreq_prev_n || s->sreq_n)) { /* slot-less failed probes not yet replayed: into the schedule, so that the image holds them */
+    for (uint32_t i = 0; i < s->sreq_prev_n; ++i) inject_val(s, s->tick, SIM_OP_SUSPECT, s->sreq_prev[2 * i], s->sreq_prev[2 * i + 1], 0, 0);
+    sreq_rotate(s);
+    for (uint32_t i = 0; i < s->sreq_prev_n; ++i) inject_val(s, s->tick + 1, SIM_OP_SUSPECT, s->sreq_prev[2 * i], s->sreq_prev[2 * i + 1], 0, 0);
+    s->sreq_prev_n = 0;
+  }
   const void* ptr[SNAP_SECTIONS];
   size_t len[SNAP_SECTIONS], tot = sizeof(snap_header);
   snap_sections(s, ptr, len);
@@ -2494,13 +2525,11 @@ static int sreq_cmp(const void* a, const void* b) {
 }
 int API(suspect_requests)(osim* s, uint32_t* out, uint32_t cap_pairs, uint32_t* n_pairs) {
   if (!s || !n_pairs || s->in_tick) return SIM_EINVAL;
-  uint32_t n = s->sreq_n;
-  s->sreq_n = 0;
+  uint32_t n = s->sreq_prev_n; /* the requests of the tick BEFORE the one that just ended */
   *n_pairs = 0;
-  if (n > SIM_SUSPECT_REQ_MAX) { s->ops_dropped += n; return SIM_OK; } /* model bound: the whole tick's list is dropped */
   if (n > cap_pairs || (n && !out)) return SIM_ERANGE;
-  qsort(s->sreq, n, 2 * sizeof(uint32_t), sreq_cmp); /* a node probes once per tick: probers are distinct */
-  memcpy(out, s->sreq, (size_t)n * 2 * sizeof(uint32_t));
+  memcpy(out, s->sreq_prev, (size_t)n * 2 * sizeof(uint32_t));
+  s->sreq_prev_n = 0;
   *n_pairs = n;
   return SIM_OK;
 }

@@ -285,7 +285,8 @@ struct Dev {
                     // {qid, n_ids, tag mask, 0, ids[12]} (QFILT); then [N] bytes, every node's tag class (TAGCLASS)
   u32* qbits;       // [SIM_QT][2][ceil(N/32)] who acked / responded, by global node id
   uint4* nullcell;  // 2 x uint4 of zeros: where the prefetch of a record without a lookup points
-  u32* sreq;        // [1 + 2 * SIM_SUSPECT_REQ_MAX]: count, then the (prober, target) pairs of the tick's slot-less failed probes
+  u32* sreq;        // [1 + 2 * SIM_SUSPECT_REQ_MAX]: count, then the (prober, target) pairs of the running tick's slot-less
+                    // failed probes (one of two buffers, by tick parity: the host reads a tick's list one tick later)
   sim_event* events;
   u32* ev_count;
   u32 ev_cap;
@@ -2588,6 +2589,13 @@ struct sim_handle {
   u32 profiling;  // 0 = off, n = HIP events around every n-th tick-kernel launch
   u64 prof_seq;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof;  // one event pair per tick-kernel launch
+  // slot-less failed probes (SIMSPEC §2.7): device lists by tick parity, their heads copied to pinned host memory behind
+  // every tick's launch; the list of tick t is read at the end of tick t + 1 — by then the copy has long landed, nobody
+  // waits for a kernel — and replayed as operations of tick t + 2
+  u32* sreq_buf[2];
+  u32* sreq_host[2];       // pinned: count + the first SREQ_HEAD pairs
+  hipEvent_t sreq_ev[2];
+  u64 sreq_tick[2];        // the tick whose list sits in the buffer (~0: none / consumed)
   u32 pp_step;  // push-pull batches: every pp_step ticks one of PP_GROUPS pair classes synchronises (0 = off)
   TickP cur_tp;            // parameters of the tick between sim_step_begin and sim_step_end
   bool in_tick, tick_timed, tick_bracket;
@@ -2668,6 +2676,7 @@ static int dalloc(sim_handle* h, T** p, size_t n) {
 }
 static inline int grid_for(size_t n) { return (int)std::min<size_t>((n + BLOCK - 1) / BLOCK, 8192); }
 #define EV_CAP (1u << 20)
+#define SREQ_HEAD 62u  // pairs of a tick's request list that travel with the per-tick copy (a longer list is fetched when it is read)
 
 extern "C" {
 
@@ -2690,6 +2699,10 @@ int sim_destroy(sim_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   for (auto& pr : h->prof) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (h->d_pp) (void)hipFree(h->d_pp);
+  for (int i = 0; i < 2; ++i) {
+    if (h->sreq_host[i]) (void)hipHostFree(h->sreq_host[i]);
+    if (h->sreq_ev[i]) (void)hipEventDestroy(h->sreq_ev[i]);
+  }
   for (void* p : h->allocs) (void)hipFree(p);
   delete h;
   return SIM_OK;
@@ -2712,6 +2725,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   h->bound = false;
   h->n_alloc = 0; h->ops_dropped = h->slots_recycled = 0; h->recycle_at = 0xFFFFFFFFu;
   h->pp_done_at = 0xFFFFFFFFu; h->d_pp = nullptr;
+  h->sreq_host[0] = h->sreq_host[1] = nullptr; h->sreq_ev[0] = h->sreq_ev[1] = nullptr; h->sreq_buf[0] = h->sreq_buf[1] = nullptr;
   h->in_tick = false;
   h->tick_timed = false;
   h->rbuf[0] = h->rbuf[1] = nullptr;
@@ -2775,7 +2789,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   DA(d.view, (size_t)d.A * Nl * 2)
   DA(d.ering, (size_t)d.Bev * Nl * 2)
   DA(d.qring, (size_t)d.Bq * Nl * 2)
-  DA(d.slot_of, d.N) DA(d.subject_of, d.A) DA(d.walk, d.A) DA(d.upmap, nup) DA(d.nullcell, 4) DA(d.sreq, 1 + 2 * SIM_SUSPECT_REQ_MAX)
+  DA(d.slot_of, d.N) DA(d.subject_of, d.A) DA(d.walk, d.A) DA(d.upmap, nup) DA(d.nullcell, 4) DA(h->sreq_buf[0], 1 + 2 * SIM_SUSPECT_REQ_MAX) DA(h->sreq_buf[1], 1 + 2 * SIM_SUSPECT_REQ_MAX)
   DA(d.qtab, QTAB_U4(d.N)) DA(d.qbits, (size_t)SIM_QT * 2 * nup)
   DA(d.events, (size_t)EV_CAP) DA(d.ev_count, 1)
   DA(h->d_base, (size_t)d.N * 2)
@@ -2791,7 +2805,13 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   HCHECK(zero(d.qpay, (size_t)SIM_Q * Nl * 16));
   HCHECK(zero(d.ev_count, 4));
   HCHECK(zero(d.nullcell, 64));
-  HCHECK(zero(d.sreq, 4));
+  HCHECK(zero(h->sreq_buf[0], 4)); HCHECK(zero(h->sreq_buf[1], 4));
+  d.sreq = h->sreq_buf[0];
+  for (int i = 0; i < 2; ++i) {
+    HCHECK(hipHostMalloc((void**)&h->sreq_host[i], (1 + 2 * SREQ_HEAD) * 4));
+    HCHECK(hipEventCreateWithFlags(&h->sreq_ev[i], hipEventDisableTiming));
+    h->sreq_tick[i] = ~0ull;
+  }
   HCHECK(zero(d.qtab, QTAB_U4(d.N) * 16)); HCHECK(zero(d.qbits, (size_t)SIM_QT * 2 * nup * 4));
   if (!d.sharded) {  // nothing has been sent yet
     HCHECK(zero(d.obox[0], (size_t)d.fp * Nl * sizeof(sim_packet))); HCHECK(zero(d.obox[1], (size_t)d.fp * Nl * sizeof(sim_packet)));
@@ -2846,6 +2866,8 @@ int sim_set_stream(sim_handle* h, void* st) {
 }
 
 static const uint4* cur_inbox(sim_handle* h);
+static int sreq_take(sim_handle* h, u64 t, uint32_t* out, uint32_t cap_pairs, uint32_t* n_pairs);
+static int inject_val(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, uint32_t b, uint64_t val);
 static void walk_upload(sim_handle* h) {  // h->walk -> d.walk (synchronous: the host vector changes again later)
   if (!h->walk.empty()) (void)hipMemcpy(h->d.walk, h->walk.data(), h->walk.size() * 4, hipMemcpyHostToDevice);
 }
@@ -2962,6 +2984,15 @@ static int recycle_scan(sim_handle* h, sim_recycle_cand* c, u32 n) {
 }
 static int recycle_apply(sim_handle* h, const sim_recycle_cand* c, u32 n) {
   Dev& d = h->d;
+  {  // a candidate that was examined and could not go goes to the back of the line (oracle recycle_apply)
+    sim_recycle_cand ex[SIM_RECYCLE_BATCH];
+    u32 ne = recycle_candidates(h, ex);
+    for (u32 j = 0; j < ne; ++j) {
+      bool agreed = false;
+      for (u32 i = 0; i < n; ++i) agreed |= c[i].subject == ex[j].subject;
+      if (!agreed) h->alloc_tick[ex[j].slot] = (u32)h->tick;
+    }
+  }
   for (u32 i = 0; i < n; ++i) {
     u32 x = c[i].subject;
     if (x >= d.N) return SIM_EINVAL;
@@ -3267,6 +3298,10 @@ int sim_step_begin(sim_handle* h) {
     int rc = recycle_local(h);
     if (rc) return rc;
   }
+  if (d.swim) {  // this tick's request list (the other buffer holds the previous tick's until it has been read)
+    d.sreq = h->sreq_buf[h->tick & 1];
+    HCHECK(hipMemsetAsync(d.sreq, 0, 4, h->stream));
+  }
   TickP& tp = h->cur_tp;
   tickp_make(&tp, &h->cfg, h->tick);
 #ifdef TICK_ABLATE
@@ -3386,37 +3421,51 @@ int sim_step_end(sim_handle* h) {
   h->prev = h->cur_tp;
   h->tick++;
   h->in_tick = false;
-  // Slot-less failed probes of this tick (possible only with packet loss: a target that is really down has a slot): every
-  // shard is here, replay them next tick.  Costs one stream synchronisation per tick — only in runs with SWIM and loss.
-  if (!h->d.sharded && h->d.swim && h->d.loss_u32) {
-    static thread_local std::vector<u32> buf(2 * SIM_SUSPECT_REQ_MAX);
-    u32 n = 0;
-    int rc = sim_suspect_requests(h, buf.data(), SIM_SUSPECT_REQ_MAX, &n);
-    if (rc) return rc;
-    for (u32 i = 0; i < n; ++i)
-      if ((rc = inject_val(h, h->tick, SIM_OP_SUSPECT, buf[2 * i], buf[2 * i + 1], 0, 0)) != SIM_OK) return rc;
+  // Slot-less failed probes: the head of this tick's list follows the launch into pinned memory; the list of the tick
+  // BEFORE is read now (its copy landed a whole tick ago) and, every shard being here, replayed next tick.
+  if (h->d.swim) {
+    const u64 t = h->tick - 1;  // the tick that just ended
+    HCHECK(hipMemcpyAsync(h->sreq_host[t & 1], h->sreq_buf[t & 1], (1 + 2 * SREQ_HEAD) * 4, hipMemcpyDeviceToHost, h->stream));
+    HCHECK(hipEventRecord(h->sreq_ev[t & 1], h->stream));
+    h->sreq_tick[t & 1] = t;
+    if (!h->d.sharded) {
+      static thread_local std::vector<u32> buf(2 * SIM_SUSPECT_REQ_MAX);
+      u32 n = 0;
+      int rc = sim_suspect_requests(h, buf.data(), SIM_SUSPECT_REQ_MAX, &n);
+      if (rc) return rc;
+      for (u32 i = 0; i < n; ++i)
+        if ((rc = inject_val(h, h->tick, SIM_OP_SUSPECT, buf[2 * i], buf[2 * i + 1], 0, 0)) != SIM_OK) return rc;
+    }
   }
   return SIM_OK;
 }
-int sim_suspect_requests(sim_handle* h, uint32_t* out, uint32_t cap_pairs, uint32_t* n_pairs) {
-  if (!h || !n_pairs || h->in_tick) return SIM_EINVAL;
+// the list of one finished tick out of its buffer (sorted by prober); marks it read
+static int sreq_take(sim_handle* h, u64 t, uint32_t* out, uint32_t cap_pairs, uint32_t* n_pairs) {
   *n_pairs = 0;
-  if (!h->d.swim || !h->d.loss_u32) return SIM_OK;  // nothing can have been requested
-  u32 n = 0;
-  HCHECK(hipMemcpyAsync(&n, h->d.sreq, 4, hipMemcpyDeviceToHost, h->stream));
-  HCHECK(hipStreamSynchronize(h->stream));
+  if (h->sreq_tick[t & 1] != t) return SIM_OK;  // nothing recorded for that tick, or read already
+  h->sreq_tick[t & 1] = ~0ull;
+  HCHECK(hipEventSynchronize(h->sreq_ev[t & 1]));
+  u32 n = h->sreq_host[t & 1][0];
   if (!n) return SIM_OK;
-  HCHECK(hipMemsetAsync(h->d.sreq, 0, 4, h->stream));
   if (n > SIM_SUSPECT_REQ_MAX) { h->ops_dropped += n; return SIM_OK; }  // model bound: the whole tick's list is dropped
   if (n > cap_pairs || !out) return SIM_ERANGE;
-  HCHECK(hipMemcpyAsync(out, h->d.sreq + 1, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
-  HCHECK(hipStreamSynchronize(h->stream));
+  if (n <= SREQ_HEAD) memcpy(out, h->sreq_host[t & 1] + 1, (size_t)n * 8);
+  else {  // a long list: the buffer on the device is untouched until the tick after next begins
+    HCHECK(hipMemcpyAsync(out, h->sreq_buf[t & 1] + 1, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    HCHECK(hipStreamSynchronize(h->stream));
+  }
   std::vector<std::pair<u32, u32>> v(n);
   for (u32 i = 0; i < n; ++i) v[i] = {out[2 * i], out[2 * i + 1]};
   std::sort(v.begin(), v.end());  // a node probes once per tick: probers are distinct
   for (u32 i = 0; i < n; ++i) { out[2 * i] = v[i].first; out[2 * i + 1] = v[i].second; }
   *n_pairs = n;
   return SIM_OK;
+}
+int sim_suspect_requests(sim_handle* h, uint32_t* out, uint32_t cap_pairs, uint32_t* n_pairs) {
+  if (!h || !n_pairs || h->in_tick) return SIM_EINVAL;
+  *n_pairs = 0;
+  if (!h->d.swim || h->tick < 2) return SIM_OK;
+  return sreq_take(h, h->tick - 2, out, cap_pairs, n_pairs);  // the requests of the tick BEFORE the one that just ended
 }
 int sim_step(sim_handle* h, uint32_t n_ticks) {
   if (!h) return SIM_EINVAL;
@@ -3722,6 +3771,17 @@ int sim_snapshot(sim_handle* h, void* buf, size_t cap, size_t* bytes) {
   if (!h || !bytes) return SIM_EINVAL;
   if (h->in_tick) return SIM_ESTATE;  // between sim_step_begin and sim_step_end the state is half a tick ahead of `tick`
   Dev& d = h->d;
+  if (d.swim && !d.sharded) {  // slot-less failed probes not yet replayed: into the schedule, so that the image holds them
+    std::vector<u32> rq(2 * SIM_SUSPECT_REQ_MAX);
+    for (u64 back = 2; back >= 1; --back) {
+      if (h->tick < back) continue;
+      u32 n = 0;
+      int rc = sreq_take(h, h->tick - back, rq.data(), SIM_SUSPECT_REQ_MAX, &n);
+      if (rc) return rc;
+      for (u32 i = 0; i < n; ++i)
+        if ((rc = inject_val(h, h->tick + 2 - back, SIM_OP_SUSPECT, rq[2 * i], rq[2 * i + 1], 0, 0)) != SIM_OK) return rc;
+    }
+  }
   size_t len[SNAP_SECTIONS], tot = sizeof(snap_header);
   snap_lengths(h, len);
   for (int i = 0; i < SNAP_SECTIONS; ++i) tot += 8 + len[i];
