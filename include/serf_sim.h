@@ -282,6 +282,13 @@ typedef struct sim_config {
 #define SIM_CF_AWARENESS_PROBE 4u  /* memberlist scales its probe interval by the node's health score (awareness, state.go
                                    * probeNode: ScaleTimeout): a node with score s probes in every (s + 1)-th round of its
                                    * group's probe phase instead of every round (App. B.3)                              */
+#define SIM_CF_JOIN_SYNC 8u        /* Serf::join is memberlist.join: a push-pull with the peer before anything else.  With this
+                                   * flag SIM_OP_JOIN first lets the joining node ADOPT the view of a running node of its own
+                                   * shard (the first one at or after `peer` mod shard size): every allocated view entry, the
+                                   * member counters, the clocks (witnessed), the suspicion timers of the adopted entries.
+                                   * The re-broadcasts a real merge would queue tell the cluster nothing it does not have
+                                   * and are not modelled.  Without it a re-joining node keeps the view it went down with
+                                   * until a push-pull batch reaches it (DESIGN.md SIMSPEC §2.8)                        */
 #define SIM_DEFAULT_SEED 0x5EEDC0DE5E4F0001ull
 
 /* Stats — mirrors serf-core/src/serf/api.rs:586-602 (`Stats`) for one simulated node. */

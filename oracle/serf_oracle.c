@@ -1045,6 +1045,46 @@ static void nctx_init(nctx* c, osim* s, uint32_t l) {
 static int has_alive_members(const osim* s) { return s->N > 1; } /* base.rs:346-359, bulk form */
 
 static void dispatch_record(nctx* c, const sim_record* r);
+/* SIM_CF_JOIN_SYNC: memberlist.join = a push-pull with the peer.  The joining node adopts the view of a running node of its
+ * own shard: the first one at or after `peer` mod shard size that is not itself. */
+static void join_sync(osim* s, nctx* c, uint32_t peer) {
+  uint32_t M = s->M, base = (c->gid / M) * M, partner = NOSLOT;
+  for (uint32_t i = 0; i < M && partner == NOSLOT; ++i) {
+    uint32_t cand = base + (peer % M + i) % M;
+    if (cand != c->gid && up_of(s, cand)) partner = cand;
+  }
+  if (partner == NOSLOT) return;
+  uint32_t lp = partner - s->shard0, now = (uint32_t)s->tick;
+  sim_row* row = c->row;
+  const sim_row* prow = &s->rows[lp];
+  const sim_view* pme = view_at(s, lp, c->gid); /* what the partner thinks of the joiner */
+  sim_view* me = view_at(s, c->l, c->gid);
+  uint32_t next = 0, nt = 0;
+  memset(row->susp, 0, sizeof row->susp);
+  for (uint32_t wi = 0; wi < s->n_walk; ++wi) {
+    uint32_t a = s->walk[wi];
+    sim_view* e = &s->view[(size_t)a * s->Nl + c->l];
+    const sim_view* pe = &s->view[(size_t)a * s->Nl + lp];
+    if (s->subject_of[a] == c->gid) { if (pe->inc > e->inc) e->inc = pe->inc; continue; } /* its own entry stays its own */
+    *e = *pe;
+    if ((e->bits & SIM_VB_KNOWN) && SIM_VB_SWIM(e->bits) == SIM_SWIM_SUSPECT) { /* the adopted suspicion keeps running here */
+      if (nt == SIM_S) { row->overflow++; continue; }
+      row->susp[nt++] = (uint16_t)(a + 1);
+      uint32_t deadline = now - ((now - SIM_VB_STAMP(e->bits)) & STAMP_MASK) + s->T[SIM_VB_NCONF(e->bits)];
+      if (!next || deadline < next) next = deadline;
+    }
+  }
+  row->susp_next = next;
+  row->reap_next = prow->reap_next;
+  row->n_known = prow->n_known;
+  uint32_t pst = (pme && (pme->bits & SIM_VB_KNOWN)) ? SIM_VB_STATUS(pme->bits) : SIM_STATUS_NONE;
+  uint32_t mst = (me && (me->bits & SIM_VB_KNOWN)) ? SIM_VB_STATUS(me->bits) : SIM_STATUS_NONE;
+  row->n_failed = prow->n_failed - (pst == SIM_STATUS_FAILED) + (mst == SIM_STATUS_FAILED);
+  row->n_left = prow->n_left - (pst == SIM_STATUS_LEFT) + (mst == SIM_STATUS_LEFT);
+  if (prow->clock > 0) lc_witness(&row->clock, prow->clock - 1); /* delegate.rs:466-480 */
+  if (prow->event_clock > 0) lc_witness(&row->event_clock, prow->event_clock - 1);
+  if (prow->query_clock > 0) lc_witness(&row->query_clock, prow->query_clock - 1);
+}
 static void apply_op(osim* s, const sim_opent* op) {
   /* ground-truth liveness is replicated on every shard (probes read it, B.3) */
   if (op->op == SIM_OP_CRASH) up_set(s, op->node, 0);
@@ -1100,6 +1140,7 @@ static void apply_op(osim* s, const sim_opent* op) {
       break;
     }
     case SIM_OP_JOIN: { /* api.rs:318-364: memberlist.join, broadcast_join(clock.time()) */
+      if (s->cfg.flags & SIM_CF_JOIN_SYNC) join_sync(s, &c, op->a);
       row->flags |= SIM_RF_UP;
       row->flags = (row->flags & ~(3u << 1)) | (SIM_SERF_ALIVE << 1);
       if (s->swim) { /* a (re)joining node announces itself with an incarnation above what it is accused of */

@@ -1944,6 +1944,93 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
   }
 }
 
+// SIM_CF_JOIN_SYNC (oracle join_sync): memberlist.join = a push-pull with the peer — the joining node adopts the view of a
+// running node of its own shard.  One block: the partner is picked by thread 0, the entries are copied in parallel, the
+// suspicion timers of the adopted entries are listed in walk order, chunk by chunk.
+__global__ void join_sync_kernel(Dev d, u32 n_slots, u32 gid, u32 peer, u32 tick) {
+  __shared__ u32 s_partner;
+  __shared__ u32 s_flag[BLOCK];  // view slot + 1 of an adopted entry that is suspect, 0 otherwise
+  __shared__ u32 s_nt, s_next, s_ovf;
+  const u32 M = d.M, base = (gid / M) * M, l = gid - d.shard0;
+  if (!threadIdx.x) {
+    u32 partner = NOSLOT;
+    for (u32 i = 0; i < M && partner == NOSLOT; ++i) {
+      u32 cand = base + (peer % M + i) % M;
+      if (cand != gid && up_of(d, cand)) partner = cand;
+    }
+    s_partner = partner;
+    s_nt = 0; s_next = 0xFFFFFFFFu; s_ovf = 0;
+  }
+  __syncthreads();
+  if (s_partner == NOSLOT) return;
+  const u32 lp = s_partner - d.shard0;
+  uint16_t* sp = reinterpret_cast<uint16_t*>(&d.R4[2 * (size_t)l]);
+  if (threadIdx.x < SIM_S) sp[threadIdx.x] = 0;
+  for (u32 w0 = 0; w0 < n_slots; w0 += BLOCK) {
+    u32 wi = w0 + threadIdx.x;
+    u32 flag = 0, deadline = 0;
+    if (wi < n_slots) {
+      u32 a = d.walk[wi];
+      uint4* e = d.view + ((size_t)a * d.Nl + l);
+      const uint4* pe = d.view + ((size_t)a * d.Nl + lp);
+      uint4 h = pe[0];
+      if (d.subject_of[a] == gid) {  // its own entry stays its own
+        uint4 mine = e[0];
+        if (h.z > mine.z) { mine.z = h.z; e[0] = mine; }
+      } else {
+        e[0] = h;
+        e[d.vtail] = pe[d.vtail];
+        if ((h.w & SIM_VB_KNOWN) && SIM_VB_SWIM(h.w) == SIM_SWIM_SUSPECT) {  // the adopted suspicion keeps running here
+          flag = a + 1;
+          deadline = tick - ((tick - SIM_VB_STAMP(h.w)) & STAMP_MASK) + d.T[SIM_VB_NCONF(h.w)];
+        }
+      }
+    }
+    s_flag[threadIdx.x] = flag;
+    __syncthreads();
+    if (!threadIdx.x)
+      for (u32 i = 0; i < BLOCK; ++i)
+        if (s_flag[i]) {
+          if (s_nt == SIM_S) s_ovf++;
+          else sp[s_nt++] = (uint16_t)s_flag[i];
+        }
+    __syncthreads();
+    // earliest deadline over the TRACKED timers: thread 0 cannot see the deadlines, so every flagged thread checks whether
+    // its slot made it into the list
+    if (flag) {
+      bool tracked = false;
+      for (u32 j = 0; j < SIM_S; ++j) tracked |= sp[j] == (uint16_t)flag;
+      if (tracked) atomicMin(&s_next, deadline);
+    }
+    __syncthreads();
+  }
+  if (!threadIdx.x) {
+    uint4 r0 = d.R0[l], r1 = d.R1[l], r2 = d.R2[l], r3 = d.R3[l];
+    const uint4 p0 = d.R0[lp], p1 = d.R1[lp], p2 = d.R2[lp], p3 = d.R3[lp];
+    u32 a_me = d.slot_of[gid];
+    u32 pst = SIM_STATUS_NONE, mst = SIM_STATUS_NONE;
+    if (a_me != NOSLOT) {
+      uint4 pm = d.view[(size_t)a_me * d.Nl + lp], mm = d.view[(size_t)a_me * d.Nl + l];
+      if (pm.w & SIM_VB_KNOWN) pst = SIM_VB_STATUS(pm.w);
+      if (mm.w & SIM_VB_KNOWN) mst = SIM_VB_STATUS(mm.w);
+    }
+    r3.y = s_next == 0xFFFFFFFFu ? 0u : s_next;  // susp_next
+    r3.w = p3.w;         // reap_next
+    r1.w = p1.w;         // n_known
+    r2.x = p2.x - (pst == SIM_STATUS_FAILED ? 1u : 0u) + (mst == SIM_STATUS_FAILED ? 1u : 0u);
+    r2.y = p2.y - (pst == SIM_STATUS_LEFT ? 1u : 0u) + (mst == SIM_STATUS_LEFT ? 1u : 0u);
+    r2.w += s_ovf;
+    u64 c = (u64)r0.x | ((u64)r0.y << 32), ec = (u64)r0.z | ((u64)r0.w << 32), qc = (u64)r1.x | ((u64)r1.y << 32);
+    u64 pc = (u64)p0.x | ((u64)p0.y << 32), pec = (u64)p0.z | ((u64)p0.w << 32), pqc = (u64)p1.x | ((u64)p1.y << 32);
+    if (pc > 0 && pc - 1 >= c) c = pc;       // witness(remote - 1): delegate.rs:466-480
+    if (pec > 0 && pec - 1 >= ec) ec = pec;
+    if (pqc > 0 && pqc - 1 >= qc) qc = pqc;
+    r0 = make_uint4((u32)c, (u32)(c >> 32), (u32)ec, (u32)(ec >> 32));
+    r1.x = (u32)qc; r1.y = (u32)(qc >> 32);
+    d.R0[l] = r0; d.R1[l] = r1; d.R2[l] = r2; d.R3[l] = r3;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // push-pull anti-entropy (memberlist pushPull, App. B.6; SerfDelegate::local_state / merge_remote_state,
 // serf-core/src/serf/delegate.rs:386-554) — SIMSPEC §2.10, oracle pp_round/pp_pair/pp_merge.
@@ -3335,6 +3422,12 @@ int sim_step_begin(sim_handle* h) {
       }
       u32 x = op_subject(h, e.op, e.node, e.a, e.b);
       if (x != NOSLOT && ensure_slot(h, x) != SIM_OK) { h->ops_dropped++; continue; }  // no free view slot: the operation does not happen
+      if (e.op == SIM_OP_JOIN && (h->cfg.flags & SIM_CF_JOIN_SYNC) && e.node >= d.shard0 && e.node < d.shard0 + d.Nl) {
+        // memberlist.join comes first: what was batched so far runs, then the joining node adopts its partner's view
+        if (ob.n) ops_kernel<<<1, 64, 0, h->stream>>>(d, ob, h->tick, d.N > 1 ? 1u : 0u, tp.query_base, h->q_timeout);
+        memset(&ob, 0, sizeof ob);
+        join_sync_kernel<<<1, BLOCK, 0, h->stream>>>(d, (u32)h->walk.size(), e.node, e.a, (u32)h->tick);
+      }
       ob.op[ob.n] = e.op; ob.node[ob.n] = e.node; ob.a[ob.n] = e.a; ob.b[ob.n] = e.b; ob.val[ob.n] = e.val;
       if (e.op == SIM_OP_QUERY) {  // a fresh tracker: who acked / responded starts empty
         u32 j = e.a % SIM_QT;

@@ -520,3 +520,37 @@ def test_awareness_scales_the_probe_interval(oracle):
         traj[flag] = sums
         assert moved > 20
     assert traj[True] != traj[False] and sum(traj[True]) >= sum(traj[False]), "degraded nodes recover more slowly when they probe less often"
+
+
+def test_join_sync_gives_a_rejoining_node_a_current_view(oracle):
+    """SIM_CF_JOIN_SYNC: Serf::join is memberlist.join, a push-pull with the peer, before anything else.  Node 10 is down
+    while node 20 leaves gracefully and node 30 crashes and is declared failed; when 10 re-joins it adopts a running
+    node's view — without the flag it keeps the view it went down with until a push-pull batch reaches it (none here)."""
+    n = 512
+    kw = dict(fanout=3, view_slots=32, event_ring=16, query_ring=8, probe_interval=2, suspicion_mult=4, suspicion_max_mult=2, leave_delay=4)
+    res = {}
+    for flag in (False, True):
+        sim = _ffi.Sim(oracle, _ffi.make_config(n, join_sync=flag, **kw))
+        sim.inject(3, _ffi.OP_CRASH, 10)
+        sim.inject(50, _ffi.OP_CRASH, 30)
+        sim.inject(52, _ffi.OP_LEAVE, 20)
+        sim.inject(57, _ffi.OP_LEAVE_FINISH, 20)
+        sim.inject(62, _ffi.OP_CRASH, 20)
+        sim.inject(120, _ffi.OP_JOIN, 10, 77)
+        sim.step(121)            # the join has just executed
+        st10, _ = sim.members(10)
+        st77, _ = sim.members(77)
+        row10, row77 = sim.dump(_ffi.ARR_ROWS)[10], sim.dump(_ffi.ARR_ROWS)[77]
+        res[flag] = (int(st10[20]), int(st10[30]), int(row10["n_failed"]), int(row10["n_left"]))
+        want = (int(st77[20]), int(st77[30]))
+        assert want == (_ffi.STATUS_LEFT, _ffi.STATUS_FAILED)
+        if flag:
+            assert res[flag][:2] == want, "the joiner sees what its partner sees"
+            assert int(row10["clock"]) >= int(row77["clock"]) - 1
+            # the partner still counts the joiner itself as failed until the refutation arrives; the joiner does not
+            assert res[flag][2] == int(row77["n_failed"]) - 1 and res[flag][3] == int(row77["n_left"])
+        sim.step(60)
+        assert sim.cluster_stats()["overflow"] == 0
+        st, _ = sim.members(200)
+        assert st[10] == _ffi.STATUS_ALIVE, "and the cluster has it back"
+    assert res[False][:2] == (_ffi.STATUS_ALIVE, _ffi.STATUS_ALIVE), "without the sync the joiner still has its old view"

@@ -93,7 +93,8 @@ def test_random_configurations(oracle, hiplib, seed):
               push_pull_interval=int(rng.choice([0, 4, 9])), recycle_interval=int(rng.choice([0, 6])) if not dense else 0)
     # memberlist options behind flags (round 3): awareness-scaled probe interval, gossip_to_the_dead_time (drawn last: the
     # configurations above are the ones the sweep has always run)
-    kw.update(awareness_probe=bool(swim and rng.random() < 0.5), gossip_to_the_dead=int(rng.choice([0, 0, 2, 8])) if swim else 0)
+    kw.update(awareness_probe=bool(swim and rng.random() < 0.5), gossip_to_the_dead=int(rng.choice([0, 0, 2, 8])) if swim else 0,
+              join_sync=bool(rng.random() < 0.5))
     try:
         g, o = pair(oracle, hiplib, n, **kw)
     except _ffi.SimError:
@@ -134,7 +135,8 @@ def test_random_configurations_paged_packets(oracle, hiplib, seed):
               queue_check_interval=int(rng.choice([0, 7])), min_queue_depth=int(rng.choice([0, 2])),
               push_pull_interval=int(rng.choice([0, 4, 9])), recycle_interval=int(rng.choice([0, 6])) if not dense else 0,
               pkt_records=int(rng.choice([8, 12, 16])))
-    kw.update(awareness_probe=bool(swim and rng.random() < 0.5), gossip_to_the_dead=int(rng.choice([0, 0, 2, 8])) if swim else 0)
+    kw.update(awareness_probe=bool(swim and rng.random() < 0.5), gossip_to_the_dead=int(rng.choice([0, 0, 2, 8])) if swim else 0,
+              join_sync=bool(rng.random() < 0.5))
     try:
         g, o = pair(oracle, hiplib, n, **kw)
     except _ffi.SimError:

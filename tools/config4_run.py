@@ -53,7 +53,8 @@ def main():
     n = args.nodes
     kw = dict(fanout=args.fanout, view_slots=args.view_slots, event_ring=args.ring, query_ring=args.ring,
               probe_interval=args.probe_interval, push_pull_interval=args.push_pull_interval, loss=args.loss,
-              reap_interval=75, queue_check_interval=150, recycle_interval=args.recycle_interval, pkt_records=args.pkt_records)
+              reap_interval=75, queue_check_interval=150, recycle_interval=args.recycle_interval, pkt_records=args.pkt_records,
+              join_sync=True)   # Serf::join = memberlist.join: the re-joining node syncs with a peer (SIM_CF_JOIN_SYNC)
     sim = _ffi.Sim(lib, _ffi.make_config(n, **kw))
     rng = np.random.default_rng(5)
     n_churn = int(n * args.churn_frac)
