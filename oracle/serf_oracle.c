@@ -1352,6 +1352,15 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
   memset(out, 0, sizeof out);
   const uint32_t PG = s->PG;
   int up = (row->flags & SIM_RF_UP) != 0;
+  /* gossip_to_the_dead_time: whom this node will not gossip to is decided on its view as the tick begins (the HIP library
+   * does it in a launch of its own ahead of the tick) */
+  uint32_t skipm = 0;
+  if (s->cfg.gossip_to_the_dead && !s->rfan)
+    for (uint32_t k = 0; k < p->feff; ++k) {
+      uint32_t h, lp;
+      fan_target(p, g, ll, k, &h, &lp);
+      if (gossip_skips(s, l, h * p->M + lp)) skipm |= 1u << k;
+    }
   if (up) {
     if (row->next_seq > 1023u - 64u) queue_renorm(row, q);
     if (s->tick > 0 && s->rfan) { /* variable in-degree: every packet addressed to this node, (sender, k) order */
@@ -1401,7 +1410,7 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
   for (uint32_t k = 0; k < p->feff; ++k) {
     uint32_t h, lp;
     fan_target(p, g, ll, k, &h, &lp);
-    if (up && (pkt_lost(p, c.gid, k) || gossip_skips(s, l, h * p->M + lp))) memset(out[k], 0, sizeof out[k]);
+    if (up && (pkt_lost(p, c.gid, k) || ((skipm >> k) & 1u))) memset(out[k], 0, sizeof out[k]);
     for (uint32_t pg = 0; pg < PG; ++pg) {
       if (s->cfg.shard_count > 1)
         s->xsend[xcell(p, s->fp, (ll % p->blk) / p->sub, h, k * PG + pg, lp)] = out[k][pg];

@@ -285,6 +285,7 @@ struct Dev {
                     // {qid, n_ids, tag mask, 0, ids[12]} (QFILT); then [N] bytes, every node's tag class (TAGCLASS)
   u32* qbits;       // [SIM_QT][2][ceil(N/32)] who acked / responded, by global node id
   uint4* nullcell;  // 2 x uint4 of zeros: where the prefetch of a record without a lookup points
+  uint8_t* skipmask;  // [Nl] gossip_to_the_dead: bit k = do not send packet k this tick (written by gossip_skip_kernel)
   u32* sreq;        // [1 + 2 * SIM_SUSPECT_REQ_MAX]: count, then the (prober, target) pairs of the running tick's slot-less
                     // failed probes (one of two buffers, by tick parity: the host reads a tick's list one tick later)
   sim_event* events;
@@ -1060,7 +1061,9 @@ __device__ static inline bool up_of(const Dev& d, u32 gid) { return (d.upmap[gid
 __device__ static void swim_probe(const Ctx& c, Node& n, const TickP& tp, const uint4* base, Ins& ins) {
   const Dev& d = c.d;
   // SIM_CF_AWARENESS_PROBE: the probe interval scales with the health score (memberlist probeNode: ScaleTimeout)
+#ifndef TICK_LEAN
   if (d.aw_probe && ((c.tick + (c.gid >> 6)) / d.PI) % (n.awareness + 1u)) return;
+#endif
   u32 t = draw_below(probe_draw(tp, c.gid, PD_TARGET), d.N - 1);
   if (t >= c.gid) ++t;
   uint4* p = view_ptr(c, t);
@@ -1081,8 +1084,10 @@ __device__ static void swim_probe(const Ctx& c, Node& n, const TickP& tp, const 
   if (ok) { aw_delta(n, -1); return; }
   aw_delta(n, +1);
   if (!p) {  // no view slot to hold the suspicion yet: taken up next tick, once the target has one (SIM_OP_SUSPECT)
+#ifndef TICK_LEAN
     u32 i = atomicAdd(d.sreq, 1u);
     if (i < SIM_SUSPECT_REQ_MAX) { d.sreq[1 + 2 * i] = c.gid; d.sreq[2 + 2 * i] = t; }
+#endif
     return;
   }
   bool dirty = false;
@@ -1402,6 +1407,14 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
     if (!SHARDED || !tp.first) {
       // the pages of the f packets, in order: packet k's page 0, 1, ... then packet k + 1 (one page each unless MP)
       u32 k = 0, pg = 0, wnp = wave_np(0);
+#ifdef TICK_NEXT_SLOTS
+      // The slot-map lookups of the NEXT page travel while this page is classified: they are issued as soon as the next
+      // cell's words are here (right behind the wait for this page's heads), and parked in the top 16 bits of this lane's
+      // staged entry pointers (48-bit addresses) so that they cost no register across the handler loop.  (16-bit slots:
+      // not with a dense view of more than 65 534 subjects.)
+      const bool use_ns = d.A <= 65534u;
+      bool have_ns = false;  // (wave-uniform) lds_p[i][tid] >> 48 = slot of record i of the page whose words are in rn ..
+#endif
       while (k < d.f) {
         if (MP) {
           if (++pg >= wnp) { ++k; pg = 0; if (k < d.f) wnp = wave_np(k); }
@@ -1425,13 +1438,27 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
           auto prefetch = [&]() __attribute__((always_inline)) { rn = ld4(cell); rn1 = ld4(cell + 1); rn2 = ld4(cell + 2); };
           TT(1);
           // wave-ballot early out: nobody in this wave received anything in packet k (an empty record is all zero)
+#ifdef TICK_NEXT_SLOTS
+          if (!__any(((ch.x | ch.y | ch.z | ch.w) & 0xF0u) != 0)) { prefetch(); have_ns = false; continue; }
+#else
           if (!__any(((ch.x | ch.y | ch.z | ch.w) & 0xF0u) != 0)) { prefetch(); continue; }
+#endif
           u32 k0 = SIM_META_KIND(ch.x), k1 = SIM_META_KIND(ch.y), k2 = SIM_META_KIND(ch.z), k3 = SIM_META_KIND(ch.w);
           if (ABL(64)) { n.dirty |= (k0 ^ k1 ^ k2 ^ k3) & tp.zero_; prefetch(); continue; }
-          u32 s0 = slot_load(d, k0, ck.x);
-          u32 s1 = slot_load(d, k1, ck.y);
-          u32 s2 = slot_load(d, k2, ck.z);
-          u32 s3 = slot_load(d, k3, ck.w);
+          u32 s0, s1, s2, s3;
+#ifdef TICK_NEXT_SLOTS
+          if (have_ns) {
+            const u64* lp = reinterpret_cast<const u64*>(&lds_p[0][0]);
+            auto dec = [](u64 v) __attribute__((always_inline)) -> u32 { u32 x = (u32)(v >> 48); return x == 0xFFFFu ? NOSLOT : x; };
+            s0 = dec(lp[0 * TBLOCK + tid]); s1 = dec(lp[1 * TBLOCK + tid]); s2 = dec(lp[2 * TBLOCK + tid]); s3 = dec(lp[3 * TBLOCK + tid]);
+          } else
+#endif
+          {
+            s0 = slot_load(d, k0, ck.x);
+            s1 = slot_load(d, k1, ck.y);
+            s2 = slot_load(d, k2, ck.z);
+            s3 = slot_load(d, k3, ck.w);
+          }
           prefetch();
           uint4 r0 = wire_unpack(ck.x, cl.x, ch.x), r1 = wire_unpack(ck.y, cl.y, ch.y);
           uint4 r2 = wire_unpack(ck.z, cl.z, ch.z), r3 = wire_unpack(ck.w, cl.w, ch.w);
@@ -1445,9 +1472,28 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
           uint4 e0 = ld4(p0 ? p0 : d.nullcell), e1 = ld4(p1 ? p1 : d.nullcell), e2 = ld4(p2 ? p2 : d.nullcell), e3 = ld4(p3 ? p3 : d.nullcell);
           TT(3);
           lds_e[0][tid] = e0; lds_e[1][tid] = e1; lds_e[2][tid] = e2; lds_e[3][tid] = e3;
+#ifdef TICK_NEXT_SLOTS
+          // (the store above waited for the heads AND for the next cell: its keys and kinds are in rn / rn2)
+          u32 ns0 = NOSLOT, ns1 = NOSLOT, ns2 = NOSLOT, ns3 = NOSLOT;
+          const bool park = use_ns && k < d.f;
+          if (park) {
+            ns0 = slot_load(d, SIM_META_KIND(rn2.x), rn.x); ns1 = slot_load(d, SIM_META_KIND(rn2.y), rn.y);
+            ns2 = slot_load(d, SIM_META_KIND(rn2.z), rn.z); ns3 = slot_load(d, SIM_META_KIND(rn2.w), rn.w);
+          }
+#endif
           // classify all four against the state as it is now: straight-line, no state is touched
           slow = (fast_retire(c, n, k0, r0, p0 != nullptr, e0) ? 0u : 1u) | (fast_retire(c, n, k1, r1, p1 != nullptr, e1) ? 0u : 2u) |
                  (fast_retire(c, n, k2, r2, p2 != nullptr, e2) ? 0u : 4u) | (fast_retire(c, n, k3, r3, p3 != nullptr, e3) ? 0u : 8u);
+#ifdef TICK_NEXT_SLOTS
+          if (park) {
+            u64* lp = reinterpret_cast<u64*>(&lds_p[0][0]);
+            lp[0 * TBLOCK + tid] = (u64)(uintptr_t)p0 | ((u64)(ns0 & 0xFFFFu) << 48);
+            lp[1 * TBLOCK + tid] = (u64)(uintptr_t)p1 | ((u64)(ns1 & 0xFFFFu) << 48);
+            lp[2 * TBLOCK + tid] = (u64)(uintptr_t)p2 | ((u64)(ns2 & 0xFFFFu) << 48);
+            lp[3 * TBLOCK + tid] = (u64)(uintptr_t)p3 | ((u64)(ns3 & 0xFFFFu) << 48);
+          }
+          have_ns = park;
+#endif
           TT(4);
         }
         // phase B: the records that need a handler, in arrival order, one rolled loop = one copy of the handler code.
@@ -1468,7 +1514,11 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
             u32 p = (u32)__ffs((int)slow) - 1u;
             slow &= slow - 1u;
             uint4 r = lds_r[p][tid];
+#ifdef TICK_NEXT_SLOTS
+            uint4* ptr = (uint4*)(__attribute__((address_space(1))) uint4*)((uintptr_t)lds_p[p][tid] & 0x0000FFFFFFFFFFFFull);
+#else
             uint4* ptr = (uint4*)(__attribute__((address_space(1))) uint4*)lds_p[p][tid];  // (global, not flat, accesses in the handlers)
+#endif
             uint4 e = lds_e[p][tid];
             if (ptr && (wall || ptr == wptr)) e = ld4(ptr);
             Ins ins;
@@ -1478,7 +1528,11 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
             if (dirty) {
 #pragma unroll 1
               for (u32 q = p + 1; q < SIM_P; ++q)
+#ifdef TICK_NEXT_SLOTS
+                if (ins.wide || (ptr && (uint4*)((uintptr_t)lds_p[q][tid] & 0x0000FFFFFFFFFFFFull) == ptr)) slow |= 1u << q;
+#else
                 if (ins.wide || (ptr && lds_p[q][tid] == ptr)) slow |= 1u << q;
+#endif
               wall |= ins.wide || (wptr != nullptr && wptr != ptr);
               wptr = ptr;
             }
@@ -1539,18 +1593,13 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
   }
   TT(7);
   u32 limit = up ? d.retransmit_mult * digits10(n.nknown) : 0;
-  // gossip_to_the_dead_time (App. B.2; oracle gossip_skips): this node's view says the target of its packet k has been dead
-  // or left for longer than that — the packet is not sent (off unless configured: the general per-node form of the map)
-  auto gossip_skips = [&](u32 k) __attribute__((always_inline)) -> bool {
-    if (!d.gttd) return false;
-    u32 hh, tt;
-    fan_target_g(tp, g, ll, k, hh, tt);
-    u32 target = hh * tp.M + tt;
-    const uint4* vp = view_ptr(c, target);
-    uint4 e = vp ? vp[0] : base[(size_t)target * 2];
-    u32 sw = SIM_VB_SWIM(e.w);
-    return (e.w & SIM_VB_KNOWN) && (sw == SIM_SWIM_DEAD || sw == SIM_SWIM_LEFT) && ((((u32)tp.tick - SIM_VB_STAMP(e.w)) & STAMP_MASK) > d.gttd);
-  };
+  // gossip_to_the_dead_time (App. B.2): the slots whose target this node believed dead for too long when the tick began
+  // (gossip_skip_kernel, launched ahead of the tick only when the option is on) — those packets are not sent
+#ifndef TICK_LEAN
+  const u32 skipm = d.gttd ? (u32)d.skipmask[l] : 0u;
+#else
+  const u32 skipm = 0u;  // (measurement build: the round's optional memberlist switches compiled out of the tick kernel)
+#endif
   const bool coop = (blockIdx.x + 1u) * TBLOCK <= cnt;  // every lane of the block is here
   // One 48-byte cell per lane that has one (`wr`), written quad-cooperatively when the whole wave is here:
   // three lanes of a quad write one whole cell per store instruction (lane i < 3 writes part i of quad-mate
@@ -1587,7 +1636,7 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
       if (up && (u32)k < tp.feff) {
         u64 nb; u32 c;
         q_round_mp(n, sk, limit, d.P, nb, c);
-        bool lost = (tp.loss_u32 && (u32)(mix64(tp.loss_base ^ ((u64)gid * 4u + k)) >> 32) < tp.loss_u32) || gossip_skips((u32)k);
+        bool lost = (tp.loss_u32 && (u32)(mix64(tp.loss_base ^ ((u64)gid * 4u + k)) >> 32) < tp.loss_u32) || ((skipm >> k) & 1u);
         if (!lost) { nib[k] = nb; cn[k] = c; }
       }
     }
@@ -1677,7 +1726,7 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
     slots[k] = 0xFFFFFFFFu;
     if (up && (u32)k < tp.feff) {
       u32 s = small ? q_round8(n, sk, limit) : q_round(n, sk, limit);
-      bool lost = (tp.loss_u32 && (u32)(mix64(tp.loss_base ^ ((u64)gid * 4u + k)) >> 32) < tp.loss_u32) || gossip_skips((u32)k);
+      bool lost = (tp.loss_u32 && (u32)(mix64(tp.loss_base ^ ((u64)gid * 4u + k)) >> 32) < tp.loss_u32) || ((skipm >> k) & 1u);
       if (!lost) slots[k] = s;
     }
   }
@@ -1944,6 +1993,23 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
   }
 }
 
+// gossip_to_the_dead_time (App. B.2; oracle gossip_skips): for every node and fan-out slot, does the node's view — as it is when
+// the tick begins — say that the packet's target has been dead / left for longer than that?  Its own launch, ahead of
+// the tick kernel and only when the option is on: the tick kernel then reads one byte per node.
+__global__ void gossip_skip_kernel(Dev d, TickP tp, const uint4* base) {
+  for (size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * blockDim.x) {
+    u32 gid = d.shard0 + (u32)l, g = gid / tp.M, ll = gid - g * tp.M, m = 0;
+    for (u32 k = 0; k < tp.feff; ++k) {
+      u32 hh, tt;
+      fan_target_g(tp, g, ll, k, hh, tt);
+      u32 target = hh * tp.M + tt, a = d.slot_of[target];
+      uint4 e = a == NOSLOT ? base[(size_t)target * 2] : d.view[(size_t)a * d.Nl + l];
+      u32 sw = SIM_VB_SWIM(e.w);
+      if ((e.w & SIM_VB_KNOWN) && (sw == SIM_SWIM_DEAD || sw == SIM_SWIM_LEFT) && ((((u32)tp.tick - SIM_VB_STAMP(e.w)) & STAMP_MASK) > d.gttd)) m |= 1u << k;
+    }
+    d.skipmask[l] = (uint8_t)m;
+  }
+}
 // SIM_CF_JOIN_SYNC (oracle join_sync): memberlist.join = a push-pull with the peer — the joining node adopts the view of a
 // running node of its own shard.  One block: the partner is picked by thread 0, the entries are copied in parallel, the
 // suspicion timers of the adopted entries are listed in walk order, chunk by chunk.
@@ -2876,7 +2942,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   DA(d.view, (size_t)d.A * Nl * 2)
   DA(d.ering, (size_t)d.Bev * Nl * 2)
   DA(d.qring, (size_t)d.Bq * Nl * 2)
-  DA(d.slot_of, d.N) DA(d.subject_of, d.A) DA(d.walk, d.A) DA(d.upmap, nup) DA(d.nullcell, 4) DA(h->sreq_buf[0], 1 + 2 * SIM_SUSPECT_REQ_MAX) DA(h->sreq_buf[1], 1 + 2 * SIM_SUSPECT_REQ_MAX)
+  DA(d.slot_of, d.N) DA(d.subject_of, d.A) DA(d.walk, d.A) DA(d.upmap, nup) DA(d.nullcell, 4) DA(d.skipmask, d.gttd ? Nl : 1) DA(h->sreq_buf[0], 1 + 2 * SIM_SUSPECT_REQ_MAX) DA(h->sreq_buf[1], 1 + 2 * SIM_SUSPECT_REQ_MAX)
   DA(d.qtab, QTAB_U4(d.N)) DA(d.qbits, (size_t)SIM_QT * 2 * nup)
   DA(d.events, (size_t)EV_CAP) DA(d.ev_count, 1)
   DA(h->d_base, (size_t)d.N * 2)
@@ -3449,6 +3515,7 @@ int sim_step_begin(sim_handle* h) {
   // (hipExtLaunchKernelGGL: start / stop = the kernel's own begin and end, no barrier packets in the stream — two
   // hipEventRecord calls around every launch cost 10 us of stream time each tick).  Several chunk launches per tick
   // (sharded, C > 1): the pair brackets them with hipEventRecord.
+  if (d.gttd) gossip_skip_kernel<<<grid_for(d.Nl), BLOCK, 0, h->stream>>>(d, tp, h->d_base);  // whom not to gossip to this tick
   h->tick_timed = h->profiling && (h->prof_seq++ % h->profiling) == 0;
   h->tick_bracket = h->tick_timed && d.sharded && tp.C > 1;
   if (h->tick_bracket) {
