@@ -18,7 +18,11 @@ out = os.path.join(ROOT, "profiles")
 
 
 def last_json(path):
-    return json.loads(open(path).read().strip().splitlines()[-1])
+    text = open(path).read().strip()
+    try:
+        return json.loads(text)                    # a JSON document ...
+    except json.JSONDecodeError:
+        return json.loads(text.splitlines()[-1])   # ... or a log whose last line is one
 
 
 for src, dst in (("bench_default.json", "r03_bench.json"), ("bench_20_5.json", "r03_bench_driver_args.json"),
@@ -37,7 +41,7 @@ traffic = {
     "kernel": "tick_kernel", "launches_averaged": pmc["launches"], "kernel_us_mean_profiled": pmc["kernel_us_mean"],
     "hbm_read_bytes": read, "hbm_write_bytes": write, "hbm_bytes_per_launch": read + write,
     "fetch_size_raw_kib": c["FETCH_SIZE"], "write_size_raw_kib": c["WRITE_SIZE"],
-    "commit": commit, "kernel_source_sha16": sha,
+    "commit": commit, "kernel_source_sha16": sha, "steps": 20, "warmup": 5,
     "workload": "bench.py defaults: 1 Mi nodes, fan-out 4, 0.25 API ops/tick, 4 records per packet, the 20 timed launches of --steps 20 --warmup 5",
     "calibration": "reads = 2 x FETCH_SIZE, writes = WRITE_SIZE: tools/calib on this kernel's access shapes "
                    "(profiles/r02_hbm_counter_calibration.json): TCC_EA0_RDREQ counts 128-byte requests, FETCH_SIZE prices "
