@@ -523,6 +523,19 @@ int sim_pp_merge(sim_handle* h, int round, const void* recv_dev);
  * counted in ops_dropped (model bound). */
 #define SIM_SUSPECT_REQ_MAX 4096u
 int sim_suspect_requests(sim_handle* h, uint32_t* out, uint32_t cap_pairs, uint32_t* n_pairs);
+/* The same hand-over WITHOUT a host round trip per tick (what serf_amd/shard.py uses: a collective whose result the host
+ * has to read before the next tick would let no rank run ahead of its GPU).  After sim_step_end(t), sim_suspect_export
+ * enqueues a copy of the HEAD of tick t's list — SIM_SREQ_HEAD_WORDS 32-bit words: the count, then the first
+ * SIM_SREQ_HEAD_PAIRS (prober, target) pairs, unsorted — into `out` (DEVICE memory for the HIP library).  The host
+ * all-gathers the heads of all shards with an asynchronous device-side collective, copies the result to host memory behind
+ * it, and any time before sim_step_begin of tick t + 2 hands it to sim_suspect_import(h, t, heads, world) on every shard,
+ * which merges the lists in ascending prober order and schedules them as SIM_OP_SUSPECT for tick t + 2 — the tick a
+ * single-process handle replays them in.  A shard whose list of one tick is longer than the head: that list is dropped
+ * and counted in ops_dropped on every shard (model bound). */
+#define SIM_SREQ_HEAD_PAIRS 255u
+#define SIM_SREQ_HEAD_WORDS 512u
+int sim_suspect_export(sim_handle* h, void* out);
+int sim_suspect_import(sim_handle* h, uint64_t of_tick, const uint32_t* heads, uint32_t world);
 int sim_recycle_due(const sim_handle* h);
 int sim_recycle_scan(sim_handle* h, sim_recycle_cand* out, uint32_t cap, uint32_t* n);
 int sim_recycle_apply(sim_handle* h, const sim_recycle_cand* agreed, uint32_t n);

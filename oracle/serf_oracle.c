@@ -2583,6 +2583,32 @@ int API(suspect_requests)(osim* s, uint32_t* out, uint32_t cap_pairs, uint32_t* 
   *n_pairs = n;
   return SIM_OK;
 }
+int API(suspect_export)(osim* s, void* out) { /* the head of the list of the tick that just ended (host memory here) */
+  if (!s || !out || s->in_tick) return SIM_EINVAL;
+  uint32_t* o = (uint32_t*)out;
+  memset(o, 0, SIM_SREQ_HEAD_WORDS * sizeof(uint32_t));
+  o[0] = s->sreq_n;
+  uint32_t n = s->sreq_n < SIM_SREQ_HEAD_PAIRS ? s->sreq_n : SIM_SREQ_HEAD_PAIRS;
+  memcpy(o + 1, s->sreq, (size_t)n * 2 * sizeof(uint32_t));
+  s->sreq_n = 0; /* handed over: step_begin has nothing to rotate */
+  return SIM_OK;
+}
+int API(suspect_import)(osim* s, uint64_t of_tick, const uint32_t* heads, uint32_t world) {
+  if (!s || !heads || !world || s->in_tick || of_tick + 2 < s->tick) return SIM_EINVAL;
+  uint32_t* all = (uint32_t*)malloc((size_t)world * SIM_SREQ_HEAD_PAIRS * 2 * sizeof(uint32_t));
+  uint32_t n = 0;
+  for (uint32_t w = 0; w < world; ++w) {
+    const uint32_t* hd = heads + (size_t)w * SIM_SREQ_HEAD_WORDS;
+    if (hd[0] > SIM_SREQ_HEAD_PAIRS) { s->ops_dropped += hd[0]; continue; } /* model bound: that shard's list is dropped */
+    memcpy(all + 2 * n, hd + 1, (size_t)hd[0] * 2 * sizeof(uint32_t));
+    n += hd[0];
+  }
+  qsort(all, n, 2 * sizeof(uint32_t), sreq_cmp);
+  int rc = SIM_OK;
+  for (uint32_t i = 0; i < n && rc == SIM_OK; ++i) rc = inject_val(s, of_tick + 2, SIM_OP_SUSPECT, all[2 * i], all[2 * i + 1], 0, 0);
+  free(all);
+  return rc;
+}
 int API(recycle_due)(const osim* s) { return s ? recycle_due(s) : SIM_EINVAL; }
 int API(recycle_scan)(osim* s, sim_recycle_cand* out, uint32_t cap, uint32_t* n) {
   if (!s || !out || !n || cap < SIM_RECYCLE_BATCH) return SIM_EINVAL;

@@ -28,7 +28,7 @@ EV_JOIN, EV_LEAVE, EV_FAILED, EV_UPDATE, EV_REAP, EV_USER, EV_QUERY = range(7)
 # enum sim_op
 OP_USER_EVENT, OP_QUERY, OP_LEAVE, OP_JOIN, OP_FORCE_LEAVE, OP_CRASH, OP_REVIVE, OP_LEAVE_FINISH = 1, 2, 3, 4, 5, 6, 7, 8
 OP_SET_TAGS, OP_QUERY_FILTER_ID, OP_QUERY_FILTER_TAGS, OP_DELIVER, OP_SUSPECT = 9, 10, 11, 12, 13
-SUSPECT_REQ_MAX = 4096
+SUSPECT_REQ_MAX, SREQ_HEAD_WORDS = 4096, 512
 QF_IDS, TAG_CLASSES, NO_TAG_FILTER = 12, 32, 0xFFFFFFFF
 # enum sim_array
 ARR_ROWS, ARR_QUEUE, ARR_INBOX, ARR_VIEW, ARR_ERING, ARR_QRING, ARR_SLOTMAP = range(7)
@@ -102,7 +102,7 @@ ABI_SYMBOLS = ("create", "destroy", "set_stream", "join", "leave", "force_leave"
                "bind_exchange", "snapshot", "restore", "query_status", "profile", "profile_read", "profile_read_stats", "cluster_stats_get",
                "bind_exchange2", "exchange_chunks", "step_begin", "step_chunk", "step_end",
                "recycle_due", "recycle_scan", "recycle_apply", "pp_due", "pp_plan", "pp_export", "pp_merge",
-               "query_filtered", "set_tags", "init_tags", "inject_record", "deliver_message", "user_event_bytes", "peek_packet", "suspect_requests",
+               "query_filtered", "set_tags", "init_tags", "inject_record", "deliver_message", "user_event_bytes", "peek_packet", "suspect_requests", "suspect_export", "suspect_import",
                "abi_version", "backend_name")
 
 
@@ -193,6 +193,8 @@ class SimLib:
             "user_event_bytes": (C.c_int, [H, u32, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]),
             "peek_packet": (C.c_int, [H, u32, u32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
             "suspect_requests": (C.c_int, [H, vp, u32, C.POINTER(u32)]),
+            "suspect_export": (C.c_int, [H, vp]),
+            "suspect_import": (C.c_int, [H, u64, vp, u32]),
             "abi_version": (u32, []),
             "backend_name": (C.c_char_p, []),
         }
@@ -439,6 +441,15 @@ class Sim:
         n = C.c_uint32()
         self._ck(self.lib.f["suspect_requests"](self.h, buf.ctypes.data, SUSPECT_REQ_MAX, C.byref(n)), "sim_suspect_requests")
         return buf[:n.value].copy()
+
+    def suspect_export(self, out_ptr):
+        """Enqueue a copy of the head (SREQ_HEAD_WORDS u32: count + pairs) of the just-ended tick's request list into
+        caller memory (device memory for the HIP library)."""
+        self._ck(self.lib.f["suspect_export"](self.h, C.c_void_p(out_ptr)), "sim_suspect_export")
+
+    def suspect_import(self, of_tick, heads_ptr, world):
+        """The gathered heads of all shards for tick `of_tick` (host memory): merged and scheduled for of_tick + 2."""
+        self._ck(self.lib.f["suspect_import"](self.h, of_tick, C.c_void_p(heads_ptr), world), "sim_suspect_import")
 
     def recycle_due(self):
         return self._ck(self.lib.f["recycle_due"](self.h), "sim_recycle_due") > 0

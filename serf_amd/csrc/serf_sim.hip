@@ -3621,6 +3621,30 @@ static int sreq_take(sim_handle* h, u64 t, uint32_t* out, uint32_t cap_pairs, ui
   *n_pairs = n;
   return SIM_OK;
 }
+int sim_suspect_export(sim_handle* h, void* out) {  // the head of the list of the tick that just ended -> device memory of the caller
+  if (!h || !out || h->in_tick || !h->tick) return SIM_EINVAL;
+  static_assert(SIM_SREQ_HEAD_WORDS * 4 <= (1 + 2 * SIM_SUSPECT_REQ_MAX) * 4, "the head is a prefix of the list buffer");
+  if (!h->d.swim) { HCHECK(hipMemsetAsync(out, 0, SIM_SREQ_HEAD_WORDS * 4, h->stream)); return SIM_OK; }
+  const u64 t = h->tick - 1;
+  HCHECK(hipMemcpyAsync(out, h->sreq_buf[t & 1], SIM_SREQ_HEAD_WORDS * 4, hipMemcpyDeviceToDevice, h->stream));
+  h->sreq_tick[t & 1] = ~0ull;  // handed over: nothing for sim_suspect_requests to read
+  return SIM_OK;
+}
+int sim_suspect_import(sim_handle* h, uint64_t of_tick, const uint32_t* heads, uint32_t world) {
+  if (!h || !heads || !world || h->in_tick || of_tick + 2 < h->tick) return SIM_EINVAL;
+  std::vector<std::pair<u32, u32>> v;
+  for (u32 w = 0; w < world; ++w) {
+    const u32* hd = heads + (size_t)w * SIM_SREQ_HEAD_WORDS;
+    if (hd[0] > SIM_SREQ_HEAD_PAIRS) { h->ops_dropped += hd[0]; continue; }  // model bound: that shard's list is dropped
+    for (u32 i = 0; i < hd[0]; ++i) v.emplace_back(hd[1 + 2 * i], hd[2 + 2 * i]);
+  }
+  std::sort(v.begin(), v.end());
+  for (auto& pr : v) {
+    int rc = inject_val(h, of_tick + 2, SIM_OP_SUSPECT, pr.first, pr.second, 0, 0);
+    if (rc) return rc;
+  }
+  return SIM_OK;
+}
 int sim_suspect_requests(sim_handle* h, uint32_t* out, uint32_t cap_pairs, uint32_t* n_pairs) {
   if (!h || !n_pairs || h->in_tick) return SIM_EINVAL;
   *n_pairs = 0;

@@ -45,8 +45,17 @@ class ShardedSim:
         self.n = n_nodes
         self.m = n_nodes // self.world
         self.lo = self.rank * self.m
-        # slot-less failed probes (possible only with the SWIM layer on and packet loss): gathered after every tick
-        self._poll_suspects = bool(kw.get("probe_interval", 0)) and kw.get("loss", 0.0) > 0
+        # slot-less failed probes (SWIM layer on): every tick's lists are gathered on the device and read two ticks later
+        self._poll_suspects = bool(kw.get("probe_interval", 0))
+        if self._poll_suspects:
+            w = _ffi.SREQ_HEAD_WORDS
+            self._sq_send = [torch.zeros(w, dtype=torch.int32, device=device) for _ in range(4)]
+            self._sq_gath = [torch.zeros(w * self.world, dtype=torch.int32, device=device) for _ in range(4)] if device.type == "cuda" else None
+            self._sq_host = [torch.zeros(w * self.world, dtype=torch.int32) for _ in range(4)]
+            if device.type == "cuda":
+                self._sq_host = [x.pin_memory() for x in self._sq_host]
+                self._sq_stream = torch.cuda.Stream(device)
+            self._sq_inflight = []
         self._pending = []  # async all-to-alls of the round in flight
         self._xt = None     # exchange timing: list of (start, end) event pairs while enabled
 
@@ -123,29 +132,38 @@ class ShardedSim:
         if self.device.type == "cuda":
             self.sim.sync()  # the buffers go away with this frame
 
-    def _suspicions(self):
-        """Probes that failed on a target without a view slot (include/serf_sim.h sim_suspect_requests): every shard's
-        list of the tick just ended, merged in ascending prober order, becomes SIM_OP_SUSPECT operations of the next
-        tick on EVERY shard (the schedule and the slot map are replicated)."""
-        mine = self.sim.suspect_requests().astype("int64")
-        cnt = torch.tensor([len(mine)], dtype=torch.int64, device=self.device)
-        cnts = [torch.zeros_like(cnt) for _ in range(self.world)]
-        dist.all_gather(cnts, cnt, group=self.group)
-        mx = max(int(c[0]) for c in cnts)
-        if mx == 0:
-            return
-        pad = torch.zeros((mx, 2), dtype=torch.int64)
-        pad[:len(mine)] = torch.from_numpy(mine)
-        pad = pad.to(self.device)
-        allp = [torch.zeros_like(pad) for _ in range(self.world)]
-        dist.all_gather(allp, pad, group=self.group)
-        pairs = sorted((int(p[i][0]), int(p[i][1])) for p, c in zip((x.cpu() for x in allp), cnts) for i in range(int(c[0])))
-        for prober, target in pairs:
-            self.sim.inject(self.sim.tick, _ffi.OP_SUSPECT, prober, target, 0)
+    def _suspicions_out(self):
+        """Probes that failed on a target without a view slot (include/serf_sim.h sim_suspect_export / _import): the head
+        of this shard's list of the tick just ended goes into an all-gather on the device, the gathered heads follow into
+        pinned host memory, and nobody waits: the result is read two ticks later (`_suspicions_in`)."""
+        t = self.sim.tick - 1
+        i = t % len(self._sq_send)
+        self.sim.suspect_export(self._sq_send[i].data_ptr())
+        if self.device.type == "cuda":
+            # on a side stream: the compute stream never waits for this collective, only the side stream waits for the export
+            self._sq_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._sq_stream):
+                dist.all_gather_into_tensor(self._sq_gath[i], self._sq_send[i], group=self.group, async_op=True).wait()
+                self._sq_host[i].copy_(self._sq_gath[i], non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self._sq_stream)
+        else:
+            done = dist.all_gather_into_tensor(self._sq_host[i], self._sq_send[i], group=self.group, async_op=True)
+        self._sq_inflight.append((t, i, done))
+
+    def _suspicions_in(self):
+        """Before tick T begins: the gathered lists of tick T - 2 become SIM_OP_SUSPECT operations of tick T on EVERY shard
+        (the schedule and the slot map are replicated) — the rule of a single-process run."""
+        while self._sq_inflight and self._sq_inflight[0][0] + 2 <= self.sim.tick:
+            t, i, done = self._sq_inflight.pop(0)
+            done.synchronize() if self.device.type == "cuda" else done.wait()  # issued two ticks ago
+            self.sim.suspect_import(t, self._sq_host[i].data_ptr(), self.world)
 
     def step(self, n_ticks=1):
         for _ in range(n_ticks):
             self._drain()
+            if self._poll_suspects:
+                self._suspicions_in()
             if self.sim.recycle_due():
                 self._recycle()
             rbuf = self.recv[self.sim.tick & 1] if self.chunks > 1 else self.recv[0]  # packets sent during tick t land in recv[t & 1]
@@ -163,7 +181,7 @@ class ShardedSim:
                     self._exchange(rbuf[lo:lo + self.chunk_bytes], self.send[lo:lo + self.chunk_bytes], True)
                 self.sim.step_end()
             if self._poll_suspects:
-                self._suspicions()
+                self._suspicions_out()
 
     def _exchange(self, recv, send, asynchronous):
         if self._xt is not None:  # measurement mode: bracket the collective with events, no overlap
@@ -233,4 +251,6 @@ class ShardedSim:
 
     def close(self):
         self._drain()
+        for _, _, done in getattr(self, "_sq_inflight", []):  # gathers still writing into our buffers
+            done.synchronize() if self.device.type == "cuda" else done.wait()
         self.sim.close()

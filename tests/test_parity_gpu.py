@@ -342,12 +342,23 @@ def test_config3_1m_properties(hiplib):
 
 
 def _suspicions_on_one_gpu(shards):
-    """serf_amd/shard.py ShardedSim._suspicions for hand-driven shards: every shard's slot-less failed probes of the tick
-    just ended, merged in ascending prober order, become SIM_OP_SUSPECT operations of the next tick on every shard."""
-    pairs = sorted((int(a), int(b)) for s in shards for a, b in s.suspect_requests())
-    for s in shards:
-        for prober, target in pairs:
-            s.inject(s.tick, _ffi.OP_SUSPECT, prober, target, 0)
+    """serf_amd/shard.py ShardedSim._suspicions_out / _in for hand-driven shards, called after every sim_step_end: every
+    shard exports the head of its list of slot-less failed probes of the tick just ended (sim_suspect_export, device
+    memory), the "all-gather" is a copy to the host, and the gathered heads of tick t - 1 are imported on every shard
+    (sim_suspect_import) before tick t + 1 begins."""
+    import torch
+
+    V, t = len(shards), shards[0].tick - 1
+    send = torch.zeros(V, _ffi.SREQ_HEAD_WORDS, dtype=torch.int32, device="cuda")
+    for v, s in enumerate(shards):
+        s.suspect_export(send[v].data_ptr())
+        s.sync()
+    q = shards[0].__dict__.setdefault("_sq_pending", [])
+    q.append((t, send.cpu().contiguous()))
+    while q and q[0][0] + 2 <= shards[0].tick:
+        of_tick, heads = q.pop(0)
+        for s in shards:
+            s.suspect_import(of_tick, heads.data_ptr(), V)
 
 
 def _push_pull_on_one_gpu(shards):

@@ -4,7 +4,8 @@ two ranks on one device): each rank compares every array of its shard, every 5 t
 single-process run of the CPU oracle (test infrastructure).  The multi-process twin of
 tests/test_parity_gpu.py::test_sharded_kernel_four_shards_on_one_gpu; run it on the GPU box under `timeout`.
 
-usage: python tools/shard_procs_check.py [world] [chunks] [swim] [nodes]"""
+usage: python tools/shard_procs_check.py [world] [chunks] [swim] [nodes] [loss]
+(loss >= 0.05: 256 view slots, and the run must have carried slot-less suspicions across the shards)"""
 import os
 import sys
 import traceback
@@ -12,7 +13,7 @@ import traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def worker(rank, world, port, n, ticks, swim, chunks, q):
+def worker(rank, world, port, n, ticks, swim, chunks, q, loss=0.02):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -40,7 +41,8 @@ def worker(rank, world, port, n, ticks, swim, chunks, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     where = "start"
     try:
-        kw = dict(fanout=3, view_slots=64, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=0.02,
+        vs = 64 if loss < 0.05 else 256
+        kw = dict(fanout=3, view_slots=vs, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=loss,
                   push_pull_interval=4 if swim else 0)
         mark("creating")
         sh = ShardedSim(serf_amd.load(), n, dev, chunks=chunks, **kw)
@@ -55,6 +57,14 @@ def worker(rank, world, port, n, ticks, swim, chunks, q):
             ref.inject(t, op, node, a, b)
         m = n // world
         lo = rank * m
+        handed = [0]
+        if swim:
+            real_import = sh.sim.suspect_import
+
+            def counting(of_tick, ptr, w):
+                handed[0] += int(sh._sq_host[of_tick % len(sh._sq_host)].view(w, -1)[:, 0].sum())
+                return real_import(of_tick, ptr, w)
+            sh.sim.suspect_import = counting
         for t in range(0, ticks, 5):
             where = f"step to tick {t + 5}"
             mark(where)
@@ -73,7 +83,7 @@ def worker(rank, world, port, n, ticks, swim, chunks, q):
                 per = len(b) // n
                 if a.tobytes() != b[lo * per:(lo + m) * per].tobytes():
                     raise AssertionError(f"rank {rank} array {which} differs at tick {t + 5}")
-            for which, rows in ((_ffi.ARR_VIEW, 64), (_ffi.ARR_ERING, 16), (_ffi.ARR_QRING, 8)):
+            for which, rows in ((_ffi.ARR_VIEW, vs), (_ffi.ARR_ERING, 16), (_ffi.ARR_QRING, 8)):
                 where = f"tick {t + 5} array {which}"
                 a = sh.sim.dump(which).reshape(rows, m)
                 b = ref.dump(which).reshape(rows, n)[:, lo:lo + m]
@@ -87,7 +97,9 @@ def worker(rank, world, port, n, ticks, swim, chunks, q):
         for qop in [op for op in ops if op[1] == _ffi.OP_QUERY and op[4] & _ffi.F_ACK][:3]:
             assert sh.query_status(qop[3]) == ref.query_status(qop[3])  # acks summed over the shards
         mark("query status agrees")
-        q.put((rank, f"ok: {ticks} ticks, every array of the shard equal to the oracle's slice at every 5th tick"))
+        if loss >= 0.05 and handed[0] <= 20:
+            raise AssertionError(f"only {handed[0]} slot-less suspicions crossed the shards")
+        q.put((rank, f"ok: {ticks} ticks, every array of the shard equal to the oracle's slice at every 5th tick; {handed[0]} slot-less suspicions handed over"))
     except BaseException as e:  # noqa: BLE001
         q.put((rank, f"FAILED at {where}: {e!r}\n{traceback.format_exc()}"))
     q.close()
@@ -103,10 +115,11 @@ def main():
     chunks = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     swim = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     n = int(sys.argv[4]) if len(sys.argv) > 4 else 2048
+    loss = float(sys.argv[5]) if len(sys.argv) > 5 else 0.02
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29300 + (os.getpid() % 300)
-    procs = [ctx.Process(target=worker, args=(r, world, port, n, 60, swim, chunks, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, n, 60, swim, chunks, q, loss)) for r in range(world)]
     for p in procs:
         p.start()
     res = []
