@@ -251,6 +251,7 @@ __device__ static inline u32 sigma_inv(const TickP& p, u32 y) {
 // ------------------------------------------------------------------------------------------------
 // device state (data layout in HBM: DESIGN.md §3)
 // ------------------------------------------------------------------------------------------------
+#define SREQ_HEAD 62u  // pairs of a tick's request list the kernel also writes into pinned host memory (a longer list is fetched when it is read)
 struct Dev {
   // row groups, one uint4 per node each
   uint4* R0;  // {clock.lo, clock.hi, event_clock.lo, event_clock.hi}
@@ -287,7 +288,10 @@ struct Dev {
   uint4* nullcell;  // 2 x uint4 of zeros: where the prefetch of a record without a lookup points
   uint8_t* skipmask;  // [Nl] gossip_to_the_dead: bit k = do not send packet k this tick (written by gossip_skip_kernel)
   u32* sreq;        // [1 + 2 * SIM_SUSPECT_REQ_MAX]: count, then the (prober, target) pairs of the running tick's slot-less
-                    // failed probes (one of two buffers, by tick parity: the host reads a tick's list one tick later)
+                    // failed probes (one of three buffers, by tick mod 3: the host reads a tick's list one tick later)
+  u32* sreq_next;   // the count word of the NEXT tick's buffer: zeroed by this tick's kernel (no memset between two ticks)
+  u32* sreq_hh;     // pinned HOST memory, [SREQ_HEAD] pairs, 0xFFFFFFFF-terminated: the head of the same list, written
+                    // straight to where the host reads it (no copy between two ticks); null in sharded handles
   sim_event* events;
   u32* ev_count;
   u32 ev_cap;
@@ -1087,6 +1091,7 @@ __device__ static void swim_probe(const Ctx& c, Node& n, const TickP& tp, const 
 #ifndef TICK_LEAN
     u32 i = atomicAdd(d.sreq, 1u);
     if (i < SIM_SUSPECT_REQ_MAX) { d.sreq[1 + 2 * i] = c.gid; d.sreq[2 + 2 * i] = t; }
+    if (d.sreq_hh && i < SREQ_HEAD) { d.sreq_hh[2 * i + 1] = t; d.sreq_hh[2 * i] = c.gid; }
 #endif
     return;
   }
@@ -1292,6 +1297,7 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
   // one launch covers `cnt` nodes: the whole shard (chunk == ~0), or sender chunk `chunk` of a sharded run = the nodes
   // whose offset inside their vblock lies in sub-slab `chunk` (V ranges of `sub` consecutive nodes)
   const u32 idx = blockIdx.x * TBLOCK + threadIdx.x;
+  if (idx == 0 && d.swim) *d.sreq_next = 0;  // the next tick's request list starts empty (its buffer was read a tick ago)
   if (idx >= cnt) return;
   u32 l = idx;
   if (SHARDED && chunk != 0xFFFFFFFFu) {
@@ -2745,10 +2751,10 @@ struct sim_handle {
   // slot-less failed probes (SIMSPEC §2.7): device lists by tick parity, their heads copied to pinned host memory behind
   // every tick's launch; the list of tick t is read at the end of tick t + 1 — by then the copy has long landed, nobody
   // waits for a kernel — and replayed as operations of tick t + 2
-  u32* sreq_buf[2];
-  u32* sreq_host[2];       // pinned: count + the first SREQ_HEAD pairs
-  hipEvent_t sreq_ev[2];
-  u64 sreq_tick[2];        // the tick whose list sits in the buffer (~0: none / consumed)
+  u32* sreq_buf[3];
+  u32* sreq_host[3];       // pinned, written by the kernel itself: the first SREQ_HEAD pairs, unused ones 0xFFFFFFFF
+  hipEvent_t sreq_ev[3];
+  u64 sreq_tick[3];        // the tick whose list sits in the buffer (~0: none / consumed)
   u32 pp_step;  // push-pull batches: every pp_step ticks one of PP_GROUPS pair classes synchronises (0 = off)
   TickP cur_tp;            // parameters of the tick between sim_step_begin and sim_step_end
   bool in_tick, tick_timed, tick_bracket;
@@ -2829,7 +2835,6 @@ static int dalloc(sim_handle* h, T** p, size_t n) {
 }
 static inline int grid_for(size_t n) { return (int)std::min<size_t>((n + BLOCK - 1) / BLOCK, 8192); }
 #define EV_CAP (1u << 20)
-#define SREQ_HEAD 62u  // pairs of a tick's request list that travel with the per-tick copy (a longer list is fetched when it is read)
 
 extern "C" {
 
@@ -2852,7 +2857,7 @@ int sim_destroy(sim_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   for (auto& pr : h->prof) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (h->d_pp) (void)hipFree(h->d_pp);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 3; ++i) {
     if (h->sreq_host[i]) (void)hipHostFree(h->sreq_host[i]);
     if (h->sreq_ev[i]) (void)hipEventDestroy(h->sreq_ev[i]);
   }
@@ -2878,7 +2883,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   h->bound = false;
   h->n_alloc = 0; h->ops_dropped = h->slots_recycled = 0; h->recycle_at = 0xFFFFFFFFu;
   h->pp_done_at = 0xFFFFFFFFu; h->d_pp = nullptr;
-  h->sreq_host[0] = h->sreq_host[1] = nullptr; h->sreq_ev[0] = h->sreq_ev[1] = nullptr; h->sreq_buf[0] = h->sreq_buf[1] = nullptr;
+  for (int i = 0; i < 3; ++i) { h->sreq_host[i] = nullptr; h->sreq_ev[i] = nullptr; h->sreq_buf[i] = nullptr; }
   h->in_tick = false;
   h->tick_timed = false;
   h->rbuf[0] = h->rbuf[1] = nullptr;
@@ -2942,7 +2947,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   DA(d.view, (size_t)d.A * Nl * 2)
   DA(d.ering, (size_t)d.Bev * Nl * 2)
   DA(d.qring, (size_t)d.Bq * Nl * 2)
-  DA(d.slot_of, d.N) DA(d.subject_of, d.A) DA(d.walk, d.A) DA(d.upmap, nup) DA(d.nullcell, 4) DA(d.skipmask, d.gttd ? Nl : 1) DA(h->sreq_buf[0], 1 + 2 * SIM_SUSPECT_REQ_MAX) DA(h->sreq_buf[1], 1 + 2 * SIM_SUSPECT_REQ_MAX)
+  DA(d.slot_of, d.N) DA(d.subject_of, d.A) DA(d.walk, d.A) DA(d.upmap, nup) DA(d.nullcell, 4) DA(d.skipmask, d.gttd ? Nl : 1) DA(h->sreq_buf[0], 1 + 2 * SIM_SUSPECT_REQ_MAX) DA(h->sreq_buf[1], 1 + 2 * SIM_SUSPECT_REQ_MAX) DA(h->sreq_buf[2], 1 + 2 * SIM_SUSPECT_REQ_MAX)
   DA(d.qtab, QTAB_U4(d.N)) DA(d.qbits, (size_t)SIM_QT * 2 * nup)
   DA(d.events, (size_t)EV_CAP) DA(d.ev_count, 1)
   DA(h->d_base, (size_t)d.N * 2)
@@ -2958,10 +2963,11 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   HCHECK(zero(d.qpay, (size_t)SIM_Q * Nl * 16));
   HCHECK(zero(d.ev_count, 4));
   HCHECK(zero(d.nullcell, 64));
-  HCHECK(zero(h->sreq_buf[0], 4)); HCHECK(zero(h->sreq_buf[1], 4));
   d.sreq = h->sreq_buf[0];
-  for (int i = 0; i < 2; ++i) {
-    HCHECK(hipHostMalloc((void**)&h->sreq_host[i], (1 + 2 * SREQ_HEAD) * 4));
+  for (int i = 0; i < 3; ++i) {
+    HCHECK(zero(h->sreq_buf[i], 4));
+    HCHECK(hipHostMalloc((void**)&h->sreq_host[i], 2 * SREQ_HEAD * 4));
+    memset(h->sreq_host[i], 0xFF, 2 * SREQ_HEAD * 4);
     HCHECK(hipEventCreateWithFlags(&h->sreq_ev[i], hipEventDisableTiming));
     h->sreq_tick[i] = ~0ull;
   }
@@ -3451,9 +3457,11 @@ int sim_step_begin(sim_handle* h) {
     int rc = recycle_local(h);
     if (rc) return rc;
   }
-  if (d.swim) {  // this tick's request list (the other buffer holds the previous tick's until it has been read)
-    d.sreq = h->sreq_buf[h->tick & 1];
-    HCHECK(hipMemsetAsync(d.sreq, 0, 4, h->stream));
+  if (d.swim) {  // this tick's request list: its count was zeroed by the previous tick's kernel (or never used); the two
+    // other buffers hold the lists of the two ticks before until they have been read
+    d.sreq = h->sreq_buf[h->tick % 3];
+    d.sreq_next = h->sreq_buf[(h->tick + 1) % 3];
+    d.sreq_hh = d.sharded ? nullptr : h->sreq_host[h->tick % 3];
   }
   TickP& tp = h->cur_tp;
   tickp_make(&tp, &h->cfg, h->tick);
@@ -3585,9 +3593,8 @@ int sim_step_end(sim_handle* h) {
   // BEFORE is read now (its copy landed a whole tick ago) and, every shard being here, replayed next tick.
   if (h->d.swim) {
     const u64 t = h->tick - 1;  // the tick that just ended
-    HCHECK(hipMemcpyAsync(h->sreq_host[t & 1], h->sreq_buf[t & 1], (1 + 2 * SREQ_HEAD) * 4, hipMemcpyDeviceToHost, h->stream));
-    HCHECK(hipEventRecord(h->sreq_ev[t & 1], h->stream));
-    h->sreq_tick[t & 1] = t;
+    HCHECK(hipEventRecord(h->sreq_ev[t % 3], h->stream));
+    h->sreq_tick[t % 3] = t;
     if (!h->d.sharded) {
       static thread_local std::vector<u32> buf(2 * SIM_SUSPECT_REQ_MAX);
       u32 n = 0;
@@ -3602,18 +3609,30 @@ int sim_step_end(sim_handle* h) {
 // the list of one finished tick out of its buffer (sorted by prober); marks it read
 static int sreq_take(sim_handle* h, u64 t, uint32_t* out, uint32_t cap_pairs, uint32_t* n_pairs) {
   *n_pairs = 0;
-  if (h->sreq_tick[t & 1] != t) return SIM_OK;  // nothing recorded for that tick, or read already
-  h->sreq_tick[t & 1] = ~0ull;
-  HCHECK(hipEventSynchronize(h->sreq_ev[t & 1]));
-  u32 n = h->sreq_host[t & 1][0];
-  if (!n) return SIM_OK;
-  if (n > SIM_SUSPECT_REQ_MAX) { h->ops_dropped += n; return SIM_OK; }  // model bound: the whole tick's list is dropped
-  if (n > cap_pairs || !out) return SIM_ERANGE;
-  if (n <= SREQ_HEAD) memcpy(out, h->sreq_host[t & 1] + 1, (size_t)n * 8);
-  else {  // a long list: the buffer on the device is untouched until the tick after next begins
-    HCHECK(hipMemcpyAsync(out, h->sreq_buf[t & 1] + 1, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+  const u32 b = (u32)(t % 3);
+  if (h->sreq_tick[b] != t) return SIM_OK;  // nothing recorded for that tick, or read already
+  h->sreq_tick[b] = ~0ull;
+  HCHECK(hipEventSynchronize(h->sreq_ev[b]));
+  u32* hh = h->sreq_host[b];
+  u32 n = 0;
+  if (!h->d.sharded) {  // the kernel wrote the head of the list here itself
+    while (n < SREQ_HEAD && hh[2 * n] != 0xFFFFFFFFu) ++n;
+    if (!n) return SIM_OK;
+  }
+  if (h->d.sharded || n == SREQ_HEAD) {  // a long list (or no host copy): the buffer on the device is untouched until the tick after next has run
+    HCHECK(hipMemcpyAsync(&n, h->sreq_buf[b], 4, hipMemcpyDeviceToHost, h->stream));
     HCHECK(hipStreamSynchronize(h->stream));
   }
+  auto forget = [&]() { if (!h->d.sharded) memset(hh, 0xFF, 2 * SREQ_HEAD * 4); };
+  if (!n) return SIM_OK;
+  if (n > SIM_SUSPECT_REQ_MAX) { h->ops_dropped += n; forget(); return SIM_OK; }  // model bound: the whole tick's list is dropped
+  if (n > cap_pairs || !out) { h->sreq_tick[b] = t; return SIM_ERANGE; }
+  if (!h->d.sharded && n <= SREQ_HEAD) memcpy(out, hh, (size_t)n * 8);
+  else {
+    HCHECK(hipMemcpyAsync(out, h->sreq_buf[b] + 1, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    HCHECK(hipStreamSynchronize(h->stream));
+  }
+  forget();
   std::vector<std::pair<u32, u32>> v(n);
   for (u32 i = 0; i < n; ++i) v[i] = {out[2 * i], out[2 * i + 1]};
   std::sort(v.begin(), v.end());  // a node probes once per tick: probers are distinct
@@ -3626,8 +3645,8 @@ int sim_suspect_export(sim_handle* h, void* out) {  // the head of the list of t
   static_assert(SIM_SREQ_HEAD_WORDS * 4 <= (1 + 2 * SIM_SUSPECT_REQ_MAX) * 4, "the head is a prefix of the list buffer");
   if (!h->d.swim) { HCHECK(hipMemsetAsync(out, 0, SIM_SREQ_HEAD_WORDS * 4, h->stream)); return SIM_OK; }
   const u64 t = h->tick - 1;
-  HCHECK(hipMemcpyAsync(out, h->sreq_buf[t & 1], SIM_SREQ_HEAD_WORDS * 4, hipMemcpyDeviceToDevice, h->stream));
-  h->sreq_tick[t & 1] = ~0ull;  // handed over: nothing for sim_suspect_requests to read
+  HCHECK(hipMemcpyAsync(out, h->sreq_buf[t % 3], SIM_SREQ_HEAD_WORDS * 4, hipMemcpyDeviceToDevice, h->stream));
+  h->sreq_tick[t % 3] = ~0ull;  // handed over: nothing for sim_suspect_requests to read
   return SIM_OK;
 }
 int sim_suspect_import(sim_handle* h, uint64_t of_tick, const uint32_t* heads, uint32_t world) {
