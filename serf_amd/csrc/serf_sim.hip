@@ -1282,8 +1282,10 @@ __device__ static inline u32 pk_word(const uint4& v, u32 p) { return p == 0 ? v.
 // (B64: local mode with 64-node blocks — the sharded instantiations read tp.B at run time and pass false)
 // (MP: packets of more than one page, sim_config.pkt_records > SIM_P: the deliver loop walks the pages of a packet, the
 //  drain takes up to d.P entries per packet; with MP = false all of that folds back to the one-page kernel)
+// (the body of the kernel as a function of the block index: written this way the compiler keeps 76 instead of 116 bytes of
+// scratch per lane — 2 % of the tick, profiles/r03_experiments.md)
 template <bool SHARDED, int F, bool B64, bool MP>
-__global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, TickP ptp, u32 cur, const uint4* base, u32 chunk, u32 cnt) {
+__device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const TickP& ptp, const u32 cur, const uint4* base, const u32 chunk, const u32 cnt, const u32 bx) {
 #ifdef TICK_TIMING
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -1296,7 +1298,7 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
   const u32 tid = threadIdx.x;
   // one launch covers `cnt` nodes: the whole shard (chunk == ~0), or sender chunk `chunk` of a sharded run = the nodes
   // whose offset inside their vblock lies in sub-slab `chunk` (V ranges of `sub` consecutive nodes)
-  const u32 idx = blockIdx.x * TBLOCK + threadIdx.x;
+  const u32 idx = bx * TBLOCK + threadIdx.x;
   if (idx == 0 && d.swim) *d.sreq_next = 0;  // the next tick's request list starts empty (its buffer was read a tick ago)
   if (idx >= cnt) return;
   u32 l = idx;
@@ -1305,8 +1307,8 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
     l = b * tp.blk + chunk * tp.sub + (idx - b * tp.sub);
   }
 #ifdef TICK_ABLATE
-  if (ABL(0xFF00u) && blockIdx.x < 1024u) {  // experiment: stagger the first generation of blocks
-    u32 slot = (blockIdx.x >> 8) & 3u, per = (tp.abl >> 8) & 0xFFu;
+  if (ABL(0xFF00u) && bx < 1024u) {  // experiment: stagger the first generation of blocks
+    u32 slot = (bx >> 8) & 3u, per = (tp.abl >> 8) & 0xFFu;
     for (u32 i = 0; i < slot * per; ++i) __builtin_amdgcn_s_sleep(127);
   }
 #endif
@@ -1606,7 +1608,7 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
 #else
   const u32 skipm = 0u;  // (measurement build: the round's optional memberlist switches compiled out of the tick kernel)
 #endif
-  const bool coop = (blockIdx.x + 1u) * TBLOCK <= cnt;  // every lane of the block is here
+  const bool coop = (bx + 1u) * TBLOCK <= cnt;  // every lane of the block is here
   // One 48-byte cell per lane that has one (`wr`), written quad-cooperatively when the whole wave is here:
   // three lanes of a quad write one whole cell per store instruction (lane i < 3 writes part i of quad-mate
   // j's packet): the texture addresser sees 48 contiguous bytes per quad and L2 one write per cell instead of
@@ -1847,6 +1849,17 @@ __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp,
 #ifdef TICK_TIMING
   if ((threadIdx.x & 63) == 0)
     for (int i = 0; i < 12; ++i) atomicAdd(&g_tt[i], tacc[i]);
+#endif
+}
+template <bool SHARDED, int F, bool B64, bool MP>
+__global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, TickP ptp, u32 cur, const uint4* base, u32 chunk, u32 cnt) {
+#ifdef TICK_PERSIST
+  // experiment (withdrawn, profiles/r03_experiments.md): as many blocks as fit on the GPU at once, each walking its share of the node blocks
+  const u32 nb = (cnt + TBLOCK - 1) / TBLOCK;
+#pragma unroll 1
+  for (u32 bx = blockIdx.x; bx < nb; bx += gridDim.x) tick_block<SHARDED, F, B64, MP>(d, tp, ptp, cur, base, chunk, cnt, bx);
+#else
+  tick_block<SHARDED, F, B64, MP>(d, tp, ptp, cur, base, chunk, cnt, blockIdx.x);
 #endif
 }
 
@@ -3539,6 +3552,9 @@ static int tick_launch(sim_handle* h, u32 chunk) {
   const TickP& ptp = h->tick ? h->prev : h->cur_tp;  // the map the packets in flight were sent with (tick 0: none are)
   u32 cnt = chunk == 0xFFFFFFFFu ? d.Nl : tp.V * tp.sub;
   int grid = (int)((cnt + TBLOCK - 1) / TBLOCK);
+#ifdef TICK_PERSIST
+  if (grid > TICK_PERSIST) grid = TICK_PERSIST;
+#endif
   u32 cur = (u32)(h->tick & 1);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->tick_timed && !h->tick_bracket) {
