@@ -12,6 +12,21 @@ from . import _ffi
 BENCH_MIX = (0.55, 0.2, 0.15, 0.05, 0.05)
 
 
+def _interleaved(n_ops, mix):
+    """The kinds of `n_ops` operations in the proportions `mix`, spread as evenly as the proportions allow (smooth
+    weighted round-robin: add the weights, take the largest, subtract the total) — every stretch of the sequence has
+    the mix of the whole, which a short timed window of a benchmark needs."""
+    w = np.array(mix, dtype=np.float64) / np.sum(mix)
+    cur = np.zeros(len(w))
+    out = np.empty(n_ops, dtype=np.int64)
+    for i in range(n_ops):
+        cur += w
+        k = int(np.argmax(cur))
+        cur[k] -= 1.0
+        out[i] = k
+    return out
+
+
 def schedule(n_nodes, n_ticks, rate, seed=1234, mix=(0.5, 0.15, 0.15, 0.1, 0.1), max_member_subjects=None, even=False):
     """Return a list of (tick, op, node, a, b).
 
@@ -24,6 +39,8 @@ def schedule(n_nodes, n_ticks, rate, seed=1234, mix=(0.5, 0.15, 0.15, 0.1, 0.1),
     if even:  # evenly spaced injections: a steady load for benchmarks (the draw above keeps the stream aligned)
         ticks = (np.arange(n_ops) * (n_ticks / n_ops)).astype(np.int64)
     kinds = rng.choice(5, n_ops, p=np.array(mix) / np.sum(mix))
+    if even:  # ... and the kinds interleaved in the proportions of the mix instead of drawn (same reason)
+        kinds = _interleaved(n_ops, mix)
     used = set()
     ops = []
     budget = max_member_subjects if max_member_subjects is not None else n_nodes // 4
