@@ -2302,10 +2302,24 @@ __global__ void uncanon_entries_kernel(uint4* arr, size_t tail, size_t first, si
   }
 }
 // keep d.walk sorted by subject: shift [pos, count) up by one, put slot a at pos (one thread; slot allocation is rare)
-__global__ void walk_insert_kernel(u32* walk, u32 count, u32 pos, u32 a) {
-  if (threadIdx.x || blockIdx.x) return;
+__device__ static inline void walk_insert(u32* walk, u32 count, u32 pos, u32 a) {
   for (u32 i = count; i > pos; --i) walk[i] = walk[i - 1];
   walk[pos] = a;
+}
+// A subject takes view slot a: its column of the view := the subject's baseline entry, the slot joins the walk order, the
+// two slot maps point at each other.  ONE launch (it used to be four, 4 - 8 us of stream time each, in front of the tick of
+// every operation that names a new subject).
+__global__ void slot_alloc_kernel(uint4* view, size_t tail, size_t Nl, u32 a, uint4 e0, uint4 e1, u32* walk, u32 count, u32 pos,
+                                  u32* slot_of_x, u32* subject_of_a, u32 subject) {
+  if (!blockIdx.x && !threadIdx.x) {
+    walk_insert(walk, count, pos, a);
+    *slot_of_x = a;
+    *subject_of_a = subject;
+  }
+  for (size_t l = blockIdx.x * (size_t)blockDim.x + threadIdx.x; l < Nl; l += (size_t)gridDim.x * blockDim.x) {
+    view[(size_t)a * Nl + l] = e0;
+    view[tail + (size_t)a * Nl + l] = e1;
+  }
 }
 __global__ void fill_iota(u32* p, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = (u32)i;
@@ -2767,6 +2781,9 @@ struct sim_handle {
   u32* sreq_buf[3];
   u32* sreq_host[3];       // pinned, written by the kernel itself: the first SREQ_HEAD pairs, unused ones 0xFFFFFFFF
   hipEvent_t sreq_ev[3];
+  hipEvent_t sreq_wait[3]; // what marks "tick t's kernel has finished": sreq_ev (recorded behind the launch, or riding on the dispatch
+                           // itself as its stop event) or the stop event of the tick's timing pair; null: the stream was synchronised since
+  bool sreq_on_dispatch;   // this tick's launch carried its completion event: sim_step_end records nothing
   u64 sreq_tick[3];        // the tick whose list sits in the buffer (~0: none / consumed)
   u32 pp_step;  // push-pull batches: every pp_step ticks one of PP_GROUPS pair classes synchronises (0 = off)
   TickP cur_tp;            // parameters of the tick between sim_step_begin and sim_step_end
@@ -2896,7 +2913,8 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   h->bound = false;
   h->n_alloc = 0; h->ops_dropped = h->slots_recycled = 0; h->recycle_at = 0xFFFFFFFFu;
   h->pp_done_at = 0xFFFFFFFFu; h->d_pp = nullptr;
-  for (int i = 0; i < 3; ++i) { h->sreq_host[i] = nullptr; h->sreq_ev[i] = nullptr; h->sreq_buf[i] = nullptr; }
+  for (int i = 0; i < 3; ++i) { h->sreq_host[i] = nullptr; h->sreq_ev[i] = nullptr; h->sreq_buf[i] = nullptr; h->sreq_wait[i] = nullptr; }
+  h->sreq_on_dispatch = false;
   h->in_tick = false;
   h->tick_timed = false;
   h->rbuf[0] = h->rbuf[1] = nullptr;
@@ -3058,15 +3076,11 @@ static int ensure_slot(sim_handle* h, u32 subject) {
   const sim_view& b = h->base[subject];
   uint4 e0 = make_uint4((u32)b.ltime, (u32)(b.ltime >> 32), b.inc, b.bits);
   uint4 e1 = make_uint4(b.conf[0], b.conf[1], b.conf[2], b.conf[3]);
-  fill_view_col<<<grid_for(d.Nl), BLOCK, 0, h->stream>>>(d.view, d.vtail, d.Nl, a, e0, e1);
-  {
-    u32 pos = (u32)h->walk.size();
-    while (pos > 0 && h->subject_of[h->walk[pos - 1]] > subject) --pos;
-    walk_insert_kernel<<<1, 64, 0, h->stream>>>(d.walk, (u32)h->walk.size(), pos, a);
-    h->walk.insert(h->walk.begin() + pos, a);
-  }
-  poke_u32<<<1, 64, 0, h->stream>>>(d.slot_of + subject, a);
-  poke_u32<<<1, 64, 0, h->stream>>>(d.subject_of + a, subject);
+  u32 pos = (u32)h->walk.size();
+  while (pos > 0 && h->subject_of[h->walk[pos - 1]] > subject) --pos;
+  slot_alloc_kernel<<<grid_for(d.Nl), BLOCK, 0, h->stream>>>(d.view, d.vtail, d.Nl, a, e0, e1, d.walk, (u32)h->walk.size(), pos,
+                                                             d.slot_of + subject, d.subject_of + a, subject);
+  h->walk.insert(h->walk.begin() + pos, a);
   return SIM_OK;
 }
 // the subject an operation needs a view slot for (NOSLOT: none) — SIMSPEC §2.6
@@ -3562,9 +3576,18 @@ static int tick_launch(sim_handle* h, u32 chunk) {
     HCHECK(hipEventCreate(&e1));
     h->prof.emplace_back(e0, e1);
   }
+  // One launch per tick and a request list to read behind it (local mode, SWIM on): the event the host waits on before it
+  // reads the list rides on the dispatch as its stop event — a hipEventRecord behind every launch is a marker packet of
+  // its own, ~5 us of stream time per tick.
+  h->sreq_on_dispatch = false;
+  if (d.swim && !d.sharded && chunk == 0xFFFFFFFFu) {
+    if (!e1) e1 = h->sreq_ev[h->tick % 3];
+    h->sreq_wait[h->tick % 3] = e1;
+    h->sreq_on_dispatch = true;
+  }
 #define LAUNCH_TICK_(SH, FF, BB, PP)                                                                                     \
   do {                                                                                                                   \
-    if (e0) hipExtLaunchKernelGGL((tick_kernel<SH, FF, BB, PP>), dim3(grid), dim3(TBLOCK), 0, h->stream, e0, e1, 0, d, tp, ptp, cur, \
+    if (e1) hipExtLaunchKernelGGL((tick_kernel<SH, FF, BB, PP>), dim3(grid), dim3(TBLOCK), 0, h->stream, e0, e1, 0, d, tp, ptp, cur, \
                                   (const uint4*)h->d_base, chunk, cnt);                                                  \
     else tick_kernel<SH, FF, BB, PP><<<grid, TBLOCK, 0, h->stream>>>(d, tp, ptp, cur, h->d_base, chunk, cnt);            \
   } while (0)
@@ -3609,7 +3632,11 @@ int sim_step_end(sim_handle* h) {
   // BEFORE is read now (its copy landed a whole tick ago) and, every shard being here, replayed next tick.
   if (h->d.swim) {
     const u64 t = h->tick - 1;  // the tick that just ended
-    HCHECK(hipEventRecord(h->sreq_ev[t % 3], h->stream));
+    if (!h->sreq_on_dispatch) {
+      HCHECK(hipEventRecord(h->sreq_ev[t % 3], h->stream));
+      h->sreq_wait[t % 3] = h->sreq_ev[t % 3];
+    }
+    h->sreq_on_dispatch = false;
     h->sreq_tick[t % 3] = t;
     if (!h->d.sharded) {
       static thread_local std::vector<u32> buf(2 * SIM_SUSPECT_REQ_MAX);
@@ -3628,7 +3655,7 @@ static int sreq_take(sim_handle* h, u64 t, uint32_t* out, uint32_t cap_pairs, ui
   const u32 b = (u32)(t % 3);
   if (h->sreq_tick[b] != t) return SIM_OK;  // nothing recorded for that tick, or read already
   h->sreq_tick[b] = ~0ull;
-  HCHECK(hipEventSynchronize(h->sreq_ev[b]));
+  if (h->sreq_wait[b]) HCHECK(hipEventSynchronize(h->sreq_wait[b]));
   u32* hh = h->sreq_host[b];
   u32 n = 0;
   if (!h->d.sharded) {  // the kernel wrote the head of the list here itself
@@ -4181,6 +4208,7 @@ int sim_profile_read(sim_handle* h, double* ms, uint64_t* launches) {
   }
   *ms = tot;
   *launches = h->prof.size();
+  for (int i = 0; i < 3; ++i) h->sreq_wait[i] = nullptr;  // (the stream was synchronised above: every tick has finished)
   h->prof.clear();
   return SIM_OK;
 }
@@ -4201,6 +4229,7 @@ int sim_profile_read_stats(sim_handle* h, double out_ms[3], uint64_t* launches) 
   }
   out_ms[0] = tot; out_ms[1] = mn; out_ms[2] = mx;
   *launches = h->prof.size();
+  for (int i = 0; i < 3; ++i) h->sreq_wait[i] = nullptr;  // (the stream was synchronised above: every tick has finished)
   h->prof.clear();
   return SIM_OK;
 }
