@@ -1249,11 +1249,13 @@ __device__ static inline uint4 sel4(u32 i, const uint4& a, const uint4& b, const
 // the tick kernel
 // ------------------------------------------------------------------------------------------------
 #ifdef TICK_TIMING
-__device__ unsigned long long g_tt[16];
+__device__ unsigned long long g_tt[32];
 // wave-uniform accumulation in scalar registers; one set of atomics per wave at the very end
 #define TT(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tprev; tprev = t_; } while (0)
+#define TCNT(i, v) do { tacc[i] += (v); } while (0)  // wave-uniform event counts next to the cycle counters (12 .. 15)
 #else
 #define TT(i)
+#define TCNT(i, v)
 #endif
 #ifdef TICK_ABLATE
 static u32 g_ablate = 0;
@@ -1287,7 +1289,7 @@ __device__ static inline u32 pk_word(const uint4& v, u32 p) { return p == 0 ? v.
 template <bool SHARDED, int F, bool B64, bool MP>
 __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const TickP& ptp, const u32 cur, const uint4* base, const u32 chunk, const u32 cnt, const u32 bx) {
 #ifdef TICK_TIMING
-  unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tacc[32] = {0};
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #endif
   // LDS staging of the per-node inbox: the packet being delivered, the slot of each record's
@@ -1516,8 +1518,12 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
         if (ABL(32)) continue;
         uint4* wptr = nullptr;
         bool wall = false;
+        TCNT(13, 1);                                          // pages delivered with at least one record in the wave
+        TCNT(14, __popcll(__ballot(slow != 0)));              // lanes with a record that needs a handler
+        TCNT(15, __any(slow != 0) ? 1 : 0);                   // pages whose handler loop ran at all
 #pragma unroll 1
         while (__any(slow != 0)) {
+          TCNT(12, 1);                                        // iterations of the handler loop
           if (slow) {
             u32 p = (u32)__ffs((int)slow) - 1u;
             slow &= slow - 1u;
@@ -1848,7 +1854,7 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   TT(11);
 #ifdef TICK_TIMING
   if ((threadIdx.x & 63) == 0)
-    for (int i = 0; i < 12; ++i) atomicAdd(&g_tt[i], tacc[i]);
+    for (int i = 0; i < 32; ++i) atomicAdd(&g_tt[i], tacc[i]);
 #endif
 }
 template <bool SHARDED, int F, bool B64, bool MP>
@@ -2874,8 +2880,8 @@ static struct AblEnv { AblEnv() { if (const char* e = getenv("SERF_ABLATE")) g_a
 #endif
 #ifdef TICK_TIMING
 int sim_debug_timing(unsigned long long* out16, int reset) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tt), 16 * 8) != hipSuccess) return SIM_EDEVICE;
-  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tt), z, 16 * 8); }
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tt), 32 * 8) != hipSuccess) return SIM_EDEVICE;  // (the caller's buffer holds 32 words)
+  if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tt), z, 32 * 8); }
   return SIM_OK;
 }
 #endif

@@ -14,7 +14,7 @@ sim = _ffi.Sim(lib, _ffi.make_config(n, **kw))
 for o in ops:
     sim.inject(*o)
 sim.step(args.preroll); sim.sync()
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 32)()
 lib.dll.sim_debug_timing(buf, 1)
 sim.step(50); sim.sync()
 lib.dll.sim_debug_timing(buf, 1)
@@ -25,3 +25,6 @@ tot = sum(buf[:12])
 for i, nm in enumerate(names):
     print(f"{nm:44s} {buf[i]/waves:10.0f} cyc/wave  {100*buf[i]/tot:5.1f}%")
 print(f"{'total':44s} {tot/waves:10.0f} cyc/wave (clock ticks of s_memtime / readcyclecounter)")
+for i, nm in ((13, "pages with records, per wave and tick"), (15, "... whose handler loop ran"), (12, "handler-loop iterations per wave and tick"),
+              (14, "lanes with a slow record, per wave and tick (sum over pages)")):
+    print(f"{nm:60s} {buf[i]/waves:8.2f}")
