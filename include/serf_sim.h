@@ -29,7 +29,7 @@ extern "C" {
 
 /* ------------------------------------------------------------------ constants */
 
-#define SIM_ABI_VERSION 9u
+#define SIM_ABI_VERSION 10u
 
 #define SIM_P 4u  /* piggyback records per packet PAGE (48-byte cell: 4 records x 12 wire bytes) */
 #define SIM_PKT_BYTES 1400u /* byte budget of a gossip packet: memberlist's UDP payload limit (lan() and wan()); a packet
@@ -270,7 +270,10 @@ typedef struct sim_config {
                                * view says the target of one of its packets has been dead / left for longer does not
                                * gossip to it (kRandomNodes would not have picked it) — here: that packet is not sent,
                                * the transmits are spent all the same.  0 = every node stays a gossip target          */
-  uint32_t reserved2;         /* keeps `seed` 8-byte aligned                                    */
+  uint32_t reconnect_interval;/* Reconnector period in ticks (options.rs reconnect_interval, 30 s = 150), 0 = off: a node
+                               * with failed members attempts, with probability failed / alive, a memberlist.join — a
+                               * push-pull — with one of them (base.rs:612-681; SIMSPEC §2.9).  Needs the SWIM layer
+                               * (members only fail there).  (ABI <= 9: this word was reserved, 0)                   */
   uint64_t seed;              /* master seed; default 0x5EEDC0DE5E4F0001                        */
 } sim_config;
 
@@ -360,6 +363,11 @@ enum sim_op {
   SIM_OP_SUSPECT = 13,          /* internal: `node` suspects a = target (from = node) — a probe that failed on a target without
                                    a view slot in the previous tick (SIMSPEC §2.7: the suspicion is taken up one tick late,
                                    once the target has its slot); scheduled by the library / by sim_suspect_requests' caller */
+  SIM_OP_RECONNECT = 14,        /* internal: `node`'s Reconnector attempts memberlist.join(a = one of its failed members) — a push-pull
+                                   between the two, run in this tick if both processes are up, no push-pull batch falls on the tick
+                                   and no earlier attempt of the tick involves either node (otherwise: the next tick; an attempt on
+                                   a process that is down fails and is forgotten).  Scheduled by the library from the tick's request
+                                   list, two ticks after the attempt was drawn (like SIM_OP_SUSPECT)                              */
   SIM_OP_DELIVER = 12           /* internal (sim_inject_record / sim_deliver_message): `node` receives one record from
                                    outside the simulated cluster — SerfDelegate::notify_message (delegate.rs:157-315) for
                                    the serf kinds, memberlist's alive / suspect / dead handling for its own              */
@@ -520,7 +528,11 @@ int sim_pp_merge(sim_handle* h, int round, const void* recv_dev);
  * out[2 i] = prober, out[2 i + 1] = target, sorted by prober; the call empties the list —, gathers the lists, and injects
  * sim_inject(h, tick, SIM_OP_SUSPECT, prober, target, 0) for the merged list, ascending by prober, on EVERY shard
  * (serf_amd/shard.py).  More than SIM_SUSPECT_REQ_MAX requests in one tick on one shard: all of them are dropped and
- * counted in ops_dropped (model bound). */
+ * counted in ops_dropped (model bound).
+ * The list also carries the tick's Reconnector attempts (sim_config.reconnect_interval): out[2 i] = node, out[2 i + 1] =
+ * target | 1 << 31; sorted by (node, second word).  Injected the same way — sim_inject(h, tick, SIM_OP_SUSPECT, node, word) —
+ * an entry with bit 31 set becomes SIM_OP_RECONNECT.  A reconnect attempt is a push-pull pair of its tick: with one shard per
+ * process sim_pp_due is then also true on a tick that has such pairs and no batch, and sim_pp_plan / _export / _merge run them. */
 #define SIM_SUSPECT_REQ_MAX 4096u
 int sim_suspect_requests(sim_handle* h, uint32_t* out, uint32_t cap_pairs, uint32_t* n_pairs);
 /* The same hand-over WITHOUT a host round trip per tick (what serf_amd/shard.py uses: a collective whose result the host
@@ -558,6 +570,13 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes);
  * (query.rs:421-427: gossip_interval * query_timeout_mult (16) * ceil(log10(N+1))); `open` = still
  * inside the deadline.  SIM_EINVAL if the id does not own its entry of the running-query table. */
 int sim_query_status(sim_handle* h, uint32_t query_id, uint64_t* acks, uint64_t* responses, int* open);
+/* WHO they are — what the reference hands the caller of Serf::query over QueryResponse::ack_rx / response_rx
+ * (serf/query.rs:201-212; handle_query_response :240-303 keeps one entry per responder: the `acks` / `responses` sets): the
+ * ids of the nodes of THIS shard whose ack (which = 0) or response (which = 1) reached the origin, ascending, as many as fit
+ * `cap`; *n = how many there are.  The response's payload is what the responding node's user passes to respond(): not
+ * simulated data, so the host supplies it per responder (serf_amd/host/serf.hpp QueryResponse, NodeResponse{from,
+ * payload}).  SIM_EINVAL like sim_query_status. */
+int sim_query_responders(sim_handle* h, uint32_t query_id, int which, uint32_t* out_ids, uint32_t cap, uint32_t* n);
 
 /* Measurement: with profiling on, launches of the tick kernel are bracketed by HIP events on the
  * handle's stream — every launch for enable == 1, every n-th for enable == n > 1 (an event pair

@@ -85,7 +85,7 @@ static inline uint64_t mix64(uint64_t z) {
 }
 enum { STREAM_PERM = 1, STREAM_OFF = 2, STREAM_ROT = 3, STREAM_LOSS = 4, STREAM_PROBE = 5, STREAM_QUERY = 6, STREAM_RFAN = 7, STREAM_RHO = 8 };
 /* sub-draws of the per-(tick, prober) probe stream */
-enum { PD_TARGET = 0, PD_PING = 1, PD_ACK = 2, PD_RELAY0 = 3 /* + 5*j: relay, 4 legs */ };
+enum { PD_TARGET = 0, PD_PING = 1, PD_ACK = 2, PD_RELAY0 = 3 /* + 5*j: relay, 4 legs */, PD_RECONNECT = 30 /* + 1: which failed member */ };
 static inline uint64_t rng_base(uint64_t seed, uint64_t stream, uint64_t a) {
   return mix64(mix64(seed ^ (stream * 0xD6E8FEB86659FD93ull)) ^ a);
 }
@@ -327,6 +327,10 @@ struct sim_handle {
                         * ticks after the probe (the HIP library reads its device list with one tick of lag, so that
                         * no tick has to wait for the one before it) */
   uint32_t sreq_prev_n;
+  /* Reconnector (base.rs:612-681): the reconnect attempts that run as push-pull pairs in THIS tick — (initiator, target),
+   * pairwise disjoint, both processes up — resolved by step_begin from the tick's SIM_OP_RECONNECT operations */
+  uint32_t rc_n, rc_cap;
+  uint32_t *rc_a, *rc_b;
   struct evreg { uint32_t key, nlen, plen; uint8_t* bytes; } *evreg;
   size_t n_evreg, cap_evreg;
 };
@@ -955,6 +959,36 @@ static void swim_probe(nctx* c, const tickp* p) {
   swim_suspect(c, t, e->inc, c->gid, wire_meta(SIM_K_SUSPECT, 0, 32));
 }
 
+/* Reconnector (base.rs:612-681), every reconnect_interval ticks (phase shared by a 64-node group, like the probe and the
+ * Reaper): a running node with failed members attempts, with probability n_failed / max(1, members - failed - left)
+ * (base.rs:643-660: "we probabilistically expect the cluster to attempt to connect to each failed member once per
+ * reconnect interval"), to reach ONE of them, drawn uniformly (base.rs:662-664; here: the idx-th failed member of the
+ * node's view in subject order — the reference's failed_members is in order of failure, which the simulator does not
+ * keep).  The attempt is memberlist.join(address) (base.rs:671): a TCP push-pull with that node.  A push-pull is an
+ * exchange between two nodes, so the attempt goes on the tick's request list — (node, target | 1 << 31), next to the
+ * slot-less suspicions — and comes back two ticks later as SIM_OP_RECONNECT, which step_begin resolves (below). */
+#define SREQ_RECONNECT 0x80000000u
+static void reconnect_run(nctx* c, const tickp* p) {
+  osim* s = c->s;
+  uint32_t RI = s->cfg.reconnect_interval, now = (uint32_t)s->tick;
+  if (!RI || !s->swim || (now + (c->gid >> 6)) % RI) return;
+  sim_row* row = c->row;
+  uint32_t nf = row->n_failed;
+  if (!nf) return; /* base.rs:640-642 */
+  uint32_t gone = nf + row->n_left, alive = row->n_known > gone ? row->n_known - gone : 0;
+  if (!alive) alive = 1; /* .max(1), base.rs:651 */
+  uint32_t r = (uint32_t)(probe_draw(p, c->gid, PD_RECONNECT) >> 32);
+  if ((uint64_t)r * alive > ((uint64_t)nf << 32)) return; /* r > prob: "forgoing reconnect for random throttling" */
+  uint32_t idx = draw_below(probe_draw(p, c->gid, PD_RECONNECT + 1), nf), target = NOSLOT;
+  for (uint32_t wi = 0; wi < s->n_walk; ++wi) {
+    const sim_view* e = &s->view[(size_t)s->walk[wi] * s->Nl + c->l];
+    if (!(e->bits & SIM_VB_KNOWN) || SIM_VB_STATUS(e->bits) != SIM_STATUS_FAILED) continue;
+    if (idx-- == 0) { target = s->subject_of[s->walk[wi]]; break; }
+  }
+  if (target == NOSLOT || target == c->gid) return;
+  uint32_t i = __atomic_fetch_add(&s->sreq_n, 1u, __ATOMIC_RELAXED);
+  if (i < SIM_SUSPECT_REQ_MAX) { s->sreq[2 * i] = c->gid; s->sreq[2 * i + 1] = target | SREQ_RECONNECT; }
+}
 /* Reaper::run (base.rs:483-610, reap! 521-553, reap_intents 1820-1822), every reap_interval ticks
  * (phase shared by a 64-node group, like the probe): failed members older than reconnect_timeout
  * and left members older than tombstone_timeout are erased (Reap event), buffered intents older
@@ -1298,9 +1332,23 @@ static int pp_batch_class(const osim* s, uint32_t* cls) {
   return 1;
 }
 static int pp_both_up(const osim* s, uint32_t ga, uint32_t gb) { return up_of(s, ga) && up_of(s, gb); } /* a TCP exchange needs both ends */
+/* pair `i` of this tick's exchange: the batch's class on a batch tick, otherwise the tick's reconnect attempts (rc_resolve:
+ * the initiator is `a`, it merges first); 0 when there is no pair i */
+static int pp_pair_at(const osim* s, const tickp* p, int batch, uint32_t cls, uint32_t i, uint32_t* ga, uint32_t* gb) {
+  if (batch) {
+    uint64_t pi = (uint64_t)cls + (uint64_t)i * s->pp_groups;
+    if (2 * pi + 1 >= p->N) return 0;
+    *ga = sigma_g_inv(p, (uint32_t)(2 * pi)); *gb = sigma_g_inv(p, (uint32_t)(2 * pi + 1));
+    return 1;
+  }
+  if (i >= s->rc_n) return 0;
+  *ga = s->rc_a[i]; *gb = s->rc_b[i];
+  return 1;
+}
 static void pp_round(osim* s, const tickp* p) {
-  uint32_t cls;
-  if (!pp_batch_class(s, &cls)) return;
+  uint32_t cls = 0, ga, gb;
+  int batch = pp_batch_class(s, &cls);
+  if (!batch && !s->rc_n) return;
   if (s->cfg.shard_count > 1) {
     if (s->pp_done_at == (uint32_t)s->tick) return; /* the host drove it (sim_pp_plan / export / merge) */
     /* in-shard pairs only would be a different protocol: the sharded host has to run the exchange */
@@ -1308,8 +1356,7 @@ static void pp_round(osim* s, const tickp* p) {
   }
   size_t rb = pp_record_bytes(s);
   uint8_t* rec = (uint8_t*)malloc(rb);
-  for (uint32_t pi = cls; 2 * (uint64_t)pi + 1 < p->N; pi += s->pp_groups) {
-    uint32_t ga = sigma_g_inv(p, 2 * pi), gb = sigma_g_inv(p, 2 * pi + 1);
+  for (uint32_t i = 0; pp_pair_at(s, p, batch, cls, i, &ga, &gb); ++i) {
     if (!pp_both_up(s, ga, gb)) continue;
     pp_pack(s, gb, rec); pp_merge(s, ga, rec);
     pp_pack(s, ga, rec); pp_merge(s, gb, rec);
@@ -1385,6 +1432,7 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
       swim_probe(&c, p);
     }
     reap_run(&c);
+    reconnect_run(&c, p);
     queue_check(&c);
     uint32_t limit = s->cfg.retransmit_mult * digits10(row->n_known); /* B.1, serf.rs:123-131 */
     for (uint32_t k = 0; k < p->feff; ++k) queue_emit(row, q, limit, s->P, out[k]);
@@ -1436,15 +1484,48 @@ static void sreq_rotate(osim* s) { /* the finished tick's list becomes the previ
   memcpy(s->sreq_prev, s->sreq, (size_t)n * 2 * sizeof(uint32_t));
   s->sreq_prev_n = n;
 }
+static void rc_push(osim* s, uint32_t a, uint32_t b) {
+  if (s->rc_n == s->rc_cap) {
+    s->rc_cap = s->rc_cap ? 2 * s->rc_cap : 16;
+    s->rc_a = (uint32_t*)realloc(s->rc_a, s->rc_cap * sizeof(uint32_t));
+    s->rc_b = (uint32_t*)realloc(s->rc_b, s->rc_cap * sizeof(uint32_t));
+  }
+  s->rc_a[s->rc_n] = a; s->rc_b[s->rc_n++] = b;
+}
+/* The tick's SIM_OP_RECONNECT operations (in schedule order) -> the push-pull pairs that run in this tick (SIMSPEC §2.9):
+ * an attempt whose initiator or target is not running fails and is forgotten ("failed to reconnect", base.rs:672); the
+ * pairs of one tick have to be disjoint (they run side by side, like the pairs of a push-pull batch), so an attempt that
+ * shares a node with an earlier one of this tick — or falls on a tick with a push-pull batch — is put back on the
+ * schedule for the next tick. */
+static void rc_resolve(osim* s, const uint32_t* req, uint32_t n) {
+  uint32_t cls;
+  int batch = pp_batch_class(s, &cls);
+  s->rc_n = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t a = req[2 * i], b = req[2 * i + 1];
+    if (a == b || !up_of(s, a) || !up_of(s, b)) continue;
+    int busy = batch;
+    for (uint32_t j = 0; j < s->rc_n && !busy; ++j) busy = s->rc_a[j] == a || s->rc_b[j] == a || s->rc_a[j] == b || s->rc_b[j] == b;
+    if (busy) inject_val(s, s->tick + 1, SIM_OP_RECONNECT, a, b, 0, 0);
+    else rc_push(s, a, b);
+  }
+}
 static void step_begin(osim* s) {
   sreq_rotate(s);
   tickp* p = &s->cur;
   tickp_make(p, &s->cfg, s->tick);
   if (s->cfg.shard_count > 1) s->xrecv = s->rbuf[(s->tick + 1) & 1];
   if (recycle_due(s) && s->cfg.shard_count <= 1) recycle_local(s);
+  uint32_t* rreq = NULL; /* this tick's reconnect attempts, in schedule order */
+  uint32_t n_rreq = 0, cap_rreq = 0;
   while (s->op_cursor < s->n_ops && s->ops[s->op_cursor].tick <= s->tick) {
     const sim_opent* op = &s->ops[s->op_cursor];
     s->op_cursor++;
+    if (op->op == SIM_OP_RECONNECT) {
+      if (n_rreq == cap_rreq) { cap_rreq = cap_rreq ? 2 * cap_rreq : 16; rreq = (uint32_t*)realloc(rreq, (size_t)cap_rreq * 2 * sizeof(uint32_t)); }
+      rreq[2 * n_rreq] = op->node; rreq[2 * n_rreq + 1] = op->a; n_rreq++;
+      continue;
+    }
     if (op->op == SIM_OP_QUERY_FILTER_ID || op->op == SIM_OP_QUERY_FILTER_TAGS || op->op == SIM_OP_QUERY) {
       /* QueryParam.filters (query.rs:439-521; base.rs:875-903 builds them into the message): the query's filter entry
        * is started by the first filter operation that names the query, kept by its SIM_OP_QUERY, and replaced by
@@ -1464,6 +1545,8 @@ static void step_begin(osim* s) {
     if (x != NOSLOT && ensure_slot(s, x) != SIM_OK) s->ops_dropped++; /* no free view slot: the operation does not happen */
     else apply_op(s, op);
   }
+  rc_resolve(s, rreq, n_rreq);
+  free(rreq);
   pp_round(s, p);
   s->in_tick = 1;
 }
@@ -1568,7 +1651,7 @@ static int cfg_check(const sim_config* c) {
 
 int API(destroy)(osim* s) {
   if (!s) return SIM_EINVAL;
-  free(s->sreq); free(s->sreq_prev);
+  free(s->sreq); free(s->sreq_prev); free(s->rc_a); free(s->rc_b);
   for (size_t i = 0; i < s->n_evreg; ++i) free(s->evreg[i].bytes);
   free(s->evreg);
   free(s->rows); free(s->queue); free(s->inbox[0]); free(s->inbox[1]);
@@ -1834,8 +1917,9 @@ static int inject_val(osim* s, uint64_t tick, uint32_t op, uint32_t node, uint32
   if (!s || node >= s->N) return SIM_EINVAL;
   if (tick < s->tick) tick = s->tick;
   int rc = SIM_OK;
+  if (op == SIM_OP_SUSPECT && (a & SREQ_RECONNECT)) { op = SIM_OP_RECONNECT; a &= ~SREQ_RECONNECT; } /* an entry of the request list, as it stands there */
   switch (op) {
-    case SIM_OP_SUSPECT: if (a >= s->N) return SIM_EINVAL; break;
+    case SIM_OP_SUSPECT: case SIM_OP_RECONNECT: if (a >= s->N) return SIM_EINVAL; break;
     case SIM_OP_DELIVER: {
       uint32_t kind = SIM_META_KIND(b);
       if (kind < SIM_K_JOIN || kind > SIM_K_DEAD || (b & ~SIM_META_WIRE_MASK)) return SIM_EINVAL;
@@ -2440,6 +2524,18 @@ int API(query_status)(osim* s, uint32_t qid, uint64_t* acks, uint64_t* responses
   *open = (uint32_t)s->tick <= s->qtab[j].deadline;
   return SIM_OK;
 }
+int API(query_responders)(osim* s, uint32_t qid, int which, uint32_t* out, uint32_t cap, uint32_t* n) {
+  if (!s || !n || !qid || (which != 0 && which != 1) || (cap && !out)) return SIM_EINVAL;
+  uint32_t j = qid % SIM_QT;
+  if (s->qtab[j].qid != qid) return SIM_EINVAL;
+  size_t words = ((size_t)s->N + 31) / 32;
+  const uint32_t* bits = s->qbits + ((size_t)j * 2 + (size_t)which) * words;
+  uint32_t k = 0;
+  for (uint32_t g = s->shard0; g < s->shard0 + s->Nl; ++g)
+    if ((bits[g >> 5] >> (g & 31)) & 1u) { if (k < cap) out[k] = g; ++k; }
+  *n = k;
+  return SIM_OK;
+}
 int API(profile)(osim* s, int enable) { (void)enable; return s ? SIM_OK : SIM_EINVAL; }
 int API(profile_read)(osim* s, double* ms, uint64_t* launches) {
   if (!s || !ms || !launches) return SIM_EINVAL;
@@ -2503,19 +2599,21 @@ int API(exchange_chunks)(const osim* s, uint32_t* chunks, size_t* bytes_per_chun
 int API(pp_due)(const osim* s) {
   uint32_t cls;
   if (!s) return SIM_EINVAL;
-  return s->cfg.shard_count > 1 && pp_batch_class(s, &cls) && s->pp_done_at != (uint32_t)s->tick;
+  /* (a reconnect attempt is a push-pull pair as well: known once sim_step_begin has resolved the tick's operations) */
+  return s->cfg.shard_count > 1 && (pp_batch_class(s, &cls) || (s->in_tick && s->rc_n)) && s->pp_done_at != (uint32_t)s->tick;
 }
 int API(pp_plan)(osim* s, uint32_t* send1, uint32_t* recv1, size_t* record_bytes) {
-  uint32_t cls;
+  uint32_t cls = 0;
   if (!s || !send1 || !recv1 || !record_bytes) return SIM_EINVAL;
-  if (!s->in_tick || s->cfg.shard_count <= 1 || !pp_batch_class(s, &cls)) return SIM_ESTATE; /* after sim_step_begin: the tick's operations come first */
+  int batch = s->in_tick ? pp_batch_class(s, &cls) : 0;
+  if (!s->in_tick || s->cfg.shard_count <= 1 || (!batch && !s->rc_n)) return SIM_ESTATE; /* after sim_step_begin: the tick's operations come first */
   tickp p;
   tickp_make(&p, &s->cfg, s->tick);
   uint32_t V = s->V, me = s->cfg.shard_rank, M = s->M;
   memset(send1, 0, V * sizeof(uint32_t));
   memset(recv1, 0, V * sizeof(uint32_t));
   free(s->pp_local_a); free(s->pp_local_b); free(s->pp_r1); free(s->pp_s1);
-  size_t cap = (size_t)s->N / (2 * s->pp_groups) + 2;
+  size_t cap = (size_t)s->N / (2 * s->pp_groups) + 2 + s->rc_n;
   s->pp_local_a = (uint32_t*)malloc(cap * 4); s->pp_local_b = (uint32_t*)malloc(cap * 4);
   s->pp_r1 = (uint32_t*)malloc(cap * 4); s->pp_s1 = (uint32_t*)malloc(cap * 4);
   s->pp_n_local = s->pp_n_r1 = s->pp_n_s1 = 0;
@@ -2523,8 +2621,8 @@ int API(pp_plan)(osim* s, uint32_t* send1, uint32_t* recv1, size_t* record_bytes
     uint32_t *off_r = (uint32_t*)calloc(V + 1, 4), *off_s = (uint32_t*)calloc(V + 1, 4);
     if (pass == 1)
       for (uint32_t h = 0; h < V; ++h) { off_r[h + 1] = off_r[h] + recv1[h]; off_s[h + 1] = off_s[h] + send1[h]; }
-    for (uint32_t pi = cls; 2 * (uint64_t)pi + 1 < p.N; pi += s->pp_groups) {
-      uint32_t ga = sigma_g_inv(&p, 2 * pi), gb = sigma_g_inv(&p, 2 * pi + 1);
+    uint32_t ga, gb;
+    for (uint32_t i = 0; pp_pair_at(s, &p, batch, cls, i, &ga, &gb); ++i) {
       if (!pp_both_up(s, ga, gb)) continue;
       uint32_t oa = ga / M, ob = gb / M;
       if (oa == me && ob == me) {
@@ -2569,8 +2667,9 @@ int API(pp_merge)(osim* s, int round, const void* recv) {
   }
   return SIM_OK;
 }
-static int sreq_cmp(const void* a, const void* b) {
+static int sreq_cmp(const void* a, const void* b) { /* by node, a node's failed probe before its reconnect attempt */
   uint32_t x = ((const uint32_t*)a)[0], y = ((const uint32_t*)b)[0];
+  if (x == y) { x = ((const uint32_t*)a)[1]; y = ((const uint32_t*)b)[1]; }
   return x < y ? -1 : x > y;
 }
 int API(suspect_requests)(osim* s, uint32_t* out, uint32_t cap_pairs, uint32_t* n_pairs) {
@@ -2762,6 +2861,16 @@ int osim_t_swim_dead(osim* s, uint32_t node, uint32_t subject, uint32_t inc, uin
 }
 int osim_t_swim_timers(osim* s, uint32_t node) { TCTX(s, node); swim_timers(&c); return SIM_OK; }
 /* pure functions of the memberlist half, for the UPSTREAM-RECALL known-answer tests (tests/test_memberlist_kat.py) */
+/* scheduled, not yet executed operations of one kind at one tick (test hook: the Reconnector's attempts are visible only there) */
+uint32_t osim_t_scheduled(const osim* s, uint32_t op, uint64_t tick, uint32_t* out_pairs, uint32_t cap) {
+  uint32_t n = 0;
+  for (size_t i = s->op_cursor; i < s->n_ops; ++i)
+    if (s->ops[i].op == op && s->ops[i].tick == tick) {
+      if (out_pairs && n < cap) { out_pairs[2 * n] = s->ops[i].node; out_pairs[2 * n + 1] = s->ops[i].a; }
+      ++n;
+    }
+  return n;
+}
 uint32_t osim_t_retransmit_limit(uint32_t retransmit_mult, uint32_t n) { return retransmit_mult * digits10(n); } /* util.go retransmitLimit */
 uint32_t osim_t_push_pull_scale(uint32_t n) { /* util.go pushPullScale, as a multiplier of the interval */
   sim_config c;

@@ -27,7 +27,7 @@ K_JOIN, K_LEAVE, K_EVENT, K_QUERY, K_ALIVE, K_SUSPECT, K_DEAD = 1, 2, 3, 4, 5, 6
 EV_JOIN, EV_LEAVE, EV_FAILED, EV_UPDATE, EV_REAP, EV_USER, EV_QUERY = range(7)
 # enum sim_op
 OP_USER_EVENT, OP_QUERY, OP_LEAVE, OP_JOIN, OP_FORCE_LEAVE, OP_CRASH, OP_REVIVE, OP_LEAVE_FINISH = 1, 2, 3, 4, 5, 6, 7, 8
-OP_SET_TAGS, OP_QUERY_FILTER_ID, OP_QUERY_FILTER_TAGS, OP_DELIVER, OP_SUSPECT = 9, 10, 11, 12, 13
+OP_SET_TAGS, OP_QUERY_FILTER_ID, OP_QUERY_FILTER_TAGS, OP_DELIVER, OP_SUSPECT, OP_RECONNECT = 9, 10, 11, 12, 13, 14
 SUSPECT_REQ_MAX, SREQ_HEAD_WORDS = 4096, 512
 QF_IDS, TAG_CLASSES, NO_TAG_FILTER = 12, 32, 0xFFFFFFFF
 # enum sim_array
@@ -50,7 +50,7 @@ class Config(C.Structure):
         "event_ring", "query_ring", "retransmit_mult", "probe_interval", "suspicion_mult",
         "suspicion_max_mult", "indirect_checks", "loss_u32", "intent_timeout", "leave_delay",
         "reap_interval", "reconnect_timeout", "tombstone_timeout", "queue_check_interval", "max_queue_depth",
-        "min_queue_depth", "push_pull_interval", "chunks", "recycle_interval", "pkt_records", "flags", "gossip_to_the_dead", "reserved2")] + [("seed", C.c_uint64)]
+        "min_queue_depth", "push_pull_interval", "chunks", "recycle_interval", "pkt_records", "flags", "gossip_to_the_dead", "reconnect_interval")] + [("seed", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -99,7 +99,7 @@ _ARR_DTYPE = {ARR_ROWS: ROW_DTYPE, ARR_QUEUE: REC_DTYPE, ARR_INBOX: PACKET_DTYPE
 ABI_SYMBOLS = ("create", "destroy", "set_stream", "join", "leave", "force_leave", "user_event",
                "query", "inject", "step", "sync", "tick", "members", "stats_get", "watch",
                "drain_events", "state_digest", "dump_state", "convergence", "convergence_many", "exchange_bytes",
-               "bind_exchange", "snapshot", "restore", "query_status", "profile", "profile_read", "profile_read_stats", "cluster_stats_get",
+               "bind_exchange", "snapshot", "restore", "query_status", "query_responders", "profile", "profile_read", "profile_read_stats", "cluster_stats_get",
                "bind_exchange2", "exchange_chunks", "step_begin", "step_chunk", "step_end",
                "recycle_due", "recycle_scan", "recycle_apply", "pp_due", "pp_plan", "pp_export", "pp_merge",
                "query_filtered", "set_tags", "init_tags", "inject_record", "deliver_message", "user_event_bytes", "peek_packet", "suspect_requests", "suspect_export", "suspect_import",
@@ -111,7 +111,7 @@ def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, vi
                 suspicion_mult=4, suspicion_max_mult=6, indirect_checks=3, loss=0.0,
                 intent_timeout=0, leave_delay=30, reap_interval=0, reconnect_timeout=432000, tombstone_timeout=432000,
                 queue_check_interval=0, max_queue_depth=4096, min_queue_depth=0, push_pull_interval=0, chunks=0, recycle_interval=0,
-                pkt_records=0, gossip_to_the_dead=0, awareness_probe=False, join_sync=False, flags=CF_BASELINE_JOINED, seed=DEFAULT_SEED):
+                pkt_records=0, gossip_to_the_dead=0, reconnect_interval=0, awareness_probe=False, join_sync=False, flags=CF_BASELINE_JOINED, seed=DEFAULT_SEED):
     cfg = Config()
     cfg.struct_size = C.sizeof(Config)
     cfg.n_nodes, cfg.vshards, cfg.shard_rank, cfg.shard_count = n_nodes, vshards, shard_rank, shard_count
@@ -125,6 +125,7 @@ def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, vi
     cfg.push_pull_interval, cfg.chunks, cfg.recycle_interval = push_pull_interval, chunks, recycle_interval
     cfg.pkt_records = pkt_records  # 0 = 4 records (one page) per packet; 8 / 12 / 16 = more pages
     cfg.gossip_to_the_dead = gossip_to_the_dead
+    cfg.reconnect_interval = reconnect_interval  # Reconnector (base.rs:612-681): 0 = off
     if awareness_probe:
         cfg.flags |= CF_AWARENESS_PROBE
     if join_sync:
@@ -184,6 +185,7 @@ class SimLib:
             "snapshot": (C.c_int, [H, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
             "restore": (C.c_int, [H, vp, C.c_size_t]),
             "query_status": (C.c_int, [H, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_int)]),
+            "query_responders": (C.c_int, [H, u32, C.c_int, C.POINTER(u32), u32, C.POINTER(u32)]),
             "profile": (C.c_int, [H, C.c_int]),
             "profile_read": (C.c_int, [H, C.POINTER(C.c_double), C.POINTER(u64)]),
             "profile_read_stats": (C.c_int, [H, C.POINTER(C.c_double * 3), C.POINTER(u64)]),
@@ -380,6 +382,15 @@ class Sim:
         a, r, o = C.c_uint64(), C.c_uint64(), C.c_int()
         self._ck(self.lib.f["query_status"](self.h, query_id, C.byref(a), C.byref(r), C.byref(o)), "sim_query_status")
         return a.value, r.value, bool(o.value)
+
+    def query_responders(self, query_id, which):
+        """Ids of this shard's nodes whose ack (which = 0) / response (which = 1) reached the origin of the running query —
+        what QueryResponse::ack_rx / response_rx deliver (query.rs:201-212), ascending."""
+        n = C.c_uint32()
+        self._ck(self.lib.f["query_responders"](self.h, query_id, which, None, 0, C.byref(n)), "sim_query_responders")
+        out = (C.c_uint32 * max(1, n.value))()
+        self._ck(self.lib.f["query_responders"](self.h, query_id, which, out, n.value, C.byref(n)), "sim_query_responders")
+        return list(out[:n.value])
 
     def profile(self, enable=True):
         self._ck(self.lib.f["profile"](self.h, int(enable)), "sim_profile")

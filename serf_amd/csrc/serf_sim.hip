@@ -67,7 +67,8 @@ __host__ __device__ static inline u64 mix64(u64 z) {
   return z ^ (z >> 31);
 }
 enum { STREAM_PERM = 1, STREAM_OFF = 2, STREAM_ROT = 3, STREAM_LOSS = 4, STREAM_PROBE = 5, STREAM_QUERY = 6, STREAM_RHO = 8 };
-enum { PD_TARGET = 0, PD_PING = 1, PD_ACK = 2, PD_RELAY0 = 3 };
+enum { PD_TARGET = 0, PD_PING = 1, PD_ACK = 2, PD_RELAY0 = 3, PD_RECONNECT = 30 /* + 1: which failed member */ };
+#define SREQ_RECONNECT 0x80000000u  // request-list entries of the Reconnector: (node, target | this)
 static inline u64 rng_base(u64 seed, u64 stream, u64 a) {
   return mix64(mix64(seed ^ (stream * 0xD6E8FEB86659FD93ull)) ^ a);
 }
@@ -305,6 +306,7 @@ struct Dev {
   u32 gttd;      // gossip_to_the_dead in ticks (0 = off)
   u32 r3on;  // R3 is live: SWIM layer or Reaper configured
   u32 reap_interval, reconnect_timeout, tombstone_timeout, intent_timeout;
+  u32 reconnect_interval;  // Reconnector period in ticks (0 = off, or no SWIM layer: nobody ever fails)
   u32 queue_check_interval, max_queue_depth, min_queue_depth;
 };
 
@@ -1134,6 +1136,29 @@ __device__ static inline u32 slot_load(const Dev& d, u32 kind, u32 key) {
   if (member_kind(kind) && key < d.N) s = d.slot_of[key];
   return s;
 }
+// Reconnector (base.rs:612-681) — see oracle reconnect_run: with probability failed / alive the node attempts a
+// memberlist.join with one of its failed members, drawn uniformly (the idx-th in subject order).  A push-pull needs both
+// nodes, so the attempt goes on the tick's request list, (node, target | 1 << 31), and the host replays it two ticks later
+// as SIM_OP_RECONNECT (sim_step_begin).  Rare: once per failed member, reconnect interval and CLUSTER.
+__device__ static void reconnect_run(const Ctx& c, const Node& n, const TickP& tp, u32 n_slots) {
+  const Dev& d = c.d;
+  u32 nf = n.nfailed, gone = nf + n.nleft, alive = n.nknown > gone ? n.nknown - gone : 0u;
+  if (!alive) alive = 1u;
+  u32 r = (u32)(probe_draw(tp, c.gid, PD_RECONNECT) >> 32);
+  if ((u64)r * alive > ((u64)nf << 32)) return;  // "forgoing reconnect for random throttling"
+  u32 idx = draw_below(probe_draw(tp, c.gid, PD_RECONNECT + 1), nf), target = NOSLOT;
+#pragma unroll 1
+  for (u32 wi = 0; wi < n_slots; ++wi) {
+    u32 a = d.walk[wi];
+    uint4 e = view_slot_ptr(c, a)[0];
+    if (!(e.w & SIM_VB_KNOWN) || SIM_VB_STATUS(e.w) != SIM_STATUS_FAILED) continue;
+    if (idx-- == 0) { target = d.subject_of[a]; break; }
+  }
+  if (target == NOSLOT || target == c.gid) return;
+  u32 i = atomicAdd(d.sreq, 1u);
+  if (i < SIM_SUSPECT_REQ_MAX) { d.sreq[1 + 2 * i] = c.gid; d.sreq[2 + 2 * i] = target | SREQ_RECONNECT; }
+  if (d.sreq_hh && i < SREQ_HEAD) { d.sreq_hh[2 * i + 1] = target | SREQ_RECONNECT; d.sreq_hh[2 * i] = c.gid; }
+}
 // Reaper::run (base.rs:483-610; reap! 521-553; reap_intents 1820-1822) — see oracle reap_run
 __device__ static void reap_run(const Ctx& c, Node& n, u32 n_slots) {
   const Dev& d = c.d;
@@ -1581,6 +1606,7 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
     bool due = ((u32)tp.tick + (gid >> 6)) % d.reap_interval == 0 && n.reap_next && (u32)tp.tick >= n.reap_next;
     if (due) reap_run(c, n, tp.n_slots);
   }
+  if (up && d.reconnect_interval && ((u32)tp.tick + (gid >> 6)) % d.reconnect_interval == 0 && n.nfailed) reconnect_run(c, n, tp, tp.n_slots);
   TT(6);
   if (ABL(1)) { if (up) node_store(d, l, n); return; }
   // ---- phase 2: queue.  Load the sort keys, queue what phase 1 parked, drain `fanout` packets.
@@ -2248,6 +2274,14 @@ __global__ void pp_local_kernel(Dev d, TickP tp, const u32* la, const u32* lb, u
   pp_merge(d, tp, la[j], PPLocal{d, lb[j]});
   pp_merge(d, tp, lb[j], PPLocal{d, la[j]});
 }
+// ... a handful of pairs handed over by value (the Reconnector's attempts of a tick: pairwise disjoint, `a` merges first) ...
+struct PairBatch { u32 n; u32 a[8], b[8]; };
+__global__ void pp_pairs_kernel(Dev d, TickP tp, PairBatch pb) {
+  u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= pb.n) return;
+  pp_merge(d, tp, pb.a[j], PPLocal{d, pb.b[j]});
+  pp_merge(d, tp, pb.b[j], PPLocal{d, pb.a[j]});
+}
 // ... the records this shard ships (one block per record: `ns` view heads + the event ring) ...
 __global__ void pp_export_kernel(Dev d, const u32* list, u32 ns, uint4* out, size_t rec_u4) {
   u32 l = list[blockIdx.x];
@@ -2760,6 +2794,7 @@ struct sim_handle {
   // the batch being driven by the sharded host: in-shard pairs, and the cross-shard pairs grouped by peer shard in
   // ascending pair order — r1: this shard owns the even node `a` (receives b in round 1, sends a in round 2); s1: owns `b`
   std::vector<u32> pp_local_a, pp_local_b, pp_r1, pp_s1;
+  std::vector<u32> rc_a, rc_b;  // Reconnector: the reconnect attempts that run as push-pull pairs in THIS tick (global ids; initiator, target)
   u32* d_pp;                    // the four lists on the device, back to back
   std::vector<sim_view> base;
   uint4* d_base;  // [N][2]
@@ -2950,6 +2985,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   d.PI = cfg->probe_interval;
   d.ic = cfg->indirect_checks;
   d.reap_interval = cfg->reap_interval; d.reconnect_timeout = cfg->reconnect_timeout;
+  d.reconnect_interval = cfg->probe_interval ? cfg->reconnect_interval : 0u;
   d.tombstone_timeout = cfg->tombstone_timeout; d.intent_timeout = cfg->intent_timeout;
   d.queue_check_interval = cfg->queue_check_interval; d.max_queue_depth = cfg->max_queue_depth;
   d.min_queue_depth = cfg->min_queue_depth;
@@ -3232,7 +3268,7 @@ static int op_validate(u32 N, u32 op, u32 node, u32 a, u32 b) {
     case SIM_OP_SET_TAGS: if (a >= SIM_TAG_CLASSES) return SIM_EINVAL; break;
     case SIM_OP_QUERY_FILTER_ID: if (!a || b >= N) return SIM_EINVAL; break;
     case SIM_OP_QUERY_FILTER_TAGS: if (!a) return SIM_EINVAL; break;
-    case SIM_OP_SUSPECT: if (a >= N) return SIM_EINVAL; break;
+    case SIM_OP_SUSPECT: case SIM_OP_RECONNECT: if (a >= N) return SIM_EINVAL; break;
     case SIM_OP_DELIVER: {
       u32 kind = SIM_META_KIND(b);
       if (kind < SIM_K_JOIN || kind > SIM_K_DEAD || (b & ~SIM_META_WIRE_MASK)) return SIM_EINVAL;
@@ -3247,6 +3283,7 @@ static int op_validate(u32 N, u32 op, u32 node, u32 a, u32 b) {
 static int inject_val(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, uint32_t b, uint64_t val) {
   if (!h) return SIM_EINVAL;
   if (tick < h->tick) tick = h->tick;
+  if (op == SIM_OP_SUSPECT && (a & SREQ_RECONNECT)) { op = SIM_OP_RECONNECT; a &= ~SREQ_RECONNECT; }  // an entry of the request list, as it stands there
   int rc = op_validate(h->d.N, op, node, a, b);
   if (rc) return rc;
   // an operation that executes now gets its view slot now (and SIM_ENOSLOT if there is none); one scheduled for a
@@ -3385,12 +3422,14 @@ static bool pp_batch_class(const sim_handle* h, u32* cls) {
 int sim_pp_due(const sim_handle* h) {
   u32 cls;
   if (!h) return SIM_EINVAL;
-  return (h->d.sharded && pp_batch_class(h, &cls) && h->pp_done_at != (u32)h->tick) ? 1 : 0;
+  // (a reconnect attempt is a push-pull pair as well: known once sim_step_begin has resolved the tick's operations)
+  return (h->d.sharded && (pp_batch_class(h, &cls) || (h->in_tick && !h->rc_a.empty())) && h->pp_done_at != (u32)h->tick) ? 1 : 0;
 }
 int sim_pp_plan(sim_handle* h, uint32_t* send1, uint32_t* recv1, size_t* record_bytes) {
-  u32 cls;
+  u32 cls = 0;
   if (!h || !send1 || !recv1 || !record_bytes) return SIM_EINVAL;
-  if (!h->in_tick || !h->d.sharded || !pp_batch_class(h, &cls)) return SIM_ESTATE;  // after sim_step_begin: the tick's operations come first
+  const bool batch = h->in_tick && pp_batch_class(h, &cls);
+  if (!h->in_tick || !h->d.sharded || (!batch && h->rc_a.empty())) return SIM_ESTATE;  // after sim_step_begin: the tick's operations come first
   Dev& d = h->d;
   const TickP& tp = h->cur_tp;
   const u32 V = d.V, me = d.shard_rank, M = d.M;
@@ -3401,14 +3440,17 @@ int sim_pp_plan(sim_handle* h, uint32_t* send1, uint32_t* recv1, size_t* record_
   for (u32 v = 0; v < V; ++v) send1[v] = recv1[v] = 0;
   h->pp_local_a.clear(); h->pp_local_b.clear();
   std::vector<std::vector<u32>> r1(V), s1(V);
-  for (u32 pi = cls; 2 * (u64)pi + 1 < tp.N; pi += PP_GROUPS) {
-    u32 ga = sigma_g_inv(tp, 2 * pi), gb = sigma_g_inv(tp, 2 * pi + 1);
-    if (!is_up(ga) || !is_up(gb)) continue;
+  auto place = [&](u32 ga, u32 gb) {
+    if (!is_up(ga) || !is_up(gb)) return;
     u32 oa = ga / M, ob = gb / M;
     if (oa == me && ob == me) { h->pp_local_a.push_back(ga - d.shard0); h->pp_local_b.push_back(gb - d.shard0); }
     else if (oa == me) r1[ob].push_back(ga - d.shard0);
     else if (ob == me) s1[oa].push_back(gb - d.shard0);
-  }
+  };
+  if (batch)
+    for (u32 pi = cls; 2 * (u64)pi + 1 < tp.N; pi += PP_GROUPS) place(sigma_g_inv(tp, 2 * pi), sigma_g_inv(tp, 2 * pi + 1));
+  else  // the tick's reconnect attempts (sim_step_begin): the initiator is `a`, it merges first
+    for (size_t i = 0; i < h->rc_a.size(); ++i) place(h->rc_a[i], h->rc_b[i]);
   h->pp_r1.clear(); h->pp_s1.clear();
   for (u32 v = 0; v < V; ++v) {
     recv1[v] = (u32)r1[v].size(); send1[v] = (u32)s1[v].size();
@@ -3503,11 +3545,14 @@ int sim_step_begin(sim_handle* h) {
 #endif
   for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) { tp.prot[k] = h->prev.rot[k]; tp.prho[k] = h->prev.rho[k]; }
   if (d.sharded) d.xrecv = h->rbuf[(h->tick + 1) & 1];  // what was sent during tick - 1
+  std::vector<u32> rc_req;  // this tick's reconnect attempts (node, target), in schedule order
+  h->rc_a.clear(); h->rc_b.clear();
   while (h->op_cursor < h->ops.size() && h->ops[h->op_cursor].tick <= h->tick) {
     OpBatch ob;
     memset(&ob, 0, sizeof ob);
     while (ob.n < 8 && h->op_cursor < h->ops.size() && h->ops[h->op_cursor].tick <= h->tick) {
       const OpEnt& e = h->ops[h->op_cursor++];
+      if (e.op == SIM_OP_RECONNECT) { rc_req.push_back(e.node); rc_req.push_back(e.a); continue; }  // resolved below, once the tick's operations have run
       if (e.op == SIM_OP_QUERY_FILTER_ID || e.op == SIM_OP_QUERY_FILTER_TAGS || e.op == SIM_OP_QUERY) {
         // the query's filter entry: started by the first filter operation that names the query, SEALED by its
         // SIM_OP_QUERY (word 3), replaced by whatever names another query with the same residue — or the same id again
@@ -3547,11 +3592,37 @@ int sim_step_begin(sim_handle* h) {
     if (ob.n) ops_kernel<<<1, 64, 0, h->stream>>>(d, ob, h->tick, d.N > 1 ? 1u : 0u, tp.query_base, h->q_timeout);
   }
   tp.n_slots = (u32)h->walk.size();  // after the operations: they may have taken slots
+  if (!rc_req.empty()) {
+    // The tick's SIM_OP_RECONNECT operations -> the push-pull pairs that run in this tick (oracle rc_resolve): an attempt
+    // whose initiator or target is not running fails and is forgotten; the pairs of a tick are disjoint and do not share
+    // the tick with a push-pull batch — an attempt that would goes back on the schedule for the next tick.
+    std::vector<u32> up(((size_t)d.N + 31) / 32);  // ground-truth liveness after this tick's operations (rare path: a copy and a wait)
+    HCHECK(hipMemcpyAsync(up.data(), d.upmap, up.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HCHECK(hipStreamSynchronize(h->stream));
+    auto is_up = [&](u32 g) { return (up[g >> 5] >> (g & 31)) & 1u; };
+    u32 cls;
+    const bool batch = pp_batch_class(h, &cls);
+    for (size_t i = 0; i + 1 < rc_req.size(); i += 2) {
+      const u32 a = rc_req[i], b = rc_req[i + 1];
+      if (a == b || !is_up(a) || !is_up(b)) continue;
+      bool busy = batch;
+      for (size_t j = 0; j < h->rc_a.size() && !busy; ++j) busy = h->rc_a[j] == a || h->rc_b[j] == a || h->rc_a[j] == b || h->rc_b[j] == b;
+      if (busy) { int rc = inject_val(h, h->tick + 1, SIM_OP_RECONNECT, a, b, 0, 0); if (rc) return rc; }
+      else { h->rc_a.push_back(a); h->rc_b.push_back(b); }
+    }
+  }
   if (!d.sharded && h->pp_step && h->tick > 0 && h->tick % h->pp_step == 0) {  // (sharded: the host runs the batch, sim_pp_*)
     u32 cls = (u32)((h->tick / h->pp_step) % PP_GROUPS);
     u32 half = tp.N / 2, n_pairs = half > cls ? (half - cls + PP_GROUPS - 1) / PP_GROUPS : 0;
     if (n_pairs) pushpull_kernel<<<(n_pairs + 63) / 64, 64, 0, h->stream>>>(d, tp, cls, n_pairs);
   }
+  if (!d.sharded)  // the Reconnector's push-pulls of this tick (none on a batch tick)
+    for (size_t i = 0; i < h->rc_a.size(); i += 8) {
+      PairBatch pb;
+      memset(&pb, 0, sizeof pb);
+      for (size_t j = i; j < h->rc_a.size() && j < i + 8; ++j) { pb.a[pb.n] = h->rc_a[j]; pb.b[pb.n++] = h->rc_b[j]; }
+      pp_pairs_kernel<<<1, 64, 0, h->stream>>>(d, tp, pb);
+    }
   // Timing of the tick's launch(es) with HIP events.  One launch per tick: the pair rides on the dispatch itself
   // (hipExtLaunchKernelGGL: start / stop = the kernel's own begin and end, no barrier packets in the stream — two
   // hipEventRecord calls around every launch cost 10 us of stream time each tick).  Several chunk launches per tick
@@ -4193,6 +4264,25 @@ int sim_query_status(sim_handle* h, uint32_t qid, uint64_t* acks, uint64_t* resp
   *acks = r[0];
   *responses = r[1];
   *open = (u32)h->tick <= tj.z;
+  return SIM_OK;
+}
+int sim_query_responders(sim_handle* h, uint32_t qid, int which, uint32_t* out, uint32_t cap, uint32_t* n) {
+  if (!h || !n || !qid || (which != 0 && which != 1) || (cap && !out)) return SIM_EINVAL;
+  Dev& d = h->d;
+  hipStream_t s = h->stream;
+  u32 j = qid % SIM_QT;
+  uint4 tj;
+  HCHECK(hipMemcpyAsync(&tj, d.qtab + j, sizeof tj, hipMemcpyDeviceToHost, s));
+  HCHECK(hipStreamSynchronize(s));
+  if (tj.x != qid) return SIM_EINVAL;
+  size_t words = ((size_t)d.N + 31) / 32;
+  std::vector<u32> bits(words);  // one bit per node: the bitmap itself is the compact form (128 KiB at 1 Mi nodes)
+  HCHECK(hipMemcpyAsync(bits.data(), d.qbits + ((size_t)j * 2 + (size_t)which) * words, words * 4, hipMemcpyDeviceToHost, s));
+  HCHECK(hipStreamSynchronize(s));
+  u32 k = 0;
+  for (u32 g = d.shard0; g < d.shard0 + d.Nl; ++g)
+    if ((bits[g >> 5] >> (g & 31)) & 1u) { if (k < cap) out[k] = g; ++k; }
+  *n = k;
   return SIM_OK;
 }
 int sim_profile(sim_handle* h, int enable) {

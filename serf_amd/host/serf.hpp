@@ -8,7 +8,10 @@
 // Errors: the reference returns `Result<_, Error>` (error.rs:64-81); here a `serf::Error` exception
 // carries the SIM_E* code.
 #pragma once
+#include <algorithm>
 #include <cstdint>
+#include <functional>
+#include <iterator>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -57,6 +60,7 @@ struct Options {
     c.reconnect_timeout = c.tombstone_timeout = 432000;  // 24 h (options.rs:507-508)
     c.queue_check_interval = 150; c.max_queue_depth = 4096; c.min_queue_depth = 0;  // options.rs:512-514
     c.push_pull_interval = 150;                    // lan(): 30 s
+    c.reconnect_interval = 150;                    // options.rs:507 reconnect_interval 30 s (Reconnector, base.rs:612-681)
     c.flags = SIM_CF_BASELINE_JOINED;
     c.seed = SIM_DEFAULT_SEED;
   }
@@ -71,6 +75,7 @@ struct Options {
   Options& with_event_buffer_size(uint32_t b) { c.event_ring = b; return *this; }
   Options& with_query_buffer_size(uint32_t b) { c.query_ring = b; return *this; }
   Options& with_packet_loss(double p) { c.loss_u32 = p >= 1.0 ? 0xFFFFFFFFu : (uint32_t)(p * 4294967296.0); return *this; }
+  Options& with_reconnect_interval(uint32_t ticks) { c.reconnect_interval = ticks; return *this; }  // options.rs:162 (0 = no Reconnector)
   Options& with_seed(uint64_t s) { c.seed = s; return *this; }
 };
 
@@ -98,6 +103,33 @@ class Serf {
   inline void set_tags(uint32_t tag_class);                                   // api.rs:219
   struct QueryStatus { uint64_t acks, responses; bool open; };                // QueryResponse, query.rs:117-303
   inline QueryStatus query_status(uint32_t query_id) const;
+  // What the caller of Serf::query holds in the reference (QueryResponse, query.rs:117-236): who acked, who responded and
+  // with what, each responder once (the `acks` / `responses` sets of handle_query_response, query.rs:240-303), until the
+  // deadline or close().  The simulator tracks the responders (include/serf_sim.h sim_query_responders); a response's
+  // PAYLOAD is what the responding node's user hands to respond() — user data, not simulated state — so it comes from the
+  // responder function the caller registers (default: empty payloads).  Polling: every call returns the responders that
+  // arrived since the previous call, like draining ack_rx / response_rx.
+  struct NodeResponse { uint32_t from; std::vector<uint8_t> payload; };       // query.rs:373-385
+  class QueryResponse {
+   public:
+    uint32_t id() const { return id_; }                                       // query.rs:129-133
+    bool finished() const;                                                    // query.rs:215-219
+    void close() { closed_ = true; }                                          // query.rs:223-237: no further deliveries
+    std::vector<uint32_t> acks();                                             // ack_rx (query.rs:203-205)
+    std::vector<NodeResponse> responses();                                    // response_rx (query.rs:209-212)
+    void on_respond(std::function<std::vector<uint8_t>(uint32_t)> f) { payload_of_ = std::move(f); }
+   private:
+    friend class Serf;
+    QueryResponse(Cluster* c, uint32_t id) : c_(c), id_(id) {}
+    std::vector<uint32_t> fresh(int which, std::vector<uint32_t>& seen);
+    Cluster* c_;
+    uint32_t id_;
+    bool closed_ = false;
+    std::vector<uint32_t> seen_acks_, seen_resp_;                             // ascending (QueryResponseCore.acks / .responses)
+    std::function<std::vector<uint8_t>(uint32_t)> payload_of_;
+  };
+  // api.rs:304 as the reference shapes it: the query goes out and the caller keeps the QueryResponse
+  inline QueryResponse query_response(uint32_t query_id, uint32_t flags = 0) { query(query_id, flags); return QueryResponse(c_, query_id); }
   inline void join(uint32_t peer);                                            // api.rs:318
   inline void leave();                                                        // api.rs:422
   inline void remove_failed_node(uint32_t id);                                // api.rs:505
@@ -194,6 +226,30 @@ inline Serf::QueryStatus Serf::query_status(uint32_t qid) const {
   check(sim_query_status(c_->raw(), qid, &st.acks, &st.responses, &open), "sim_query_status");
   st.open = open != 0;
   return st;
+}
+inline bool Serf::QueryResponse::finished() const {
+  if (closed_) return true;
+  uint64_t a, r;
+  int open = 0;
+  check(sim_query_status(c_->raw(), id_, &a, &r, &open), "sim_query_status");
+  return !open;
+}
+inline std::vector<uint32_t> Serf::QueryResponse::fresh(int which, std::vector<uint32_t>& seen) {
+  std::vector<uint32_t> out;
+  if (closed_) return out;
+  uint32_t n = 0;
+  check(sim_query_responders(c_->raw(), id_, which, nullptr, 0, &n), "sim_query_responders");
+  std::vector<uint32_t> all(n);
+  if (n) check(sim_query_responders(c_->raw(), id_, which, all.data(), n, &n), "sim_query_responders");
+  std::set_difference(all.begin(), all.end(), seen.begin(), seen.end(), std::back_inserter(out));  // both ascending
+  seen = std::move(all);
+  return out;
+}
+inline std::vector<uint32_t> Serf::QueryResponse::acks() { return fresh(0, seen_acks_); }
+inline std::vector<Serf::NodeResponse> Serf::QueryResponse::responses() {
+  std::vector<NodeResponse> out;
+  for (uint32_t from : fresh(1, seen_resp_)) out.push_back(NodeResponse{from, payload_of_ ? payload_of_(from) : std::vector<uint8_t>{}});
+  return out;
 }
 inline void Serf::join(uint32_t peer) { check(sim_join(c_->raw(), id_, peer), "sim_join"); }
 inline void Serf::leave() { check(sim_leave(c_->raw(), id_), "sim_leave"); }

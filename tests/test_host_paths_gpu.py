@@ -7,6 +7,7 @@ import pytest
 
 from serf_amd import _ffi, snapshot as snap, wire
 from serf_amd.coalesce import MemberEventCoalescer, UserEventCoalescer, coalesce_loop
+from tests import _scenario as sc
 
 pytestmark = pytest.mark.gpu
 
@@ -188,3 +189,36 @@ def test_memberlist_flags_on_the_gpu(oracle, hiplib):
         g.step(1)
         o.step(1)
         assert g.digest() == o.digest(), f"awareness probe: tick {t}"
+
+
+def test_reconnector_on_the_gpu(oracle, hiplib):
+    # tests/test_oracle_reconnect.py on the HIP library, the oracle beside it tick by tick: a node that resumes after it was
+    # declared failed, with nobody gossiping to it any more, is reached by a peer's Reconnector (base.rs:612-681), refutes,
+    # and is alive again everywhere; eight nodes that stay down keep drawing attempts (request list -> SIM_OP_RECONNECT ->
+    # nothing happens); hand-placed attempts that share a node run one per tick
+    n = 512
+    kw = dict(fanout=3, view_slots=32, event_ring=16, query_ring=8, probe_interval=2, suspicion_mult=4, suspicion_max_mult=2)
+    g, o = both(oracle, hiplib, n, gossip_to_the_dead=1, reconnect_interval=8, push_pull_interval=40, **kw)
+    for s in (g, o):
+        s.inject(3, _ffi.OP_CRASH, 10)
+        s.inject(32, _ffi.OP_REVIVE, 10)
+        for x in range(100, 500, 50):
+            s.inject(2, _ffi.OP_CRASH, x)
+    for t in range(200):
+        g.step(1)
+        o.step(1)
+        assert g.digest() == o.digest(), f"reconnector: tick {t}"
+    assert int(g.members(201)[0][10]) == _ffi.STATUS_ALIVE and int(g.dump(_ffi.ARR_ROWS)["inc"][10]) >= 1
+    assert int(g.members(201)[0][100]) == _ffi.STATUS_FAILED
+    t0 = g.tick
+    for s in (g, o):
+        s.inject(t0, _ffi.OP_RECONNECT, 5, 100)     # the target is down: forgotten
+        s.inject(t0, _ffi.OP_RECONNECT, 6, 10)
+        s.inject(t0, _ffi.OP_RECONNECT, 7, 10)      # shares node 10 with the attempt before: next tick
+        s.inject(t0, _ffi.OP_RECONNECT, 10, 8)      # and so does this one
+        s.inject(t0, _ffi.OP_RECONNECT, 20, 21)
+    for t in range(6):
+        g.step(1)
+        o.step(1)
+        assert g.digest() == o.digest(), f"hand-placed attempts: tick {t}"
+    sc.assert_same_state(g, o, "reconnector final")

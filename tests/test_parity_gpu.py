@@ -16,7 +16,7 @@ def pair(oracle, hiplib, n, **kw):
 
 def test_backend_is_hip(hiplib):
     assert hiplib.backend_name() == "hip-gfx950"
-    assert hiplib.abi_version() == 9
+    assert hiplib.abi_version() == 10
 
 
 @pytest.mark.parametrize("swim", [0, 5, 2])
@@ -95,6 +95,7 @@ def test_random_configurations(oracle, hiplib, seed):
     # configurations above are the ones the sweep has always run)
     kw.update(awareness_probe=bool(swim and rng.random() < 0.5), gossip_to_the_dead=int(rng.choice([0, 0, 2, 8])) if swim else 0,
               join_sync=bool(rng.random() < 0.5))
+    kw.update(reconnect_interval=int(rng.choice([0, 0, 3, 7])) if swim else 0)  # Reconnector (drawn after everything else)
     try:
         g, o = pair(oracle, hiplib, n, **kw)
     except _ffi.SimError:
@@ -137,6 +138,7 @@ def test_random_configurations_paged_packets(oracle, hiplib, seed):
               pkt_records=int(rng.choice([8, 12, 16])))
     kw.update(awareness_probe=bool(swim and rng.random() < 0.5), gossip_to_the_dead=int(rng.choice([0, 0, 2, 8])) if swim else 0,
               join_sync=bool(rng.random() < 0.5))
+    kw.update(reconnect_interval=int(rng.choice([0, 0, 3, 7])) if swim else 0)  # Reconnector (drawn after everything else)
     try:
         g, o = pair(oracle, hiplib, n, **kw)
     except _ffi.SimError:
@@ -394,8 +396,8 @@ def _push_pull_on_one_gpu(shards):
             s.sync()
 
 
-@pytest.mark.parametrize("swim,chunks,pkt", [(0, 1, 0), (4, 1, 0), (4, 2, 0), (0, 4, 0), (4, 2, 8), (0, 1, 16)])
-def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim, chunks, pkt):
+@pytest.mark.parametrize("swim,chunks,pkt,rc", [(0, 1, 0, 0), (4, 1, 0, 0), (4, 2, 0, 0), (0, 4, 0, 0), (4, 2, 8, 0), (0, 1, 16, 0), (2, 2, 0, 3)])
+def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim, chunks, pkt, rc):
     # BASELINE configs[3] shape (G shards by node-id range, the round's all-to-all), scaled down and run as 4 handles
     # on ONE GPU: the exchange of serf_amd/shard.py is done with device-to-device copies (for every sender chunk c:
     # slab g of shard s's send region c -> slab s of shard g's receive region c), which is what the per-chunk
@@ -403,10 +405,13 @@ def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim, chunks, pkt
     # with the double-buffered receive side.  Every shard is compared with the oracle's matching slice.
     import torch
 
-    n, V, ticks = 2048, 4, 50
+    # rc: the Reconnector — its attempts cross the shards on the request list and run as push-pull pairs of their tick
+    # (sim_pp_due / _plan / _export / _merge on a tick without a batch), most of them between two shards
+    n, V, ticks = 2048, 4, 50 if not rc else 90
     m = n // V
     kw = dict(fanout=4, view_slots=96, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=0.02,
-              push_pull_interval=3 if swim else 0, chunks=chunks if chunks > 1 else 0, pkt_records=pkt)   # pkt: paged packets in the exchange buffers
+              push_pull_interval=3 if swim else 0, chunks=chunks if chunks > 1 else 0, pkt_records=pkt,   # pkt: paged packets in the exchange buffers
+              reconnect_interval=rc, **(dict(suspicion_mult=3, suspicion_max_mult=2, gossip_to_the_dead=1) if rc else {}))
     ref = _ffi.Sim(oracle, _ffi.make_config(n, vshards=V, **kw))
     shards, send, recv = [], [], []
     for g in range(V):
@@ -420,12 +425,19 @@ def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim, chunks, pkt
     ops = sc.schedule(n, ticks // 2, rate=0.8 if not pkt else 3.0, seed=5, max_member_subjects=60)
     for s in shards + [ref]:
         sc.apply_schedule(s, ops)
+        for x in ((7, 300, 777, 1200, 1500, 2000) if rc else ()):   # six nodes go down and are declared failed; four of them resume
+            s.inject(1, _ffi.OP_CRASH, x)                            # when nobody gossips to them any more (gossip_to_the_dead):
+            if x > 500:                                              # only a peer's Reconnector can bring those back
+                s.inject(50, _ffi.OP_REVIVE, x)
     region = send[0].numel() // chunks
     slab = region // V
+    rc_ticks = 0
+    pp_step = max(1, kw["push_pull_interval"] * (int(np.ceil(np.log2(n) - 5)) + 1) // 8)   # oracle pp_params
     for t in range(ticks):
         for s in shards:
             s.step_begin()
         if shards[0].pp_due():
+            rc_ticks += 0 if (t > 0 and t % pp_step == 0) else 1   # not a batch tick: the exchange runs for reconnect attempts alone
             _push_pull_on_one_gpu(shards)
         for c in range(chunks):
             for s in shards:
@@ -453,6 +465,10 @@ def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim, chunks, pkt
                     a = s.dump(which).reshape(rows, m)
                     b = np.ascontiguousarray(ref.dump(which).reshape(rows, n)[:, lo:lo + m])
                     assert a.tobytes() == b.tobytes(), f"shard {g} array {which} differs at tick {t}"
+    assert not rc or rc_ticks >= 2, "no reconnect attempt ran as a push-pull of its own"
+    if rc:
+        st = shards[0].members(5)[0]
+        assert [int(st[x]) for x in (777, 1200, 1500, 2000)] == [_ffi.STATUS_ALIVE] * 4 and int(st[7]) == _ffi.STATUS_FAILED
     for qop in [op for op in ops if op[1] == _ffi.OP_QUERY and op[4] & _ffi.F_ACK][:3]:
         parts = [s.query_status(qop[3]) for s in shards]
         assert (sum(p[0] for p in parts), sum(p[1] for p in parts), parts[0][2]) == ref.query_status(qop[3])

@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, n, ticks, swim, chunks, q, jitter=0.0, pkt=0, loss=0.02):
+def _worker(rank, world, port, n, ticks, swim, chunks, q, jitter=0.0, pkt=0, loss=0.02, rc=0):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -50,7 +50,8 @@ def _worker(rank, world, port, n, ticks, swim, chunks, q, jitter=0.0, pkt=0, los
     try:
         lib = load_oracle()
         kw = dict(fanout=3, view_slots=64 if loss < 0.05 else 256, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=loss,
-                  push_pull_interval=4 if swim else 0, pkt_records=pkt)
+                  push_pull_interval=4 if swim else 0, pkt_records=pkt, reconnect_interval=rc,
+                  **(dict(suspicion_mult=3, suspicion_max_mult=2, gossip_to_the_dead=1) if rc else {}))
         sh = ShardedSim(lib, n, torch.device("cpu"), chunks=chunks, **kw)
         ref = _ffi.Sim(lib, _ffi.make_config(n, vshards=world, chunks=chunks if chunks > 1 else 0, **kw))  # all shards in one process
         ops = sc.schedule(n, ticks // 2, rate=0.7 if not pkt else 3.0, seed=17, max_member_subjects=40)
@@ -61,16 +62,23 @@ def _worker(rank, world, port, n, ticks, swim, chunks, q, jitter=0.0, pkt=0, los
         for t, op, node, a, b in ops:
             sh.inject(t, op, node, a, b)
             ref.inject(t, op, node, a, b)
+        for x in ((7, 300, 777, 1000) if rc else ()):   # nodes that go down and are declared failed; two of them resume when nobody
+            for s_ in (sh, ref):                         # gossips to them any more: only a peer's Reconnector brings those back
+                s_.inject(1, _ffi.OP_CRASH, x)
+                if x > 500:
+                    s_.inject(50, _ffi.OP_REVIVE, x)
         m = n // world
         lo = rank * m
         vs = kw["view_slots"]
-        handed = [0]
+        handed = [0, 0]
         if swim:
             real_import = sh.sim.suspect_import
 
             def counting(of_tick, ptr, w):   # how many slot-less suspicions crossed the shards
                 hs = sh._sq_host[of_tick % len(sh._sq_host)].view(w, -1)
                 handed[0] += int(hs[:, 0].sum())
+                for row in hs:   # entries with bit 31 of the second word: the Reconnector's attempts
+                    handed[1] += int((row[2:1 + 2 * int(row[0]):2] < 0).sum())
                 return real_import(of_tick, ptr, w)
             sh.sim.suspect_import = counting
         for t in range(0, ticks, 5):
@@ -93,6 +101,12 @@ def _worker(rank, world, port, n, ticks, swim, chunks, q, jitter=0.0, pkt=0, los
             # a probe that fails on a member without a view slot: every shard's list of tick t, gathered behind the tick
             # and replayed at t + 2 on every shard (sim_suspect_export / _import), must reproduce the single-process run
             assert handed[0] > 20, handed
+        if rc:
+            # Reconnector attempts cross the shards like the suspicions (request list -> SIM_OP_RECONNECT on every shard) and
+            # run as push-pull pairs of their tick through sim_pp_plan / _export / _merge, most of them between two shards
+            assert handed[1] > 20, handed
+            st = ref.members(5)[0]
+            assert [int(st[x]) for x in (777, 1000)] == [_ffi.STATUS_ALIVE] * 2 and int(st[7]) == _ffi.STATUS_FAILED, "the Reconnector brought the resumed nodes back"
         q.put((rank, "ok"))
     except BaseException as e:  # noqa: BLE001 — report to the parent, then re-raise
         q.put((rank, repr(e)))
@@ -101,20 +115,21 @@ def _worker(rank, world, port, n, ticks, swim, chunks, q, jitter=0.0, pkt=0, los
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,chunks,swim,n,jitter,pkt,loss", [(2, 1, 0, 1024, 0, 0, .02), (2, 1, 4, 1024, 0, 0, .02), (2, 2, 4, 1024, 0, 0, .02),
-                                                                 (4, 2, 4, 1024, 0, 0, .02), (4, 4, 0, 1024, 0, 0, .02), (4, 4, 4, 4096, 0.004, 0, .02),
-                                                                 (2, 2, 4, 1024, 0, 16, .02), (2, 1, 2, 1024, 0, 0, .12), (4, 2, 2, 2048, 0, 16, .12)])
-def test_shards_gloo_match_single_process(world, chunks, swim, n, jitter, pkt, loss):
+@pytest.mark.parametrize("world,chunks,swim,n,jitter,pkt,loss,rc", [(2, 1, 0, 1024, 0, 0, .02, 0), (2, 1, 4, 1024, 0, 0, .02, 0), (2, 2, 4, 1024, 0, 0, .02, 0),
+                                                                    (4, 2, 4, 1024, 0, 0, .02, 0), (4, 4, 0, 1024, 0, 0, .02, 0), (4, 4, 4, 4096, 0.004, 0, .02, 0),
+                                                                    (2, 2, 4, 1024, 0, 16, .02, 0), (2, 1, 2, 1024, 0, 0, .12, 0), (4, 2, 2, 2048, 0, 16, .12, 0),
+                                                                    (2, 2, 1, 1024, 0, 0, .02, 2), (4, 1, 1, 1024, 0, 0, .0, 3)])
+def test_shards_gloo_match_single_process(world, chunks, swim, n, jitter, pkt, loss, rc):
     # chunks > 1: the tick runs as `chunks` launches, each followed by the asynchronous all-to-all of its slabs
     # (double-buffered receive side) — the overlapped path of serf_amd/shard.py
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 300) + swim + 7 * world + chunks + (40 if loss > .05 else 0)
+    port = 29600 + (os.getpid() % 300) + swim + 7 * world + chunks + (40 if loss > .05 else 0) + 11 * rc
     # (the last case is the configuration that stalled on one GPU in round 2 — world 4, 4 chunks, SWIM and push-pull
     # batches, 4 096 nodes — here with CPU tensors and every collective randomly delayed)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, 60, swim, chunks, q, jitter, pkt, loss)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, 60 if not rc else 100, swim, chunks, q, jitter, pkt, loss, rc)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
