@@ -92,6 +92,28 @@ int main() {
     REQUIRE(code == 0);                                                        // 490 + framing <= 512
     cl.step();
     REQUIRE(s3.stats().event_time == t0 + 2);
+    // ---- Serf::query -> QueryResponse (api.rs:304, query.rs:117-303): who acked, who responded, with what ----
+    Serf s9 = cl.node(9);
+    Serf::QueryResponse qr = s9.query_response(77, SIM_F_ACK | SIM_F_RESPOND);
+    qr.on_respond([](uint32_t from) { return Bytes{(uint8_t)(from & 0xFF), (uint8_t)(from >> 8)}; });  // every node answers with its id
+    std::vector<uint32_t> ackers;
+    std::vector<Serf::NodeResponse> answers;
+    for (int t = 0; t < 14; ++t) {
+      cl.step();
+      for (uint32_t a : qr.acks()) ackers.push_back(a);                       // each call: the responders new since the last one
+      for (auto& nr : qr.responses()) answers.push_back(nr);
+    }
+    std::vector<uint32_t> once = ackers;
+    std::sort(once.begin(), once.end());
+    REQUIRE(std::adjacent_find(once.begin(), once.end()) == once.end());       // every responder exactly once (QueryResponseCore.acks)
+    REQUIRE(ackers.size() == 256 && answers.size() == 256);                    // lossless cluster: everybody, the origin included
+    Serf::QueryStatus qs = s9.query_status(77);
+    REQUIRE(qs.acks == ackers.size() && qs.responses == answers.size());
+    for (auto& nr : answers) REQUIRE(nr.payload.size() == 2 && (uint32_t)(nr.payload[0] | (nr.payload[1] << 8)) == nr.from);
+    REQUIRE(!qr.finished());                                                   // deadline 16 * ceil(log10(257)) = 48 ticks
+    qr.close();
+    REQUIRE(qr.finished() && qr.acks().empty());
+    printf("query_acks %zu query_responses %zu\n", ackers.size(), answers.size());
   } catch (const Error& er) {
     fprintf(stderr, "unexpected %s\n", er.what());
     return 2;

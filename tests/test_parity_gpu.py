@@ -472,6 +472,8 @@ def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim, chunks, pkt
     for qop in [op for op in ops if op[1] == _ffi.OP_QUERY and op[4] & _ffi.F_ACK][:3]:
         parts = [s.query_status(qop[3]) for s in shards]
         assert (sum(p[0] for p in parts), sum(p[1] for p in parts), parts[0][2]) == ref.query_status(qop[3])
+        # every shard lists the responders among ITS nodes: together, the single-process list
+        assert sorted(x for s in shards for x in s.query_responders(qop[3], 0)) == ref.query_responders(qop[3], 0)
     tot = [sum(x) for x in zip(*(s.convergence(_ffi.K_LEAVE, next(o for o in ops if o[1] == _ffi.OP_LEAVE)[2], 1) for s in shards))]
     assert tuple(tot) == ref.convergence(_ffi.K_LEAVE, next(o for o in ops if o[1] == _ffi.OP_LEAVE)[2], 1)
 
@@ -792,6 +794,9 @@ def test_query_filters_and_tags_parity(oracle, hiplib, n, swim):
             except _ffi.SimError:   # its tracker was taken over by a later query with the same residue
                 continue
             assert g.query_status(op[3]) == so
+            for which in (0, 1):   # and WHO they are (QueryResponse::ack_rx / response_rx): the same nodes, not only as many
+                who = g.query_responders(op[3], which)
+                assert who == o.query_responders(op[3], which) and len(who) == so[which] and who == sorted(set(who))
             n_checked += 1
             n_filtered_small += op[3] in filtered and so[0] < n // 2
     assert n_checked > 10 and n_filtered_small > 3, "the scenario must exercise filtered queries"

@@ -108,6 +108,9 @@ def test_filter_bounds(oracle):
     sim.step(30)
     assert sim.cluster_stats()["ops_dropped"] == 1
     assert sim.query_status(3)[0] == 12
+    assert sim.query_responders(3, 0) == list(range(1, 13)) and sim.query_responders(3, 1) == []   # the twelve ids of the filter acked
+    with pytest.raises(_ffi.SimError):
+        sim.query_responders(4, 0)              # no such running query
     with pytest.raises(_ffi.SimError):
         sim.set_tags(0, 32)
     with pytest.raises(_ffi.SimError):
