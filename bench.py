@@ -450,12 +450,21 @@ def run(args, lib=None, dev=None, backend="nccl"):
         # (the bytes a launch moves follow the load of the ticks it covers: the profile's figure is this run's only when the
         # same ticks are timed)
         same_ticks = bool(prov) and prov["timed_ticks_of_the_profile"] == {"steps": args.steps, "warmup": args.warmup}
+        # `achieved` / `frac` follow the measurement contract: ALGORITHMIC bytes per launch (SURVEY.md §8d's per-member-tick
+        # figure x the nodes one launch processes) over the kernel's average launch duration.  That figure counts f copies of
+        # every packet, which this kernel does not write: what is actually on the pins is `traffic` (PMC counters, when they
+        # were collected on this kernel source, load and timed ticks) and `measured` = traffic over the same duration — the
+        # number to read as bandwidth.
+        achieved = algorithmic
+        basis = ("the contract's formula: SURVEY.md §8d algorithmic bytes per member-tick x nodes per launch / average launch duration; "
+                 "bytes actually moved: roofline.traffic, roofline.measured (PMC counters) — or roofline.layout when no PMC profile of this "
+                 "kernel source, load and timed ticks is on file")
         if traffic and prov["matches_this_kernel"] and default_load and same_ticks:
-            achieved, basis = traffic / kern_s / 1e9, "HBM bytes per launch measured with rocprofv3 PMC counters on this kernel source (roofline.traffic)"
+            measured = {"achieved": traffic / kern_s / 1e9, "frac": traffic / kern_s / 1e9 / 8000.0, "unit": "GB/s",
+                        "what": "HBM bytes per launch measured with rocprofv3 PMC counters on this kernel source (roofline.traffic) / average launch duration"}
         else:
             traffic = None  # a figure measured on another kernel source (or another load) is not this run's traffic
-            achieved, basis = layout, ("bytes per member-tick of the frozen layout (roofline.layout; no PMC measurement of this kernel source, "
-                                       "load and timed ticks is on file)")
+            measured = None
         out = {
             "metric": "member-ticks/sec", "value": value, "unit": "member-ticks/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -492,13 +501,12 @@ def run(args, lib=None, dev=None, backend="nccl"):
                                               "1 Mi (CPU oracle, 1 000 rumours each, profiles/r02_fanout_model_*.json)"}
                              if rounds else None),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic, "achieved_from": basis,
+                         "frac": achieved / 8000.0, "traffic": traffic, "measured": measured, "achieved_from": basis,
                          "kernel": "tick_kernel", "kernel_ms": kern_s * 1e3,
                          "kernel_ms_min": prof_min, "kernel_ms_max": prof_max, "kernel_launches": int(prof_n),
                          "kernel_timing": f"HIP event pair on every {profile_every}{'th' if profile_every > 1 else 'st'} tick_kernel dispatch of the timed region (hipExtLaunchKernelGGL start/stop events, on the launch stream)",
                          "stream_ms_per_step": ev_ms / args.steps,
-                         # SURVEY.md §8d's v0 figure — the formula the contract prices `achieved` with; it counts 4 copies
-                         # of every packet, which this kernel does not write, so it overstates the bytes on the pins
+                         # (the same figure again under its own name, next to the layout's)
                          "algorithmic": {"b_tick_bytes": bt, "achieved": algorithmic, "frac": algorithmic / 8000.0,
                                          "what": "SURVEY.md §8d B_tick(f) = 2R + 2QE + 2fPE + 4(f+2) x nodes / kernel time"},
                          "layout": {"b_tick_bytes": bt2, "achieved": layout, "frac": layout / 8000.0,

@@ -25,7 +25,7 @@ import json
 for f in ('bench_20_5','bench_default','bench_traced'):
     try:
         d=json.loads(open('$OUT/%s.json'%f).read().strip().splitlines()[-1]); r=d['roofline']
-        print(f, 'value %.3e'%d['value'], 'ms/step %.4f'%d['ms_per_step'], 'kernel_ms %.4f'%r['kernel_ms'], 'frac %.3f'%r['frac'], 'alg %.3f'%r['algorithmic']['frac'], 'drops', d['config']['model_bound_drops'],
+        print(f, 'value %.3e'%d['value'], 'ms/step %.4f'%d['ms_per_step'], 'kernel_ms %.4f'%r['kernel_ms'], 'frac %.3f'%r['frac'], 'measured', (r.get('measured') or {}).get('frac'), 'drops', d['config']['model_bound_drops'],
               'parity', d.get('parity', {}).get('digest_match'), 'second', {k: d['second_load'][k] for k in ('value','kernel_ms','model_bound_drops')} if 'second_load' in d else None,
               'rounds', {k: d['rounds_to_99'][k] for k in ('median','p90','max','n')} if d.get('rounds_to_99') else None)
     except Exception as e:
