@@ -68,6 +68,9 @@ def workload(args, n_total):
               recycle_interval=args.recycle_interval)
     if getattr(args, "pkt_records", 4) != 4:
         kw["pkt_records"] = args.pkt_records
+    if getattr(args, "random_fanout", False):  # memberlist's literal kRandomNodes instead of the per-tick bijection (one GPU)
+        from serf_amd import _ffi
+        kw["flags"] = _ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT
     ops = wl.schedule(n_total, horizon(args), rate=args.rate, seed=3, mix=wl.BENCH_MIX,
                       max_member_subjects=args.view_slots // 2, even=True)
     return kw, ops
@@ -214,6 +217,9 @@ def parse_args(argv=None):
     ap.add_argument("--push-pull-interval", type=int, default=150, help="memberlist push_pull_interval in ticks before log2(N) scaling (0 = off)")
     ap.add_argument("--recycle-interval", type=int, default=75, help="view-slot recycling pass every this many ticks (0 = never)")
     ap.add_argument("--second-rate", type=float, default=0.35, help="API operations per tick of the second measured load (16 records per packet)")
+    ap.add_argument("--random-fanout", action="store_true",
+                    help="gossip targets by memberlist's literal kRandomNodes (uniform, variable in-degree; the tick's fan-out graph as an explicit "
+                         "CSR built by a per-tick sort) instead of the per-tick bijection — a fidelity mode, not the headline (N = 1 only)")
     ap.add_argument("--no-second-load", action="store_true", help="skip the second measured load (N = 1: 16 records per packet at --second-rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence", action="store_true", help="skip the rounds-to-99 %% measurement (profiling runs)")
@@ -446,7 +452,7 @@ def run(args, lib=None, dev=None, backend="nccl"):
         algorithmic = args.nodes_per_gpu * bt / kern_s / 1e9
         layout = args.nodes_per_gpu * bt2 / kern_s / 1e9
         traffic, prov = measured_traffic()
-        default_load = args.pkt_records == 4 and args.rate == 0.25 and args.nodes_per_gpu == 1 << 20 and world == 1
+        default_load = args.pkt_records == 4 and args.rate == 0.25 and args.nodes_per_gpu == 1 << 20 and world == 1 and not args.random_fanout
         # (the bytes a launch moves follow the load of the ticks it covers: the profile's figure is this run's only when the
         # same ticks are timed)
         same_ticks = bool(prov) and prov["timed_ticks_of_the_profile"] == {"steps": args.steps, "warmup": args.warmup}
@@ -472,7 +478,7 @@ def run(args, lib=None, dev=None, backend="nccl"):
             "data": "synthetic",
             "config": {"workload": f"{n_total} nodes ({args.nodes_per_gpu}/GPU), fan-out {args.fanout}, "
                                    f"{args.rate} API ops/tick evenly spaced, mix (0.55, 0.2, 0.15, 0.05, 0.05) of (user event, query, leave, crash+remove, crash+revive) evenly interleaved, "
-                                   f"{args.pkt_records} records per packet, "
+                                   f"{args.pkt_records} records per packet, " + ("gossip targets by memberlist's literal kRandomNodes (--random-fanout), " if args.random_fanout else "") +
                                    f"view_slots {args.view_slots}, rings {args.ring}, probe interval {args.probe_interval} ticks, push-pull interval "
                                    f"{args.push_pull_interval} ticks (x log2 scaling), reaper and queue checker on — BASELINE configs[2]; "
                                    f"{args.preroll} untimed pre-roll ticks under the same load before the warm-up (steady state)",
@@ -496,9 +502,12 @@ def run(args, lib=None, dev=None, backend="nccl"):
                               "what": "gossip rounds until >= 99 % of running nodes have applied a user event, for every user event the workload itself "
                                       f"issues in ticks [{conv_first}, {conv_first + CONV_WINDOW}) (a fixed window: independent of --steps / --warmup), "
                                       "all outstanding events polled once per tick (sim_convergence_many)",
-                              "fanout_model": "per-tick bijection (every node receives exactly `fanout` packets per round); memberlist's literal "
-                                              "kRandomNodes (Poisson-like in-degree) needs one round more: 10 vs 9 at 64 Ki nodes, 12 vs 11 at "
-                                              "1 Mi (CPU oracle, 1 000 rumours each, profiles/r02_fanout_model_*.json)"}
+                              "fanout_model": ("memberlist's literal kRandomNodes (--random-fanout: uniform targets, Poisson-like in-degree, the "
+                                               "fan-out graph as an explicit per-tick CSR)" if args.random_fanout else
+                                               "per-tick bijection (every node receives exactly `fanout` packets per round); memberlist's literal "
+                                               "kRandomNodes (Poisson-like in-degree; `--random-fanout`) needs one round more: 10 vs 9 at 64 Ki nodes, "
+                                               "12 vs 11 at 1 Mi (profiles/r02_fanout_model_*.json on the CPU oracle, "
+                                               "profiles/r03_bench_random_fanout.json on the GPU)")}
                              if rounds else None),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "measured": measured, "achieved_from": basis,

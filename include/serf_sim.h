@@ -278,10 +278,14 @@ typedef struct sim_config {
 } sim_config;
 
 #define SIM_CF_BASELINE_JOINED 1u /* all nodes known+Alive at status_time 1, clock 2 (config 2-5) */
-#define SIM_CF_RANDOM_FANOUT 2u   /* CPU oracle only (the product returns SIM_EINVAL): gossip targets are memberlist's literal
-                                   * kRandomNodes (uniform, no replacement, skip self — App. B.2) instead of the per-tick
-                                   * bijection; in-degree is then Poisson-like.  Exists to put an error bar on the bijection's
-                                   * effect on rounds-to-99 % (tools/convergence_hist.py --random-fanout) */
+#define SIM_CF_RANDOM_FANOUT 2u   /* gossip targets are memberlist's literal kRandomNodes (uniform, no replacement, skip self —
+                                   * App. B.2) instead of the per-tick bijection; in-degree is then Poisson-like and a node's
+                                   * packets are handed over in (sender, slot) order.  One shard, one chunk, packets of one
+                                   * page (SIM_EINVAL otherwise); no checkpoints (sim_snapshot / sim_restore: SIM_ESTATE).
+                                   * (r3) Oracle AND product: the HIP library draws the targets ahead of the tick, builds
+                                   * the tick's fan-out graph as an explicit CSR with a stable radix sort, and the deliver
+                                   * loop walks a node's row of it — about half the headline's rate at 1 Mi nodes; the
+                                   * fidelity mode next to the bijection the benchmark runs on */
 #define SIM_CF_AWARENESS_PROBE 4u  /* memberlist scales its probe interval by the node's health score (awareness, state.go
                                    * probeNode: ScaleTimeout): a node with score s probes in every (s + 1)-th round of its
                                    * group's probe phase instead of every round (App. B.3)                              */

@@ -23,7 +23,7 @@
  *   - the model's capacity bounds (SIM_Q / SIM_C / SIM_S, view slots) are separated from the protocol:
  *     `make liboracle_unbounded.so` builds this same source with the bounds out of reach, and
  *     tests/test_oracle_unbounded.py shows that a bounded run with overflow == 0 is the unbounded run.
- *   - SIM_CF_RANDOM_FANOUT (this library only): memberlist's literal kRandomNodes instead of the per-tick
+ *   - SIM_CF_RANDOM_FANOUT (round 3: the HIP library has it too): memberlist's literal kRandomNodes instead of the per-tick
  *     bijection, to put an error bar on the fan-out model (tests/fanout_model_hist.py).
  *   - view-slot recycling, the chunk-structured fan-out map and the cross-shard push-pull records are
  *     simulator constructions (DESIGN.md SIMSPEC §2.3, §2.6, §2.10): defined here and in the HIP library,
@@ -1408,6 +1408,21 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
       fan_target(p, g, ll, k, &h, &lp);
       if (gossip_skips(s, l, h * p->M + lp)) skipm |= 1u << k;
     }
+  /* SIM_CF_RANDOM_FANOUT — kRandomNodes (App. B.2): uniform draws, skip self and duplicates, up to 3n tries.  Drawn as the
+   * tick begins, like the skips above (the HIP library draws in a launch of its own ahead of the tick kernel): a slot
+   * without a target (fewer than `fanout` other nodes) sends nothing */
+  uint32_t chosen[SIM_MAX_FANOUT], nc = 0;
+  if (s->rfan) {
+    uint64_t rb = rng_base(s->cfg.seed, STREAM_RFAN, s->tick);
+    for (uint32_t i = 0; i < 3u * s->N && nc < p->feff; ++i) {
+      uint32_t t = (uint32_t)(((mix64(rb ^ ((uint64_t)c.gid * 4096u + i)) >> 32) * (uint64_t)s->N) >> 32);
+      int dup = (t == c.gid);
+      for (uint32_t j = 0; j < nc; ++j) dup |= (chosen[j] == t);
+      if (!dup) chosen[nc++] = t;
+    }
+    for (uint32_t k = 0; k < p->feff; ++k)
+      if (k >= nc || gossip_skips(s, l, chosen[k])) skipm |= 1u << k;
+  }
   if (up) {
     if (row->next_seq > 1023u - 64u) queue_renorm(row, q);
     if (s->tick > 0 && s->rfan) { /* variable in-degree: every packet addressed to this node, (sender, k) order */
@@ -1437,18 +1452,11 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
     uint32_t limit = s->cfg.retransmit_mult * digits10(row->n_known); /* B.1, serf.rs:123-131 */
     for (uint32_t k = 0; k < p->feff; ++k) queue_emit(row, q, limit, s->P, out[k]);
   }
-  if (s->rfan) { /* kRandomNodes (App. B.2): uniform draws, skip self and duplicates, up to 3n tries */
-    uint64_t rb = rng_base(s->cfg.seed, STREAM_RFAN, s->tick);
-    uint32_t chosen[SIM_MAX_FANOUT], nc = 0;
-    for (uint32_t i = 0; i < 3u * s->N && nc < p->feff; ++i) {
-      uint32_t t = (uint32_t)(((mix64(rb ^ ((uint64_t)c.gid * 4096u + i)) >> 32) * (uint64_t)s->N) >> 32);
-      int dup = (t == c.gid);
-      for (uint32_t j = 0; j < nc; ++j) dup |= (chosen[j] == t);
-      if (!dup) chosen[nc++] = t;
-    }
+  if (s->rfan) { /* the packets stay in the sender's cells; rtgt says where each one goes */
+    for (uint32_t k = p->feff; k < s->f; ++k) s->rtgt[(size_t)k * s->Nl + l] = NOSLOT; /* slots a small cluster does not use */
     for (uint32_t k = 0; k < p->feff; ++k) {
       size_t cell = (size_t)k * s->Nl + l;
-      if (k >= nc || (up && (pkt_lost(p, c.gid, k) || gossip_skips(s, l, chosen[k])))) memset(out[k], 0, sizeof out[k]);
+      if (((skipm >> k) & 1u) || (up && pkt_lost(p, c.gid, k))) memset(out[k], 0, sizeof out[k]);
       for (uint32_t pg = 0; pg < PG; ++pg) s->inbox[(s->tick + 1) & 1][((size_t)k * PG + pg) * s->Nl + l] = out[k][pg];
       s->rtgt[cell] = k < nc ? chosen[k] : NOSLOT;
     }
@@ -2404,7 +2412,7 @@ static void snap_sections(osim* s, const void* ptr[SNAP_SECTIONS], size_t len[SN
 }
 int API(snapshot)(osim* s, void* buf, size_t cap, size_t* bytes) {
   if (!s || !bytes) return SIM_EINVAL;
-  if (s->in_tick) return SIM_ESTATE;
+  if (s->in_tick || s->rfan) return SIM_ESTATE; /* (the image has no section for the targets of the packets in flight) */
   if (s->cfg.shard_count <= 1 && (s->sreq_prev_n || s->sreq_n)) { /* slot-less failed probes not yet replayed: into the schedule, so that the image holds them */
     for (uint32_t i = 0; i < s->sreq_prev_n; ++i) inject_val(s, s->tick, SIM_OP_SUSPECT, s->sreq_prev[2 * i], s->sreq_prev[2 * i + 1], 0, 0);
     sreq_rotate(s);
@@ -2435,7 +2443,7 @@ int API(snapshot)(osim* s, void* buf, size_t cap, size_t* bytes) {
 }
 int API(restore)(osim* s, const void* buf, size_t bytes) {
   if (!s || !buf || bytes < sizeof(snap_header)) return SIM_EINVAL;
-  if (s->tick != 0 || s->n_ops != 0) return SIM_ESTATE;
+  if (s->tick != 0 || s->n_ops != 0 || s->rfan) return SIM_ESTATE;
   snap_header h;
   memcpy(&h, buf, sizeof h);
   if (h.magic != SNAP_MAGIC || h.abi != SIM_ABI_VERSION || memcmp(&h.cfg, &s->cfg, sizeof(sim_config))) return SIM_EINVAL;

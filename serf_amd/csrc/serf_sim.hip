@@ -29,6 +29,7 @@
 // returns SIM_EDEVICE.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <hipcub/hipcub.hpp>  // DeviceRadixSort: the per-tick CSR of the random fan-out mode (SIM_CF_RANDOM_FANOUT)
 
 #include <algorithm>
 #include <cmath>
@@ -66,7 +67,7 @@ __host__ __device__ static inline u64 mix64(u64 z) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-enum { STREAM_PERM = 1, STREAM_OFF = 2, STREAM_ROT = 3, STREAM_LOSS = 4, STREAM_PROBE = 5, STREAM_QUERY = 6, STREAM_RHO = 8 };
+enum { STREAM_PERM = 1, STREAM_OFF = 2, STREAM_ROT = 3, STREAM_LOSS = 4, STREAM_PROBE = 5, STREAM_QUERY = 6, STREAM_RFAN = 7, STREAM_RHO = 8 };
 enum { PD_TARGET = 0, PD_PING = 1, PD_ACK = 2, PD_RELAY0 = 3, PD_RECONNECT = 30 /* + 1: which failed member */ };
 #define SREQ_RECONNECT 0x80000000u  // request-list entries of the Reconnector: (node, target | this)
 static inline u64 rng_base(u64 seed, u64 stream, u64 a) {
@@ -288,6 +289,13 @@ struct Dev {
   u32* qbits;       // [SIM_QT][2][ceil(N/32)] who acked / responded, by global node id
   uint4* nullcell;  // 2 x uint4 of zeros: where the prefetch of a record without a lookup points
   uint8_t* skipmask;  // [Nl] gossip_to_the_dead: bit k = do not send packet k this tick (written by gossip_skip_kernel)
+  // SIM_CF_RANDOM_FANOUT (memberlist's literal kRandomNodes, App. B.2): the fan-out graph of a tick as an explicit CSR — for
+  // receiver l the packets addressed to it are rsrc[rcsr[l] .. rcsr[l + 1]), each entry sender * 4 + slot, senders
+  // ascending, then slots (the order memberlist's packets would be handed to the oracle in); built per tick by a stable
+  // radix sort of (target, sender * 4 + slot) pairs.  Double buffered by tick parity like the packets themselves.
+  u32* rcsr[2];  // [Nl + 1]
+  u32* rsrc[2];  // [f * Nl]
+  u32 rfan;      // the mode is on (local mode, one page per packet)
   u32* sreq;        // [1 + 2 * SIM_SUSPECT_REQ_MAX]: count, then the (prober, target) pairs of the running tick's slot-less
                     // failed probes (one of three buffers, by tick mod 3: the host reads a tick's list one tick later)
   u32* sreq_next;   // the count word of the NEXT tick's buffer: zeroed by this tick's kernel (no memset between two ticks)
@@ -1311,7 +1319,7 @@ __device__ static inline u32 pk_word(const uint4& v, u32 p) { return p == 0 ? v.
 //  drain takes up to d.P entries per packet; with MP = false all of that folds back to the one-page kernel)
 // (the body of the kernel as a function of the block index: written this way the compiler keeps 76 instead of 116 bytes of
 // scratch per lane — 2 % of the tick, profiles/r03_experiments.md)
-template <bool SHARDED, int F, bool B64, bool MP>
+template <bool SHARDED, int F, bool B64, bool MP, bool RF>
 __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const TickP& ptp, const u32 cur, const uint4* base, const u32 chunk, const u32 cnt, const u32 bx) {
 #ifdef TICK_TIMING
   unsigned long long tacc[32] = {0};
@@ -1352,7 +1360,7 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   // (B64, 64-node blocks: pi(j2) and the four sender blocks are wave-uniform and pinned in SGPRs; small or ragged
   // shards, B = 1, work the four senders out once through the general per-node form of the map.)
   u32 ry = 0, sj0 = 0, sj1 = 0, sj2 = 0, sj3 = 0;
-  if (!SHARDED && B64 && tp.feff) {
+  if (!SHARDED && B64 && !RF && tp.feff) {
     u32 ru2 = ll;  // index inside the receiving chunk: (vblock, offset)
     if (tp.V != 1 || tp.C != 1) {
       u32 rbb = ll / tp.blk, w = ll - rbb * tp.blk;
@@ -1366,7 +1374,7 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
     };
     sj0 = blk_of(0); sj1 = blk_of(1); sj2 = blk_of(2); sj3 = blk_of(3);
   }
-  if (!SHARDED && !B64) {
+  if (!SHARDED && !B64 && !RF) {
 #pragma unroll 1
     for (u32 k = 0; k < tp.feff; ++k) {
       u32 gs, sl;
@@ -1388,7 +1396,18 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   // local mode: byte k = where the sender of slot k put that packet: first page << 2 | pages - 1 (0xFF: nothing sent)
   u32 jw = 0xFFFFFFFFu;
   // page pg of the packet of fan-out slot k (sharded: the block of the receive buffer the source shard filled)
+  // RF (literal kRandomNodes): the node's incoming packets are entries rin0 .. rin0 + rcnt of the tick's CSR (Dev::rsrc:
+  // sender * 4 + slot); "slot k" of the deliver loop is then the k-th incoming packet, and the loop runs as often as the lane
+  // of the wave with the most packets needs (in-degree is Poisson-like: mean f)
+  u32 rin0 = 0, rcnt = 0;
+  if (RF) { rin0 = d.rcsr[cur][l]; rcnt = d.rcsr[cur][l + 1] - rin0; }
   auto cell_of = [&](u32 k, u32 pg) __attribute__((always_inline)) -> const uint4* {
+    if (RF) {
+      if (k >= rcnt) return d.nullcell;
+      const u32 ent = d.rsrc[cur][rin0 + k], snd = ent >> 2, slot = ent & 3u;
+      const u32 jb = (d.omap[cur][snd] >> (8u * slot)) & 0xFFu;
+      return jb == 0xFFu ? d.nullcell : d.obox[cur] + ((size_t)(jb >> 2) * d.Nl + snd) * PK_U4;
+    }
     if (SHARDED) {  // [sender chunk][source shard][slot * PG + page][sub] (oracle xcell)
       u32 b = l / tp.blk, w = l - b * tp.blk, sl = w / tp.sub;
       u32 src = (d.shard_rank + b + tp.prot[k]) % tp.V;
@@ -1415,7 +1434,14 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   // requested before the map word is known and dropped if the word says "nothing sent".
   const uint4* cell;
   u32 om0 = 0xFFFFFFFFu, om1 = 0xFFFFFFFFu, om2 = 0xFFFFFFFFu, om3 = 0xFFFFFFFFu;
-  if (SHARDED) cell = tp.first ? d.nullcell : cell_of(0, 0);
+  u32 rf_npk = 0;  // RF: packets the wave walks (the most any lane received)
+  if (RF) {
+    cell = cell_of(0, 0);
+    u32 w = rcnt;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) w = max(w, (u32)__shfl_xor((int)w, o, 64));
+    rf_npk = w;
+  } else if (SHARDED) cell = tp.first ? d.nullcell : cell_of(0, 0);
   else {
     // (the four senders first, then the four loads back to back from selected addresses: a load inside a branch gets
     // its own s_waitcnt — four round trips before the row was even asked for)
@@ -1430,7 +1456,7 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   uint4 rn = ld4(cell), rn1 = ld4((SHARDED && tp.first) ? cell : cell + 1), rn2 = ld4((SHARDED && tp.first) ? cell : cell + 2);
   Node n;
   node_load(d, l, n);
-  if (!SHARDED) {
+  if (!SHARDED && !RF) {
     jw = (tp.feff > 0 ? om0 & 0xFFu : 0xFFu) | (tp.feff > 1 ? om1 & 0xFF00u : 0xFF00u) |
          (tp.feff > 2 ? om2 & 0xFF0000u : 0xFF0000u) | (tp.feff > 3 ? om3 & 0xFF000000u : 0xFF000000u);
     if ((jw & 0xFFu) == 0xFFu) rn = rn1 = rn2 = zero;
@@ -1442,6 +1468,7 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
     if (!SHARDED || !tp.first) {
       // the pages of the f packets, in order: packet k's page 0, 1, ... then packet k + 1 (one page each unless MP)
       u32 k = 0, pg = 0, wnp = wave_np(0);
+      const u32 npk = RF ? rf_npk : d.f;  // packets to walk
 #ifdef TICK_NEXT_SLOTS
       // The slot-map lookups of the NEXT page travel while this page is classified: they are issued as soon as the next
       // cell's words are here (right behind the wait for this page's heads), and parked in the top 16 bits of this lane's
@@ -1450,9 +1477,9 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
       const bool use_ns = d.A <= 65534u;
       bool have_ns = false;  // (wave-uniform) lds_p[i][tid] >> 48 = slot of record i of the page whose words are in rn ..
 #endif
-      while (k < d.f) {
+      while (k < npk) {
         if (MP) {
-          if (++pg >= wnp) { ++k; pg = 0; if (k < d.f) wnp = wave_np(k); }
+          if (++pg >= wnp) { ++k; pg = 0; if (k < npk) wnp = wave_np(k); }
         } else ++k;
         // from here on (k, pg) is the page AFTER the one being delivered (whose three words are in rn, rn1, rn2)
         u32 slow;  // records of this page that need a handler
@@ -1469,7 +1496,7 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
           // on top; issued behind the slot-map loads it travels together with the head loads.
           // (its address is worked out up here: what that needs may come back from scratch, and a scratch reload
           // between two loads makes the second wait for the first)
-          cell = k < d.f ? cell_of(k, pg) : d.nullcell;
+          cell = k < npk ? cell_of(k, pg) : d.nullcell;
           auto prefetch = [&]() __attribute__((always_inline)) { rn = ld4(cell); rn1 = ld4(cell + 1); rn2 = ld4(cell + 2); };
           TT(1);
           // wave-ballot early out: nobody in this wave received anything in packet k (an empty record is all zero)
@@ -1636,7 +1663,7 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   // gossip_to_the_dead_time (App. B.2): the slots whose target this node believed dead for too long when the tick began
   // (gossip_skip_kernel, launched ahead of the tick only when the option is on) — those packets are not sent
 #ifndef TICK_LEAN
-  const u32 skipm = d.gttd ? (u32)d.skipmask[l] : 0u;
+  const u32 skipm = (d.gttd || RF) ? (u32)d.skipmask[l] : 0u;  // (RF: also the slots that drew no target)
 #else
   const u32 skipm = 0u;  // (measurement build: the round's optional memberlist switches compiled out of the tick kernel)
 #endif
@@ -1883,15 +1910,15 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
     for (int i = 0; i < 32; ++i) atomicAdd(&g_tt[i], tacc[i]);
 #endif
 }
-template <bool SHARDED, int F, bool B64, bool MP>
+template <bool SHARDED, int F, bool B64, bool MP, bool RF = false>
 __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, TickP ptp, u32 cur, const uint4* base, u32 chunk, u32 cnt) {
 #ifdef TICK_PERSIST
   // experiment (withdrawn, profiles/r03_experiments.md): as many blocks as fit on the GPU at once, each walking its share of the node blocks
   const u32 nb = (cnt + TBLOCK - 1) / TBLOCK;
 #pragma unroll 1
-  for (u32 bx = blockIdx.x; bx < nb; bx += gridDim.x) tick_block<SHARDED, F, B64, MP>(d, tp, ptp, cur, base, chunk, cnt, bx);
+  for (u32 bx = blockIdx.x; bx < nb; bx += gridDim.x) tick_block<SHARDED, F, B64, MP, RF>(d, tp, ptp, cur, base, chunk, cnt, bx);
 #else
-  tick_block<SHARDED, F, B64, MP>(d, tp, ptp, cur, base, chunk, cnt, blockIdx.x);
+  tick_block<SHARDED, F, B64, MP, RF>(d, tp, ptp, cur, base, chunk, cnt, blockIdx.x);
 #endif
 }
 
@@ -2044,6 +2071,48 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
   }
 }
 
+// SIM_CF_RANDOM_FANOUT — memberlist's kRandomNodes (App. B.2; oracle tick_node): every node draws its `fanout` gossip targets
+// uniformly over the other nodes, without replacement, as the tick begins.  Output: the (target, sender * 4 + slot) pairs in
+// (sender, slot) order — a slot that drew no target (fewer than `fanout` other nodes) gets the key N, which sorts behind every
+// node — and the node's skip byte: no target, or gossip_to_the_dead says the target has been dead for too long.
+__global__ void rfan_draw_kernel(Dev d, TickP tp, const uint4* base, u64 rb, u32* keys, u32* vals) {
+  for (size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * blockDim.x) {
+    const u32 gid = d.shard0 + (u32)l;
+    u32 chosen[SIM_MAX_FANOUT], nc = 0, m = 0;
+    for (u32 i = 0; i < 3u * d.N && nc < tp.feff; ++i) {
+      u32 t = (u32)(((mix64(rb ^ ((u64)gid * 4096u + i)) >> 32) * (u64)d.N) >> 32);
+      bool dup = t == gid;
+      for (u32 j = 0; j < nc; ++j) dup |= chosen[j] == t;
+      if (!dup) { chosen[nc] = t; ++nc; }
+    }
+    for (u32 k = 0; k < d.f; ++k) {
+      u32 key = d.N;
+      if (k < nc && k < tp.feff) {
+        key = chosen[k];
+        if (d.gttd) {
+          u32 a = d.slot_of[key];
+          uint4 e = a == NOSLOT ? base[(size_t)key * 2] : d.view[(size_t)a * d.Nl + l];
+          u32 sw = SIM_VB_SWIM(e.w);
+          if ((e.w & SIM_VB_KNOWN) && (sw == SIM_SWIM_DEAD || sw == SIM_SWIM_LEFT) && ((((u32)tp.tick - SIM_VB_STAMP(e.w)) & STAMP_MASK) > d.gttd)) m |= 1u << k;
+        }
+      } else m |= 1u << k;
+      keys[l * d.f + k] = key;
+      vals[l * d.f + k] = (u32)l * 4u + k;
+    }
+    d.skipmask[l] = (uint8_t)m;
+  }
+}
+// row starts of the CSR from the sorted keys: rcsr[t] = first position whose key is >= t (t = 0 .. Nl)
+__global__ void rfan_csr_kernel(const u32* sorted_keys, u32 n, u32 Nl, u32* rcsr) {
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t <= Nl; t += (size_t)gridDim.x * blockDim.x) {
+    u32 lo = 0, hi = n;
+    while (lo < hi) {
+      u32 mid = (lo + hi) >> 1;
+      if (sorted_keys[mid] < (u32)t) lo = mid + 1; else hi = mid;
+    }
+    rcsr[t] = lo;
+  }
+}
 // gossip_to_the_dead_time (App. B.2; oracle gossip_skips): for every node and fan-out slot, does the node's view — as it is when
 // the tick begins — say that the packet's target has been dead / left for longer than that?  Its own launch, ahead of
 // the tick kernel and only when the option is on: the tick kernel then reads one byte per node.
@@ -2729,7 +2798,13 @@ __global__ void materialize_kernel(Dev d, TickP p, u32 cur, u32 valid, uint4* ou
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     u32 kk = (u32)(i / d.Nl), l = (u32)(i - (size_t)kk * d.Nl), k = kk / d.PG, pg = kk - k * d.PG;
     uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a;
-    if (valid && k < p.feff) {
+    if (d.rfan) {  // random fan-out: the canonical form is the oracle's — packets in the SENDER's cells, [slot][sender]
+      u32 jb = valid ? (d.omap[cur][l] >> (8u * k)) & 0xFFu : 0xFFu;
+      if (jb != 0xFFu) {
+        const uint4* cp = d.obox[cur] + ((size_t)(jb >> 2) * d.Nl + l) * PK_U4;
+        a = cp[0]; b = cp[1]; c = cp[2];
+      }
+    } else if (valid && k < p.feff) {
       u32 h = l / p.M, t = l - h * p.M, g, ll;
       fan_source_g(p, PICK4(p.off, k), PICK4(p.rot, k), PICK4(p.rho, k), h, t, k, g, ll);
       u32 s = g * p.M + ll;
@@ -2835,6 +2910,12 @@ struct sim_handle {
   // what dumps, digests and images hold), produced from Dev::obox on demand; mat_tick = the tick it was made for
   uint4* inbox_mat;
   u64 mat_tick;
+  // SIM_CF_RANDOM_FANOUT: this tick's draws as (target, sender * 4 + slot) pairs in (sender, slot) order, the sorted keys, and
+  // the radix sort's scratch
+  u32 *rf_keys, *rf_vals, *rf_keys_sorted;
+  void* rf_tmp;
+  size_t rf_tmp_bytes;
+  int rf_bits;
 };
 
 #define HCHECK(x)                                                                        \
@@ -2860,7 +2941,8 @@ static int cfg_check(const sim_config* c) {
   if (c->shard_rank >= c->shard_count) return SIM_EINVAL;
   if (c->fanout < 1 || c->fanout > SIM_MAX_FANOUT) return SIM_EINVAL;
   if (c->chunks > 1 && ((M / c->vshards) % c->chunks || (M / c->vshards) / c->chunks < 1)) return SIM_EINVAL;
-  if (c->flags & SIM_CF_RANDOM_FANOUT) return SIM_EINVAL;  // oracle-only comparison mode (variable in-degree)
+  // memberlist's literal kRandomNodes (variable in-degree, an explicit CSR per tick): one shard, one chunk, one page per packet
+  if ((c->flags & SIM_CF_RANDOM_FANOUT) && (c->vshards != 1 || c->shard_count != 1 || c->chunks > 1 || c->pkt_records > SIM_P)) return SIM_EINVAL;
   if (c->event_ring < 1 || c->query_ring < 1) return SIM_EINVAL;
   if (c->pkt_records && (c->pkt_records % SIM_P || c->pkt_records > SIM_PKT_RECORDS_MAX)) return SIM_EINVAL;
   if (c->retransmit_mult * h_digits10(c->n_nodes) > 63u) return SIM_EINVAL;
@@ -2993,6 +3075,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   d.loss_u32 = cfg->loss_u32;
   d.aw_probe = (cfg->flags & SIM_CF_AWARENESS_PROBE) ? 1u : 0u;
   d.gttd = cfg->gossip_to_the_dead;
+  d.rfan = (cfg->flags & SIM_CF_RANDOM_FANOUT) ? 1u : 0u;
   h->qt_cursor = 0;
   h->q_timeout = 16u * h_digits10(cfg->n_nodes);  // query.rs:421-427, query_timeout_mult = 16 (options.rs:518)
   h->pp_step = 0;
@@ -3020,7 +3103,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   DA(d.view, (size_t)d.A * Nl * 2)
   DA(d.ering, (size_t)d.Bev * Nl * 2)
   DA(d.qring, (size_t)d.Bq * Nl * 2)
-  DA(d.slot_of, d.N) DA(d.subject_of, d.A) DA(d.walk, d.A) DA(d.upmap, nup) DA(d.nullcell, 4) DA(d.skipmask, d.gttd ? Nl : 1) DA(h->sreq_buf[0], 1 + 2 * SIM_SUSPECT_REQ_MAX) DA(h->sreq_buf[1], 1 + 2 * SIM_SUSPECT_REQ_MAX) DA(h->sreq_buf[2], 1 + 2 * SIM_SUSPECT_REQ_MAX)
+  DA(d.slot_of, d.N) DA(d.subject_of, d.A) DA(d.walk, d.A) DA(d.upmap, nup) DA(d.nullcell, 4) DA(d.skipmask, (d.gttd || d.rfan) ? Nl : 1) DA(h->sreq_buf[0], 1 + 2 * SIM_SUSPECT_REQ_MAX) DA(h->sreq_buf[1], 1 + 2 * SIM_SUSPECT_REQ_MAX) DA(h->sreq_buf[2], 1 + 2 * SIM_SUSPECT_REQ_MAX)
   DA(d.qtab, QTAB_U4(d.N)) DA(d.qbits, (size_t)SIM_QT * 2 * nup)
   DA(d.events, (size_t)EV_CAP) DA(d.ev_count, 1)
   DA(h->d_base, (size_t)d.N * 2)
@@ -3028,6 +3111,21 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   DA(h->d_mst, d.N)
   DA(h->d_mlt, d.N)
   DA(h->d_stats, 1)
+  d.rcsr[0] = d.rcsr[1] = d.rsrc[0] = d.rsrc[1] = nullptr;
+  h->rf_keys = h->rf_vals = h->rf_keys_sorted = nullptr;
+  h->rf_tmp = nullptr; h->rf_tmp_bytes = 0; h->rf_bits = 32;
+  if (d.rfan) {  // the fan-out graph as a CSR, rebuilt every tick (SIM_CF_RANDOM_FANOUT)
+    const size_t np = (size_t)d.f * Nl;
+    DA(d.rcsr[0], Nl + 1) DA(d.rcsr[1], Nl + 1) DA(d.rsrc[0], np) DA(d.rsrc[1], np)
+    DA(h->rf_keys, np) DA(h->rf_vals, np) DA(h->rf_keys_sorted, np)
+    h->rf_bits = 1;
+    while ((1ull << h->rf_bits) <= (u64)d.N) h->rf_bits++;  // keys are node ids, and N for "no target"
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, h->rf_tmp_bytes, h->rf_keys, h->rf_keys_sorted, h->rf_vals, d.rsrc[0], (int)np, 0, h->rf_bits, h->stream) != hipSuccess) { sim_destroy(h); return SIM_EDEVICE; }
+    uint8_t* tmp = nullptr;
+    DA(tmp, h->rf_tmp_bytes + 16)
+    h->rf_tmp = tmp;
+    if (hipMemset(d.rcsr[0], 0, (Nl + 1) * 4) != hipSuccess || hipMemset(d.rcsr[1], 0, (Nl + 1) * 4) != hipSuccess) { sim_destroy(h); return SIM_EDEVICE; }
+  }
 #undef DA
   bool joined = cfg->flags & SIM_CF_BASELINE_JOINED;
   hipStream_t s = h->stream;
@@ -3627,7 +3725,18 @@ int sim_step_begin(sim_handle* h) {
   // (hipExtLaunchKernelGGL: start / stop = the kernel's own begin and end, no barrier packets in the stream — two
   // hipEventRecord calls around every launch cost 10 us of stream time each tick).  Several chunk launches per tick
   // (sharded, C > 1): the pair brackets them with hipEventRecord.
-  if (d.gttd) gossip_skip_kernel<<<grid_for(d.Nl), BLOCK, 0, h->stream>>>(d, tp, h->d_base);  // whom not to gossip to this tick
+  if (d.gttd && !d.rfan) gossip_skip_kernel<<<grid_for(d.Nl), BLOCK, 0, h->stream>>>(d, tp, h->d_base);  // whom not to gossip to this tick
+  if (d.rfan) {
+    // kRandomNodes: this tick's targets are drawn now (and with them whom not to gossip to), and the packets' CSR — who
+    // receives what at tick + 1 — is sorted out of them while the tick runs: pairs in (sender, slot) order, a stable radix
+    // sort by target keeps that order inside a receiver's row
+    const u32 w = (u32)((h->tick + 1) & 1);
+    const int np = (int)((size_t)d.f * d.Nl);
+    rfan_draw_kernel<<<grid_for(d.Nl), BLOCK, 0, h->stream>>>(d, tp, h->d_base, rng_base(h->cfg.seed, STREAM_RFAN, h->tick), h->rf_keys, h->rf_vals);
+    size_t tb = h->rf_tmp_bytes;
+    HCHECK(hipcub::DeviceRadixSort::SortPairs(h->rf_tmp, tb, h->rf_keys, h->rf_keys_sorted, h->rf_vals, d.rsrc[w], np, 0, h->rf_bits, h->stream));
+    rfan_csr_kernel<<<grid_for(d.Nl + 1), BLOCK, 0, h->stream>>>(h->rf_keys_sorted, (u32)np, d.Nl, d.rcsr[w]);
+  }
   h->tick_timed = h->profiling && (h->prof_seq++ % h->profiling) == 0;
   h->tick_bracket = h->tick_timed && d.sharded && tp.C > 1;
   if (h->tick_bracket) {
@@ -3669,7 +3778,15 @@ static int tick_launch(sim_handle* h, u32 chunk) {
     else tick_kernel<SH, FF, BB, PP><<<grid, TBLOCK, 0, h->stream>>>(d, tp, ptp, cur, h->d_base, chunk, cnt);            \
   } while (0)
 #define LAUNCH_TICK(SH, FF, BB) do { if (d.PG > 1u) LAUNCH_TICK_(SH, FF, BB, true); else LAUNCH_TICK_(SH, FF, BB, false); } while (0)
-#define LAUNCH_LOCAL(FF) do { if (tp.B == 64u) LAUNCH_TICK(false, FF, true); else LAUNCH_TICK(false, FF, false); } while (0)
+#define LAUNCH_LOCAL(FF)                                                                                                 \
+  do {                                                                                                                   \
+    if (d.rfan) {                                                                                                        \
+      if (e1) hipExtLaunchKernelGGL((tick_kernel<false, FF, false, false, true>), dim3(grid), dim3(TBLOCK), 0, h->stream, e0, e1, 0, d, tp, ptp, \
+                                    cur, (const uint4*)h->d_base, chunk, cnt);                                           \
+      else tick_kernel<false, FF, false, false, true><<<grid, TBLOCK, 0, h->stream>>>(d, tp, ptp, cur, h->d_base, chunk, cnt); \
+    } else if (tp.B == 64u) LAUNCH_TICK(false, FF, true);                                                                \
+    else LAUNCH_TICK(false, FF, false);                                                                                  \
+  } while (0)
   switch (tp.feff + (d.sharded ? 4u : 0u)) {  // one instantiation per fan-out: the drain loop is fully unrolled
     case 0: case 1: LAUNCH_LOCAL(1); break;
     case 2: LAUNCH_LOCAL(2); break;
@@ -4094,6 +4211,7 @@ int sim_snapshot(sim_handle* h, void* buf, size_t cap, size_t* bytes) {
   if (!h || !bytes) return SIM_EINVAL;
   if (h->in_tick) return SIM_ESTATE;  // between sim_step_begin and sim_step_end the state is half a tick ahead of `tick`
   Dev& d = h->d;
+  if (d.rfan) return SIM_ESTATE;  // (the image has no section for the targets of the packets in flight: random fan-out runs are not checkpointed)
   if (d.swim && !d.sharded) {  // slot-less failed probes not yet replayed: into the schedule, so that the image holds them
     std::vector<u32> rq(2 * SIM_SUSPECT_REQ_MAX);
     for (u64 back = 2; back >= 1; --back) {
@@ -4143,7 +4261,7 @@ int sim_snapshot(sim_handle* h, void* buf, size_t cap, size_t* bytes) {
 }
 int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
   if (!h || !buf || bytes < sizeof(snap_header)) return SIM_EINVAL;
-  if (h->tick != 0 || !h->ops.empty()) return SIM_ESTATE;
+  if (h->tick != 0 || !h->ops.empty() || h->d.rfan) return SIM_ESTATE;
   Dev& d = h->d;
   snap_header hd;
   memcpy(&hd, buf, sizeof hd);

@@ -2,7 +2,8 @@
 """Error bar on the fan-out model: rounds-to-99 % of the same rumours under the simulator's
 per-tick bijection (every node receives exactly `fanout` packets per round) and under memberlist's literal
 kRandomNodes (uniform targets without replacement, skip self — SURVEY.md App. B.2; in-degree Poisson-like),
-both on the CPU oracle (the random mode exists only there: SIM_CF_RANDOM_FANOUT), serf layer alone, with packet loss.
+both on the CPU oracle (round 2: the random mode existed only there; since round 3 the HIP library has SIM_CF_RANDOM_FANOUT
+too — `bench.py --random-fanout`), serf layer alone, with packet loss.
 
     python -m tests.fanout_model_hist --nodes 65536 --rumors 1000 --out profiles/r02_fanout_model_64k.json
 

@@ -114,6 +114,39 @@ def test_random_configurations(oracle, hiplib, seed):
     assert g.cluster_stats()["ops_dropped"] == o.cluster_stats()["ops_dropped"]
 
 
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_fanout_kRandomNodes(oracle, hiplib, seed):
+    # SIM_CF_RANDOM_FANOUT: memberlist's literal kRandomNodes (App. B.2) — uniform targets, no replacement, variable in-degree —
+    # in the PRODUCT: the tick's fan-out graph is an explicit CSR (a stable radix sort of (target, sender, slot) per tick) and the
+    # deliver loop walks a node's row of it.  Seeded sweep: tiny clusters (fewer other nodes than the fan-out: slots without a
+    # target), ragged and block-sized ones, dense and slotted views, SWIM / loss / gossip_to_the_dead / push-pull / reaper /
+    # recycling / Reconnector on or off; digests after every tick, every array at the end.
+    rng = np.random.default_rng(9000 + seed)
+    n = int([2, 3, 5, 96, 200, 1000, 2048, 4096][seed % 8])
+    dense = n <= 600 and rng.random() < 0.5
+    swim = int(rng.choice([0, 2, 3]))
+    kw = dict(fanout=int(rng.integers(1, 5)), view_slots=0 if dense else int(rng.choice([16, 48])),
+              event_ring=int(rng.choice([8, 12, 16])), query_ring=int(rng.choice([8, 10])), leave_delay=int(rng.integers(3, 9)),
+              loss=float(rng.choice([0.0, 0.02, 0.1])), probe_interval=swim, reap_interval=int(rng.choice([0, 5])) if swim else 0,
+              reconnect_timeout=20, tombstone_timeout=30, intent_timeout=15, queue_check_interval=int(rng.choice([0, 7])),
+              push_pull_interval=int(rng.choice([0, 4])), recycle_interval=int(rng.choice([0, 6])) if not dense else 0,
+              gossip_to_the_dead=int(rng.choice([0, 2, 8])) if swim else 0, reconnect_interval=int(rng.choice([0, 3])) if swim else 0,
+              join_sync=bool(rng.random() < 0.5), flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT)
+    g, o = pair(oracle, hiplib, n, **kw)
+    ops = sc.schedule(n, 40, rate=float(rng.choice([0.3, 1.0, 2.5])), seed=seed, max_member_subjects=max(1, min(n // 2, 12 if not dense else 30)))
+    sc.apply_schedule(g, ops)
+    sc.apply_schedule(o, ops)
+    for t in range(64):
+        g.step(1)
+        o.step(1)
+        if g.digest() != o.digest():
+            sc.assert_same_state(g, o, f"seed {seed} n={n} {kw} tick {t}")
+            raise AssertionError(f"digest differs after tick {t} but the arrays agree")
+    sc.assert_same_state(g, o, f"seed {seed} final")
+    with pytest.raises(_ffi.SimError):
+        g.snapshot()   # random fan-out runs are not checkpointed (the image has no section for the packets' targets)
+
+
 @pytest.mark.parametrize("seed", list(range(24)))
 def test_random_configurations_paged_packets(oracle, hiplib, seed):
     # the same sweep with packets of 8, 12 and 16 records (sim_config.pkt_records: pages of 4 records)
