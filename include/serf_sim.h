@@ -296,6 +296,16 @@ typedef struct sim_config {
                                    * The re-broadcasts a real merge would queue tell the cluster nothing it does not have
                                    * and are not modelled.  Without it a re-joining node keeps the view it went down with
                                    * until a push-pull batch reaches it (DESIGN.md SIMSPEC §2.8)                        */
+#define SIM_CF_TCP_FALLBACK 16u     /* memberlist probeNode's fallback (state.go; `disable_tcp_pings` = false is memberlist's default):
+                                   * next to the indirect pings the prober pings the target over TCP, and a probe whose UDP legs
+                                   * were all lost still SUCCEEDS when that stream ping gets through — reliable in this model, so
+                                   * with the flag a probe fails only when the target's process is down: packet loss produces no
+                                   * false suspicions (at 1 Mi nodes and 1 % loss they were 0.26 per tick, each a suspicion and a
+                                   * refutation for everybody to carry)                                                          */
+#define SIM_CF_NACKS 32u           /* memberlist's nack accounting (protocol >= 4): a probe that fails raises the prober's health
+                                   * score by the number of relays that were asked and did NOT answer with a nack (relay down,
+                                   * or the request / the nack lost) instead of by one — a prober whose own network is fine
+                                   * does not degrade itself for a peer that is really dead; no relay asked: + 1 as before     */
 #define SIM_DEFAULT_SEED 0x5EEDC0DE5E4F0001ull
 
 /* Stats — mirrors serf-core/src/serf/api.rs:586-602 (`Stats`) for one simulated node. */

@@ -948,9 +948,21 @@ static void swim_probe(nctx* c, const tickp* p) {
       ok = !leg_lost(p, c->gid, PD_RELAY0 + 5 * j + 1) && !leg_lost(p, c->gid, PD_RELAY0 + 5 * j + 2) &&
            !leg_lost(p, c->gid, PD_RELAY0 + 5 * j + 3) && !leg_lost(p, c->gid, PD_RELAY0 + 5 * j + 4);
     }
+    /* SIM_CF_TCP_FALLBACK (memberlist probeNode, UPSTREAM-RECALL state.go: the fallback ping over the stream transport runs
+     * next to the indirect pings; "didContact" => the probe returns without suspecting, awareness delta - 1) */
+    if (!ok && (s->cfg.flags & SIM_CF_TCP_FALLBACK)) ok = 1;
   }
   if (ok) { aw_delta(c->row, -1); return; }
-  aw_delta(c->row, +1);
+  if (s->cfg.flags & SIM_CF_NACKS) { /* awarenessDelta = expectedNacks - nacks received (no relay asked: + 1) */
+    int expected = 0, nacks = 0;
+    for (uint32_t j = 0; j < s->cfg.indirect_checks && j < 4; ++j) {
+      uint32_t r = draw_below(probe_draw(p, c->gid, PD_RELAY0 + 5 * j), s->N);
+      if (r == c->gid || r == t) continue; /* kRandomNodes does not pick these */
+      ++expected;
+      if (up_of(s, r) && !leg_lost(p, c->gid, PD_RELAY0 + 5 * j + 1) && !leg_lost(p, c->gid, PD_RELAY0 + 5 * j + 4)) ++nacks;
+    }
+    aw_delta(c->row, expected ? expected - nacks : 1);
+  } else aw_delta(c->row, +1);
   if (!e) { /* no view slot to hold the suspicion yet: taken up next tick, once the target has one (SIM_OP_SUSPECT) */
     uint32_t i = __atomic_fetch_add(&s->sreq_n, 1u, __ATOMIC_RELAXED);
     if (i < SIM_SUSPECT_REQ_MAX) { s->sreq[2 * i] = c->gid; s->sreq[2 * i + 1] = t; }

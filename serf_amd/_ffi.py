@@ -34,7 +34,7 @@ QF_IDS, TAG_CLASSES, NO_TAG_FILTER = 12, 32, 0xFFFFFFFF
 ARR_ROWS, ARR_QUEUE, ARR_INBOX, ARR_VIEW, ARR_ERING, ARR_QRING, ARR_SLOTMAP = range(7)
 # enum sim_swim_state (memberlist node state)
 SWIM_ALIVE, SWIM_SUSPECT, SWIM_DEAD, SWIM_LEFT = 0, 1, 2, 3
-CF_BASELINE_JOINED, CF_RANDOM_FANOUT, CF_AWARENESS_PROBE, CF_JOIN_SYNC = 1, 2, 4, 8
+CF_BASELINE_JOINED, CF_RANDOM_FANOUT, CF_AWARENESS_PROBE, CF_JOIN_SYNC, CF_TCP_FALLBACK, CF_NACKS = 1, 2, 4, 8, 16, 32
 F_NO_BROADCAST, F_ACK, F_RESPOND = 1, 2, 4
 
 
@@ -111,7 +111,7 @@ def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, vi
                 suspicion_mult=4, suspicion_max_mult=6, indirect_checks=3, loss=0.0,
                 intent_timeout=0, leave_delay=30, reap_interval=0, reconnect_timeout=432000, tombstone_timeout=432000,
                 queue_check_interval=0, max_queue_depth=4096, min_queue_depth=0, push_pull_interval=0, chunks=0, recycle_interval=0,
-                pkt_records=0, gossip_to_the_dead=0, reconnect_interval=0, awareness_probe=False, join_sync=False, flags=CF_BASELINE_JOINED, seed=DEFAULT_SEED):
+                pkt_records=0, gossip_to_the_dead=0, reconnect_interval=0, tcp_fallback=False, nacks=False, awareness_probe=False, join_sync=False, flags=CF_BASELINE_JOINED, seed=DEFAULT_SEED):
     cfg = Config()
     cfg.struct_size = C.sizeof(Config)
     cfg.n_nodes, cfg.vshards, cfg.shard_rank, cfg.shard_count = n_nodes, vshards, shard_rank, shard_count
@@ -130,6 +130,10 @@ def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, vi
         cfg.flags |= CF_AWARENESS_PROBE
     if join_sync:
         cfg.flags |= CF_JOIN_SYNC
+    if tcp_fallback:
+        cfg.flags |= CF_TCP_FALLBACK   # memberlist's stream-transport fallback ping: packet loss alone never fails a probe
+    if nacks:
+        cfg.flags |= CF_NACKS          # awareness += relays that were asked and did not nack
     return cfg
 
 

@@ -311,6 +311,7 @@ struct Dev {
   u32 swim, PI, kconf, ic, T[SIM_MAX_CONF];
   u32 loss_u32;
   u32 aw_probe;  // SIM_CF_AWARENESS_PROBE
+  u32 tcp_fallback, nacks;  // SIM_CF_TCP_FALLBACK, SIM_CF_NACKS
   u32 gttd;      // gossip_to_the_dead in ticks (0 = off)
   u32 r3on;  // R3 is live: SWIM layer or Reaper configured
   u32 reap_interval, reconnect_timeout, tombstone_timeout, intent_timeout;
@@ -1095,8 +1096,18 @@ __device__ static void swim_probe(const Ctx& c, Node& n, const TickP& tp, const 
            !leg_lost(tp, c.gid, PD_RELAY0 + 5 * j + 3) && !leg_lost(tp, c.gid, PD_RELAY0 + 5 * j + 4);
     }
   }
+  if (!ok && d.tcp_fallback && up_of(d, t)) ok = true;  // SIM_CF_TCP_FALLBACK: the stream ping next to the indirect ones gets through
   if (ok) { aw_delta(n, -1); return; }
-  aw_delta(n, +1);
+  if (d.nacks) {  // SIM_CF_NACKS: the score rises by the relays that were asked and did not nack (none asked: + 1)
+    int expected = 0, nk = 0;
+    for (u32 j = 0; j < d.ic && j < 4; ++j) {
+      u32 r = draw_below(probe_draw(tp, c.gid, PD_RELAY0 + 5 * j), d.N);
+      if (r == c.gid || r == t) continue;
+      ++expected;
+      if (up_of(d, r) && !leg_lost(tp, c.gid, PD_RELAY0 + 5 * j + 1) && !leg_lost(tp, c.gid, PD_RELAY0 + 5 * j + 4)) ++nk;
+    }
+    aw_delta(n, expected ? expected - nk : 1);
+  } else aw_delta(n, +1);
   if (!p) {  // no view slot to hold the suspicion yet: taken up next tick, once the target has one (SIM_OP_SUSPECT)
 #ifndef TICK_LEAN
     u32 i = atomicAdd(d.sreq, 1u);
@@ -3074,6 +3085,8 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   d.r3on = d.swim || d.reap_interval;
   d.loss_u32 = cfg->loss_u32;
   d.aw_probe = (cfg->flags & SIM_CF_AWARENESS_PROBE) ? 1u : 0u;
+  d.tcp_fallback = (cfg->flags & SIM_CF_TCP_FALLBACK) ? 1u : 0u;
+  d.nacks = (cfg->flags & SIM_CF_NACKS) ? 1u : 0u;
   d.gttd = cfg->gossip_to_the_dead;
   d.rfan = (cfg->flags & SIM_CF_RANDOM_FANOUT) ? 1u : 0u;
   h->qt_cursor = 0;

@@ -554,3 +554,42 @@ def test_join_sync_gives_a_rejoining_node_a_current_view(oracle):
         st, _ = sim.members(200)
         assert st[10] == _ffi.STATUS_ALIVE, "and the cluster has it back"
     assert res[False][:2] == (_ffi.STATUS_ALIVE, _ffi.STATUS_ALIVE), "without the sync the joiner still has its old view"
+
+
+def test_tcp_fallback_ping_leaves_no_false_suspicions(oracle):
+    """SIM_CF_TCP_FALLBACK — memberlist probeNode's stream-transport fallback (UPSTREAM-RECALL state.go; on by default in
+    memberlist): a probe whose UDP legs were all lost still succeeds when the TCP ping gets through.  Under 10 % loss without
+    it live nodes are suspected and refute all the time; with it nobody is suspected who is up — and a node that really
+    crashed is declared failed all the same."""
+    n = 1024
+    kw = dict(fanout=3, view_slots=64, event_ring=16, query_ring=8, probe_interval=2, suspicion_mult=4, suspicion_max_mult=2, loss=0.10)
+    res = {}
+    for fb in (False, True):
+        sim = _ffi.Sim(oracle, _ffi.make_config(n, tcp_fallback=fb, **kw))
+        sim.inject(5, _ffi.OP_CRASH, 77)
+        sim.step(120)
+        rows = sim.dump(_ffi.ARR_ROWS)
+        st, _ = sim.members(3)
+        res[fb] = (int(rows["inc"].sum()), int(st[77]), int(rows["awareness"].max()))
+    assert res[False][0] > 20, res                       # refutations of false suspicions
+    assert res[True][0] == 0, res                        # none with the fallback
+    assert res[True][1] == _ffi.STATUS_FAILED and res[False][1] == _ffi.STATUS_FAILED, res
+
+
+def test_nacks_keep_a_healthy_prober_healthy(oracle):
+    """SIM_CF_NACKS — memberlist's nack accounting (UPSTREAM-RECALL state.go: awarenessDelta = expectedNacks - nackCount): a
+    probe that fails on a node that is really dead costs the prober one point per relay that did NOT answer; with every
+    relay up and no loss that is nothing, where the plain rule charges one point per failed probe."""
+    n, PI = 1024, 2
+    kw = dict(fanout=3, view_slots=32, event_ring=16, query_ring=8, probe_interval=PI, suspicion_mult=6, suspicion_max_mult=3)
+    score = {}
+    for nk in (False, True):
+        sim = _ffi.Sim(oracle, _ffi.make_config(n, nacks=nk, **kw))
+        for x in range(100, 1000, 45):
+            sim.inject(2, _ffi.OP_CRASH, x)
+        tot = 0
+        for _ in range(30):
+            sim.step(1)
+            tot += int(sim.dump(_ffi.ARR_ROWS)["awareness"].astype(np.int64).sum())
+        score[nk] = tot
+    assert score[False] > 50 and score[True] * 10 < score[False], score   # (a relay that is itself one of the dead nodes: no nack)

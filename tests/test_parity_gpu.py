@@ -96,6 +96,7 @@ def test_random_configurations(oracle, hiplib, seed):
     kw.update(awareness_probe=bool(swim and rng.random() < 0.5), gossip_to_the_dead=int(rng.choice([0, 0, 2, 8])) if swim else 0,
               join_sync=bool(rng.random() < 0.5))
     kw.update(reconnect_interval=int(rng.choice([0, 0, 3, 7])) if swim else 0)  # Reconnector (drawn after everything else)
+    kw.update(tcp_fallback=bool(swim and rng.random() < 0.4), nacks=bool(swim and rng.random() < 0.4))  # memberlist's fallback ping / nack accounting
     try:
         g, o = pair(oracle, hiplib, n, **kw)
     except _ffi.SimError:
@@ -132,6 +133,7 @@ def test_random_fanout_kRandomNodes(oracle, hiplib, seed):
               push_pull_interval=int(rng.choice([0, 4])), recycle_interval=int(rng.choice([0, 6])) if not dense else 0,
               gossip_to_the_dead=int(rng.choice([0, 2, 8])) if swim else 0, reconnect_interval=int(rng.choice([0, 3])) if swim else 0,
               join_sync=bool(rng.random() < 0.5), flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT)
+    kw.update(tcp_fallback=bool(swim and rng.random() < 0.4), nacks=bool(swim and rng.random() < 0.4))
     g, o = pair(oracle, hiplib, n, **kw)
     ops = sc.schedule(n, 40, rate=float(rng.choice([0.3, 1.0, 2.5])), seed=seed, max_member_subjects=max(1, min(n // 2, 12 if not dense else 30)))
     sc.apply_schedule(g, ops)
@@ -172,6 +174,7 @@ def test_random_configurations_paged_packets(oracle, hiplib, seed):
     kw.update(awareness_probe=bool(swim and rng.random() < 0.5), gossip_to_the_dead=int(rng.choice([0, 0, 2, 8])) if swim else 0,
               join_sync=bool(rng.random() < 0.5))
     kw.update(reconnect_interval=int(rng.choice([0, 0, 3, 7])) if swim else 0)  # Reconnector (drawn after everything else)
+    kw.update(tcp_fallback=bool(swim and rng.random() < 0.4), nacks=bool(swim and rng.random() < 0.4))  # memberlist's fallback ping / nack accounting
     try:
         g, o = pair(oracle, hiplib, n, **kw)
     except _ffi.SimError:

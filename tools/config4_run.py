@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--recycle-interval", type=int, default=75)
     ap.add_argument("--pkt-records", type=int, default=4)
     ap.add_argument("--max-rounds", type=int, default=60)
+    ap.add_argument("--tcp-fallback", action="store_true", help="memberlist's stream-transport fallback ping (its default): packet loss alone never fails a probe")
+    ap.add_argument("--nacks", action="store_true", help="memberlist's nack accounting for the health score")
     ap.add_argument("--reconnect-interval", type=int, default=0, help="Reconnector period in ticks (reference: 30 s = 150; 0 = off)")
     ap.add_argument("--gossip-to-the-dead", type=int, default=0, help="memberlist gossip_to_the_dead_time in ticks (lan: 30 s = 150; 0 = off)")
     ap.add_argument("--lib", default=None, help="oracle: run the CPU oracle instead (small sizes; for checking the tool)")
@@ -57,6 +59,7 @@ def main():
               probe_interval=args.probe_interval, push_pull_interval=args.push_pull_interval, loss=args.loss,
               reap_interval=75, queue_check_interval=150, recycle_interval=args.recycle_interval, pkt_records=args.pkt_records,
               reconnect_interval=args.reconnect_interval, gossip_to_the_dead=args.gossip_to_the_dead,
+              tcp_fallback=args.tcp_fallback, nacks=args.nacks,
               join_sync=True)   # Serf::join = memberlist.join: the re-joining node syncs with a peer (SIM_CF_JOIN_SYNC)
     sim = _ffi.Sim(lib, _ffi.make_config(n, **kw))
     rng = np.random.default_rng(5)
