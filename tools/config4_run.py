@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--recycle-interval", type=int, default=75)
     ap.add_argument("--pkt-records", type=int, default=4)
     ap.add_argument("--max-rounds", type=int, default=60)
+    ap.add_argument("--random-fanout", action="store_true", help="gossip targets by memberlist's literal kRandomNodes (explicit per-tick CSR) instead of the bijection")
     ap.add_argument("--tcp-fallback", action="store_true", help="memberlist's stream-transport fallback ping (its default): packet loss alone never fails a probe")
     ap.add_argument("--nacks", action="store_true", help="memberlist's nack accounting for the health score")
     ap.add_argument("--reconnect-interval", type=int, default=0, help="Reconnector period in ticks (reference: 30 s = 150; 0 = off)")
@@ -60,6 +61,7 @@ def main():
               reap_interval=75, queue_check_interval=150, recycle_interval=args.recycle_interval, pkt_records=args.pkt_records,
               reconnect_interval=args.reconnect_interval, gossip_to_the_dead=args.gossip_to_the_dead,
               tcp_fallback=args.tcp_fallback, nacks=args.nacks,
+              **({"flags": _ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT} if args.random_fanout else {}),
               join_sync=True)   # Serf::join = memberlist.join: the re-joining node syncs with a peer (SIM_CF_JOIN_SYNC)
     sim = _ffi.Sim(lib, _ffi.make_config(n, **kw))
     rng = np.random.default_rng(5)

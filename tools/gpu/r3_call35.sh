@@ -6,5 +6,5 @@ OUT=$ROOT/gpurun_out/c35
 mkdir -p $OUT
 cd $ROOT
 V=serf_amd/csrc/variants
-timeout 600 python tools/ab.py --ticks 120 --rounds 3 $V/base.so serf_amd/csrc/libserf_sim.so > $OUT/ab.log 2>&1; echo "ab rc=$?"
+timeout 600 python tools/ab.py --ticks 120 --rounds 3 $V/prerf.so serf_amd/csrc/libserf_sim.so > $OUT/ab.log 2>&1; echo "ab rc=$?"
 grep -v amdgpu.ids $OUT/ab.log | tail -8
