@@ -2317,8 +2317,8 @@ int API(drain_events)(osim* s, sim_event* out, uint32_t cap, uint32_t* n) {
     }
   }
   uint32_t m = (uint32_t)(s->n_events < cap ? s->n_events : cap);
-  if (out) memcpy(out, s->events, m * sizeof(sim_event));
-  memmove(s->events, s->events + m, (s->n_events - m) * sizeof(sim_event));
+  if (out && m) memcpy(out, s->events, m * sizeof(sim_event));
+  if (m && s->n_events > m) memmove(s->events, s->events + m, (s->n_events - m) * sizeof(sim_event)); /* (nothing logged yet: the array is NULL) */
   s->n_events -= m;
   *n = m;
   return SIM_OK;
