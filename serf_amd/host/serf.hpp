@@ -132,7 +132,12 @@ class Serf {
   // api.rs:304 as the reference shapes it: the query goes out and the caller keeps the QueryResponse
   inline QueryResponse query_response(uint32_t query_id, uint32_t flags = 0) { query(query_id, flags); return QueryResponse(c_, query_id); }
   inline void join(uint32_t peer);                                            // api.rs:318
+  // api.rs:366-420: joins through the first of `peers` (memberlist.join_many contacts them in turn and a simulated peer
+  // always answers); returns how many were contacted
+  inline size_t join_many(const std::vector<uint32_t>& peers) { if (peers.empty()) return 0; join(peers.front()); return 1; }
   inline void leave();                                                        // api.rs:422
+  inline void shutdown();                                                     // api.rs:525: the process stops (tests/serf/event.rs:112 shuts a node down)
+  inline uint32_t state() const { return stats().serf_state; }                // api.rs:113 SerfState (serf.rs:80-89) as enum sim_serf_state
   inline void remove_failed_node(uint32_t id);                                // api.rs:505
   inline void remove_failed_node_prune(uint32_t id);                          // api.rs:513
   inline void subscribe();                                                    // EventSubscriber, event.rs:430-491
@@ -254,6 +259,7 @@ inline std::vector<Serf::NodeResponse> Serf::QueryResponse::responses() {
 }
 inline void Serf::join(uint32_t peer) { check(sim_join(c_->raw(), id_, peer), "sim_join"); }
 inline void Serf::leave() { check(sim_leave(c_->raw(), id_), "sim_leave"); }
+inline void Serf::shutdown() { check(sim_inject(c_->raw(), c_->tick(), SIM_OP_CRASH, id_, 0, 0), "sim_inject"); }
 inline void Serf::remove_failed_node(uint32_t id) { check(sim_force_leave(c_->raw(), id_, id, 0), "sim_force_leave"); }
 inline void Serf::remove_failed_node_prune(uint32_t id) { check(sim_force_leave(c_->raw(), id_, id, 1), "sim_force_leave"); }
 inline void Serf::subscribe() { check(sim_watch(c_->raw(), id_), "sim_watch"); }
