@@ -855,11 +855,13 @@ __device__ static bool handle_user_event(const Ctx& c, Node& n, u32 key, u64 lti
 // should_process_query (query.rs:439-521): every filter must match — the node's id is in the Filter::Id list, its tag
 // class is in the mask the host made of the Filter::Tag expressions (include/serf_sim.h).  Rare path: runs once per
 // (node, query), after the de-dup.
-__device__ static bool query_should_process(const Dev& d, u32 gid, u32 id) {
+// (`h` = the filter entry's first word group, `tcls` = the node's tag class, `t` in query_respond = the tracker entry: the
+// caller loads the three together — they do not depend on each other, and fetched one inside the other they were three of
+// the four dependent round trips of a first-seen query, with the whole wave waiting: profiles/r03_experiments.md)
+__device__ static bool query_should_process(const Dev& d, u32 gid, u32 id, const uint4& h, u32 tcls) {
   const uint4* f = QFILT(d) + (size_t)(id % SIM_QT) * (SIM_QF_WORDS / 4);
-  uint4 h = f[0];
   if (h.x != id) return true;  // no filters on record for this query
-  if (h.z != 0xFFFFFFFFu && !((h.z >> TAGCLASS(d)[gid]) & 1u)) return false;
+  if (h.z != 0xFFFFFFFFu && !((h.z >> tcls) & 1u)) return false;
   if (!h.y) return true;
   const u32* ids = reinterpret_cast<const u32*>(f + 1);
   for (u32 i = 0; i < h.y; ++i)
@@ -869,11 +871,10 @@ __device__ static bool query_should_process(const Dev& d, u32 gid, u32 id) {
 // Responder half of handle_query (base.rs:1075-1154) and origin half (base.rs:1158-1204,
 // query.rs:240-303) — see oracle query_respond: one bit per (running query, node) for acks, one for
 // responses; the counts are popcounts taken when somebody asks (no hot atomic counter).
-__device__ static void query_respond(const Ctx& c, u32 id, u32 flags) {
+__device__ static void query_respond(const Ctx& c, u32 id, u32 flags, const uint4& t) {
   const Dev& d = c.d;
   if (!(flags & (SIM_F_ACK | SIM_F_RESPOND))) return;
   u32 j = id % SIM_QT;
-  uint4 t = d.qtab[j];
   if (t.x != id) return;  // "reply for non-running query"
   if (c.tick > t.z || !((d.upmap[t.y >> 5] >> (t.y & 31)) & 1u)) return;
   u64 base = mix64(c.qbase ^ ((u64)id << 32));
@@ -913,8 +914,10 @@ __device__ static bool handle_query(const Ctx& c, Node& n, u32 id, u64 ltime, u3
   }
   dirty = true;
   // base.rs:1062-1073: a node the filters exclude still rebroadcasts what it sees for the first time
-  if (!query_should_process(c.d, c.gid, id)) return !(flags & SIM_F_NO_BROADCAST);
-  query_respond(c, id, flags);
+  const uint4 fh = ld4(QFILT(c.d) + (size_t)(id % SIM_QT) * (SIM_QF_WORDS / 4)), trk = ld4(&c.d.qtab[id % SIM_QT]);
+  const u32 tcls = TAGCLASS(c.d)[c.gid];
+  if (!query_should_process(c.d, c.gid, id, fh, tcls)) return !(flags & SIM_F_NO_BROADCAST);
+  query_respond(c, id, flags, trk);
   emit_event(c, n, SIM_EV_QUERY, id, ltime);
   return !(flags & SIM_F_NO_BROADCAST);
 }
@@ -929,15 +932,34 @@ __device__ static inline void aw_delta(Node& n, int dlt) {
 // plain 2-byte accesses)
 static_assert(SIM_S == 16u, "R4 is laid out as two uint4 per node");
 __device__ static inline uint16_t* susp_of(const Ctx& c) { return reinterpret_cast<uint16_t*>(&c.d.R4[2 * (size_t)c.l]); }
+__device__ static inline u32 pk_word(const uint4& v, u32 p) { return p == 0 ? v.x : p == 1 ? v.y : p == 2 ? v.z : v.w; }
+// (the sixteen entries are read as the two uint4 they are — one round trip — and looked at in registers; entry by entry
+// they were up to sixteen dependent 2-byte loads, with the whole wave waiting for each: the handlers that touch the timers
+// and the timer walk of the tick kernel run at a few active lanes)
+__device__ static inline void susp_load(const Ctx& c, uint4& a, uint4& b) {
+  const uint4* r4 = &c.d.R4[2 * (size_t)c.l];
+  a = ld4(r4); b = ld4(r4 + 1);
+}
+__device__ static inline u32 susp_get(const uint4& a, const uint4& b, u32 j) {  // entry j of the two words groups
+  u32 w = (j & 8u) ? pk_word(b, (j >> 1) & 3u) : pk_word(a, (j >> 1) & 3u);
+  return (j & 1u) ? (w >> 16) : (w & 0xFFFFu);
+}
 __device__ static inline void susp_forget(const Ctx& c, u32 slot) {
   uint16_t* sp = susp_of(c);
+  uint4 a, b;
+  susp_load(c, a, b);
+#pragma unroll
   for (u32 j = 0; j < SIM_S; ++j)
-    if (sp[j] == slot + 1) sp[j] = 0;
+    if (susp_get(a, b, j) == slot + 1) sp[j] = 0;
 }
 __device__ static inline void susp_track(const Ctx& c, Node& n, u32 slot, u32 deadline) {
   uint16_t* sp = susp_of(c);
-  u32 j = 0;
-  while (j < SIM_S && sp[j]) ++j;
+  uint4 a, b;
+  susp_load(c, a, b);
+  u32 j = SIM_S;
+#pragma unroll
+  for (int i = (int)SIM_S - 1; i >= 0; --i)
+    if (!susp_get(a, b, (u32)i)) j = (u32)i;  // the first free entry
   if (j == SIM_S) { n.overflow++; n.dirty |= DR2; return; }  // model bound: the timer is not tracked
   sp[j] = (uint16_t)(slot + 1);
   if (!n.susp_next || deadline < n.susp_next) { n.susp_next = deadline; n.dirty |= DR3; }
@@ -1042,11 +1064,10 @@ __device__ static void swim_dead(const Ctx& c, Node& n, u32 subject, u32 inc, u3
 }
 // suspicion timers (B.5): fire -> deadNode(inc, from = self).  One call examines timer j;
 // `next` accumulates the earliest deadline still pending.
-__device__ static void swim_timer_j(const Ctx& c, Node& n, u32 j, u32& next, Ins& ins) {
+__device__ static void swim_timer_j(const Ctx& c, Node& n, u32 j, u32 a /* entry j of the node's timer list as the walk began */, u32& next, Ins& ins) {
   const Dev& d = c.d;
   u32 now = c.tick;
   uint16_t* sp = susp_of(c);
-  u32 a = sp[j];
   if (!a) return;
   uint4* p = view_slot_ptr(c, a - 1);
   uint4 e = p[0];
@@ -1324,7 +1345,6 @@ __device__ static inline void wire_pack(const uint4& r, u32& key, u32& lo, u32& 
   lo = two ? ((r.z & 0xFFFFFFu) | (r.w << 24)) : r.z;
   hm = ((two ? (r.w >> 8) : r.w) << 16) | (((r.y >> 18) & 0x3Fu) << 8) | (r.y & 0xFFu);
 }
-__device__ static inline u32 pk_word(const uint4& v, u32 p) { return p == 0 ? v.x : p == 1 ? v.y : p == 2 ? v.z : v.w; }
 // (B64: local mode with 64-node blocks — the sharded instantiations read tp.B at run time and pass false)
 // (MP: packets of more than one page, sim_config.pkt_records > SIM_P: the deliver loop walks the pages of a packet, the
 //  drain takes up to d.P entries per packet; with MP = false all of that folds back to the one-page kernel)
@@ -1626,11 +1646,15 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
       bool probing = d.N >= 2 && ((u32)tp.tick + (gid >> 6)) % d.PI == 0;
       if (__any(due || probing)) {
         u32 next = 0;
+        // the timer list, read once (one round trip instead of one per entry).  Nothing in the walk changes another entry than
+        // the one it is looking at: a timer that fires forgets its own slot (swim_dead -> susp_forget), nothing starts one
+        uint4 ta = make_uint4(0, 0, 0, 0), tb = ta;
+        if (due) susp_load(c, ta, tb);
 #pragma unroll 1
         for (u32 j = 0; j <= SIM_S; ++j) {
           Ins ins;
           ins.has = ins.wide = 0;
-          if (j < SIM_S) { if (due) swim_timer_j(c, n, j, next, ins); }
+          if (j < SIM_S) { if (due) swim_timer_j(c, n, j, susp_get(ta, tb, j), next, ins); }
           else {
             if (due) { n.susp_next = next; n.dirty |= DR3; }
             if (probing) swim_probe(c, n, tp, base, ins);
