@@ -29,7 +29,7 @@ extern "C" {
 
 /* ------------------------------------------------------------------ constants */
 
-#define SIM_ABI_VERSION 10u
+#define SIM_ABI_VERSION 11u
 
 #define SIM_P 4u  /* piggyback records per packet PAGE (48-byte cell: 4 records x 12 wire bytes) */
 #define SIM_PKT_BYTES 1400u /* byte budget of a gossip packet: memberlist's UDP payload limit (lan() and wan()); a packet
@@ -278,14 +278,20 @@ typedef struct sim_config {
 } sim_config;
 
 #define SIM_CF_BASELINE_JOINED 1u /* all nodes known+Alive at status_time 1, clock 2 (config 2-5) */
-#define SIM_CF_RANDOM_FANOUT 2u   /* gossip targets are memberlist's literal kRandomNodes (uniform, no replacement, skip self —
-                                   * App. B.2) instead of the per-tick bijection; in-degree is then Poisson-like and a node's
-                                   * packets are handed over in (sender, slot) order.  One shard, one chunk, packets of one
-                                   * page (SIM_EINVAL otherwise); no checkpoints (sim_snapshot / sim_restore: SIM_ESTATE).
-                                   * (r3) Oracle AND product: the HIP library draws the targets ahead of the tick, builds
-                                   * the tick's fan-out graph as an explicit CSR with a stable radix sort, and the deliver
-                                   * loop walks a node's row of it — about half the headline's rate at 1 Mi nodes; the
-                                   * fidelity mode next to the bijection the benchmark runs on */
+#define SIM_CF_RANDOM_FANOUT 2u   /* gossip targets are memberlist's literal kRandomNodes (uniform over the other nodes, no
+                                   * replacement, skip self — App. B.2) instead of the per-tick bijection; in-degree is then
+                                   * Poisson-like and a node's packets are handed over in (sender, slot) order.  One shard, one
+                                   * chunk (SIM_EINVAL otherwise); packets of 1 - 4 pages; checkpoints like every other run
+                                   * (the targets of the packets in flight are a function of (seed, tick, sender): drawn again
+                                   * on restore).  Canonical form of the packets in flight in this mode (SIM_ARR_INBOX, digests,
+                                   * images): inbox[k * PG + pg][SENDER].
+                                   * (r4) The HIP library builds the tick's fan-out graph ahead of the tick with its own
+                                   * two-level bucket sort (LDS histograms; rows ranked by sender inside a bucket), every sender
+                                   * PUSHES its packets to their positions in the receivers' CSR rows, and the deliver loop
+                                   * reads one contiguous run of cells per node */
+/* random fan-out only: broadcast requests one node can park in ONE tick beyond f * pkt_records + SIM_S + 1 (the bijection's
+ * maximum; with a random in-degree there is none).  A counted model bound, the same in the oracle. */
+#define SIM_RF_PEND_EXTRA 32u
 #define SIM_CF_AWARENESS_PROBE 4u  /* memberlist scales its probe interval by the node's health score (awareness, state.go
                                    * probeNode: ScaleTimeout): a node with score s probes in every (s + 1)-th round of its
                                    * group's probe phase instead of every round (App. B.3)                              */

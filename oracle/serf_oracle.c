@@ -366,6 +366,10 @@ typedef struct nctx {
   sim_row* row;
   sim_record* q; /* this node's Q queue slots, sorted by meta */
   int mute;      /* push-pull merge: handlers run but nothing is queued (delegate.rs:427-554) */
+  /* SIM_CF_RANDOM_FANOUT: broadcasts the handlers of ONE tick may request (the HIP library parks them in a per-node array of
+   * that many rows before it queues them; with the bijection f packets can ask for at most f * P + SIM_S + 1, with a random
+   * in-degree there is no such maximum: a counted model bound, SIM_RF_PEND_EXTRA requests beyond that figure) */
+  uint32_t npend, pend_cap; /* pend_cap == 0: no bound */
 } nctx;
 
 static inline sim_view* view_at(osim* s, uint32_t l, uint32_t subject) {
@@ -438,6 +442,7 @@ static void queue_renorm(sim_row* row, sim_record* q) {
 static void q_push(nctx* c, uint32_t key, uint32_t wmeta, uint64_t val) {
   if (c->mute) return;
   sim_row* row = c->row;
+  if (c->pend_cap && c->npend++ >= c->pend_cap) { row->overflow++; return; } /* model bound (random fan-out only), see nctx */
   sim_record* q = c->q;
   uint32_t kind = SIM_META_KIND(wmeta), cls = kind_class(kind);
   uint32_t seq = row->next_seq++;
@@ -1087,6 +1092,7 @@ static void nctx_init(nctx* c, osim* s, uint32_t l) {
   c->row = &s->rows[l];
   c->q = &s->queue[(size_t)l * SIM_Q];
   c->mute = 0;
+  c->npend = c->pend_cap = 0;
 }
 static int has_alive_members(const osim* s) { return s->N > 1; } /* base.rs:346-359, bulk form */
 
@@ -1401,9 +1407,23 @@ static int gossip_skips(osim* s, uint32_t l, uint32_t target) {
   if (sw != SIM_SWIM_DEAD && sw != SIM_SWIM_LEFT) return 0;
   return (((uint32_t)s->tick - SIM_VB_STAMP(e->bits)) & STAMP_MASK) > G;
 }
+/* SIM_CF_RANDOM_FANOUT — kRandomNodes (App. B.2): uniform draws over all N nodes, skip self and duplicates, up to 3 N tries;
+ * a function of (seed, tick, node) alone.  Returns how many of the `feff` slots found a target. */
+static uint32_t rf_draw(const osim* s, uint64_t tick, uint32_t gid, uint32_t feff, uint32_t chosen[SIM_MAX_FANOUT]) {
+  uint64_t rb = rng_base(s->cfg.seed, STREAM_RFAN, tick);
+  uint32_t nc = 0;
+  for (uint32_t i = 0; i < 3u * s->N && nc < feff; ++i) {
+    uint32_t t = (uint32_t)(((mix64(rb ^ ((uint64_t)gid * 4096u + i)) >> 32) * (uint64_t)s->N) >> 32);
+    int dup = (t == gid);
+    for (uint32_t j = 0; j < nc; ++j) dup |= (chosen[j] == t);
+    if (!dup) chosen[nc++] = t;
+  }
+  return nc;
+}
 static void tick_node(osim* s, const tickp* p, uint32_t l) {
   nctx c;
   nctx_init(&c, s, l);
+  if (s->rfan) c.pend_cap = s->f * s->P + SIM_S + 1u + SIM_RF_PEND_EXTRA;
   sim_row* row = c.row;
   sim_record* q = &s->queue[(size_t)l * SIM_Q];
   uint32_t g = c.gid / p->M, ll = c.gid % p->M;
@@ -1425,13 +1445,7 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
    * without a target (fewer than `fanout` other nodes) sends nothing */
   uint32_t chosen[SIM_MAX_FANOUT], nc = 0;
   if (s->rfan) {
-    uint64_t rb = rng_base(s->cfg.seed, STREAM_RFAN, s->tick);
-    for (uint32_t i = 0; i < 3u * s->N && nc < p->feff; ++i) {
-      uint32_t t = (uint32_t)(((mix64(rb ^ ((uint64_t)c.gid * 4096u + i)) >> 32) * (uint64_t)s->N) >> 32);
-      int dup = (t == c.gid);
-      for (uint32_t j = 0; j < nc; ++j) dup |= (chosen[j] == t);
-      if (!dup) chosen[nc++] = t;
-    }
+    nc = rf_draw(s, s->tick, c.gid, p->feff, chosen);
     for (uint32_t k = 0; k < p->feff; ++k)
       if (k >= nc || gossip_skips(s, l, chosen[k])) skipm |= 1u << k;
   }
@@ -1584,23 +1598,25 @@ static void step_chunk(osim* s, uint32_t chunk) {
       tick_node(s, p, chunk == NOSLOT ? i : (i / p->sub) * p->blk + chunk * p->sub + i % p->sub);
   }
 }
+/* random fan-out: group the cells by target — counting sort, senders ascending within a target, then slots */
+static void rf_group(osim* s) {
+  memset(s->rcsr, 0, ((size_t)s->Nl + 1) * sizeof(uint32_t));
+  size_t cells = (size_t)s->f * s->Nl;
+  for (size_t i = 0; i < cells; ++i)
+    if (s->rtgt[i] != NOSLOT) s->rcsr[s->rtgt[i] + 1]++;
+  for (uint32_t l = 0; l < s->Nl; ++l) s->rcsr[l + 1] += s->rcsr[l];
+  uint32_t* fill = (uint32_t*)malloc((size_t)s->Nl * sizeof(uint32_t));
+  memcpy(fill, s->rcsr, (size_t)s->Nl * sizeof(uint32_t));
+  for (uint32_t l = 0; l < s->Nl; ++l)          /* (sender, k) order */
+    for (uint32_t k = 0; k < s->f; ++k) {
+      size_t cell = (size_t)k * s->Nl + l;
+      if (s->rtgt[cell] != NOSLOT) s->rsrc[fill[s->rtgt[cell]]++] = (uint32_t)cell;
+    }
+  free(fill);
+}
 static void step_end(osim* s) {
   const tickp p = s->cur;
-  if (s->rfan) { /* group the cells by target: counting sort, senders ascending within a target */
-    memset(s->rcsr, 0, ((size_t)s->Nl + 1) * sizeof(uint32_t));
-    size_t cells = (size_t)s->f * s->Nl;
-    for (size_t i = 0; i < cells; ++i)
-      if (s->rtgt[i] != NOSLOT) s->rcsr[s->rtgt[i] + 1]++;
-    for (uint32_t l = 0; l < s->Nl; ++l) s->rcsr[l + 1] += s->rcsr[l];
-    uint32_t* fill = (uint32_t*)malloc((size_t)s->Nl * sizeof(uint32_t));
-    memcpy(fill, s->rcsr, (size_t)s->Nl * sizeof(uint32_t));
-    for (uint32_t l = 0; l < s->Nl; ++l)          /* (sender, k) order */
-      for (uint32_t k = 0; k < s->f; ++k) {
-        size_t cell = (size_t)k * s->Nl + l;
-        if (s->rtgt[cell] != NOSLOT) s->rsrc[fill[s->rtgt[cell]]++] = (uint32_t)cell;
-      }
-    free(fill);
-  }
+  if (s->rfan) rf_group(s);
   s->prev = p;
   s->tick++;
   s->in_tick = 0;
@@ -2139,7 +2155,7 @@ static size_t dec_str(uint32_t v, uint8_t out[12]) { int n = snprintf((char*)out
 static void w_message(wtr* w, uint32_t tag, const uint8_t* body, size_t n) { w_byte(w, (uint8_t)((tag << 3) | 2)); w_ld(w, body, n); }
 int API(peek_packet)(osim* s, uint32_t node, uint32_t k, uint8_t* buf, size_t cap, size_t* len) {
   if (!s || !len || k >= s->f) return SIM_EINVAL;
-  if (node < s->shard0 || node >= s->shard0 + s->Nl || s->rfan || s->in_tick) return SIM_EINVAL;
+  if (node < s->shard0 || node >= s->shard0 + s->Nl || s->in_tick) return SIM_EINVAL;
   wtr w = {buf, buf ? cap : 0, 0};
   if (s->tick > 0 && k < s->prev.feff) {
     const tickp* p = &s->prev; /* the map the packets in flight were sent with */
@@ -2148,6 +2164,7 @@ int API(peek_packet)(osim* s, uint32_t node, uint32_t k, uint8_t* buf, size_t ca
     for (uint32_t pg = 0; pg < s->PG; ++pg) {
       const sim_packet* pk = s->cfg.shard_count > 1
           ? &s->xsend[xcell(p, s->fp, (ll % p->blk) / p->sub, h, k * s->PG + pg, lp)]
+          : s->rfan ? &s->inbox[s->tick & 1][((size_t)k * s->PG + pg) * s->Nl + (node - s->shard0)] /* random fan-out: the packets stay in their senders' cells */
           : &s->inbox[s->tick & 1][((size_t)k * s->PG + pg) * s->Nl + (size_t)h * p->M + lp];
       for (uint32_t r = 0; r < SIM_P; ++r) {
         uint32_t kind = pk_kind(pk, r);
@@ -2424,7 +2441,9 @@ static void snap_sections(osim* s, const void* ptr[SNAP_SECTIONS], size_t len[SN
 }
 int API(snapshot)(osim* s, void* buf, size_t cap, size_t* bytes) {
   if (!s || !bytes) return SIM_EINVAL;
-  if (s->in_tick || s->rfan) return SIM_ESTATE; /* (the image has no section for the targets of the packets in flight) */
+  if (s->in_tick) return SIM_ESTATE;
+  /* (random fan-out: the inbox section holds the packets in their senders' cells, [slot][sender]; where each one goes is a
+   * function of (seed, tick - 1, sender) and is drawn again on restore) */
   if (s->cfg.shard_count <= 1 && (s->sreq_prev_n || s->sreq_n)) { /* slot-less failed probes not yet replayed: into the schedule, so that the image holds them */
     for (uint32_t i = 0; i < s->sreq_prev_n; ++i) inject_val(s, s->tick, SIM_OP_SUSPECT, s->sreq_prev[2 * i], s->sreq_prev[2 * i + 1], 0, 0);
     sreq_rotate(s);
@@ -2455,7 +2474,7 @@ int API(snapshot)(osim* s, void* buf, size_t cap, size_t* bytes) {
 }
 int API(restore)(osim* s, const void* buf, size_t bytes) {
   if (!s || !buf || bytes < sizeof(snap_header)) return SIM_EINVAL;
-  if (s->tick != 0 || s->n_ops != 0 || s->rfan) return SIM_ESTATE;
+  if (s->tick != 0 || s->n_ops != 0) return SIM_ESTATE;
   snap_header h;
   memcpy(&h, buf, sizeof h);
   if (h.magic != SNAP_MAGIC || h.abi != SIM_ABI_VERSION || memcmp(&h.cfg, &s->cfg, sizeof(sim_config))) return SIM_EINVAL;
@@ -2481,6 +2500,13 @@ int API(restore)(osim* s, const void* buf, size_t bytes) {
     in += n;
   }
   if (s->tick > 0) tickp_make(&s->prev, &s->cfg, s->tick - 1); /* the parameters the packets in flight were sent with */
+  if (s->rfan && s->tick > 0) { /* the targets of the packets in flight: drawn again, grouped again */
+    for (uint32_t l = 0; l < s->Nl; ++l) {
+      uint32_t chosen[SIM_MAX_FANOUT], nc = rf_draw(s, s->tick - 1, s->shard0 + l, s->prev.feff, chosen);
+      for (uint32_t k = 0; k < s->f; ++k) s->rtgt[(size_t)k * s->Nl + l] = (k < s->prev.feff && k < nc) ? chosen[k] : NOSLOT;
+    }
+    rf_group(s);
+  }
   s->n_watched = 0;
   for (uint32_t l = 0; l < s->Nl; ++l) s->n_watched += (s->rows[l].flags & SIM_RF_WATCHED) != 0;
   walk_rebuild(s);

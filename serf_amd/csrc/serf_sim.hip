@@ -29,7 +29,6 @@
 // returns SIM_EDEVICE.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
-#include <hipcub/hipcub.hpp>  // DeviceRadixSort: the per-tick CSR of the random fan-out mode (SIM_CF_RANDOM_FANOUT)
 
 #include <algorithm>
 #include <cmath>
@@ -289,13 +288,16 @@ struct Dev {
   u32* qbits;       // [SIM_QT][2][ceil(N/32)] who acked / responded, by global node id
   uint4* nullcell;  // 2 x uint4 of zeros: where the prefetch of a record without a lookup points
   uint8_t* skipmask;  // [Nl] gossip_to_the_dead: bit k = do not send packet k this tick (written by gossip_skip_kernel)
-  // SIM_CF_RANDOM_FANOUT (memberlist's literal kRandomNodes, App. B.2): the fan-out graph of a tick as an explicit CSR — for
-  // receiver l the packets addressed to it are rsrc[rcsr[l] .. rcsr[l + 1]), each entry sender * 4 + slot, senders
-  // ascending, then slots (the order memberlist's packets would be handed to the oracle in); built per tick by a stable
-  // radix sort of (target, sender * 4 + slot) pairs.  Double buffered by tick parity like the packets themselves.
-  u32* rcsr[2];  // [Nl + 1]
-  u32* rsrc[2];  // [f * Nl]
-  u32 rfan;      // the mode is on (local mode, one page per packet)
+  // SIM_CF_RANDOM_FANOUT (memberlist's literal kRandomNodes, App. B.2): the fan-out graph of a tick as an explicit CSR, and the
+  // packets PUSHED to their places in it.  Receiver l's incoming packets of a tick are the cells pbox[rcsr[l] .. rcsr[l + 1])
+  // (PG pages each), in (sender, slot) order — the order memberlist's packets would be handed to the oracle in —; sender l's
+  // packet of slot k goes to cell rpos[4 l + k] (NOSLOT: the slot drew no target).  Both are functions of (seed, tick) alone
+  // and are built ahead of the tick by the rf_* kernels (a two-level bucket sort); all three double buffered by tick parity:
+  // what tick t sends is described by rcsr / rpos [(t + 1) & 1] and lands in pbox[(t + 1) & 1].  obox / omap are not used.
+  uint4* pbox[2];  // [f * Nl * PG] cells
+  u32* rcsr[2];    // [Nl + 1]
+  u32* rpos[2];    // [4 * Nl]
+  u32 rfan;        // the mode is on (local mode)
   u32* sreq;        // [1 + 2 * SIM_SUSPECT_REQ_MAX]: count, then the (prober, target) pairs of the running tick's slot-less
                     // failed probes (one of three buffers, by tick mod 3: the host reads a tick's list one tick later)
   u32* sreq_next;   // the count word of the NEXT tick's buffer: zeroed by this tick's kernel (no memset between two ticks)
@@ -1427,17 +1429,16 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   // local mode: byte k = where the sender of slot k put that packet: first page << 2 | pages - 1 (0xFF: nothing sent)
   u32 jw = 0xFFFFFFFFu;
   // page pg of the packet of fan-out slot k (sharded: the block of the receive buffer the source shard filled)
-  // RF (literal kRandomNodes): the node's incoming packets are entries rin0 .. rin0 + rcnt of the tick's CSR (Dev::rsrc:
-  // sender * 4 + slot); "slot k" of the deliver loop is then the k-th incoming packet, and the loop runs as often as the lane
-  // of the wave with the most packets needs (in-degree is Poisson-like: mean f)
+  // RF (literal kRandomNodes): the node's incoming packets are the cells rin0 .. rin0 + rcnt of Dev::pbox — their senders pushed
+  // them there, in (sender, slot) order —; "slot k" of the deliver loop is then the k-th incoming packet, and the loop runs as
+  // often as the lane of the wave with the most packets needs (in-degree is Poisson-like: mean f).  A wave's 64 rows are one
+  // contiguous run of cells.
   u32 rin0 = 0, rcnt = 0;
   if (RF) { rin0 = d.rcsr[cur][l]; rcnt = d.rcsr[cur][l + 1] - rin0; }
   auto cell_of = [&](u32 k, u32 pg) __attribute__((always_inline)) -> const uint4* {
     if (RF) {
       if (k >= rcnt) return d.nullcell;
-      const u32 ent = d.rsrc[cur][rin0 + k], snd = ent >> 2, slot = ent & 3u;
-      const u32 jb = (d.omap[cur][snd] >> (8u * slot)) & 0xFFu;
-      return jb == 0xFFu ? d.nullcell : d.obox[cur] + ((size_t)(jb >> 2) * d.Nl + snd) * PK_U4;
+      return d.pbox[cur] + ((size_t)(rin0 + k) * (MP ? d.PG : 1u) + (MP ? pg : 0u)) * PK_U4;
     }
     if (SHARDED) {  // [sender chunk][source shard][slot * PG + page][sub] (oracle xcell)
       u32 b = l / tp.blk, w = l - b * tp.blk, sl = w / tp.sub;
@@ -1452,7 +1453,7 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   // pages the wave walks for slot k: the most any of its lanes received (a lane with fewer reads the zero cell)
   auto wave_np = [&](u32 k) __attribute__((always_inline)) -> u32 {
     if (!MP) return 1u;
-    if (SHARDED) return d.PG;
+    if (SHARDED || RF) return d.PG;
     u32 jb = (jw >> (8u * k)) & 0xFFu, np = jb == 0xFFu ? 0u : (jb & 3u) + 1u, w = 1u;
     if (__any(np >= 2u)) w = 2u;
     if (__any(np >= 3u)) w = 3u;
@@ -1698,7 +1699,7 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   // gossip_to_the_dead_time (App. B.2): the slots whose target this node believed dead for too long when the tick began
   // (gossip_skip_kernel, launched ahead of the tick only when the option is on) — those packets are not sent
 #ifndef TICK_LEAN
-  const u32 skipm = (d.gttd || RF) ? (u32)d.skipmask[l] : 0u;  // (RF: also the slots that drew no target)
+  const u32 skipm = d.gttd ? (u32)d.skipmask[l] : 0u;
 #else
   const u32 skipm = 0u;  // (measurement build: the round's optional memberlist switches compiled out of the tick kernel)
 #endif
@@ -1754,16 +1755,24 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
     if (SHARDED && tp.B == 64u) { fj = (u32)__builtin_amdgcn_readfirstlane((int)(uu >> 6)); fi = uu & 63u; }
     const u32 pj = (SHARDED && tp.feff) ? pi_f(tp, fj) : 0;
     u32 jout = 0xFFFFFFFFu, used = 0;  // local mode: the map word, pages handed out so far
+    uint4 rp = make_uint4(NOSLOT, NOSLOT, NOSLOT, NOSLOT);  // RF: the cells this node's packets go to
+    if (RF) rp = ld4(reinterpret_cast<const uint4*>(d.rpos[cur ^ 1]) + l);
 #pragma unroll
     for (int k = 0; k < F; ++k) {
       if ((u32)k >= tp.feff) break;
       const bool has = cn[k] != 0u;  // (nothing queued, or the packet was lost: no cell)
       const u32 np = (cn[k] + SIM_P - 1u) / SIM_P;
       u32 first = 0;
-      bool isnew = SHARDED;
+      bool isnew = SHARDED || RF;
+      bool rfcell = false;  // RF: slot k has a target, i.e. a cell (all its pages are written, empty ones too: the buffer is reused)
       uint4* dbase;  // page 0 of this packet's cells; page pg is pstride uint4s further on
       size_t pstride;
-      if (SHARDED) {
+      if (RF) {
+        const u32 rpk = SEL4(k, rp.x, rp.y, rp.z, rp.w);
+        rfcell = rpk != NOSLOT;
+        dbase = d.pbox[cur ^ 1] + (size_t)rpk * d.PG * PK_U4;
+        pstride = PK_U4;
+      } else if (SHARDED) {
         u32 y = pj + tp.off[k];
         if (y >= tp.nbc) y -= tp.nbc;
         u32 j2 = pi_inv(tp, y);
@@ -1790,8 +1799,8 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
         dbase = d.obox[cur ^ 1] + ((size_t)first * d.Nl + l) * PK_U4;
         pstride = (size_t)d.Nl * PK_U4;
       }
-      u32 wmax = SHARDED ? d.PG : 0u;  // pages the wave writes for this slot (uniform)
-      if (!SHARDED) {
+      u32 wmax = (SHARDED || RF) ? d.PG : 0u;  // pages the wave writes for this slot (uniform)
+      if (!SHARDED && !RF) {
         if (__any(isnew)) wmax = 1u;
         if (__any(isnew && np >= 2u)) wmax = 2u;
         if (__any(isnew && np >= 3u)) wmax = 3u;
@@ -1799,7 +1808,7 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
       }
 #pragma unroll 1
       for (u32 pgi = 0; pgi < wmax; ++pgi) {
-        const bool wr = SHARDED || (isnew && pgi < np);
+        const bool wr = RF ? rfcell : (SHARDED || (isnew && pgi < np));
         uint4 pk[SIM_P];
 #pragma unroll
         for (int p = 0; p < (int)SIM_P; ++p) {
@@ -1814,7 +1823,7 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
         store_cell(dbase + (size_t)pgi * pstride, wr, wk, wl, wh);
       }
     }
-    if (!SHARDED) d.omap[cur ^ 1][l] = jout;
+    if (!SHARDED && !RF) d.omap[cur ^ 1][l] = jout;
   } else {
   // all F drain rounds first (pure register work on the sort keys) ...
   u32 slots[F];
@@ -1863,6 +1872,8 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   const u32 pj = (SHARDED && tp.feff) ? pi_f(tp, fj) : 0;
   // local mode: which of this node's cells holds the packet of every slot (0xFF: nothing sent), distinct packets so far
   u32 jout = 0xFFFFFFFFu, ndist = 0;
+  uint4 rp = make_uint4(NOSLOT, NOSLOT, NOSLOT, NOSLOT);  // RF: the cells this node's packets go to (its places in its targets' rows)
+  if (RF) rp = ld4(reinterpret_cast<const uint4*>(d.rpos[cur ^ 1]) + l);
 #pragma unroll
   for (int k = 0; k < F; ++k) {
     if ((u32)k >= tp.feff || ABL(4)) break;
@@ -1887,7 +1898,11 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
     }
     uint4* dst;
     bool wr = true;  // this lane has a cell to write for slot k
-    if (SHARDED) {
+    if (RF) {  // every slot with a target writes its cell, an empty packet too (a node that is down, a lost packet): the buffer is reused
+      const u32 rpk = SEL4(k, rp.x, rp.y, rp.z, rp.w);
+      wr = rpk != NOSLOT;
+      dst = d.pbox[cur ^ 1] + (size_t)rpk * PK_U4;
+    } else if (SHARDED) {
       u32 y = pj + tp.off[k];
       if (y >= tp.nbc) y -= tp.nbc;
       u32 j2 = pi_inv(tp, y);
@@ -1914,7 +1929,7 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
       jout = (jout & ~(0xFFu << (8 * k))) | ((j == 0xFFu ? 0xFFu : j << 2) << (8 * k));  // first page << 2 | pages - 1
       dst = d.obox[cur ^ 1] + ((size_t)j * d.Nl + l) * PK_U4;
     }
-    const bool store = SHARDED || __any(wr);  // (wave-uniform)
+    const bool store = SHARDED || RF || __any(wr);  // (wave-uniform)
     uint4 wk, wl, wh;  // the packet in its wire form
     if (store) {
       wire_pack(pkc[0], wk.x, wl.x, wh.x); wire_pack(pkc[1], wk.y, wl.y, wh.y);
@@ -1932,7 +1947,7 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
     if (!store) continue;
     store_cell(dst, wr, wk, wl, wh);
   }
-  if (!SHARDED && !ABL(4)) d.omap[cur ^ 1][l] = jout;
+  if (!SHARDED && !RF && !ABL(4)) d.omap[cur ^ 1][l] = jout;
   }
   TT(10);
   if (up && !ABL(16)) {
@@ -2106,46 +2121,203 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
   }
 }
 
-// SIM_CF_RANDOM_FANOUT — memberlist's kRandomNodes (App. B.2; oracle tick_node): every node draws its `fanout` gossip targets
-// uniformly over the other nodes, without replacement, as the tick begins.  Output: the (target, sender * 4 + slot) pairs in
-// (sender, slot) order — a slot that drew no target (fewer than `fanout` other nodes) gets the key N, which sorts behind every
-// node — and the node's skip byte: no target, or gossip_to_the_dead says the target has been dead for too long.
-__global__ void rfan_draw_kernel(Dev d, TickP tp, const uint4* base, u64 rb, u32* keys, u32* vals) {
-  for (size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * blockDim.x) {
-    const u32 gid = d.shard0 + (u32)l;
-    u32 chosen[SIM_MAX_FANOUT], nc = 0, m = 0;
-    for (u32 i = 0; i < 3u * d.N && nc < tp.feff; ++i) {
-      u32 t = (u32)(((mix64(rb ^ ((u64)gid * 4096u + i)) >> 32) * (u64)d.N) >> 32);
-      bool dup = t == gid;
-      for (u32 j = 0; j < nc; ++j) dup |= chosen[j] == t;
-      if (!dup) { chosen[nc] = t; ++nc; }
+// ------------------------------------------------------------------------------------------------
+// SIM_CF_RANDOM_FANOUT — memberlist's kRandomNodes (App. B.2; oracle rf_draw / rf_group): the tick's fan-out graph
+// ------------------------------------------------------------------------------------------------
+// Every node draws its `fanout` gossip targets uniformly over the other nodes, without replacement: a function of (seed,
+// tick, node) alone, so the graph of tick t can be built before — or while — anything else of tick t runs, and any kernel
+// that needs a target draws it again instead of reading it (a handful of mix64 per node against 16 bytes of HBM).
+// What the tick kernel needs of it: for every receiver the row start rcsr[t] of its packets, and for every (sender, slot)
+// pair p = 4 l + k the cell rpos[p] = rcsr[target] + (rank of p among the pairs with the same target, ascending): the
+// oracle hands a node its packets in (sender, slot) order.  That is a sort of f * N pairs by (target, p); the keys are
+// uniform, so it is done as a two-level bucket sort written for this job (no library on the per-tick path):
+//   rf_count    every workgroup draws the targets of its SPW senders and counts them per level-1 bucket (= 2^LB consecutive
+//               targets) in an LDS histogram                                       -> ghist[workgroup][bucket]
+//   rf_scan     per bucket: exclusive prefix over the workgroups, bucket totals    -> ghist (in place), btot[bucket]
+//   rf_bstart   exclusive prefix over the bucket totals                            -> bstart[bucket], bstart[NB]
+//   rf_scatter  the same draws again; pair p goes to l1[bstart[b] + ghist[wg][b] + (LDS cursor of b)++] — any order inside
+//               a bucket will do, because the order that counts is restored by rank, not by stability
+//   rf_rows     one workgroup per bucket (~ 4 * 2^LB pairs): LDS counting sort by target -> the bucket's part of rcsr; then
+//               every pair ranks itself among the ~ f pairs of its row (p ascending) -> rpos[p].  A bucket that does not fit
+//               the LDS tables (never with uniform draws; forced by the tests through SERF_RF_CAP) ranks straight from l1.
+struct RfP {
+  u64 rb;       // rng_base(seed, STREAM_RFAN, tick)
+  u32 N, Nl, shard0, feff, f;
+  u32 LB, NB;   // level-1 buckets: NB = ceil(Nl / 2^LB) ranges of 2^LB consecutive (local) targets
+  u32 SPW, NWG; // senders per workgroup of rf_count / rf_scatter, number of those workgroups
+  u32 cap;      // pairs rf_rows can rank in LDS
+};
+#define RF_CAP_MAX 4096u
+#define RF_ROWS_MAX 1024u  // 2^LB <= this
+__device__ static inline u32 rf_draw(u64 rb, u32 gid, u32 N, u32 feff, u32 (&chosen)[SIM_MAX_FANOUT]) {
+  u32 nc = 0;
+  chosen[0] = chosen[1] = chosen[2] = chosen[3] = NOSLOT;
+  for (u32 i = 0; i < 3u * N && nc < feff; ++i) {
+    u32 t = (u32)(((mix64(rb ^ ((u64)gid * 4096u + i)) >> 32) * (u64)N) >> 32);
+    bool dup = t == gid;
+#pragma unroll
+    for (u32 j = 0; j < SIM_MAX_FANOUT; ++j) dup |= (j < nc) & (chosen[j] == t);
+    if (!dup) {
+      if (nc == 0) chosen[0] = t; else if (nc == 1) chosen[1] = t; else if (nc == 2) chosen[2] = t; else chosen[3] = t;
+      ++nc;
     }
-    for (u32 k = 0; k < d.f; ++k) {
-      u32 key = d.N;
-      if (k < nc && k < tp.feff) {
-        key = chosen[k];
-        if (d.gttd) {
-          u32 a = d.slot_of[key];
-          uint4 e = a == NOSLOT ? base[(size_t)key * 2] : d.view[(size_t)a * d.Nl + l];
-          u32 sw = SIM_VB_SWIM(e.w);
-          if ((e.w & SIM_VB_KNOWN) && (sw == SIM_SWIM_DEAD || sw == SIM_SWIM_LEFT) && ((((u32)tp.tick - SIM_VB_STAMP(e.w)) & STAMP_MASK) > d.gttd)) m |= 1u << k;
-        }
-      } else m |= 1u << k;
-      keys[l * d.f + k] = key;
-      vals[l * d.f + k] = (u32)l * 4u + k;
+  }
+  return nc;
+}
+__device__ static inline u32 rf_target_of(const RfP& r, u32 p) {  // the target of pair p = 4 l + k (it has one: it was scattered)
+  u32 ch[SIM_MAX_FANOUT];
+  rf_draw(r.rb, r.shard0 + (p >> 2), r.N, r.feff, ch);
+  return SEL4(p & 3u, ch[0], ch[1], ch[2], ch[3]);
+}
+__global__ __launch_bounds__(BLOCK) void rf_count_kernel(RfP r, u32* ghist) {
+  extern __shared__ u32 rf_lds[];  // [NB]
+  for (u32 b = threadIdx.x; b < r.NB; b += BLOCK) rf_lds[b] = 0;
+  __syncthreads();
+  const u32 l0 = blockIdx.x * r.SPW;
+  for (u32 i = threadIdx.x; i < r.SPW && l0 + i < r.Nl; i += BLOCK) {
+    u32 ch[SIM_MAX_FANOUT];
+    const u32 nc = rf_draw(r.rb, r.shard0 + l0 + i, r.N, r.feff, ch);
+#pragma unroll
+    for (u32 k = 0; k < SIM_MAX_FANOUT; ++k)
+      if (k < nc) atomicAdd(&rf_lds[(ch[k] - r.shard0) >> r.LB], 1u);
+  }
+  __syncthreads();
+  for (u32 b = threadIdx.x; b < r.NB; b += BLOCK) ghist[(size_t)blockIdx.x * r.NB + b] = rf_lds[b];
+}
+// exclusive prefix over the 64 lanes of a wave (`total` = the sum)
+__device__ static inline u32 wave_excl_scan(u32 v, u32& total) {
+  u32 x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    u32 y = (u32)__shfl_up((int)x, o, 64);
+    if ((threadIdx.x & 63u) >= (u32)o) x += y;
+  }
+  total = (u32)__shfl((int)x, 63, 64);
+  return x - v;
+}
+// one WAVE per bucket: lane i takes the workgroups [i * per, (i + 1) * per) of the bucket's column (loads 16 KiB apart — the
+// neighbouring columns belong to the neighbouring waves and share the lines: an L2 matter, 4 MiB in all at 1 Mi nodes)
+__global__ __launch_bounds__(BLOCK) void rf_scan_kernel(RfP r, u32* ghist, u32* btot) {
+  const u32 b = blockIdx.x * (BLOCK / 64u) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (b >= r.NB) return;
+  const u32 per = (r.NWG + 63u) / 64u, w0 = lane * per;
+  u32 v[4], sum = 0;  // per <= 4: NWG <= 256
+#pragma unroll
+  for (u32 j = 0; j < 4; ++j) {
+    v[j] = (j < per && w0 + j < r.NWG) ? ghist[(size_t)(w0 + j) * r.NB + b] : 0u;
+    sum += v[j];
+  }
+  u32 total, run = wave_excl_scan(sum, total);
+#pragma unroll
+  for (u32 j = 0; j < 4; ++j)
+    if (j < per && w0 + j < r.NWG) { ghist[(size_t)(w0 + j) * r.NB + b] = run; run += v[j]; }
+  if (lane == 0) btot[b] = total;
+}
+__global__ __launch_bounds__(1024) void rf_bstart_kernel(RfP r, const u32* btot, u32* bstart) {
+  __shared__ u32 part[1024];
+  const u32 per = (r.NB + 1023u) / 1024u, b0 = threadIdx.x * per;
+  u32 sum = 0;
+  for (u32 i = 0; i < per && b0 + i < r.NB; ++i) sum += btot[b0 + i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (u32 o = 1; o < 1024u; o <<= 1) {  // Hillis-Steele over the 1024 partial sums
+    u32 v = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  u32 run = part[threadIdx.x] - sum;
+  for (u32 i = 0; i < per && b0 + i < r.NB; ++i) { bstart[b0 + i] = run; run += btot[b0 + i]; }
+  if (threadIdx.x == 1023u) bstart[r.NB] = part[1023];
+}
+__global__ __launch_bounds__(BLOCK) void rf_scatter_kernel(RfP r, const u32* ghist, const u32* bstart, u32* l1, u32* rpos) {
+  extern __shared__ u32 rf_lds[];  // [NB] cursors
+  for (u32 b = threadIdx.x; b < r.NB; b += BLOCK) rf_lds[b] = 0;
+  __syncthreads();
+  const u32 l0 = blockIdx.x * r.SPW;
+  for (u32 i = threadIdx.x; i < r.SPW && l0 + i < r.Nl; i += BLOCK) {
+    u32 ch[SIM_MAX_FANOUT];
+    const u32 l = l0 + i, nc = rf_draw(r.rb, r.shard0 + l, r.N, r.feff, ch);
+#pragma unroll
+    for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) {
+      if (k < nc) {
+        const u32 b = (ch[k] - r.shard0) >> r.LB;
+        l1[bstart[b] + ghist[(size_t)blockIdx.x * r.NB + b] + atomicAdd(&rf_lds[b], 1u)] = 4u * l + k;
+      } else rpos[4u * l + k] = NOSLOT;  // a slot without a target (fewer other nodes than the fan-out): nothing is sent
     }
-    d.skipmask[l] = (uint8_t)m;
   }
 }
-// row starts of the CSR from the sorted keys: rcsr[t] = first position whose key is >= t (t = 0 .. Nl)
-__global__ void rfan_csr_kernel(const u32* sorted_keys, u32 n, u32 Nl, u32* rcsr) {
-  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t <= Nl; t += (size_t)gridDim.x * blockDim.x) {
-    u32 lo = 0, hi = n;
-    while (lo < hi) {
-      u32 mid = (lo + hi) >> 1;
-      if (sorted_keys[mid] < (u32)t) lo = mid + 1; else hi = mid;
+__global__ __launch_bounds__(BLOCK) void rf_rows_kernel(RfP r, const u32* bstart, const u32* l1, u32* rcsr, u32* rpos) {
+  __shared__ u32 cnt[RF_ROWS_MAX + 1], cur[RF_ROWS_MAX];
+  __shared__ u32 ent_p[RF_CAP_MAX], rowp[RF_CAP_MAX];
+  __shared__ uint16_t ent_t[RF_CAP_MAX];
+  const u32 b = blockIdx.x, base = bstart[b], n = bstart[b + 1] - base;
+  const u32 R = 1u << r.LB, t0 = b << r.LB, nrows = min(R, r.Nl - t0);
+  for (u32 i = threadIdx.x; i <= R; i += BLOCK) cnt[i] = 0;
+  __syncthreads();
+  const bool fits = n <= r.cap;
+  for (u32 i = threadIdx.x; i < n; i += BLOCK) {
+    const u32 p = l1[base + i], tl = rf_target_of(r, p) - r.shard0 - t0;
+    if (fits) { ent_p[i] = p; ent_t[i] = (uint16_t)tl; }
+    atomicAdd(&cnt[tl], 1u);
+  }
+  __syncthreads();
+  {  // exclusive prefix over the bucket's rows: every thread R / 256 consecutive ones (R is 256, 512 or 1024)
+    __shared__ u32 wtot[BLOCK / 64u];
+    const u32 per = R / BLOCK, i0 = threadIdx.x * per;
+    u32 v[RF_ROWS_MAX / BLOCK], sum = 0;
+#pragma unroll
+    for (u32 j = 0; j < RF_ROWS_MAX / BLOCK; ++j) { v[j] = j < per ? cnt[i0 + j] : 0u; sum += v[j]; }
+    u32 wsum, run = wave_excl_scan(sum, wsum);
+    if ((threadIdx.x & 63u) == 0) wtot[threadIdx.x >> 6] = wsum;
+    __syncthreads();
+    for (u32 w = 0; w < (threadIdx.x >> 6); ++w) run += wtot[w];
+#pragma unroll
+    for (u32 j = 0; j < RF_ROWS_MAX / BLOCK; ++j)
+      if (j < per) { cnt[i0 + j] = run; run += v[j]; }
+    if (threadIdx.x == BLOCK - 1u) cnt[R] = run;
+  }
+  for (u32 i = threadIdx.x; i < R; i += BLOCK) cur[i] = 0;
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < nrows; i += BLOCK) rcsr[t0 + i] = base + cnt[i];
+  if (b == r.NB - 1u && threadIdx.x == 0) rcsr[r.Nl] = base + n;
+  if (fits) {
+    for (u32 i = threadIdx.x; i < n; i += BLOCK) {
+      const u32 tl = ent_t[i];
+      rowp[cnt[tl] + atomicAdd(&cur[tl], 1u)] = ent_p[i];
     }
-    rcsr[t] = lo;
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < n; i += BLOCK) {
+      const u32 tl = ent_t[i], p = ent_p[i], lo = cnt[tl], hi = cnt[tl + 1];
+      u32 rank = 0;
+      for (u32 j = lo; j < hi; ++j) rank += rowp[j] < p ? 1u : 0u;
+      rpos[p] = base + lo + rank;
+    }
+  } else {  // the bucket does not fit the tables: rank every pair against the whole bucket, straight from l1
+    for (u32 i = threadIdx.x; i < n; i += BLOCK) {
+      const u32 p = l1[base + i], tl = rf_target_of(r, p) - r.shard0 - t0;
+      u32 rank = 0;
+      for (u32 j = 0; j < n; ++j) {
+        const u32 q = l1[base + j];
+        rank += (q < p && rf_target_of(r, q) - r.shard0 - t0 == tl) ? 1u : 0u;
+      }
+      rpos[p] = base + cnt[tl] + rank;
+    }
+  }
+}
+// gossip_to_the_dead_time with random fan-out (oracle tick_node): bit k of the node's skip byte = its view, as the tick begins,
+// says the target it drew for slot k has been dead / left for longer than that.  Its own launch, only when the option is on.
+__global__ void rf_skip_kernel(Dev d, TickP tp, RfP r, const uint4* base) {
+  for (size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * blockDim.x) {
+    u32 ch[SIM_MAX_FANOUT], m = 0;
+    const u32 nc = rf_draw(r.rb, d.shard0 + (u32)l, r.N, r.feff, ch);
+    for (u32 k = 0; k < nc; ++k) {
+      const u32 key = SEL4(k, ch[0], ch[1], ch[2], ch[3]), a = d.slot_of[key];
+      uint4 e = a == NOSLOT ? base[(size_t)key * 2] : d.view[(size_t)a * d.Nl + l];
+      u32 sw = SIM_VB_SWIM(e.w);
+      if ((e.w & SIM_VB_KNOWN) && (sw == SIM_SWIM_DEAD || sw == SIM_SWIM_LEFT) && ((((u32)tp.tick - SIM_VB_STAMP(e.w)) & STAMP_MASK) > d.gttd)) m |= 1u << k;
+    }
+    d.skipmask[l] = (uint8_t)m;
   }
 }
 // gossip_to_the_dead_time (App. B.2; oracle gossip_skips): for every node and fan-out slot, does the node's view — as it is when
@@ -2834,9 +3006,9 @@ __global__ void materialize_kernel(Dev d, TickP p, u32 cur, u32 valid, uint4* ou
     u32 kk = (u32)(i / d.Nl), l = (u32)(i - (size_t)kk * d.Nl), k = kk / d.PG, pg = kk - k * d.PG;
     uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a;
     if (d.rfan) {  // random fan-out: the canonical form is the oracle's — packets in the SENDER's cells, [slot][sender]
-      u32 jb = valid ? (d.omap[cur][l] >> (8u * k)) & 0xFFu : 0xFFu;
-      if (jb != 0xFFu) {
-        const uint4* cp = d.obox[cur] + ((size_t)(jb >> 2) * d.Nl + l) * PK_U4;
+      const u32 rp = valid ? d.rpos[cur][4u * l + k] : NOSLOT;  // (rpos of the tick they were sent in shares the packets' parity)
+      if (rp != NOSLOT) {
+        const uint4* cp = d.pbox[cur] + ((size_t)rp * d.PG + pg) * PK_U4;
         a = cp[0]; b = cp[1]; c = cp[2];
       }
     } else if (valid && k < p.feff) {
@@ -2854,6 +3026,18 @@ __global__ void materialize_kernel(Dev d, TickP p, u32 cur, u32 valid, uint4* ou
 }
 __global__ void unmaterialize_kernel(Dev d, TickP p, u32 cur, u32 valid, const uint4* in) {
   for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < d.Nl; s += (size_t)gridDim.x * blockDim.x) {
+    if (d.rfan) {  // random fan-out: every packet back to its place in its target's row (rpos / rcsr of the sending tick: rebuilt by the caller)
+      for (u32 k = 0; valid && k < d.f; ++k) {
+        const u32 rp = d.rpos[cur][4u * (u32)s + k];
+        if (rp == NOSLOT) continue;
+        for (u32 pg = 0; pg < d.PG; ++pg) {
+          const uint4* cp = in + ((size_t)(k * d.PG + pg) * d.Nl + s) * PK_U4;
+          uint4* op = d.pbox[cur] + ((size_t)rp * d.PG + pg) * PK_U4;
+          op[0] = cp[0]; op[1] = cp[1]; op[2] = cp[2];
+        }
+      }
+      continue;
+    }
     u32 jw = 0xFFFFFFFFu;
     if (valid) {
       u32 g = (u32)s / p.M, ll = (u32)s - g * p.M;
@@ -2945,12 +3129,9 @@ struct sim_handle {
   // what dumps, digests and images hold), produced from Dev::obox on demand; mat_tick = the tick it was made for
   uint4* inbox_mat;
   u64 mat_tick;
-  // SIM_CF_RANDOM_FANOUT: this tick's draws as (target, sender * 4 + slot) pairs in (sender, slot) order, the sorted keys, and
-  // the radix sort's scratch
-  u32 *rf_keys, *rf_vals, *rf_keys_sorted;
-  void* rf_tmp;
-  size_t rf_tmp_bytes;
-  int rf_bits;
+  // SIM_CF_RANDOM_FANOUT: scratch of the per-tick graph build (rf_* kernels)
+  u32 *rf_ghist, *rf_btot, *rf_bstart, *rf_l1;
+  RfP rfp;  // the parameters that do not change from tick to tick
 };
 
 #define HCHECK(x)                                                                        \
@@ -2976,8 +3157,8 @@ static int cfg_check(const sim_config* c) {
   if (c->shard_rank >= c->shard_count) return SIM_EINVAL;
   if (c->fanout < 1 || c->fanout > SIM_MAX_FANOUT) return SIM_EINVAL;
   if (c->chunks > 1 && ((M / c->vshards) % c->chunks || (M / c->vshards) / c->chunks < 1)) return SIM_EINVAL;
-  // memberlist's literal kRandomNodes (variable in-degree, an explicit CSR per tick): one shard, one chunk, one page per packet
-  if ((c->flags & SIM_CF_RANDOM_FANOUT) && (c->vshards != 1 || c->shard_count != 1 || c->chunks > 1 || c->pkt_records > SIM_P)) return SIM_EINVAL;
+  // memberlist's literal kRandomNodes (variable in-degree, an explicit CSR per tick): one shard, one chunk
+  if ((c->flags & SIM_CF_RANDOM_FANOUT) && (c->vshards != 1 || c->shard_count != 1 || c->chunks > 1 || c->n_nodes > (1u << 23))) return SIM_EINVAL;
   if (c->event_ring < 1 || c->query_ring < 1) return SIM_EINVAL;
   if (c->pkt_records && (c->pkt_records % SIM_P || c->pkt_records > SIM_PKT_RECORDS_MAX)) return SIM_EINVAL;
   if (c->retransmit_mult * h_digits10(c->n_nodes) > 63u) return SIM_EINVAL;
@@ -3093,7 +3274,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   d.P = cfg->pkt_records ? cfg->pkt_records : SIM_P;
   d.PG = d.P / SIM_P;
   d.fp = d.f * d.PG;
-  d.npend = d.f * d.P + SIM_S + 1u;
+  d.npend = d.f * d.P + SIM_S + 1u + ((cfg->flags & SIM_CF_RANDOM_FANOUT) ? SIM_RF_PEND_EXTRA : 0u);
   d.vtail = (size_t)d.A * d.Nl; d.etail = (size_t)d.Bev * d.Nl; d.qtail = (size_t)d.Bq * d.Nl;
   d.bev_mask = (d.Bev > 1 && !(d.Bev & (d.Bev - 1))) ? d.Bev - 1 : 0;
   d.bq_mask = (d.Bq > 1 && !(d.Bq & (d.Bq - 1))) ? d.Bq - 1 : 0;
@@ -3134,7 +3315,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   h->inbox_mat = nullptr;
   h->mat_tick = ~0ull;
   if (!d.sharded) {
-    DA(d.obox[0], (size_t)d.fp * Nl * PK_U4) DA(d.obox[1], (size_t)d.fp * Nl * PK_U4) DA(d.omap[0], Nl) DA(d.omap[1], Nl)
+    if (!d.rfan) { DA(d.obox[0], (size_t)d.fp * Nl * PK_U4) DA(d.obox[1], (size_t)d.fp * Nl * PK_U4) DA(d.omap[0], Nl) DA(d.omap[1], Nl) }
     DA(h->inbox_mat, (size_t)d.fp * Nl * PK_U4)
   }
   DA(d.view, (size_t)d.A * Nl * 2)
@@ -3148,20 +3329,26 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   DA(h->d_mst, d.N)
   DA(h->d_mlt, d.N)
   DA(h->d_stats, 1)
-  d.rcsr[0] = d.rcsr[1] = d.rsrc[0] = d.rsrc[1] = nullptr;
-  h->rf_keys = h->rf_vals = h->rf_keys_sorted = nullptr;
-  h->rf_tmp = nullptr; h->rf_tmp_bytes = 0; h->rf_bits = 32;
-  if (d.rfan) {  // the fan-out graph as a CSR, rebuilt every tick (SIM_CF_RANDOM_FANOUT)
+  d.rcsr[0] = d.rcsr[1] = d.rpos[0] = d.rpos[1] = nullptr;
+  d.pbox[0] = d.pbox[1] = nullptr;
+  h->rf_ghist = h->rf_btot = h->rf_bstart = h->rf_l1 = nullptr;
+  memset(&h->rfp, 0, sizeof h->rfp);
+  if (d.rfan) {  // the fan-out graph as a CSR, rebuilt every tick, and the packets pushed into it (SIM_CF_RANDOM_FANOUT)
     const size_t np = (size_t)d.f * Nl;
-    DA(d.rcsr[0], Nl + 1) DA(d.rcsr[1], Nl + 1) DA(d.rsrc[0], np) DA(d.rsrc[1], np)
-    DA(h->rf_keys, np) DA(h->rf_vals, np) DA(h->rf_keys_sorted, np)
-    h->rf_bits = 1;
-    while ((1ull << h->rf_bits) <= (u64)d.N) h->rf_bits++;  // keys are node ids, and N for "no target"
-    if (hipcub::DeviceRadixSort::SortPairs(nullptr, h->rf_tmp_bytes, h->rf_keys, h->rf_keys_sorted, h->rf_vals, d.rsrc[0], (int)np, 0, h->rf_bits, h->stream) != hipSuccess) { sim_destroy(h); return SIM_EDEVICE; }
-    uint8_t* tmp = nullptr;
-    DA(tmp, h->rf_tmp_bytes + 16)
-    h->rf_tmp = tmp;
-    if (hipMemset(d.rcsr[0], 0, (Nl + 1) * 4) != hipSuccess || hipMemset(d.rcsr[1], 0, (Nl + 1) * 4) != hipSuccess) { sim_destroy(h); return SIM_EDEVICE; }
+    RfP& r = h->rfp;
+    r.N = d.N; r.Nl = d.Nl; r.shard0 = d.shard0; r.f = d.f;
+    r.LB = 8;
+    while (((size_t)Nl + (1u << r.LB) - 1u) >> r.LB > 16384u) r.LB++;  // the level-1 histogram lives in 64 KiB of LDS
+    r.NB = (u32)(((size_t)Nl + (1u << r.LB) - 1u) >> r.LB);
+    r.SPW = std::max<u32>(4096u, (u32)(((size_t)Nl + 255u) / 256u));
+    r.NWG = (u32)(((size_t)Nl + r.SPW - 1u) / r.SPW);
+    r.cap = RF_CAP_MAX;
+    if (const char* e = getenv("SERF_RF_CAP")) r.cap = std::min<u32>(RF_CAP_MAX, (u32)strtoul(e, nullptr, 0));  // tests: force rf_rows' slow path
+    DA(d.rcsr[0], Nl + 1) DA(d.rcsr[1], Nl + 1) DA(d.rpos[0], 4 * Nl) DA(d.rpos[1], 4 * Nl)
+    DA(d.pbox[0], np * d.PG * PK_U4) DA(d.pbox[1], np * d.PG * PK_U4)
+    DA(h->rf_ghist, (size_t)r.NWG * r.NB) DA(h->rf_btot, r.NB) DA(h->rf_bstart, r.NB + 1) DA(h->rf_l1, np)
+    if (hipMemset(d.rcsr[0], 0, (Nl + 1) * 4) != hipSuccess || hipMemset(d.rcsr[1], 0, (Nl + 1) * 4) != hipSuccess ||
+        hipMemset(d.rpos[0], 0xFF, 4 * Nl * 4) != hipSuccess || hipMemset(d.rpos[1], 0xFF, 4 * Nl * 4) != hipSuccess) { sim_destroy(h); return SIM_EDEVICE; }
   }
 #undef DA
   bool joined = cfg->flags & SIM_CF_BASELINE_JOINED;
@@ -3180,7 +3367,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
     h->sreq_tick[i] = ~0ull;
   }
   HCHECK(zero(d.qtab, QTAB_U4(d.N) * 16)); HCHECK(zero(d.qbits, (size_t)SIM_QT * 2 * nup * 4));
-  if (!d.sharded) {  // nothing has been sent yet
+  if (!d.sharded && !d.rfan) {  // nothing has been sent yet
     HCHECK(zero(d.obox[0], (size_t)d.fp * Nl * sizeof(sim_packet))); HCHECK(zero(d.obox[1], (size_t)d.fp * Nl * sizeof(sim_packet)));
     HCHECK(hipMemsetAsync(d.omap[0], 0xFF, Nl * 4, s)); HCHECK(hipMemsetAsync(d.omap[1], 0xFF, Nl * 4, s));
   }
@@ -3317,7 +3504,7 @@ static int recycle_scan(sim_handle* h, sim_recycle_cand* c, u32 n) {
   if (e == hipSuccess) e = hipMemcpyAsync(scr, hs, sizeof hs, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) e = hipMemsetAsync(d_ref, 0, SIM_RECYCLE_BATCH * 16, s);
   if (e == hipSuccess) {
-    recycle_refd_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, d.sharded ? cur_inbox(h) : nullptr, (u32)(h->tick & 1), refd, scr);
+    recycle_refd_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, (d.sharded || d.rfan) ? cur_inbox(h) : nullptr, (u32)(h->tick & 1), refd, scr);
     recycle_view_kernel<<<dim3((unsigned)std::min<size_t>((d.Nl + BLOCK - 1) / BLOCK, 1024), n), BLOCK, 0, s>>>(d, scr + 4, scr, d_ref, scr + 4 + SIM_RECYCLE_BATCH);
     e = hipMemcpyAsync(hs, scr, sizeof hs, hipMemcpyDeviceToHost, s);
   }
@@ -3658,6 +3845,23 @@ int sim_recycle_apply(sim_handle* h, const sim_recycle_cand* agreed, uint32_t n)
   h->recycle_at = (u32)h->tick;
   return rc;
 }
+// the fan-out graph of `tick` (random fan-out): rcsr[w] / rpos[w] := rows and places of the packets sent during `tick`
+static int rf_build(sim_handle* h, u64 tick, u32 w) {
+  Dev& d = h->d;
+  RfP r = h->rfp;
+  TickP tp;
+  tickp_make(&tp, &h->cfg, tick);
+  r.rb = rng_base(h->cfg.seed, STREAM_RFAN, tick);
+  r.feff = tp.feff;
+  hipStream_t s = h->stream;
+  rf_count_kernel<<<r.NWG, BLOCK, r.NB * 4, s>>>(r, h->rf_ghist);
+  rf_scan_kernel<<<(r.NB + BLOCK / 64 - 1) / (BLOCK / 64), BLOCK, 0, s>>>(r, h->rf_ghist, h->rf_btot);
+  rf_bstart_kernel<<<1, 1024, 0, s>>>(r, h->rf_btot, h->rf_bstart);
+  rf_scatter_kernel<<<r.NWG, BLOCK, r.NB * 4, s>>>(r, h->rf_ghist, h->rf_bstart, h->rf_l1, d.rpos[w]);
+  rf_rows_kernel<<<r.NB, BLOCK, 0, s>>>(r, h->rf_bstart, h->rf_l1, d.rcsr[w], d.rpos[w]);
+  HCHECK(hipGetLastError());
+  return SIM_OK;
+}
 int sim_step_begin(sim_handle* h) {
   if (!h) return SIM_EINVAL;
   Dev& d = h->d;
@@ -3764,15 +3968,15 @@ int sim_step_begin(sim_handle* h) {
   // (sharded, C > 1): the pair brackets them with hipEventRecord.
   if (d.gttd && !d.rfan) gossip_skip_kernel<<<grid_for(d.Nl), BLOCK, 0, h->stream>>>(d, tp, h->d_base);  // whom not to gossip to this tick
   if (d.rfan) {
-    // kRandomNodes: this tick's targets are drawn now (and with them whom not to gossip to), and the packets' CSR — who
-    // receives what at tick + 1 — is sorted out of them while the tick runs: pairs in (sender, slot) order, a stable radix
-    // sort by target keeps that order inside a receiver's row
-    const u32 w = (u32)((h->tick + 1) & 1);
-    const int np = (int)((size_t)d.f * d.Nl);
-    rfan_draw_kernel<<<grid_for(d.Nl), BLOCK, 0, h->stream>>>(d, tp, h->d_base, rng_base(h->cfg.seed, STREAM_RFAN, h->tick), h->rf_keys, h->rf_vals);
-    size_t tb = h->rf_tmp_bytes;
-    HCHECK(hipcub::DeviceRadixSort::SortPairs(h->rf_tmp, tb, h->rf_keys, h->rf_keys_sorted, h->rf_vals, d.rsrc[w], np, 0, h->rf_bits, h->stream));
-    rfan_csr_kernel<<<grid_for(d.Nl + 1), BLOCK, 0, h->stream>>>(h->rf_keys_sorted, (u32)np, d.Nl, d.rcsr[w]);
+    // kRandomNodes: the graph of THIS tick's packets — where every sender's packets go (rpos) and where every receiver will
+    // find them at tick + 1 (rcsr) — is built now, ahead of the tick kernel that pushes them
+    int rc = rf_build(h, h->tick, (u32)((h->tick + 1) & 1));
+    if (rc) return rc;
+    if (d.gttd) {
+      RfP r = h->rfp;
+      r.rb = rng_base(h->cfg.seed, STREAM_RFAN, h->tick); r.feff = tp.feff;
+      rf_skip_kernel<<<grid_for(d.Nl), BLOCK, 0, h->stream>>>(d, tp, r, h->d_base);
+    }
   }
   h->tick_timed = h->profiling && (h->prof_seq++ % h->profiling) == 0;
   h->tick_bracket = h->tick_timed && d.sharded && tp.C > 1;
@@ -3817,7 +4021,11 @@ static int tick_launch(sim_handle* h, u32 chunk) {
 #define LAUNCH_TICK(SH, FF, BB) do { if (d.PG > 1u) LAUNCH_TICK_(SH, FF, BB, true); else LAUNCH_TICK_(SH, FF, BB, false); } while (0)
 #define LAUNCH_LOCAL(FF)                                                                                                 \
   do {                                                                                                                   \
-    if (d.rfan) {                                                                                                        \
+    if (d.rfan && d.PG > 1u) {                                                                                           \
+      if (e1) hipExtLaunchKernelGGL((tick_kernel<false, FF, false, true, true>), dim3(grid), dim3(TBLOCK), 0, h->stream, e0, e1, 0, d, tp, ptp, \
+                                    cur, (const uint4*)h->d_base, chunk, cnt);                                           \
+      else tick_kernel<false, FF, false, true, true><<<grid, TBLOCK, 0, h->stream>>>(d, tp, ptp, cur, h->d_base, chunk, cnt); \
+    } else if (d.rfan) {                                                                                                 \
       if (e1) hipExtLaunchKernelGGL((tick_kernel<false, FF, false, false, true>), dim3(grid), dim3(TBLOCK), 0, h->stream, e0, e1, 0, d, tp, ptp, \
                                     cur, (const uint4*)h->d_base, chunk, cnt);                                           \
       else tick_kernel<false, FF, false, false, true><<<grid, TBLOCK, 0, h->stream>>>(d, tp, ptp, cur, h->d_base, chunk, cnt); \
@@ -4150,6 +4358,7 @@ int sim_peek_packet(sim_handle* h, uint32_t node, uint32_t k, uint8_t* buf, size
     const uint4* src = d.sharded ? d.xsend : cur_inbox(h);
     for (u32 pg = 0; pg < d.PG; ++pg) {
       size_t cell = d.sharded ? ((((size_t)((ll % p.blk) / p.sub) * p.V + hh) * d.fp + (size_t)k * d.PG + pg) * p.sub + lp % p.sub)
+                    : d.rfan  ? (((size_t)k * d.PG + pg) * d.Nl + node)  // random fan-out: the canonical inbox is sender-indexed
                               : (((size_t)k * d.PG + pg) * d.Nl + (size_t)hh * p.M + lp);
       HCHECK(hipMemcpyAsync(&pages[pg], src + cell * PK_U4, sizeof(sim_packet), hipMemcpyDeviceToHost, h->stream));
     }
@@ -4248,7 +4457,6 @@ int sim_snapshot(sim_handle* h, void* buf, size_t cap, size_t* bytes) {
   if (!h || !bytes) return SIM_EINVAL;
   if (h->in_tick) return SIM_ESTATE;  // between sim_step_begin and sim_step_end the state is half a tick ahead of `tick`
   Dev& d = h->d;
-  if (d.rfan) return SIM_ESTATE;  // (the image has no section for the targets of the packets in flight: random fan-out runs are not checkpointed)
   if (d.swim && !d.sharded) {  // slot-less failed probes not yet replayed: into the schedule, so that the image holds them
     std::vector<u32> rq(2 * SIM_SUSPECT_REQ_MAX);
     for (u64 back = 2; back >= 1; --back) {
@@ -4298,7 +4506,7 @@ int sim_snapshot(sim_handle* h, void* buf, size_t cap, size_t* bytes) {
 }
 int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
   if (!h || !buf || bytes < sizeof(snap_header)) return SIM_EINVAL;
-  if (h->tick != 0 || !h->ops.empty() || h->d.rfan) return SIM_ESTATE;
+  if (h->tick != 0 || !h->ops.empty()) return SIM_ESTATE;
   Dev& d = h->d;
   snap_header hd;
   memcpy(&hd, buf, sizeof hd);
@@ -4369,6 +4577,9 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
       if (!d.sharded) {  // the packets in flight go back to their senders (one cell per slot)
         TickP p;
         tickp_make(&p, &h->cfg, hd.tick ? hd.tick - 1 : 0);
+        // (random fan-out: back to their places in their targets' rows — the graph of the tick they were sent in is a
+        // function of (seed, tick) and is built again first)
+        if (d.rfan && hd.tick && rf_build(h, hd.tick - 1, (u32)(hd.tick & 1)) != SIM_OK) rc = SIM_EDEVICE;
         unmaterialize_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, p, (u32)(hd.tick & 1), hd.tick ? 1u : 0u, h->inbox_mat);
       }
       RCHECK(hipGetLastError());

@@ -50,8 +50,33 @@ def test_random_fanout_spreads_one_round_slower_than_the_bijection(oracle):
     assert 0.3 < rounds[RF] - rounds[_ffi.CF_BASELINE_JOINED] < 2.0, rounds
 
 
-def test_no_checkpoints_in_this_mode(oracle):
-    sim = _ffi.Sim(oracle, _ffi.make_config(64, fanout=3, flags=RF))
-    sim.step(3)
-    with pytest.raises(_ffi.SimError):
-        sim.snapshot()
+@pytest.mark.parametrize("pkt", [4, 12])
+def test_checkpoint_and_resume_in_this_mode(oracle, pkt):
+    """The image holds the packets in flight in their senders' cells; where each one goes is a function of (seed, tick,
+    sender) and is drawn again on restore: the resumed run is the uninterrupted one."""
+    kw = dict(fanout=3, view_slots=16, event_ring=16, query_ring=8, probe_interval=3, loss=0.03, pkt_records=pkt, flags=RF)
+    a = _ffi.Sim(oracle, _ffi.make_config(700, **kw))
+    for i in range(30):
+        a.inject(1 + i % 7, _ffi.OP_USER_EVENT, 13 * i, 900 + i, 40)
+    a.inject(3, _ffi.OP_CRASH, 5)
+    a.step(9)
+    img = a.snapshot()
+    b = _ffi.Sim(oracle, _ffi.make_config(700, **kw))
+    b.restore(img)
+    assert a.digest() == b.digest()
+    for _ in range(6):
+        a.step(4)
+        b.step(4)
+        assert a.digest() == b.digest()
+
+
+def test_the_request_bound_of_one_tick_is_counted(oracle):
+    """With a random in-degree there is no maximum to the broadcasts the packets of one tick can ask for: requests beyond
+    f * P + SIM_S + 1 + SIM_RF_PEND_EXTRA are dropped and counted (the HIP library parks them in an array of that many rows).
+    Far out of reach of anything but a constructed case — here: nothing is dropped under a heavy load."""
+    sim = _ffi.Sim(oracle, _ffi.make_config(512, fanout=4, view_slots=64, event_ring=64, query_ring=8, pkt_records=16, flags=RF))
+    for i in range(200):
+        sim.inject(1 + i // 20, _ffi.OP_USER_EVENT, i % 512, 5000 + i, 30)
+    sim.step(30)
+    rows = sim.dump(_ffi.ARR_ROWS)
+    assert int(rows["overflow"].sum()) == sim.cluster_stats()["overflow"]
