@@ -77,6 +77,7 @@ static inline u64 rng4(u64 seed, u64 stream, u64 a, u64 b) { return mix64(rng_ba
 struct TickP {  // per-tick parameters, passed by value (lands in SGPRs)
   u64 tick;
   u64 loss_base, probe_base, query_base;
+  u64 rfan_base;  // random fan-out: the base of this tick's target draws
   u32 M, mask, shift, feff, V, blk, loss_u32, first;  // first: tick 0 has no inbox yet
   u32 n_slots;  // length of d.walk: view slots in use (the Reaper and the push-pull merge walk them)
   u32 zero_;    // always 0 (opaque to the compiler)
@@ -149,6 +150,7 @@ static void tickp_make(TickP* p, const sim_config* c, u64 tick) {
   p->loss_base = rng_base(c->seed, STREAM_LOSS, tick);
   p->probe_base = rng_base(c->seed, STREAM_PROBE, tick);
   p->query_base = rng_base(c->seed, STREAM_QUERY, tick);
+  p->rfan_base = rng_base(c->seed, STREAM_RFAN, tick);
   p->loss_u32 = c->loss_u32;
   p->first = (tick == 0);
 }
@@ -288,15 +290,15 @@ struct Dev {
   u32* qbits;       // [SIM_QT][2][ceil(N/32)] who acked / responded, by global node id
   uint4* nullcell;  // 2 x uint4 of zeros: where the prefetch of a record without a lookup points
   uint8_t* skipmask;  // [Nl] gossip_to_the_dead: bit k = do not send packet k this tick (written by gossip_skip_kernel)
-  // SIM_CF_RANDOM_FANOUT (memberlist's literal kRandomNodes, App. B.2): the fan-out graph of a tick as an explicit CSR, and the
-  // packets PUSHED to their places in it.  Receiver l's incoming packets of a tick are the cells pbox[rcsr[l] .. rcsr[l + 1])
-  // (PG pages each), in (sender, slot) order — the order memberlist's packets would be handed to the oracle in —; sender l's
-  // packet of slot k goes to cell rpos[4 l + k] (NOSLOT: the slot drew no target).  Both are functions of (seed, tick) alone
-  // and are built ahead of the tick by the rf_* kernels (a two-level bucket sort); all three double buffered by tick parity:
-  // what tick t sends is described by rcsr / rpos [(t + 1) & 1] and lands in pbox[(t + 1) & 1].  obox / omap are not used.
-  uint4* pbox[2];  // [f * Nl * PG] cells
-  u32* rcsr[2];    // [Nl + 1]
-  u32* rpos[2];    // [4 * Nl]
+  // SIM_CF_RANDOM_FANOUT (memberlist's literal kRandomNodes, App. B.2): the fan-out graph of a tick as an explicit CSR — for
+  // receiver l the packets addressed to it are rsrc[rcsr[l] .. rcsr[l + 1]), each entry sender * 4 + slot, in (sender, slot)
+  // order: the order memberlist's packets would be handed to the oracle in.  A function of (seed, tick) alone, built ahead of
+  // the tick by the rf_* kernels (a two-level bucket sort) on a stream of their own, while the tick before runs; the host
+  // points rcsr / rsrc at the graph of the packets this tick RECEIVES (sim_handle::rf_rcsr / rf_rsrc, three buffers each by
+  // sending tick).  The packets stay with their senders as in the bijection's local mode, in 64-byte cells (RF_CELL_U4) whose
+  // cell 0 carries the sender's map word in its fourth quarter — no omap array in this mode.
+  u32* rcsr;       // [Nl + 1]
+  u32* rsrc;       // [f * Nl]
   u32 rfan;        // the mode is on (local mode)
   u32* sreq;        // [1 + 2 * SIM_SUSPECT_REQ_MAX]: count, then the (prober, target) pairs of the running tick's slot-less
                     // failed probes (one of three buffers, by tick mod 3: the host reads a tick's list one tick later)
@@ -1143,6 +1145,23 @@ __device__ static void swim_probe(const Ctx& c, Node& n, const TickP& tp, const 
   swim_suspect(c, n, t, e.z, c.gid, wire_meta(SIM_K_SUSPECT, 0, 32), p, e, dirty, ins);
 }
 
+// SIM_CF_RANDOM_FANOUT: a node's gossip targets of a tick (memberlist kRandomNodes, App. B.2; oracle rf_draw) — uniform over all N
+// nodes, skip self and duplicates, up to 3 N tries: a function of (seed, tick, node).  Returns how many of the feff slots found one.
+__device__ static inline u32 rf_draw(u64 rb, u32 gid, u32 N, u32 feff, u32 (&chosen)[SIM_MAX_FANOUT]) {
+  u32 nc = 0;
+  chosen[0] = chosen[1] = chosen[2] = chosen[3] = NOSLOT;
+  for (u32 i = 0; i < 3u * N && nc < feff; ++i) {
+    u32 t = (u32)(((mix64(rb ^ ((u64)gid * 4096u + i)) >> 32) * (u64)N) >> 32);
+    bool dup = t == gid;
+#pragma unroll
+    for (u32 j = 0; j < SIM_MAX_FANOUT; ++j) dup |= (j < nc) & (chosen[j] == t);
+    if (!dup) {
+      if (nc == 0) chosen[0] = t; else if (nc == 1) chosen[1] = t; else if (nc == 2) chosen[2] = t; else chosen[3] = t;
+      ++nc;
+    }
+  }
+  return nc;
+}
 // ---- SerfDelegate::notify_message: delegate.rs:183-300 -----------------------------------------------
 __device__ static inline bool member_kind(u32 kind) {
   return kind == SIM_K_JOIN || kind == SIM_K_LEAVE || kind >= SIM_K_ALIVE;
@@ -1336,6 +1355,7 @@ static u32 g_ablate = 0;
 // A record between its 16-byte working form {key, wire meta, val} and its 12 bytes in a packet (include/serf_sim.h
 // sim_packet: key, value bits 31..0, value bits 47..32 | len64 | kind | flags; SUSPECT / DEAD carry inc : 24 | from : 24)
 #define PK_U4 3u  // a packet cell is three uint4: the four keys, the four low words, the four high words
+#define RF_CELL_U4 4u  // random fan-out: a sender's cell is 64 bytes — the packet's 48 and, in cell 0, the sender's map word (slot -> cell): entry -> cell is ONE scattered line
 __device__ static inline uint4 wire_unpack(u32 key, u32 lo, u32 hm) {
   u32 meta = (((hm >> 8) & 0x3Fu) << 18) | (hm & 0xFFu), hi = hm >> 16;
   bool two = ((hm >> 5) & 7u) == 3u;  // kind 6 or 7
@@ -1429,16 +1449,20 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   // local mode: byte k = where the sender of slot k put that packet: first page << 2 | pages - 1 (0xFF: nothing sent)
   u32 jw = 0xFFFFFFFFu;
   // page pg of the packet of fan-out slot k (sharded: the block of the receive buffer the source shard filled)
-  // RF (literal kRandomNodes): the node's incoming packets are the cells rin0 .. rin0 + rcnt of Dev::pbox — their senders pushed
-  // them there, in (sender, slot) order —; "slot k" of the deliver loop is then the k-th incoming packet, and the loop runs as
-  // often as the lane of the wave with the most packets needs (in-degree is Poisson-like: mean f).  A wave's 64 rows are one
-  // contiguous run of cells.
-  u32 rin0 = 0, rcnt = 0;
-  if (RF) { rin0 = d.rcsr[cur][l]; rcnt = d.rcsr[cur][l + 1] - rin0; }
+  // RF (literal kRandomNodes): the node's incoming packets are the entries rin0 .. rin0 + rcnt of the tick's CSR (Dev::rsrc:
+  // sender * 4 + slot, in (sender, slot) order: the order the oracle hands them over in); "slot k" of the deliver loop is then
+  // the k-th incoming packet, and the loop runs as often as the lane of the wave with the most packets needs (in-degree is
+  // Poisson-like: mean f).  A packet is FETCHED from its sender, like in the bijection's local mode — but here a sender's cells
+  // are 64 bytes and cell 0 carries the sender's map word in its spare quarter, so entry -> cell is all there is: ONE
+  // scattered line per packet (99 % of the packets sit in their sender's cell 0; another cell, or a further page, is a second
+  // fetch).  rf_e = the entry of the packet whose first page is in rn .. / rf_map, rf_en = the next one (requested an
+  // iteration ahead), rf_jb = where the packet being delivered sits (first page << 2 | pages - 1; 0xFF: nothing).
+  u32 rin0 = 0, rcnt = 0, rf_e = NOSLOT, rf_en = NOSLOT, rf_map = 0, rf_jb = 0xFFu, rf_snd = 0;
+  if (RF) { rin0 = d.rcsr[l]; rcnt = d.rcsr[l + 1] - rin0; }
   auto cell_of = [&](u32 k, u32 pg) __attribute__((always_inline)) -> const uint4* {
-    if (RF) {
-      if (k >= rcnt) return d.nullcell;
-      return d.pbox[cur] + ((size_t)(rin0 + k) * (MP ? d.PG : 1u) + (MP ? pg : 0u)) * PK_U4;
+    if (RF) {  // first page: the sender's cell 0, asked for before its map word is known; further pages: where the map said
+      if (!MP || pg == 0) return rf_e == NOSLOT ? d.nullcell : d.obox[cur] + (size_t)(rf_e >> 2) * RF_CELL_U4;
+      return (rf_jb == 0xFFu || pg > (rf_jb & 3u)) ? d.nullcell : d.obox[cur] + ((size_t)((rf_jb >> 2) + pg) * d.Nl + rf_snd) * RF_CELL_U4;
     }
     if (SHARDED) {  // [sender chunk][source shard][slot * PG + page][sub] (oracle xcell)
       u32 b = l / tp.blk, w = l - b * tp.blk, sl = w / tp.sub;
@@ -1468,6 +1492,8 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   u32 om0 = 0xFFFFFFFFu, om1 = 0xFFFFFFFFu, om2 = 0xFFFFFFFFu, om3 = 0xFFFFFFFFu;
   u32 rf_npk = 0;  // RF: packets the wave walks (the most any lane received)
   if (RF) {
+    rf_e = rcnt > 0 ? d.rsrc[rin0] : NOSLOT;
+    rf_en = rcnt > 1 ? d.rsrc[rin0 + 1] : NOSLOT;
     cell = cell_of(0, 0);
     u32 w = rcnt;
 #pragma unroll
@@ -1486,6 +1512,7 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
     om0 = *a0; om1 = *a1; om2 = *a2; om3 = *a3;
   }
   uint4 rn = ld4(cell), rn1 = ld4((SHARDED && tp.first) ? cell : cell + 1), rn2 = ld4((SHARDED && tp.first) ? cell : cell + 2);
+  if (RF) rf_map = reinterpret_cast<const u32*>(cell)[12];  // (the zero cell: "cell 0, one page" of nothing)
   Node n;
   node_load(d, l, n);
   if (!SHARDED && !RF) {
@@ -1510,9 +1537,28 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
       bool have_ns = false;  // (wave-uniform) lds_p[i][tid] >> 48 = slot of record i of the page whose words are in rn ..
 #endif
       while (k < npk) {
+        if (RF) {
+          // the page in rn .. : a first page came from its sender's cell 0 on spec — now that the map word is here: nothing
+          // sent (or lost) -> an empty page; the packet is another of the sender's cells (1 % of them) -> fetched now
+          if (!MP || pg == 0) {
+            rf_jb = rf_e == NOSLOT ? 0xFFu : (rf_map >> (8u * (rf_e & 3u))) & 0xFFu;
+            rf_snd = rf_e >> 2;
+            if (rf_jb == 0xFFu) rn = rn1 = rn2 = zero;
+            const bool far = rf_jb != 0xFFu && (rf_jb >> 2) != 0u;
+            if (__any(far)) {
+              const uint4* c2 = far ? d.obox[cur] + ((size_t)(rf_jb >> 2) * d.Nl + rf_snd) * RF_CELL_U4 : d.nullcell;
+              const uint4 a0 = ld4(c2), a1 = ld4(c2 + 1), a2 = ld4(c2 + 2);
+              if (far) { rn = a0; rn1 = a1; rn2 = a2; }
+            }
+          }
+        }
         if (MP) {
           if (++pg >= wnp) { ++k; pg = 0; if (k < npk) wnp = wave_np(k); }
         } else ++k;
+        if (RF && (!MP || pg == 0)) {  // on to the next packet: its entry was asked for an iteration ago; ask for the one after it
+          rf_e = rf_en;
+          rf_en = k + 1u < rcnt ? d.rsrc[rin0 + k + 1u] : NOSLOT;
+        }
         // from here on (k, pg) is the page AFTER the one being delivered (whose three words are in rn, rn1, rn2)
         u32 slow;  // records of this page that need a handler
         // ---- stage the packet in LDS (one 16-byte column per record and lane: conflict-free) ----
@@ -1529,7 +1575,10 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
           // (its address is worked out up here: what that needs may come back from scratch, and a scratch reload
           // between two loads makes the second wait for the first)
           cell = k < npk ? cell_of(k, pg) : d.nullcell;
-          auto prefetch = [&]() __attribute__((always_inline)) { rn = ld4(cell); rn1 = ld4(cell + 1); rn2 = ld4(cell + 2); };
+          auto prefetch = [&]() __attribute__((always_inline)) {
+            rn = ld4(cell); rn1 = ld4(cell + 1); rn2 = ld4(cell + 2);
+            if (RF && (!MP || pg == 0)) rf_map = reinterpret_cast<const u32*>(cell)[12];
+          };
           TT(1);
           // wave-ballot early out: nobody in this wave received anything in packet k (an empty record is all zero)
 #ifdef TICK_NEXT_SLOTS
@@ -1699,7 +1748,15 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   // gossip_to_the_dead_time (App. B.2): the slots whose target this node believed dead for too long when the tick began
   // (gossip_skip_kernel, launched ahead of the tick only when the option is on) — those packets are not sent
 #ifndef TICK_LEAN
-  const u32 skipm = d.gttd ? (u32)d.skipmask[l] : 0u;
+  u32 skipm = d.gttd ? (u32)d.skipmask[l] : 0u;
+  if (RF && d.N < 256u) {
+    // a slot that drew no target sends nothing (oracle tick_node).  Only a cluster with fewer other nodes than the fan-out, or
+    // a very small one out of luck, has such slots: with 256 nodes or more, 3 N tries that fail to find `fanout` distinct
+    // peers have a probability below 1e-1000 and are not looked for
+    u32 ch[SIM_MAX_FANOUT];
+    const u32 nc = rf_draw(tp.rfan_base, gid, d.N, tp.feff, ch);
+    skipm |= (0xFu << nc) & 0xFu;
+  }
 #else
   const u32 skipm = 0u;  // (measurement build: the round's optional memberlist switches compiled out of the tick kernel)
 #endif
@@ -1709,7 +1766,9 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   // j's packet): the texture addresser sees 48 contiguous bytes per quad and L2 one write per cell instead of
   // three.  The transpose goes through this wave's columns of lds_r (free in phase 2), XOR-swizzled so that
   // neither side has bank conflicts.  A lane without a cell to write hands its quad a null address.
-  auto store_cell = [&](uint4* dst, bool wr, const uint4& wk, const uint4& wl, const uint4& wh) __attribute__((always_inline)) {
+  // (RF: the cells are 64 bytes and every store writes all four quarters — one whole, aligned burst —, the fourth being the
+  // node's map word `mapw`: it is cell 0's that the receivers read, the copies in the other cells are never looked at)
+  auto store_cell = [&](uint4* dst, bool wr, const uint4& wk, const uint4& wl, const uint4& wh, u32 mapw) __attribute__((always_inline)) {
     if (coop) {
       lds_r[0][tid] = wk; lds_r[1][tid ^ 1] = wl; lds_r[2][tid ^ 2] = wh;
       __builtin_amdgcn_wave_barrier();
@@ -1720,13 +1779,15 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
         uint4 v = lds_r[part][(qb + j) ^ part];                                                    \
         u32 lo = (u32)__builtin_amdgcn_mov_dpp((int)dlo, j * 0x55, 0xF, 0xF, true);                \
         u32 hi = (u32)__builtin_amdgcn_mov_dpp((int)dhi, j * 0x55, 0xF, 0xF, true);                \
-        if (qi < 3u && (lo | hi) != 0u) ((uint4*)(((uintptr_t)hi << 32) | lo))[qi] = v;           \
+        if (RF) { u32 mw = (u32)__builtin_amdgcn_mov_dpp((int)mapw, j * 0x55, 0xF, 0xF, true); if (qi == 3u) v = make_uint4(mw, 0u, 0u, 0u); } \
+        if ((RF || qi < 3u) && (lo | hi) != 0u) ((uint4*)(((uintptr_t)hi << 32) | lo))[qi] = v;   \
       }
       COOP_STORE(0) COOP_STORE(1) COOP_STORE(2) COOP_STORE(3)
 #undef COOP_STORE
       __builtin_amdgcn_wave_barrier();
     } else if (wr) {
       dst[0] = wk; dst[1] = wl; dst[2] = wh;
+      if (RF) dst[3] = make_uint4(mapw, 0u, 0u, 0u);
     }
   };
   if (MP) {
@@ -1755,24 +1816,33 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
     if (SHARDED && tp.B == 64u) { fj = (u32)__builtin_amdgcn_readfirstlane((int)(uu >> 6)); fi = uu & 63u; }
     const u32 pj = (SHARDED && tp.feff) ? pi_f(tp, fj) : 0;
     u32 jout = 0xFFFFFFFFu, used = 0;  // local mode: the map word, pages handed out so far
-    uint4 rp = make_uint4(NOSLOT, NOSLOT, NOSLOT, NOSLOT);  // RF: the cells this node's packets go to
-    if (RF) rp = ld4(reinterpret_cast<const uint4*>(d.rpos[cur ^ 1]) + l);
+    // RF: the map word travels IN cell 0, which is written first: the word is worked out before anything is stored (the same
+    // arithmetic as in the loop below, on registers)
+    u32 jfin = 0xFFFFFFFFu;
+    if (RF) {
+      u32 usedp = 0;
+#pragma unroll
+      for (int k = 0; k < F; ++k) {
+        if ((u32)k >= tp.feff || cn[k] == 0u) continue;
+        u32 jenc = 0xFFu;
+        bool nw = true;
+#pragma unroll
+        for (int q = k - 1; q >= 0; --q)
+          if (cn[q] == cn[k] && nib[q] == nib[k]) { jenc = (jfin >> (8 * q)) & 0xFFu; nw = false; }
+        if (nw) { const u32 npk_ = (cn[k] + SIM_P - 1u) / SIM_P; jenc = (usedp << 2) | (npk_ - 1u); usedp += npk_; }
+        jfin = (jfin & ~(0xFFu << (8 * k))) | (jenc << (8 * k));
+      }
+    }
 #pragma unroll
     for (int k = 0; k < F; ++k) {
       if ((u32)k >= tp.feff) break;
       const bool has = cn[k] != 0u;  // (nothing queued, or the packet was lost: no cell)
       const u32 np = (cn[k] + SIM_P - 1u) / SIM_P;
       u32 first = 0;
-      bool isnew = SHARDED || RF;
-      bool rfcell = false;  // RF: slot k has a target, i.e. a cell (all its pages are written, empty ones too: the buffer is reused)
+      bool isnew = SHARDED;
       uint4* dbase;  // page 0 of this packet's cells; page pg is pstride uint4s further on
       size_t pstride;
-      if (RF) {
-        const u32 rpk = SEL4(k, rp.x, rp.y, rp.z, rp.w);
-        rfcell = rpk != NOSLOT;
-        dbase = d.pbox[cur ^ 1] + (size_t)rpk * d.PG * PK_U4;
-        pstride = PK_U4;
-      } else if (SHARDED) {
+      if (SHARDED) {
         u32 y = pj + tp.off[k];
         if (y >= tp.nbc) y -= tp.nbc;
         u32 j2 = pi_inv(tp, y);
@@ -1796,11 +1866,11 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
           if (isnew) { first = used; used += np; jenc = (first << 2) | (np - 1u); }
         }
         jout = (jout & ~(0xFFu << (8 * k))) | (jenc << (8 * k));
-        dbase = d.obox[cur ^ 1] + ((size_t)first * d.Nl + l) * PK_U4;
-        pstride = (size_t)d.Nl * PK_U4;
+        dbase = d.obox[cur ^ 1] + ((size_t)first * d.Nl + l) * (RF ? RF_CELL_U4 : PK_U4);
+        pstride = (size_t)d.Nl * (RF ? RF_CELL_U4 : PK_U4);
       }
-      u32 wmax = (SHARDED || RF) ? d.PG : 0u;  // pages the wave writes for this slot (uniform)
-      if (!SHARDED && !RF) {
+      u32 wmax = SHARDED ? d.PG : 0u;  // pages the wave writes for this slot (uniform)
+      if (!SHARDED) {
         if (__any(isnew)) wmax = 1u;
         if (__any(isnew && np >= 2u)) wmax = 2u;
         if (__any(isnew && np >= 3u)) wmax = 3u;
@@ -1808,7 +1878,7 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
       }
 #pragma unroll 1
       for (u32 pgi = 0; pgi < wmax; ++pgi) {
-        const bool wr = RF ? rfcell : (SHARDED || (isnew && pgi < np));
+        const bool wr = SHARDED || (isnew && pgi < np);
         uint4 pk[SIM_P];
 #pragma unroll
         for (int p = 0; p < (int)SIM_P; ++p) {
@@ -1820,10 +1890,12 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
         uint4 wk, wl, wh;
         wire_pack(pk[0], wk.x, wl.x, wh.x); wire_pack(pk[1], wk.y, wl.y, wh.y);
         wire_pack(pk[2], wk.z, wl.z, wh.z); wire_pack(pk[3], wk.w, wl.w, wh.w);
-        store_cell(dbase + (size_t)pgi * pstride, wr, wk, wl, wh);
+        store_cell(dbase + (size_t)pgi * pstride, wr, wk, wl, wh, jfin);
       }
     }
     if (!SHARDED && !RF) d.omap[cur ^ 1][l] = jout;
+    // RF: a node that sent nothing has not written its cell 0 — its map word (all 0xFF) has to stand there all the same
+    if (RF && jfin == 0xFFFFFFFFu) d.obox[cur ^ 1][(size_t)l * RF_CELL_U4 + 3u] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
   } else {
   // all F drain rounds first (pure register work on the sort keys) ...
   u32 slots[F];
@@ -1872,8 +1944,21 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   const u32 pj = (SHARDED && tp.feff) ? pi_f(tp, fj) : 0;
   // local mode: which of this node's cells holds the packet of every slot (0xFF: nothing sent), distinct packets so far
   u32 jout = 0xFFFFFFFFu, ndist = 0;
-  uint4 rp = make_uint4(NOSLOT, NOSLOT, NOSLOT, NOSLOT);  // RF: the cells this node's packets go to (its places in its targets' rows)
-  if (RF) rp = ld4(reinterpret_cast<const uint4*>(d.rpos[cur ^ 1]) + l);
+  // RF: the map word travels IN cell 0, which is written first: the word is worked out before anything is stored
+  u32 jfin = 0xFFFFFFFFu;
+  if (RF) {
+    u32 nd = 0;
+#pragma unroll
+    for (int k = 0; k < F; ++k) {
+      if ((u32)k >= tp.feff || slots[k] == 0xFFFFFFFFu) continue;
+      u32 j = 0xFFu;
+#pragma unroll
+      for (int q = k - 1; q >= 0; --q)
+        if (slots[q] == slots[k]) j = ((jfin >> (8 * q)) & 0xFFu) >> 2;
+      if (j == 0xFFu) j = nd++;
+      jfin = (jfin & ~(0xFFu << (8 * k))) | ((j << 2) << (8 * k));
+    }
+  }
 #pragma unroll
   for (int k = 0; k < F; ++k) {
     if ((u32)k >= tp.feff || ABL(4)) break;
@@ -1898,11 +1983,7 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
     }
     uint4* dst;
     bool wr = true;  // this lane has a cell to write for slot k
-    if (RF) {  // every slot with a target writes its cell, an empty packet too (a node that is down, a lost packet): the buffer is reused
-      const u32 rpk = SEL4(k, rp.x, rp.y, rp.z, rp.w);
-      wr = rpk != NOSLOT;
-      dst = d.pbox[cur ^ 1] + (size_t)rpk * PK_U4;
-    } else if (SHARDED) {
+    if (SHARDED) {
       u32 y = pj + tp.off[k];
       if (y >= tp.nbc) y -= tp.nbc;
       u32 j2 = pi_inv(tp, y);
@@ -1927,9 +2008,9 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
         if (wr) j = ndist++;
       }
       jout = (jout & ~(0xFFu << (8 * k))) | ((j == 0xFFu ? 0xFFu : j << 2) << (8 * k));  // first page << 2 | pages - 1
-      dst = d.obox[cur ^ 1] + ((size_t)j * d.Nl + l) * PK_U4;
+      dst = d.obox[cur ^ 1] + ((size_t)j * d.Nl + l) * (RF ? RF_CELL_U4 : PK_U4);
     }
-    const bool store = SHARDED || RF || __any(wr);  // (wave-uniform)
+    const bool store = SHARDED || __any(wr);  // (wave-uniform)
     uint4 wk, wl, wh;  // the packet in its wire form
     if (store) {
       wire_pack(pkc[0], wk.x, wl.x, wh.x); wire_pack(pkc[1], wk.y, wl.y, wh.y);
@@ -1945,9 +2026,11 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
       }
     }
     if (!store) continue;
-    store_cell(dst, wr, wk, wl, wh);
+    store_cell(dst, wr, wk, wl, wh, jfin);
   }
   if (!SHARDED && !RF && !ABL(4)) d.omap[cur ^ 1][l] = jout;
+  // RF: a node that sent nothing has not written its cell 0 — its map word (all 0xFF) has to stand there all the same
+  if (RF && jfin == 0xFFFFFFFFu && !ABL(4)) d.obox[cur ^ 1][(size_t)l * RF_CELL_U4 + 3u] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
   }
   TT(10);
   if (up && !ABL(16)) {
@@ -2127,9 +2210,9 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
 // Every node draws its `fanout` gossip targets uniformly over the other nodes, without replacement: a function of (seed,
 // tick, node) alone, so the graph of tick t can be built before — or while — anything else of tick t runs, and any kernel
 // that needs a target draws it again instead of reading it (a handful of mix64 per node against 16 bytes of HBM).
-// What the tick kernel needs of it: for every receiver the row start rcsr[t] of its packets, and for every (sender, slot)
-// pair p = 4 l + k the cell rpos[p] = rcsr[target] + (rank of p among the pairs with the same target, ascending): the
-// oracle hands a node its packets in (sender, slot) order.  That is a sort of f * N pairs by (target, p); the keys are
+// What the tick kernel needs of it: for every receiver the row rsrc[rcsr[t] .. rcsr[t + 1]) of the (sender, slot) pairs
+// p = 4 l + k that drew it, p ascending: the oracle hands a node its packets in (sender, slot) order.  That is a sort of
+// f * N pairs by (target, p); the keys are
 // uniform, so it is done as a two-level bucket sort written for this job (no library on the per-tick path):
 //   rf_count    every workgroup draws the targets of its SPW senders and counts them per level-1 bucket (= 2^LB consecutive
 //               targets) in an LDS histogram                                       -> ghist[workgroup][bucket]
@@ -2138,8 +2221,8 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
 //   rf_scatter  the same draws again; pair p goes to l1[bstart[b] + ghist[wg][b] + (LDS cursor of b)++] — any order inside
 //               a bucket will do, because the order that counts is restored by rank, not by stability
 //   rf_rows     one workgroup per bucket (~ 4 * 2^LB pairs): LDS counting sort by target -> the bucket's part of rcsr; then
-//               every pair ranks itself among the ~ f pairs of its row (p ascending) -> rpos[p].  A bucket that does not fit
-//               the LDS tables (never with uniform draws; forced by the tests through SERF_RF_CAP) ranks straight from l1.
+//               every pair ranks itself among the ~ f pairs of its row (p ascending) -> its place in rsrc.  A bucket that does
+//               not fit the LDS tables (never with uniform draws; forced by the tests through SERF_RF_CAP) ranks straight from l1.
 struct RfP {
   u64 rb;       // rng_base(seed, STREAM_RFAN, tick)
   u32 N, Nl, shard0, feff, f;
@@ -2147,34 +2230,19 @@ struct RfP {
   u32 SPW, NWG; // senders per workgroup of rf_count / rf_scatter, number of those workgroups
   u32 cap;      // pairs rf_rows can rank in LDS
 };
-#define RF_CAP_MAX 4096u
-#define RF_ROWS_MAX 1024u  // 2^LB <= this
-__device__ static inline u32 rf_draw(u64 rb, u32 gid, u32 N, u32 feff, u32 (&chosen)[SIM_MAX_FANOUT]) {
-  u32 nc = 0;
-  chosen[0] = chosen[1] = chosen[2] = chosen[3] = NOSLOT;
-  for (u32 i = 0; i < 3u * N && nc < feff; ++i) {
-    u32 t = (u32)(((mix64(rb ^ ((u64)gid * 4096u + i)) >> 32) * (u64)N) >> 32);
-    bool dup = t == gid;
-#pragma unroll
-    for (u32 j = 0; j < SIM_MAX_FANOUT; ++j) dup |= (j < nc) & (chosen[j] == t);
-    if (!dup) {
-      if (nc == 0) chosen[0] = t; else if (nc == 1) chosen[1] = t; else if (nc == 2) chosen[2] = t; else chosen[3] = t;
-      ++nc;
-    }
-  }
-  return nc;
-}
+#define RFB 1024          // threads of an rf_* workgroup
+#define RF_LB_MAX 12u     // at most 4096 rows per level-1 bucket
 __device__ static inline u32 rf_target_of(const RfP& r, u32 p) {  // the target of pair p = 4 l + k (it has one: it was scattered)
   u32 ch[SIM_MAX_FANOUT];
   rf_draw(r.rb, r.shard0 + (p >> 2), r.N, r.feff, ch);
   return SEL4(p & 3u, ch[0], ch[1], ch[2], ch[3]);
 }
-__global__ __launch_bounds__(BLOCK) void rf_count_kernel(RfP r, u32* ghist) {
+__global__ __launch_bounds__(RFB) void rf_count_kernel(RfP r, u32* ghist) {
   extern __shared__ u32 rf_lds[];  // [NB]
-  for (u32 b = threadIdx.x; b < r.NB; b += BLOCK) rf_lds[b] = 0;
+  for (u32 b = threadIdx.x; b < r.NB; b += RFB) rf_lds[b] = 0;
   __syncthreads();
   const u32 l0 = blockIdx.x * r.SPW;
-  for (u32 i = threadIdx.x; i < r.SPW && l0 + i < r.Nl; i += BLOCK) {
+  for (u32 i = threadIdx.x; i < r.SPW && l0 + i < r.Nl; i += RFB) {
     u32 ch[SIM_MAX_FANOUT];
     const u32 nc = rf_draw(r.rb, r.shard0 + l0 + i, r.N, r.feff, ch);
 #pragma unroll
@@ -2182,7 +2250,7 @@ __global__ __launch_bounds__(BLOCK) void rf_count_kernel(RfP r, u32* ghist) {
       if (k < nc) atomicAdd(&rf_lds[(ch[k] - r.shard0) >> r.LB], 1u);
   }
   __syncthreads();
-  for (u32 b = threadIdx.x; b < r.NB; b += BLOCK) ghist[(size_t)blockIdx.x * r.NB + b] = rf_lds[b];
+  for (u32 b = threadIdx.x; b < r.NB; b += RFB) ghist[(size_t)blockIdx.x * r.NB + b] = rf_lds[b];
 }
 // exclusive prefix over the 64 lanes of a wave (`total` = the sum)
 __device__ static inline u32 wave_excl_scan(u32 v, u32& total) {
@@ -2230,12 +2298,12 @@ __global__ __launch_bounds__(1024) void rf_bstart_kernel(RfP r, const u32* btot,
   for (u32 i = 0; i < per && b0 + i < r.NB; ++i) { bstart[b0 + i] = run; run += btot[b0 + i]; }
   if (threadIdx.x == 1023u) bstart[r.NB] = part[1023];
 }
-__global__ __launch_bounds__(BLOCK) void rf_scatter_kernel(RfP r, const u32* ghist, const u32* bstart, u32* l1, u32* rpos) {
+__global__ __launch_bounds__(RFB) void rf_scatter_kernel(RfP r, const u32* ghist, const u32* bstart, u32* l1) {
   extern __shared__ u32 rf_lds[];  // [NB] cursors
-  for (u32 b = threadIdx.x; b < r.NB; b += BLOCK) rf_lds[b] = 0;
+  for (u32 b = threadIdx.x; b < r.NB; b += RFB) rf_lds[b] = 0;
   __syncthreads();
   const u32 l0 = blockIdx.x * r.SPW;
-  for (u32 i = threadIdx.x; i < r.SPW && l0 + i < r.Nl; i += BLOCK) {
+  for (u32 i = threadIdx.x; i < r.SPW && l0 + i < r.Nl; i += RFB) {
     u32 ch[SIM_MAX_FANOUT];
     const u32 l = l0 + i, nc = rf_draw(r.rb, r.shard0 + l, r.N, r.feff, ch);
 #pragma unroll
@@ -2243,65 +2311,68 @@ __global__ __launch_bounds__(BLOCK) void rf_scatter_kernel(RfP r, const u32* ghi
       if (k < nc) {
         const u32 b = (ch[k] - r.shard0) >> r.LB;
         l1[bstart[b] + ghist[(size_t)blockIdx.x * r.NB + b] + atomicAdd(&rf_lds[b], 1u)] = 4u * l + k;
-      } else rpos[4u * l + k] = NOSLOT;  // a slot without a target (fewer other nodes than the fan-out): nothing is sent
+      }  // (a slot without a target — fewer other nodes than the fan-out — is in nobody's row)
     }
   }
 }
-__global__ __launch_bounds__(BLOCK) void rf_rows_kernel(RfP r, const u32* bstart, const u32* l1, u32* rcsr, u32* rpos) {
-  __shared__ u32 cnt[RF_ROWS_MAX + 1], cur[RF_ROWS_MAX];
-  __shared__ u32 ent_p[RF_CAP_MAX], rowp[RF_CAP_MAX];
-  __shared__ uint16_t ent_t[RF_CAP_MAX];
+// LDS of rf_rows (dynamic): cnt[R + 1] | cur[R] | rowp[cap] | ent_t[cap] (u16)
+static inline size_t rf_rows_lds(const RfP& r) { return ((size_t)(2u << r.LB) + 1u + r.cap) * 4u + (size_t)r.cap * 2u + 16u; }
+__global__ __launch_bounds__(RFB) void rf_rows_kernel(RfP r, const u32* bstart, const u32* l1, u32* rcsr, u32* rsrc) {
+  extern __shared__ u32 rf_lds[];
+  const u32 R = 1u << r.LB;
+  u32 *cnt = rf_lds, *cur = cnt + R + 1u, *rowp = cur + R;
+  uint16_t* ent_t = reinterpret_cast<uint16_t*>(rowp + r.cap);
+  __shared__ u32 wtot[RFB / 64u];
   const u32 b = blockIdx.x, base = bstart[b], n = bstart[b + 1] - base;
-  const u32 R = 1u << r.LB, t0 = b << r.LB, nrows = min(R, r.Nl - t0);
-  for (u32 i = threadIdx.x; i <= R; i += BLOCK) cnt[i] = 0;
+  const u32 t0 = b << r.LB, nrows = min(R, r.Nl - t0);
+  for (u32 i = threadIdx.x; i <= R; i += RFB) cnt[i] = 0;
   __syncthreads();
   const bool fits = n <= r.cap;
-  for (u32 i = threadIdx.x; i < n; i += BLOCK) {
-    const u32 p = l1[base + i], tl = rf_target_of(r, p) - r.shard0 - t0;
-    if (fits) { ent_p[i] = p; ent_t[i] = (uint16_t)tl; }
+  for (u32 i = threadIdx.x; i < n; i += RFB) {
+    const u32 tl = rf_target_of(r, l1[base + i]) - r.shard0 - t0;
+    if (fits) ent_t[i] = (uint16_t)tl;
     atomicAdd(&cnt[tl], 1u);
   }
   __syncthreads();
-  {  // exclusive prefix over the bucket's rows: every thread R / 256 consecutive ones (R is 256, 512 or 1024)
-    __shared__ u32 wtot[BLOCK / 64u];
-    const u32 per = R / BLOCK, i0 = threadIdx.x * per;
-    u32 v[RF_ROWS_MAX / BLOCK], sum = 0;
+  {  // exclusive prefix over the bucket's rows: every thread R / 1024 consecutive ones (R <= 4096; a smaller R: one each)
+    const u32 per = (R + RFB - 1u) / RFB, i0 = threadIdx.x * per;
+    u32 v[(1u << RF_LB_MAX) / RFB], sum = 0;
 #pragma unroll
-    for (u32 j = 0; j < RF_ROWS_MAX / BLOCK; ++j) { v[j] = j < per ? cnt[i0 + j] : 0u; sum += v[j]; }
+    for (u32 j = 0; j < (1u << RF_LB_MAX) / RFB; ++j) { v[j] = (j < per && i0 + j < R) ? cnt[i0 + j] : 0u; sum += v[j]; }
     u32 wsum, run = wave_excl_scan(sum, wsum);
     if ((threadIdx.x & 63u) == 0) wtot[threadIdx.x >> 6] = wsum;
     __syncthreads();
     for (u32 w = 0; w < (threadIdx.x >> 6); ++w) run += wtot[w];
 #pragma unroll
-    for (u32 j = 0; j < RF_ROWS_MAX / BLOCK; ++j)
-      if (j < per) { cnt[i0 + j] = run; run += v[j]; }
-    if (threadIdx.x == BLOCK - 1u) cnt[R] = run;
+    for (u32 j = 0; j < (1u << RF_LB_MAX) / RFB; ++j)
+      if (j < per && i0 + j < R) { cnt[i0 + j] = run; run += v[j]; }
+    if (threadIdx.x == RFB - 1u) cnt[R] = run;
   }
-  for (u32 i = threadIdx.x; i < R; i += BLOCK) cur[i] = 0;
+  for (u32 i = threadIdx.x; i < R; i += RFB) cur[i] = 0;
   __syncthreads();
-  for (u32 i = threadIdx.x; i < nrows; i += BLOCK) rcsr[t0 + i] = base + cnt[i];
+  for (u32 i = threadIdx.x; i < nrows; i += RFB) rcsr[t0 + i] = base + cnt[i];
   if (b == r.NB - 1u && threadIdx.x == 0) rcsr[r.Nl] = base + n;
   if (fits) {
-    for (u32 i = threadIdx.x; i < n; i += BLOCK) {
+    for (u32 i = threadIdx.x; i < n; i += RFB) {
       const u32 tl = ent_t[i];
-      rowp[cnt[tl] + atomicAdd(&cur[tl], 1u)] = ent_p[i];
+      rowp[cnt[tl] + atomicAdd(&cur[tl], 1u)] = l1[base + i];
     }
     __syncthreads();
-    for (u32 i = threadIdx.x; i < n; i += BLOCK) {
-      const u32 tl = ent_t[i], p = ent_p[i], lo = cnt[tl], hi = cnt[tl + 1];
+    for (u32 i = threadIdx.x; i < n; i += RFB) {
+      const u32 tl = ent_t[i], p = l1[base + i], lo = cnt[tl], hi = cnt[tl + 1];
       u32 rank = 0;
       for (u32 j = lo; j < hi; ++j) rank += rowp[j] < p ? 1u : 0u;
-      rpos[p] = base + lo + rank;
+      rsrc[base + lo + rank] = p;  // (inside the bucket's own window of the array: the workgroup's stores meet in L2)
     }
   } else {  // the bucket does not fit the tables: rank every pair against the whole bucket, straight from l1
-    for (u32 i = threadIdx.x; i < n; i += BLOCK) {
+    for (u32 i = threadIdx.x; i < n; i += RFB) {
       const u32 p = l1[base + i], tl = rf_target_of(r, p) - r.shard0 - t0;
       u32 rank = 0;
       for (u32 j = 0; j < n; ++j) {
         const u32 q = l1[base + j];
         rank += (q < p && rf_target_of(r, q) - r.shard0 - t0 == tl) ? 1u : 0u;
       }
-      rpos[p] = base + cnt[tl] + rank;
+      rsrc[base + cnt[tl] + rank] = p;
     }
   }
 }
@@ -3006,9 +3077,9 @@ __global__ void materialize_kernel(Dev d, TickP p, u32 cur, u32 valid, uint4* ou
     u32 kk = (u32)(i / d.Nl), l = (u32)(i - (size_t)kk * d.Nl), k = kk / d.PG, pg = kk - k * d.PG;
     uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a;
     if (d.rfan) {  // random fan-out: the canonical form is the oracle's — packets in the SENDER's cells, [slot][sender]
-      const u32 rp = valid ? d.rpos[cur][4u * l + k] : NOSLOT;  // (rpos of the tick they were sent in shares the packets' parity)
-      if (rp != NOSLOT) {
-        const uint4* cp = d.pbox[cur] + ((size_t)rp * d.PG + pg) * PK_U4;
+      const u32 jb = valid ? (d.obox[cur][(size_t)l * RF_CELL_U4 + 3u].x >> (8u * k)) & 0xFFu : 0xFFu;  // the map word sits in cell 0
+      if (jb != 0xFFu && pg <= (jb & 3u)) {
+        const uint4* cp = d.obox[cur] + ((size_t)((jb >> 2) + pg) * d.Nl + l) * RF_CELL_U4;
         a = cp[0]; b = cp[1]; c = cp[2];
       }
     } else if (valid && k < p.feff) {
@@ -3026,16 +3097,21 @@ __global__ void materialize_kernel(Dev d, TickP p, u32 cur, u32 valid, uint4* ou
 }
 __global__ void unmaterialize_kernel(Dev d, TickP p, u32 cur, u32 valid, const uint4* in) {
   for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < d.Nl; s += (size_t)gridDim.x * blockDim.x) {
-    if (d.rfan) {  // random fan-out: every packet back to its place in its target's row (rpos / rcsr of the sending tick: rebuilt by the caller)
+    if (d.rfan) {  // random fan-out: the image is sender-indexed already; every slot gets its own pages k * PG ..., the map word goes into cell 0
+      u32 jw = 0xFFFFFFFFu;
       for (u32 k = 0; valid && k < d.f; ++k) {
-        const u32 rp = d.rpos[cur][4u * (u32)s + k];
-        if (rp == NOSLOT) continue;
+        u32 np = 0;
         for (u32 pg = 0; pg < d.PG; ++pg) {
           const uint4* cp = in + ((size_t)(k * d.PG + pg) * d.Nl + s) * PK_U4;
-          uint4* op = d.pbox[cur] + ((size_t)rp * d.PG + pg) * PK_U4;
-          op[0] = cp[0]; op[1] = cp[1]; op[2] = cp[2];
+          uint4 a = cp[0], b = cp[1], c = cp[2];
+          if (((c.x | c.y | c.z | c.w) & 0xF0u) == 0) break;
+          uint4* op = d.obox[cur] + ((size_t)(k * d.PG + pg) * d.Nl + s) * RF_CELL_U4;
+          op[0] = a; op[1] = b; op[2] = c;
+          np = pg + 1;
         }
+        if (np) jw = (jw & ~(0xFFu << (8u * k))) | ((((k * d.PG) << 2) | (np - 1u)) << (8u * k));
       }
+      d.obox[cur][(size_t)s * RF_CELL_U4 + 3u] = make_uint4(jw, 0u, 0u, 0u);
       continue;
     }
     u32 jw = 0xFFFFFFFFu;
@@ -3132,6 +3208,15 @@ struct sim_handle {
   // SIM_CF_RANDOM_FANOUT: scratch of the per-tick graph build (rf_* kernels)
   u32 *rf_ghist, *rf_btot, *rf_bstart, *rf_l1;
   RfP rfp;  // the parameters that do not change from tick to tick
+  // The graph of tick s is a function of (seed, s): it is built on a stream of its own while tick s - 1 runs.  rf_rcsr[s % 3] /
+  // rf_rsrc[s % 3] = the rows of the packets SENT during tick s (tick s + 1 still reads them while the build of tick s + 2
+  // writes: three of each); rf_built = the tick whose graph has been enqueued on rf_stream (~0: none), rf_done marks it.
+  u32* rf_rcsr[3];
+  u32* rf_rsrc[3];
+  hipStream_t rf_stream;
+  hipEvent_t rf_done, rf_go[2];
+  u64 rf_built;
+  bool rf_sync;
 };
 
 #define HCHECK(x)                                                                        \
@@ -3224,6 +3309,9 @@ const char* sim_backend_name(void) { return "hip-gfx950"; }
 int sim_destroy(sim_handle* h) {
   if (!h) return SIM_EINVAL;
   (void)hipStreamSynchronize(h->stream);
+  if (h->rf_stream) { (void)hipStreamSynchronize(h->rf_stream); (void)hipStreamDestroy(h->rf_stream); }
+  if (h->rf_done) (void)hipEventDestroy(h->rf_done);
+  for (int i = 0; i < 2; ++i) if (h->rf_go[i]) (void)hipEventDestroy(h->rf_go[i]);
   for (auto& pr : h->prof) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (h->d_pp) (void)hipFree(h->d_pp);
   for (int i = 0; i < 3; ++i) {
@@ -3315,7 +3403,9 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   h->inbox_mat = nullptr;
   h->mat_tick = ~0ull;
   if (!d.sharded) {
-    if (!d.rfan) { DA(d.obox[0], (size_t)d.fp * Nl * PK_U4) DA(d.obox[1], (size_t)d.fp * Nl * PK_U4) DA(d.omap[0], Nl) DA(d.omap[1], Nl) }
+    const size_t cu4 = d.rfan ? RF_CELL_U4 : PK_U4;  // (random fan-out: 64-byte cells, the map word inside cell 0)
+    DA(d.obox[0], (size_t)d.fp * Nl * cu4) DA(d.obox[1], (size_t)d.fp * Nl * cu4)
+    if (!d.rfan) { DA(d.omap[0], Nl) DA(d.omap[1], Nl) }
     DA(h->inbox_mat, (size_t)d.fp * Nl * PK_U4)
   }
   DA(d.view, (size_t)d.A * Nl * 2)
@@ -3329,26 +3419,37 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   DA(h->d_mst, d.N)
   DA(h->d_mlt, d.N)
   DA(h->d_stats, 1)
-  d.rcsr[0] = d.rcsr[1] = d.rpos[0] = d.rpos[1] = nullptr;
-  d.pbox[0] = d.pbox[1] = nullptr;
+  d.rcsr = d.rsrc = nullptr;
+  for (int i = 0; i < 3; ++i) h->rf_rcsr[i] = h->rf_rsrc[i] = nullptr;
+  h->rf_stream = nullptr; h->rf_done = h->rf_go[0] = h->rf_go[1] = nullptr; h->rf_built = ~0ull;
   h->rf_ghist = h->rf_btot = h->rf_bstart = h->rf_l1 = nullptr;
   memset(&h->rfp, 0, sizeof h->rfp);
   if (d.rfan) {  // the fan-out graph as a CSR, rebuilt every tick, and the packets pushed into it (SIM_CF_RANDOM_FANOUT)
     const size_t np = (size_t)d.f * Nl;
     RfP& r = h->rfp;
     r.N = d.N; r.Nl = d.Nl; r.shard0 = d.shard0; r.f = d.f;
-    r.LB = 8;
-    while (((size_t)Nl + (1u << r.LB) - 1u) >> r.LB > 16384u) r.LB++;  // the level-1 histogram lives in 64 KiB of LDS
+    // level-1 buckets of 2^LB targets: the bigger they are, the longer the runs rf_scatter writes (a workgroup of SPW senders
+    // has 4 * SPW / NB pairs per bucket) and the more pairs one rf_rows workgroup ranks in LDS (~ 4 * 2^LB: 56 ... 152 KiB)
+    r.LB = 11;
+    if (const char* e = getenv("SERF_RF_LB")) r.LB = std::min<u32>(RF_LB_MAX, std::max<u32>(8u, (u32)strtoul(e, nullptr, 0)));
+    while (((size_t)Nl + (1u << r.LB) - 1u) >> r.LB > 4096u) r.LB++;  // the level-1 histogram: 16 KiB of LDS
+    if (r.LB > RF_LB_MAX) { sim_destroy(h); return SIM_EINVAL; }
     r.NB = (u32)(((size_t)Nl + (1u << r.LB) - 1u) >> r.LB);
     r.SPW = std::max<u32>(4096u, (u32)(((size_t)Nl + 255u) / 256u));
     r.NWG = (u32)(((size_t)Nl + r.SPW - 1u) / r.SPW);
-    r.cap = RF_CAP_MAX;
-    if (const char* e = getenv("SERF_RF_CAP")) r.cap = std::min<u32>(RF_CAP_MAX, (u32)strtoul(e, nullptr, 0));  // tests: force rf_rows' slow path
-    DA(d.rcsr[0], Nl + 1) DA(d.rcsr[1], Nl + 1) DA(d.rpos[0], 4 * Nl) DA(d.rpos[1], 4 * Nl)
-    DA(d.pbox[0], np * d.PG * PK_U4) DA(d.pbox[1], np * d.PG * PK_U4)
+    r.cap = (r.LB >= 12u ? 5u : 6u) << r.LB;  // mean 4 * 2^LB pairs, sigma 2 * 2^(LB/2): 32 sigma and more of room
+    if (const char* e = getenv("SERF_RF_CAP")) r.cap = std::min<u32>(r.cap, (u32)strtoul(e, nullptr, 0));  // tests: force rf_rows' slow path
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rf_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rf_rows_lds(r)) != hipSuccess) { sim_destroy(h); return SIM_EDEVICE; }
+    h->rf_sync = getenv("SERF_RF_SYNC") != nullptr;  // measurements: build on the tick's own stream, nothing overlaps
+    for (int i = 0; i < 3; ++i) { DA(h->rf_rcsr[i], Nl + 1) DA(h->rf_rsrc[i], np) }
     DA(h->rf_ghist, (size_t)r.NWG * r.NB) DA(h->rf_btot, r.NB) DA(h->rf_bstart, r.NB + 1) DA(h->rf_l1, np)
-    if (hipMemset(d.rcsr[0], 0, (Nl + 1) * 4) != hipSuccess || hipMemset(d.rcsr[1], 0, (Nl + 1) * 4) != hipSuccess ||
-        hipMemset(d.rpos[0], 0xFF, 4 * Nl * 4) != hipSuccess || hipMemset(d.rpos[1], 0xFF, 4 * Nl * 4) != hipSuccess) { sim_destroy(h); return SIM_EDEVICE; }
+    bool ok = true;
+    for (int i = 0; i < 3; ++i) ok = ok && hipMemset(h->rf_rcsr[i], 0, (Nl + 1) * 4) == hipSuccess;  // tick 0 receives nothing
+    ok = ok && hipStreamCreateWithFlags(&h->rf_stream, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&h->rf_done, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&h->rf_go[0], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&h->rf_go[1], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { sim_destroy(h); return SIM_EDEVICE; }
   }
 #undef DA
   bool joined = cfg->flags & SIM_CF_BASELINE_JOINED;
@@ -3370,6 +3471,9 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   if (!d.sharded && !d.rfan) {  // nothing has been sent yet
     HCHECK(zero(d.obox[0], (size_t)d.fp * Nl * sizeof(sim_packet))); HCHECK(zero(d.obox[1], (size_t)d.fp * Nl * sizeof(sim_packet)));
     HCHECK(hipMemsetAsync(d.omap[0], 0xFF, Nl * 4, s)); HCHECK(hipMemsetAsync(d.omap[1], 0xFF, Nl * 4, s));
+  }
+  if (d.rfan) {  // (all 0xFF: every map word says "nothing sent")
+    HCHECK(hipMemsetAsync(d.obox[0], 0xFF, (size_t)d.fp * Nl * RF_CELL_U4 * 16, s)); HCHECK(hipMemsetAsync(d.obox[1], 0xFF, (size_t)d.fp * Nl * RF_CELL_U4 * 16, s));
   }
   HCHECK(zero(d.view, (size_t)d.A * Nl * 32));
   HCHECK(zero(d.ering, (size_t)d.Bev * Nl * 32));
@@ -3845,20 +3949,19 @@ int sim_recycle_apply(sim_handle* h, const sim_recycle_cand* agreed, uint32_t n)
   h->recycle_at = (u32)h->tick;
   return rc;
 }
-// the fan-out graph of `tick` (random fan-out): rcsr[w] / rpos[w] := rows and places of the packets sent during `tick`
-static int rf_build(sim_handle* h, u64 tick, u32 w) {
-  Dev& d = h->d;
+// the fan-out graph of `tick` (random fan-out), on stream `s`: rf_rcsr / rf_rsrc [tick % 3] := the rows of the packets sent during `tick`
+static int rf_build(sim_handle* h, u64 tick, hipStream_t s) {
   RfP r = h->rfp;
   TickP tp;
   tickp_make(&tp, &h->cfg, tick);
   r.rb = rng_base(h->cfg.seed, STREAM_RFAN, tick);
   r.feff = tp.feff;
-  hipStream_t s = h->stream;
-  rf_count_kernel<<<r.NWG, BLOCK, r.NB * 4, s>>>(r, h->rf_ghist);
+  u32 *rcsr = h->rf_rcsr[tick % 3], *rsrc = h->rf_rsrc[tick % 3];
+  rf_count_kernel<<<r.NWG, RFB, r.NB * 4, s>>>(r, h->rf_ghist);
   rf_scan_kernel<<<(r.NB + BLOCK / 64 - 1) / (BLOCK / 64), BLOCK, 0, s>>>(r, h->rf_ghist, h->rf_btot);
   rf_bstart_kernel<<<1, 1024, 0, s>>>(r, h->rf_btot, h->rf_bstart);
-  rf_scatter_kernel<<<r.NWG, BLOCK, r.NB * 4, s>>>(r, h->rf_ghist, h->rf_bstart, h->rf_l1, d.rpos[w]);
-  rf_rows_kernel<<<r.NB, BLOCK, 0, s>>>(r, h->rf_bstart, h->rf_l1, d.rcsr[w], d.rpos[w]);
+  rf_scatter_kernel<<<r.NWG, RFB, r.NB * 4, s>>>(r, h->rf_ghist, h->rf_bstart, h->rf_l1);
+  rf_rows_kernel<<<r.NB, RFB, rf_rows_lds(r), s>>>(r, h->rf_bstart, h->rf_l1, rcsr, rsrc);
   HCHECK(hipGetLastError());
   return SIM_OK;
 }
@@ -3968,10 +4071,25 @@ int sim_step_begin(sim_handle* h) {
   // (sharded, C > 1): the pair brackets them with hipEventRecord.
   if (d.gttd && !d.rfan) gossip_skip_kernel<<<grid_for(d.Nl), BLOCK, 0, h->stream>>>(d, tp, h->d_base);  // whom not to gossip to this tick
   if (d.rfan) {
-    // kRandomNodes: the graph of THIS tick's packets — where every sender's packets go (rpos) and where every receiver will
-    // find them at tick + 1 (rcsr) — is built now, ahead of the tick kernel that pushes them
-    int rc = rf_build(h, h->tick, (u32)((h->tick + 1) & 1));
-    if (rc) return rc;
+    // kRandomNodes: the graph of the packets this tick RECEIVES — sent during tick - 1 — has to stand before the tick kernel
+    // reads it.  It was built on its own stream while the tick before ran (right after a restore, or with SERF_RF_SYNC: here
+    // and now); the graph of THIS tick's packets, which tick + 1 will read, is started as soon as everything enqueued so far
+    // has finished — it overwrites buffers the tick before this one read — and has this whole tick to get done.
+    if (h->tick > 0) {
+      if (h->rf_built == h->tick - 1) HCHECK(hipStreamWaitEvent(h->stream, h->rf_done, 0));
+      else if (h->rf_built != h->tick) { int rc = rf_build(h, h->tick - 1, h->stream); if (rc) return rc; }
+    }
+    d.rcsr = h->rf_rcsr[(h->tick + 2) % 3];  // (tick 0: a buffer of zeros — nothing has been sent)
+    d.rsrc = h->rf_rsrc[(h->tick + 2) % 3];
+    if (!h->rf_sync) {
+      hipEvent_t go = h->rf_go[h->tick & 1];
+      HCHECK(hipEventRecord(go, h->stream));
+      HCHECK(hipStreamWaitEvent(h->rf_stream, go, 0));
+      int rc = rf_build(h, h->tick, h->rf_stream);
+      if (rc) return rc;
+      HCHECK(hipEventRecord(h->rf_done, h->rf_stream));
+      h->rf_built = h->tick;
+    }
     if (d.gttd) {
       RfP r = h->rfp;
       r.rb = rng_base(h->cfg.seed, STREAM_RFAN, h->tick); r.feff = tp.feff;
@@ -4579,7 +4697,7 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
         tickp_make(&p, &h->cfg, hd.tick ? hd.tick - 1 : 0);
         // (random fan-out: back to their places in their targets' rows — the graph of the tick they were sent in is a
         // function of (seed, tick) and is built again first)
-        if (d.rfan && hd.tick && rf_build(h, hd.tick - 1, (u32)(hd.tick & 1)) != SIM_OK) rc = SIM_EDEVICE;
+        // (random fan-out: the graph of the packets in flight is a function of (seed, tick - 1): sim_step_begin builds it again)
         unmaterialize_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, p, (u32)(hd.tick & 1), hd.tick ? 1u : 0u, h->inbox_mat);
       }
       RCHECK(hipGetLastError());
@@ -4610,6 +4728,7 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
   h->recycle_at = 0xFFFFFFFFu;
   h->pp_done_at = 0xFFFFFFFFu;
   h->op_cursor = 0;
+  h->rf_built = ~0ull;
   return SIM_OK;
 }
 int sim_query_status(sim_handle* h, uint32_t qid, uint64_t* acks, uint64_t* responses, int* open) {

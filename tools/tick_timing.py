@@ -8,7 +8,7 @@ import serf_amd
 from serf_amd import _ffi
 lib = _ffi.SimLib(os.path.join(os.path.dirname(serf_amd.LIB_PATH), "libserf_sim_timing.so"))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
-args = bench.parse_args(["--nodes-per-gpu", str(n)])
+args = bench.parse_args(["--nodes-per-gpu", str(n)] + sys.argv[2:])  # e.g. --random-fanout
 kw, ops = bench.workload(args, n)
 sim = _ffi.Sim(lib, _ffi.make_config(n, **kw))
 for o in ops:
