@@ -625,7 +625,7 @@ __device__ static void q_renorm(Node& n, SK sk) {
 
 // Park a broadcast request; phase 2 of the tick queues them in this order (queue_broadcast order
 // is arrival order, and no handler looks at the queue, so deferring is exact).
-__device__ static inline void pend_push(const Ctx& c, Node& n, const Ins& q) {
+__device__ static __forceinline__ void pend_push(const Ctx& c, Node& n, const Ins& q) {
   if (n.npend >= c.d.npend) { n.overflow++; n.dirty |= DR2; return; }  // cannot happen (npend is the per-tick maximum); never write past the array
   c.d.pend[(size_t)n.npend * c.d.Nl + c.l] = make_uint4(q.key, q.wmeta, (u32)q.val, (u32)(q.val >> 32));
   n.npend++;
@@ -1178,7 +1178,7 @@ __device__ static inline u64 pin_uniform(const void* p) {
   u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(uintptr_t)p), hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)((uintptr_t)p >> 32));
   return ((u64)hi << 32) | lo;
 }
-__device__ static inline uint4* lookup_ptr(const Ctx& c, u64 vbase, u64 eoff, u64 qoff, u32 kind, u32 key, u64 val, u32 slot) {
+__device__ static __forceinline__ uint4* lookup_ptr(const Ctx& c, u64 vbase, u64 eoff, u64 qoff, u32 kind, u32 key, u64 val, u32 slot) {
   const Dev& d = c.d;
   bool isq = kind == SIM_K_QUERY, isring = isq || kind == SIM_K_EVENT;
   u32 B = isq ? d.Bq : d.Bev, mask = isq ? d.bq_mask : d.bev_mask;
@@ -1192,7 +1192,7 @@ __device__ static inline uint4* lookup_ptr(const Ctx& c, u64 vbase, u64 eoff, u6
   return none ? nullptr : p;
 }
 // slot of a member record's subject (NOSLOT for other kinds and for ids out of range)
-__device__ static inline u32 slot_load(const Dev& d, u32 kind, u32 key) {
+__device__ static __forceinline__ u32 slot_load(const Dev& d, u32 kind, u32 key) {
   u32 s = NOSLOT;
   if (member_kind(kind) && key < d.N) s = d.slot_of[key];
   return s;
@@ -1278,7 +1278,7 @@ __device__ static void queue_check(const Ctx& c, Node& n, SK sk) {
 // which is the fate of ~95 % of all records; the caller then applies the witness and is done.
 // Anything else (a new rumour, a refutation, a confirmation...) is left to the full handlers.
 // The conditions are the early `return false` exits of the handlers, in the handlers' order.
-__device__ static inline bool fast_noop(const Ctx& c, const Node& n, u32 kind, const uint4& r, bool has, const uint4& e) {
+__device__ static __forceinline__ bool fast_noop(const Ctx& c, const Node& n, u32 kind, const uint4& r, bool has, const uint4& e) {
   // Straight-line predicate logic (& and |, no ?: on booleans, no short-circuit): this runs for
   // every record of every node, and the lane masks combine on the scalar unit.
   const Dev& d = c.d;
@@ -1306,13 +1306,13 @@ __device__ static inline bool fast_noop(const Ctx& c, const Node& n, u32 kind, c
 // A record can be retired without a handler when it is a no-op (fast_noop) that does not even advance the Lamport
 // clock it witnesses (it has been seen before: the common duplicate).  The property survives whatever the handlers of
 // earlier records do to the node — clocks and incarnations only grow — as long as they leave the record's own entry alone.
-__device__ static inline bool fast_retire(const Ctx& c, const Node& n, u32 kind, const uint4& r, bool has, const uint4& e) {
+__device__ static __forceinline__ bool fast_retire(const Ctx& c, const Node& n, u32 kind, const uint4& r, bool has, const uint4& e) {
   u64 lt = (u64)r.z | ((u64)r.w << 32);
   bool adv = ((kind == SIM_K_EVENT) & (lt >= n.eclock)) | ((kind == SIM_K_QUERY) & (lt >= n.qclock)) |
              (((kind - SIM_K_JOIN) < 2u) & (lt >= n.clock));
   return fast_noop(c, n, kind, r, has, e) & !adv;
 }
-__device__ static inline void dispatch(const Ctx& c, Node& n, const uint4& r, uint4* p, uint4& e, bool& dirty, Ins& ins) {
+__device__ static __forceinline__ void dispatch(const Ctx& c, Node& n, const uint4& r, uint4* p, uint4& e, bool& dirty, Ins& ins) {
   u32 kind = SIM_META_KIND(r.y), flags = SIM_META_FLAGS(r.y);
   u64 val = (u64)r.z | ((u64)r.w << 32);
   bool rb = false;
@@ -1355,6 +1355,8 @@ static u32 g_ablate = 0;
 // A record between its 16-byte working form {key, wire meta, val} and its 12 bytes in a packet (include/serf_sim.h
 // sim_packet: key, value bits 31..0, value bits 47..32 | len64 | kind | flags; SUSPECT / DEAD carry inc : 24 | from : 24)
 #define PK_U4 3u  // a packet cell is three uint4: the four keys, the four low words, the four high words
+#define RF_TMAX 512u   // random fan-out, balanced classification: incoming packets of one wave's 64 nodes the LDS tables hold (mean 256)
+#define RF_STASH 128u  // ... and records in need of a handler whose unpacked form and entry pointer are kept for it (mean 46)
 #define RF_CELL_U4 4u  // random fan-out: a sender's cell is 64 bytes — the packet's 48 and, in cell 0, the sender's map word (slot -> cell): entry -> cell is ONE scattered line
 __device__ static inline uint4 wire_unpack(u32 key, u32 lo, u32 hm) {
   u32 meta = (((hm >> 8) & 0x3Fu) << 18) | (hm & 0xFFu), hi = hm >> 16;
@@ -1491,14 +1493,24 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   const uint4* cell;
   u32 om0 = 0xFFFFFFFFu, om1 = 0xFFFFFFFFu, om2 = 0xFFFFFFFFu, om3 = 0xFFFFFFFFu;
   u32 rf_npk = 0;  // RF: packets the wave walks (the most any lane received)
+  // RF, one page per packet: BALANCED classification (below) when the whole wave is here and its packets fit the LDS tables
+  bool bal = false;   // (wave-uniform)
+  u32 rb_base = 0, rb_T = 0;
   if (RF) {
-    rf_e = rcnt > 0 ? d.rsrc[rin0] : NOSLOT;
-    rf_en = rcnt > 1 ? d.rsrc[rin0 + 1] : NOSLOT;
-    cell = cell_of(0, 0);
     u32 w = rcnt;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) w = max(w, (u32)__shfl_xor((int)w, o, 64));
     rf_npk = w;
+    if (!MP && (bx + 1u) * TBLOCK <= cnt) {
+      rb_base = (u32)__builtin_amdgcn_readfirstlane((int)rin0);
+      rb_T = (u32)__builtin_amdgcn_readlane((int)(rin0 + rcnt), 63) - rb_base;
+      bal = rb_T <= RF_TMAX && !ABL(2) && !ABL(64);
+    }
+    if (MP) {
+      rf_e = rcnt > 0 ? d.rsrc[rin0] : NOSLOT;
+      rf_en = rcnt > 1 ? d.rsrc[rin0 + 1] : NOSLOT;
+    }
+    cell = MP ? cell_of(0, 0) : d.nullcell;
   } else if (SHARDED) cell = tp.first ? d.nullcell : cell_of(0, 0);
   else {
     // (the four senders first, then the four loads back to back from selected addresses: a load inside a branch gets
@@ -1522,9 +1534,187 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   }
   bool up = n.flags & SIM_RF_UP;
   TT(0);
+  // ---- RF: balanced classification.  With a random in-degree a node-per-lane deliver loop runs as often as the wave's
+  // busiest node has packets (9.4 times at 1 Mi nodes, fan-out 4) at 4 / 9.4 of its lanes — and the loop is issue-bound.  But
+  // the wave's packets are ONE run of the tick's CSR (its nodes' rows, back to back): here lane j takes packet base + 64 r + j,
+  // whoever it is for — 4.2 rounds at full width — and judges its four records against the OWNER's clocks (staged in LDS) the
+  // way the deliver loop's fast path does.  What that leaves (~5 % of the records: a new rumour, a refutation ...) is noted per
+  // packet (LDS: a mask and, for member records, a hash of the subject) with the unpacked record and its entry pointer in a
+  // stash; then every node walks the notes of ITS packets in arrival order and runs the handlers (phase 1 below: one record
+  // per lane and iteration, its entry read afresh).  Exact because a record judged to change nothing — not even a clock — at
+  // the start of the tick still changes nothing at its turn: clocks and incarnations only grow, ring buckets only gain keys,
+  // and a member entry is only ever written by a handler of a record about the same subject — such a later record is sent
+  // through the handlers as well (the hash, conservatively).
+  // (A wave that is not all here — the last one of a ragged shard — or whose packets do not fit the tables — clusters of a few
+  // nodes — skips the classification: every record of every packet goes through the handlers, which is always right.)
+  u64 rb_need = 0;  // records of this node's packets 0 .. 15 that need a handler: bit 4 k + q
+  if (RF && !MP && !bal) rb_need = rcnt >= 16u ? ~0ull : (1ull << (4u * rcnt)) - 1ull;
+  if (RF && !MP && bal) {
+    u32* const sum = reinterpret_cast<u32*>(&lds_r[0][0]);          // [RF_TMAX] slow mask | 4 x 6-bit subject hash (0: not a member record)
+    uint8_t* const own = reinterpret_cast<uint8_t*>(&lds_p[0][0]);  // [RF_TMAX] the lane a packet is for
+    uint8_t* const sidx = own + RF_TMAX;                            // [RF_TMAX] first stash entry of the packet's slow records (0xFF: none)
+    u64* const st_p = reinterpret_cast<u64*>(own + 2 * RF_TMAX);    // [RF_STASH] entry pointers
+    uint4* const nst = &lds_e[0][0];                                // [64][2] the nodes' clocks, flags, incarnation as the tick begins
+    uint4* const st_r = &lds_e[2][0];                               // [RF_STASH] unpacked records
+    static_assert(2 * RF_TMAX + 8 * RF_STASH <= SIM_P * TBLOCK * 8 && RF_TMAX * 4 <= SIM_P * TBLOCK * 16 && RF_STASH <= 2 * TBLOCK, "LDS overlay");
+    const u32 rown = rin0 - rb_base;
+#pragma unroll 1
+    for (u32 i = 0; i < rf_npk; ++i)
+      if (i < rcnt) own[rown + i] = (uint8_t)tid;
+    nst[2 * tid] = make_uint4((u32)n.eclock, (u32)(n.eclock >> 32), (u32)n.qclock, (u32)(n.qclock >> 32));
+    nst[2 * tid + 1] = make_uint4((u32)n.clock, (u32)(n.clock >> 32), n.flags, n.inc);
+    __builtin_amdgcn_wave_barrier();
+    TT(1);
+    u32 nstash = 0;  // (wave-uniform)
+    const u32 l0 = l - tid, g0 = gid - tid;
+    const u64 lt_mask = (1ull << tid) - 1ull;
+    u32 ea = tid < rb_T ? d.rsrc[rb_base + tid] : NOSLOT, eb = 64u + tid < rb_T ? d.rsrc[rb_base + 64u + tid] : NOSLOT;
+    const uint4* cp = ea == NOSLOT ? d.nullcell : d.obox[cur] + (size_t)(ea >> 2) * RF_CELL_U4;
+    uint4 a0 = ld4(cp), a1 = ld4(cp + 1), a2 = ld4(cp + 2);
+    u32 am = reinterpret_cast<const u32*>(cp)[12];
+#pragma unroll 1
+    for (u32 c0 = 0; c0 < rb_T; c0 += 64u) {
+      const u32 cc = c0 + tid, e = ea;
+      const bool live = cc < rb_T;
+      u32 jb = e == NOSLOT ? 0xFFu : (am >> (8u * (e & 3u))) & 0xFFu;
+      uint4 ck = a0, cl = a1, ch = a2;
+      if (jb == 0xFFu) ck = cl = ch = zero;
+      const bool far = jb != 0xFFu && (jb >> 2) != 0u;  // not the sender's cell 0 (1 % of the packets)
+      if (__any(far)) {
+        const uint4* c2 = far ? d.obox[cur] + ((size_t)(jb >> 2) * d.Nl + (e >> 2)) * RF_CELL_U4 : d.nullcell;
+        const uint4 b0 = ld4(c2), b1 = ld4(c2 + 1), b2 = ld4(c2 + 2);
+        if (far) { ck = b0; cl = b1; ch = b2; }
+      }
+      // the next round's cell is asked for behind this round's slot-map loads, the entry of the round after it right away
+      ea = eb;
+      eb = c0 + 128u + tid < rb_T ? d.rsrc[rb_base + c0 + 128u + tid] : NOSLOT;
+      cp = ea == NOSLOT ? d.nullcell : d.obox[cur] + (size_t)(ea >> 2) * RF_CELL_U4;
+      auto prefetch = [&]() __attribute__((always_inline)) { a0 = ld4(cp); a1 = ld4(cp + 1); a2 = ld4(cp + 2); am = reinterpret_cast<const u32*>(cp)[12]; };
+      if (!__any(((ch.x | ch.y | ch.z | ch.w) & 0xF0u) != 0)) {  // nothing in any of the round's packets
+        prefetch();
+        if (live) { sum[cc] = 0; sidx[cc] = 0xFFu; }
+        continue;
+      }
+      const u32 k0 = SIM_META_KIND(ch.x), k1 = SIM_META_KIND(ch.y), k2 = SIM_META_KIND(ch.z), k3 = SIM_META_KIND(ch.w);
+      const u32 s0 = slot_load(d, k0, ck.x), s1 = slot_load(d, k1, ck.y), s2 = slot_load(d, k2, ck.z), s3 = slot_load(d, k3, ck.w);
+      prefetch();
+      const uint4 r0 = wire_unpack(ck.x, cl.x, ch.x), r1 = wire_unpack(ck.y, cl.y, ch.y);
+      const uint4 r2 = wire_unpack(ck.z, cl.z, ch.z), r3 = wire_unpack(ck.w, cl.w, ch.w);
+      const u32 o = live ? (u32)own[cc] : 0u;
+      const Ctx co{d, l0 + o, g0 + o, (u32)tp.tick, tp.query_base};
+      uint4* const p0 = lookup_ptr(co, vbase, eoff, qoff, k0, r0.x, (u64)r0.z | ((u64)r0.w << 32), s0);
+      uint4* const p1 = lookup_ptr(co, vbase, eoff, qoff, k1, r1.x, (u64)r1.z | ((u64)r1.w << 32), s1);
+      uint4* const p2 = lookup_ptr(co, vbase, eoff, qoff, k2, r2.x, (u64)r2.z | ((u64)r2.w << 32), s2);
+      uint4* const p3 = lookup_ptr(co, vbase, eoff, qoff, k3, r3.x, (u64)r3.z | ((u64)r3.w << 32), s3);
+      const uint4 e0 = ld4(p0 ? p0 : d.nullcell), e1 = ld4(p1 ? p1 : d.nullcell), e2 = ld4(p2 ? p2 : d.nullcell), e3 = ld4(p3 ? p3 : d.nullcell);
+      const uint4 na = nst[2 * o], nb = nst[2 * o + 1];
+      Node no;
+      no.eclock = (u64)na.x | ((u64)na.y << 32); no.qclock = (u64)na.z | ((u64)na.w << 32);
+      no.clock = (u64)nb.x | ((u64)nb.y << 32); no.flags = nb.z; no.inc = nb.w;
+      u32 m = (fast_retire(co, no, k0, r0, p0 != nullptr, e0) ? 0u : 1u) | (fast_retire(co, no, k1, r1, p1 != nullptr, e1) ? 0u : 2u) |
+              (fast_retire(co, no, k2, r2, p2 != nullptr, e2) ? 0u : 4u) | (fast_retire(co, no, k3, r3, p3 != nullptr, e3) ? 0u : 8u);
+      if (!live || !(no.flags & SIM_RF_UP)) m = 0;  // (packets for a process that is down are dropped)
+      auto hsh = [](u32 kind, u32 key) __attribute__((always_inline)) -> u32 { return member_kind(kind) ? ((key * 0x9E3779B1u) >> 27) + 1u : 0u; };
+      const u32 note = m | (hsh(k0, r0.x) << 4) | (hsh(k1, r1.x) << 10) | (hsh(k2, r2.x) << 16) | (hsh(k3, r3.x) << 22);
+      // stash entries for the slow records: a prefix sum of popcount(m) over the lanes, from three ballots
+      const u32 pm = (u32)__popc(m);
+      const u64 q0 = __ballot(pm & 1u), q1 = __ballot(pm & 2u), q2 = __ballot(pm & 4u);
+      const u32 first = nstash + (u32)__popcll(q0 & lt_mask) + 2u * (u32)__popcll(q1 & lt_mask) + 4u * (u32)__popcll(q2 & lt_mask);
+      nstash += (u32)__popcll(q0) + 2u * (u32)__popcll(q1) + 4u * (u32)__popcll(q2);
+      const bool keep = m != 0u && first + pm <= RF_STASH;
+      if (keep) {
+        u32 j = first;
+        if (m & 1u) { st_r[j] = r0; st_p[j] = (u64)(uintptr_t)p0; ++j; }
+        if (m & 2u) { st_r[j] = r1; st_p[j] = (u64)(uintptr_t)p1; ++j; }
+        if (m & 4u) { st_r[j] = r2; st_p[j] = (u64)(uintptr_t)p2; ++j; }
+        if (m & 8u) { st_r[j] = r3; st_p[j] = (u64)(uintptr_t)p3; ++j; }
+      }
+      if (live) { sum[cc] = note; sidx[cc] = keep ? (uint8_t)first : (uint8_t)0xFFu; }
+      TCNT(13, 1);  // rounds that looked anything up
+    }
+    __builtin_amdgcn_wave_barrier();
+    TT(2);
+    TCNT(14, nstash);  // records left for the handlers by the classification
+    // every node over the notes of its own packets, in arrival order: a member record about a subject that an earlier record
+    // in need of a handler is about needs one too
+    u64 hot = 0;
+    const u32 wmax = min(rf_npk, 16u);
+#pragma unroll 1
+    for (u32 i = 0; i < wmax; ++i) {
+      if (i < rcnt) {
+        const u32 sn = sum[rown + i];
+        u32 m = sn & 15u;
+#pragma unroll
+        for (u32 q = 0; q < SIM_P; ++q) {
+          const u32 hq = (sn >> (4u + 6u * q)) & 63u;
+          if (hq && ((hot >> hq) & 1ull)) m |= 1u << q;
+          if (hq && ((m >> q) & 1u)) hot |= 1ull << hq;
+        }
+        rb_need |= (u64)m << (4u * i);
+      }
+    }
+    TT(3);
+  }
   // ---- phase 1: deliver.  The queue is not touched: handlers park their broadcasts in d.pend.
   if (up && !ABL(2)) {
-    if (!SHARDED || !tp.first) {
+    if (RF && !MP) {
+      // the records the balanced pass left for the handlers, in arrival order, one per lane and iteration
+      const u32* const sum = reinterpret_cast<const u32*>(&lds_r[0][0]);
+      const uint8_t* const sidx = reinterpret_cast<const uint8_t*>(&lds_p[0][0]) + RF_TMAX;
+      const u64* const st_p = reinterpret_cast<const u64*>(reinterpret_cast<const uint8_t*>(&lds_p[0][0]) + 2 * RF_TMAX);
+      const uint4* const st_r = &lds_e[2][0];
+      const u32 rown = rin0 - rb_base;
+      // a record that was not stashed (a later record about a subject of an earlier one; a stash that ran full; a packet
+      // beyond a node's sixteenth): entry -> cell -> slot map, on the spot
+      auto reload = [&](u32 k, u32 q, uint4& r, uint4*& ptr) __attribute__((always_inline)) {
+        const u32 ent = d.rsrc[rin0 + k], snd = ent >> 2;
+        const u32 mp = reinterpret_cast<const u32*>(d.obox[cur] + (size_t)snd * RF_CELL_U4)[12];
+        const u32 jb = (mp >> (8u * (ent & 3u))) & 0xFFu;
+        r = make_uint4(0, 0, 0, 0);
+        ptr = nullptr;
+        if (jb != 0xFFu) {
+          const u32* cw = reinterpret_cast<const u32*>(d.obox[cur] + ((size_t)(jb >> 2) * d.Nl + snd) * RF_CELL_U4);
+          r = wire_unpack(cw[q], cw[4u + q], cw[8u + q]);
+          const u32 kind = SIM_META_KIND(r.y);
+          ptr = lookup_ptr(c, vbase, eoff, qoff, kind, r.x, (u64)r.z | ((u64)r.w << 32), slot_load(d, kind, r.x));
+        }
+      };
+      auto run = [&](const uint4& r, uint4* ptr) __attribute__((always_inline)) {
+        uint4 e = ld4(ptr ? ptr : d.nullcell);
+        Ins ins;
+        ins.has = ins.wide = 0;
+        bool dirty = false;
+        dispatch(c, n, r, ptr, e, dirty, ins);
+        if (ins.has) pend_push(c, n, ins);
+      };
+      // (packets beyond a node's sixteenth — never at any realistic size — have no bits in rb_need: every record of theirs goes
+      // through the handlers, after the others, by way of the cursor xcur = 4 k + q)
+      u32 xcur = 64u;
+      const u32 xend = rcnt > 16u ? 4u * rcnt : 0u;
+#pragma unroll 1
+      while (!ABL(32) && __any(rb_need != 0 || xcur < xend)) {
+        TCNT(12, 1);
+        u32 bit = NOSLOT;
+        if (rb_need) { bit = (u32)__ffsll((unsigned long long)rb_need) - 1u; rb_need &= rb_need - 1ull; }
+        else if (xcur < xend) bit = xcur++;
+        if (bit != NOSLOT) {
+          const u32 k = bit >> 2, q = bit & 3u;
+          const bool noted = bal && k < 16u;
+          const u32 m0 = noted ? sum[rown + k] & 15u : 0u, si = noted ? (u32)sidx[rown + k] : 0xFFu;
+          const bool st = ((m0 >> q) & 1u) && si != 0xFFu;
+          uint4 r;
+          uint4* ptr;
+          if (st) {
+            const u32 j = si + (u32)__popc(m0 & ((1u << q) - 1u));
+            r = st_r[j];
+            ptr = (uint4*)(__attribute__((address_space(1))) uint4*)st_p[j];
+          } else reload(k, q, r, ptr);
+          TCNT(15, __popcll(__ballot(!st)));  // records fetched again (not stashed)
+          if (SIM_META_KIND(r.y) != SIM_K_EMPTY) run(r, ptr);
+        }
+      }
+      TT(5);
+    } else if (!SHARDED || !tp.first) {  // (not compiled into the RF one-page instantiation: it has ONE site that calls the handlers)
       // the pages of the f packets, in order: packet k's page 0, 1, ... then packet k + 1 (one page each unless MP)
       u32 k = 0, pg = 0, wnp = wave_np(0);
       const u32 npk = RF ? rf_npk : d.f;  // packets to walk

@@ -25,6 +25,16 @@ tot = sum(buf[:12])
 for i, nm in enumerate(names):
     print(f"{nm:44s} {buf[i]/waves:10.0f} cyc/wave  {100*buf[i]/tot:5.1f}%")
 print(f"{'total':44s} {tot/waves:10.0f} cyc/wave (clock ticks of s_memtime / readcyclecounter)")
+rf = "--random-fanout" in sys.argv
+if rf:
+    names[1:6] = ["RF: owner table + node state to LDS", "RF: balanced rounds (cell, slot map, heads, classify, stash)", "RF: every node over its packets' notes", "-", "RF: handlers, one record per lane and iteration"]
+    print("(random fan-out: rows 2 - 6 are the balanced classification and the handler loop)")
+    for i, nm in enumerate(names[:6]):
+        print(f"{nm:60s} {buf[i]/waves:10.0f} cyc/wave  {100*buf[i]/tot:5.1f}%")
+    for i, nm in ((13, "balanced rounds with records, per wave and tick"), (12, "handler iterations per wave and tick"),
+                  (14, "records left for the handlers, per wave and tick"), (15, "of those, fetched again (not stashed)")):
+        print(f"{nm:60s} {buf[i]/waves:8.2f}")
+    sys.exit(0)
 for i, nm in ((13, "pages with records, per wave and tick"), (15, "... whose handler loop ran"), (12, "handler-loop iterations per wave and tick"),
               (14, "lanes with a slow record, per wave and tick (sum over pages)")):
     print(f"{nm:60s} {buf[i]/waves:8.2f}")
