@@ -2,8 +2,11 @@
 """bench.py — member-ticks/sec of the bulk SWIM/Serf gossip hot path on MI355X.
 
 A "step" is one gossip tick of every simulated node.  N=1: BASELINE.json configs[2]
-(1 Mi nodes, fan-out 4, HBM-roofline report).  N>1: one shard of 1 Mi nodes per GPU (weak
-scaling), the round's RCCL all-to-all issued chunk-wise and overlapped with compute.  Prints ONE JSON line on rank 0.
+(1 Mi nodes, fan-out 4, HBM-roofline report), measured on BOTH fan-out models in one run: the HEADLINE (`value`,
+`ms_per_step`, `roofline`) is memberlist's literal kRandomNodes peer selection — the reference's —,
+the per-tick bijection (every node receives exactly `fanout` packets) is reported next to it under `fanout_models`.
+N>1: one shard of 1 Mi nodes per GPU (weak scaling), the round's RCCL all-to-all issued chunk-wise and overlapped
+with compute (bijection: the random fan-out is not sharded yet).  Prints ONE JSON line on rank 0.
 
 `python bench.py --gpus N` without a launcher (WORLD_SIZE unset) starts its N ranks itself (one process per GPU,
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set for them, rendezvous on 127.0.0.1) and supervises them: a rank that dies
@@ -42,15 +45,21 @@ def b_tick_layout(f):
     return 2 * 64 + (2 * 16 * 4 + 4 * 16) + (48 + 4) + f * (48 + 4) + f * 4 * (4 + 16)
 
 
-PMC_TRAFFIC = ("profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")  # newest first
+PMC_TRAFFIC = {"krandomnodes": ("profiles/r04_pmc_traffic_krandomnodes.json",),  # newest first
+               "bijection": ("profiles/r04_pmc_traffic_bijection.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")}
+LONG_WINDOW = 300  # ticks of the second timed window (with --steps < 300): long enough to hold a push-pull batch and recycling passes
 KERNEL_SOURCE = os.path.join("serf_amd", "csrc", "serf_sim.hip")
 # rounds-to-99 %: every user event the workload issues in CONV_WINDOW ticks starting CONV_OFFSET ticks after the
 # pre-roll (at most CONV_RUMOURS of them), each followed for at most CONV_MAX_ROUNDS rounds
 CONV_RUMOURS, CONV_MAX_ROUNDS, CONV_OFFSET, CONV_WINDOW = 64, 60, 400, 480
 
 
+def long_window(args):
+    return LONG_WINDOW if args.steps < LONG_WINDOW else 0
+
+
 def conv_start_tick(args):
-    return args.preroll + max(CONV_OFFSET, args.warmup + args.steps)
+    return args.preroll + max(CONV_OFFSET, args.warmup + args.steps + long_window(args))
 
 
 def horizon(args):
@@ -58,8 +67,10 @@ def horizon(args):
     return (h + 39) // 40 * 40
 
 
-def workload(args, n_total):
+def workload(args, n_total, model=None):
     """(config kwargs, operation schedule) of the benchmark — the same for the GPU run and the CPU baseline."""
+    if model is None:  # (the tools: one model, by flag)
+        model = "krandomnodes" if getattr(args, "fanout_model", "both") == "krandomnodes" else "bijection"
     from serf_amd import workload as wl
 
     kw = dict(fanout=args.fanout, view_slots=args.view_slots, event_ring=args.ring, query_ring=args.ring,
@@ -68,7 +79,7 @@ def workload(args, n_total):
               recycle_interval=args.recycle_interval)
     if getattr(args, "pkt_records", 4) != 4:
         kw["pkt_records"] = args.pkt_records
-    if getattr(args, "random_fanout", False):  # memberlist's literal kRandomNodes instead of the per-tick bijection (one GPU)
+    if model == "krandomnodes":  # memberlist's literal kRandomNodes instead of the per-tick bijection (one GPU)
         from serf_amd import _ffi
         kw["flags"] = _ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT
     ops = wl.schedule(n_total, horizon(args), rate=args.rate, seed=3, mix=wl.BENCH_MIX,
@@ -83,11 +94,11 @@ def kernel_source_sha16():
         return None
 
 
-def measured_traffic():
-    """HBM bytes per tick-kernel launch from the newest committed PMC profile — valid only for the kernel source it was
-    measured on (the profile records the source's hash; a file without one is treated as stale)."""
+def measured_traffic(model):
+    """HBM bytes per tick-kernel launch from the newest committed PMC profile of that fan-out model — valid only for the
+    kernel source it was measured on (the profile records the source's hash; a file without one is treated as stale)."""
     sha = kernel_source_sha16()
-    for rel in PMC_TRAFFIC:
+    for rel in PMC_TRAFFIC[model]:
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
             continue
@@ -103,19 +114,20 @@ def measured_traffic():
     return None, None
 
 
-def cpu_baseline(args, parity_tick, seconds_budget=240.0):
-    """The CPU oracle ("port") on the SAME configuration and schedule as the N=1 GPU run (rank 0 only): rolled through
-    the same ticks up to `parity_tick` (= the first timed tick of the GPU run), where its state digest is taken for the
-    parity block, then a bounded number of timed ticks on all cores and a few on one thread.  When the host cannot hold
-    the configuration (it needs ~64 KiB of address space per node, a fraction of it resident) it falls back to a smaller
-    cluster, says so, and the parity block is void."""
+def cpu_baseline(args, model, parity_ticks, timed=True, seconds_budget=300.0):
+    """The CPU oracle ("port") on the SAME configuration, fan-out model and schedule as the N=1 GPU run (rank 0 only): rolled
+    through the same ticks; its state digest is taken at every tick of `parity_ticks` (the first timed tick of the GPU run
+    and the tick right after its last timed one) for the parity block.  With `timed`, the ticks of the timed region — at most
+    32 of them — are timed on all cores, and 8 more on one thread behind the last parity tick.  When the host cannot hold the
+    configuration (it needs ~64 KiB of address space per node, a fraction of it resident) it falls back to a smaller cluster,
+    says so, and the parity block is void."""
     from serf_amd import _ffi
 
     lib = _ffi.SimLib(os.path.join(ROOT, "oracle", "liboracle.so"), prefix="osim_")  # test infrastructure: the checker, timed
     n = args.nodes_per_gpu
     note = ""
     while True:
-        kw, ops = workload(args, n)
+        kw, ops = workload(args, n, model)
         try:
             sim = _ffi.Sim(lib, _ffi.make_config(n, **kw))
             break
@@ -129,37 +141,53 @@ def cpu_baseline(args, parity_tick, seconds_budget=240.0):
     cores = int(lib.dll.osim_t_threads())
     t0 = time.perf_counter()
     rolled = 0
-    while rolled < parity_tick:  # untimed, like the GPU run's pre-roll + warm-up — never shortened
-        k = min(5, parity_tick - rolled)
-        sim.step(k)
-        rolled += k
-        if time.perf_counter() - t0 > seconds_budget:
-            raise SystemExit(f"bench.py: the CPU oracle needed more than {seconds_budget:.0f} s for {rolled} of {parity_tick} pre-roll ticks "
-                             "on this host — cpu_baseline would not be timing the GPU's ticks; rerun with --no-cpu-baseline or a smaller --preroll")
+    first, last = parity_ticks[0], parity_ticks[-1]
+
+    def roll(to):
+        nonlocal rolled
+        while rolled < to:  # untimed, like the GPU run's pre-roll + warm-up — never shortened
+            k = min(5, to - rolled)
+            sim.step(k)
+            rolled += k
+            if time.perf_counter() - t0 > seconds_budget:
+                raise SystemExit(f"bench.py: the CPU oracle needed more than {seconds_budget:.0f} s for {rolled} of {last} ticks "
+                                 "on this host — cpu_baseline would not be timing the GPU's ticks; rerun with --no-cpu-baseline or a smaller --preroll")
+
+    roll(first)
     t_roll = time.perf_counter() - t0
-    digest = sim.digest() if n == args.nodes_per_gpu else None
-    ticks_all, ticks_one = 32, 8
-    t1 = time.perf_counter()
-    done = 0
-    while done < ticks_all and time.perf_counter() - t1 < 20.0:
-        sim.step(4)
-        done += 4
-    dt = time.perf_counter() - t1
-    lib.dll.osim_t_set_threads(1)  # SURVEY.md §8d asks for both legs
-    t2 = time.perf_counter()
-    done1 = 0
-    while done1 < ticks_one and time.perf_counter() - t2 < 15.0:
-        sim.step(1)
-        done1 += 1
-    dt1 = time.perf_counter() - t2
-    lib.dll.osim_t_set_threads(0)
-    drops = sim.cluster_stats()["overflow"]
+    digests = {first: sim.digest() if n == args.nodes_per_gpu else None}
+    done, dt = 0, 0.0
+    if timed:  # the first ticks of the GPU's timed region, on all cores
+        ticks_all = min(32, last - first)
+        t1 = time.perf_counter()
+        while done < ticks_all and time.perf_counter() - t1 < 20.0:
+            k = min(4, ticks_all - done)
+            sim.step(k)
+            done += k
+        dt = time.perf_counter() - t1
+        rolled += done
+    for t in parity_ticks[1:]:
+        roll(t)
+        digests[t] = sim.digest() if n == args.nodes_per_gpu else None
+    res = None
+    if timed:
+        lib.dll.osim_t_set_threads(1)  # SURVEY.md §8d asks for both legs
+        t2 = time.perf_counter()
+        done1 = 0
+        while done1 < 8 and time.perf_counter() - t2 < 15.0:
+            sim.step(1)
+            done1 += 1
+        dt1 = time.perf_counter() - t2
+        lib.dll.osim_t_set_threads(0)
+        drops = sim.cluster_stats()["overflow"]
+        res = {"value": n * done / dt, "unit": "member-ticks/s", "cores": cores, "kind": "port",
+               "single_thread_value": n * done1 / dt1, "fanout_model": model,
+               "sample": f"same configuration, fan-out model ({model}) and schedule as the GPU run{note}: {n} nodes, view_slots {args.view_slots}, "
+                         f"rings {args.ring}, fan-out {args.fanout}; {first} untimed pre-roll ticks ({t_roll:.1f} s), then ticks {first}..{first + done - 1} "
+                         f"timed on {cores} threads (OpenMP over nodes), on to tick {last} for the second parity digest, and {done1} more on one "
+                         f"thread; model_bound_drops {drops}"}
     sim.close()
-    return {"value": n * done / dt, "unit": "member-ticks/s", "cores": cores, "kind": "port",
-            "single_thread_value": n * done1 / dt1,
-            "sample": f"same configuration and schedule as the GPU run{note}: {n} nodes, view_slots {args.view_slots}, rings {args.ring}, "
-                      f"fan-out {args.fanout}; {rolled} untimed pre-roll ticks ({t_roll:.1f} s), then ticks {rolled}..{rolled + done - 1} timed on "
-                      f"{cores} threads (OpenMP over nodes) and {done1} more on one thread; model_bound_drops {drops}"}, digest
+    return res, digests
 
 
 def second_load(args, lib, dev, torch):
@@ -217,9 +245,15 @@ def parse_args(argv=None):
     ap.add_argument("--push-pull-interval", type=int, default=150, help="memberlist push_pull_interval in ticks before log2(N) scaling (0 = off)")
     ap.add_argument("--recycle-interval", type=int, default=75, help="view-slot recycling pass every this many ticks (0 = never)")
     ap.add_argument("--second-rate", type=float, default=0.35, help="API operations per tick of the second measured load (16 records per packet)")
-    ap.add_argument("--random-fanout", action="store_true",
-                    help="gossip targets by memberlist's literal kRandomNodes (uniform, variable in-degree; the tick's fan-out graph as an explicit "
-                         "CSR built by a per-tick sort) instead of the per-tick bijection — a fidelity mode, not the headline (N = 1 only)")
+    ap.add_argument("--fanout-model", choices=["both", "krandomnodes", "bijection"], default="both",
+                    help="N = 1: which fan-out model(s) to measure.  both (default): memberlist's literal kRandomNodes — the reference's peer "
+                         "selection, the HEADLINE — and the per-tick bijection next to it (fanout_models)")
+    ap.add_argument("--random-fanout", action="store_true", help="shorthand for --fanout-model krandomnodes")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="N = 1: run the cluster as ONE shard through the sharded path (ShardedSim, exchange buffers, the round's all-to-all "
+                         "over the collective library) — a one-rank rehearsal of the N > 1 line")
+    ap.add_argument("--exchange", choices=["auto", "torch", "rccl"], default="auto",
+                    help="sharded runs: who issues the round's all-to-all — the library itself over RCCL (sim_exchange_*), or torch.distributed")
     ap.add_argument("--no-second-load", action="store_true", help="skip the second measured load (N = 1: 16 records per packet at --second-rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence", action="store_true", help="skip the rounds-to-99 %% measurement (profiling runs)")
@@ -232,7 +266,12 @@ def parse_args(argv=None):
     ap.add_argument("--watchdog", type=float, default=120.0,
                     help="N > 1: seconds without progress after which a rank gives up (a JSON line with \"error\" on rank 0, exit code 3)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched N > 1 run: seconds the supervisor waits for its ranks")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.random_fanout:
+        a.fanout_model = "krandomnodes"
+    if a.force_sharded:
+        a.fanout_model = "bijection"
+    return a
 
 
 class Progress:
@@ -256,6 +295,14 @@ class Progress:
                                           value=None)), flush=True)
                 sys.stderr.write(f"bench.py rank {self.rank}: watchdog: stuck in '{self.what}'\n")
                 os._exit(3)
+
+
+MODEL_WHAT = {
+    "krandomnodes": "memberlist's literal kRandomNodes (uniform targets over the other nodes, no replacement: Poisson-like in-degree; the "
+                    "tick's fan-out graph an explicit CSR, built per tick by the library's own bucket sort) — the REFERENCE's peer selection",
+    "bijection": "per-tick pseudo-random bijection (every node sends `fanout` packets AND receives exactly `fanout`): an implicit, "
+                 "coalescing-friendly fan-out graph — not the reference's peer selection",
+}
 
 
 def run(args, lib=None, dev=None, backend="nccl"):
@@ -283,8 +330,12 @@ def run(args, lib=None, dev=None, backend="nccl"):
             local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:  # a world of one rank: the N > 1 path (ShardedSim, exchange buffers, the collective library) on one GPU
+            os.environ.setdefault("MASTER_PORT", "29577")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         progress("init_process_group")
         if on_gpu:
             dist.init_process_group(backend, device_id=dev)
@@ -295,35 +346,26 @@ def run(args, lib=None, dev=None, backend="nccl"):
     n_total = args.nodes_per_gpu * world
     if lib is None:
         lib = serf_amd.load()
-    kw, ops = workload(args, n_total)
-    progress("create")
+    # which fan-out models: both at N = 1 (the reference's first: it is the headline), the bijection alone when sharded
     if world > 1:
-        sim = ShardedSim(lib, n_total, dev, chunks=args.chunks, **kw)
+        models = ["bijection"]
+    elif args.fanout_model == "both":
+        models = ["krandomnodes", "bijection"]
     else:
-        sim = _ffi.Sim(lib, _ffi.make_config(n_total, **kw))
-        if on_gpu:
-            sim.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-    raw = sim.sim if world > 1 else sim
+        models = [args.fanout_model]
+    sharded = world > 1 or args.force_sharded
 
-    def step(k):
-        # (a heartbeat every few ticks: a long pre-roll is progress, a stuck collective is not)
-        while k > 0:
-            j = min(k, 20)
-            sim.step(j)
-            progress(f"step (tick {raw.tick})")
-            k -= j
+    class _HostEvent:  # CPU stand-in for torch.cuda.Event in the plumbing test
+        def __init__(self, enable_timing=True):
+            self.t = 0.0
 
-    for t, op, node, a, b in ops:
-        sim.inject(t, op, node, a, b)
+        def record(self):
+            self.t = time.perf_counter()
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        if on_gpu:
-            torch.cuda.synchronize()
-        else:
-            raw.sync()
-        progress("barrier")
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+
+    Event = torch.cuda.Event if on_gpu else _HostEvent
 
     def allsum(vals):
         if world == 1:
@@ -339,227 +381,311 @@ def run(args, lib=None, dev=None, backend="nccl"):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return int(t[0])
 
-    def load_now():  # cluster-wide load: records per packet in flight, queue entries per node, model-bound drops
-        if world > 1:
-            sim.sync()  # the round's exchanges have landed
-        cs = raw.cluster_stats()
-        inbox, queued, drops, up, mxq = allsum([cs["inbox_records"], sum(cs["queued"]), cs["overflow"], cs["up"], 0])
-        # operations skipped for want of a view slot are counted on the (replicated) schedule, the same on every rank
-        return {"records_per_packet": inbox / (args.fanout * n_total), "queued_per_node": queued / n_total,
-                "drops": drops + int(cs["ops_dropped"]), "up": up, "slots_in_use": int(cs["slots_in_use"]),
-                "slots_recycled": int(cs["slots_recycled"]), "max_queue": allmax(cs["max_queue"])}
+    def measure(model):
+        """One cluster on one fan-out model: pre-roll, warm-up, the timed K steps, the long window, rounds-to-99 %."""
+        kw, ops = workload(args, n_total, model)
+        progress(f"create ({model})")
+        if sharded:
+            sim = ShardedSim(lib, n_total, dev, chunks=args.chunks, exchange=args.exchange, **kw)
+        else:
+            sim = _ffi.Sim(lib, _ffi.make_config(n_total, **kw))
+            if on_gpu:
+                sim.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        raw = sim.sim if sharded else sim
 
-    class _HostEvent:  # CPU stand-in for torch.cuda.Event in the plumbing test
-        def __init__(self, enable_timing=True):
-            self.t = 0.0
+        def step(k):
+            # (a heartbeat every few ticks: a long pre-roll is progress, a stuck collective is not)
+            while k > 0:
+                j = min(k, 20)
+                sim.step(j)
+                progress(f"step (tick {raw.tick})")
+                k -= j
 
-        def record(self):
-            self.t = time.perf_counter()
+        for t, op, node, a, b in ops:
+            sim.inject(t, op, node, a, b)
 
-        def elapsed_time(self, other):
-            return (other.t - self.t) * 1e3
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            if on_gpu:
+                torch.cuda.synchronize()
+            else:
+                raw.sync()
+            progress("barrier")
 
-    Event = torch.cuda.Event if on_gpu else _HostEvent
+        def load_now():  # cluster-wide load: records per packet in flight, queue entries per node, model-bound drops
+            if sharded:
+                sim.sync()  # the round's exchanges have landed
+            cs = raw.cluster_stats()
+            inbox, queued, drops, up, mxq = allsum([cs["inbox_records"], sum(cs["queued"]), cs["overflow"], cs["up"], 0])
+            # operations skipped for want of a view slot are counted on the (replicated) schedule, the same on every rank
+            return {"records_per_packet": inbox / (args.fanout * n_total), "queued_per_node": queued / n_total,
+                    "drops": drops + int(cs["ops_dropped"]), "up": up, "slots_in_use": int(cs["slots_in_use"]),
+                    "slots_recycled": int(cs["slots_recycled"]), "max_queue": allmax(cs["max_queue"])}
 
-    # ---- untimed: pre-roll to the stationary load, then the contract's warm-up ----
-    trace = []
-    done = 0
-    while done < args.preroll:
-        k = min(40, args.preroll - done)
-        step(k)
-        done += k
-        trace.append(round(load_now()["records_per_packet"], 3))
-    step(args.warmup)
-    barrier()
-    load0 = load_now()
-    # parity block: the state the timed region starts from, digested (all 8 arrays); rank 0's cpu_baseline() rolls the
-    # oracle through the same schedule to the same tick and compares
-    parity_tick = args.preroll + args.warmup
-    want_parity = world == 1 and not args.no_cpu_baseline
-    gpu_digest = raw.digest() if want_parity else None
-    # an event pair costs ~10 us of stream time: time a sample of the launches on long runs, all of them on short ones
-    profile_every = 4 if args.steps >= 100 else 1
-    raw.profile(profile_every)
-    barrier()
-    # ---- timed: exactly K steps between two barriers.  The launches go to torch's current stream
-    # (sim_set_stream above), so one pair of torch events brackets them as well.
-    t0 = time.perf_counter()
-    ev0, ev1 = Event(enable_timing=True), Event(enable_timing=True)
-    ev0.record()
-    sim.step(args.steps)
-    ev1.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-    (prof_ms, prof_min, prof_max), prof_n = raw.profile_read_stats()
-    raw.profile(False)
-    load1 = load_now()
-    # N > 1 diagnosis, outside the timed region: the same ticks with every all-to-all bracketed by events and run
-    # synchronously (no overlap) — what one round's exchange costs on its own, next to the kernel
-    exchange_ms, diag_ticks = None, 20
-    if world > 1:
+        def timed(k, profile_every):
+            """exactly k steps between two barriers; the launches go to torch's current stream (sim_set_stream above), so one
+            pair of torch events brackets them as well"""
+            raw.profile(profile_every)
+            barrier()
+            t0 = time.perf_counter()
+            ev0, ev1 = Event(enable_timing=True), Event(enable_timing=True)
+            ev0.record()
+            sim.step(k)
+            ev1.record()
+            barrier()
+            dt = time.perf_counter() - t0
+            ev_ms = ev0.elapsed_time(ev1)
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t[0])
+            (ms, mn, mx), cnt = raw.profile_read_stats()
+            raw.profile(False)
+            kern_s = ms / 1e3 / max(1, cnt) if ms > 0 else ev_ms / 1e3 / k  # (the oracle behind a CPU test has no kernel)
+            return {"dt": dt, "ev_ms": ev_ms, "kern_s": kern_s, "kmin": mn, "kmax": mx, "kn": int(cnt), "every": profile_every}
+
+        m = {"model": model, "ops": ops}
+        # ---- untimed: pre-roll to the stationary load, then the contract's warm-up ----
+        trace = []
+        done = 0
+        while done < args.preroll:
+            k = min(40, args.preroll - done)
+            step(k)
+            done += k
+            trace.append(round(load_now()["records_per_packet"], 3))
+        step(args.warmup)
         barrier()
-        sim.time_exchange(True)
-        td0 = time.perf_counter()
-        step(diag_ticks)
-        barrier()
-        serial_ms = (time.perf_counter() - td0) * 1e3 / diag_ticks
-        exchange_ms = sim.time_exchange(False) / diag_ticks
+        m["trace"] = trace
+        m["load0"] = load_now()
+        # parity block: the state the timed region starts from and the state it ends in, digested (all 8 arrays); rank 0's
+        # cpu_baseline() rolls the oracle through the same schedule to the same ticks and compares
+        m["parity_ticks"] = [args.preroll + args.warmup, args.preroll + args.warmup + args.steps]
+        want_parity = world == 1 and not args.no_cpu_baseline
+        m["digests"] = {}
+        if want_parity:
+            m["digests"][m["parity_ticks"][0]] = raw.digest()
+        # an event pair costs ~10 us of stream time: time a sample of the launches on long runs, all of them on short ones
+        m["timed"] = timed(args.steps, 4 if args.steps >= 100 else 1)
+        if want_parity:
+            m["digests"][m["parity_ticks"][1]] = raw.digest()
+        m["load1"] = load_now()
+        # second window: 300 further ticks timed the same way — push-pull batch (every 300) and recycling passes (every 75) inside
+        m["long"] = timed(long_window(args), 4) if long_window(args) else None
+        # N > 1 diagnosis, outside the timed region: the same ticks with every all-to-all bracketed by events and run
+        # synchronously (no overlap) — what one round's exchange costs on its own, next to the kernel
+        m["exchange_ms"], diag_ticks = None, 20
+        if sharded:
+            barrier()
+            sim.time_exchange(True)
+            td0 = time.perf_counter()
+            step(diag_ticks)
+            barrier()
+            m["serial_ms"] = (time.perf_counter() - td0) * 1e3 / diag_ticks
+            m["exchange_ms"] = sim.time_exchange(False) / diag_ticks
+            m["diag_ticks"] = diag_ticks
+            m["chunks"] = sim.chunks
+            m["exchange_bytes"] = raw.exchange_bytes()
+            m["collectives"] = sim.collective_library()
+        # ---- second half of the metric: rounds to 99 % convergence of the workload's OWN user events (no extra load),
+        # every one issued in a fixed window of ticks, all outstanding ones polled with one launch per tick
+        rounds, conv_first, conv_last = [], None, None
+        if not args.no_convergence:
+            c0 = conv_start_tick(args)
+            step(c0 - raw.tick)
+            evs = [(t, node, a) for (t, op, node, a, b) in ops if op == _ffi.OP_USER_EVENT and c0 <= t < c0 + CONV_WINDOW][:CONV_RUMOURS]
+            by_tick = {}
+            for t, node, key in evs:
+                by_tick.setdefault(t, []).append((node, key))
+            outstanding = {}  # key -> (ltime, tick issued)
+            last = (max(by_tick) if by_tick else c0) + CONV_MAX_ROUNDS
+            while raw.tick <= last and (outstanding or raw.tick <= (max(by_tick) if by_tick else c0)):
+                t = raw.tick
+                bump = {}
+                for node, key in by_tick.get(t, ()):  # the Lamport time the event is going to get: its origin's event clock now
+                    owner = node // args.nodes_per_gpu
+                    lt = allmax(raw.stats(node).event_time if owner == rank else 0) + bump.get(node, 0)
+                    bump[node] = bump.get(node, 0) + 1
+                    outstanding[key] = (lt, t)
+                step(1)
+                keys = list(outstanding)
+                if keys:
+                    seen, up = sim.convergence_many([(_ffi.K_EVENT, k, outstanding[k][0]) for k in keys])
+                    for k, sn in zip(keys, seen):
+                        r = raw.tick - outstanding[k][1]
+                        if sn * 100 >= up * 99 or r > CONV_MAX_ROUNDS:
+                            rounds.append(r)
+                            del outstanding[k]
+            rounds += [CONV_MAX_ROUNDS + 1] * len(outstanding)
+            conv_first, conv_last = c0, raw.tick
+        m["rounds"], m["conv"] = rounds, (conv_first, conv_last)
+        m["load2"] = load_now()
+        raw.close()  # two clusters need not sit next to each other (66 GB each at 1 Mi nodes)
+        return m
 
-    # ---- second half of the metric: rounds to 99 % convergence of the workload's OWN user events (no extra load),
-    # every one issued in a fixed window of ticks, all outstanding ones polled with one launch per tick
-    rounds, conv_first, conv_last = [], None, None
-    if not args.no_convergence:
-        c0 = conv_start_tick(args)
-        step(c0 - raw.tick)
-        evs = [(t, node, a) for (t, op, node, a, b) in ops if op == _ffi.OP_USER_EVENT and c0 <= t < c0 + CONV_WINDOW][:CONV_RUMOURS]
-        by_tick = {}
-        for t, node, key in evs:
-            by_tick.setdefault(t, []).append((node, key))
-        outstanding = {}  # key -> (ltime, tick issued)
-        last = (max(by_tick) if by_tick else c0) + CONV_MAX_ROUNDS
-        while raw.tick <= last and (outstanding or raw.tick <= (max(by_tick) if by_tick else c0)):
-            t = raw.tick
-            bump = {}
-            for node, key in by_tick.get(t, ()):  # the Lamport time the event is going to get: its origin's event clock now
-                owner = node // args.nodes_per_gpu
-                lt = allmax(raw.stats(node).event_time if owner == rank else 0) + bump.get(node, 0)
-                bump[node] = bump.get(node, 0) + 1
-                outstanding[key] = (lt, t)
-            step(1)
-            keys = list(outstanding)
-            if keys:
-                seen, up = sim.convergence_many([(_ffi.K_EVENT, k, outstanding[k][0]) for k in keys])
-                for k, s in zip(keys, seen):
-                    r = raw.tick - outstanding[k][1]
-                    if s * 100 >= up * 99 or r > CONV_MAX_ROUNDS:
-                        rounds.append(r)
-                        del outstanding[k]
-        rounds += [CONV_MAX_ROUNDS + 1] * len(outstanding)
-        conv_first, conv_last = c0, raw.tick
-    load2 = load_now()
-    out = None
-    if rank == 0:
-        value = n_total * args.steps / dt
+    def roofline_of(m):
+        """the `roofline` object of one measured cluster (dominant kernel = tick_kernel: one launch per tick; HIP events around
+        the launches of the timed region, sim_profile)"""
+        model, t = m["model"], m["timed"]
         bt, bt2 = b_tick_v0(args.fanout), b_tick_layout(args.fanout)
-        # dominant kernel = tick_kernel: one launch per tick; HIP events around the launches of the timed
-        # region (sim_profile); ev_ms (everything on the stream, ops + push-pull included) for reference
-        kern_s = prof_ms / 1e3 / max(1, prof_n) if prof_ms > 0 else ev_ms / 1e3 / args.steps  # (the oracle behind a CPU test has no kernel)
+        kern_s = t["kern_s"]
         algorithmic = args.nodes_per_gpu * bt / kern_s / 1e9
         layout = args.nodes_per_gpu * bt2 / kern_s / 1e9
-        traffic, prov = measured_traffic()
-        default_load = args.pkt_records == 4 and args.rate == 0.25 and args.nodes_per_gpu == 1 << 20 and world == 1 and not args.random_fanout
+        traffic, prov = measured_traffic(model)
+        default_load = args.pkt_records == 4 and args.rate == 0.25 and args.nodes_per_gpu == 1 << 20 and world == 1
         # (the bytes a launch moves follow the load of the ticks it covers: the profile's figure is this run's only when the
         # same ticks are timed)
         same_ticks = bool(prov) and prov["timed_ticks_of_the_profile"] == {"steps": args.steps, "warmup": args.warmup}
         # `achieved` / `frac` follow the measurement contract: ALGORITHMIC bytes per launch (SURVEY.md §8d's per-member-tick
-        # figure x the nodes one launch processes) over the kernel's average launch duration.  That figure counts f copies of
-        # every packet, which this kernel does not write: what is actually on the pins is `traffic` (PMC counters, when they
-        # were collected on this kernel source, load and timed ticks) and `measured` = traffic over the same duration — the
-        # number to read as bandwidth.
-        achieved = algorithmic
-        basis = ("the contract's formula: SURVEY.md §8d algorithmic bytes per member-tick x nodes per launch / average launch duration; "
-                 "bytes actually moved: roofline.traffic, roofline.measured (PMC counters) — or roofline.layout when no PMC profile of this "
-                 "kernel source, load and timed ticks is on file")
+        # figure x the nodes one launch processes) over the kernel's average launch duration.  What is actually on the pins is
+        # `traffic` (PMC counters, when they were collected on this kernel source, fan-out model, load and timed ticks) and
+        # `frac_measured` = traffic over the same duration over the 8 TB/s peak — the number to read as bandwidth.
         if traffic and prov["matches_this_kernel"] and default_load and same_ticks:
             measured = {"achieved": traffic / kern_s / 1e9, "frac": traffic / kern_s / 1e9 / 8000.0, "unit": "GB/s",
                         "what": "HBM bytes per launch measured with rocprofv3 PMC counters on this kernel source (roofline.traffic) / average launch duration"}
         else:
             traffic = None  # a figure measured on another kernel source (or another load) is not this run's traffic
             measured = None
+        every = t["every"]
+        out = {"bound": "hbm", "achieved": algorithmic, "peak": 8000.0, "unit": "GB/s", "frac": algorithmic / 8000.0,
+               "frac_measured": measured["frac"] if measured else None, "traffic": traffic, "measured": measured,
+               "achieved_from": "the contract's formula: SURVEY.md §8d algorithmic bytes per member-tick x nodes per launch / average launch "
+                                "duration; bytes actually moved: roofline.traffic and roofline.frac_measured (PMC counters) — null when no "
+                                "PMC profile of this kernel source, fan-out model, load and timed ticks is on file",
+               "kernel": "tick_kernel", "kernel_ms": kern_s * 1e3, "kernel_ms_min": t["kmin"], "kernel_ms_max": t["kmax"],
+               "kernel_launches": t["kn"],
+               "kernel_timing": f"HIP event pair on every {every}{'th' if every > 1 else 'st'} tick_kernel dispatch of the timed region "
+                                "(hipExtLaunchKernelGGL start/stop events, on the launch stream)",
+               "stream_ms_per_step": t["ev_ms"] / args.steps,
+               "algorithmic": {"b_tick_bytes": bt, "achieved": algorithmic, "frac": algorithmic / 8000.0,
+                               "what": "SURVEY.md §8d B_tick(f) = 2R + 2QE + 2fPE + 4(f+2) x nodes / kernel time"},
+               "traffic_over_algorithmic": (traffic / (args.nodes_per_gpu * bt)) if traffic else None,
+               "traffic_provenance": prov}
+        if model == "bijection":
+            out["layout"] = {"b_tick_bytes": bt2, "achieved": layout, "frac": layout / 8000.0,
+                             "what": "the same accounting for the bijection's frozen layout (DESIGN.md §4): packets kept at the sender"}
+        else:
+            out["graph_build"] = ("the fan-out graph of a tick (rf_count / rf_scan / rf_bstart / rf_scatter / rf_rows: ~0.11 ms at 1 Mi nodes, on a "
+                                  "stream of its own) is part of ms_per_step and of `value`, not of kernel_ms: profiles/r04_kernel_stats_krandomnodes.csv")
+        return out
+
+    def rounds_of(m):
+        rounds, (conv_first, conv_last) = m["rounds"], m["conv"]
+        if not rounds:
+            return None
+        return {"median": float(np.median(rounds)), "p90": float(np.percentile(rounds, 90)), "max": int(max(rounds)),
+                "min": int(min(rounds)), "mean": float(np.mean(rounds)), "n": len(rounds),
+                "histogram": {str(r): int(c) for r, c in zip(*np.unique(rounds, return_counts=True))},
+                "window_ticks": [conv_first, conv_last], "fanout_model": m["model"],
+                "parity": "memberlist half (queue order and limit, peer selection, loss) is parity-UNPINNED: DESIGN.md §6",
+                "what": "gossip rounds until >= 99 % of running nodes have applied a user event, for every user event the workload itself "
+                        f"issues in ticks [{conv_first}, {conv_first + CONV_WINDOW}) (a fixed window: independent of --steps / --warmup), "
+                        "all outstanding events polled once per tick (sim_convergence_many)"}
+
+    def summary_of(m):
+        t, lw = m["timed"], m["long"]
+        d = {"what": MODEL_WHAT[m["model"]], "value": n_total * args.steps / t["dt"], "unit": "member-ticks/s",
+             "ms_per_step": t["dt"] / args.steps * 1e3, "kernel_ms": t["kern_s"] * 1e3, "roofline": roofline_of(m),
+             "rounds_to_99": rounds_of(m), "model_bound_drops": m["load2"]["drops"],
+             "records_per_packet": [round(m["load0"]["records_per_packet"], 3), round(m["load1"]["records_per_packet"], 3)],
+             "deepest_queue": m["load1"]["max_queue"]}
+        if lw:
+            d["long_window"] = {"steps": long_window(args), "value": n_total * long_window(args) / lw["dt"], "ms_per_step": lw["dt"] / long_window(args) * 1e3,
+                                "kernel_ms": lw["kern_s"] * 1e3, "kernel_ms_max": lw["kmax"],
+                                "ticks": [m["parity_ticks"][1], m["parity_ticks"][1] + long_window(args) - 1],
+                                "what": "the ticks right behind the timed region, measured the same way: a push-pull batch (every 300 ticks at this "
+                                        "size) and the recycling passes (every 75) fall inside"}
+        return d
+
+    res = {}
+    for model in models:
+        res[model] = measure(model)
+    out = None
+    drops = sum(res[mo]["load2"]["drops"] for mo in models)
+    if rank == 0:
+        head = res[models[0]]
+        t = head["timed"]
+        live = "about 10 rumours live at any time (0.41 new ones per tick, each alive ~20 ticks) — SURVEY.md §8d's config 3 asks for 1 024, which neither " \
+               "the reference's 1 400-byte packets (~220) nor this model's 16-slot queue (~12) can carry at this size (DESIGN.md §7)"
         out = {
-            "metric": "member-ticks/sec", "value": value, "unit": "member-ticks/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "metric": "member-ticks/sec", "value": n_total * args.steps / t["dt"], "unit": "member-ticks/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": t["dt"] / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": f"{n_total} nodes ({args.nodes_per_gpu}/GPU), fan-out {args.fanout}, "
-                                   f"{args.rate} API ops/tick evenly spaced, mix (0.55, 0.2, 0.15, 0.05, 0.05) of (user event, query, leave, crash+remove, crash+revive) evenly interleaved, "
-                                   f"{args.pkt_records} records per packet, " + ("gossip targets by memberlist's literal kRandomNodes (--random-fanout), " if args.random_fanout else "") +
-                                   f"view_slots {args.view_slots}, rings {args.ring}, probe interval {args.probe_interval} ticks, push-pull interval "
+            "config": {"workload": f"{n_total} nodes ({args.nodes_per_gpu}/GPU), fan-out {args.fanout}; HEADLINE fan-out model: {models[0]} — {MODEL_WHAT[models[0]]}"
+                                   + (f" (the other model, {models[1]}, under fanout_models)" if len(models) > 1 else "") + "; "
+                                   f"{args.rate} API ops/tick evenly spaced, mix (0.55, 0.2, 0.15, 0.05, 0.05) of (user event, query, leave, crash+remove, crash+revive) evenly interleaved: {live}; "
+                                   f"{args.pkt_records} records per packet, view_slots {args.view_slots}, rings {args.ring}, probe interval {args.probe_interval} ticks, push-pull interval "
                                    f"{args.push_pull_interval} ticks (x log2 scaling), reaper and queue checker on — BASELINE configs[2]; "
-                                   f"{args.preroll} untimed pre-roll ticks under the same load before the warm-up (steady state)",
-                       "parallelism": (f"node-id range shards x{world}, {args.chunks} chunk-wise all_to_all_single per tick, overlapped with compute"
-                                       if world > 1 else "single GPU"),
+                                   f"{args.preroll} untimed pre-roll ticks under the same load before the warm-up (steady state); the timed region is the "
+                                   f"{args.steps} ticks the driver asks for (not SURVEY §8d's 1 000)"
+                                   + (f", the {long_window(args)} ticks behind it are measured as well (long_window)" if long_window(args) else ""),
+                       "fanout_model": models[0],
+                       "parallelism": (f"node-id range shards x{world}, {args.chunks} chunk-wise all-to-all per tick, overlapped with compute"
+                                       if sharded else "single GPU"),
                        "preroll": args.preroll, "schedule_horizon": horizon(args),
                        "timed_ticks": [args.preroll + args.warmup, args.preroll + args.warmup + args.steps - 1],
-                       "model_bound_drops": load2["drops"],
-                       "load": {"records_per_packet_start": round(load0["records_per_packet"], 3),
-                                "records_per_packet_end": round(load1["records_per_packet"], 3),
-                                "queued_per_node_start": round(load0["queued_per_node"], 3),
-                                "queued_per_node_end": round(load1["queued_per_node"], 3),
-                                "deepest_queue": load1["max_queue"],
-                                "records_per_packet_preroll_every_40_ticks": trace,
-                                "nodes_up": load1["up"], "view_slots_in_use": load2["slots_in_use"],
-                                "view_slots_recycled": load2["slots_recycled"]}},
-            "rounds_to_99": ({"median": float(np.median(rounds)), "p90": float(np.percentile(rounds, 90)), "max": int(max(rounds)),
-                              "min": int(min(rounds)), "mean": float(np.mean(rounds)), "n": len(rounds),
-                              "histogram": {str(r): int(c) for r, c in zip(*np.unique(rounds, return_counts=True))},
-                              "window_ticks": [conv_first, conv_last],
-                              "what": "gossip rounds until >= 99 % of running nodes have applied a user event, for every user event the workload itself "
-                                      f"issues in ticks [{conv_first}, {conv_first + CONV_WINDOW}) (a fixed window: independent of --steps / --warmup), "
-                                      "all outstanding events polled once per tick (sim_convergence_many)",
-                              "fanout_model": ("memberlist's literal kRandomNodes (--random-fanout: uniform targets, Poisson-like in-degree, the "
-                                               "fan-out graph as an explicit per-tick CSR)" if args.random_fanout else
-                                               "per-tick bijection (every node receives exactly `fanout` packets per round); memberlist's literal "
-                                               "kRandomNodes (Poisson-like in-degree; `--random-fanout`) needs one round more: 10 vs 9 at 64 Ki nodes, "
-                                               "12 vs 11 at 1 Mi (profiles/r02_fanout_model_*.json on the CPU oracle, "
-                                               "profiles/r03_bench_random_fanout.json on the GPU)")}
-                             if rounds else None),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic, "measured": measured, "achieved_from": basis,
-                         "kernel": "tick_kernel", "kernel_ms": kern_s * 1e3,
-                         "kernel_ms_min": prof_min, "kernel_ms_max": prof_max, "kernel_launches": int(prof_n),
-                         "kernel_timing": f"HIP event pair on every {profile_every}{'th' if profile_every > 1 else 'st'} tick_kernel dispatch of the timed region (hipExtLaunchKernelGGL start/stop events, on the launch stream)",
-                         "stream_ms_per_step": ev_ms / args.steps,
-                         # (the same figure again under its own name, next to the layout's)
-                         "algorithmic": {"b_tick_bytes": bt, "achieved": algorithmic, "frac": algorithmic / 8000.0,
-                                         "what": "SURVEY.md §8d B_tick(f) = 2R + 2QE + 2fPE + 4(f+2) x nodes / kernel time"},
-                         "layout": {"b_tick_bytes": bt2, "achieved": layout, "frac": layout / 8000.0,
-                                    "what": "the same accounting for the frozen layout (DESIGN.md §4): packets kept at the sender"},
-                         "traffic_over_algorithmic": (traffic / (args.nodes_per_gpu * bt)) if traffic else None,
-                         "traffic_provenance": prov},
+                       "model_bound_drops": drops,
+                       "load": {"records_per_packet_start": round(head["load0"]["records_per_packet"], 3),
+                                "records_per_packet_end": round(head["load1"]["records_per_packet"], 3),
+                                "queued_per_node_start": round(head["load0"]["queued_per_node"], 3),
+                                "queued_per_node_end": round(head["load1"]["queued_per_node"], 3),
+                                "deepest_queue": head["load1"]["max_queue"],
+                                "records_per_packet_preroll_every_40_ticks": head["trace"],
+                                "nodes_up": head["load1"]["up"], "view_slots_in_use": head["load2"]["slots_in_use"],
+                                "view_slots_recycled": head["load2"]["slots_recycled"]}},
+            "rounds_to_99": rounds_of(head),
+            "roofline": roofline_of(head),
+            "fanout_models": {mo: summary_of(res[mo]) for mo in models},
         }
-        if world > 1:
-            xb = raw.exchange_bytes()
-            out["exchange"] = {"chunks": sim.chunks, "exchange_ms": exchange_ms, "kernel_ms": kern_s * 1e3,
-                               "serial_ms_per_step": serial_ms, "overlapped_ms_per_step": dt / args.steps * 1e3,
+        if head["long"]:
+            out["long_window"] = out["fanout_models"][models[0]]["long_window"]
+        if sharded:
+            xb = head["exchange_bytes"]
+            out["exchange"] = {"chunks": head["chunks"], "exchange_ms": head["exchange_ms"], "kernel_ms": t["kern_s"] * 1e3,
+                               "serial_ms_per_step": head["serial_ms"], "overlapped_ms_per_step": t["dt"] / args.steps * 1e3,
                                "bytes_per_peer": xb // world, "bytes_per_gpu_per_tick": xb,
                                "bytes_leaving_gpu_per_tick": xb // world * (world - 1),
-                               "what": f"the timed region runs each tick as {sim.chunks} chunk launches with the all-to-all of chunk c in flight "
+                               "what": f"the timed region runs each tick as {head['chunks']} chunk launches with the all-to-all of chunk c in flight "
                                        "while chunk c + 1 computes (overlapped_ms_per_step = ms_per_step); exchange_ms and serial_ms_per_step come "
-                                       f"from {diag_ticks} further ticks with the collectives run one after the other between events (rank 0): "
+                                       f"from {head['diag_ticks']} further ticks with the collectives run one after the other between events (rank 0): "
                                        "exchange_ms = all-to-alls of one round, serial_ms_per_step = that round without overlap"}
-            out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                                  "collective_library": ("RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version())
-                                                         if on_gpu and backend == "nccl" else backend)}
-        if world == 1 and on_gpu and not args.no_second_load and args.pkt_records == 4:
+            out["distributed"] = {"backend": dist.get_backend() if world > 1 else None, "world_size": world,
+                                  "collective_library": head["collectives"]}
+        if world == 1 and on_gpu and not args.no_second_load and args.pkt_records == 4 and not sharded:
             progress("second load")
-            raw.close()  # both clusters do not fit next to each other (66 GB each at 1 Mi nodes)
             out["second_load"] = second_load(args, lib, dev, torch)
         if world == 1 and not args.no_cpu_baseline:
-            progress("cpu_baseline")
-            out["cpu_baseline"], cpu_digest = cpu_baseline(args, parity_tick)
-            if cpu_digest is None:
-                out["parity"] = {"tick": parity_tick, "digest_match": None, "why": "the host could not hold the configuration: oracle ran a smaller cluster"}
-            else:
-                out["parity"] = {"tick": parity_tick, "digest_match": tuple(cpu_digest) == tuple(gpu_digest), "arrays": 8,
-                                 "what": "sim_state_digest of the GPU run right before the timed region (rows, queues, packets in flight, views, "
-                                         "both rings, slot map + liveness, query tables) against the CPU oracle rolled through the same "
-                                         "schedule to the same tick (oracle/liboracle.so, the checker)",
-                                 "gpu": [f"{x:016x}" for x in gpu_digest], "oracle": [f"{x:016x}" for x in cpu_digest]}
+            out["parity"] = {}
+            for i, mo in enumerate(models):
+                progress(f"cpu_baseline ({mo})")
+                m = res[mo]
+                cb, cpu_dig = cpu_baseline(args, mo, m["parity_ticks"], timed=(i == 0))
+                if i == 0:
+                    out["cpu_baseline"] = cb
+                pt = m["parity_ticks"]
+                if any(cpu_dig[tk] is None for tk in pt):
+                    out["parity"][mo] = {"ticks": pt, "digest_match": None, "why": "the host could not hold the configuration: oracle ran a smaller cluster"}
+                else:
+                    ok = [tuple(cpu_dig[tk]) == tuple(m["digests"][tk]) for tk in pt]
+                    out["parity"][mo] = {"ticks": pt, "digest_match": all(ok), "digest_match_per_tick": ok, "arrays": 8,
+                                         "what": "sim_state_digest of the GPU run right before the timed region AND right behind its last timed tick (rows, "
+                                                 "queues, packets in flight, views, both rings, slot map + liveness, query tables) against the CPU "
+                                                 "oracle rolled through the same schedule to the same ticks (oracle/liboracle.so, the checker): the "
+                                                 "timed launches themselves are covered",
+                                         "gpu": {str(tk): [f"{x:016x}" for x in m["digests"][tk]] for tk in pt},
+                                         "oracle": {str(tk): [f"{x:016x}" for x in cpu_dig[tk]] for tk in pt}}
+            out["parity"]["digest_match"] = all(v.get("digest_match") is not False for v in out["parity"].values() if isinstance(v, dict))
+            out["parity"]["ticks"] = head["parity_ticks"]
         print(json.dumps(out), flush=True)
     progress.done = True
-    if world > 1:
+    if world > 1 or args.force_sharded:
         dist.destroy_process_group()
     if out is not None and out.get("parity", {}).get("digest_match") is False:
-        raise SystemExit("bench.py: the GPU state at the first timed tick differs from the CPU oracle's — result invalid")
-    if load2["drops"] and not args.allow_drops:
+        raise SystemExit("bench.py: the GPU state at the ends of the timed region differs from the CPU oracle's — result invalid")
+    if drops and not args.allow_drops:
         # a run that hit a model bound is not a run of the protocol the parity tests cover: refuse it
-        raise SystemExit(f"bench.py: model bound hit ({load2['drops']} drops: queue slots / bucket keys / timers) — result invalid")
+        raise SystemExit(f"bench.py: model bound hit ({drops} drops: queue slots / bucket keys / timers) — result invalid")
     return out
 
 

@@ -312,6 +312,10 @@ typedef struct sim_config {
                                    * score by the number of relays that were asked and did NOT answer with a nack (relay down,
                                    * or the request / the nack lost) instead of by one — a prober whose own network is fine
                                    * does not degrade itself for a peer that is really dead; no relay asked: + 1 as before     */
+#define SIM_CF_FORCE_SHARDED 64u     /* run the handle as ONE SHARD of a sharded cluster although shard_count == 1 (vshards == 1): exchange
+                                   * buffers, the sharded instantiation of the tick kernel, the host-driven push-pull / recycling /
+                                   * suspicion hand-over — the N > 1 path with a single rank, so that it (and its collective) can be
+                                   * rehearsed on one GPU.  State and digests are those of the plain single-handle run.            */
 #define SIM_DEFAULT_SEED 0x5EEDC0DE5E4F0001ull
 
 /* Stats — mirrors serf-core/src/serf/api.rs:586-602 (`Stats`) for one simulated node. */
@@ -519,6 +523,28 @@ int sim_bind_exchange(sim_handle* h, void* send_dev, void* recv_dev);
  * sim_step_end  — and every exchange of tick t must have completed before sim_step_chunk of tick t + 1. */
 int sim_bind_exchange2(sim_handle* h, void* send_dev, void* recv0_dev, void* recv1_dev);
 int sim_exchange_chunks(const sim_handle* h, uint32_t* chunks, size_t* bytes_per_chunk);
+/* The round's all-to-all ISSUED BY THE LIBRARY over RCCL (grouped ncclSend / ncclRecv pairs over xGMI) — for a
+ * host that has no collective library of its own (the north star's Rust host) and to take the per-chunk host cost out of the
+ * tick: sim_exchange_chunk is one call, no tensor bookkeeping, and the ordering lives on streams, not in the host.
+ *   sim_exchange_unique_id(id)            rank 0 makes the communicator's id (ncclGetUniqueId) and hands the SIM_EXCHANGE_ID_BYTES
+ *                                         bytes to every rank over whatever side channel the host has
+ *   sim_exchange_init(h, id, rank, world) ncclCommInitRank; world == the handle's shard count, rank == its shard rank; the
+ *                                         exchange buffers must be bound (sim_bind_exchange2).  Collective: every rank calls it.
+ *   sim_exchange_chunk(h, c)              after sim_step_chunk(h, c): the slabs of sender chunk c — [V peers] equal splits of
+ *                                         bytes_per_chunk / V — go out and come in as ONE group of V ncclSend + V ncclRecv on the
+ *                                         library's exchange stream, which waits for that chunk's launch only: chunk c travels
+ *                                         while chunk c + 1 computes.  Packets sent during tick t land in recv[t & 1].
+ *   sim_exchange_wait(h)                  the handle's stream waits (on the device, no host wait) for every exchange issued so
+ *                                         far; sim_step_begin does it by itself before the next tick reads the packets.
+ *   sim_exchange_library(buf, cap)        "RCCL <major>.<minor>.<patch>" of the library the calls above go to.
+ * SIM_ESTATE before sim_exchange_init; SIM_EDEVICE when RCCL reports an error.  (The CPU oracle has no collective library:
+ * its entry points return SIM_EDEVICE — a test moves its buffers by hand.) */
+#define SIM_EXCHANGE_ID_BYTES 128u
+int sim_exchange_unique_id(uint8_t* id_out);
+int sim_exchange_init(sim_handle* h, const uint8_t* id, uint32_t rank, uint32_t world);
+int sim_exchange_chunk(sim_handle* h, uint32_t chunk);
+int sim_exchange_wait(sim_handle* h);
+int sim_exchange_library(char* buf, size_t cap);
 /* View-slot recycling in sharded runs.  A single-process handle runs the pass inside sim_step_begin.  With one shard
  * per process the verdict needs every shard: when sim_recycle_due() the host calls sim_recycle_scan on every shard
  * (same candidates everywhere: the slot bookkeeping is replicated), keeps the candidates for which NO shard set flag 1

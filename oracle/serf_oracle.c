@@ -335,6 +335,9 @@ struct sim_handle {
   size_t n_evreg, cap_evreg;
 };
 typedef struct sim_handle osim;
+/* one shard per process — or one handle run AS a shard (SIM_CF_FORCE_SHARDED: the one-rank rehearsal of the N > 1 path) */
+#define SHARDED(s) ((s)->cfg.shard_count > 1 || ((s)->cfg.flags & SIM_CF_FORCE_SHARDED))
+#define CFG_SHARDED(c) ((c)->shard_count > 1 || ((c)->flags & SIM_CF_FORCE_SHARDED))
 
 static inline uint32_t digits10(uint32_t n) { /* = ceil(log10(n+1)), App. B.1 retransmit limit */
   uint32_t d = 0;
@@ -1367,7 +1370,7 @@ static void pp_round(osim* s, const tickp* p) {
   uint32_t cls = 0, ga, gb;
   int batch = pp_batch_class(s, &cls);
   if (!batch && !s->rc_n) return;
-  if (s->cfg.shard_count > 1) {
+  if (SHARDED(s)) {
     if (s->pp_done_at == (uint32_t)s->tick) return; /* the host drove it (sim_pp_plan / export / merge) */
     /* in-shard pairs only would be a different protocol: the sharded host has to run the exchange */
     return;
@@ -1386,7 +1389,7 @@ static void pp_round(osim* s, const tickp* p) {
  * The tick (DESIGN.md SIMSPEC §4)
  * ===================================================================================== */
 static inline const sim_packet* inbox_cell(const osim* s, uint32_t k, uint32_t pg, uint32_t l) {
-  if (s->cfg.shard_count > 1) { /* sharded: [src shard][k * PG + pg][blk] written by the previous tick */
+  if (SHARDED(s)) { /* sharded: [src shard][k * PG + pg][blk] written by the previous tick */
     const tickp* pp = &s->prev;
     uint32_t b = l / pp->blk, sl = (l % pp->blk) / pp->sub;
     uint32_t g = (s->cfg.shard_rank + b + pp->rot[k]) % pp->V;
@@ -1494,7 +1497,7 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
     fan_target(p, g, ll, k, &h, &lp);
     if (up && (pkt_lost(p, c.gid, k) || ((skipm >> k) & 1u))) memset(out[k], 0, sizeof out[k]);
     for (uint32_t pg = 0; pg < PG; ++pg) {
-      if (s->cfg.shard_count > 1)
+      if (SHARDED(s))
         s->xsend[xcell(p, s->fp, (ll % p->blk) / p->sub, h, k * PG + pg, lp)] = out[k][pg];
       else
         s->inbox[(s->tick + 1) & 1][((size_t)k * PG + pg) * s->Nl + (size_t)h * p->M + lp] = out[k][pg];
@@ -1545,11 +1548,18 @@ static void rc_resolve(osim* s, const uint32_t* req, uint32_t n) {
   }
 }
 static void step_begin(osim* s) {
+  /* every shard is here: the slot-less suspicions / reconnect attempts of the tick BEFORE the one that just ended are replayed
+   * now — behind whatever the caller scheduled for this tick so far, which is where a sharded host (sim_suspect_import at
+   * the start of its step) puts them too */
+  if (!SHARDED(s) && s->sreq_prev_n) {
+    for (uint32_t i = 0; i < s->sreq_prev_n; ++i) inject_val(s, s->tick, SIM_OP_SUSPECT, s->sreq_prev[2 * i], s->sreq_prev[2 * i + 1], 0, 0);
+    s->sreq_prev_n = 0;
+  }
   sreq_rotate(s);
   tickp* p = &s->cur;
   tickp_make(p, &s->cfg, s->tick);
-  if (s->cfg.shard_count > 1) s->xrecv = s->rbuf[(s->tick + 1) & 1];
-  if (recycle_due(s) && s->cfg.shard_count <= 1) recycle_local(s);
+  if (SHARDED(s)) s->xrecv = s->rbuf[(s->tick + 1) & 1];
+  if (recycle_due(s) && !SHARDED(s)) recycle_local(s);
   uint32_t* rreq = NULL; /* this tick's reconnect attempts, in schedule order */
   uint32_t n_rreq = 0, cap_rreq = 0;
   while (s->op_cursor < s->n_ops && s->ops[s->op_cursor].tick <= s->tick) {
@@ -1620,10 +1630,6 @@ static void step_end(osim* s) {
   s->prev = p;
   s->tick++;
   s->in_tick = 0;
-  if (s->cfg.shard_count <= 1 && s->sreq_prev_n) { /* every shard is here: replay the PREVIOUS tick's slot-less suspicions next tick */
-    for (uint32_t i = 0; i < s->sreq_prev_n; ++i) inject_val(s, s->tick, SIM_OP_SUSPECT, s->sreq_prev[2 * i], s->sreq_prev[2 * i + 1], 0, 0);
-    s->sreq_prev_n = 0;
-  }
 }
 static void step_one(osim* s) {
   step_begin(s);
@@ -1634,6 +1640,12 @@ static void step_one(osim* s) {
 /* =====================================================================================
  * C ABI (same shape as include/serf_sim.h, prefix osim_)
  * ===================================================================================== */
+/* the round's all-to-all over a collective library: the oracle has none (a test moves its buffers by hand) */
+int API(exchange_unique_id)(uint8_t* id) { (void)id; return SIM_EDEVICE; }
+int API(exchange_init)(osim* s, const uint8_t* id, uint32_t rank, uint32_t world) { (void)s; (void)id; (void)rank; (void)world; return SIM_EDEVICE; }
+int API(exchange_chunk)(osim* s, uint32_t chunk) { (void)s; (void)chunk; return SIM_EDEVICE; }
+int API(exchange_wait)(osim* s) { (void)s; return SIM_EDEVICE; }
+int API(exchange_library)(char* buf, size_t cap) { (void)buf; (void)cap; return SIM_EDEVICE; }
 uint32_t API(abi_version)(void) { return SIM_ABI_VERSION; }
 const char* API(backend_name)(void) { return "cpu-oracle"; }
 
@@ -1672,6 +1684,7 @@ static int cfg_check(const sim_config* c) {
   if (c->vshards > 1 && (M % c->vshards || M <= SIM_MAX_FANOUT)) return SIM_EINVAL;
   if (c->shard_count != 1 && c->shard_count != c->vshards) return SIM_EINVAL;
   if (c->shard_rank >= c->shard_count) return SIM_EINVAL;
+  if ((c->flags & SIM_CF_FORCE_SHARDED) && c->shard_count != c->vshards) return SIM_EINVAL; /* one rank of the N > 1 path: V == 1 */
   if (c->fanout < 1 || c->fanout > SIM_MAX_FANOUT) return SIM_EINVAL;
   if (c->chunks > 1 && ((M / c->vshards) % c->chunks || (M / c->vshards) / c->chunks < 1)) return SIM_EINVAL;
   if (c->event_ring < 1 || c->query_ring < 1) return SIM_EINVAL;
@@ -1705,8 +1718,8 @@ int API(create)(const sim_config* cfg, osim** out) {
   if (!s) return SIM_ENOMEM;
   s->cfg = *cfg;
   s->N = cfg->n_nodes; s->V = cfg->vshards; s->M = s->N / s->V;
-  s->Nl = cfg->shard_count > 1 ? s->M : s->N;
-  s->shard0 = cfg->shard_count > 1 ? cfg->shard_rank * s->M : 0;
+  s->Nl = CFG_SHARDED(cfg) ? s->M : s->N;
+  s->shard0 = CFG_SHARDED(cfg) ? cfg->shard_rank * s->M : 0;
   s->dense = (cfg->view_slots == 0 || cfg->view_slots >= s->N);
   s->A = s->dense ? s->N : cfg->view_slots;
   s->Bev = cfg->event_ring; s->Bq = cfg->query_ring; s->f = cfg->fanout;
@@ -1716,7 +1729,7 @@ int API(create)(const sim_config* cfg, osim** out) {
   size_t Nl = s->Nl;
   s->rows = (sim_row*)calloc(Nl, sizeof(sim_row));
   s->queue = (sim_record*)malloc(Nl * SIM_Q * sizeof(sim_record));
-  if (cfg->shard_count > 1) {
+  if (CFG_SHARDED(cfg)) {
     size_t cells = (size_t)s->fp * s->M;
     s->xsend = (sim_packet*)calloc(cells, sizeof(sim_packet));
     s->xrecv = (sim_packet*)calloc(cells, sizeof(sim_packet));
@@ -1746,14 +1759,14 @@ int API(create)(const sim_config* cfg, osim** out) {
   s->q_timeout = 16u * digits10(s->N); /* query.rs:421-427 with query_timeout_mult = 16 (options.rs:518) */
   pp_params(cfg, &s->pp_step, &s->pp_groups);
   if (!s->qbits || !s->upmap || !s->rows || !s->queue || !s->view || !s->ering || !s->qring || !s->slot_of ||
-      !s->subject_of || !s->walk || !s->alloc_tick || !s->base || (cfg->shard_count > 1 ? (!s->xsend || !s->xrecv)
+      !s->subject_of || !s->walk || !s->alloc_tick || !s->base || (CFG_SHARDED(cfg) ? (!s->xsend || !s->xrecv)
                                                           : (!s->inbox[0] || !s->inbox[1]))) {
     API(destroy)(s);
     return SIM_ENOMEM;
   }
   s->rfan = (cfg->flags & SIM_CF_RANDOM_FANOUT) != 0;
   if (s->rfan) {
-    if (cfg->shard_count > 1 || cfg->vshards > 1) { API(destroy)(s); return SIM_EINVAL; }
+    if (CFG_SHARDED(cfg) || cfg->vshards > 1) { API(destroy)(s); return SIM_EINVAL; }
     s->rtgt = (uint32_t*)malloc((size_t)s->f * Nl * sizeof(uint32_t));
     s->rcsr = (uint32_t*)calloc((size_t)Nl + 1, sizeof(uint32_t));
     s->rsrc = (uint32_t*)malloc((size_t)s->f * Nl * sizeof(uint32_t));
@@ -2162,7 +2175,7 @@ int API(peek_packet)(osim* s, uint32_t node, uint32_t k, uint8_t* buf, size_t ca
     uint32_t g = node / p->M, ll = node % p->M, h, lp;
     fan_target(p, g, ll, k, &h, &lp);
     for (uint32_t pg = 0; pg < s->PG; ++pg) {
-      const sim_packet* pk = s->cfg.shard_count > 1
+      const sim_packet* pk = SHARDED(s)
           ? &s->xsend[xcell(p, s->fp, (ll % p->blk) / p->sub, h, k * s->PG + pg, lp)]
           : s->rfan ? &s->inbox[s->tick & 1][((size_t)k * s->PG + pg) * s->Nl + (node - s->shard0)] /* random fan-out: the packets stay in their senders' cells */
           : &s->inbox[s->tick & 1][((size_t)k * s->PG + pg) * s->Nl + (size_t)h * p->M + lp];
@@ -2264,7 +2277,7 @@ int API(set_tags)(osim* s, uint32_t node, uint32_t tag_class) {
 int API(step)(osim* s, uint32_t n) {
   if (!s) return SIM_EINVAL;
   for (uint32_t i = 0; i < n; ++i) {
-    if (s->cfg.shard_count > 1) { /* needs the host between begin and end when a cross-shard push-pull batch is due */
+    if (SHARDED(s)) { /* needs the host between begin and end when a cross-shard push-pull batch is due */
       uint32_t cls;
       if (recycle_due(s)) return SIM_ESTATE;
       if (pp_batch_class(s, &cls) && s->pp_done_at != (uint32_t)s->tick) return SIM_ESTATE;
@@ -2352,7 +2365,7 @@ static uint64_t dig_words(const void* p, size_t n_words) {
   return acc;
 }
 static const sim_packet* cur_inbox(const osim* s) {
-  return s->cfg.shard_count > 1 ? s->rbuf[(s->tick + 1) & 1] : s->inbox[s->tick & 1];
+  return SHARDED(s) ? s->rbuf[(s->tick + 1) & 1] : s->inbox[s->tick & 1];
 }
 int API(state_digest)(osim* s, uint64_t out[8]) {
   if (!s || !out) return SIM_EINVAL;
@@ -2444,7 +2457,7 @@ int API(snapshot)(osim* s, void* buf, size_t cap, size_t* bytes) {
   if (s->in_tick) return SIM_ESTATE;
   /* (random fan-out: the inbox section holds the packets in their senders' cells, [slot][sender]; where each one goes is a
    * function of (seed, tick - 1, sender) and is drawn again on restore) */
-  if (s->cfg.shard_count <= 1 && (s->sreq_prev_n || s->sreq_n)) { /* slot-less failed probes not yet replayed: into the schedule, so that the image holds them */
+  if (!SHARDED(s) && (s->sreq_prev_n || s->sreq_n)) { /* slot-less failed probes not yet replayed: into the schedule, so that the image holds them */
     for (uint32_t i = 0; i < s->sreq_prev_n; ++i) inject_val(s, s->tick, SIM_OP_SUSPECT, s->sreq_prev[2 * i], s->sreq_prev[2 * i + 1], 0, 0);
     sreq_rotate(s);
     for (uint32_t i = 0; i < s->sreq_prev_n; ++i) inject_val(s, s->tick + 1, SIM_OP_SUSPECT, s->sreq_prev[2 * i], s->sreq_prev[2 * i + 1], 0, 0);
@@ -2618,11 +2631,11 @@ int API(cluster_stats_get)(osim* s, sim_cluster_stats* o) {
 }
 int API(exchange_bytes)(const osim* s, size_t* bytes) {
   if (!s || !bytes) return SIM_EINVAL;
-  *bytes = s->cfg.shard_count > 1 ? (size_t)s->fp * s->M * sizeof(sim_packet) : 0;
+  *bytes = SHARDED(s) ? (size_t)s->fp * s->M * sizeof(sim_packet) : 0;
   return SIM_OK;
 }
 int API(bind_exchange2)(osim* s, void* send, void* recv0, void* recv1) {
-  if (!s || s->cfg.shard_count <= 1 || !send || !recv0 || !recv1) return SIM_EINVAL;
+  if (!s || !SHARDED(s) || !send || !recv0 || !recv1) return SIM_EINVAL;
   if (s->own_x) { free(s->xsend); free(s->xrecv); s->own_x = 0; }
   s->xsend = (sim_packet*)send;
   s->rbuf[0] = (sim_packet*)recv0;
@@ -2637,8 +2650,8 @@ int API(bind_exchange)(osim* s, void* send, void* recv) { return API(bind_exchan
 int API(exchange_chunks)(const osim* s, uint32_t* chunks, size_t* bytes_per_chunk) {
   if (!s || !chunks || !bytes_per_chunk) return SIM_EINVAL;
   uint32_t C = s->cfg.chunks ? s->cfg.chunks : 1;
-  *chunks = s->cfg.shard_count > 1 ? C : 1;
-  *bytes_per_chunk = s->cfg.shard_count > 1 ? (size_t)s->fp * s->M * sizeof(sim_packet) / C : 0;
+  *chunks = SHARDED(s) ? C : 1;
+  *bytes_per_chunk = SHARDED(s) ? (size_t)s->fp * s->M * sizeof(sim_packet) / C : 0;
   return SIM_OK;
 }
 /* ---- cross-shard push-pull, driven by the sharded host (include/serf_sim.h) ---- */
@@ -2646,13 +2659,13 @@ int API(pp_due)(const osim* s) {
   uint32_t cls;
   if (!s) return SIM_EINVAL;
   /* (a reconnect attempt is a push-pull pair as well: known once sim_step_begin has resolved the tick's operations) */
-  return s->cfg.shard_count > 1 && (pp_batch_class(s, &cls) || (s->in_tick && s->rc_n)) && s->pp_done_at != (uint32_t)s->tick;
+  return SHARDED(s) && (pp_batch_class(s, &cls) || (s->in_tick && s->rc_n)) && s->pp_done_at != (uint32_t)s->tick;
 }
 int API(pp_plan)(osim* s, uint32_t* send1, uint32_t* recv1, size_t* record_bytes) {
   uint32_t cls = 0;
   if (!s || !send1 || !recv1 || !record_bytes) return SIM_EINVAL;
   int batch = s->in_tick ? pp_batch_class(s, &cls) : 0;
-  if (!s->in_tick || s->cfg.shard_count <= 1 || (!batch && !s->rc_n)) return SIM_ESTATE; /* after sim_step_begin: the tick's operations come first */
+  if (!s->in_tick || !SHARDED(s) || (!batch && !s->rc_n)) return SIM_ESTATE; /* after sim_step_begin: the tick's operations come first */
   tickp p;
   tickp_make(&p, &s->cfg, s->tick);
   uint32_t V = s->V, me = s->cfg.shard_rank, M = s->M;
@@ -2772,7 +2785,7 @@ int API(recycle_apply)(osim* s, const sim_recycle_cand* agreed, uint32_t n) {
 int API(step_begin)(osim* s) {
   if (!s) return SIM_EINVAL;
   if (s->in_tick) return SIM_ESTATE;
-  if (s->cfg.shard_count > 1 && recycle_due(s)) return SIM_ESTATE; /* the host runs the pass first (it needs every shard) */
+  if (SHARDED(s) && recycle_due(s)) return SIM_ESTATE; /* the host runs the pass first (it needs every shard) */
 
   step_begin(s);
   return SIM_OK;
@@ -2780,7 +2793,7 @@ int API(step_begin)(osim* s) {
 int API(step_chunk)(osim* s, uint32_t chunk) {
   if (!s) return SIM_EINVAL;
   if (!s->in_tick) return SIM_ESTATE;
-  if (s->cfg.shard_count <= 1 || chunk >= s->cur.C) return SIM_EINVAL;
+  if (!SHARDED(s) || chunk >= s->cur.C) return SIM_EINVAL;
   if (API(pp_due)(s) > 0) return SIM_ESTATE; /* the push-pull batch of this tick comes first (its pairs span shards: the host runs it) */
   step_chunk(s, s->cur.C == 1 ? NOSLOT : chunk);
   return SIM_OK;
@@ -2913,6 +2926,14 @@ uint32_t osim_t_scheduled(const osim* s, uint32_t op, uint64_t tick, uint32_t* o
   for (size_t i = s->op_cursor; i < s->n_ops; ++i)
     if (s->ops[i].op == op && s->ops[i].tick == tick) {
       if (out_pairs && n < cap) { out_pairs[2 * n] = s->ops[i].node; out_pairs[2 * n + 1] = s->ops[i].a; }
+      ++n;
+    }
+  /* (the request list the next step_begin turns into operations of its tick: slot-less suspicions, reconnect attempts) */
+  if (!SHARDED(s) && tick == s->tick && (op == SIM_OP_SUSPECT || op == SIM_OP_RECONNECT))
+    for (uint32_t i = 0; i < s->sreq_prev_n; ++i) {
+      uint32_t a = s->sreq_prev[2 * i + 1];
+      if (((a & SREQ_RECONNECT) != 0) != (op == SIM_OP_RECONNECT)) continue;
+      if (out_pairs && n < cap) { out_pairs[2 * n] = s->sreq_prev[2 * i]; out_pairs[2 * n + 1] = a & ~SREQ_RECONNECT; }
       ++n;
     }
   return n;

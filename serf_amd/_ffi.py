@@ -34,7 +34,8 @@ QF_IDS, TAG_CLASSES, NO_TAG_FILTER = 12, 32, 0xFFFFFFFF
 ARR_ROWS, ARR_QUEUE, ARR_INBOX, ARR_VIEW, ARR_ERING, ARR_QRING, ARR_SLOTMAP = range(7)
 # enum sim_swim_state (memberlist node state)
 SWIM_ALIVE, SWIM_SUSPECT, SWIM_DEAD, SWIM_LEFT = 0, 1, 2, 3
-CF_BASELINE_JOINED, CF_RANDOM_FANOUT, CF_AWARENESS_PROBE, CF_JOIN_SYNC, CF_TCP_FALLBACK, CF_NACKS = 1, 2, 4, 8, 16, 32
+CF_BASELINE_JOINED, CF_RANDOM_FANOUT, CF_AWARENESS_PROBE, CF_JOIN_SYNC, CF_TCP_FALLBACK, CF_NACKS, CF_FORCE_SHARDED = 1, 2, 4, 8, 16, 32, 64
+EXCHANGE_ID_BYTES = 128
 F_NO_BROADCAST, F_ACK, F_RESPOND = 1, 2, 4
 
 
@@ -103,6 +104,7 @@ ABI_SYMBOLS = ("create", "destroy", "set_stream", "join", "leave", "force_leave"
                "bind_exchange2", "exchange_chunks", "step_begin", "step_chunk", "step_end",
                "recycle_due", "recycle_scan", "recycle_apply", "pp_due", "pp_plan", "pp_export", "pp_merge",
                "query_filtered", "set_tags", "init_tags", "inject_record", "deliver_message", "user_event_bytes", "peek_packet", "suspect_requests", "suspect_export", "suspect_import",
+               "exchange_unique_id", "exchange_init", "exchange_chunk", "exchange_wait", "exchange_library",
                "abi_version", "backend_name")
 
 
@@ -111,7 +113,7 @@ def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, vi
                 suspicion_mult=4, suspicion_max_mult=6, indirect_checks=3, loss=0.0,
                 intent_timeout=0, leave_delay=30, reap_interval=0, reconnect_timeout=432000, tombstone_timeout=432000,
                 queue_check_interval=0, max_queue_depth=4096, min_queue_depth=0, push_pull_interval=0, chunks=0, recycle_interval=0,
-                pkt_records=0, gossip_to_the_dead=0, reconnect_interval=0, tcp_fallback=False, nacks=False, awareness_probe=False, join_sync=False, flags=CF_BASELINE_JOINED, seed=DEFAULT_SEED):
+                pkt_records=0, gossip_to_the_dead=0, reconnect_interval=0, tcp_fallback=False, nacks=False, awareness_probe=False, join_sync=False, force_sharded=False, flags=CF_BASELINE_JOINED, seed=DEFAULT_SEED):
     cfg = Config()
     cfg.struct_size = C.sizeof(Config)
     cfg.n_nodes, cfg.vshards, cfg.shard_rank, cfg.shard_count = n_nodes, vshards, shard_rank, shard_count
@@ -134,6 +136,8 @@ def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, vi
         cfg.flags |= CF_TCP_FALLBACK   # memberlist's stream-transport fallback ping: packet loss alone never fails a probe
     if nacks:
         cfg.flags |= CF_NACKS          # awareness += relays that were asked and did not nack
+    if force_sharded:
+        cfg.flags |= CF_FORCE_SHARDED  # one rank of the N > 1 path: exchange buffers, the sharded kernel, host-driven push-pull
     return cfg
 
 
@@ -201,6 +205,11 @@ class SimLib:
             "suspect_requests": (C.c_int, [H, vp, u32, C.POINTER(u32)]),
             "suspect_export": (C.c_int, [H, vp]),
             "suspect_import": (C.c_int, [H, u64, vp, u32]),
+            "exchange_unique_id": (C.c_int, [vp]),
+            "exchange_init": (C.c_int, [H, vp, u32, u32]),
+            "exchange_chunk": (C.c_int, [H, u32]),
+            "exchange_wait": (C.c_int, [H]),
+            "exchange_library": (C.c_int, [C.c_char_p, C.c_size_t]),
             "abi_version": (u32, []),
             "backend_name": (C.c_char_p, []),
         }
@@ -211,6 +220,19 @@ class SimLib:
 
     def backend_name(self):
         return self.f["backend_name"]().decode()
+
+    def exchange_unique_id(self) -> bytes:
+        """ncclGetUniqueId through the library (rank 0); the bytes go to every rank, then Sim.exchange_init."""
+        buf = C.create_string_buffer(EXCHANGE_ID_BYTES)
+        rc = self.f["exchange_unique_id"](buf)
+        if rc:
+            raise SimError(rc, "sim_exchange_unique_id")
+        return buf.raw
+
+    def exchange_library(self):
+        """"RCCL x.y.z" of the collective library behind sim_exchange_* (None: the implementation has none)."""
+        buf = C.create_string_buffer(64)
+        return buf.value.decode() if self.f["exchange_library"](buf, 64) == 0 else None
 
     def abi_version(self):
         return self.f["abi_version"]()
@@ -307,6 +329,16 @@ class Sim:
 
     def set_stream(self, stream_ptr):
         self._ck(self.lib.f["set_stream"](self.h, C.c_void_p(stream_ptr)), "sim_set_stream")
+
+    # ---- the round's all-to-all issued by the library itself over RCCL (include/serf_sim.h sim_exchange_*) ----
+    def exchange_init(self, unique_id: bytes, rank, world):
+        self._ck(self.lib.f["exchange_init"](self.h, unique_id, rank, world), "sim_exchange_init")
+
+    def exchange_chunk(self, chunk):
+        self._ck(self.lib.f["exchange_chunk"](self.h, chunk), "sim_exchange_chunk")
+
+    def exchange_wait(self):
+        self._ck(self.lib.f["exchange_wait"](self.h), "sim_exchange_wait")
 
     def step(self, n=1):
         self._ck(self.lib.f["step"](self.h, n), "sim_step")

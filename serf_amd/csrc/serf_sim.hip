@@ -29,6 +29,7 @@
 // returns SIM_EDEVICE.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <rccl/rccl.h>  // the round's all-to-all issued by the library itself (sim_exchange_*): grouped ncclSend / ncclRecv over xGMI
 
 #include <algorithm>
 #include <cmath>
@@ -3396,6 +3397,14 @@ struct sim_handle {
   uint4* inbox_mat;
   u64 mat_tick;
   // SIM_CF_RANDOM_FANOUT: scratch of the per-tick graph build (rf_* kernels)
+  // the round's all-to-all over RCCL, issued by the library (sim_exchange_*): the communicator, a stream of its own for the
+  // collectives (it waits for one chunk's launch, the handle's stream waits for all of a round's exchanges before the next
+  // tick reads them), the events that carry those two orderings
+  ncclComm_t xcomm;
+  hipStream_t xstream;
+  hipEvent_t xev_go, xev_done;
+  u32 xworld;
+  bool xpending;  // exchanges issued since the handle's stream last waited for them
   u32 *rf_ghist, *rf_btot, *rf_bstart, *rf_l1;
   RfP rfp;  // the parameters that do not change from tick to tick
   // The graph of tick s is a function of (seed, s): it is built on a stream of its own while tick s - 1 runs.  rf_rcsr[s % 3] /
@@ -3430,10 +3439,11 @@ static int cfg_check(const sim_config* c) {
   if (c->vshards > 1 && (M % c->vshards || M <= SIM_MAX_FANOUT)) return SIM_EINVAL;
   if (c->shard_count != 1 && c->shard_count != c->vshards) return SIM_EINVAL;
   if (c->shard_rank >= c->shard_count) return SIM_EINVAL;
+  if ((c->flags & SIM_CF_FORCE_SHARDED) && c->shard_count != c->vshards) return SIM_EINVAL;  // one rank of the N > 1 path: V == 1
   if (c->fanout < 1 || c->fanout > SIM_MAX_FANOUT) return SIM_EINVAL;
   if (c->chunks > 1 && ((M / c->vshards) % c->chunks || (M / c->vshards) / c->chunks < 1)) return SIM_EINVAL;
   // memberlist's literal kRandomNodes (variable in-degree, an explicit CSR per tick): one shard, one chunk
-  if ((c->flags & SIM_CF_RANDOM_FANOUT) && (c->vshards != 1 || c->shard_count != 1 || c->chunks > 1 || c->n_nodes > (1u << 23))) return SIM_EINVAL;
+  if ((c->flags & SIM_CF_RANDOM_FANOUT) && (c->vshards != 1 || c->shard_count != 1 || (c->flags & SIM_CF_FORCE_SHARDED) || c->chunks > 1 || c->n_nodes > (1u << 23))) return SIM_EINVAL;
   if (c->event_ring < 1 || c->query_ring < 1) return SIM_EINVAL;
   if (c->pkt_records && (c->pkt_records % SIM_P || c->pkt_records > SIM_PKT_RECORDS_MAX)) return SIM_EINVAL;
   if (c->retransmit_mult * h_digits10(c->n_nodes) > 63u) return SIM_EINVAL;
@@ -3499,6 +3509,11 @@ const char* sim_backend_name(void) { return "hip-gfx950"; }
 int sim_destroy(sim_handle* h) {
   if (!h) return SIM_EINVAL;
   (void)hipStreamSynchronize(h->stream);
+  if (h->xstream) (void)hipStreamSynchronize(h->xstream);
+  if (h->xcomm) (void)ncclCommDestroy(h->xcomm);
+  if (h->xstream) (void)hipStreamDestroy(h->xstream);
+  if (h->xev_go) (void)hipEventDestroy(h->xev_go);
+  if (h->xev_done) (void)hipEventDestroy(h->xev_done);
   if (h->rf_stream) { (void)hipStreamSynchronize(h->rf_stream); (void)hipStreamDestroy(h->rf_stream); }
   if (h->rf_done) (void)hipEventDestroy(h->rf_done);
   for (int i = 0; i < 2; ++i) if (h->rf_go[i]) (void)hipEventDestroy(h->rf_go[i]);
@@ -3535,6 +3550,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   h->in_tick = false;
   h->tick_timed = false;
   h->rbuf[0] = h->rbuf[1] = nullptr;
+  h->xcomm = nullptr; h->xstream = nullptr; h->xev_go = h->xev_done = nullptr; h->xworld = 0; h->xpending = false;
   h->profiling = 0;
   h->prof_seq = 0;
   memset(&h->prev, 0, sizeof h->prev);
@@ -3542,7 +3558,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   Dev& d = h->d;
   memset(&d, 0, sizeof d);
   d.N = cfg->n_nodes; d.V = cfg->vshards; d.M = d.N / d.V;
-  d.sharded = cfg->shard_count > 1;
+  d.sharded = cfg->shard_count > 1 || (cfg->flags & SIM_CF_FORCE_SHARDED);  // (the flag: ONE shard run as a shard — the N > 1 path with a single rank)
   d.Nl = d.sharded ? d.M : d.N;
   d.shard0 = d.sharded ? cfg->shard_rank * d.M : 0;
   d.shard_rank = cfg->shard_rank;
@@ -4159,6 +4175,18 @@ int sim_step_begin(sim_handle* h) {
   if (!h) return SIM_EINVAL;
   Dev& d = h->d;
   if (h->in_tick || (d.sharded && !h->bound)) return SIM_ESTATE;
+  if (h->xpending) { int rc = sim_exchange_wait(h); if (rc) return rc; }  // the packets of the round before have landed
+  if (d.swim && !d.sharded) {
+    // every shard is here: the slot-less suspicions / reconnect attempts of the tick BEFORE the one that just ended are
+    // replayed now — behind whatever the caller scheduled for this tick so far, which is where a sharded host
+    // (sim_suspect_import at the start of its step) puts them too
+    static thread_local std::vector<u32> buf(2 * SIM_SUSPECT_REQ_MAX);
+    u32 n = 0;
+    int rc = sim_suspect_requests(h, buf.data(), SIM_SUSPECT_REQ_MAX, &n);
+    if (rc) return rc;
+    for (u32 i = 0; i < n; ++i)
+      if ((rc = inject_val(h, h->tick, SIM_OP_SUSPECT, buf[2 * i], buf[2 * i + 1], 0, 0)) != SIM_OK) return rc;
+  }
   if (recycle_is_due(h)) {
     if (d.sharded) return SIM_ESTATE;  // the host runs the pass first (it needs every shard's verdict)
     int rc = recycle_local(h);
@@ -4385,14 +4413,6 @@ int sim_step_end(sim_handle* h) {
     }
     h->sreq_on_dispatch = false;
     h->sreq_tick[t % 3] = t;
-    if (!h->d.sharded) {
-      static thread_local std::vector<u32> buf(2 * SIM_SUSPECT_REQ_MAX);
-      u32 n = 0;
-      int rc = sim_suspect_requests(h, buf.data(), SIM_SUSPECT_REQ_MAX, &n);
-      if (rc) return rc;
-      for (u32 i = 0; i < n; ++i)
-        if ((rc = inject_val(h, h->tick, SIM_OP_SUSPECT, buf[2 * i], buf[2 * i + 1], 0, 0)) != SIM_OK) return rc;
-    }
   }
   return SIM_OK;
 }
@@ -5053,6 +5073,80 @@ int sim_exchange_chunks(const sim_handle* h, uint32_t* chunks, size_t* bytes_per
   u32 C = h->cfg.chunks ? h->cfg.chunks : 1;
   *chunks = h->d.sharded ? C : 1;
   *bytes_per_chunk = h->d.sharded ? (size_t)h->d.fp * h->d.M * sizeof(sim_packet) / C : 0;
+  return SIM_OK;
+}
+
+// ---- the round's all-to-all over RCCL, issued by the library (include/serf_sim.h sim_exchange_*) ----
+#define NCHECK(x)                                                                                          \
+  do {                                                                                                     \
+    ncclResult_t r_ = (x);                                                                                 \
+    if (r_ != ncclSuccess) {                                                                               \
+      fprintf(stderr, "serf_sim: %s failed: %s (%s:%d)\n", #x, ncclGetErrorString(r_), __FILE__, __LINE__); \
+      return SIM_EDEVICE;                                                                                  \
+    }                                                                                                      \
+  } while (0)
+static_assert(sizeof(ncclUniqueId) <= SIM_EXCHANGE_ID_BYTES, "the communicator id travels as SIM_EXCHANGE_ID_BYTES bytes");
+int sim_exchange_unique_id(uint8_t* id_out) {
+  if (!id_out) return SIM_EINVAL;
+  ncclUniqueId id;
+  NCHECK(ncclGetUniqueId(&id));
+  memset(id_out, 0, SIM_EXCHANGE_ID_BYTES);
+  memcpy(id_out, &id, sizeof id);
+  return SIM_OK;
+}
+int sim_exchange_library(char* buf, size_t cap) {
+  if (!buf || cap < 16) return SIM_EINVAL;
+  int v = 0;
+  NCHECK(ncclGetVersion(&v));  // major * 10000 + minor * 100 + patch
+  snprintf(buf, cap, "RCCL %d.%d.%d", v / 10000, (v / 100) % 100, v % 100);
+  return SIM_OK;
+}
+int sim_exchange_init(sim_handle* h, const uint8_t* id, uint32_t rank, uint32_t world) {
+  if (!h || !id) return SIM_EINVAL;
+  Dev& d = h->d;
+  if (!d.sharded || world != h->cfg.shard_count || rank != h->cfg.shard_rank) return SIM_EINVAL;
+  if (!h->bound || h->xcomm) return SIM_ESTATE;
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof uid);
+  HCHECK(hipSetDevice(h->device));
+  NCHECK(ncclCommInitRank(&h->xcomm, (int)world, uid, (int)rank));
+  HCHECK(hipStreamCreateWithFlags(&h->xstream, hipStreamNonBlocking));
+  HCHECK(hipEventCreateWithFlags(&h->xev_go, hipEventDisableTiming));
+  HCHECK(hipEventCreateWithFlags(&h->xev_done, hipEventDisableTiming));
+  h->xworld = world;
+  return SIM_OK;
+}
+int sim_exchange_chunk(sim_handle* h, uint32_t chunk) {
+  if (!h) return SIM_EINVAL;
+  if (!h->xcomm) return SIM_ESTATE;
+  Dev& d = h->d;
+  const u32 C = h->cfg.chunks ? h->cfg.chunks : 1, V = h->xworld;
+  if (chunk >= C) return SIM_EINVAL;
+  // (called behind sim_step_chunk(chunk), before or after sim_step_end: the packets sent during tick t land in recv[t & 1])
+  const u64 t = h->in_tick ? h->tick : h->tick - 1;
+  const size_t chunk_bytes = (size_t)d.fp * d.M * sizeof(sim_packet) / C, slab = chunk_bytes / V;
+  const uint8_t* send = reinterpret_cast<const uint8_t*>(d.xsend) + (size_t)chunk * chunk_bytes;
+  uint8_t* recv = reinterpret_cast<uint8_t*>(h->rbuf[t & 1]) + (size_t)chunk * chunk_bytes;
+  // the exchange stream waits for what the handle's stream holds now — this chunk's launch —, not for the chunks after it
+  HCHECK(hipEventRecord(h->xev_go, h->stream));
+  HCHECK(hipStreamWaitEvent(h->xstream, h->xev_go, 0));
+  NCHECK(ncclGroupStart());
+  for (u32 p = 0; p < V; ++p) {
+    NCHECK(ncclSend(send + (size_t)p * slab, slab, ncclUint8, (int)p, h->xcomm, h->xstream));
+    NCHECK(ncclRecv(recv + (size_t)p * slab, slab, ncclUint8, (int)p, h->xcomm, h->xstream));
+  }
+  NCHECK(ncclGroupEnd());
+  h->xpending = true;
+  return SIM_OK;
+}
+int sim_exchange_wait(sim_handle* h) {
+  if (!h) return SIM_EINVAL;
+  if (!h->xcomm) return SIM_ESTATE;
+  if (h->xpending) {
+    HCHECK(hipEventRecord(h->xev_done, h->xstream));
+    HCHECK(hipStreamWaitEvent(h->stream, h->xev_done, 0));
+    h->xpending = false;
+  }
   return SIM_OK;
 }
 

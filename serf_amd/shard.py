@@ -27,12 +27,19 @@ class ShardedSim:
     """`Serf`-shaped facade over one shard; every rank issues the same API calls (the slot map
     and the op schedule are replicated, each shard applies the ops of the nodes it owns)."""
 
-    def __init__(self, lib: _ffi.SimLib, n_nodes: int, device: torch.device, group=None, chunks: int = 1, **kw):
+    def __init__(self, lib: _ffi.SimLib, n_nodes: int, device: torch.device, group=None, chunks: int = 1, exchange: str = "auto", **kw):
+        """exchange: who issues the round's all-to-all — "rccl": the library itself (sim_exchange_*: grouped ncclSend / ncclRecv on
+        a stream of its own, ordered against the chunk launches on the device), "torch": torch.distributed.all_to_all_single,
+        "auto": the library when the tensors live on a GPU, the process group is RCCL's and the library has the entry points.
+        A world of ONE rank runs the same path (SIM_CF_FORCE_SHARDED): the rehearsal of the N > 1 line on one GPU."""
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.device = device
         kw.update(vshards=self.world, shard_rank=self.rank, shard_count=self.world, chunks=chunks if chunks > 1 else 0)
+        if self.world == 1:
+            kw["force_sharded"] = True
+        self.lib = lib
         self.sim = _ffi.Sim(lib, _ffi.make_config(n_nodes, **kw))
         nbytes = self.sim.exchange_bytes()
         self.chunks, self.chunk_bytes = self.sim.exchange_chunks()
@@ -42,6 +49,17 @@ class ShardedSim:
         if device.type == "cuda":
             self.sim.set_stream(torch.cuda.current_stream(device).cuda_stream)
         self.sim.bind_exchange2(self.send.data_ptr(), self.recv[0].data_ptr(), self.recv[-1].data_ptr())
+        backend = dist.get_backend(group)
+        self.use_lib = exchange == "rccl" or (exchange == "auto" and device.type == "cuda" and backend == "nccl" and lib.exchange_library() is not None)
+        if self.use_lib:
+            # the communicator's id: made by rank 0 (ncclGetUniqueId through the library), handed round as plain bytes
+            idt = torch.zeros(_ffi.EXCHANGE_ID_BYTES, dtype=torch.uint8)
+            if self.rank == 0:
+                idt = torch.frombuffer(bytearray(lib.exchange_unique_id()), dtype=torch.uint8).clone()
+            if backend == "nccl":
+                idt = idt.to(device)
+            dist.broadcast(idt, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            self.sim.exchange_init(bytes(idt.cpu().numpy().tobytes()), self.rank, self.world)
         self.n = n_nodes
         self.m = n_nodes // self.world
         self.lo = self.rank * self.m
@@ -87,9 +105,32 @@ class ShardedSim:
     # the hot loop -----------------------------------------------------------------------------
     def _drain(self):
         """Every exchange of the previous round has landed (and the compute stream knows it)."""
+        if self.use_lib:
+            self.sim.exchange_wait()  # on the device: the handle's stream waits for the exchange stream, the host does not
+            return
         for w in self._pending:
             w.wait()
         self._pending = []
+
+    def collective_library(self):
+        """what moves the round's packets: "RCCL x.y.z (issued by the library: grouped ncclSend / ncclRecv)" or torch's backend"""
+        if self.use_lib:
+            return self.lib.exchange_library() + " — issued by libserf_sim (sim_exchange_chunk: grouped ncclSend / ncclRecv per peer)"
+        backend = dist.get_backend(self.group)
+        if backend == "nccl" and self.device.type == "cuda":
+            return "RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version()) + " — torch.distributed.all_to_all_single"
+        return backend
+
+    def snapshot(self):
+        """sim_snapshot of this shard.  The lists of slot-less suspicions that are still travelling (all-gathers of the last two
+        ticks) are waited for and imported first: they live in the host's buffers, not in the handle, and would be lost."""
+        self._drain()
+        if self._poll_suspects:
+            while self._sq_inflight:
+                t, i, done = self._sq_inflight.pop(0)
+                done.synchronize() if self.device.type == "cuda" else done.wait()
+                self.sim.suspect_import(t, self._sq_host[i].data_ptr(), self.world)
+        return self.sim.snapshot()
 
     def _recycle(self):
         """View-slot recycling needs every shard's verdict (include/serf_sim.h): scan locally, all-gather, keep the
@@ -173,23 +214,29 @@ class ShardedSim:
             if self.chunks == 1:
                 self.sim.step_chunk(0)  # reads recv (packets of the previous round), fills send
                 self.sim.step_end()
-                self._exchange(self.recv[0], self.send, False)
+                self._exchange(0, self.recv[0], self.send, False)
             else:
                 for c in range(self.chunks):
                     self.sim.step_chunk(c)
                     lo = c * self.chunk_bytes
-                    self._exchange(rbuf[lo:lo + self.chunk_bytes], self.send[lo:lo + self.chunk_bytes], True)
+                    self._exchange(c, rbuf[lo:lo + self.chunk_bytes], self.send[lo:lo + self.chunk_bytes], True)
                 self.sim.step_end()
             if self._poll_suspects:
                 self._suspicions_out()
 
-    def _exchange(self, recv, send, asynchronous):
+    def _exchange(self, c, recv, send, asynchronous):
         if self._xt is not None:  # measurement mode: bracket the collective with events, no overlap
             e0, e1 = self._event(), self._event()
             e0.record()
-            dist.all_to_all_single(recv, send, group=self.group)
+            if self.use_lib:
+                self.sim.exchange_chunk(c)
+                self.sim.exchange_wait()
+            else:
+                dist.all_to_all_single(recv, send, group=self.group)
             e1.record()
             self._xt.append((e0, e1))
+        elif self.use_lib:
+            self.sim.exchange_chunk(c)  # the library orders it behind chunk c's launch and ahead of the next tick, on the device
         elif asynchronous:
             self._pending.append(dist.all_to_all_single(recv, send, group=self.group, async_op=True))
         else:

@@ -118,7 +118,9 @@ def _worker(rank, world, port, n, ticks, swim, chunks, q, jitter=0.0, pkt=0, los
 @pytest.mark.parametrize("world,chunks,swim,n,jitter,pkt,loss,rc", [(2, 1, 0, 1024, 0, 0, .02, 0), (2, 1, 4, 1024, 0, 0, .02, 0), (2, 2, 4, 1024, 0, 0, .02, 0),
                                                                     (4, 2, 4, 1024, 0, 0, .02, 0), (4, 4, 0, 1024, 0, 0, .02, 0), (4, 4, 4, 4096, 0.004, 0, .02, 0),
                                                                     (2, 2, 4, 1024, 0, 16, .02, 0), (2, 1, 2, 1024, 0, 0, .12, 0), (4, 2, 2, 2048, 0, 16, .12, 0),
-                                                                    (2, 2, 1, 1024, 0, 0, .02, 2), (4, 1, 1, 1024, 0, 0, .0, 3)])
+                                                                    (2, 2, 1, 1024, 0, 0, .02, 2), (4, 1, 1, 1024, 0, 0, .0, 3),
+                                                                    # a world of ONE rank: the same path (SIM_CF_FORCE_SHARDED) against the plain handle
+                                                                    (1, 1, 4, 1024, 0, 0, .02, 0), (1, 2, 2, 1024, 0, 8, .12, 2)])
 def test_shards_gloo_match_single_process(world, chunks, swim, n, jitter, pkt, loss, rc):
     # chunks > 1: the tick runs as `chunks` launches, each followed by the asynchronous all-to-all of its slabs
     # (double-buffered receive side) — the overlapped path of serf_amd/shard.py

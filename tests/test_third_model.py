@@ -1,0 +1,126 @@
+"""The oracle (CPU) and the HIP library (GPU) against a THIRD model of the serf handlers (tests/third_model.py: pure Python,
+dictionary state, unbounded, written from the Rust sources alone).  Oracle and kernel have one author and one reading of
+base.rs; their 4-node known-answer tests pin single handlers.  Here whole runs are compared: the third model is fed the very
+packets the implementation under test delivers — its canonical inbox, dumped before every tick — and the API operations of
+the schedule, and after every tick every node's clocks, member table, buffered intents, both de-dup rings and every
+rebroadcast decision must be the same ("two restatements by one author").  Model bounds never bite in these runs
+(overflow == 0 is asserted): a bounded run without drops is the unbounded protocol (tests/test_oracle_unbounded.py)."""
+import numpy as np
+import pytest
+
+from serf_amd import _ffi
+from tests import third_model as tm
+from tests._oracle import load_oracle
+from tests import _scenario as sc
+
+RING_EV, RING_Q, PG = 64, 32, 4   # packets of 4 pages = 16 records: they carry a node's whole queue, nothing waits for a turn
+
+
+def run_against_third_model(sim, n, fanout, ops, ticks, joined):
+    nodes = [tm.Node(i, n, RING_EV, RING_Q, joined) for i in range(n)]
+    by_tick = {}
+    for o in ops:
+        by_tick.setdefault(o[0], []).append(o)
+        sim.inject(*o)
+    approved = [set() for _ in range(n)]   # every (kind, key, ltime) a node's delegate has asked to (re)broadcast so far
+    for t in range(ticks):
+        inbox = sim.dump(_ffi.ARR_INBOX).reshape(fanout * PG, n)   # the packets about to be delivered: [slot * PG + page][receiver]
+        # (0) the tick's operations, in call order (SIMSPEC §2.1)
+        for _, op, node, a, b in by_tick.get(t, ()):
+            x = nodes[node]
+            if op == _ffi.OP_CRASH:
+                x.up = False
+            elif op == _ffi.OP_REVIVE:
+                x.up = True
+            elif op == _ffi.OP_JOIN:
+                x.join()
+            elif op == _ffi.OP_LEAVE_FINISH:
+                if x.up and x.state == tm.S_LEAVING:
+                    x.state = tm.S_LEFT
+            elif not x.up:
+                pass
+            elif op == _ffi.OP_USER_EVENT:
+                x.user_event(a)
+            elif op == _ffi.OP_QUERY:
+                x.query(a, b & 15)
+            elif op == _ffi.OP_LEAVE:
+                x.leave()
+            elif op == _ffi.OP_FORCE_LEAVE:
+                x.force_leave(a, bool(b))
+        # (1) deliveries: slot 0 first, records in packet order
+        for i, x in enumerate(nodes):
+            if not x.up:
+                continue
+            for k in range(fanout * PG):
+                pk = inbox[k, i]
+                for r in range(4):
+                    hm = int(pk["hi_meta"][r])
+                    kind = (hm >> 4) & 15
+                    if kind == 0:
+                        continue
+                    assert kind <= 4, "the SWIM layer is off in these runs"
+                    x.notify(kind, int(pk["key"][r]), int(pk["val_lo"][r]) | ((hm >> 16) << 32), hm & 15)
+        sim.step(1)
+        # ---- compare
+        rows = sim.dump(_ffi.ARR_ROWS)
+        view = sim.dump(_ffi.ARR_VIEW).reshape(n, n)        # dense view: [subject][observer]
+        er = sim.dump(_ffi.ARR_ERING).reshape(RING_EV, n)
+        qr = sim.dump(_ffi.ARR_QRING).reshape(RING_Q, n)
+        queue = sim.dump(_ffi.ARR_QUEUE).reshape(n, 16)
+        assert int(rows["overflow"].sum()) == 0, f"tick {t}: a model bound was hit"
+
+        for i, x in enumerate(nodes):
+            w = f"tick {t} node {i}"
+            assert (int(rows["clock"][i]), int(rows["event_clock"][i]), int(rows["query_clock"][i])) == \
+                   (x.clock.time(), x.event_clock.time(), x.query_clock.time()), w
+            assert bool(rows["flags"][i] & 1) == x.up and ((int(rows["flags"][i]) >> 1) & 3) == x.state, w
+            assert int(rows["n_known"][i]) == len(x.members), w
+            for s in range(n):
+                e = view[s, i]
+                bits = int(e["bits"])
+                if s in x.members:
+                    assert bits & 1 and ((bits >> 1) & 7, int(e["ltime"])) == tuple(x.members[s]), f"{w} subject {s}"
+                else:
+                    it = x.intents.get(s)
+                    assert not (bits & 1), f"{w} subject {s}"
+                    assert ((bits >> 6) & 3, int(e["ltime"])) == ((it[0], it[1]) if it else (0, 0)), f"{w} subject {s} intent"
+            for ring, buf, name in ((er, x.event_buf, "event"), (qr, x.query_buf, "query")):
+                for j, want in enumerate(buf):
+                    b = ring[j, i]
+                    got = [int(v) for v in b["keys"] if v]
+                    if want is None:
+                        assert not got, f"{w} {name} bucket {j}"
+                    else:
+                        assert (int(b["ltime"]), got) == (want[0], want[1]), f"{w} {name} bucket {j}"
+            # every rebroadcast the delegate asked for this tick is in the node's queue (nothing expires within a tick:
+            # retransmit limit 8 > fanout); everything in the queue was asked for at some point
+            approved[i].update(x.rebroadcast)
+            live = {(int((r["meta"] >> 4) & 15), int(r["key"]), int(r["val"])) for r in queue[i] if r["meta"] != 0xFFFFFFFF}
+            if x.up:
+                assert set(x.rebroadcast) <= live, f"{w}: asked for {set(x.rebroadcast) - live} and it is not queued"
+            assert live <= approved[i], f"{w}: queued without the delegate's say: {live - approved[i]}"
+            x.rebroadcast = []
+
+
+def _schedule(n, ticks, seed, joined):
+    ops = sc.schedule(n, ticks - 20, rate=0.6, seed=seed, mix=(0.45, 0.2, 0.15, 0.1, 0.1), max_member_subjects=n // 3)
+    if not joined:  # nobody knows anybody (and with the SWIM layer off nobody ever will): every intent about another node is buffered
+        ops = [o for o in ops if o[1] != _ffi.OP_FORCE_LEAVE or True]
+    return ops
+
+
+@pytest.mark.parametrize("seed,n,fanout,joined", [(1, 48, 3, True), (2, 64, 4, True), (3, 33, 2, True), (4, 48, 3, False), (5, 20, 3, False)])   # (not joined: every node knows one member, the retransmit limit is 4 — fan-out 3 keeps a record queued past its tick)
+def test_oracle_matches_the_third_model(seed, n, fanout, joined):
+    kw = dict(fanout=fanout, view_slots=0, event_ring=RING_EV, query_ring=RING_Q, leave_delay=4, pkt_records=4 * PG,
+              flags=_ffi.CF_BASELINE_JOINED if joined else 0)
+    sim = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw))
+    run_against_third_model(sim, n, fanout, _schedule(n, 70, seed, joined), 70, joined)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,fanout,joined,rf", [(1, 48, 3, True, False), (2, 64, 4, True, False), (4, 48, 3, False, False)])
+def test_hip_matches_the_third_model(hiplib, seed, n, fanout, joined, rf):
+    kw = dict(fanout=fanout, view_slots=0, event_ring=RING_EV, query_ring=RING_Q, leave_delay=4, pkt_records=4 * PG,
+              flags=_ffi.CF_BASELINE_JOINED if joined else 0)
+    sim = _ffi.Sim(hiplib, _ffi.make_config(n, **kw))
+    run_against_third_model(sim, n, fanout, _schedule(n, 70, seed, joined), 70, joined)

@@ -1,0 +1,202 @@
+"""A THIRD, independent model of serf-core's per-message handlers — test infrastructure, pure Python, dictionary state like the
+reference's `HashMap`s, no capacity bounds — written from the Rust sources alone (not from oracle/serf_oracle.c, not from the
+HIP kernel), so that a misreading the oracle and the kernel share (they have one author and one reading of base.rs) has
+somewhere to show: tests/test_third_model.py feeds it the very record stream the oracle (or the HIP library) delivers at
+N <= 64 and compares clocks, member table, intents, de-dup rings and every rebroadcast decision, node by node, tick by tick.
+
+Reference (relative to /root/reference/serf-core/src/):
+  LamportClock            types/clock.rs:125-172   (new = 0, `Serf::new` increments every clock once: serf/base.rs:196-205)
+  handle_user_event       serf/base.rs:750-837
+  handle_query (de-dup)   serf/base.rs:972-1073
+  handle_node_join_intent serf/base.rs:1338-1373
+  handle_node_leave_intent serf/base.rs:1442-1572
+  upsert_intent           serf/base.rs:1835-1866
+  broadcast_join          serf/base.rs:381-397
+  Serf::user_event        serf/api.rs:241-299     Serf::query  serf/base.rs:875-942
+  Serf::leave             serf/api.rs:422-460     force_leave  serf/base.rs:452-480     Serf::join  serf/api.rs:318-364
+"""
+NONE, ALIVE, LEAVING, LEFT, FAILED = 0, 1, 2, 3, 4          # MemberStatus, types/member.rs:54-87
+S_ALIVE, S_LEAVING, S_LEFT, S_SHUTDOWN = 0, 1, 2, 3         # SerfState, serf.rs:80-89
+JOIN, LEAVE, EVENT, QUERY = 1, 2, 3, 4                      # the record kinds of the simulated packets
+NO_BROADCAST = 1                                            # QueryFlag::NO_BROADCAST as the simulator carries it
+
+
+class Clock:
+    """types/clock.rs:125-172"""
+
+    def __init__(self):
+        self.v = 0
+
+    def time(self):
+        return self.v
+
+    def increment(self):
+        self.v += 1
+        return self.v
+
+    def witness(self, t):
+        if t < self.v:
+            return
+        self.v = t + 1
+
+
+class Node:
+    def __init__(self, me, n, ring_ev, ring_q, everybody_joined):
+        self.me, self.up, self.state = me, True, S_ALIVE
+        self.clock, self.event_clock, self.query_clock = Clock(), Clock(), Clock()
+        for c in (self.clock, self.event_clock, self.query_clock):
+            c.increment()                                   # serf/base.rs:196-205
+        self.members = {}                                   # id -> [status, status_time]   (Members.states)
+        self.intents = {}                                   # id -> [type, ltime]           (Members.recent_intents)
+        self.event_buf = [None] * ring_ev                   # EventCore.buffer: Option<UserEvents{ltime, events}>
+        self.query_buf = [None] * ring_q                    # QueryCore.buffer: Option<Queries{ltime, query_ids}>
+        self.event_min = self.query_min = 0
+        self.rebroadcast = []                               # (kind, key, ltime) the delegate re-queues, in order
+        if everybody_joined:                                # the simulator's pre-joined baseline: every member Alive at status_time 1,
+            for s in range(n):                              # the own join at ltime 1 witnessed
+                self.members[s] = [ALIVE, 1]
+            self.clock.witness(1)
+        else:
+            self.members[me] = [ALIVE, 0]                   # new_in's synthetic notify_join(local)
+
+    # ---- serf/base.rs:1835-1866
+    def upsert_intent(self, node, ty, ltime):
+        cur = self.intents.get(node)
+        if cur is not None:
+            if ltime > cur[1]:
+                cur[0], cur[1] = ty, ltime
+                return True
+            return False
+        self.intents[node] = [ty, ltime]
+        return True
+
+    # ---- serf/base.rs:1338-1373
+    def handle_node_join_intent(self, node, ltime):
+        self.clock.witness(ltime)
+        member = self.members.get(node)
+        if member is None:
+            return self.upsert_intent(node, JOIN, ltime)
+        if ltime <= member[1]:
+            return False
+        member[1] = ltime
+        if member[0] == LEAVING:
+            member[0] = ALIVE
+        return True
+
+    # ---- serf/base.rs:381-397
+    def broadcast_join(self, ltime):
+        self.clock.witness(ltime)
+        self.handle_node_join_intent(self.me, ltime)
+        self.rebroadcast.append((JOIN, self.me, ltime))
+
+    # ---- serf/base.rs:1442-1572
+    def handle_node_leave_intent(self, node, ltime, prune=False):
+        state = self.state
+        self.clock.witness(ltime)
+        if node not in self.members:
+            return self.upsert_intent(node, LEAVE, ltime)
+        member = self.members[node]
+        if ltime <= member[1]:
+            return False
+        if node == self.me and state == S_ALIVE:            # refute: a join at the current clock, nothing rebroadcast
+            self.broadcast_join(self.clock.time())
+            return False
+        member[1] = ltime
+        st = member[0]
+        if st == NONE:
+            return False
+        if st == ALIVE:
+            member[0] = LEAVING
+        elif st == FAILED:
+            member[0] = LEFT
+        elif st not in (LEAVING, LEFT):
+            member[0] = LEAVING
+        if prune:                                           # handle_prune: the member is erased (serf/base.rs:1628-1653)
+            del self.members[node]
+            self.intents.pop(node, None)
+        return True
+
+    # ---- serf/base.rs:750-837
+    def handle_user_event(self, key, ltime):
+        self.event_clock.witness(ltime)
+        if ltime < self.event_min:
+            return False
+        b = len(self.event_buf)
+        cur = self.event_clock.time()
+        if cur > b and ltime < cur - b:
+            return False
+        idx = ltime % b
+        seen = self.event_buf[idx]
+        if seen is not None:
+            if key in seen[1]:                              # (the bucket's ltime is NOT compared: base.rs:801-806)
+                return False
+            seen[1].append(key)
+        else:
+            self.event_buf[idx] = [ltime, [key]]
+        return True
+
+    # ---- serf/base.rs:972-1073 (the filters, acks and responses behind it are not part of this model)
+    def handle_query(self, qid, ltime, flags):
+        self.query_clock.witness(ltime)
+        if ltime < self.query_min:
+            return False
+        cur = self.query_clock.time()
+        q_time = len(self.query_buf)
+        if cur > q_time and q_time < cur - q_time:          # (sic: base.rs:1013)
+            return False
+        idx = ltime % q_time
+        seen = self.query_buf[idx]
+        if seen is not None:
+            if seen[0] == ltime and qid in seen[1]:
+                return False
+            seen[1].append(qid)                             # (the bucket keeps its old ltime: base.rs:1035)
+        else:
+            self.query_buf[idx] = [ltime, [qid]]
+        return not (flags & NO_BROADCAST)
+
+    # ---- SerfDelegate::notify_message, serf/delegate.rs:183-300: dispatch, re-queue the original message when told to
+    def notify(self, kind, key, ltime, flags):
+        if kind == LEAVE:
+            rb = self.handle_node_leave_intent(key, ltime, bool(flags & 1))
+        elif kind == JOIN:
+            rb = self.handle_node_join_intent(key, ltime)
+        elif kind == EVENT:
+            rb = self.handle_user_event(key, ltime)
+        elif kind == QUERY:
+            rb = self.handle_query(key, ltime, flags)
+        else:
+            return
+        if rb:
+            self.rebroadcast.append((kind, key, ltime))
+
+    # ---- the user-facing calls
+    def user_event(self, key):                              # serf/api.rs:241-299
+        ltime = self.event_clock.time()
+        self.event_clock.increment()
+        self.handle_user_event(key, ltime)
+        self.rebroadcast.append((EVENT, key, ltime))
+
+    def query(self, qid, flags):                            # serf/base.rs:875-942
+        ltime = self.query_clock.time()
+        self.handle_query(qid, ltime, flags)
+        self.rebroadcast.append((QUERY, qid, ltime))
+
+    def leave(self, others_alive=True):                     # serf/api.rs:422-460
+        if self.state != S_ALIVE:
+            return
+        self.state = S_LEAVING
+        ltime = self.clock.time()
+        self.clock.increment()
+        self.handle_node_leave_intent(self.me, ltime)
+        if others_alive:
+            self.rebroadcast.append((LEAVE, self.me, ltime))
+
+    def force_leave(self, subject, prune, others_alive=True):   # serf/base.rs:452-480
+        ltime = self.clock.time()
+        self.handle_node_leave_intent(subject, ltime, prune)
+        if others_alive:
+            self.rebroadcast.append((LEAVE, subject, ltime))
+
+    def join(self):                                         # serf/api.rs:318-364 behind memberlist.join
+        self.up, self.state = True, S_ALIVE
+        self.broadcast_join(self.clock.time())
