@@ -1680,6 +1680,8 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
           ptr = lookup_ptr(c, vbase, eoff, qoff, kind, r.x, (u64)r.z | ((u64)r.w << 32), slot_load(d, kind, r.x));
         }
       };
+      // (tried: the head of the NEXT record requested while this record's handler runs — ten more live registers across the
+      // handlers, 10 spilled VGPRs, + 6 %: profiles/r04_experiments.md)
       auto run = [&](const uint4& r, uint4* ptr) __attribute__((always_inline)) {
         uint4 e = ld4(ptr ? ptr : d.nullcell);
         Ins ins;
@@ -2403,46 +2405,35 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
 // that needs a target draws it again instead of reading it (a handful of mix64 per node against 16 bytes of HBM).
 // What the tick kernel needs of it: for every receiver the row rsrc[rcsr[t] .. rcsr[t + 1]) of the (sender, slot) pairs
 // p = 4 l + k that drew it, p ascending: the oracle hands a node its packets in (sender, slot) order.  That is a sort of
-// f * N pairs by (target, p); the keys are
-// uniform, so it is done as a two-level bucket sort written for this job (no library on the per-tick path):
-//   rf_count    every workgroup draws the targets of its SPW senders and counts them per level-1 bucket (= 2^LB consecutive
-//               targets) in an LDS histogram                                       -> ghist[workgroup][bucket]
-//   rf_scan     per bucket: exclusive prefix over the workgroups, bucket totals    -> ghist (in place), btot[bucket]
-//   rf_bstart   exclusive prefix over the bucket totals                            -> bstart[bucket], bstart[NB]
-//   rf_scatter  the same draws again; pair p goes to l1[bstart[b] + ghist[wg][b] + (LDS cursor of b)++] — any order inside
-//               a bucket will do, because the order that counts is restored by rank, not by stability
-//   rf_rows     one workgroup per bucket (~ 4 * 2^LB pairs): LDS counting sort by target -> the bucket's part of rcsr; then
-//               every pair ranks itself among the ~ f pairs of its row (p ascending) -> its place in rsrc.  A bucket that does
-//               not fit the LDS tables (never with uniform draws; forced by the tests through SERF_RF_CAP) ranks straight from l1.
+// f * N pairs by (target, p); the keys are uniform, so it is done as a two-level bucket sort written for this job (no
+// library on the per-tick path), two launches per tick:
+//   rf_scatter  every workgroup draws the targets of its SPW senders, counts them per level-1 bucket (= 2^LB consecutive
+//               targets) in LDS, reserves its share of every bucket's REGION with one global atomic per (workgroup, bucket),
+//               draws again and writes the pairs there: l1[b * bcap + ...], runs of ~ 4 SPW / NB pairs.  The regions have a
+//               fixed capacity bcap (mean 4 * 2^LB + 12 sigma: uniform draws never fill one); what does not fit all the
+//               same goes onto an overflow list.  Any order inside a bucket will do: the order that counts is restored by
+//               rank, not by stability — so the result does not depend on who won which atomic.
+//   rf_rows     one workgroup per bucket: its place in the output = the sum of the totals of the buckets before it; an LDS
+//               counting sort by target -> the bucket's part of rcsr; every pair ranks itself among the ~ f pairs of its row
+//               (p ascending) -> its place in rsrc, laid down in LDS and written out as one run.  Pairs and targets stay in
+//               registers between the passes.  A bucket that does not fit the LDS tables (never with uniform draws; forced
+//               by the tests through SERF_RF_CAP) ranks straight from global memory.
 struct RfP {
   u64 rb;       // rng_base(seed, STREAM_RFAN, tick)
   u32 N, Nl, shard0, feff, f;
   u32 LB, NB;   // level-1 buckets: NB = ceil(Nl / 2^LB) ranges of 2^LB consecutive (local) targets
-  u32 SPW, NWG; // senders per workgroup of rf_count / rf_scatter, number of those workgroups
-  u32 cap;      // pairs rf_rows can rank in LDS
+  u32 PB;       // bits of a pair id p = 4 l + k; a scattered entry is (target - bucket start) << PB | p — 32 bits when they fit
+  u32 NWG;      // workgroups of rf_scatter (RF_SPW senders each)
+  u32 cap;      // pairs rf_rows can rank in LDS (a multiple of RFR, at most RF_EPT * RFR)
+  u32 bcap;     // pairs a bucket's region of l1 holds
+  u32 ocap;     // entries of the overflow list
 };
-#define RFB 1024          // threads of an rf_* workgroup
-#define RF_LB_MAX 12u     // at most 4096 rows per level-1 bucket
-__device__ static inline u32 rf_target_of(const RfP& r, u32 p) {  // the target of pair p = 4 l + k (it has one: it was scattered)
-  u32 ch[SIM_MAX_FANOUT];
-  rf_draw(r.rb, r.shard0 + (p >> 2), r.N, r.feff, ch);
-  return SEL4(p & 3u, ch[0], ch[1], ch[2], ch[3]);
-}
-__global__ __launch_bounds__(RFB) void rf_count_kernel(RfP r, u32* ghist) {
-  extern __shared__ u32 rf_lds[];  // [NB]
-  for (u32 b = threadIdx.x; b < r.NB; b += RFB) rf_lds[b] = 0;
-  __syncthreads();
-  const u32 l0 = blockIdx.x * r.SPW;
-  for (u32 i = threadIdx.x; i < r.SPW && l0 + i < r.Nl; i += RFB) {
-    u32 ch[SIM_MAX_FANOUT];
-    const u32 nc = rf_draw(r.rb, r.shard0 + l0 + i, r.N, r.feff, ch);
-#pragma unroll
-    for (u32 k = 0; k < SIM_MAX_FANOUT; ++k)
-      if (k < nc) atomicAdd(&rf_lds[(ch[k] - r.shard0) >> r.LB], 1u);
-  }
-  __syncthreads();
-  for (u32 b = threadIdx.x; b < r.NB; b += RFB) ghist[(size_t)blockIdx.x * r.NB + b] = rf_lds[b];
-}
+#define RFB 1024          // threads of an rf_scatter workgroup
+#define RF_GCS 1u         // stride of the buckets' fill counters in words (a line each — 32 — made the atomics slower: 55.7 vs 47.6 us, profiles/r04_experiments.md)
+#define RF_SPW 4096u      // senders of an rf_scatter workgroup: four per thread, their targets stay in registers between its two passes
+#define RFR 512           // threads of an rf_rows workgroup
+#define RF_LB_MAX 11u     // at most 2048 rows per level-1 bucket
+#define RF_EPT 24u        // pairs one thread of rf_rows keeps in registers: cap <= RF_EPT * RFR
 // exclusive prefix over the 64 lanes of a wave (`total` = the sum)
 __device__ static inline u32 wave_excl_scan(u32 v, u32& total) {
   u32 x = v;
@@ -2454,116 +2445,147 @@ __device__ static inline u32 wave_excl_scan(u32 v, u32& total) {
   total = (u32)__shfl((int)x, 63, 64);
   return x - v;
 }
-// one WAVE per bucket: lane i takes the workgroups [i * per, (i + 1) * per) of the bucket's column (loads 16 KiB apart — the
-// neighbouring columns belong to the neighbouring waves and share the lines: an L2 matter, 4 MiB in all at 1 Mi nodes)
-__global__ __launch_bounds__(BLOCK) void rf_scan_kernel(RfP r, u32* ghist, u32* btot) {
-  const u32 b = blockIdx.x * (BLOCK / 64u) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-  if (b >= r.NB) return;
-  const u32 per = (r.NWG + 63u) / 64u, w0 = lane * per;
-  u32 v[4], sum = 0;  // per <= 4: NWG <= 256
-#pragma unroll
-  for (u32 j = 0; j < 4; ++j) {
-    v[j] = (j < per && w0 + j < r.NWG) ? ghist[(size_t)(w0 + j) * r.NB + b] : 0u;
-    sum += v[j];
-  }
-  u32 total, run = wave_excl_scan(sum, total);
-#pragma unroll
-  for (u32 j = 0; j < 4; ++j)
-    if (j < per && w0 + j < r.NWG) { ghist[(size_t)(w0 + j) * r.NB + b] = run; run += v[j]; }
-  if (lane == 0) btot[b] = total;
-}
-__global__ __launch_bounds__(1024) void rf_bstart_kernel(RfP r, const u32* btot, u32* bstart) {
-  __shared__ u32 part[1024];
-  const u32 per = (r.NB + 1023u) / 1024u, b0 = threadIdx.x * per;
-  u32 sum = 0;
-  for (u32 i = 0; i < per && b0 + i < r.NB; ++i) sum += btot[b0 + i];
-  part[threadIdx.x] = sum;
+// gcur[NB]: pairs in each bucket so far (zero at launch: rf_rows of the build before zeroed it); ovf: [0] = entries, then (bucket, entry) pairs
+template <typename E>
+__global__ __launch_bounds__(RFB) void rf_scatter_kernel(RfP r, u32* gcur, E* l1, E* ovf) {
+  extern __shared__ u32 rf_lds[];  // [NB] counts, then the workgroup's base in the bucket's region; [NB] cursors
+  u32 *cnt = rf_lds, *cur = rf_lds + r.NB;
+  for (u32 b = threadIdx.x; b < 2u * r.NB; b += RFB) rf_lds[b] = 0;
   __syncthreads();
-  for (u32 o = 1; o < 1024u; o <<= 1) {  // Hillis-Steele over the 1024 partial sums
-    u32 v = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
+  const u32 l0 = blockIdx.x * RF_SPW;
+  u32 tg[RF_SPW / RFB][SIM_MAX_FANOUT], nc[RF_SPW / RFB];
+#pragma unroll
+  for (u32 j = 0; j < RF_SPW / RFB; ++j) {
+    const u32 l = l0 + j * RFB + threadIdx.x;
+    nc[j] = l < r.Nl ? rf_draw(r.rb, r.shard0 + l, r.N, r.feff, tg[j]) : 0u;
+#pragma unroll
+    for (u32 k = 0; k < SIM_MAX_FANOUT; ++k)
+      if (k < nc[j]) atomicAdd(&cnt[(tg[j][k] - r.shard0) >> r.LB], 1u);
   }
-  u32 run = part[threadIdx.x] - sum;
-  for (u32 i = 0; i < per && b0 + i < r.NB; ++i) { bstart[b0 + i] = run; run += btot[b0 + i]; }
-  if (threadIdx.x == 1023u) bstart[r.NB] = part[1023];
-}
-__global__ __launch_bounds__(RFB) void rf_scatter_kernel(RfP r, const u32* ghist, const u32* bstart, u32* l1) {
-  extern __shared__ u32 rf_lds[];  // [NB] cursors
-  for (u32 b = threadIdx.x; b < r.NB; b += RFB) rf_lds[b] = 0;
   __syncthreads();
-  const u32 l0 = blockIdx.x * r.SPW;
-  for (u32 i = threadIdx.x; i < r.SPW && l0 + i < r.Nl; i += RFB) {
-    u32 ch[SIM_MAX_FANOUT];
-    const u32 l = l0 + i, nc = rf_draw(r.rb, r.shard0 + l, r.N, r.feff, ch);
+  for (u32 b = threadIdx.x; b < r.NB; b += RFB) {
+    const u32 c = cnt[b];
+    cnt[b] = c ? atomicAdd(&gcur[(size_t)b * RF_GCS], c) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (u32 j = 0; j < RF_SPW / RFB; ++j) {
+    const u32 l = l0 + j * RFB + threadIdx.x;
 #pragma unroll
     for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) {
-      if (k < nc) {
-        const u32 b = (ch[k] - r.shard0) >> r.LB;
-        l1[bstart[b] + ghist[(size_t)blockIdx.x * r.NB + b] + atomicAdd(&rf_lds[b], 1u)] = 4u * l + k;
-      }  // (a slot without a target — fewer other nodes than the fan-out — is in nobody's row)
+      if (k < nc[j]) {  // (a slot without a target — fewer other nodes than the fan-out — is in nobody's row)
+        const u32 t = tg[j][k] - r.shard0, b = t >> r.LB, at = cnt[b] + atomicAdd(&cur[b], 1u);
+        const E e = ((E)(t - (b << r.LB)) << r.PB) | (E)(4u * l + k);
+        if (at < r.bcap) l1[(size_t)b * r.bcap + at] = e;
+        else {
+          const u32 o = atomicAdd(reinterpret_cast<u32*>(ovf), 1u);
+          if (o < r.ocap) { ovf[1u + 2u * o] = (E)b; ovf[2u + 2u * o] = e; }
+        }
+      }
     }
   }
 }
-// LDS of rf_rows (dynamic): cnt[R + 1] | cur[R] | rowp[cap] | ent_t[cap] (u16)
-static inline size_t rf_rows_lds(const RfP& r) { return ((size_t)(2u << r.LB) + 1u + r.cap) * 4u + (size_t)r.cap * 2u + 16u; }
-__global__ __launch_bounds__(RFB) void rf_rows_kernel(RfP r, const u32* bstart, const u32* l1, u32* rcsr, u32* rsrc) {
+// LDS of rf_rows (dynamic): cnt[R + 1] | cur[R] | rowp[cap]
+static inline size_t rf_rows_lds(const RfP& r) { return ((size_t)(2u << r.LB) + 1u + r.cap) * 4u + 16u; }
+template <typename E>
+__global__ __launch_bounds__(RFR) void rf_rows_kernel(RfP r, u32* gcur, u32* gcur_next, const E* l1, E* ovf, E* ovf_next, u32* rcsr, u32* rsrc) {
   extern __shared__ u32 rf_lds[];
   const u32 R = 1u << r.LB;
   u32 *cnt = rf_lds, *cur = cnt + R + 1u, *rowp = cur + R;
-  uint16_t* ent_t = reinterpret_cast<uint16_t*>(rowp + r.cap);
-  __shared__ u32 wtot[RFB / 64u];
-  const u32 b = blockIdx.x, base = bstart[b], n = bstart[b + 1] - base;
+  __shared__ u32 wtot[RFR / 64u], s_base;
+  const u32 b = blockIdx.x, n = gcur[(size_t)b * RF_GCS], nreg = min(n, r.bcap);
   const u32 t0 = b << r.LB, nrows = min(R, r.Nl - t0);
-  for (u32 i = threadIdx.x; i <= R; i += RFB) cnt[i] = 0;
-  __syncthreads();
-  const bool fits = n <= r.cap;
-  for (u32 i = threadIdx.x; i < n; i += RFB) {
-    const u32 tl = rf_target_of(r, l1[base + i]) - r.shard0 - t0;
-    if (fits) ent_t[i] = (uint16_t)tl;
-    atomicAdd(&cnt[tl], 1u);
-  }
-  __syncthreads();
-  {  // exclusive prefix over the bucket's rows: every thread R / 1024 consecutive ones (R <= 4096; a smaller R: one each)
-    const u32 per = (R + RFB - 1u) / RFB, i0 = threadIdx.x * per;
-    u32 v[(1u << RF_LB_MAX) / RFB], sum = 0;
-#pragma unroll
-    for (u32 j = 0; j < (1u << RF_LB_MAX) / RFB; ++j) { v[j] = (j < per && i0 + j < R) ? cnt[i0 + j] : 0u; sum += v[j]; }
-    u32 wsum, run = wave_excl_scan(sum, wsum);
+  const E pmask = ((E)1 << r.PB) - (E)1;
+  // the bucket's place in the output: behind everything the buckets before it hold
+  {
+    u32 part = 0;
+    for (u32 i = threadIdx.x; i < b; i += RFR) part += gcur[(size_t)i * RF_GCS];
+    u32 wsum;
+    (void)wave_excl_scan(part, wsum);
     if ((threadIdx.x & 63u) == 0) wtot[threadIdx.x >> 6] = wsum;
+  }
+  for (u32 i = threadIdx.x; i <= R; i += RFR) cnt[i] = 0;
+  for (u32 i = threadIdx.x; i < R; i += RFR) cur[i] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 sum = 0;
+    for (u32 w = 0; w < RFR / 64u; ++w) sum += wtot[w];
+    s_base = sum;
+    gcur_next[(size_t)b * RF_GCS] = 0;  // the next build's counters start from zero (it runs behind this one, on the same stream)
+    if (b == 0) *reinterpret_cast<u32*>(ovf_next) = 0;
+  }
+  // entry i of the bucket: the first nreg in its region of l1, the rest on the overflow list (any order)
+  auto entry = [&](u32 i) __attribute__((always_inline)) -> E {
+    if (i < nreg) return l1[(size_t)b * r.bcap + i];
+    u32 seen = 0, tot = min(*reinterpret_cast<const u32*>(ovf), r.ocap);
+    for (u32 j = 0; j < tot; ++j)
+      if (ovf[1u + 2u * j] == (E)b) { if (seen == i - nreg) return ovf[2u + 2u * j]; ++seen; }
+    return (E)0;  // (cannot happen: the list holds the rest of this bucket — it cannot run full, sim_create sizes it for every pair)
+  };
+  const bool fits = n <= r.cap;
+  u32 pv[RF_EPT];
+  uint16_t tv[RF_EPT];
+#pragma unroll
+  for (u32 j = 0; j < RF_EPT; ++j) {
+    const u32 i = threadIdx.x + j * RFR;
+    pv[j] = NOSLOT; tv[j] = 0;
+    if (fits && i < n) {
+      const E e = entry(i);
+      pv[j] = (u32)(e & pmask);
+      tv[j] = (uint16_t)(e >> r.PB);
+      atomicAdd(&cnt[tv[j]], 1u);
+    }
+  }
+  if (!fits)
+    for (u32 i = threadIdx.x; i < n; i += RFR) atomicAdd(&cnt[(u32)(entry(i) >> r.PB)], 1u);
+  __syncthreads();
+  const u32 base = s_base;
+  {  // exclusive prefix over the bucket's rows: every thread R / RFR consecutive ones (R <= 4096; a smaller R: one each)
+    const u32 per = (R + RFR - 1u) / RFR, i0 = threadIdx.x * per;
+    u32 v[(1u << RF_LB_MAX) / RFR], sum = 0;
+#pragma unroll
+    for (u32 j = 0; j < (1u << RF_LB_MAX) / RFR; ++j) { v[j] = (j < per && i0 + j < R) ? cnt[i0 + j] : 0u; sum += v[j]; }
+    u32 wsum, run = wave_excl_scan(sum, wsum);
+    if ((threadIdx.x & 63u) == 0) wtot[threadIdx.x >> 6] = wsum;  // (everybody is past the sync behind the first use of wtot)
     __syncthreads();
     for (u32 w = 0; w < (threadIdx.x >> 6); ++w) run += wtot[w];
 #pragma unroll
-    for (u32 j = 0; j < (1u << RF_LB_MAX) / RFB; ++j)
+    for (u32 j = 0; j < (1u << RF_LB_MAX) / RFR; ++j)
       if (j < per && i0 + j < R) { cnt[i0 + j] = run; run += v[j]; }
-    if (threadIdx.x == RFB - 1u) cnt[R] = run;
+    if (threadIdx.x == RFR - 1u) cnt[R] = run;
   }
-  for (u32 i = threadIdx.x; i < R; i += RFB) cur[i] = 0;
   __syncthreads();
-  for (u32 i = threadIdx.x; i < nrows; i += RFB) rcsr[t0 + i] = base + cnt[i];
+  for (u32 i = threadIdx.x; i < nrows; i += RFR) rcsr[t0 + i] = base + cnt[i];
   if (b == r.NB - 1u && threadIdx.x == 0) rcsr[r.Nl] = base + n;
   if (fits) {
-    for (u32 i = threadIdx.x; i < n; i += RFB) {
-      const u32 tl = ent_t[i];
-      rowp[cnt[tl] + atomicAdd(&cur[tl], 1u)] = l1[base + i];
-    }
+#pragma unroll
+    for (u32 j = 0; j < RF_EPT; ++j)
+      if (pv[j] != NOSLOT) rowp[cnt[tv[j]] + atomicAdd(&cur[tv[j]], 1u)] = pv[j];
     __syncthreads();
-    for (u32 i = threadIdx.x; i < n; i += RFB) {
-      const u32 tl = ent_t[i], p = l1[base + i], lo = cnt[tl], hi = cnt[tl + 1];
-      u32 rank = 0;
-      for (u32 j = lo; j < hi; ++j) rank += rowp[j] < p ? 1u : 0u;
-      rsrc[base + lo + rank] = p;  // (inside the bucket's own window of the array: the workgroup's stores meet in L2)
+#pragma unroll
+    for (u32 j = 0; j < RF_EPT; ++j) {
+      if (pv[j] != NOSLOT) {
+        const u32 lo = cnt[tv[j]], hi = cnt[tv[j] + 1u];
+        u32 rank = 0;
+        for (u32 q = lo; q < hi; ++q) rank += rowp[q] < pv[j] ? 1u : 0u;
+        tv[j] = (uint16_t)(lo + rank);  // (its place in the bucket: below 2^16, the row is not needed any more)
+      }
     }
-  } else {  // the bucket does not fit the tables: rank every pair against the whole bucket, straight from l1
-    for (u32 i = threadIdx.x; i < n; i += RFB) {
-      const u32 p = l1[base + i], tl = rf_target_of(r, p) - r.shard0 - t0;
+    __syncthreads();  // the rows have been read: the sorted bucket goes into the same LDS, then out as one run
+#pragma unroll
+    for (u32 j = 0; j < RF_EPT; ++j)
+      if (pv[j] != NOSLOT) rowp[tv[j]] = pv[j];
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < n; i += RFR) rsrc[base + i] = rowp[i];
+  } else {  // the bucket does not fit the tables: rank every pair against the whole bucket, straight from global memory
+    for (u32 i = threadIdx.x; i < n; i += RFR) {
+      const E e = entry(i);
       u32 rank = 0;
       for (u32 j = 0; j < n; ++j) {
-        const u32 q = l1[base + j];
-        rank += (q < p && rf_target_of(r, q) - r.shard0 - t0 == tl) ? 1u : 0u;
+        const E q = entry(j);
+        rank += ((q >> r.PB) == (e >> r.PB) && (q & pmask) < (e & pmask)) ? 1u : 0u;
       }
-      rsrc[base + cnt[tl] + rank] = p;
+      rsrc[base + cnt[(u32)(e >> r.PB)] + rank] = (u32)(e & pmask);
     }
   }
 }
@@ -3405,7 +3427,10 @@ struct sim_handle {
   hipEvent_t xev_go, xev_done;
   u32 xworld;
   bool xpending;  // exchanges issued since the handle's stream last waited for them
-  u32 *rf_ghist, *rf_btot, *rf_bstart, *rf_l1;
+  u32 *rf_gcur[2];     // bucket fill counters (two: a build zeroes the next one's)
+  void *rf_ovf[2], *rf_l1;  // overflow lists (two, likewise) and the buckets' regions: u32 entries when a pair id and a target's offset fit, u64 otherwise
+  bool rf_wide;        // ... u64
+  u32 rf_par;                          // which of the two this build uses
   RfP rfp;  // the parameters that do not change from tick to tick
   // The graph of tick s is a function of (seed, s): it is built on a stream of its own while tick s - 1 runs.  rf_rcsr[s % 3] /
   // rf_rsrc[s % 3] = the rows of the packets SENT during tick s (tick s + 1 still reads them while the build of tick s + 2
@@ -3628,29 +3653,46 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   d.rcsr = d.rsrc = nullptr;
   for (int i = 0; i < 3; ++i) h->rf_rcsr[i] = h->rf_rsrc[i] = nullptr;
   h->rf_stream = nullptr; h->rf_done = h->rf_go[0] = h->rf_go[1] = nullptr; h->rf_built = ~0ull;
-  h->rf_ghist = h->rf_btot = h->rf_bstart = h->rf_l1 = nullptr;
+  h->rf_gcur[0] = h->rf_gcur[1] = nullptr; h->rf_ovf[0] = h->rf_ovf[1] = h->rf_l1 = nullptr; h->rf_par = 0; h->rf_wide = false;
   memset(&h->rfp, 0, sizeof h->rfp);
   if (d.rfan) {  // the fan-out graph as a CSR, rebuilt every tick, and the packets pushed into it (SIM_CF_RANDOM_FANOUT)
     const size_t np = (size_t)d.f * Nl;
     RfP& r = h->rfp;
     r.N = d.N; r.Nl = d.Nl; r.shard0 = d.shard0; r.f = d.f;
-    // level-1 buckets of 2^LB targets: the bigger they are, the longer the runs rf_scatter writes (a workgroup of SPW senders
-    // has 4 * SPW / NB pairs per bucket) and the more pairs one rf_rows workgroup ranks in LDS (~ 4 * 2^LB: 56 ... 152 KiB)
-    r.LB = 11;
+    // level-1 buckets of 2^LB targets.  A scattered entry carries the pair id (PB bits) and the target's offset in its bucket
+    // (LB bits) — rf_rows does not draw again —; 32-bit entries when both fit (1 Mi nodes: 22 + 10), 64-bit ones otherwise
+    r.PB = 1;
+    while ((1ull << r.PB) < 4ull * Nl) r.PB++;
+    r.LB = std::min<u32>(11u, 32u - std::min<u32>(r.PB, 24u));
     if (const char* e = getenv("SERF_RF_LB")) r.LB = std::min<u32>(RF_LB_MAX, std::max<u32>(8u, (u32)strtoul(e, nullptr, 0)));
-    while (((size_t)Nl + (1u << r.LB) - 1u) >> r.LB > 4096u) r.LB++;  // the level-1 histogram: 16 KiB of LDS
+    while (((size_t)Nl + (1u << r.LB) - 1u) >> r.LB > 4096u) r.LB++;  // rf_scatter's two tables: 32 KiB of LDS
     if (r.LB > RF_LB_MAX) { sim_destroy(h); return SIM_EINVAL; }
+    h->rf_wide = r.PB + r.LB > 32u || getenv("SERF_RF_WIDE") != nullptr;
     r.NB = (u32)(((size_t)Nl + (1u << r.LB) - 1u) >> r.LB);
-    r.SPW = std::max<u32>(4096u, (u32)(((size_t)Nl + 255u) / 256u));
-    r.NWG = (u32)(((size_t)Nl + r.SPW - 1u) / r.SPW);
-    r.cap = (r.LB >= 12u ? 5u : 6u) << r.LB;  // mean 4 * 2^LB pairs, sigma 2 * 2^(LB/2): 32 sigma and more of room
-    if (const char* e = getenv("SERF_RF_CAP")) r.cap = std::min<u32>(r.cap, (u32)strtoul(e, nullptr, 0));  // tests: force rf_rows' slow path
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rf_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rf_rows_lds(r)) != hipSuccess) { sim_destroy(h); return SIM_EDEVICE; }
+    r.NWG = (u32)(((size_t)Nl + RF_SPW - 1u) / RF_SPW);
+    r.cap = std::min<u32>(6u << r.LB, RF_EPT * RFR);  // mean 4 * 2^LB pairs, sigma 2 * 2^(LB/2): 32 sigma and more of room
+    if (const char* e = getenv("SERF_RF_CAP")) r.cap = std::max<u32>(RFR, std::min<u32>(r.cap, (u32)strtoul(e, nullptr, 0)) / RFR * RFR);  // tests: force rf_rows' slow path
+    // a bucket's region of l1: f pairs per row it can have at most when the shard is one bucket, else the mean and 12 sigma
+    {
+      const double mean = (double)d.f * (double)(1u << r.LB);
+      r.bcap = (u32)(mean + 12.0 * std::sqrt(mean)) + 64u;
+      if (const char* e = getenv("SERF_RF_BCAP")) r.bcap = std::max<u32>(1u, (u32)strtoul(e, nullptr, 0));  // tests: force the overflow list
+      r.ocap = (u32)np;  // (every pair would fit: the list cannot run full)
+    }
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rf_rows_kernel<u32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rf_rows_lds(r)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(rf_rows_kernel<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rf_rows_lds(r)) != hipSuccess) { sim_destroy(h); return SIM_EDEVICE; }
     h->rf_sync = getenv("SERF_RF_SYNC") != nullptr;  // measurements: build on the tick's own stream, nothing overlaps
     for (int i = 0; i < 3; ++i) { DA(h->rf_rcsr[i], Nl + 1) DA(h->rf_rsrc[i], np) }
-    DA(h->rf_ghist, (size_t)r.NWG * r.NB) DA(h->rf_btot, r.NB) DA(h->rf_bstart, r.NB + 1) DA(h->rf_l1, np)
+    {
+      const size_t esz = h->rf_wide ? 2 : 1;  // (in u32 words)
+      u32* p32 = nullptr;
+      for (int i = 0; i < 2; ++i) { DA(h->rf_gcur[i], (size_t)r.NB * RF_GCS) DA(p32, (1 + 2 * (size_t)r.ocap) * esz) h->rf_ovf[i] = p32; }
+      DA(p32, (size_t)r.NB * r.bcap * esz)
+      h->rf_l1 = p32;
+    }
     bool ok = true;
     for (int i = 0; i < 3; ++i) ok = ok && hipMemset(h->rf_rcsr[i], 0, (Nl + 1) * 4) == hipSuccess;  // tick 0 receives nothing
+    for (int i = 0; i < 2; ++i) ok = ok && hipMemset(h->rf_gcur[i], 0, (size_t)r.NB * RF_GCS * 4) == hipSuccess && hipMemset(h->rf_ovf[i], 0, 8) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&h->rf_stream, hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&h->rf_done, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&h->rf_go[0], hipEventDisableTiming) == hipSuccess &&
@@ -4163,11 +4205,15 @@ static int rf_build(sim_handle* h, u64 tick, hipStream_t s) {
   r.rb = rng_base(h->cfg.seed, STREAM_RFAN, tick);
   r.feff = tp.feff;
   u32 *rcsr = h->rf_rcsr[tick % 3], *rsrc = h->rf_rsrc[tick % 3];
-  rf_count_kernel<<<r.NWG, RFB, r.NB * 4, s>>>(r, h->rf_ghist);
-  rf_scan_kernel<<<(r.NB + BLOCK / 64 - 1) / (BLOCK / 64), BLOCK, 0, s>>>(r, h->rf_ghist, h->rf_btot);
-  rf_bstart_kernel<<<1, 1024, 0, s>>>(r, h->rf_btot, h->rf_bstart);
-  rf_scatter_kernel<<<r.NWG, RFB, r.NB * 4, s>>>(r, h->rf_ghist, h->rf_bstart, h->rf_l1);
-  rf_rows_kernel<<<r.NB, RFB, rf_rows_lds(r), s>>>(r, h->rf_bstart, h->rf_l1, rcsr, rsrc);
+  const u32 par = h->rf_par;
+  h->rf_par ^= 1u;
+  if (h->rf_wide) {
+    rf_scatter_kernel<u64><<<r.NWG, RFB, 2 * r.NB * 4, s>>>(r, h->rf_gcur[par], (u64*)h->rf_l1, (u64*)h->rf_ovf[par]);
+    rf_rows_kernel<u64><<<r.NB, RFR, rf_rows_lds(r), s>>>(r, h->rf_gcur[par], h->rf_gcur[par ^ 1u], (const u64*)h->rf_l1, (u64*)h->rf_ovf[par], (u64*)h->rf_ovf[par ^ 1u], rcsr, rsrc);
+  } else {
+    rf_scatter_kernel<u32><<<r.NWG, RFB, 2 * r.NB * 4, s>>>(r, h->rf_gcur[par], (u32*)h->rf_l1, (u32*)h->rf_ovf[par]);
+    rf_rows_kernel<u32><<<r.NB, RFR, rf_rows_lds(r), s>>>(r, h->rf_gcur[par], h->rf_gcur[par ^ 1u], (const u32*)h->rf_l1, (u32*)h->rf_ovf[par], (u32*)h->rf_ovf[par ^ 1u], rcsr, rsrc);
+  }
   HCHECK(hipGetLastError());
   return SIM_OK;
 }

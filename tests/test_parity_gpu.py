@@ -168,15 +168,19 @@ def test_random_fanout_kRandomNodes(oracle, hiplib, seed):
         assert g2.digest() == o2.digest() == g.digest()
 
 
-@pytest.mark.parametrize("n,cap", [(1 << 16, None), (300_000, None), (150_016, None), (2048, 48), (5000, 300)])
+@pytest.mark.parametrize("n,cap", [(1 << 16, None), (300_000, None), (150_016, None), (2048, 48), (5000, 300), (20_000, -7000), (3000, -1), (70_000, 0)])
 def test_random_fanout_graph_build_at_size(oracle, hiplib, n, cap, monkeypatch):
     # the graph build over many level-1 buckets and more than one workgroup of senders (64 Ki nodes: 256 buckets, 16 workgroups;
     # 300 000: a ragged last bucket and a ragged last workgroup), and — SERF_RF_CAP — buckets that do NOT fit rf_rows' LDS
     # tables, which are then ranked straight from global memory; SWIM, loss and (150 016 nodes) paged packets on; digests every
     # few ticks.  At 300 000 nodes x 40 ticks a dozen nodes receive more than sixteen packets in a tick (Poisson tail): the
     # balanced classification's cursor path for the packets beyond a node's sixteenth
-    if cap is not None:
+    if cap is not None and cap > 0:
         monkeypatch.setenv("SERF_RF_CAP", str(cap))
+    if cap == 0:   # 64-bit entries (what a shard of more than 4 Mi nodes uses: a pair id and a target's offset do not fit 32 bits)
+        monkeypatch.setenv("SERF_RF_WIDE", "1")
+    if cap is not None and cap < 0:   # regions too small for their buckets (8 192 pairs each): the rest goes through the overflow list
+        monkeypatch.setenv("SERF_RF_BCAP", str(-cap))
     kw = dict(fanout=4, view_slots=32, event_ring=32, query_ring=16, probe_interval=5, loss=0.01, push_pull_interval=20,
               pkt_records=8 if n == 150_016 else 4, flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT)
     g, o = pair(oracle, hiplib, n, **kw)
