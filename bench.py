@@ -55,7 +55,7 @@ CONV_RUMOURS, CONV_MAX_ROUNDS, CONV_OFFSET, CONV_WINDOW = 64, 60, 400, 480
 
 
 def long_window(args):
-    return LONG_WINDOW if args.steps < LONG_WINDOW else 0
+    return LONG_WINDOW if args.steps < LONG_WINDOW and not getattr(args, "no_long_window", False) else 0
 
 
 def conv_start_tick(args):
@@ -256,6 +256,7 @@ def parse_args(argv=None):
                     help="sharded runs: who issues the round's all-to-all — the library itself over RCCL (sim_exchange_*), or torch.distributed")
     ap.add_argument("--no-second-load", action="store_true", help="skip the second measured load (N = 1: 16 records per packet at --second-rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-long-window", action="store_true", help="skip the second timed window (profiling runs: the LAST launches are then the timed ones)")
     ap.add_argument("--no-convergence", action="store_true", help="skip the rounds-to-99 %% measurement (profiling runs)")
     ap.add_argument("--allow-drops", action="store_true", help="do not fail when the run hit a model bound (overflow > 0)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N > 1 run (nccl = RCCL; gloo only for rehearsals)")

@@ -1383,9 +1383,13 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
 #endif
   // LDS staging of the per-node inbox: the packet being delivered, the slot of each record's
   // subject's entry and the head of that entry (10 KiB per wave: 16 waves per CU = all of its 160 KiB)
-  __shared__ uint4 lds_r[SIM_P][TBLOCK];
-  __shared__ uint4 lds_e[SIM_P][TBLOCK];
-  __shared__ uint4* lds_p[SIM_P][TBLOCK];  // where each record's entry lives (null: nothing to look at)
+  // (one allocation, carved: the RF one-page instantiation stages nothing per record — its tables fit lds_r and lds_e, 8 KiB per
+  // wave = 20 waves per CU —, so for it lds_p is only a name for lds_r's memory that dead code refers to)
+  constexpr bool kNoP = RF && !MP;
+  __shared__ uint4 lds_all[kNoP ? 2 * SIM_P * TBLOCK : 2 * SIM_P * TBLOCK + SIM_P * TBLOCK / 2];
+  uint4 (&lds_r)[SIM_P][TBLOCK] = *reinterpret_cast<uint4 (*)[SIM_P][TBLOCK]>(&lds_all[0]);
+  uint4 (&lds_e)[SIM_P][TBLOCK] = *reinterpret_cast<uint4 (*)[SIM_P][TBLOCK]>(&lds_all[SIM_P * TBLOCK]);
+  uint4* (&lds_p)[SIM_P][TBLOCK] = *reinterpret_cast<uint4* (*)[SIM_P][TBLOCK]>(&lds_all[kNoP ? 0 : 2 * SIM_P * TBLOCK]);  // where each record's entry lives (null: nothing to look at)
   const u32 tid = threadIdx.x;
   // one launch covers `cnt` nodes: the whole shard (chunk == ~0), or sender chunk `chunk` of a sharded run = the nodes
   // whose offset inside their vblock lies in sub-slab `chunk` (V ranges of `sub` consecutive nodes)
@@ -1552,12 +1556,12 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   if (RF && !MP && !bal) rb_need = rcnt >= 16u ? ~0ull : (1ull << (4u * rcnt)) - 1ull;
   if (RF && !MP && bal) {
     u32* const sum = reinterpret_cast<u32*>(&lds_r[0][0]);          // [RF_TMAX] slow mask | 4 x 6-bit subject hash (0: not a member record)
-    uint8_t* const own = reinterpret_cast<uint8_t*>(&lds_p[0][0]);  // [RF_TMAX] the lane a packet is for
+    uint8_t* const own = reinterpret_cast<uint8_t*>(&lds_r[2][0]);  // [RF_TMAX] the lane a packet is for (the upper half of lds_r)
     uint8_t* const sidx = own + RF_TMAX;                            // [RF_TMAX] first stash entry of the packet's slow records (0xFF: none)
     u64* const st_p = reinterpret_cast<u64*>(own + 2 * RF_TMAX);    // [RF_STASH] entry pointers
     uint4* const nst = &lds_e[0][0];                                // [64][2] the nodes' clocks, flags, incarnation as the tick begins
     uint4* const st_r = &lds_e[2][0];                               // [RF_STASH] unpacked records
-    static_assert(2 * RF_TMAX + 8 * RF_STASH <= SIM_P * TBLOCK * 8 && RF_TMAX * 4 <= SIM_P * TBLOCK * 16 && RF_STASH <= 2 * TBLOCK, "LDS overlay");
+    static_assert(2 * RF_TMAX + 8 * RF_STASH <= 2 * TBLOCK * 16 && RF_TMAX * 4 <= 2 * TBLOCK * 16 && RF_STASH <= 2 * TBLOCK, "LDS overlay");
     const u32 rown = rin0 - rb_base;
 #pragma unroll 1
     for (u32 i = 0; i < rf_npk; ++i)
@@ -1661,8 +1665,8 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
     if (RF && !MP) {
       // the records the balanced pass left for the handlers, in arrival order, one per lane and iteration
       const u32* const sum = reinterpret_cast<const u32*>(&lds_r[0][0]);
-      const uint8_t* const sidx = reinterpret_cast<const uint8_t*>(&lds_p[0][0]) + RF_TMAX;
-      const u64* const st_p = reinterpret_cast<const u64*>(reinterpret_cast<const uint8_t*>(&lds_p[0][0]) + 2 * RF_TMAX);
+      const uint8_t* const sidx = reinterpret_cast<const uint8_t*>(&lds_r[2][0]) + RF_TMAX;
+      const u64* const st_p = reinterpret_cast<const u64*>(reinterpret_cast<const uint8_t*>(&lds_r[2][0]) + 2 * RF_TMAX);
       const uint4* const st_r = &lds_e[2][0];
       const u32 rown = rin0 - rb_base;
       // a record that was not stashed (a later record about a subject of an earlier one; a stash that ran full; a packet
@@ -2235,6 +2239,14 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   if ((threadIdx.x & 63) == 0)
     for (int i = 0; i < 32; ++i) atomicAdd(&g_tt[i], tacc[i]);
 #endif
+}
+#ifndef TICK_OCC_RF
+#define TICK_OCC_RF 4
+#endif
+// the RF one-page instantiation under its own launch bounds (8 KiB of LDS per wave: 20 waves per CU if the registers allow 5 per SIMD)
+template <int F>
+__global__ __launch_bounds__(TBLOCK, TICK_OCC_RF) void tick_kernel_rf(Dev d, TickP tp, TickP ptp, u32 cur, const uint4* base, u32 chunk, u32 cnt) {
+  tick_block<false, F, false, false, true>(d, tp, ptp, cur, base, chunk, cnt, blockIdx.x);
 }
 template <bool SHARDED, int F, bool B64, bool MP, bool RF = false>
 __global__ __launch_bounds__(TBLOCK, TICK_OCC) void tick_kernel(Dev d, TickP tp, TickP ptp, u32 cur, const uint4* base, u32 chunk, u32 cnt) {
@@ -4408,9 +4420,9 @@ static int tick_launch(sim_handle* h, u32 chunk) {
                                     cur, (const uint4*)h->d_base, chunk, cnt);                                           \
       else tick_kernel<false, FF, false, true, true><<<grid, TBLOCK, 0, h->stream>>>(d, tp, ptp, cur, h->d_base, chunk, cnt); \
     } else if (d.rfan) {                                                                                                 \
-      if (e1) hipExtLaunchKernelGGL((tick_kernel<false, FF, false, false, true>), dim3(grid), dim3(TBLOCK), 0, h->stream, e0, e1, 0, d, tp, ptp, \
+      if (e1) hipExtLaunchKernelGGL((tick_kernel_rf<FF>), dim3(grid), dim3(TBLOCK), 0, h->stream, e0, e1, 0, d, tp, ptp, \
                                     cur, (const uint4*)h->d_base, chunk, cnt);                                           \
-      else tick_kernel<false, FF, false, false, true><<<grid, TBLOCK, 0, h->stream>>>(d, tp, ptp, cur, h->d_base, chunk, cnt); \
+      else tick_kernel_rf<FF><<<grid, TBLOCK, 0, h->stream>>>(d, tp, ptp, cur, h->d_base, chunk, cnt); \
     } else if (tp.B == 64u) LAUNCH_TICK(false, FF, true);                                                                \
     else LAUNCH_TICK(false, FF, false);                                                                                  \
   } while (0)

@@ -126,6 +126,7 @@ class Serf {
     Cluster* c_;
     uint32_t id_;
     bool closed_ = false;
+    mutable bool started_ = false;  // the tracker has been seen under this id (the tick that executes the query has run)
     std::vector<uint32_t> seen_acks_, seen_resp_;                             // ascending (QueryResponseCore.acks / .responses)
     std::function<std::vector<uint8_t>(uint32_t)> payload_of_;
   };
@@ -233,18 +234,27 @@ inline Serf::QueryStatus Serf::query_status(uint32_t qid) const {
   st.open = open != 0;
   return st;
 }
+// (SIM_EINVAL from the two tracker reads means "this id does not own its tracker entry": before the tick that executes the
+// query has run — the channels exist and are empty, query.rs:201-212 — or after a newer query with the same residue took the
+// entry over — the reference's receivers would simply be closed.  Neither is an error of the caller.)
 inline bool Serf::QueryResponse::finished() const {
   if (closed_) return true;
   uint64_t a, r;
   int open = 0;
-  check(sim_query_status(c_->raw(), id_, &a, &r, &open), "sim_query_status");
+  const int rc = sim_query_status(c_->raw(), id_, &a, &r, &open);
+  if (rc == SIM_EINVAL) return started_;  // not started yet: still open; evicted: finished
+  check(rc, "sim_query_status");
+  started_ = true;
   return !open;
 }
 inline std::vector<uint32_t> Serf::QueryResponse::fresh(int which, std::vector<uint32_t>& seen) {
   std::vector<uint32_t> out;
   if (closed_) return out;
   uint32_t n = 0;
-  check(sim_query_responders(c_->raw(), id_, which, nullptr, 0, &n), "sim_query_responders");
+  const int rc = sim_query_responders(c_->raw(), id_, which, nullptr, 0, &n);
+  if (rc == SIM_EINVAL) return out;  // nobody yet (the query's tick has not run) or nobody any more (tracker taken over)
+  check(rc, "sim_query_responders");
+  started_ = true;
   std::vector<uint32_t> all(n);
   if (n) check(sim_query_responders(c_->raw(), id_, which, all.data(), n, &n), "sim_query_responders");
   std::set_difference(all.begin(), all.end(), seen.begin(), seen.end(), std::back_inserter(out));  // both ascending

@@ -162,6 +162,9 @@ def test_random_fanout_kRandomNodes(oracle, hiplib, seed):
             o2.restore(gi)
             assert g2.digest() == o2.digest() == g.digest()
     sc.assert_same_state(g, o, f"seed {seed} final")
+    for node in (0, n // 2, n - 1):   # the byte boundary in this mode: the packets a node SENT (the canonical inbox is sender-indexed)
+        for k in range(kw["fanout"]):
+            assert g.peek_packet(node, k) == o.peek_packet(node, k)
     if g2 is not None:
         g2.step(33)
         o2.step(33)

@@ -45,9 +45,10 @@ def main():
     ap.add_argument("--ticks", type=int, default=120)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--nodes", type=int, default=1 << 20)
+    ap.add_argument("--fanout-model", default="bijection", choices=["bijection", "krandomnodes"])
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
-    args = bench.parse_args(["--nodes-per-gpu", str(a.nodes)])
+    args = bench.parse_args(["--nodes-per-gpu", str(a.nodes), "--fanout-model", a.fanout_model])
     res = {p: [] for p in a.libs}
     digs = {}
     for r in range(a.rounds):

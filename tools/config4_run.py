@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--nacks", action="store_true", help="memberlist's nack accounting for the health score")
     ap.add_argument("--reconnect-interval", type=int, default=0, help="Reconnector period in ticks (reference: 30 s = 150; 0 = off)")
     ap.add_argument("--gossip-to-the-dead", type=int, default=0, help="memberlist gossip_to_the_dead_time in ticks (lan: 30 s = 150; 0 = off)")
+    ap.add_argument("--vshards", type=int, default=1, help="virtual shards of the fan-out map (the shape of one rank's share of a V-way sharded cluster)")
+    ap.add_argument("--chunks", type=int, default=0, help="sender chunks per shard (the chunk-wise exchange's layout)")
     ap.add_argument("--lib", default=None, help="oracle: run the CPU oracle instead (small sizes; for checking the tool)")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_config4_churn5_loss1_swim.json"))
     args = ap.parse_args()
@@ -60,7 +62,7 @@ def main():
               probe_interval=args.probe_interval, push_pull_interval=args.push_pull_interval, loss=args.loss,
               reap_interval=75, queue_check_interval=150, recycle_interval=args.recycle_interval, pkt_records=args.pkt_records,
               reconnect_interval=args.reconnect_interval, gossip_to_the_dead=args.gossip_to_the_dead,
-              tcp_fallback=args.tcp_fallback, nacks=args.nacks,
+              tcp_fallback=args.tcp_fallback, nacks=args.nacks, vshards=args.vshards, chunks=args.chunks,
               **({"flags": _ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT} if args.random_fanout else {}),
               join_sync=True)   # Serf::join = memberlist.join: the re-joining node syncs with a peer (SIM_CF_JOIN_SYNC)
     sim = _ffi.Sim(lib, _ffi.make_config(n, **kw))
@@ -132,6 +134,13 @@ def main():
         "max_view_slots_in_use_seen": stats["max_slots_in_use"], "deepest_queue_seen": stats["max_queue"],
         "nodes_up_at_end": int(cs["up"]), "wall_s": dt, "member_ticks_per_s_incl_host_polling": n * int(sim.tick) / dt,
     }
+    try:
+        import torch
+        free, tot = torch.cuda.mem_get_info()
+        out["device_memory"] = {"in_use_bytes_at_end": int(tot - free), "total_bytes": int(tot),
+                                "what": "hipMemGetInfo at the end of the run: this handle's arrays (views, rings, packets, rows) and the runtime's own"}
+    except Exception:
+        pass
     json.dump(out, open(args.out, "w"), indent=1)
     print(json.dumps({k: out[k] for k in ("ticks", "churn_events", "rounds_to_99", "model_bound_drops", "ops_dropped_no_slot", "failure_detector", "wall_s")}), "->", args.out)
 
