@@ -275,6 +275,26 @@ def parse_args(argv=None):
     return a
 
 
+_OUT = None  # the process's REAL stdout once run() has claimed it (see claim_stdout)
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries below us write there too (RCCL prints a version banner through C
+    stdio when a communicator is made, flushed at exit): keep a private handle on the real stdout for the JSON line and point
+    file descriptor 1 at stderr for everybody else."""
+    global _OUT
+    if _OUT is None:
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        _OUT = os.fdopen(saved, "w")
+    return _OUT
+
+
+def emit(obj):
+    print(json.dumps(obj), file=_OUT if _OUT is not None else sys.stdout, flush=True)
+
+
 class Progress:
     """Heartbeat of a rank: every phase of run() touches it; a watchdog thread ends the process when it goes stale
     (a collective that never completes would otherwise hang the whole job without a word)."""
@@ -292,8 +312,7 @@ class Progress:
             time.sleep(1.0)
             if not self.done and time.monotonic() - self.t > self.limit:
                 if self.rank == 0:
-                    print(json.dumps(dict(self.meta, error=f"no progress for {self.limit:.0f} s in phase '{self.what}' (collective hung?)",
-                                          value=None)), flush=True)
+                    emit(dict(self.meta, error=f"no progress for {self.limit:.0f} s in phase '{self.what}' (collective hung?)", value=None))
                 sys.stderr.write(f"bench.py rank {self.rank}: watchdog: stuck in '{self.what}'\n")
                 os._exit(3)
 
@@ -322,6 +341,8 @@ def run(args, lib=None, dev=None, backend="nccl"):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     on_gpu = dev is None
+    if on_gpu:
+        claim_stdout()
     progress = Progress(args.watchdog if world > 1 else 0.0, rank,
                         {"metric": "member-ticks/sec", "unit": "member-ticks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup})
     if on_gpu:
@@ -678,7 +699,7 @@ def run(args, lib=None, dev=None, backend="nccl"):
                                          "oracle": {str(tk): [f"{x:016x}" for x in cpu_dig[tk]] for tk in pt}}
             out["parity"]["digest_match"] = all(v.get("digest_match") is not False for v in out["parity"].values() if isinstance(v, dict))
             out["parity"]["ticks"] = head["parity_ticks"]
-        print(json.dumps(out), flush=True)
+        emit(out)
     progress.done = True
     if world > 1 or args.force_sharded:
         dist.destroy_process_group()

@@ -22,7 +22,7 @@ def last_json(path):
     try:
         return json.loads(text)                    # a JSON document ...
     except json.JSONDecodeError:
-        return json.loads(text.splitlines()[-1])   # ... or a log whose last line is one
+        return json.loads([ln for ln in text.splitlines() if ln.startswith("{")][-1])   # ... or a log with one JSON line in it
 
 
 for src, dst in (("bench_default.json", "r04_bench.json"), ("bench_20_5.json", "r04_bench_driver_args.json"),
