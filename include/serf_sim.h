@@ -392,10 +392,22 @@ enum sim_op {
                                    and no earlier attempt of the tick involves either node (otherwise: the next tick; an attempt on
                                    a process that is down fails and is forgotten).  Scheduled by the library from the tick's request
                                    list, two ticks after the attempt was drawn (like SIM_OP_SUSPECT)                              */
-  SIM_OP_DELIVER = 12           /* internal (sim_inject_record / sim_deliver_message): `node` receives one record from
+  SIM_OP_DELIVER = 12,          /* internal (sim_inject_record / sim_deliver_message): `node` receives one record from
                                    outside the simulated cluster — SerfDelegate::notify_message (delegate.rs:157-315) for
-                                   the serf kinds, memberlist's alive / suspect / dead handling for its own              */
+                                   the serf kinds, memberlist's alive / suspect / dead handling for its own.  b = the wire bits
+                                   of meta; b | SIM_DELIVER_MUTE: the record comes out of a PushPull message —
+                                   merge_remote_state (delegate.rs:427-554) runs the handler and re-queues nothing but a
+                                   refutation                                                                              */
+  SIM_OP_QRESP = 15,            /* internal (sim_deliver_message of a QueryResponseMessage, or of a Relay that wraps one): `node`,
+                                   the origin of running query a, receives the ack (b bit 31 set) or the response (clear) of
+                                   node b & 0xFFFFFF — counted when the query is still inside its deadline and names `node`
+                                   as its origin (handle_query_response base.rs:1158-1204, query.rs:240-303; one entry per
+                                   responder), exactly like one that arrived over the simulated network.  A relayed one
+                                   (relay_response, query.rs:523-601) arrives only if the relaying node is running          */
+  SIM_OP_WITNESS = 16           /* internal (a PushPull message's clocks, delegate.rs:466-480): `node` witnesses Lamport time
+                                   `val` on clock a (0 member, 1 event, 2 query) — the caller passes remote - 1              */
 };
+#define SIM_DELIVER_MUTE 0x80000000u
 
 /* ------------------------------------------------------------------ entry points */
 
@@ -441,9 +453,16 @@ int sim_inject(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, uint32_
  * sim_inject_record: at the start of tick `tick`, `node` receives `rec` (key, wire bits of meta, val) as if it had come
  *   in a packet: the handler runs, a rebroadcast is queued.  A member record whose subject finds no view slot is
  *   dropped and counted like an operation (ops_dropped).
- * sim_deliver_message: decode ONE framed serf message (Join, Leave, UserEvent, Query) from buf[0 .. len) and
- *   sim_inject_record it for the next tick; *consumed (may be NULL) = bytes used, so a caller can walk a packet of several
- *   messages.  A user event is identified by the 32-bit FNV-1a key of (name, payload) (serf_amd/host/wire.hpp
+ * sim_deliver_message: decode ONE framed serf message from buf[0 .. len) and schedule what it means for the next tick;
+ *   *consumed (may be NULL) = bytes used, so a caller can walk a packet of several messages.  Join, Leave, UserEvent, Query:
+ *   sim_inject_record.  (r4) QueryResponse (types/query/response.rs): the origin `node` counts the ack / response of the
+ *   node it names (SIM_OP_QRESP).  Relay (types/message.rs:431-470: a destination Node and a framed message): `node`
+ *   forwards the inner message to the destination if it is running at that tick; the inner message must be a
+ *   QueryResponse — what relay_response wraps (query.rs:523-601) — anything else inside is refused (SIM_EINVAL).
+ *   PushPull (types/push_pull.rs; merge_remote_state delegate.rs:427-554): the three clocks are witnessed at remote - 1
+ *   (SIM_OP_WITNESS), every left member becomes a leave intent at its status_ltime + 1, every other member a join intent at
+ *   its status_ltime, every buffered user event is replayed — all with SIM_DELIVER_MUTE: nothing is rebroadcast but a
+ *   refutation.  A user event is identified by the 32-bit FNV-1a key of (name, payload) (serf_amd/host/wire.hpp
  *   event_key) and its content is remembered for sim_peek_packet; QueryFlag bits are mapped (ACK 1 -> SIM_F_ACK,
  *   NO_BROADCAST 2 -> SIM_F_NO_BROADCAST); Filter::Id lists are installed for the query, a Filter::Tag is refused with
  *   SIM_EINVAL (tag expressions are evaluated by the host: sim_query_filtered).  SIM_EINVAL for anything malformed.

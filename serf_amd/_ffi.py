@@ -28,6 +28,7 @@ EV_JOIN, EV_LEAVE, EV_FAILED, EV_UPDATE, EV_REAP, EV_USER, EV_QUERY = range(7)
 # enum sim_op
 OP_USER_EVENT, OP_QUERY, OP_LEAVE, OP_JOIN, OP_FORCE_LEAVE, OP_CRASH, OP_REVIVE, OP_LEAVE_FINISH = 1, 2, 3, 4, 5, 6, 7, 8
 OP_SET_TAGS, OP_QUERY_FILTER_ID, OP_QUERY_FILTER_TAGS, OP_DELIVER, OP_SUSPECT, OP_RECONNECT = 9, 10, 11, 12, 13, 14
+OP_QRESP, OP_WITNESS = 15, 16   # internal: scheduled by sim_deliver_message (a QueryResponse / a PushPull's clocks), refused by sim_inject
 SUSPECT_REQ_MAX, SREQ_HEAD_WORDS = 4096, 512
 QF_IDS, TAG_CLASSES, NO_TAG_FILTER = 12, 32, 0xFFFFFFFF
 # enum sim_array

@@ -2283,6 +2283,15 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
     // base.rs:905-930: the QueryResponse is registered before the query goes out (every shard counts its own nodes)
     if (op == SIM_OP_QUERY) d.qtab[ob.c[i]] = make_uint4(ob.a[i], gid, (u32)tick + q_timeout, ob.b[i]);
     if (op == SIM_OP_SET_TAGS) TAGCLASS(d)[gid] = (uint8_t)ob.a[i];  // replicated like liveness: a table the host fills
+    if (op == SIM_OP_QRESP) {  // handle_query_response (base.rs:1158-1204): an ack / a response that came in over the byte boundary.
+      // Trackers and liveness are replicated; the responder's bit lives on the shard that owns the responder
+      const u32 j = ob.a[i] % SIM_QT, from = ob.b[i] & 0xFFFFFFu, which = (ob.b[i] >> 31) ? 0u : 1u, via = (u32)ob.val[i];
+      const size_t words = ((size_t)d.N + 31) / 32;
+      const uint4 t = d.qtab[j];
+      if (from >= d.shard0 && from < d.shard0 + d.Nl && up_of(d, gid) && t.x == ob.a[i] && t.y == gid && (u32)tick <= t.z && (!via || up_of(d, via - 1u)))
+        d.qbits[((size_t)j * 2 + which) * words + (from >> 5)] |= 1u << (from & 31);
+      continue;
+    }
     if (gid < d.shard0 || gid >= d.shard0 + d.Nl) continue;
     u32 l = gid - d.shard0;
     Ctx c{d, l, gid, (u32)tick, qbase};
@@ -2391,12 +2400,26 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
       case SIM_OP_DELIVER:  // a record from outside the cluster: notify_message (delegate.rs:157-315) / memberlist's own handling
         if (up) {
           u64 val = ob.val[i];
+          const bool mute = b & SIM_DELIVER_MUTE;
+          b &= SIM_META_WIRE_MASK;
           uint4 r = make_uint4(a, b, (u32)val, (u32)(val >> 32));
           u32 kind = SIM_META_KIND(b);
           u64 vbase = (u64)(uintptr_t)d.view;
           uint4* p = lookup_ptr(c, vbase, (u64)(uintptr_t)d.ering - vbase, (u64)(uintptr_t)d.qring - vbase, kind, a, val, slot_load(d, kind, a));
           uint4 e_ = p ? p[0] : make_uint4(0, 0, 0, 0);
-          dispatch(c, n, r, p, e_, dirty, ins);
+          if (mute) {  // out of a PushPull message: merge_remote_state (delegate.rs:495-552) — the handlers' verdicts are dropped, a
+                       // refutation (broadcast_join: `ins`, set inside the handler) is not
+            if (kind == SIM_K_LEAVE) (void)handle_leave_intent(c, n, a, val, false, p, e_, dirty, ins);
+            else if (kind == SIM_K_JOIN) (void)handle_join_intent(c, n, a, val, p, e_, dirty);
+            else if (kind == SIM_K_EVENT) (void)handle_user_event(c, n, a, val, p, e_, dirty);
+          } else dispatch(c, n, r, p, e_, dirty, ins);
+        }
+        break;
+      case SIM_OP_WITNESS:  // a PushPull message's clocks (delegate.rs:466-480)
+        if (up) {
+          if (a == 0) witness(n, n.clock, ob.val[i], DR0);
+          else if (a == 1) witness(n, n.eclock, ob.val[i], DR1);
+          else witness(n, n.qclock, ob.val[i], DR1);
         }
         break;
       default: break;
@@ -3957,11 +3980,14 @@ static int op_validate(u32 N, u32 op, u32 node, u32 a, u32 b) {
     case SIM_OP_SUSPECT: case SIM_OP_RECONNECT: if (a >= N) return SIM_EINVAL; break;
     case SIM_OP_DELIVER: {
       u32 kind = SIM_META_KIND(b);
-      if (kind < SIM_K_JOIN || kind > SIM_K_DEAD || (b & ~SIM_META_WIRE_MASK)) return SIM_EINVAL;
+      if (kind < SIM_K_JOIN || kind > SIM_K_DEAD || (b & ~(SIM_META_WIRE_MASK | SIM_DELIVER_MUTE))) return SIM_EINVAL;
+      if ((b & SIM_DELIVER_MUTE) && kind != SIM_K_JOIN && kind != SIM_K_LEAVE && kind != SIM_K_EVENT) return SIM_EINVAL;
       if (kind == SIM_K_EVENT || kind == SIM_K_QUERY) { if (!a) return SIM_EINVAL; }
       else if (a >= N) return SIM_EINVAL;
       break;
     }
+    case SIM_OP_QRESP: if (!a || (b & 0xFFFFFFu) >= N || (b & 0x7F000000u)) return SIM_EINVAL; break;
+    case SIM_OP_WITNESS: if (a > 2u) return SIM_EINVAL; break;
     default: return SIM_EINVAL;
   }
   return SIM_OK;
@@ -3971,6 +3997,7 @@ static int inject_val(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, 
   if (tick < h->tick) tick = h->tick;
   if (op == SIM_OP_SUSPECT && (a & SREQ_RECONNECT)) { op = SIM_OP_RECONNECT; a &= ~SREQ_RECONNECT; }  // an entry of the request list, as it stands there
   int rc = op_validate(h->d.N, op, node, a, b);
+  if (rc == SIM_OK && op == SIM_OP_QRESP && val > h->d.N) rc = SIM_EINVAL;  // val = the relaying node + 1 (0: sent directly)
   if (rc) return rc;
   // an operation that executes now gets its view slot now (and SIM_ENOSLOT if there is none); one scheduled for a
   // later tick gets it when it executes — and is dropped and counted if none is free then (SIMSPEC §2.6)
@@ -3984,7 +4011,7 @@ static int inject_val(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, 
   return SIM_OK;
 }
 int sim_inject(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, uint32_t a, uint32_t b) {
-  if (op == SIM_OP_DELIVER) return SIM_EINVAL;  // needs a value: sim_inject_record
+  if (op == SIM_OP_DELIVER || op == SIM_OP_QRESP || op == SIM_OP_WITNESS) return SIM_EINVAL;  // internal, with a value: sim_inject_record / sim_deliver_message
   return inject_val(h, tick, op, node, a, b, 0);
 }
 // ---- the byte boundary of the delegate (include/serf_sim.h; oracle: the same entry points with its own C codec) ----
@@ -4001,16 +4028,65 @@ int sim_user_event_bytes(sim_handle* h, uint32_t node, const uint8_t* name, size
   h->evreg.emplace(key, std::make_pair(nm, pl));  // the first content under a key stays
   return sim_user_event(h, node, key, (uint32_t)w::user_event_len(1, nm, pl, cc != 0), cc);
 }
-int sim_deliver_message(sim_handle* h, uint32_t node, const uint8_t* buf, size_t len, size_t* consumed) {
+// `via`: 0, or 1 + the node that relays the message to `node` (a Relay's inner message)
+static int deliver_one(sim_handle* h, uint32_t node, const uint8_t* buf, size_t len, size_t* consumed, u32 via) {
   if (!h || !buf || !len || node >= h->d.N) return SIM_EINVAL;
   namespace w = serf::wire;
   try {
     w::Bytes in(buf, buf + len);
+    if (in[0] == w::merge(w::WIRE_LEN, w::RELAY)) {
+      // Relay (types/message.rs:431-470): `node` forwards the wrapped message to the node it names (delegate.rs:262-313) if it
+      // is running then; what relay_response wraps is a QueryResponse (query.rs:523-601) — nothing else is accepted inside
+      if (via) return SIM_EINVAL;
+      auto [dest, off] = w::unwrap_relay(in);
+      if (dest >= h->d.N || off >= len || (buf[off] >> 3) != w::QUERY_RESPONSE) return SIM_EINVAL;
+      size_t in_used = 0;
+      int rc = deliver_one(h, dest, buf + off, len - off, &in_used, node + 1u);
+      if (rc == SIM_OK && consumed) *consumed = off + in_used;
+      return rc;
+    }
     size_t used = 0;
     auto [tag, body] = w::unframe(in, used);
     sim_record rec;
     memset(&rec, 0, sizeof rec);
     int rc = SIM_OK;
+    if (tag == w::QUERY_RESPONSE) {  // -> SIM_OP_QRESP at the origin
+      w::QueryResponse m = w::decode_query_response(body);
+      if (m.from_node >= h->d.N || !m.id) return SIM_EINVAL;
+      rc = inject_val(h, h->tick, SIM_OP_QRESP, node, m.id, m.from_node | ((m.flags & 1u) ? 0x80000000u : 0u), via);
+      if (rc == SIM_OK && consumed) *consumed = used;
+      return rc;
+    }
+    if (via) return SIM_EINVAL;
+    if (tag == w::PUSH_PULL) {  // what merge_remote_state (delegate.rs:427-554) does with it
+      w::PushPull m = w::decode_push_pull(body);
+      for (auto& st : m.status_ltimes)
+        if (st.first >= h->d.N) return SIM_EINVAL;
+      for (u32 id : m.left_members)
+        if (id >= h->d.N) return SIM_EINVAL;
+      const u64 clk[3] = {m.ltime, m.event_ltime, m.query_ltime};
+      for (u32 i = 0; i < 3 && rc == SIM_OK; ++i)  // "we subtract 1 since no message with that clock has been sent yet"
+        if (clk[i] > 0) rc = inject_val(h, h->tick, SIM_OP_WITNESS, node, i, 0, clk[i] - 1);
+      auto is_left = [&](u32 id) { return std::find(m.left_members.begin(), m.left_members.end(), id) != m.left_members.end(); };
+      for (size_t i = 0; i < m.left_members.size() && rc == SIM_OK; ++i) {  // the left members first, one past their status time
+        size_t j = 0;
+        while (j < m.status_ltimes.size() && m.status_ltimes[j].first != m.left_members[i]) ++j;
+        if (j < m.status_ltimes.size())
+          rc = inject_val(h, h->tick, SIM_OP_DELIVER, node, m.left_members[i], wire_meta(SIM_K_LEAVE, 0, 16) | SIM_DELIVER_MUTE, m.status_ltimes[j].second + 1);
+      }
+      for (size_t j = 0; j < m.status_ltimes.size() && rc == SIM_OK; ++j)  // every other member: an artificial join message at its status time
+        if (!is_left(m.status_ltimes[j].first))
+          rc = inject_val(h, h->tick, SIM_OP_DELIVER, node, m.status_ltimes[j].first, wire_meta(SIM_K_JOIN, 0, 16) | SIM_DELIVER_MUTE, m.status_ltimes[j].second);
+      for (auto& bucket : m.events)  // the event buffer, replayed in order
+        for (auto& ev : bucket.second) {
+          if (rc != SIM_OK) break;
+          u32 key = w::event_key(ev.first, ev.second);
+          h->evreg.emplace(key, std::make_pair(ev.first, ev.second));
+          rc = inject_val(h, h->tick, SIM_OP_DELIVER, node, key, wire_meta(SIM_K_EVENT, 0, 32) | SIM_DELIVER_MUTE, bucket.first);
+        }
+      if (rc == SIM_OK && consumed) *consumed = used;
+      return rc;
+    }
     if (tag == w::JOIN) {
       w::Join m = w::decode_join(body);
       if (m.id >= h->d.N) return SIM_EINVAL;
@@ -4050,6 +4126,9 @@ int sim_deliver_message(sim_handle* h, uint32_t node, const uint8_t* buf, size_t
   } catch (const std::exception&) {
     return SIM_EINVAL;
   }
+}
+int sim_deliver_message(sim_handle* h, uint32_t node, const uint8_t* buf, size_t len, size_t* consumed) {
+  return deliver_one(h, node, buf, len, consumed, 0);
 }
 int sim_join(sim_handle* h, uint32_t node, uint32_t peer) { return sim_inject(h, h ? h->tick : 0, SIM_OP_JOIN, node, peer, 0); }
 int sim_leave(sim_handle* h, uint32_t node) {

@@ -261,6 +261,89 @@ inline Query decode_query(const Bytes& body) {
   return m;
 }
 
+// QueryResponseMessage (types/query/response.rs:9-19): ltime 1, id 2, from 3 (Node), flags 4 (QueryFlag: ACK = 1), payload 5
+struct QueryResponse {
+  uint64_t ltime = 0;
+  uint32_t id = 0, from_node = 0, flags = 0;
+  Bytes payload;
+};
+inline QueryResponse decode_query_response(const Bytes& body) {
+  QueryResponse m;
+  bool have = false;
+  for (const Field& f : fields(body)) {
+    switch (f.tag) {
+      case 1: m.ltime = f.v; break;
+      case 2: m.id = (uint32_t)f.v; break;
+      case 3: m.from_node = decode_node(f.data); have = true; break;
+      case 4: m.flags = (uint32_t)f.v; break;
+      case 5: m.payload = f.data; break;
+      default: break;
+    }
+  }
+  if (!have) throw std::invalid_argument("query response without a sender");
+  return m;
+}
+// A Relay (types/message.rs:431-470) at the head of `buf` — RELAY_MESSAGE_BYTE, RELAY_NODE_BYTE <node>, RELAY_MSG_BYTE, then the
+// wrapped message framed as usual to the end of the buffer (no length of its own): the node to forward to and where the
+// wrapped message starts
+inline std::pair<uint32_t, size_t> unwrap_relay(const Bytes& buf) {
+  if (buf.size() < 3 || buf[0] != merge(WIRE_LEN, RELAY) || buf[1] != merge(WIRE_LEN, 1)) throw std::invalid_argument("not a relay message");
+  size_t off = 2;
+  Bytes node = read_ld(buf, off);
+  if (off >= buf.size() || buf[off] != merge(WIRE_LEN, 2)) throw std::invalid_argument("relay message without a message");
+  return {decode_node(node), off + 1};
+}
+// PushPullMessage (types/push_pull.rs): ltime 1, status_ltimes 2 {id 1, ltime 2}, left_members 3, event_ltime 4, events 5
+// {ltime 1, events 2 {name 1, payload 2}}, query_ltime 6 — in message order
+struct PushPull {
+  uint64_t ltime = 0, event_ltime = 0, query_ltime = 0;
+  std::vector<std::pair<uint32_t, uint64_t>> status_ltimes;
+  std::vector<uint32_t> left_members;
+  std::vector<std::pair<uint64_t, std::vector<std::pair<Bytes, Bytes>>>> events;
+};
+inline PushPull decode_push_pull(const Bytes& body) {
+  PushPull m;
+  for (const Field& f : fields(body)) {
+    switch (f.tag) {
+      case 1: m.ltime = f.v; break;
+      case 2: {
+        uint32_t id = 0;
+        uint64_t lt = 0;
+        bool have = false;
+        for (const Field& g : fields(f.data)) {
+          if (g.tag == 1) { id = parse_node_id(g.data); have = true; }
+          else if (g.tag == 2) lt = g.v;
+        }
+        if (!have) throw std::invalid_argument("status entry without a node");
+        m.status_ltimes.emplace_back(id, lt);
+        break;
+      }
+      case 3: m.left_members.push_back(parse_node_id(f.data)); break;
+      case 4: m.event_ltime = f.v; break;
+      case 5: {
+        uint64_t lt = 0;
+        std::vector<std::pair<Bytes, Bytes>> evs;
+        for (const Field& g : fields(f.data)) {
+          if (g.tag == 1) lt = g.v;
+          else if (g.tag == 2) {
+            Bytes name, payload;
+            for (const Field& e : fields(g.data)) {
+              if (e.tag == 1) name = e.data;
+              else if (e.tag == 2) payload = e.data;
+            }
+            evs.emplace_back(std::move(name), std::move(payload));
+          }
+        }
+        m.events.emplace_back(lt, std::move(evs));
+        break;
+      }
+      case 6: m.query_ltime = f.v; break;
+      default: break;
+    }
+  }
+  return m;
+}
+
 // What the simulator is told about a user event: the 32-bit identity of (name, payload) its de-dup ring compares
 // (base.rs:783-813 compares name and payload; FNV-1a over name, a separator, payload; never 0 = "no key") and the
 // framed wire length TransmitLimitedQueue sorts and budgets by.

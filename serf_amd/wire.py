@@ -219,11 +219,40 @@ class PushPull:
         return out + bytes([merge(WIRE_VARINT, 6)]) + varint(self.query_ltime)
 
 
-_TAG_OF = {Leave: LEAVE, Join: JOIN, PushPull: PUSH_PULL, UserEvent: USER_EVENT, Query: QUERY}
+@dataclass
+class QueryResponse:
+    """QueryResponseMessage (types/query/response.rs:9-19, 244-300): ltime 1, id 2, from 3 (Node), flags 4 (QueryFlag: ACK = 1),
+    payload 5 (omitted when empty)."""
+    ltime: int
+    id: int
+    from_node: int
+    flags: int = 0
+    payload: bytes = b""
+
+    def body(self) -> bytes:
+        out = bytes([merge(WIRE_VARINT, 1)]) + varint(self.ltime) + bytes([merge(WIRE_VARINT, 2)]) + varint(self.id)
+        out += bytes([merge(WIRE_LEN, 3)]) + ld(encode_node(self.from_node)) + bytes([merge(WIRE_VARINT, 4)]) + varint(self.flags)
+        if self.payload:
+            out += bytes([merge(WIRE_LEN, 5)]) + ld(self.payload)
+        return out
+
+
+@dataclass
+class Relay:
+    """encode_relay_message (types/message.rs:431-470): RELAY_MESSAGE_BYTE, then — with NO length of its own —
+    RELAY_NODE_BYTE <node, length-delimited>, RELAY_MSG_BYTE, and the wrapped message framed as usual, to the end of the buffer."""
+    node: int          # whom the receiver is asked to forward the message to
+    msg: object        # the wrapped message (relay_response wraps a QueryResponse: query.rs:523-601)
+
+
+_TAG_OF = {Leave: LEAVE, Join: JOIN, PushPull: PUSH_PULL, UserEvent: USER_EVENT, Query: QUERY, QueryResponse: QUERY_RESPONSE}
 
 
 def encode_message(msg) -> bytes:
     """types/message.rs:397-428: type byte, varint body length, body."""
+    if isinstance(msg, Relay):
+        return (bytes([merge(WIRE_LEN, RELAY), merge(WIRE_LEN, 1)]) + ld(encode_node(msg.node)) + bytes([merge(WIRE_LEN, 2)])
+                + encode_message(msg.msg))
     body = msg.body()
     return bytes([merge(WIRE_LEN, _TAG_OF[type(msg)])]) + varint(len(body)) + body
 
@@ -260,6 +289,14 @@ def decode_message(buf: bytes):
     ty, tag = split(buf[0])
     if ty != WIRE_LEN:
         raise ValueError("message type byte is not length-delimited")
+    if tag == RELAY:   # no length of its own: node, then the wrapped message to the end of the buffer
+        if buf[1] != merge(WIRE_LEN, 1):
+            raise ValueError("relay message without a node")
+        node, off = read_ld(buf, 2)
+        if off >= len(buf) or buf[off] != merge(WIRE_LEN, 2):
+            raise ValueError("relay message without a message")
+        inner, used = decode_message(buf[off + 1:])
+        return Relay(decode_node(node), inner), off + 1 + used
     body, end = read_ld(buf, 1)
     f = list(_fields(body, raw_byte_tags=(6,) if tag == QUERY else ()))
     if tag == JOIN:
@@ -274,6 +311,9 @@ def decode_message(buf: bytes):
     elif tag == QUERY:
         d = {t: v for t, v in f if t != 4}
         msg = Query(d[1], d[2], decode_node(d[3]), d[5], d[6], d[7], d.get(8, b""), d.get(9, b""), [v for t, v in f if t == 4])
+    elif tag == QUERY_RESPONSE:
+        d = dict(f)
+        msg = QueryResponse(d[1], d[2], decode_node(d[3]), d.get(4, 0), d.get(5, b""))
     elif tag == PUSH_PULL:
         msg = PushPull(0)
         for t, v in f:

@@ -99,8 +99,12 @@ def test_peek_decode_deliver_reproduces_the_rumour_in_a_second_cluster(oracle):
 def test_malformed_and_unsupported_messages_are_refused(oracle):
     sim = _ffi.Sim(oracle, _ffi.make_config(64, **KW))
     good = wire.encode_message(wire.Join(3, 5))
+    qr = wire.QueryResponse(3, 9, 5, 1)
     for bad in (b"", good[:-1], bytes([good[0] ^ 1]) + good[1:], wire.encode_message(wire.Join(3, 9999)),
-                wire.encode_message(wire.PushPull(4))):
+                wire.encode_message(wire.PushPull(4, {9999: 3})), wire.encode_message(wire.PushPull(4, {3: 3}, [70])),
+                wire.encode_message(wire.QueryResponse(3, 9, 64, 1)), wire.encode_message(wire.QueryResponse(3, 0, 5, 1)),
+                wire.encode_message(wire.Relay(64, qr)), wire.encode_message(wire.Relay(7, wire.Join(3, 5))),   # only a QueryResponse travels in a Relay
+                wire.encode_message(wire.Relay(7, wire.Relay(8, qr))), wire.encode_message(wire.Relay(7, qr))[:-2]):
         if not bad:
             continue
         with pytest.raises(_ffi.SimError):
@@ -132,3 +136,86 @@ def test_swim_records_can_be_handed_in_too(oracle):
     sim.step(30)
     st, _ = sim.members(100)
     assert st[9] == _ffi.STATUS_FAILED
+
+
+# ---- round 4: QueryResponse, Relay and PushPull at the byte boundary ---------------------------------------------------
+def deliver_query_traffic(sim, n):
+    """A query of node 4 that asks for acks; node 9 is cut off (crashed) before it can answer; then, over the byte boundary:
+    an ack and a response in 9's name, a relayed response in 11's name through a running and through a crashed relay, and
+    answers that must NOT count: to a node that is not the origin, for an id that is not running."""
+    sim.inject(0, _ffi.OP_CRASH, 9)
+    sim.inject(0, _ffi.OP_CRASH, 30)
+    sim.query(4, 77, _ffi.F_ACK)
+    sim.step(3)
+    ack, resp = wire.QueryResponse(5, 77, 9, 1), wire.QueryResponse(5, 77, 9, 0, b"pong")
+    for m in (ack, resp):
+        data = wire.encode_message(m)
+        assert sim.deliver_message(4, data + b"\x01") == len(data)
+    rel = wire.encode_message(wire.Relay(4, wire.QueryResponse(5, 77, 30, 0, b"x")))
+    assert sim.deliver_message(20, rel) == len(rel)          # node 20 runs: the response reaches the origin
+    rel2 = wire.encode_message(wire.Relay(4, wire.QueryResponse(5, 77, 9, 1)))
+    sim.deliver_message(30, rel2)                            # node 30 is down: nothing is forwarded (9's ack came in directly anyway)
+    rel3 = wire.encode_message(wire.Relay(4, wire.QueryResponse(5, 77, 31, 0)))
+    sim.deliver_message(30, rel3)                            # ... and 31's response is lost with it
+    sim.deliver_message(5, wire.encode_message(wire.QueryResponse(5, 77, 40, 0)))     # 5 is not the origin
+    sim.deliver_message(4, wire.encode_message(wire.QueryResponse(5, 78, 41, 0)))     # no such query
+    sim.step(1)
+
+
+def test_query_responses_and_relays_over_the_byte_boundary(oracle):
+    n = 64
+    sim = _ffi.Sim(oracle, _ffi.make_config(n, **KW))
+    deliver_query_traffic(sim, n)
+    acks, resps = set(sim.query_responders(77, 0)), set(sim.query_responders(77, 1))
+    assert 9 in acks and 9 in resps and 30 in resps
+    assert not ({31, 40, 41} & resps) and 30 not in acks
+    a, r, still_open = sim.query_status(77)
+    assert a == len(acks) and r == len(resps) and still_open
+    sim.step(40)   # past the deadline: a late answer is not counted
+    before = sim.query_responders(77, 1)
+    sim.deliver_message(4, wire.encode_message(wire.QueryResponse(5, 77, 50, 0)))
+    sim.step(1)
+    assert sim.query_responders(77, 1) == before
+
+
+def push_pull_message():
+    return wire.PushPull(40, {3: 12, 5: 20, 8: 25, 17: 1}, [5, 21], 30,
+                         [(7, [(b"deploy", b"v1"), (b"deploy", b"v2")]), (9, [(b"restart", b"")])], 22)
+
+
+def test_push_pull_over_the_byte_boundary_is_merge_remote_state(oracle):
+    n = 64
+    sim = _ffi.Sim(oracle, _ffi.make_config(n, **KW))
+    sim.watch(2)
+    data = wire.encode_message(push_pull_message())
+    assert sim.deliver_message(2, data) == len(data)
+    sim.step(1)
+    row = sim.dump(_ffi.ARR_ROWS)[2]
+    assert (int(row["clock"]), int(row["event_clock"]), int(row["query_clock"])) == (40, 30, 22)   # witness(remote - 1) = remote
+    st, lt = sim.members(2)
+    assert (st[3], lt[3]) == (_ffi.STATUS_ALIVE, 12) and (st[8], lt[8]) == (_ffi.STATUS_ALIVE, 25)
+    assert (st[5], lt[5]) == (_ffi.STATUS_LEAVING, 21)        # left member: a leave intent one past its status time
+    assert (st[17], lt[17]) == (_ffi.STATUS_ALIVE, 1)         # not newer than what node 2 holds: nothing changes
+    assert st[21] == _ffi.STATUS_ALIVE                        # on the left list without a status time: skipped (delegate.rs:504-509)
+    got = {(e[3], e[4]) for e in sim.drain_events() if e[1] == 2 and e[2] == _ffi.EV_USER}
+    assert got == {(event_key(b"deploy", b"v1"), 7), (event_key(b"deploy", b"v2"), 7), (event_key(b"restart", b""), 9)}
+    # merge_remote_state re-queues nothing: node 2 has nothing to send
+    assert sim.peek_packet(2, 0) == b""
+    # ... the same records delivered as messages ARE rebroadcast
+    other = _ffi.Sim(oracle, _ffi.make_config(n, **KW))
+    other.deliver_message(2, wire.encode_message(wire.UserEvent(7, b"deploy", b"v1", False)))
+    other.step(1)
+    assert other.peek_packet(2, 0) != b""
+
+
+def test_push_pull_that_names_the_receiver_as_left_is_refuted(oracle):
+    n = 64
+    sim = _ffi.Sim(oracle, _ffi.make_config(n, **KW))
+    data = wire.encode_message(wire.PushPull(10, {2: 5}, [2]))
+    sim.deliver_message(2, data)
+    sim.step(1)
+    raw = sim.peek_packet(2, 0)
+    m, _ = wire.decode_message(raw)
+    assert isinstance(m, wire.Join) and m.id == 2 and m.ltime >= 10   # broadcast_join at the witnessed clock (base.rs:1470-1480)
+    st, _ = sim.members(2)
+    assert st[2] == _ffi.STATUS_ALIVE

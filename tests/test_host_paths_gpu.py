@@ -166,6 +166,54 @@ def test_byte_boundary_of_the_delegate_on_the_gpu(oracle, hiplib):
     assert sorted(names) == sorted(b"ev%d" % i for i in range(14))
 
 
+@pytest.mark.parametrize("view_slots", [0, 16])
+def test_query_response_relay_and_push_pull_on_the_gpu(oracle, hiplib, view_slots):
+    # tests/test_bridge.py's round-4 scenarios (QueryResponse, Relay, PushPull at sim_deliver_message) on the HIP library, the
+    # oracle beside it: the C++ decoder (serf_amd/host/wire.hpp) against the oracle's C one, SIM_OP_QRESP / SIM_OP_WITNESS /
+    # the muted deliveries in ops_kernel against apply_op
+    from tests.test_bridge import KW, deliver_query_traffic, push_pull_message
+
+    n = 64
+    kw = dict(KW, view_slots=view_slots)
+    g, o = both(oracle, hiplib, n, **kw)
+    for s in (g, o):
+        deliver_query_traffic(s, n)
+    assert g.digest() == o.digest()
+    for which in (0, 1):
+        assert g.query_responders(77, which) == o.query_responders(77, which)
+    assert 9 in g.query_responders(77, 0) and 30 in g.query_responders(77, 1) and 31 not in g.query_responders(77, 1)
+    assert g.query_status(77) == o.query_status(77)
+    data = wire.encode_message(push_pull_message())
+    for s in (g, o):
+        s.watch(2)
+        assert s.deliver_message(2, data + b"\x00") == len(data)
+        s.deliver_message(6, wire.encode_message(wire.PushPull(10, {6: 5}, [6])))   # names its receiver as left: refuted
+        s.step(1)
+    assert g.digest() == o.digest()
+    assert g.drain_events() == o.drain_events()
+    for node in (2, 6):
+        assert g.peek_packet(node, 0) == o.peek_packet(node, 0)
+    m, _ = wire.decode_message(g.peek_packet(6, 0))
+    assert isinstance(m, wire.Join) and m.id == 6
+    for t in range(20):
+        g.step(1)
+        o.step(1)
+        assert g.digest() == o.digest(), f"tick {t}"
+    # the same refusals
+    qr = wire.QueryResponse(3, 9, 5, 1)
+    for bad in (wire.encode_message(wire.PushPull(4, {9999: 3})), wire.encode_message(wire.QueryResponse(3, 9, 64, 1)),
+                wire.encode_message(wire.Relay(7, wire.Join(3, 5))), wire.encode_message(wire.Relay(7, wire.Relay(8, qr))),
+                wire.encode_message(wire.Relay(7, qr))[:-2], wire.encode_message(wire.Relay(64, qr))):
+        for s in (g, o):
+            with pytest.raises(_ffi.SimError) as e:
+                s.deliver_message(1, bad)
+            assert e.value.code == _ffi.EINVAL
+    for s in (g, o):
+        for op in (_ffi.OP_DELIVER, _ffi.OP_QRESP, _ffi.OP_WITNESS):
+            with pytest.raises(_ffi.SimError):
+                s.inject(s.tick, op, 1, 1, 0)
+
+
 def test_memberlist_flags_on_the_gpu(oracle, hiplib):
     # tests/test_oracle_swim.py::test_gossip_to_the_dead_time and ::test_awareness_scales_the_probe_interval on the HIP
     # library, the oracle beside it tick by tick
