@@ -2444,7 +2444,8 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
 // library on the per-tick path), two launches per tick:
 //   rf_scatter  every workgroup draws the targets of its SPW senders, counts them per level-1 bucket (= 2^LB consecutive
 //               targets) in LDS, reserves its share of every bucket's REGION with one global atomic per (workgroup, bucket),
-//               draws again and writes the pairs there: l1[b * bcap + ...], runs of ~ 4 SPW / NB pairs.  The regions have a
+//               lays the pairs down in LDS bucket by bucket and writes them out from there: l1[b * bcap + ...], runs of
+//               ~ 4 SPW / NB pairs stored by consecutive lanes.  The regions have a
 //               fixed capacity bcap (mean 4 * 2^LB + 12 sigma: uniform draws never fill one); what does not fit all the
 //               same goes onto an overflow list.  Any order inside a bucket will do: the order that counts is restored by
 //               rank, not by stability — so the result does not depend on who won which atomic.
@@ -2458,14 +2459,16 @@ struct RfP {
   u32 N, Nl, shard0, feff, f;
   u32 LB, NB;   // level-1 buckets: NB = ceil(Nl / 2^LB) ranges of 2^LB consecutive (local) targets
   u32 PB;       // bits of a pair id p = 4 l + k; a scattered entry is (target - bucket start) << PB | p — 32 bits when they fit
-  u32 NWG;      // workgroups of rf_scatter (RF_SPW senders each)
+  u32 NWG;      // workgroups of rf_scatter (RfSpw senders each)
   u32 cap;      // pairs rf_rows can rank in LDS (a multiple of RFR, at most RF_EPT * RFR)
   u32 bcap;     // pairs a bucket's region of l1 holds
   u32 ocap;     // entries of the overflow list
 };
 #define RFB 1024          // threads of an rf_scatter workgroup
 #define RF_GCS 1u         // stride of the buckets' fill counters in words (a line each — 32 — made the atomics slower: 55.7 vs 47.6 us, profiles/r04_experiments.md)
-#define RF_SPW 4096u      // senders of an rf_scatter workgroup: four per thread, their targets stay in registers between its two passes
+// senders of an rf_scatter workgroup, by entry width: their pairs are staged in LDS (6 / 10 bytes a pair) and leave as runs of
+// 4 SPW / NB entries — 4096 senders: 102 KiB of LDS with 32-bit entries; 64-bit entries (above 4 Mi nodes) take 2048
+template <typename E> struct RfSpw { static constexpr u32 v = sizeof(E) == 4 ? 4096u : 2048u; };
 #define RFR 512           // threads of an rf_rows workgroup
 #define RF_LB_MAX 11u     // at most 2048 rows per level-1 bucket
 #define RF_EPT 24u        // pairs one thread of rf_rows keeps in registers: cap <= RF_EPT * RFR
@@ -2481,16 +2484,26 @@ __device__ static inline u32 wave_excl_scan(u32 v, u32& total) {
   return x - v;
 }
 // gcur[NB]: pairs in each bucket so far (zero at launch: rf_rows of the build before zeroed it); ovf: [0] = entries, then (bucket, entry) pairs
+// LDS of rf_scatter (dynamic): cnt[NB] | lst[NB] | cur[NB] | stage: E[f * SPW] | stb: u16[f * SPW]
+template <typename E>
+static inline size_t rf_scatter_lds(const RfP& r) { return (((size_t)3u * r.NB * 4u + 7u) & ~(size_t)7u) + (size_t)SIM_MAX_FANOUT * RfSpw<E>::v * (sizeof(E) + 2u); }
 template <typename E>
 __global__ __launch_bounds__(RFB) void rf_scatter_kernel(RfP r, u32* gcur, E* l1, E* ovf) {
-  extern __shared__ u32 rf_lds[];  // [NB] counts, then the workgroup's base in the bucket's region; [NB] cursors
-  u32 *cnt = rf_lds, *cur = rf_lds + r.NB;
-  for (u32 b = threadIdx.x; b < 2u * r.NB; b += RFB) rf_lds[b] = 0;
+  constexpr u32 SPW = RfSpw<E>::v;
+  extern __shared__ u32 rf_lds[];
+  // cnt: the workgroup's pairs per bucket, then its base in the bucket's region; lst: where the bucket's run starts in the
+  // staging area; cur: cursors.  The pairs are laid down in LDS bucket by bucket and leave as runs: consecutive lanes store
+  // consecutive entries of a region (scattered 4-byte stores straight from the drawing lanes cost 30 of this kernel's 48 us)
+  u32 *cnt = rf_lds, *lst = cnt + r.NB, *cur = lst + r.NB;
+  E* stage = reinterpret_cast<E*>(reinterpret_cast<char*>(rf_lds) + (((size_t)3u * r.NB * 4u + 7u) & ~(size_t)7u));
+  uint16_t* stb = reinterpret_cast<uint16_t*>(stage + (size_t)SIM_MAX_FANOUT * SPW);
+  __shared__ u32 wsum[RFB / 64u];
+  for (u32 b = threadIdx.x; b < 3u * r.NB; b += RFB) rf_lds[b] = 0;
   __syncthreads();
-  const u32 l0 = blockIdx.x * RF_SPW;
-  u32 tg[RF_SPW / RFB][SIM_MAX_FANOUT], nc[RF_SPW / RFB];
+  const u32 l0 = blockIdx.x * SPW;
+  u32 tg[SPW / RFB][SIM_MAX_FANOUT], nc[SPW / RFB];
 #pragma unroll
-  for (u32 j = 0; j < RF_SPW / RFB; ++j) {
+  for (u32 j = 0; j < SPW / RFB; ++j) {
     const u32 l = l0 + j * RFB + threadIdx.x;
     nc[j] = l < r.Nl ? rf_draw(r.rb, r.shard0 + l, r.N, r.feff, tg[j]) : 0u;
 #pragma unroll
@@ -2498,25 +2511,45 @@ __global__ __launch_bounds__(RFB) void rf_scatter_kernel(RfP r, u32* gcur, E* l1
       if (k < nc[j]) atomicAdd(&cnt[(tg[j][k] - r.shard0) >> r.LB], 1u);
   }
   __syncthreads();
-  for (u32 b = threadIdx.x; b < r.NB; b += RFB) {
-    const u32 c = cnt[b];
-    cnt[b] = c ? atomicAdd(&gcur[(size_t)b * RF_GCS], c) : 0u;
+  {  // exclusive prefix of the counts (every thread a stretch of buckets), and the workgroup's share of every region
+    const u32 per = (r.NB + RFB - 1u) / RFB, b0 = threadIdx.x * per, b1 = min(b0 + per, r.NB);
+    u32 sum = 0;
+    for (u32 b = b0; b < b1; ++b) sum += cnt[b];
+    u32 wtot;
+    u32 run = wave_excl_scan(sum, wtot);
+    if ((threadIdx.x & 63u) == 0) wsum[threadIdx.x >> 6] = wtot;
+    __syncthreads();
+    for (u32 w = 0; w < (threadIdx.x >> 6); ++w) run += wsum[w];
+    for (u32 b = b0; b < b1; ++b) {
+      const u32 c = cnt[b];
+      lst[b] = run;
+      run += c;
+      cnt[b] = c ? atomicAdd(&gcur[(size_t)b * RF_GCS], c) : 0u;
+    }
   }
   __syncthreads();
 #pragma unroll
-  for (u32 j = 0; j < RF_SPW / RFB; ++j) {
+  for (u32 j = 0; j < SPW / RFB; ++j) {
     const u32 l = l0 + j * RFB + threadIdx.x;
 #pragma unroll
     for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) {
       if (k < nc[j]) {  // (a slot without a target — fewer other nodes than the fan-out — is in nobody's row)
-        const u32 t = tg[j][k] - r.shard0, b = t >> r.LB, at = cnt[b] + atomicAdd(&cur[b], 1u);
-        const E e = ((E)(t - (b << r.LB)) << r.PB) | (E)(4u * l + k);
-        if (at < r.bcap) l1[(size_t)b * r.bcap + at] = e;
-        else {
-          const u32 o = atomicAdd(reinterpret_cast<u32*>(ovf), 1u);
-          if (o < r.ocap) { ovf[1u + 2u * o] = (E)b; ovf[2u + 2u * o] = e; }
-        }
+        const u32 t = tg[j][k] - r.shard0, b = t >> r.LB, at = lst[b] + atomicAdd(&cur[b], 1u);
+        stage[at] = ((E)(t - (b << r.LB)) << r.PB) | (E)(4u * l + k);
+        stb[at] = (uint16_t)b;
       }
+    }
+  }
+  __syncthreads();
+  u32 total = 0;
+  for (u32 w = 0; w < RFB / 64u; ++w) total += wsum[w];
+  for (u32 i = threadIdx.x; i < total; i += RFB) {  // any order inside a bucket will do (rf_rows ranks)
+    const u32 b = stb[i], at = cnt[b] + (i - lst[b]);
+    const E e = stage[i];
+    if (at < r.bcap) l1[(size_t)b * r.bcap + at] = e;
+    else {
+      const u32 o = atomicAdd(reinterpret_cast<u32*>(ovf), 1u);
+      if (o < r.ocap) { ovf[1u + 2u * o] = (E)b; ovf[2u + 2u * o] = e; }
     }
   }
 }
@@ -3700,11 +3733,11 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
     while ((1ull << r.PB) < 4ull * Nl) r.PB++;
     r.LB = std::min<u32>(11u, 32u - std::min<u32>(r.PB, 24u));
     if (const char* e = getenv("SERF_RF_LB")) r.LB = std::min<u32>(RF_LB_MAX, std::max<u32>(8u, (u32)strtoul(e, nullptr, 0)));
-    while (((size_t)Nl + (1u << r.LB) - 1u) >> r.LB > 4096u) r.LB++;  // rf_scatter's two tables: 32 KiB of LDS
+    while (((size_t)Nl + (1u << r.LB) - 1u) >> r.LB > 4096u) r.LB++;  // rf_scatter's three tables: 48 KiB of LDS next to its staging area
     if (r.LB > RF_LB_MAX) { sim_destroy(h); return SIM_EINVAL; }
     h->rf_wide = r.PB + r.LB > 32u || getenv("SERF_RF_WIDE") != nullptr;
     r.NB = (u32)(((size_t)Nl + (1u << r.LB) - 1u) >> r.LB);
-    r.NWG = (u32)(((size_t)Nl + RF_SPW - 1u) / RF_SPW);
+    r.NWG = (u32)(((size_t)Nl + (h->rf_wide ? RfSpw<u64>::v : RfSpw<u32>::v) - 1u) / (h->rf_wide ? RfSpw<u64>::v : RfSpw<u32>::v));
     r.cap = std::min<u32>(6u << r.LB, RF_EPT * RFR);  // mean 4 * 2^LB pairs, sigma 2 * 2^(LB/2): 32 sigma and more of room
     if (const char* e = getenv("SERF_RF_CAP")) r.cap = std::max<u32>(RFR, std::min<u32>(r.cap, (u32)strtoul(e, nullptr, 0)) / RFR * RFR);  // tests: force rf_rows' slow path
     // a bucket's region of l1: f pairs per row it can have at most when the shard is one bucket, else the mean and 12 sigma
@@ -3714,8 +3747,10 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
       if (const char* e = getenv("SERF_RF_BCAP")) r.bcap = std::max<u32>(1u, (u32)strtoul(e, nullptr, 0));  // tests: force the overflow list
       r.ocap = (u32)np;  // (every pair would fit: the list cannot run full)
     }
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rf_rows_kernel<u32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rf_rows_lds(r)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(rf_rows_kernel<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rf_rows_lds(r)) != hipSuccess) { sim_destroy(h); return SIM_EDEVICE; }
+    if (h->rf_wide ? (hipFuncSetAttribute(reinterpret_cast<const void*>(rf_rows_kernel<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rf_rows_lds(r)) != hipSuccess ||
+                      hipFuncSetAttribute(reinterpret_cast<const void*>(rf_scatter_kernel<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rf_scatter_lds<u64>(r)) != hipSuccess)
+                   : (hipFuncSetAttribute(reinterpret_cast<const void*>(rf_rows_kernel<u32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rf_rows_lds(r)) != hipSuccess ||
+                      hipFuncSetAttribute(reinterpret_cast<const void*>(rf_scatter_kernel<u32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rf_scatter_lds<u32>(r)) != hipSuccess)) { sim_destroy(h); return SIM_EDEVICE; }
     h->rf_sync = getenv("SERF_RF_SYNC") != nullptr;  // measurements: build on the tick's own stream, nothing overlaps
     for (int i = 0; i < 3; ++i) { DA(h->rf_rcsr[i], Nl + 1) DA(h->rf_rsrc[i], np) }
     {
@@ -4299,10 +4334,10 @@ static int rf_build(sim_handle* h, u64 tick, hipStream_t s) {
   const u32 par = h->rf_par;
   h->rf_par ^= 1u;
   if (h->rf_wide) {
-    rf_scatter_kernel<u64><<<r.NWG, RFB, 2 * r.NB * 4, s>>>(r, h->rf_gcur[par], (u64*)h->rf_l1, (u64*)h->rf_ovf[par]);
+    rf_scatter_kernel<u64><<<r.NWG, RFB, rf_scatter_lds<u64>(r), s>>>(r, h->rf_gcur[par], (u64*)h->rf_l1, (u64*)h->rf_ovf[par]);
     rf_rows_kernel<u64><<<r.NB, RFR, rf_rows_lds(r), s>>>(r, h->rf_gcur[par], h->rf_gcur[par ^ 1u], (const u64*)h->rf_l1, (u64*)h->rf_ovf[par], (u64*)h->rf_ovf[par ^ 1u], rcsr, rsrc);
   } else {
-    rf_scatter_kernel<u32><<<r.NWG, RFB, 2 * r.NB * 4, s>>>(r, h->rf_gcur[par], (u32*)h->rf_l1, (u32*)h->rf_ovf[par]);
+    rf_scatter_kernel<u32><<<r.NWG, RFB, rf_scatter_lds<u32>(r), s>>>(r, h->rf_gcur[par], (u32*)h->rf_l1, (u32*)h->rf_ovf[par]);
     rf_rows_kernel<u32><<<r.NB, RFR, rf_rows_lds(r), s>>>(r, h->rf_gcur[par], h->rf_gcur[par ^ 1u], (const u32*)h->rf_l1, (u32*)h->rf_ovf[par], (u32*)h->rf_ovf[par ^ 1u], rcsr, rsrc);
   }
   HCHECK(hipGetLastError());

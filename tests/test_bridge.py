@@ -219,3 +219,34 @@ def test_push_pull_that_names_the_receiver_as_left_is_refuted(oracle):
     assert isinstance(m, wire.Join) and m.id == 2 and m.ltime >= 10   # broadcast_join at the witnessed clock (base.rs:1470-1480)
     st, _ = sim.members(2)
     assert st[2] == _ffi.STATUS_ALIVE
+
+
+def merge_kat_message():
+    """The fake push-pull of delegate_merge_remote_state (serf/base/tests/serf/delegate.rs:117-180) with node ids for names:
+    "test" = 1, "foo" = 2."""
+    return wire.PushPull(42, {1: 20, 2: 15}, [2], 50, [(45, [(b"test", b"")])], 100)
+
+
+def check_merge_kat(sim, n):
+    """... and what the reference asserts after `merge_remote_state(&buf, false)` on a just-constructed Serf (node 0)."""
+    row = sim.dump(_ffi.ARR_ROWS)[0]
+    assert int(row["clock"]) == 42, "bad lamport clock"
+    assert int(row["event_clock"]) == 50, "bad event clock"
+    assert int(row["query_clock"]) == 100, "bad query clock"
+    view = sim.dump(_ffi.ARR_VIEW).reshape(n, n)       # dense view: [subject][observer]
+    for subject, ty, ltime in ((1, 1, 20), (2, 2, 16)):   # recent_intent(test, Join) == 20, recent_intent(foo, Leave) == 16
+        e = view[subject, 0]
+        assert not (int(e["bits"]) & 1), "a pending intent, not a member"
+        assert ((int(e["bits"]) >> 6) & 3, int(e["ltime"])) == (ty, ltime)
+    ring = sim.dump(_ffi.ARR_ERING).reshape(512, n)
+    b = ring[45, 0]
+    assert int(b["ltime"]) == 45 and int(b["keys"][0]) == event_key(b"test", b""), "missing event buffer for time"
+
+
+def test_reference_merge_remote_state_kat_in_byte_form(oracle):
+    n = 8
+    sim = _ffi.Sim(oracle, _ffi.make_config(n, flags=0, view_slots=0, event_ring=512))   # Serf::new: only itself known, clocks at 1
+    data = wire.encode_message(merge_kat_message())
+    assert sim.deliver_message(0, data) == len(data)
+    sim.step(1)
+    check_merge_kat(sim, n)

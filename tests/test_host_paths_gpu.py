@@ -214,6 +214,18 @@ def test_query_response_relay_and_push_pull_on_the_gpu(oracle, hiplib, view_slot
                 s.inject(s.tick, op, 1, 1, 0)
 
 
+def test_reference_merge_remote_state_kat_on_the_gpu(hiplib):
+    # delegate_merge_remote_state (serf/base/tests/serf/delegate.rs:117-180), the message in bytes, the HIP library alone
+    from tests.test_bridge import check_merge_kat, merge_kat_message
+
+    n = 8
+    sim = _ffi.Sim(hiplib, _ffi.make_config(n, flags=0, view_slots=0, event_ring=512))
+    data = wire.encode_message(merge_kat_message())
+    assert sim.deliver_message(0, data) == len(data)
+    sim.step(1)
+    check_merge_kat(sim, n)
+
+
 def test_memberlist_flags_on_the_gpu(oracle, hiplib):
     # tests/test_oracle_swim.py::test_gossip_to_the_dead_time and ::test_awareness_scales_the_probe_interval on the HIP
     # library, the oracle beside it tick by tick
