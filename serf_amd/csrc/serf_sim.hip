@@ -3263,7 +3263,10 @@ __global__ void stats_kernel(Dev d, u32 l, sim_stats* o) {
 }
 // cluster-wide load figures: out[0] up, [1..4] queue entries by class, [5] overflow, [6] records in flight,
 // [7] failed, [8] left, [9] deepest queue (max)
-__global__ void cluster_stats_kernel(Dev d, const uint4* inbox, u64* out) {
+// Two levels: every workgroup leaves its ten partial figures in part[blockIdx.x][10] (no atomics: 4096 workgroups adding to
+// ten words cost 0.4 ms), cluster_stats_fold adds them up.
+#define CSTAT_WG 1024
+__global__ void cluster_stats_kernel(Dev d, const uint4* inbox, u64* part) {
   u64 a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   u32 mx = 0;
   for (size_t l = blockIdx.x * (size_t)BLOCK + threadIdx.x; l < d.Nl; l += (size_t)gridDim.x * BLOCK) {
@@ -3281,8 +3284,30 @@ __global__ void cluster_stats_kernel(Dev d, const uint4* inbox, u64* out) {
       for (u32 k = 0; k < d.fp; ++k)
         for (u32 p = 0; p < SIM_P; ++p) a[6] += SIM_META_KIND(pk_word(inbox[((size_t)k * d.Nl + l) * PK_U4 + 2], p)) != SIM_K_EMPTY;
   }
-  for (int i = 0; i < 9; ++i) block_sum_add(a[i], out + i);
-  atomicMax((unsigned long long*)(out + 9), (unsigned long long)mx);
+  __shared__ u64 sm[10][BLOCK / 64];
+  for (int i = 0; i < 9; ++i) {
+    u64 v = a[i];
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sm[i][threadIdx.x >> 6] = v;
+  }
+  for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (u32)__shfl_down((int)mx, o, 64));
+  if ((threadIdx.x & 63) == 0) sm[9][threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x < 10) {
+    u64 t = 0;
+    for (int i = 0; i < BLOCK / 64; ++i) t = threadIdx.x == 9 ? max(t, sm[9][i]) : t + sm[threadIdx.x][i];
+    part[(size_t)blockIdx.x * 10 + threadIdx.x] = t;
+  }
+}
+__global__ void cluster_stats_fold(const u64* part, u32 nwg, u64* out) {  // one workgroup of 64 x 10 threads: figure = threadIdx.y
+  const u32 i = threadIdx.y;
+  u64 t = 0;
+  for (u32 w = threadIdx.x; w < nwg; w += 64u) t = i == 9 ? max(t, part[(size_t)w * 10 + i]) : t + part[(size_t)w * 10 + i];
+  for (int o = 32; o >= 1; o >>= 1) {
+    const u64 y = __shfl_down(t, o, 64);
+    t = i == 9 ? max(t, y) : t + y;
+  }
+  if (threadIdx.x == 0) out[i] = t;
 }
 // single-word / single-entry updates of device tables with the value passed by value (no host buffer to outlive)
 __global__ void poke_u32(u32* p, u32 v) { if (!threadIdx.x && !blockIdx.x) *p = v; }
@@ -5200,13 +5225,15 @@ int sim_cluster_stats_get(sim_handle* h, sim_cluster_stats* out) {
   if (!h || !out) return SIM_EINVAL;
   Dev& d = h->d;
   hipStream_t s = h->stream;
-  u64* scr = nullptr;
-  if (hipMalloc((void**)&scr, 10 * 8) != hipSuccess) return SIM_ENOMEM;
+  u64* scr = nullptr;  // [10] the figures, then [workgroups][10] partial ones
+  const u32 nwg = (u32)std::min<int>(grid_for(d.Nl), CSTAT_WG);
+  if (hipMalloc((void**)&scr, (size_t)(1 + nwg) * 10 * 8) != hipSuccess) return SIM_ENOMEM;
   u64 r[10];
-  hipError_t e = hipMemsetAsync(scr, 0, 10 * 8, s);
-  if (e == hipSuccess) {
+  hipError_t e = hipSuccess;
+  {
     // sharded: the packets in flight sit in the receive buffer, [src][k][blk] = f * Nl cells as well
-    cluster_stats_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, cur_inbox(h), scr);
+    cluster_stats_kernel<<<nwg, BLOCK, 0, s>>>(d, cur_inbox(h), scr + 10);
+    cluster_stats_fold<<<1, dim3(64, 10), 0, s>>>(scr + 10, nwg, scr);
     e = hipMemcpyAsync(r, scr, sizeof r, hipMemcpyDeviceToHost, s);
   }
   u32 evc = 0;
