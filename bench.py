@@ -587,8 +587,9 @@ def run(args, lib=None, dev=None, backend="nccl"):
             out["layout"] = {"b_tick_bytes": bt2, "achieved": layout, "frac": layout / 8000.0,
                              "what": "the same accounting for the bijection's frozen layout (DESIGN.md §4): packets kept at the sender"}
         else:
-            out["graph_build"] = ("the fan-out graph of a tick (rf_count / rf_scan / rf_bstart / rf_scatter / rf_rows: ~0.11 ms at 1 Mi nodes, on a "
-                                  "stream of its own) is part of ms_per_step and of `value`, not of kernel_ms: profiles/r04_kernel_stats_krandomnodes.csv")
+            out["graph_build"] = ("the fan-out graph of a tick (rf_scatter + rf_rows: ~0.05 ms at 1 Mi nodes when they run alone; built two ticks "
+                                  "ahead on a stream of its own, next to the tick kernels) is part of ms_per_step and of `value`, not of kernel_ms: "
+                                  "profiles/r04_kernel_stats_krandomnodes.csv")
         return out
 
     def rounds_of(m):

@@ -2469,7 +2469,9 @@ struct RfP {
 // senders of an rf_scatter workgroup, by entry width: their pairs are staged in LDS (6 / 10 bytes a pair) and leave as runs of
 // 4 SPW / NB entries — 4096 senders: 102 KiB of LDS with 32-bit entries; 64-bit entries (above 4 Mi nodes) take 2048
 template <typename E> struct RfSpw { static constexpr u32 v = sizeof(E) == 4 ? 4096u : 2048u; };
+#ifndef RFR
 #define RFR 512           // threads of an rf_rows workgroup
+#endif
 #define RF_LB_MAX 11u     // at most 2048 rows per level-1 bucket
 #define RF_EPT 24u        // pairs one thread of rf_rows keeps in registers: cap <= RF_EPT * RFR
 // exclusive prefix over the 64 lanes of a wave (`total` = the sum)
@@ -3525,14 +3527,16 @@ struct sim_handle {
   bool rf_wide;        // ... u64
   u32 rf_par;                          // which of the two this build uses
   RfP rfp;  // the parameters that do not change from tick to tick
-  // The graph of tick s is a function of (seed, s): it is built on a stream of its own while tick s - 1 runs.  rf_rcsr[s % 3] /
-  // rf_rsrc[s % 3] = the rows of the packets SENT during tick s (tick s + 1 still reads them while the build of tick s + 2
-  // writes: three of each); rf_built = the tick whose graph has been enqueued on rf_stream (~0: none), rf_done marks it.
+  // The graph of tick s is a function of (seed, s): it is built on a stream of its own, TWO ticks ahead — enqueued when tick
+  // s - 1 begins, read by tick s + 1 — so that no tick ever waits for a build (one tick ahead, the build ran in the tail of
+  // the tick kernel and the next tick waited 25 us for rf_rows).  rf_rcsr[s % 3] / rf_rsrc[s % 3] = the rows of the packets SENT
+  // during tick s: while tick t reads buffer (t - 1) % 3 the builds of t and t + 1 may still be writing the other two.
+  // rf_q[i] = the tick whose graph buffer i holds or is getting (~0: none), rf_done[i] marks its build.
   u32* rf_rcsr[3];
   u32* rf_rsrc[3];
   hipStream_t rf_stream;
-  hipEvent_t rf_done, rf_go[2];
-  u64 rf_built;
+  hipEvent_t rf_done[3], rf_go[2];
+  u64 rf_q[3];
   bool rf_sync;
 };
 
@@ -3633,7 +3637,7 @@ int sim_destroy(sim_handle* h) {
   if (h->xev_go) (void)hipEventDestroy(h->xev_go);
   if (h->xev_done) (void)hipEventDestroy(h->xev_done);
   if (h->rf_stream) { (void)hipStreamSynchronize(h->rf_stream); (void)hipStreamDestroy(h->rf_stream); }
-  if (h->rf_done) (void)hipEventDestroy(h->rf_done);
+  for (int i = 0; i < 3; ++i) if (h->rf_done[i]) (void)hipEventDestroy(h->rf_done[i]);
   for (int i = 0; i < 2; ++i) if (h->rf_go[i]) (void)hipEventDestroy(h->rf_go[i]);
   for (auto& pr : h->prof) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (h->d_pp) (void)hipFree(h->d_pp);
@@ -3745,7 +3749,8 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   DA(h->d_stats, 1)
   d.rcsr = d.rsrc = nullptr;
   for (int i = 0; i < 3; ++i) h->rf_rcsr[i] = h->rf_rsrc[i] = nullptr;
-  h->rf_stream = nullptr; h->rf_done = h->rf_go[0] = h->rf_go[1] = nullptr; h->rf_built = ~0ull;
+  h->rf_stream = nullptr; h->rf_go[0] = h->rf_go[1] = nullptr;
+  for (int i = 0; i < 3; ++i) { h->rf_done[i] = nullptr; h->rf_q[i] = ~0ull; }
   h->rf_gcur[0] = h->rf_gcur[1] = nullptr; h->rf_ovf[0] = h->rf_ovf[1] = h->rf_l1 = nullptr; h->rf_par = 0; h->rf_wide = false;
   memset(&h->rfp, 0, sizeof h->rfp);
   if (d.rfan) {  // the fan-out graph as a CSR, rebuilt every tick, and the packets pushed into it (SIM_CF_RANDOM_FANOUT)
@@ -3789,7 +3794,9 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
     for (int i = 0; i < 3; ++i) ok = ok && hipMemset(h->rf_rcsr[i], 0, (Nl + 1) * 4) == hipSuccess;  // tick 0 receives nothing
     for (int i = 0; i < 2; ++i) ok = ok && hipMemset(h->rf_gcur[i], 0, (size_t)r.NB * RF_GCS * 4) == hipSuccess && hipMemset(h->rf_ovf[i], 0, 8) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&h->rf_stream, hipStreamNonBlocking) == hipSuccess &&
-         hipEventCreateWithFlags(&h->rf_done, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&h->rf_done[0], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&h->rf_done[1], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&h->rf_done[2], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&h->rf_go[0], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&h->rf_go[1], hipEventDisableTiming) == hipSuccess;
     if (!ok) { sim_destroy(h); return SIM_EDEVICE; }
@@ -4487,23 +4494,34 @@ int sim_step_begin(sim_handle* h) {
   if (d.gttd && !d.rfan) gossip_skip_kernel<<<grid_for(d.Nl), BLOCK, 0, h->stream>>>(d, tp, h->d_base);  // whom not to gossip to this tick
   if (d.rfan) {
     // kRandomNodes: the graph of the packets this tick RECEIVES — sent during tick - 1 — has to stand before the tick kernel
-    // reads it.  It was built on its own stream while the tick before ran (right after a restore, or with SERF_RF_SYNC: here
-    // and now); the graph of THIS tick's packets, which tick + 1 will read, is started as soon as everything enqueued so far
-    // has finished — it overwrites buffers the tick before this one read — and has this whole tick to get done.
+    // reads it.  It was enqueued on the build stream two ticks ago (right after a restore, at tick 1, or with SERF_RF_SYNC: it
+    // is built here and now); the graphs of THIS tick's packets and the next tick's are enqueued now if they are not yet — as
+    // soon as everything enqueued so far has finished: they overwrite a buffer the tick before this one read.
     if (h->tick > 0) {
-      if (h->rf_built == h->tick - 1) HCHECK(hipStreamWaitEvent(h->stream, h->rf_done, 0));
-      else if (h->rf_built != h->tick) { int rc = rf_build(h, h->tick - 1, h->stream); if (rc) return rc; }
+      const u64 s = h->tick - 1;
+      if (h->rf_q[s % 3] != s) {
+        int rc = rf_build(h, s, h->stream);
+        if (rc) return rc;
+        h->rf_q[s % 3] = s;
+      } else HCHECK(hipStreamWaitEvent(h->stream, h->rf_done[s % 3], 0));
     }
     d.rcsr = h->rf_rcsr[(h->tick + 2) % 3];  // (tick 0: a buffer of zeros — nothing has been sent)
     d.rsrc = h->rf_rsrc[(h->tick + 2) % 3];
     if (!h->rf_sync) {
-      hipEvent_t go = h->rf_go[h->tick & 1];
-      HCHECK(hipEventRecord(go, h->stream));
-      HCHECK(hipStreamWaitEvent(h->rf_stream, go, 0));
-      int rc = rf_build(h, h->tick, h->rf_stream);
-      if (rc) return rc;
-      HCHECK(hipEventRecord(h->rf_done, h->rf_stream));
-      h->rf_built = h->tick;
+      bool waited = false;
+      for (u64 s = h->tick; s <= h->tick + 1; ++s) {
+        if (h->rf_q[s % 3] == s) continue;
+        if (!waited) {
+          hipEvent_t go = h->rf_go[h->tick & 1];
+          HCHECK(hipEventRecord(go, h->stream));
+          HCHECK(hipStreamWaitEvent(h->rf_stream, go, 0));
+          waited = true;
+        }
+        int rc = rf_build(h, s, h->rf_stream);
+        if (rc) return rc;
+        HCHECK(hipEventRecord(h->rf_done[s % 3], h->rf_stream));
+        h->rf_q[s % 3] = s;
+      }
     }
     if (d.gttd) {
       RfP r = h->rfp;
@@ -5135,7 +5153,8 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
   h->recycle_at = 0xFFFFFFFFu;
   h->pp_done_at = 0xFFFFFFFFu;
   h->op_cursor = 0;
-  h->rf_built = ~0ull;
+  if (h->rf_stream) HCHECK(hipStreamSynchronize(h->rf_stream));  // a build of the run that is being replaced may still be writing the scratch
+  for (int i = 0; i < 3; ++i) h->rf_q[i] = ~0ull;
   return SIM_OK;
 }
 int sim_query_status(sim_handle* h, uint32_t qid, uint64_t* acks, uint64_t* responses, int* open) {

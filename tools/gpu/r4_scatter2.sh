@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r4sc2
 mkdir -p $OUT
 cd $ROOT
-timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k "graph_build" 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k "random_fanout or rf or rccl" 2>&1 | tail -3
 B="--fanout-model krandomnodes --steps 20 --warmup 5 --no-second-load --no-cpu-baseline --no-convergence --no-long-window"
 cd /tmp && export TMPDIR=/tmp
 one() {  # name, env...
@@ -20,8 +20,5 @@ for r in csv.DictReader(open("$OUT/$name/t_kernel_stats.csv")):
 PY
 }
 one base SERF_RF_SYNC=1
-for V in spw4k spw1k; do one $V SERF_RF_SYNC=1 SERF_SIM_LIB=$ROOT/serf_amd/csrc/libserf_sim_x_$V.so; done
 one base_async A=1
-one base_async_noprio SERF_RF_NOPRIO=1
-for V in spw4k spw1k; do one ${V}_async SERF_SIM_LIB=$ROOT/serf_amd/csrc/libserf_sim_x_$V.so; done
 one base_async_again A=1
