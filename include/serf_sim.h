@@ -402,8 +402,7 @@ enum sim_op {
                                    the origin of running query a, receives the ack (b bit 31 set) or the response (clear) of
                                    node b & 0xFFFFFF — counted when the query is still inside its deadline and names `node`
                                    as its origin (handle_query_response base.rs:1158-1204, query.rs:240-303; one entry per
-                                   responder), exactly like one that arrived over the simulated network.  A relayed one
-                                   (relay_response, query.rs:523-601) arrives only if the relaying node is running          */
+                                   responder), exactly like one that arrived over the simulated network                      */
   SIM_OP_WITNESS = 16           /* internal (a PushPull message's clocks, delegate.rs:466-480): `node` witnesses Lamport time
                                    `val` on clock a (0 member, 1 event, 2 query) — the caller passes remote - 1              */
 };
@@ -457,8 +456,10 @@ int sim_inject(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, uint32_
  *   *consumed (may be NULL) = bytes used, so a caller can walk a packet of several messages.  Join, Leave, UserEvent, Query:
  *   sim_inject_record.  (r4) QueryResponse (types/query/response.rs): the origin `node` counts the ack / response of the
  *   node it names (SIM_OP_QRESP).  Relay (types/message.rs:431-470: a destination Node and a framed message): `node`
- *   forwards the inner message to the destination if it is running at that tick; the inner message must be a
- *   QueryResponse — what relay_response wraps (query.rs:523-601) — anything else inside is refused (SIM_EINVAL).
+ *   forwards the wrapped message to the destination as it is (delegate.rs:262-313: memberlist.send) — it is delivered to the
+ *   destination exactly as if handed to it directly, provided `node` is running as of the last tick; a relay that is down
+ *   forwards nothing (SIM_OK, the bytes are consumed).  A Relay or a PushPull inside a Relay is refused (SIM_EINVAL).
+ *   ConflictResponse: taken and ignored — notify_message has no arm for it (delegate.rs:286-288).
  *   PushPull (types/push_pull.rs; merge_remote_state delegate.rs:427-554): the three clocks are witnessed at remote - 1
  *   (SIM_OP_WITNESS), every left member becomes a leave intent at its status_ltime + 1, every other member a join intent at
  *   its status_ltime, every buffered user event is replayed — all with SIM_DELIVER_MUTE: nothing is rebroadcast but a

@@ -1154,10 +1154,10 @@ static void apply_op(osim* s, const sim_opent* op) {
   }
   if (op->op == SIM_OP_QRESP) { /* handle_query_response (base.rs:1158-1204): an ack / a response that came in over the byte boundary.
                                  * Trackers and liveness are replicated; the responder's bit lives on the shard that owns the responder */
-    uint32_t j = op->a % SIM_QT, from = op->b & 0xFFFFFFu, which = (op->b >> 31) ? 0u : 1u, via = (uint32_t)op->val;
+    uint32_t j = op->a % SIM_QT, from = op->b & 0xFFFFFFu, which = (op->b >> 31) ? 0u : 1u;
     size_t words = ((size_t)s->N + 31) / 32;
     if (from >= s->shard0 && from < s->shard0 + s->Nl && up_of(s, op->node) && s->qtab[j].qid == op->a && s->qtab[j].origin == op->node &&
-        (uint32_t)s->tick <= s->qtab[j].deadline && (!via || up_of(s, via - 1u)))
+        (uint32_t)s->tick <= s->qtab[j].deadline)
       s->qbits[((size_t)j * 2 + which) * words + (from >> 5)] |= 1u << (from & 31);
     return;
   }
@@ -1995,7 +1995,7 @@ static int inject_val(osim* s, uint64_t tick, uint32_t op, uint32_t node, uint32
       else if (a >= s->N) return SIM_EINVAL;
       break;
     }
-    case SIM_OP_QRESP: if (!a || (b & 0xFFFFFFu) >= s->N || (b & 0x7F000000u) || val > s->N) return SIM_EINVAL; break;
+    case SIM_OP_QRESP: if (!a || (b & 0xFFFFFFu) >= s->N || (b & 0x7F000000u)) return SIM_EINVAL; break;
     case SIM_OP_WITNESS: if (a > 2u) return SIM_EINVAL; break;
     case SIM_OP_USER_EVENT: if (!a) return SIM_EINVAL; if ((b & 0x7FFFFFFFu) > 9 * 1024) return SIM_ETOOBIG; break; /* bit 31: cc */
     case SIM_OP_QUERY: if (!a) return SIM_EINVAL; break;
@@ -2117,9 +2117,9 @@ static int parse_node(rdr d, uint32_t* id) {
   }
   return have && !d.bad;
 }
-static int deliver_one(osim* s, uint32_t node, const uint8_t* buf, size_t len, size_t* consumed, uint32_t via);
+static int deliver_one(osim* s, uint32_t node, const uint8_t* buf, size_t len, size_t* consumed, int relayed);
 /* QueryResponseMessage (types/query/response.rs: ltime 1, id 2, from 3, flags 4, payload 5) -> SIM_OP_QRESP at the origin */
-static int deliver_query_response(osim* s, uint32_t node, rdr body, uint32_t via) {
+static int deliver_query_response(osim* s, uint32_t node, rdr body) {
   uint64_t qid = 0, flags = 0;
   uint32_t from = 0, have_from = 0;
   while (body.off < body.n && !body.bad) {
@@ -2131,7 +2131,7 @@ static int deliver_query_response(osim* s, uint32_t node, rdr body, uint32_t via
     else return SIM_EINVAL;
   }
   if (body.bad || !have_from || from >= s->N || !qid || qid > 0xFFFFFFFFull) return SIM_EINVAL;
-  return inject_val(s, s->tick, SIM_OP_QRESP, node, (uint32_t)qid, from | ((flags & 1) ? 0x80000000u : 0u), via);
+  return inject_val(s, s->tick, SIM_OP_QRESP, node, (uint32_t)qid, from | ((flags & 1) ? 0x80000000u : 0u), 0);
 }
 /* PushPullMessage (types/push_pull.rs: ltime 1, status_ltimes 2 {id 1, ltime 2}, left_members 3, event_ltime 4, events 5
  * {ltime 1, events 2 {name 1, payload 2}}, query_ltime 6) -> what merge_remote_state (delegate.rs:427-554) does with it */
@@ -2231,23 +2231,33 @@ static int deliver_push_pull(osim* s, uint32_t node, rdr body) {
 int API(deliver_message)(osim* s, uint32_t node, const uint8_t* buf, size_t len, size_t* consumed) {
   return deliver_one(s, node, buf, len, consumed, 0);
 }
-static int deliver_one(osim* s, uint32_t node, const uint8_t* buf, size_t len, size_t* consumed, uint32_t via) {
+static int deliver_one(osim* s, uint32_t node, const uint8_t* buf, size_t len, size_t* consumed, int relayed) {
   if (!s || !buf || !len || node >= s->N) return SIM_EINVAL;
   rdr r = {buf, len, 0, 0};
   uint8_t tb = r.p[r.off++];
   if ((tb & 7) != 2) return SIM_EINVAL; /* the type byte is length-delimited */
   uint32_t tag = tb >> 3;
   if (tag == 8) { /* Relay (types/message.rs:431-470): NO length of its own — RELAY_NODE_BYTE <node>, RELAY_MSG_BYTE, then a framed message
-                   * to the end of the buffer.  `node` forwards it to the named node (delegate.rs:262-313) if it is running then */
+                   * to the end of the buffer.  `node` forwards the wrapped message to the named node as it is (delegate.rs:262-313:
+                   * memberlist.send) — if it is running; a process that is down forwards nothing */
     uint32_t dest = 0, have = 0;
-    if (via) return SIM_EINVAL; /* a relay inside a relay is not something serf sends */
+    if (relayed) return SIM_EINVAL; /* a relay inside a relay is not something serf sends */
     while (r.off < r.n && !r.bad) {
       uint8_t fb = r.p[r.off++];
       if (fb == ((1u << 3) | 2u)) { rdr d = rd_ld(&r); have = (uint32_t)parse_node(d, &dest); }
       else if (fb == ((2u << 3) | 2u)) {
-        if (!have || dest >= s->N || r.off >= r.n || (r.p[r.off] >> 3) != 6) return SIM_EINVAL; /* what relay_response wraps: a QueryResponse */
+        if (!have || dest >= s->N || r.off >= r.n) return SIM_EINVAL;
+        uint32_t in_tag = r.p[r.off] >> 3;
+        if (in_tag == 3 || in_tag == 8) return SIM_EINVAL; /* a push-pull does not travel as a user message; no nesting */
         size_t in_used = 0;
-        int rc = deliver_one(s, dest, r.p + r.off, r.n - r.off, &in_used, node + 1u);
+        int rc = SIM_OK;
+        if (up_of(s, node)) rc = deliver_one(s, dest, r.p + r.off, r.n - r.off, &in_used, 1);
+        else { /* dropped with its relay: still walk the inner frame so that the caller learns its length */
+          rdr in = {r.p + r.off, r.n - r.off, 1, 0};
+          (void)rd_ld(&in);
+          if (in.bad) return SIM_EINVAL;
+          in_used = in.off;
+        }
         if (rc == SIM_OK && consumed) *consumed = r.off + in_used;
         return rc;
       } else return SIM_EINVAL;
@@ -2257,12 +2267,15 @@ static int deliver_one(osim* s, uint32_t node, const uint8_t* buf, size_t len, s
   rdr body = rd_ld(&r);
   if (r.bad) return SIM_EINVAL;
   size_t used = r.off;
+  if (tag == 7) { /* ConflictResponse: notify_message has no arm for it ("receive unexpected message type", delegate.rs:286-288) */
+    if (consumed) *consumed = used;
+    return SIM_OK;
+  }
   if (tag == 6 || tag == 3) {
-    int rc = tag == 6 ? deliver_query_response(s, node, body, via) : deliver_push_pull(s, node, body);
+    int rc = tag == 6 ? deliver_query_response(s, node, body) : deliver_push_pull(s, node, body);
     if (rc == SIM_OK && consumed) *consumed = used;
     return rc;
   }
-  if (via) return SIM_EINVAL;
   uint64_t ltime = 0, flags = 0, qid = 0;
   uint32_t id = 0, have_id = 0, prune = 0, cc = 0, n_fid = 0, fids[SIM_QF_IDS];
   rdr name = {NULL, 0, 0, 0}, payload = {NULL, 0, 0, 0};

@@ -2285,10 +2285,10 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
     if (op == SIM_OP_SET_TAGS) TAGCLASS(d)[gid] = (uint8_t)ob.a[i];  // replicated like liveness: a table the host fills
     if (op == SIM_OP_QRESP) {  // handle_query_response (base.rs:1158-1204): an ack / a response that came in over the byte boundary.
       // Trackers and liveness are replicated; the responder's bit lives on the shard that owns the responder
-      const u32 j = ob.a[i] % SIM_QT, from = ob.b[i] & 0xFFFFFFu, which = (ob.b[i] >> 31) ? 0u : 1u, via = (u32)ob.val[i];
+      const u32 j = ob.a[i] % SIM_QT, from = ob.b[i] & 0xFFFFFFu, which = (ob.b[i] >> 31) ? 0u : 1u;
       const size_t words = ((size_t)d.N + 31) / 32;
       const uint4 t = d.qtab[j];
-      if (from >= d.shard0 && from < d.shard0 + d.Nl && up_of(d, gid) && t.x == ob.a[i] && t.y == gid && (u32)tick <= t.z && (!via || up_of(d, via - 1u)))
+      if (from >= d.shard0 && from < d.shard0 + d.Nl && up_of(d, gid) && t.x == ob.a[i] && t.y == gid && (u32)tick <= t.z)
         d.qbits[((size_t)j * 2 + which) * words + (from >> 5)] |= 1u << (from & 31);
       continue;
     }
@@ -4064,7 +4064,6 @@ static int inject_val(sim_handle* h, uint64_t tick, uint32_t op, uint32_t node, 
   if (tick < h->tick) tick = h->tick;
   if (op == SIM_OP_SUSPECT && (a & SREQ_RECONNECT)) { op = SIM_OP_RECONNECT; a &= ~SREQ_RECONNECT; }  // an entry of the request list, as it stands there
   int rc = op_validate(h->d.N, op, node, a, b);
-  if (rc == SIM_OK && op == SIM_OP_QRESP && val > h->d.N) rc = SIM_EINVAL;  // val = the relaying node + 1 (0: sent directly)
   if (rc) return rc;
   // an operation that executes now gets its view slot now (and SIM_ENOSLOT if there is none); one scheduled for a
   // later tick gets it when it executes — and is dropped and counted if none is free then (SIMSPEC §2.6)
@@ -4095,20 +4094,30 @@ int sim_user_event_bytes(sim_handle* h, uint32_t node, const uint8_t* name, size
   h->evreg.emplace(key, std::make_pair(nm, pl));  // the first content under a key stays
   return sim_user_event(h, node, key, (uint32_t)w::user_event_len(1, nm, pl, cc != 0), cc);
 }
-// `via`: 0, or 1 + the node that relays the message to `node` (a Relay's inner message)
-static int deliver_one(sim_handle* h, uint32_t node, const uint8_t* buf, size_t len, size_t* consumed, u32 via) {
+// `relayed`: the message is the inside of a Relay
+static int deliver_one(sim_handle* h, uint32_t node, const uint8_t* buf, size_t len, size_t* consumed, bool relayed) {
   if (!h || !buf || !len || node >= h->d.N) return SIM_EINVAL;
   namespace w = serf::wire;
   try {
     w::Bytes in(buf, buf + len);
     if (in[0] == w::merge(w::WIRE_LEN, w::RELAY)) {
-      // Relay (types/message.rs:431-470): `node` forwards the wrapped message to the node it names (delegate.rs:262-313) if it
-      // is running then; what relay_response wraps is a QueryResponse (query.rs:523-601) — nothing else is accepted inside
-      if (via) return SIM_EINVAL;
+      // Relay (types/message.rs:431-470): `node` forwards the wrapped message to the node it names as it is (delegate.rs:262-313:
+      // memberlist.send) — if it is running; a process that is down forwards nothing
+      if (relayed) return SIM_EINVAL;
       auto [dest, off] = w::unwrap_relay(in);
-      if (dest >= h->d.N || off >= len || (buf[off] >> 3) != w::QUERY_RESPONSE) return SIM_EINVAL;
+      if (dest >= h->d.N || off >= len) return SIM_EINVAL;
+      const u32 in_tag = buf[off] >> 3;
+      if (in_tag == w::PUSH_PULL || in_tag == w::RELAY) return SIM_EINVAL;  // a push-pull does not travel as a user message; no nesting
+      u32 word = 0;  // ground-truth liveness as of the end of the last tick (rare call: one word, one wait)
+      HCHECK(hipMemcpyAsync(&word, h->d.upmap + (node >> 5), 4, hipMemcpyDeviceToHost, h->stream));
+      HCHECK(hipStreamSynchronize(h->stream));
       size_t in_used = 0;
-      int rc = deliver_one(h, dest, buf + off, len - off, &in_used, node + 1u);
+      int rc = SIM_OK;
+      if ((word >> (node & 31)) & 1u) rc = deliver_one(h, dest, buf + off, len - off, &in_used, true);
+      else {  // dropped with its relay: the inner frame is still walked so that the caller learns its length
+        w::Bytes inner(buf + off, buf + len);
+        (void)w::unframe(inner, in_used);
+      }
       if (rc == SIM_OK && consumed) *consumed = off + in_used;
       return rc;
     }
@@ -4120,11 +4129,14 @@ static int deliver_one(sim_handle* h, uint32_t node, const uint8_t* buf, size_t 
     if (tag == w::QUERY_RESPONSE) {  // -> SIM_OP_QRESP at the origin
       w::QueryResponse m = w::decode_query_response(body);
       if (m.from_node >= h->d.N || !m.id) return SIM_EINVAL;
-      rc = inject_val(h, h->tick, SIM_OP_QRESP, node, m.id, m.from_node | ((m.flags & 1u) ? 0x80000000u : 0u), via);
+      rc = inject_val(h, h->tick, SIM_OP_QRESP, node, m.id, m.from_node | ((m.flags & 1u) ? 0x80000000u : 0u), 0);
       if (rc == SIM_OK && consumed) *consumed = used;
       return rc;
     }
-    if (via) return SIM_EINVAL;
+    if (tag == w::CONFLICT_RESPONSE) {  // notify_message has no arm for it ("receive unexpected message type", delegate.rs:286-288)
+      if (consumed) *consumed = used;
+      return SIM_OK;
+    }
     if (tag == w::PUSH_PULL) {  // what merge_remote_state (delegate.rs:427-554) does with it
       w::PushPull m = w::decode_push_pull(body);
       for (auto& st : m.status_ltimes)
@@ -4195,7 +4207,7 @@ static int deliver_one(sim_handle* h, uint32_t node, const uint8_t* buf, size_t 
   }
 }
 int sim_deliver_message(sim_handle* h, uint32_t node, const uint8_t* buf, size_t len, size_t* consumed) {
-  return deliver_one(h, node, buf, len, consumed, 0);
+  return deliver_one(h, node, buf, len, consumed, false);
 }
 int sim_join(sim_handle* h, uint32_t node, uint32_t peer) { return sim_inject(h, h ? h->tick : 0, SIM_OP_JOIN, node, peer, 0); }
 int sim_leave(sim_handle* h, uint32_t node) {

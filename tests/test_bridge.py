@@ -103,7 +103,7 @@ def test_malformed_and_unsupported_messages_are_refused(oracle):
     for bad in (b"", good[:-1], bytes([good[0] ^ 1]) + good[1:], wire.encode_message(wire.Join(3, 9999)),
                 wire.encode_message(wire.PushPull(4, {9999: 3})), wire.encode_message(wire.PushPull(4, {3: 3}, [70])),
                 wire.encode_message(wire.QueryResponse(3, 9, 64, 1)), wire.encode_message(wire.QueryResponse(3, 0, 5, 1)),
-                wire.encode_message(wire.Relay(64, qr)), wire.encode_message(wire.Relay(7, wire.Join(3, 5))),   # only a QueryResponse travels in a Relay
+                wire.encode_message(wire.Relay(64, qr)), wire.encode_message(wire.Relay(7, wire.PushPull(4))),   # a push-pull does not travel as a user message
                 wire.encode_message(wire.Relay(7, wire.Relay(8, qr))), wire.encode_message(wire.Relay(7, qr))[:-2]):
         if not bad:
             continue
@@ -176,6 +176,31 @@ def test_query_responses_and_relays_over_the_byte_boundary(oracle):
     sim.deliver_message(4, wire.encode_message(wire.QueryResponse(5, 77, 50, 0)))
     sim.step(1)
     assert sim.query_responders(77, 1) == before
+
+
+def test_a_relay_forwards_whatever_it_wraps(oracle):
+    # delegate.rs:262-313: the wrapped bytes go to the named node as they are (memberlist.send) — a user event handed to node 7
+    # for node 12 is a user event handed to node 12; a relay that is down forwards nothing; a ConflictResponse is ignored
+    n = 64
+    a, b, c = (_ffi.Sim(oracle, _ffi.make_config(n, **KW)) for _ in range(3))
+    ev = wire.UserEvent(5, b"deploy", b"v3", False)
+    direct, relayed = wire.encode_message(ev), wire.encode_message(wire.Relay(12, ev))
+    assert a.deliver_message(12, direct) == len(direct)
+    assert b.deliver_message(7, relayed + b"\x09") == len(relayed)
+    c.inject(0, _ffi.OP_CRASH, 7)
+    c.step(1)
+    a.step(1)
+    b.step(1)
+    assert c.deliver_message(7, relayed) == len(relayed)      # taken, and lost with its relay
+    conflict = bytes([wire.merge(wire.WIRE_LEN, wire.CONFLICT_RESPONSE), 2, 0x08, 0x01])
+    assert c.deliver_message(3, conflict + b"\x00") == len(conflict)
+    for t in range(12):
+        a.step(1)
+        b.step(1)
+        c.step(1)
+        assert a.digest() == b.digest(), f"tick {t}"
+    assert c.convergence(_ffi.K_EVENT, event_key(b"deploy", b"v3"), 5)[0] == 0
+    assert a.convergence(_ffi.K_EVENT, event_key(b"deploy", b"v3"), 5)[0] == n
 
 
 def push_pull_message():

@@ -172,6 +172,7 @@ def test_query_response_relay_and_push_pull_on_the_gpu(oracle, hiplib, view_slot
     # oracle beside it: the C++ decoder (serf_amd/host/wire.hpp) against the oracle's C one, SIM_OP_QRESP / SIM_OP_WITNESS /
     # the muted deliveries in ops_kernel against apply_op
     from tests.test_bridge import KW, deliver_query_traffic, push_pull_message
+    from tests.test_bridge import event_key as _ffi_event_key
 
     n = 64
     kw = dict(KW, view_slots=view_slots)
@@ -199,10 +200,22 @@ def test_query_response_relay_and_push_pull_on_the_gpu(oracle, hiplib, view_slot
         g.step(1)
         o.step(1)
         assert g.digest() == o.digest(), f"tick {t}"
+    # a relay forwards whatever it wraps; a relay that is down forwards nothing; a ConflictResponse is ignored
+    ev = wire.encode_message(wire.Relay(12, wire.UserEvent(5, b"deploy", b"v3", False)))
+    conflict = bytes([wire.merge(wire.WIRE_LEN, wire.CONFLICT_RESPONSE), 2, 0x08, 0x01])
+    for s in (g, o):
+        assert s.deliver_message(7, ev + b"\x09") == len(ev)
+        assert s.deliver_message(30, ev) == len(ev)          # node 30 is down
+        assert s.deliver_message(3, conflict) == len(conflict)
+    for t in range(12):
+        g.step(1)
+        o.step(1)
+        assert g.digest() == o.digest(), f"relayed event, tick {t}"
+    assert g.convergence(_ffi.K_EVENT, _ffi_event_key(b"deploy", b"v3"), 5) == o.convergence(_ffi.K_EVENT, _ffi_event_key(b"deploy", b"v3"), 5) == (n, n)
     # the same refusals
     qr = wire.QueryResponse(3, 9, 5, 1)
     for bad in (wire.encode_message(wire.PushPull(4, {9999: 3})), wire.encode_message(wire.QueryResponse(3, 9, 64, 1)),
-                wire.encode_message(wire.Relay(7, wire.Join(3, 5))), wire.encode_message(wire.Relay(7, wire.Relay(8, qr))),
+                wire.encode_message(wire.Relay(7, wire.PushPull(4))), wire.encode_message(wire.Relay(7, wire.Relay(8, qr))),
                 wire.encode_message(wire.Relay(7, qr))[:-2], wire.encode_message(wire.Relay(64, qr))):
         for s in (g, o):
             with pytest.raises(_ffi.SimError) as e:
