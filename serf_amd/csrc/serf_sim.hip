@@ -1612,6 +1612,9 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
       uint4* const p2 = lookup_ptr(co, vbase, eoff, qoff, k2, r2.x, (u64)r2.z | ((u64)r2.w << 32), s2);
       uint4* const p3 = lookup_ptr(co, vbase, eoff, qoff, k3, r3.x, (u64)r3.z | ((u64)r3.w << 32), s3);
       const uint4 e0 = ld4(p0 ? p0 : d.nullcell), e1 = ld4(p1 ? p1 : d.nullcell), e2 = ld4(p2 ? p2 : d.nullcell), e3 = ld4(p3 ? p3 : d.nullcell);
+      // all four heads are asked for before any of them is looked at: left to itself the scheduler sinks each load to its first
+      // use — to save registers — and the round makes three or four trips to memory, one after the other, instead of one
+      __builtin_amdgcn_sched_barrier(0);
       const uint4 na = nst[2 * o], nb = nst[2 * o + 1];
       Node no;
       no.eclock = (u64)na.x | ((u64)na.y << 32); no.qclock = (u64)na.z | ((u64)na.w << 32);

@@ -16,11 +16,13 @@ MASKS = [(0, "full tick"), (1, "phase 1 only (no queue phase)"), (2, "phase 2 on
          (4, "no scatter stores"), (8, "no payload gathers"), (16, "no row/key stores"), (4 | 8 | 16, "no scatter/gather/row stores"),
          (32, "no handler loop"), (64, "records loaded, no lookups, no handlers"), (1 | 64, "row + record loads only"), (1 | 2, "row load/store only")]
 ticks = (330, 333, 351)  # inside the benchmark's timed region (stationary load); probe phases differ per tick
-args = bench.parse_args(["--nodes-per-gpu", str(n)] + [a for a in sys.argv[2:] if not a.startswith("masks=")])  # e.g. --random-fanout
+args = bench.parse_args(["--nodes-per-gpu", str(n)] + [a for a in sys.argv[2:] if not a.startswith(("masks=", "ticks="))])  # e.g. --random-fanout
 for a in sys.argv[2:]:
     if a.startswith("masks="):
         want = {int(x, 0) for x in a[6:].split(",")}
-        MASKS = [m for m in MASKS if m[0] in want]
+        MASKS = [m for m in MASKS if m[0] in want] + [(m, f"mask {m}") for m in sorted(want - {m[0] for m in MASKS})]
+    if a.startswith("ticks="):   # (under rocprofv3 --pmc: one mask, one tick per process — the ablated launch is the last tick-kernel dispatch)
+        ticks = tuple(int(x) for x in a[6:].split(","))
 kw, ops = bench.workload(args, n)
 res = {}
 for mask, name in MASKS:
