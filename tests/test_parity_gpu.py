@@ -387,6 +387,34 @@ def test_long_soak_everything_on(oracle, hiplib):
     assert len(ev_g) > 100 and ev_g == ev_o  # the watched observers' event streams, in order
 
 
+def test_long_soak_everything_on_random_fanout(oracle, hiplib):
+    # the soak above on memberlist's literal kRandomNodes (the benchmark's headline model): the graph built two ticks ahead for
+    # 1 600 ticks, balanced classification, paged packets, gossip_to_the_dead, the Reconnector, a checkpoint in the middle
+    n = 1 << 14
+    kw = dict(fanout=4, view_slots=96, event_ring=48, query_ring=48, probe_interval=3, loss=0.02, pkt_records=8,
+              push_pull_interval=16, reap_interval=25, reconnect_timeout=300, tombstone_timeout=200, reconnect_interval=40,
+              queue_check_interval=40, max_queue_depth=12, intent_timeout=120, gossip_to_the_dead=30,
+              flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT)
+    g, o = pair(oracle, hiplib, n, **kw)
+    for w in (5, 4099, n - 1):
+        g.watch(w)
+        o.watch(w)
+    ops = sc.schedule(n, 1500, rate=0.35, seed=78, max_member_subjects=90)
+    sc.apply_schedule(g, ops)
+    sc.apply_schedule(o, ops)
+    for t in range(0, 1600, 100):
+        g.step(100)
+        o.step(100)
+        assert g.digest() == o.digest(), f"digest differs after tick {t + 100}"
+        if t == 700:   # the oracle's image into the HIP library: the run goes on from it (the graphs in flight are drawn again)
+            ev_g, ev_o = g.drain_events(), o.drain_events()
+            assert len(ev_g) > 50 and ev_g == ev_o
+            g.close()
+            g = _ffi.Sim(hiplib, _ffi.make_config(n, **kw))   # (an image goes into a fresh handle)
+            g.restore(o.snapshot())
+            assert g.digest() == o.digest()
+
+
 def test_config3_1m_bit_exact_digests(oracle, hiplib):
     # BASELINE config 3 size (1 Mi nodes, fan-out 4, SWIM layer on): digests of every array against the
     # CPU oracle over the first ticks of a busy schedule (what the oracle finishes in seconds)
