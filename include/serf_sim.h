@@ -29,7 +29,7 @@ extern "C" {
 
 /* ------------------------------------------------------------------ constants */
 
-#define SIM_ABI_VERSION 11u
+#define SIM_ABI_VERSION 12u
 
 #define SIM_P 4u  /* piggyback records per packet PAGE (48-byte cell: 4 records x 12 wire bytes) */
 #define SIM_PKT_BYTES 1400u /* byte budget of a gossip packet: memberlist's UDP payload limit (lan() and wan()); a packet
@@ -543,6 +543,17 @@ int sim_bind_exchange(sim_handle* h, void* send_dev, void* recv_dev);
  * sim_step_end  — and every exchange of tick t must have completed before sim_step_chunk of tick t + 1. */
 int sim_bind_exchange2(sim_handle* h, void* send_dev, void* recv0_dev, void* recv1_dev);
 int sim_exchange_chunks(const sim_handle* h, uint32_t* chunks, size_t* bytes_per_chunk);
+/* (r4) What the round's exchange of this handle IS.  SIM_XCHG_ALL_TO_ALL: the slabs above — one plane, receive buffer as big as
+ * the send buffer.  SIM_XCHG_ALL_GATHER (SIM_CF_RANDOM_FANOUT on a shard): memberlist's kRandomNodes sends a packet to ANY node
+ * of the cluster, so the packets stay in their senders' cells on a shard too — the send buffer is the shard's cells,
+ * `planes` planes of send_plane_bytes each ([plane][local sender]) — and the exchange gathers plane j of every shard, in rank
+ * order, into plane j of the receive buffer ([plane][global sender]: recv_bytes = shard count x the send buffer), from which
+ * every node pulls what the tick's graph addresses to it.  The host moves plane j with one all-gather of send_plane_bytes per
+ * rank (serf_amd/shard.py: all_gather_into_tensor; sim_exchange_chunk: ncclAllGather); both buffers are bound with
+ * sim_bind_exchange2 as before (recv0 / recv1 of recv_bytes each). */
+#define SIM_XCHG_ALL_TO_ALL 0u
+#define SIM_XCHG_ALL_GATHER 1u
+int sim_exchange_layout(const sim_handle* h, uint32_t* kind, uint32_t* planes, size_t* send_plane_bytes, size_t* recv_bytes);
 /* The round's all-to-all ISSUED BY THE LIBRARY over RCCL (grouped ncclSend / ncclRecv pairs over xGMI) — for a
  * host that has no collective library of its own (the north star's Rust host) and to take the per-chunk host cost out of the
  * tick: sim_exchange_chunk is one call, no tensor bookkeeping, and the ordering lives on streams, not in the host.

@@ -338,6 +338,10 @@ typedef struct sim_handle osim;
 /* one shard per process — or one handle run AS a shard (SIM_CF_FORCE_SHARDED: the one-rank rehearsal of the N > 1 path) */
 #define SHARDED(s) ((s)->cfg.shard_count > 1 || ((s)->cfg.flags & SIM_CF_FORCE_SHARDED))
 #define CFG_SHARDED(c) ((c)->shard_count > 1 || ((c)->flags & SIM_CF_FORCE_SHARDED))
+/* random fan-out on a shard (r4): the packets stay with their senders here too — the shard's cells, [slot * PG + page][local sender],
+ * are its SEND buffer; the round's exchange is an all-gather, plane by plane, into a receive buffer [slot * PG + page][global
+ * sender], from which every node pulls the packets the tick's graph says are addressed to it */
+#define RF_SH(s) ((s)->rfan && SHARDED(s))
 
 static inline uint32_t digits10(uint32_t n) { /* = ceil(log10(n+1)), App. B.1 retransmit limit */
   uint32_t d = 0;
@@ -1473,10 +1477,12 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
   if (up) {
     if (row->next_seq > 1023u - 64u) queue_renorm(row, q);
     if (s->tick > 0 && s->rfan) { /* variable in-degree: every packet addressed to this node, (sender, k) order */
-      for (uint32_t i = s->rcsr[l]; i < s->rcsr[l + 1]; ++i) { /* rsrc: k * Nl + sender */
-        uint32_t k = s->rsrc[i] / s->Nl, snd = s->rsrc[i] % s->Nl;
+      const uint32_t NS = RF_SH(s) ? s->N : s->Nl; /* senders a cell plane spans: the shard's own, or — gathered — everybody's */
+      const sim_packet* cells = RF_SH(s) ? s->xrecv : s->inbox[s->tick & 1];
+      for (uint32_t i = s->rcsr[l]; i < s->rcsr[l + 1]; ++i) { /* rsrc: k * NS + sender */
+        uint32_t k = s->rsrc[i] / NS, snd = s->rsrc[i] % NS;
         for (uint32_t pg = 0; pg < PG; ++pg) {
-          const sim_packet* pk = &s->inbox[s->tick & 1][((size_t)k * PG + pg) * s->Nl + snd];
+          const sim_packet* pk = &cells[((size_t)k * PG + pg) * NS + snd];
           for (uint32_t r = 0; r < SIM_P; ++r)
             if (pk_kind(pk, r) != SIM_K_EMPTY) { sim_record rec = pk_get(pk, r); dispatch_record(&c, &rec); }
         }
@@ -1504,7 +1510,8 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
     for (uint32_t k = 0; k < p->feff; ++k) {
       size_t cell = (size_t)k * s->Nl + l;
       if (((skipm >> k) & 1u) || (up && pkt_lost(p, c.gid, k))) memset(out[k], 0, sizeof out[k]);
-      for (uint32_t pg = 0; pg < PG; ++pg) s->inbox[(s->tick + 1) & 1][((size_t)k * PG + pg) * s->Nl + l] = out[k][pg];
+      sim_packet* dst = RF_SH(s) ? s->xsend : s->inbox[(s->tick + 1) & 1];
+      for (uint32_t pg = 0; pg < PG; ++pg) dst[((size_t)k * PG + pg) * s->Nl + l] = out[k][pg];
       s->rtgt[cell] = k < nc ? chosen[k] : NOSLOT;
     }
     return;
@@ -1627,6 +1634,28 @@ static void step_chunk(osim* s, uint32_t chunk) {
   }
 }
 /* random fan-out: group the cells by target — counting sort, senders ascending within a target, then slots */
+/* ... on a shard: the rows of the shard's nodes over the senders of the WHOLE cluster — every shard draws everybody's targets of
+ * tick `tick` (a function of seed, tick and node) and keeps the pairs that land in its range; entries k * N + sender */
+static void rf_group_sharded(osim* s, uint64_t tick, uint32_t feff) {
+  memset(s->rcsr, 0, ((size_t)s->Nl + 1) * sizeof(uint32_t));
+  uint32_t cap = s->f * s->Nl, n = 0;
+  uint32_t (*pairs)[2] = (uint32_t (*)[2])malloc(((size_t)s->f * s->N + 1) * sizeof *pairs); /* (target, cell), (sender, k) order */
+  for (uint32_t g = 0; g < s->N; ++g) {
+    uint32_t chosen[SIM_MAX_FANOUT], nc = rf_draw(s, tick, g, feff, chosen);
+    for (uint32_t k = 0; k < nc && k < feff; ++k)
+      if (chosen[k] >= s->shard0 && chosen[k] < s->shard0 + s->Nl) { pairs[n][0] = chosen[k] - s->shard0; pairs[n][1] = k * s->N + g; ++n; }
+  }
+  if (n > cap) { /* more packets for this shard than it has cells for rows: grow (uniform draws: the mean is f * Nl) */
+    s->rsrc = (uint32_t*)realloc(s->rsrc, (size_t)n * sizeof(uint32_t));
+  }
+  for (uint32_t i = 0; i < n; ++i) s->rcsr[pairs[i][0] + 1]++;
+  for (uint32_t l = 0; l < s->Nl; ++l) s->rcsr[l + 1] += s->rcsr[l];
+  uint32_t* fill = (uint32_t*)malloc((size_t)s->Nl * sizeof(uint32_t));
+  memcpy(fill, s->rcsr, (size_t)s->Nl * sizeof(uint32_t));
+  for (uint32_t i = 0; i < n; ++i) s->rsrc[fill[pairs[i][0]]++] = pairs[i][1];
+  free(fill);
+  free(pairs);
+}
 static void rf_group(osim* s) {
   memset(s->rcsr, 0, ((size_t)s->Nl + 1) * sizeof(uint32_t));
   size_t cells = (size_t)s->f * s->Nl;
@@ -1644,7 +1673,8 @@ static void rf_group(osim* s) {
 }
 static void step_end(osim* s) {
   const tickp p = s->cur;
-  if (s->rfan) rf_group(s);
+  if (RF_SH(s)) rf_group_sharded(s, s->tick, p.feff);
+  else if (s->rfan) rf_group(s);
   s->prev = p;
   s->tick++;
   s->in_tick = 0;
@@ -1750,7 +1780,7 @@ int API(create)(const sim_config* cfg, osim** out) {
   if (CFG_SHARDED(cfg)) {
     size_t cells = (size_t)s->fp * s->M;
     s->xsend = (sim_packet*)calloc(cells, sizeof(sim_packet));
-    s->xrecv = (sim_packet*)calloc(cells, sizeof(sim_packet));
+    s->xrecv = (sim_packet*)calloc((cfg->flags & SIM_CF_RANDOM_FANOUT) ? (size_t)s->fp * s->N : cells, sizeof(sim_packet));
     s->rbuf[0] = s->rbuf[1] = s->xrecv;
     s->own_x = 1;
   } else {
@@ -1784,7 +1814,7 @@ int API(create)(const sim_config* cfg, osim** out) {
   }
   s->rfan = (cfg->flags & SIM_CF_RANDOM_FANOUT) != 0;
   if (s->rfan) {
-    if (CFG_SHARDED(cfg) || cfg->vshards > 1) { API(destroy)(s); return SIM_EINVAL; }
+    if (cfg->chunks > 1) { API(destroy)(s); return SIM_EINVAL; }
     s->rtgt = (uint32_t*)malloc((size_t)s->f * Nl * sizeof(uint32_t));
     s->rcsr = (uint32_t*)calloc((size_t)Nl + 1, sizeof(uint32_t));
     s->rsrc = (uint32_t*)malloc((size_t)s->f * Nl * sizeof(uint32_t));
@@ -2358,8 +2388,8 @@ int API(peek_packet)(osim* s, uint32_t node, uint32_t k, uint8_t* buf, size_t ca
     uint32_t g = node / p->M, ll = node % p->M, h, lp;
     fan_target(p, g, ll, k, &h, &lp);
     for (uint32_t pg = 0; pg < s->PG; ++pg) {
-      const sim_packet* pk = SHARDED(s)
-          ? &s->xsend[xcell(p, s->fp, (ll % p->blk) / p->sub, h, k * s->PG + pg, lp)]
+      const sim_packet* pk = RF_SH(s) ? &s->xsend[((size_t)k * s->PG + pg) * s->Nl + (node - s->shard0)]
+          : SHARDED(s) ? &s->xsend[xcell(p, s->fp, (ll % p->blk) / p->sub, h, k * s->PG + pg, lp)]
           : s->rfan ? &s->inbox[s->tick & 1][((size_t)k * s->PG + pg) * s->Nl + (node - s->shard0)] /* random fan-out: the packets stay in their senders' cells */
           : &s->inbox[s->tick & 1][((size_t)k * s->PG + pg) * s->Nl + (size_t)h * p->M + lp];
       for (uint32_t r = 0; r < SIM_P; ++r) {
@@ -2548,6 +2578,7 @@ static uint64_t dig_words(const void* p, size_t n_words) {
   return acc;
 }
 static const sim_packet* cur_inbox(const osim* s) {
+  if (RF_SH(s)) return s->xsend; /* the packets in flight, canonical form: in their (local) senders' cells */
   return SHARDED(s) ? s->rbuf[(s->tick + 1) & 1] : s->inbox[s->tick & 1];
 }
 int API(state_digest)(osim* s, uint64_t out[8]) {
@@ -2696,7 +2727,8 @@ int API(restore)(osim* s, const void* buf, size_t bytes) {
     in += n;
   }
   if (s->tick > 0) tickp_make(&s->prev, &s->cfg, s->tick - 1); /* the parameters the packets in flight were sent with */
-  if (s->rfan && s->tick > 0) { /* the targets of the packets in flight: drawn again, grouped again */
+  if (RF_SH(s) && s->tick > 0) rf_group_sharded(s, s->tick - 1, s->prev.feff); /* (the host gathers the cells again: sim_exchange_layout) */
+  else if (s->rfan && s->tick > 0) { /* the targets of the packets in flight: drawn again, grouped again */
     for (uint32_t l = 0; l < s->Nl; ++l) {
       uint32_t chosen[SIM_MAX_FANOUT], nc = rf_draw(s, s->tick - 1, s->shard0 + l, s->prev.feff, chosen);
       for (uint32_t k = 0; k < s->f; ++k) s->rtgt[(size_t)k * s->Nl + l] = (k < s->prev.feff && k < nc) ? chosen[k] : NOSLOT;
@@ -2817,6 +2849,13 @@ int API(exchange_bytes)(const osim* s, size_t* bytes) {
   *bytes = SHARDED(s) ? (size_t)s->fp * s->M * sizeof(sim_packet) : 0;
   return SIM_OK;
 }
+int API(exchange_layout)(const osim* s, uint32_t* kind, uint32_t* planes, size_t* send_plane_bytes, size_t* recv_bytes) {
+  if (!s || !kind || !planes || !send_plane_bytes || !recv_bytes) return SIM_EINVAL;
+  size_t send = SHARDED(s) ? (size_t)s->fp * s->M * sizeof(sim_packet) : 0;
+  if (RF_SH(s)) { *kind = SIM_XCHG_ALL_GATHER; *planes = s->fp; *send_plane_bytes = (size_t)s->M * sizeof(sim_packet); *recv_bytes = send * s->V; }
+  else { *kind = SIM_XCHG_ALL_TO_ALL; *planes = 1; *send_plane_bytes = send; *recv_bytes = send; }
+  return SIM_OK;
+}
 int API(bind_exchange2)(osim* s, void* send, void* recv0, void* recv1) {
   if (!s || !SHARDED(s) || !send || !recv0 || !recv1) return SIM_EINVAL;
   if (s->own_x) { free(s->xsend); free(s->xrecv); s->own_x = 0; }
@@ -2824,9 +2863,10 @@ int API(bind_exchange2)(osim* s, void* send, void* recv0, void* recv1) {
   s->rbuf[0] = (sim_packet*)recv0;
   s->rbuf[1] = (sim_packet*)recv1;
   s->xrecv = s->rbuf[(s->tick + 1) & 1];
-  memset(send, 0, (size_t)s->fp * s->M * sizeof(sim_packet));
-  memset(recv0, 0, (size_t)s->fp * s->M * sizeof(sim_packet));
-  memset(recv1, 0, (size_t)s->fp * s->M * sizeof(sim_packet));
+  size_t nsend = (size_t)s->fp * s->M * sizeof(sim_packet), nrecv = RF_SH(s) ? nsend * s->V : nsend;
+  memset(send, 0, nsend);
+  memset(recv0, 0, nrecv);
+  memset(recv1, 0, nrecv);
   return SIM_OK;
 }
 int API(bind_exchange)(osim* s, void* send, void* recv) { return API(bind_exchange2)(s, send, recv, recv); }

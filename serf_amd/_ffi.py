@@ -36,6 +36,7 @@ ARR_ROWS, ARR_QUEUE, ARR_INBOX, ARR_VIEW, ARR_ERING, ARR_QRING, ARR_SLOTMAP = ra
 # enum sim_swim_state (memberlist node state)
 SWIM_ALIVE, SWIM_SUSPECT, SWIM_DEAD, SWIM_LEFT = 0, 1, 2, 3
 CF_BASELINE_JOINED, CF_RANDOM_FANOUT, CF_AWARENESS_PROBE, CF_JOIN_SYNC, CF_TCP_FALLBACK, CF_NACKS, CF_FORCE_SHARDED = 1, 2, 4, 8, 16, 32, 64
+XCHG_ALL_TO_ALL, XCHG_ALL_GATHER = 0, 1
 EXCHANGE_ID_BYTES = 128
 F_NO_BROADCAST, F_ACK, F_RESPOND = 1, 2, 4
 
@@ -102,7 +103,7 @@ ABI_SYMBOLS = ("create", "destroy", "set_stream", "join", "leave", "force_leave"
                "query", "inject", "step", "sync", "tick", "members", "stats_get", "watch",
                "drain_events", "state_digest", "dump_state", "convergence", "convergence_many", "exchange_bytes",
                "bind_exchange", "snapshot", "restore", "query_status", "query_responders", "profile", "profile_read", "profile_read_stats", "cluster_stats_get",
-               "bind_exchange2", "exchange_chunks", "step_begin", "step_chunk", "step_end",
+               "bind_exchange2", "exchange_chunks", "exchange_layout", "step_begin", "step_chunk", "step_end",
                "recycle_due", "recycle_scan", "recycle_apply", "pp_due", "pp_plan", "pp_export", "pp_merge",
                "query_filtered", "set_tags", "init_tags", "inject_record", "deliver_message", "user_event_bytes", "peek_packet", "suspect_requests", "suspect_export", "suspect_import",
                "exchange_unique_id", "exchange_init", "exchange_chunk", "exchange_wait", "exchange_library",
@@ -181,6 +182,7 @@ class SimLib:
             "bind_exchange": (C.c_int, [H, vp, vp]),
             "bind_exchange2": (C.c_int, [H, vp, vp, vp]),
             "exchange_chunks": (C.c_int, [H, C.POINTER(u32), C.POINTER(C.c_size_t)]),
+            "exchange_layout": (C.c_int, [H, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
             "step_begin": (C.c_int, [H]),
             "step_chunk": (C.c_int, [H, u32]),
             "step_end": (C.c_int, [H]),
@@ -466,6 +468,13 @@ class Sim:
         c, n = C.c_uint32(), C.c_size_t()
         self._ck(self.lib.f["exchange_chunks"](self.h, C.byref(c), C.byref(n)), "sim_exchange_chunks")
         return c.value, n.value
+
+    def exchange_layout(self):
+        """(kind, planes, bytes of one plane of the send buffer, bytes of the receive buffer) — XCHG_ALL_TO_ALL: the slabs of the
+        bijection; XCHG_ALL_GATHER: the random fan-out on a shard (plane j of every shard gathered into plane j of the receiver)."""
+        k, p, a, b = C.c_uint32(), C.c_uint32(), C.c_size_t(), C.c_size_t()
+        self._ck(self.lib.f["exchange_layout"](self.h, C.byref(k), C.byref(p), C.byref(a), C.byref(b)), "sim_exchange_layout")
+        return k.value, p.value, a.value, b.value
 
     def pp_due(self):
         return self._ck(self.lib.f["pp_due"](self.h), "sim_pp_due") > 0

@@ -299,8 +299,13 @@ struct Dev {
   // sending tick).  The packets stay with their senders as in the bijection's local mode, in 64-byte cells (RF_CELL_U4) whose
   // cell 0 carries the sender's map word in its fourth quarter — no omap array in this mode.
   u32* rcsr;       // [Nl + 1]
-  u32* rsrc;       // [f * Nl]
-  u32 rfan;        // the mode is on (local mode)
+  u32* rsrc;       // [f * Nl] (a shard: the packets for its nodes — f * Nl on average, room for more)
+  u32 rfan;        // the mode is on
+  // where a receiver finds the cells, and how many senders a plane of cells spans: the handle's own cells of the tick before
+  // (obox[cur], Nl senders) — or, on a shard, the receive buffer the cells of EVERY shard were gathered into (N senders: the
+  // entries of rsrc then carry global sender ids).  Set per tick by the host.
+  const uint4* rfrd;
+  u32 NC;
   u32* sreq;        // [1 + 2 * SIM_SUSPECT_REQ_MAX]: count, then the (prober, target) pairs of the running tick's slot-less
                     // failed probes (one of three buffers, by tick mod 3: the host reads a tick's list one tick later)
   u32* sreq_next;   // the count word of the NEXT tick's buffer: zeroed by this tick's kernel (no memset between two ticks)
@@ -1468,8 +1473,8 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   if (RF) { rin0 = d.rcsr[l]; rcnt = d.rcsr[l + 1] - rin0; }
   auto cell_of = [&](u32 k, u32 pg) __attribute__((always_inline)) -> const uint4* {
     if (RF) {  // first page: the sender's cell 0, asked for before its map word is known; further pages: where the map said
-      if (!MP || pg == 0) return rf_e == NOSLOT ? d.nullcell : d.obox[cur] + (size_t)(rf_e >> 2) * RF_CELL_U4;
-      return (rf_jb == 0xFFu || pg > (rf_jb & 3u)) ? d.nullcell : d.obox[cur] + ((size_t)((rf_jb >> 2) + pg) * d.Nl + rf_snd) * RF_CELL_U4;
+      if (!MP || pg == 0) return rf_e == NOSLOT ? d.nullcell : d.rfrd + (size_t)(rf_e >> 2) * RF_CELL_U4;
+      return (rf_jb == 0xFFu || pg > (rf_jb & 3u)) ? d.nullcell : d.rfrd + ((size_t)((rf_jb >> 2) + pg) * d.NC + rf_snd) * RF_CELL_U4;
     }
     if (SHARDED) {  // [sender chunk][source shard][slot * PG + page][sub] (oracle xcell)
       u32 b = l / tp.blk, w = l - b * tp.blk, sl = w / tp.sub;
@@ -1574,7 +1579,7 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
     const u32 l0 = l - tid, g0 = gid - tid;
     const u64 lt_mask = (1ull << tid) - 1ull;
     u32 ea = tid < rb_T ? d.rsrc[rb_base + tid] : NOSLOT, eb = 64u + tid < rb_T ? d.rsrc[rb_base + 64u + tid] : NOSLOT;
-    const uint4* cp = ea == NOSLOT ? d.nullcell : d.obox[cur] + (size_t)(ea >> 2) * RF_CELL_U4;
+    const uint4* cp = ea == NOSLOT ? d.nullcell : d.rfrd + (size_t)(ea >> 2) * RF_CELL_U4;
     uint4 a0 = ld4(cp), a1 = ld4(cp + 1), a2 = ld4(cp + 2);
     u32 am = reinterpret_cast<const u32*>(cp)[12];
 #pragma unroll 1
@@ -1586,14 +1591,14 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
       if (jb == 0xFFu) ck = cl = ch = zero;
       const bool far = jb != 0xFFu && (jb >> 2) != 0u;  // not the sender's cell 0 (1 % of the packets)
       if (__any(far)) {
-        const uint4* c2 = far ? d.obox[cur] + ((size_t)(jb >> 2) * d.Nl + (e >> 2)) * RF_CELL_U4 : d.nullcell;
+        const uint4* c2 = far ? d.rfrd + ((size_t)(jb >> 2) * d.NC + (e >> 2)) * RF_CELL_U4 : d.nullcell;
         const uint4 b0 = ld4(c2), b1 = ld4(c2 + 1), b2 = ld4(c2 + 2);
         if (far) { ck = b0; cl = b1; ch = b2; }
       }
       // the next round's cell is asked for behind this round's slot-map loads, the entry of the round after it right away
       ea = eb;
       eb = c0 + 128u + tid < rb_T ? d.rsrc[rb_base + c0 + 128u + tid] : NOSLOT;
-      cp = ea == NOSLOT ? d.nullcell : d.obox[cur] + (size_t)(ea >> 2) * RF_CELL_U4;
+      cp = ea == NOSLOT ? d.nullcell : d.rfrd + (size_t)(ea >> 2) * RF_CELL_U4;
       auto prefetch = [&]() __attribute__((always_inline)) { a0 = ld4(cp); a1 = ld4(cp + 1); a2 = ld4(cp + 2); am = reinterpret_cast<const u32*>(cp)[12]; };
       if (!__any(((ch.x | ch.y | ch.z | ch.w) & 0xF0u) != 0)) {  // nothing in any of the round's packets
         prefetch();
@@ -1676,12 +1681,12 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
       // beyond a node's sixteenth): entry -> cell -> slot map, on the spot
       auto reload = [&](u32 k, u32 q, uint4& r, uint4*& ptr) __attribute__((always_inline)) {
         const u32 ent = d.rsrc[rin0 + k], snd = ent >> 2;
-        const u32 mp = reinterpret_cast<const u32*>(d.obox[cur] + (size_t)snd * RF_CELL_U4)[12];
+        const u32 mp = reinterpret_cast<const u32*>(d.rfrd + (size_t)snd * RF_CELL_U4)[12];
         const u32 jb = (mp >> (8u * (ent & 3u))) & 0xFFu;
         r = make_uint4(0, 0, 0, 0);
         ptr = nullptr;
         if (jb != 0xFFu) {
-          const u32* cw = reinterpret_cast<const u32*>(d.obox[cur] + ((size_t)(jb >> 2) * d.Nl + snd) * RF_CELL_U4);
+          const u32* cw = reinterpret_cast<const u32*>(d.rfrd + ((size_t)(jb >> 2) * d.NC + snd) * RF_CELL_U4);
           r = wire_unpack(cw[q], cw[4u + q], cw[8u + q]);
           const u32 kind = SIM_META_KIND(r.y);
           ptr = lookup_ptr(c, vbase, eoff, qoff, kind, r.x, (u64)r.z | ((u64)r.w << 32), slot_load(d, kind, r.x));
@@ -1746,7 +1751,7 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
             if (rf_jb == 0xFFu) rn = rn1 = rn2 = zero;
             const bool far = rf_jb != 0xFFu && (rf_jb >> 2) != 0u;
             if (__any(far)) {
-              const uint4* c2 = far ? d.obox[cur] + ((size_t)(rf_jb >> 2) * d.Nl + rf_snd) * RF_CELL_U4 : d.nullcell;
+              const uint4* c2 = far ? d.rfrd + ((size_t)(rf_jb >> 2) * d.NC + rf_snd) * RF_CELL_U4 : d.nullcell;
               const uint4 a0 = ld4(c2), a1 = ld4(c2 + 1), a2 = ld4(c2 + 2);
               if (far) { rn = a0; rn1 = a1; rn2 = a2; }
             }
@@ -2460,6 +2465,9 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
 struct RfP {
   u64 rb;       // rng_base(seed, STREAM_RFAN, tick)
   u32 N, Nl, shard0, feff, f;
+  u32 Ns;       // senders whose targets are drawn: Nl — or, on a shard, all N (every shard draws the whole cluster's targets and
+                // keeps the pairs that land on its own nodes [shard0, shard0 + Nl); pair ids p = 4 * sender + slot are global then)
+  u32 rcap;     // entries rsrc holds
   u32 LB, NB;   // level-1 buckets: NB = ceil(Nl / 2^LB) ranges of 2^LB consecutive (local) targets
   u32 PB;       // bits of a pair id p = 4 l + k; a scattered entry is (target - bucket start) << PB | p — 32 bits when they fit
   u32 NWG;      // workgroups of rf_scatter (RfSpw senders each)
@@ -2509,11 +2517,13 @@ __global__ __launch_bounds__(RFB) void rf_scatter_kernel(RfP r, u32* gcur, E* l1
   u32 tg[SPW / RFB][SIM_MAX_FANOUT], nc[SPW / RFB];
 #pragma unroll
   for (u32 j = 0; j < SPW / RFB; ++j) {
-    const u32 l = l0 + j * RFB + threadIdx.x;
-    nc[j] = l < r.Nl ? rf_draw(r.rb, r.shard0 + l, r.N, r.feff, tg[j]) : 0u;
+    const u32 l = l0 + j * RFB + threadIdx.x;  // the sender (its global id: a handle that is not a shard has shard0 == 0)
+    nc[j] = l < r.Ns ? rf_draw(r.rb, l, r.N, r.feff, tg[j]) : 0u;
 #pragma unroll
-    for (u32 k = 0; k < SIM_MAX_FANOUT; ++k)
-      if (k < nc[j]) atomicAdd(&cnt[(tg[j][k] - r.shard0) >> r.LB], 1u);
+    for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) {
+      if (k < nc[j] && tg[j][k] - r.shard0 >= r.Nl) tg[j][k] = NOSLOT;  // another shard's node
+      if (k < nc[j] && tg[j][k] != NOSLOT) atomicAdd(&cnt[(tg[j][k] - r.shard0) >> r.LB], 1u);
+    }
   }
   __syncthreads();
   {  // exclusive prefix of the counts (every thread a stretch of buckets), and the workgroup's share of every region
@@ -2538,7 +2548,7 @@ __global__ __launch_bounds__(RFB) void rf_scatter_kernel(RfP r, u32* gcur, E* l1
     const u32 l = l0 + j * RFB + threadIdx.x;
 #pragma unroll
     for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) {
-      if (k < nc[j]) {  // (a slot without a target — fewer other nodes than the fan-out — is in nobody's row)
+      if (k < nc[j] && tg[j][k] != NOSLOT) {  // (a slot without a target — fewer other nodes than the fan-out — is in nobody's row)
         const u32 t = tg[j][k] - r.shard0, b = t >> r.LB, at = lst[b] + atomicAdd(&cur[b], 1u);
         stage[at] = ((E)(t - (b << r.LB)) << r.PB) | (E)(4u * l + k);
         stb[at] = (uint16_t)b;
@@ -2649,7 +2659,8 @@ __global__ __launch_bounds__(RFR) void rf_rows_kernel(RfP r, u32* gcur, u32* gcu
     for (u32 j = 0; j < RF_EPT; ++j)
       if (pv[j] != NOSLOT) rowp[tv[j]] = pv[j];
     __syncthreads();
-    for (u32 i = threadIdx.x; i < n; i += RFR) rsrc[base + i] = rowp[i];
+    for (u32 i = threadIdx.x; i < n; i += RFR)
+      if (base + i < r.rcap) rsrc[base + i] = rowp[i];  // (a shard: more packets than rsrc has room for — mean + 12 sigma — cannot happen)
   } else {  // the bucket does not fit the tables: rank every pair against the whole bucket, straight from global memory
     for (u32 i = threadIdx.x; i < n; i += RFR) {
       const E e = entry(i);
@@ -2658,7 +2669,8 @@ __global__ __launch_bounds__(RFR) void rf_rows_kernel(RfP r, u32* gcur, u32* gcu
         const E q = entry(j);
         rank += ((q >> r.PB) == (e >> r.PB) && (q & pmask) < (e & pmask)) ? 1u : 0u;
       }
-      rsrc[base + cnt[(u32)(e >> r.PB)] + rank] = (u32)(e & pmask);
+      const u32 at = base + cnt[(u32)(e >> r.PB)] + rank;
+      if (at < r.rcap) rsrc[at] = (u32)(e & pmask);
     }
   }
 }
@@ -3568,7 +3580,7 @@ static int cfg_check(const sim_config* c) {
   if (c->fanout < 1 || c->fanout > SIM_MAX_FANOUT) return SIM_EINVAL;
   if (c->chunks > 1 && ((M / c->vshards) % c->chunks || (M / c->vshards) / c->chunks < 1)) return SIM_EINVAL;
   // memberlist's literal kRandomNodes (variable in-degree, an explicit CSR per tick): one shard, one chunk
-  if ((c->flags & SIM_CF_RANDOM_FANOUT) && (c->vshards != 1 || c->shard_count != 1 || (c->flags & SIM_CF_FORCE_SHARDED) || c->chunks > 1 || c->n_nodes > (1u << 23))) return SIM_EINVAL;
+  if ((c->flags & SIM_CF_RANDOM_FANOUT) && (c->chunks > 1 || c->n_nodes > (1u << 23))) return SIM_EINVAL;  // (shards: r4 — sim_exchange_layout)
   if (c->event_ring < 1 || c->query_ring < 1) return SIM_EINVAL;
   if (c->pkt_records && (c->pkt_records % SIM_P || c->pkt_records > SIM_PKT_RECORDS_MAX)) return SIM_EINVAL;
   if (c->retransmit_mult * h_digits10(c->n_nodes) > 63u) return SIM_EINVAL;
@@ -3738,6 +3750,9 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
     DA(d.obox[0], (size_t)d.fp * Nl * cu4) DA(d.obox[1], (size_t)d.fp * Nl * cu4)
     if (!d.rfan) { DA(d.omap[0], Nl) DA(d.omap[1], Nl) }
     DA(h->inbox_mat, (size_t)d.fp * Nl * PK_U4)
+  } else if (d.rfan) {  // a shard with the random fan-out: its cells ARE the send buffer the host binds (sim_bind_exchange2)
+    d.obox[0] = d.obox[1] = nullptr;
+    DA(h->inbox_mat, (size_t)d.fp * Nl * PK_U4)
   }
   DA(d.view, (size_t)d.A * Nl * 2)
   DA(d.ering, (size_t)d.Bev * Nl * 2)
@@ -3757,20 +3772,23 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   h->rf_gcur[0] = h->rf_gcur[1] = nullptr; h->rf_ovf[0] = h->rf_ovf[1] = h->rf_l1 = nullptr; h->rf_par = 0; h->rf_wide = false;
   memset(&h->rfp, 0, sizeof h->rfp);
   if (d.rfan) {  // the fan-out graph as a CSR, rebuilt every tick, and the packets pushed into it (SIM_CF_RANDOM_FANOUT)
-    const size_t np = (size_t)d.f * Nl;
     RfP& r = h->rfp;
     r.N = d.N; r.Nl = d.Nl; r.shard0 = d.shard0; r.f = d.f;
+    r.Ns = d.sharded ? d.N : d.Nl;
+    // the packets for this handle's nodes: exactly f * Nl of them at most — on a shard f * Nl on average (room: 12 sigma and some)
+    const size_t np = (size_t)d.f * Nl + (d.sharded ? (size_t)(12.0 * std::sqrt((double)d.f * Nl)) + 4096u : 0u);
+    r.rcap = (u32)np;
     // level-1 buckets of 2^LB targets.  A scattered entry carries the pair id (PB bits) and the target's offset in its bucket
     // (LB bits) — rf_rows does not draw again —; 32-bit entries when both fit (1 Mi nodes: 22 + 10), 64-bit ones otherwise
     r.PB = 1;
-    while ((1ull << r.PB) < 4ull * Nl) r.PB++;
+    while ((1ull << r.PB) < 4ull * r.Ns) r.PB++;
     r.LB = std::min<u32>(11u, 32u - std::min<u32>(r.PB, 24u));
     if (const char* e = getenv("SERF_RF_LB")) r.LB = std::min<u32>(RF_LB_MAX, std::max<u32>(8u, (u32)strtoul(e, nullptr, 0)));
     while (((size_t)Nl + (1u << r.LB) - 1u) >> r.LB > 4096u) r.LB++;  // rf_scatter's three tables: 48 KiB of LDS next to its staging area
     if (r.LB > RF_LB_MAX) { sim_destroy(h); return SIM_EINVAL; }
     h->rf_wide = r.PB + r.LB > 32u || getenv("SERF_RF_WIDE") != nullptr;
     r.NB = (u32)(((size_t)Nl + (1u << r.LB) - 1u) >> r.LB);
-    r.NWG = (u32)(((size_t)Nl + (h->rf_wide ? RfSpw<u64>::v : RfSpw<u32>::v) - 1u) / (h->rf_wide ? RfSpw<u64>::v : RfSpw<u32>::v));
+    r.NWG = (u32)(((size_t)r.Ns + (h->rf_wide ? RfSpw<u64>::v : RfSpw<u32>::v) - 1u) / (h->rf_wide ? RfSpw<u64>::v : RfSpw<u32>::v));
     r.cap = std::min<u32>(6u << r.LB, RF_EPT * RFR);  // mean 4 * 2^LB pairs, sigma 2 * 2^(LB/2): 32 sigma and more of room
     if (const char* e = getenv("SERF_RF_CAP")) r.cap = std::max<u32>(RFR, std::min<u32>(r.cap, (u32)strtoul(e, nullptr, 0)) / RFR * RFR);  // tests: force rf_rows' slow path
     // a bucket's region of l1: f pairs per row it can have at most when the shard is one bucket, else the mean and 12 sigma
@@ -3825,7 +3843,7 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
     HCHECK(zero(d.obox[0], (size_t)d.fp * Nl * sizeof(sim_packet))); HCHECK(zero(d.obox[1], (size_t)d.fp * Nl * sizeof(sim_packet)));
     HCHECK(hipMemsetAsync(d.omap[0], 0xFF, Nl * 4, s)); HCHECK(hipMemsetAsync(d.omap[1], 0xFF, Nl * 4, s));
   }
-  if (d.rfan) {  // (all 0xFF: every map word says "nothing sent")
+  if (d.rfan && !d.sharded) {  // (all 0xFF: every map word says "nothing sent"; a shard's cells: sim_bind_exchange2)
     HCHECK(hipMemsetAsync(d.obox[0], 0xFF, (size_t)d.fp * Nl * RF_CELL_U4 * 16, s)); HCHECK(hipMemsetAsync(d.obox[1], 0xFF, (size_t)d.fp * Nl * RF_CELL_U4 * 16, s));
   }
   HCHECK(zero(d.view, (size_t)d.A * Nl * 32));
@@ -4522,6 +4540,9 @@ int sim_step_begin(sim_handle* h) {
     }
     d.rcsr = h->rf_rcsr[(h->tick + 2) % 3];  // (tick 0: a buffer of zeros — nothing has been sent)
     d.rsrc = h->rf_rsrc[(h->tick + 2) % 3];
+    // ... and the cells those packets sit in: this handle's own of the tick before, or what the shards' exchange gathered
+    d.rfrd = d.sharded ? h->rbuf[(h->tick + 1) & 1] : d.obox[h->tick & 1];
+    d.NC = d.sharded ? d.N : d.Nl;
     if (!h->rf_sync) {
       bool waited = false;
       for (u64 s = h->tick; s <= h->tick + 1; ++s) {
@@ -4598,7 +4619,8 @@ static int tick_launch(sim_handle* h, u32 chunk) {
     } else if (tp.B == 64u) LAUNCH_TICK(false, FF, true);                                                                \
     else LAUNCH_TICK(false, FF, false);                                                                                  \
   } while (0)
-  switch (tp.feff + (d.sharded ? 4u : 0u)) {  // one instantiation per fan-out: the drain loop is fully unrolled
+  switch (tp.feff + ((d.sharded && !d.rfan) ? 4u : 0u)) {  // one instantiation per fan-out: the drain loop is fully unrolled
+    // (the random fan-out on a shard runs the local instantiation: its packets stay in its cells, the exchange gathers them)
     case 0: case 1: LAUNCH_LOCAL(1); break;
     case 2: LAUNCH_LOCAL(2); break;
     case 3: LAUNCH_LOCAL(3); break;
@@ -4794,7 +4816,7 @@ int sim_drain_events(sim_handle* h, sim_event* out, uint32_t cap, uint32_t* n) {
 // The packets in flight, receiver-indexed ([f][Nl] cells).  Sharded: the receive buffer.  Local mode: Dev::obox turned
 // inside out on h->stream (every user launches on that stream afterwards); the map is the one of the tick they were sent in.
 static const uint4* cur_inbox(sim_handle* h) {
-  if (h->d.sharded) return h->rbuf[(h->tick + 1) & 1];
+  if (h->d.sharded && !h->d.rfan) return h->rbuf[(h->tick + 1) & 1];
   if (h->mat_tick != h->tick) {
     const Dev& d = h->d;
     TickP p;
@@ -4913,10 +4935,10 @@ int sim_peek_packet(sim_handle* h, uint32_t node, uint32_t k, uint8_t* buf, size
     u32 g = node / p.M, ll = node - g * p.M, hh, lp;
     fan_target_g(p, g, ll, k, hh, lp);
     std::vector<sim_packet> pages(d.PG);
-    const uint4* src = d.sharded ? d.xsend : cur_inbox(h);
+    const uint4* src = (d.sharded && !d.rfan) ? d.xsend : cur_inbox(h);
     for (u32 pg = 0; pg < d.PG; ++pg) {
-      size_t cell = d.sharded ? ((((size_t)((ll % p.blk) / p.sub) * p.V + hh) * d.fp + (size_t)k * d.PG + pg) * p.sub + lp % p.sub)
-                    : d.rfan  ? (((size_t)k * d.PG + pg) * d.Nl + node)  // random fan-out: the canonical inbox is sender-indexed
+      size_t cell = d.rfan    ? (((size_t)k * d.PG + pg) * d.Nl + (node - d.shard0))  // random fan-out: the canonical inbox is sender-indexed
+                    : d.sharded ? ((((size_t)((ll % p.blk) / p.sub) * p.V + hh) * d.fp + (size_t)k * d.PG + pg) * p.sub + lp % p.sub)
                               : (((size_t)k * d.PG + pg) * d.Nl + (size_t)hh * p.M + lp);
       HCHECK(hipMemcpyAsync(&pages[pg], src + cell * PK_U4, sizeof(sim_packet), hipMemcpyDeviceToHost, h->stream));
     }
@@ -5088,8 +5110,8 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
       in += n;
     }
   }
-  uint4* inbox_dst = d.sharded ? h->rbuf[(hd.tick + 1) & 1] : h->inbox_mat;
-  if (len[2] && !inbox_dst) return SIM_ESTATE;  // sharded: bind the exchange buffers first
+  uint4* inbox_dst = (d.sharded && !d.rfan) ? h->rbuf[(hd.tick + 1) & 1] : h->inbox_mat;
+  if ((len[2] && !inbox_dst) || (d.sharded && d.rfan && !h->bound)) return SIM_ESTATE;  // sharded: bind the exchange buffers first
   {  // slot maps must be consistent with n_slots (they index the view) and with each other (the recycling scan and
      // ensure_slot go from a slot to its subject and back)
     const u32* so = (const u32*)sec[6];
@@ -5132,7 +5154,7 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
     if (rc == SIM_OK) {
       restore_queue_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, (const uint4*)tmp_queue);
       restore_rows_kernel<<<grid_for(d.Nl), BLOCK, 0, s>>>(d, (const u64*)tmp_rows);
-      if (!d.sharded) {  // the packets in flight go back to their senders (one cell per slot)
+      if (!d.sharded || d.rfan) {  // the packets in flight go back to their senders (one cell per slot)
         TickP p;
         tickp_make(&p, &h->cfg, hd.tick ? hd.tick - 1 : 0);
         // (random fan-out: back to their places in their targets' rows — the graph of the tick they were sent in is a
@@ -5149,7 +5171,7 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
   if (tmp_queue) (void)hipFree(tmp_queue);
   if (rc != SIM_OK) return rc;
   h->tick = hd.tick;
-  h->mat_tick = d.sharded ? ~0ull : hd.tick;  // the image's inbox section is what sits in inbox_mat
+  h->mat_tick = (d.sharded && !d.rfan) ? ~0ull : hd.tick;  // the image's inbox section is what sits in inbox_mat
   h->n_slots = hd.n_slots;
   if (hd.tick > 0) tickp_make(&h->prev, &h->cfg, hd.tick - 1);  // the parameters the packets in flight were sent with
   memcpy(h->slot_of.data(), sec[6], len[6]);
@@ -5282,9 +5304,25 @@ int sim_cluster_stats_get(sim_handle* h, sim_cluster_stats* out) {
   out->events_lost = h->events_lost + (evc > d.ev_cap ? evc - d.ev_cap : 0);
   return SIM_OK;
 }
+// bytes of the handle's send buffer: the slabs [C][V dst][fp][M / V / C] of 48-byte packets — or, random fan-out on a shard, the
+// shard's own 64-byte cells [fp planes][M senders] (the packets stay with their senders: sim_exchange_layout)
+static size_t xsend_bytes(const sim_handle* h) {
+  const Dev& d = h->d;
+  if (!d.sharded) return 0;
+  return d.rfan ? (size_t)d.fp * d.M * RF_CELL_U4 * 16 : (size_t)d.fp * d.M * sizeof(sim_packet);
+}
+static size_t xrecv_bytes(const sim_handle* h) { return (h->d.sharded && h->d.rfan) ? xsend_bytes(h) * h->d.V : xsend_bytes(h); }
 int sim_exchange_bytes(const sim_handle* h, size_t* bytes) {
   if (!h || !bytes) return SIM_EINVAL;
-  *bytes = h->d.sharded ? (size_t)h->d.fp * h->d.M * sizeof(sim_packet) : 0;
+  *bytes = xsend_bytes(h);
+  return SIM_OK;
+}
+int sim_exchange_layout(const sim_handle* h, uint32_t* kind, uint32_t* planes, size_t* send_plane_bytes, size_t* recv_bytes) {
+  if (!h || !kind || !planes || !send_plane_bytes || !recv_bytes) return SIM_EINVAL;
+  const Dev& d = h->d;
+  if (d.sharded && d.rfan) { *kind = SIM_XCHG_ALL_GATHER; *planes = d.fp; *send_plane_bytes = (size_t)d.M * RF_CELL_U4 * 16; }
+  else { *kind = SIM_XCHG_ALL_TO_ALL; *planes = 1; *send_plane_bytes = xsend_bytes(h); }
+  *recv_bytes = xrecv_bytes(h);
   return SIM_OK;
 }
 int sim_bind_exchange2(sim_handle* h, void* send, void* recv0, void* recv1) {
@@ -5293,10 +5331,11 @@ int sim_bind_exchange2(sim_handle* h, void* send, void* recv0, void* recv1) {
   h->rbuf[0] = (uint4*)recv0;
   h->rbuf[1] = (uint4*)recv1;
   h->d.xrecv = h->rbuf[(h->tick + 1) & 1];
-  size_t n = (size_t)h->d.fp * h->d.M * sizeof(sim_packet);
-  HCHECK(hipMemsetAsync(send, 0, n, h->stream));
-  HCHECK(hipMemsetAsync(recv0, 0, n, h->stream));
-  if (recv1 != recv0) HCHECK(hipMemsetAsync(recv1, 0, n, h->stream));
+  if (h->d.rfan) h->d.obox[0] = h->d.obox[1] = (uint4*)send;  // the shard's cells: written by its senders, gathered by the exchange
+  const int fill = h->d.rfan ? 0xFF : 0;  // (random fan-out: all 0xFF — every map word says "nothing sent")
+  HCHECK(hipMemsetAsync(send, fill, xsend_bytes(h), h->stream));
+  HCHECK(hipMemsetAsync(recv0, fill, xrecv_bytes(h), h->stream));
+  if (recv1 != recv0) HCHECK(hipMemsetAsync(recv1, fill, xrecv_bytes(h), h->stream));
   h->bound = true;
   return SIM_OK;
 }
@@ -5305,7 +5344,7 @@ int sim_exchange_chunks(const sim_handle* h, uint32_t* chunks, size_t* bytes_per
   if (!h || !chunks || !bytes_per_chunk) return SIM_EINVAL;
   u32 C = h->cfg.chunks ? h->cfg.chunks : 1;
   *chunks = h->d.sharded ? C : 1;
-  *bytes_per_chunk = h->d.sharded ? (size_t)h->d.fp * h->d.M * sizeof(sim_packet) / C : 0;
+  *bytes_per_chunk = xsend_bytes(h) / C;
   return SIM_OK;
 }
 
@@ -5357,6 +5396,18 @@ int sim_exchange_chunk(sim_handle* h, uint32_t chunk) {
   if (chunk >= C) return SIM_EINVAL;
   // (called behind sim_step_chunk(chunk), before or after sim_step_end: the packets sent during tick t land in recv[t & 1])
   const u64 t = h->in_tick ? h->tick : h->tick - 1;
+  if (d.rfan) {  // SIM_XCHG_ALL_GATHER: plane j of every shard's cells, in rank order, into plane j of the receive buffer
+    const size_t pb = (size_t)d.M * RF_CELL_U4 * 16;
+    HCHECK(hipEventRecord(h->xev_go, h->stream));
+    HCHECK(hipStreamWaitEvent(h->xstream, h->xev_go, 0));
+    NCHECK(ncclGroupStart());
+    for (u32 j = 0; j < d.fp; ++j)
+      NCHECK(ncclAllGather(reinterpret_cast<const uint8_t*>(d.xsend) + (size_t)j * pb, reinterpret_cast<uint8_t*>(h->rbuf[t & 1]) + (size_t)j * pb * V, pb, ncclUint8,
+                           h->xcomm, h->xstream));
+    NCHECK(ncclGroupEnd());
+    h->xpending = true;
+    return SIM_OK;
+  }
   const size_t chunk_bytes = (size_t)d.fp * d.M * sizeof(sim_packet) / C, slab = chunk_bytes / V;
   const uint8_t* send = reinterpret_cast<const uint8_t*>(d.xsend) + (size_t)chunk * chunk_bytes;
   uint8_t* recv = reinterpret_cast<uint8_t*>(h->rbuf[t & 1]) + (size_t)chunk * chunk_bytes;

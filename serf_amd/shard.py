@@ -43,9 +43,12 @@ class ShardedSim:
         self.sim = _ffi.Sim(lib, _ffi.make_config(n_nodes, **kw))
         nbytes = self.sim.exchange_bytes()
         self.chunks, self.chunk_bytes = self.sim.exchange_chunks()
+        # what the round's exchange is: the bijection's slabs (all-to-all) or — memberlist's kRandomNodes, whose packets stay in
+        # their senders' cells — an all-gather of the shards' cells, plane by plane (include/serf_sim.h sim_exchange_layout)
+        self.kind, self.planes, self.plane_bytes, recv_bytes = self.sim.exchange_layout()
         # plain byte tensors: torch only provides device memory + the collective
         self.send = torch.zeros(nbytes, dtype=torch.uint8, device=device)
-        self.recv = [torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(2 if self.chunks > 1 else 1)]
+        self.recv = [torch.zeros(recv_bytes, dtype=torch.uint8, device=device) for _ in range(2 if self.chunks > 1 else 1)]
         if device.type == "cuda":
             self.sim.set_stream(torch.cuda.current_stream(device).cuda_stream)
         self.sim.bind_exchange2(self.send.data_ptr(), self.recv[0].data_ptr(), self.recv[-1].data_ptr())
@@ -224,7 +227,30 @@ class ShardedSim:
             if self._poll_suspects:
                 self._suspicions_out()
 
+    def _gather(self, recv, send):
+        """SIM_XCHG_ALL_GATHER: plane j of every shard's cells, in rank order, into plane j of the receive buffer"""
+        pb = self.plane_bytes
+        for j in range(self.planes):
+            dist.all_gather_into_tensor(recv[j * pb * self.world:(j + 1) * pb * self.world], send[j * pb:(j + 1) * pb], group=self.group)
+
+    def restore(self, image):
+        """sim_restore of this shard's image.  With the random fan-out the image holds the shard's OWN cells (the packets in
+        flight in their senders' cells): what the other shards sent has to be gathered again before the next tick."""
+        self.sim.restore(image)
+        if self.kind == _ffi.XCHG_ALL_GATHER:
+            self._exchange(0, self.recv[0], self.send, False)
+
     def _exchange(self, c, recv, send, asynchronous):
+        if self.kind == _ffi.XCHG_ALL_GATHER and not self.use_lib:
+            if self._xt is not None:
+                e0, e1 = self._event(), self._event()
+                e0.record()
+                self._gather(recv, send)
+                e1.record()
+                self._xt.append((e0, e1))
+            else:
+                self._gather(recv, send)
+            return
         if self._xt is not None:  # measurement mode: bracket the collective with events, no overlap
             e0, e1 = self._event(), self._event()
             e0.record()

@@ -594,6 +594,77 @@ def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim, chunks, pkt
     assert tuple(tot) == ref.convergence(_ffi.K_LEAVE, next(o for o in ops if o[1] == _ffi.OP_LEAVE)[2], 1)
 
 
+@pytest.mark.parametrize("swim,pkt,rc,n", [(0, 0, 0, 2048), (4, 0, 0, 2048), (4, 8, 0, 2048), (2, 0, 3, 2048), (4, 0, 0, 1 << 16)])
+def test_random_fanout_four_shards_on_one_gpu(oracle, hiplib, swim, pkt, rc, n):
+    # memberlist's kRandomNodes on shards (r4): 4 handles on ONE GPU, each drawing the whole cluster's
+    # targets and keeping the rows of its own nodes; the packets stay in their senders' cells and the round's exchange is
+    # an all-gather of the shards' cells (sim_exchange_layout: SIM_XCHG_ALL_GATHER), done here with device-to-device copies —
+    # plane j of shard g into plane j of every receive buffer, at g's place.  Every shard against the oracle's matching slice
+    # of ONE handle that holds every node; the cross-shard push-pull / suspicion hand-over as in the bijection's test.
+    import torch
+
+    V, ticks = 4, 50 if not rc else 90
+    m = n // V
+    kw = dict(fanout=4, view_slots=96, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=0.02,
+              push_pull_interval=3 if swim else 0, pkt_records=pkt, reconnect_interval=rc, flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT,
+              **(dict(suspicion_mult=3, suspicion_max_mult=2, gossip_to_the_dead=1) if rc else {}))
+    ref = _ffi.Sim(oracle, _ffi.make_config(n, vshards=V, **kw))
+    shards, send, recv = [], [], []
+    for g in range(V):
+        s = _ffi.Sim(hiplib, _ffi.make_config(n, vshards=V, shard_rank=g, shard_count=V, **kw))
+        kind, planes, pb, rb = s.exchange_layout()
+        assert kind == _ffi.XCHG_ALL_GATHER and planes * pb == s.exchange_bytes() and rb == V * planes * pb
+        send.append(torch.zeros(planes * pb, dtype=torch.uint8, device="cuda"))
+        recv.append(torch.zeros(rb, dtype=torch.uint8, device="cuda"))
+        s.bind_exchange2(send[-1].data_ptr(), recv[-1].data_ptr(), recv[-1].data_ptr())
+        shards.append(s)
+    ops = sc.schedule(n, ticks // 2, rate=0.8 if not pkt else 3.0, seed=5, max_member_subjects=60)
+    for s in shards + [ref]:
+        sc.apply_schedule(s, ops)
+        for x in ((7, 300, 777, 1200, 1500, 2000) if rc else ()):
+            s.inject(1, _ffi.OP_CRASH, x)
+            if x > 500:
+                s.inject(50, _ffi.OP_REVIVE, x)
+    fp = 4 * max(1, pkt // 4)
+    for t in range(ticks):
+        for s in shards:
+            s.step_begin()
+        if shards[0].pp_due():
+            _push_pull_on_one_gpu(shards)
+        for s in shards:
+            s.step_chunk(0)
+        for s in shards:
+            s.step_end()
+            s.sync()
+        for g in range(V):              # the all-gather, plane by plane
+            for j in range(planes):
+                for src in range(V):
+                    recv[g][(j * V + src) * pb:(j * V + src + 1) * pb].copy_(send[src][j * pb:(j + 1) * pb])
+        _suspicions_on_one_gpu(shards)
+        torch.cuda.synchronize()
+        ref.step(1)
+        if t % 7 == 0 or t == ticks - 1:
+            for g, s in enumerate(shards):
+                lo = g * m
+                for which in (_ffi.ARR_ROWS, _ffi.ARR_QUEUE):
+                    a, b = s.dump(which), ref.dump(which)
+                    per = len(b) // n
+                    i = sc.first_diff(a, b[lo * per:(lo + m) * per])
+                    assert i is None, f"shard {g} array {which} element {i} differs at tick {t}"
+                for which, rows in ((_ffi.ARR_VIEW, 96), (_ffi.ARR_ERING, 16), (_ffi.ARR_QRING, 8), (_ffi.ARR_INBOX, fp)):
+                    a = s.dump(which).reshape(rows, m)
+                    b = np.ascontiguousarray(ref.dump(which).reshape(rows, n)[:, lo:lo + m])
+                    assert a.tobytes() == b.tobytes(), f"shard {g} array {which} differs at tick {t}"
+    tot = [sum(x) for x in zip(*(s.convergence(_ffi.K_LEAVE, next(o for o in ops if o[1] == _ffi.OP_LEAVE)[2], 1) for s in shards))]
+    assert tuple(tot) == ref.convergence(_ffi.K_LEAVE, next(o for o in ops if o[1] == _ffi.OP_LEAVE)[2], 1)
+    # a checkpoint of shard 1 into a fresh handle: its own cells come back, the others' are gathered again, the run goes on
+    img = shards[1].snapshot()
+    fresh = _ffi.Sim(hiplib, _ffi.make_config(n, vshards=V, shard_rank=1, shard_count=V, **kw))
+    fresh.bind_exchange2(send[1].data_ptr(), recv[1].data_ptr(), recv[1].data_ptr())
+    fresh.restore(img)
+    assert fresh.digest() == shards[1].digest()
+
+
 def test_sharded_kernel_b64_four_shards_of_64k_on_one_gpu(oracle, hiplib):
     """the SHARDED instantiation of the tick kernel with 64-node blocks, at a shard size near the
     bench's — 4 handles x 64 Ki nodes on one GPU, 2 sender chunks (2 x 512 blocks per shard and tick: tp.B == 64, the
@@ -998,6 +1069,21 @@ def _one_rank_rccl_worker(port, q):
                 assert keep(sh.sim.digest()) == keep(plain.digest()) == keep(orc.digest()), f"chunks {chunks}: digests differ after tick {5 * t + 4}"
             out[chunks] = sh.collective_library()
             sh.close()
+        # the random fan-out as one rank of the N > 1 path: the round's all-gather of the cells as ncclAllGather issued by the library
+        kw_rf = dict(kw, flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT, recycle_interval=0)
+        sh = ShardedSim(lib, n, dev, chunks=1, exchange="rccl", **kw_rf)
+        assert sh.use_lib and sh.kind == _ffi.XCHG_ALL_GATHER
+        plain = _ffi.Sim(lib, _ffi.make_config(n, **kw_rf))
+        orc = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw_rf))
+        for x in (sh, plain, orc):
+            sc.apply_schedule(x, ops)
+        for t in range(12):
+            sh.step(5)
+            plain.step(5)
+            orc.step(5)
+            sh.sync()
+            assert sh.sim.digest() == plain.digest() == orc.digest(), f"random fan-out over ncclAllGather: digests differ after tick {5 * t + 4}"
+        sh.close()
         dist.destroy_process_group()
         q.put(("ok", out[1]))
     except BaseException as e:  # noqa: BLE001
