@@ -270,8 +270,8 @@ def parse_args(argv=None):
     a = ap.parse_args(argv)
     if a.random_fanout:
         a.fanout_model = "krandomnodes"
-    if a.force_sharded:
-        a.fanout_model = "bijection"
+    if a.force_sharded and a.fanout_model == "both":
+        a.fanout_model = "bijection"   # (one model per sharded run; --fanout-model krandomnodes: the random fan-out's all-gather path)
     return a
 
 
@@ -369,8 +369,9 @@ def run(args, lib=None, dev=None, backend="nccl"):
     if lib is None:
         lib = serf_amd.load()
     # which fan-out models: both at N = 1 (the reference's first: it is the headline), the bijection alone when sharded
-    if world > 1:
-        models = ["bijection"]
+    if world > 1:   # one model per sharded run: the bijection (its all-to-all moves f packets per node) unless asked otherwise —
+        # the random fan-out on shards exchanges every shard's cells with everybody (an all-gather: O(N) bytes per shard)
+        models = ["krandomnodes" if args.fanout_model == "krandomnodes" else "bijection"]
     elif args.fanout_model == "both":
         models = ["krandomnodes", "bijection"]
     else:
@@ -408,7 +409,7 @@ def run(args, lib=None, dev=None, backend="nccl"):
         kw, ops = workload(args, n_total, model)
         progress(f"create ({model})")
         if sharded:
-            sim = ShardedSim(lib, n_total, dev, chunks=args.chunks, exchange=args.exchange, **kw)
+            sim = ShardedSim(lib, n_total, dev, chunks=1 if model == "krandomnodes" else args.chunks, exchange=args.exchange, **kw)
         else:
             sim = _ffi.Sim(lib, _ffi.make_config(n_total, **kw))
             if on_gpu:

@@ -117,11 +117,13 @@ class ShardedSim:
 
     def collective_library(self):
         """what moves the round's packets: "RCCL x.y.z (issued by the library: grouped ncclSend / ncclRecv)" or torch's backend"""
+        gather = self.kind == _ffi.XCHG_ALL_GATHER
         if self.use_lib:
-            return self.lib.exchange_library() + " — issued by libserf_sim (sim_exchange_chunk: grouped ncclSend / ncclRecv per peer)"
+            return self.lib.exchange_library() + (" — issued by libserf_sim (sim_exchange_chunk: ncclAllGather per plane of cells)" if gather else
+                                                  " — issued by libserf_sim (sim_exchange_chunk: grouped ncclSend / ncclRecv per peer)")
         backend = dist.get_backend(self.group)
         if backend == "nccl" and self.device.type == "cuda":
-            return "RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version()) + " — torch.distributed.all_to_all_single"
+            return "RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version()) + (" — torch.distributed.all_gather_into_tensor" if gather else " — torch.distributed.all_to_all_single")
         return backend
 
     def snapshot(self):

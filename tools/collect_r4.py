@@ -26,7 +26,8 @@ def last_json(path):
 
 
 for src, dst in (("bench_default.json", "r04_bench.json"), ("bench_20_5.json", "r04_bench_driver_args.json"),
-                 ("bench_one_rank_rccl.json", "r04_bench_one_rank_rccl.json")):
+                 ("bench_one_rank_rccl.json", "r04_bench_one_rank_rccl.json"),
+                 ("bench_one_rank_rccl_krandomnodes.json", "r04_bench_one_rank_rccl_krandomnodes.json")):
     if os.path.exists(os.path.join(call, src)):
         json.dump(last_json(os.path.join(call, src)), open(os.path.join(out, dst), "w"), indent=1)
 sha = hashlib.sha256(open(os.path.join(ROOT, "serf_amd", "csrc", "serf_sim.hip"), "rb").read()).hexdigest()[:16]

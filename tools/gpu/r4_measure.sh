@@ -10,6 +10,7 @@ cd $ROOT
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_20_5.json 2> $OUT/bench_20_5.err; echo "bench (driver args) rc=$?"
 timeout 400 python bench.py --no-cpu-baseline > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench default rc=$?"
 timeout 400 python bench.py --gpus 1 --force-sharded --exchange rccl --chunks 2 --steps 20 --warmup 5 --no-cpu-baseline --no-second-load > $OUT/bench_one_rank_rccl.json 2> $OUT/bench_one_rank_rccl.err; echo "bench one rank over RCCL rc=$?"
+timeout 400 python bench.py --gpus 1 --force-sharded --fanout-model krandomnodes --exchange rccl --steps 20 --warmup 5 --no-cpu-baseline --no-second-load > $OUT/bench_one_rank_rccl_krandomnodes.json 2> $OUT/bench_one_rank_rccl_krandomnodes.err; echo "bench one rank, random fan-out, over RCCL rc=$?"
 cd /tmp && export TMPDIR=/tmp
 for M in krandomnodes bijection; do
   ARGS="--fanout-model $M --no-cpu-baseline --no-convergence --no-second-load --no-long-window --steps 20 --warmup 5"
@@ -26,7 +27,7 @@ done
 cd $ROOT
 python - <<PY
 import json
-for f in ('bench_20_5','bench_default','bench_one_rank_rccl'):
+for f in ('bench_20_5','bench_default','bench_one_rank_rccl','bench_one_rank_rccl_krandomnodes'):
     try:
         d=json.loads(open('$OUT/%s.json'%f).read().strip().splitlines()[-1]); r=d['roofline']
         print(f, d['config'].get('fanout_model'), 'value %.3e'%d['value'], 'ms/step %.4f'%d['ms_per_step'], 'kernel_ms %.4f'%r['kernel_ms'], 'frac %.3f'%r['frac'], 'drops', d['config']['model_bound_drops'],
