@@ -280,15 +280,17 @@ typedef struct sim_config {
 #define SIM_CF_BASELINE_JOINED 1u /* all nodes known+Alive at status_time 1, clock 2 (config 2-5) */
 #define SIM_CF_RANDOM_FANOUT 2u   /* gossip targets are memberlist's literal kRandomNodes (uniform over the other nodes, no
                                    * replacement, skip self — App. B.2) instead of the per-tick bijection; in-degree is then
-                                   * Poisson-like and a node's packets are handed over in (sender, slot) order.  One shard, one
-                                   * chunk (SIM_EINVAL otherwise); packets of 1 - 4 pages; checkpoints like every other run
+                                   * Poisson-like and a node's packets are handed over in (sender, slot) order.  One chunk
+                                   * (SIM_EINVAL otherwise); packets of 1 - 4 pages; checkpoints like every other run
                                    * (the targets of the packets in flight are a function of (seed, tick, sender): drawn again
                                    * on restore).  Canonical form of the packets in flight in this mode (SIM_ARR_INBOX, digests,
-                                   * images): inbox[k * PG + pg][SENDER].
-                                   * (r4) The HIP library builds the tick's fan-out graph ahead of the tick with its own
-                                   * two-level bucket sort (LDS histograms; rows ranked by sender inside a bucket), every sender
-                                   * PUSHES its packets to their positions in the receivers' CSR rows, and the deliver loop
-                                   * reads one contiguous run of cells per node */
+                                   * images): inbox[k * PG + pg][SENDER] — on a shard: its own senders.
+                                   * (r4) The packets stay in their senders' cells and every receiver pulls what the tick's graph
+                                   * (a CSR the HIP library builds two ticks ahead with its own two-level bucket sort) addresses
+                                   * to it.  On SHARDS (r4): every shard draws the whole cluster's targets and
+                                   * keeps its own nodes' rows; the round's exchange is an ALL-GATHER of the shards' cells
+                                   * (sim_exchange_layout) — O(N) bytes per shard and round where the bijection's all-to-all
+                                   * moves O(f N / V): correct and checkpointable, not the scalable form */
 /* random fan-out only: broadcast requests one node can park in ONE tick beyond f * pkt_records + SIM_S + 1 (the bijection's
  * maximum; with a random in-degree there is none).  A counted model bound, the same in the oracle. */
 #define SIM_RF_PEND_EXTRA 32u
