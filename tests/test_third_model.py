@@ -16,7 +16,7 @@ from tests import _scenario as sc
 RING_EV, RING_Q, PG = 64, 32, 4   # packets of 4 pages = 16 records: they carry a node's whole queue, nothing waits for a turn
 
 
-def run_against_third_model(sim, n, fanout, ops, ticks, joined):
+def run_against_third_model(sim, n, fanout, ops, ticks, joined, rf=False):
     nodes = [tm.Node(i, n, RING_EV, RING_Q, joined) for i in range(n)]
     by_tick = {}
     for o in ops:
@@ -25,6 +25,13 @@ def run_against_third_model(sim, n, fanout, ops, ticks, joined):
     approved = [set() for _ in range(n)]   # every (kind, key, ltime) a node's delegate has asked to (re)broadcast so far
     for t in range(ticks):
         inbox = sim.dump(_ffi.ARR_INBOX).reshape(fanout * PG, n)   # the packets about to be delivered: [slot * PG + page][receiver]
+        if rf and t > 0:
+            # memberlist's kRandomNodes: the dump is SENDER-indexed in this mode; who receives what is drawn here, from the
+            # specification (third_model.k_random_nodes), and handed over in (sender, slot) order
+            rows = [[] for _ in range(n)]
+            for snd in range(n):
+                for k, tgt in enumerate(tm.k_random_nodes(_ffi.DEFAULT_SEED, t - 1, snd, n, fanout)):
+                    rows[tgt].append((snd, k))
         # (0) the tick's operations, in call order (SIMSPEC §2.1)
         for _, op, node, a, b in by_tick.get(t, ()):
             x = nodes[node]
@@ -51,8 +58,9 @@ def run_against_third_model(sim, n, fanout, ops, ticks, joined):
         for i, x in enumerate(nodes):
             if not x.up:
                 continue
-            for k in range(fanout * PG):
-                pk = inbox[k, i]
+            cells = [inbox[k * PG + pg, snd] for snd, k in rows[i] for pg in range(PG)] if rf and t > 0 else \
+                    [] if rf else [inbox[k, i] for k in range(fanout * PG)]
+            for pk in cells:
                 for r in range(4):
                     hm = int(pk["hi_meta"][r])
                     kind = (hm >> 4) & 15
@@ -109,18 +117,20 @@ def _schedule(n, ticks, seed, joined):
     return ops
 
 
-@pytest.mark.parametrize("seed,n,fanout,joined", [(1, 48, 3, True), (2, 64, 4, True), (3, 33, 2, True), (4, 48, 3, False), (5, 20, 3, False)])   # (not joined: every node knows one member, the retransmit limit is 4 — fan-out 3 keeps a record queued past its tick)
-def test_oracle_matches_the_third_model(seed, n, fanout, joined):
+@pytest.mark.parametrize("seed,n,fanout,joined,rf", [(1, 48, 3, True, False), (2, 64, 4, True, False), (3, 33, 2, True, False), (4, 48, 3, False, False), (5, 20, 3, False, False),
+                                                     (6, 48, 3, True, True), (7, 64, 4, True, True), (8, 24, 3, False, True)])   # (not joined: every node knows one member, the retransmit limit is 4 — fan-out 3 keeps a record queued past its tick)
+def test_oracle_matches_the_third_model(seed, n, fanout, joined, rf):
+    # rf: memberlist's kRandomNodes — who receives which packet is drawn by the third model itself, from the specification
     kw = dict(fanout=fanout, view_slots=0, event_ring=RING_EV, query_ring=RING_Q, leave_delay=4, pkt_records=4 * PG,
-              flags=_ffi.CF_BASELINE_JOINED if joined else 0)
+              flags=(_ffi.CF_BASELINE_JOINED if joined else 0) | (_ffi.CF_RANDOM_FANOUT if rf else 0))
     sim = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw))
-    run_against_third_model(sim, n, fanout, _schedule(n, 70, seed, joined), 70, joined)
+    run_against_third_model(sim, n, fanout, _schedule(n, 70, seed, joined), 70, joined, rf)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,n,fanout,joined,rf", [(1, 48, 3, True, False), (2, 64, 4, True, False), (4, 48, 3, False, False)])
+@pytest.mark.parametrize("seed,n,fanout,joined,rf", [(1, 48, 3, True, False), (2, 64, 4, True, False), (4, 48, 3, False, False), (6, 48, 3, True, True), (7, 64, 4, True, True)])
 def test_hip_matches_the_third_model(hiplib, seed, n, fanout, joined, rf):
     kw = dict(fanout=fanout, view_slots=0, event_ring=RING_EV, query_ring=RING_Q, leave_delay=4, pkt_records=4 * PG,
-              flags=_ffi.CF_BASELINE_JOINED if joined else 0)
+              flags=(_ffi.CF_BASELINE_JOINED if joined else 0) | (_ffi.CF_RANDOM_FANOUT if rf else 0))
     sim = _ffi.Sim(hiplib, _ffi.make_config(n, **kw))
-    run_against_third_model(sim, n, fanout, _schedule(n, 70, seed, joined), 70, joined)
+    run_against_third_model(sim, n, fanout, _schedule(n, 70, seed, joined), 70, joined, rf)

@@ -21,6 +21,32 @@ JOIN, LEAVE, EVENT, QUERY = 1, 2, 3, 4                      # the record kinds o
 NO_BROADCAST = 1                                            # QueryFlag::NO_BROADCAST as the simulator carries it
 
 
+M64 = (1 << 64) - 1
+
+
+def mix64(z):
+    """splitmix64's finaliser (DESIGN.md SIMSPEC §2.2: the simulator's only source of randomness)"""
+    z = (z + 0x9E3779B97F4A7C15) & M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    return z ^ (z >> 31)
+
+
+def k_random_nodes(seed, tick, node, n, fanout):
+    """memberlist's kRandomNodes as the simulator specifies it (SIM_CF_RANDOM_FANOUT): up to 3 n uniform
+    draws over all n nodes from stream 7 of (seed, tick), skipping the node itself and nodes already chosen, until `fanout` are
+    found — written from the specification, not from the oracle's rf_draw."""
+    base = mix64(mix64(seed ^ ((7 * 0xD6E8FEB86659FD93) & M64)) ^ tick)
+    chosen = []
+    for i in range(3 * n):
+        if len(chosen) == fanout:
+            break
+        t = ((mix64(base ^ ((node * 4096 + i) & M64)) >> 32) * n) >> 32
+        if t != node and t not in chosen:
+            chosen.append(t)
+    return chosen
+
+
 class Clock:
     """types/clock.rs:125-172"""
 
