@@ -143,7 +143,7 @@ def test_random_fanout_kRandomNodes(oracle, hiplib, seed):
     if seed >= 16:
         kw.update(pkt_records=int(rng.choice([8, 12, 16])))
         rate = float(rng.choice([1.0, 2.5, 5.0]))
-    if n >= 1000 and seed % 3 == 0:
+    if n >= 2048 and seed % 3 == 0:
         kw.update(vshards=4)   # (r4) ONE handle that holds a cluster of 4 virtual shards: what a 4-shard run is compared with
     g, o = pair(oracle, hiplib, n, **kw)
     ops = sc.schedule(n, 40, rate=rate, seed=seed, max_member_subjects=max(1, min(n // 2, 12 if not dense else 30)))
