@@ -121,9 +121,8 @@ def test_random_configurations(oracle, hiplib, seed):
 @pytest.mark.parametrize("seed", list(range(32)))
 def test_random_fanout_kRandomNodes(oracle, hiplib, seed):
     # SIM_CF_RANDOM_FANOUT: memberlist's literal kRandomNodes (App. B.2) — uniform targets, no replacement, variable in-degree —
-    # in the PRODUCT: the tick's fan-out graph is built ahead of the tick by the library's own two-level bucket sort (rf_*
-    # kernels), every sender pushes its packets to their places in the receivers' CSR rows, the deliver loop reads a node's run
-    # of cells.  Seeded sweep: tiny clusters (fewer other nodes than the fan-out: slots without a target), ragged and block-sized
+    # in the PRODUCT: the tick's fan-out graph is built two ticks ahead by the library's own two-level bucket sort (rf_*
+    # kernels), the packets stay in their senders' cells and every receiver pulls the ones its CSR row names.  Seeded sweep: tiny clusters (fewer other nodes than the fan-out: slots without a target), ragged and block-sized
     # ones, dense and slotted views, SWIM / loss / gossip_to_the_dead / push-pull / reaper / recycling / Reconnector on or off,
     # packets of 1 - 4 pages (seeds 16 ..); digests after every tick, every array at the end, a checkpoint in the middle that
     # goes through the canonical (sender-indexed) inbox and back, both ways.
