@@ -4,7 +4,8 @@ two ranks on one device): each rank compares every array of its shard, every 5 t
 single-process run of the CPU oracle (test infrastructure).  The multi-process twin of
 tests/test_parity_gpu.py::test_sharded_kernel_four_shards_on_one_gpu; run it on the GPU box under `timeout`.
 
-usage: python tools/shard_procs_check.py [world] [chunks] [swim] [nodes] [loss]
+usage: python tools/shard_procs_check.py [world] [chunks] [swim] [nodes] [loss] [rf]
+(rf = 1: memberlist's kRandomNodes — the round's exchange is the all-gather of the shards' cells; chunks must be 1)
 (loss >= 0.05: 256 view slots, and the run must have carried slot-less suspicions across the shards)"""
 import os
 import sys
@@ -13,7 +14,7 @@ import traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def worker(rank, world, port, n, ticks, swim, chunks, q, loss=0.02):
+def worker(rank, world, port, n, ticks, swim, chunks, q, loss=0.02, rf=0):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -44,6 +45,8 @@ def worker(rank, world, port, n, ticks, swim, chunks, q, loss=0.02):
         vs = 64 if loss < 0.05 else 256
         kw = dict(fanout=3, view_slots=vs, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=loss,
                   push_pull_interval=4 if swim else 0)
+        if rf:
+            kw["flags"] = _ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT
         mark("creating")
         sh = ShardedSim(serf_amd.load(), n, dev, chunks=chunks, **kw)
         mark("created")
@@ -89,6 +92,11 @@ def worker(rank, world, port, n, ticks, swim, chunks, q, loss=0.02):
                 b = ref.dump(which).reshape(rows, n)[:, lo:lo + m]
                 if a.tobytes() != np.ascontiguousarray(b).tobytes():
                     raise AssertionError(f"rank {rank} array {which} differs at tick {t + 5}")
+            if rf:  # the packets in flight: the shard's own senders' cells
+                a = sh.sim.dump(_ffi.ARR_INBOX).reshape(3, m)
+                b = ref.dump(_ffi.ARR_INBOX).reshape(3, n)[:, lo:lo + m]
+                if a.tobytes() != np.ascontiguousarray(b).tobytes():
+                    raise AssertionError(f"rank {rank} packets in flight differ at tick {t + 5}")
         where = "convergence"
         ev = next(op for op in ops if op[1] == _ffi.OP_USER_EVENT)
         assert sh.convergence(_ffi.K_EVENT, ev[3], 1) == ref.convergence(_ffi.K_EVENT, ev[3], 1)
@@ -116,10 +124,11 @@ def main():
     swim = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     n = int(sys.argv[4]) if len(sys.argv) > 4 else 2048
     loss = float(sys.argv[5]) if len(sys.argv) > 5 else 0.02
+    rf = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29300 + (os.getpid() % 300)
-    procs = [ctx.Process(target=worker, args=(r, world, port, n, 60, swim, chunks, q, loss)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, n, 60, swim, chunks, q, loss, rf)) for r in range(world)]
     for p in procs:
         p.start()
     res = []
