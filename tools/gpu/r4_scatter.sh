@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 4: where rf_scatter's 48 us go.  Variant builds of the library (compile-time switches, never shipped):
+# round 4: where rf_scatter's 48 us went (a record of the experiment: the variants were built with compile-time switches —
+# -DRF_SPW / -DRFB / -DRF_ABLATE — that the source no longer has; results in profiles/r04_experiments.md).  Variant builds:
 #   x_spw8k  8192 senders per workgroup (half the returning atomics, half the workgroups)
 #   x_spw2k  2048 senders / 512 threads per workgroup (twice the atomics, twice the workgroups)
 #   x_ab1    no global atomics (positions made up), x_ab2 no stores, x_ab3 neither
