@@ -666,10 +666,13 @@ def run(args, lib=None, dev=None, backend="nccl"):
             out["long_window"] = out["fanout_models"][models[0]]["long_window"]
         if sharded:
             xb = head["exchange_bytes"]
+            gather = models[0] == "krandomnodes"   # the random fan-out on shards: an all-gather of the shards' cells (every peer gets all of xb)
             out["exchange"] = {"chunks": head["chunks"], "exchange_ms": head["exchange_ms"], "kernel_ms": t["kern_s"] * 1e3,
+                               "collective": "all-gather of the shard's cells, plane by plane" if gather else "equal-split all-to-all per chunk",
                                "serial_ms_per_step": head["serial_ms"], "overlapped_ms_per_step": t["dt"] / args.steps * 1e3,
-                               "bytes_per_peer": xb // world, "bytes_per_gpu_per_tick": xb,
-                               "bytes_leaving_gpu_per_tick": xb // world * (world - 1),
+                               "bytes_per_peer": xb if gather else xb // world, "bytes_per_gpu_per_tick": xb,
+                               "bytes_leaving_gpu_per_tick": xb * (world - 1) if gather else xb // world * (world - 1),
+                               "bytes_arriving_per_gpu_per_tick": xb * (world - 1) if gather else xb // world * (world - 1),
                                "what": f"the timed region runs each tick as {head['chunks']} chunk launches with the all-to-all of chunk c in flight "
                                        "while chunk c + 1 computes (overlapped_ms_per_step = ms_per_step); exchange_ms and serial_ms_per_step come "
                                        f"from {head['diag_ticks']} further ticks with the collectives run one after the other between events (rank 0): "
