@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, extra=()):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
@@ -21,7 +21,7 @@ def _worker(rank, world, port, q):
 
     try:
         args = bench.parse_args(["--gpus", str(world), "--steps", "20", "--warmup", "10", "--nodes-per-gpu", "2048",
-                                 "--view-slots", "64", "--ring", "32", "--no-cpu-baseline", "--allow-drops"])
+                                 "--view-slots", "64", "--ring", "32", "--no-cpu-baseline", "--allow-drops", *extra])
         out = bench.run(args, lib=load_oracle(), dev=torch.device("cpu"), backend="gloo")
         q.put((rank, json.dumps(out) if out is not None else "null"))
     except BaseException as e:  # noqa: BLE001
@@ -55,6 +55,27 @@ def test_bench_control_flow(world):
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     if world > 1:
         assert all(res[r] == "null" for r in range(1, world))
+
+
+def test_bench_control_flow_random_fanout_on_two_ranks():
+    # (r4) the N > 1 line on memberlist's kRandomNodes: ShardedSim's all-gather of the shards' cells, the JSON's exchange section
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 200) + 7
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, ("--fanout-model", "krandomnodes"))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    res = dict(q.get(timeout=5) for _ in procs)
+    assert not any(str(v).startswith("ERR") for v in res.values()), res
+    out = json.loads(res[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["fanout_model"] == "krandomnodes"
+    assert out["exchange"]["collective"].startswith("all-gather") and out["exchange"]["chunks"] == 1
+    assert out["exchange"]["bytes_arriving_per_gpu_per_tick"] == out["exchange"]["bytes_per_gpu_per_tick"]
+    assert 1 <= out["rounds_to_99"]["median"] <= 60
 
 
 def test_bench_launches_its_own_ranks(tmp_path):
