@@ -2135,73 +2135,131 @@ int API(user_event_bytes)(osim* s, uint32_t node, const uint8_t* name, size_t nl
   /* the length is priced at Lamport time 1 (one varint byte): what Serf::user_event in serf_amd/host/serf.hpp does */
   return API(user_event)(s, node, key, (uint32_t)user_event_wire_len(1, nlen, plen, cc), cc);
 }
-/* Node{id: tag 1, addr: tag 2} (memberlist-proto; serf_amd/wire.py encode_node): the id */
+/* ---- decoding, by the reference's rule (types/join.rs:58-105 and its siblings): a body is a run of fields, each opened by ONE key byte
+ * (tag << 3 | wire type); a decoder knows the key bytes of its message — a known one that comes twice is an error
+ * (DecodeError::duplicate_field), any other key byte is skipped by its wire type (Byte: one raw byte; Varint; LengthDelimited;
+ * anything else cannot be skipped: error), and the fields the reference unwraps without a default must have come
+ * (DecodeError::missing_field). */
+#define KB(tag, wt) ((uint8_t)(((tag) << 3) | (wt)))
+typedef struct { uint8_t kb; uint64_t v; rdr d; } fld;
+/* the next field of `r`.  raw1: a key byte whose value is ONE raw byte although its wire type says Varint (QueryMessage.relay_factor,
+ * types/query.rs:484-490); 0: none */
+static int rd_field(rdr* r, fld* f, uint8_t raw1) {
+  f->kb = r->p[r->off++];
+  f->v = 0;
+  f->d.p = NULL; f->d.n = f->d.off = 0; f->d.bad = 0;
+  uint32_t wt = f->kb & 7u;
+  if ((raw1 && f->kb == raw1) || wt == 0) { if (r->off >= r->n) { r->bad = 1; return 0; } f->v = r->p[r->off++]; }
+  else if (wt == 1) f->v = rd_varint(r);
+  else if (wt == 2) f->d = rd_ld(r);
+  else { r->bad = 1; return 0; }
+  return !r->bad;
+}
+/* a known field that is allowed once: 0 if it has been seen before */
+static int once(uint32_t* seen, uint32_t bit) { if (*seen & bit) return 0; *seen |= bit; return 1; }
+/* Node{id: key (1, LengthDelimited), addr: key (2, LengthDelimited)} (memberlist-proto; serf_amd/wire.py encode_node): the id */
 static int parse_node(rdr d, uint32_t* id) {
-  int have = 0;
-  while (d.off < d.n && !d.bad) {
-    uint8_t fb = d.p[d.off++];
-    if ((fb & 7) == 2) { rdr v = rd_ld(&d); if ((fb >> 3) == 1) have = parse_node_id(v, id); }
-    else if ((fb & 7) == 1) (void)rd_varint(&d);
-    else if ((fb & 7) == 0) d.off++;
-    else return 0;
+  uint32_t seen = 0;
+  fld f;
+  while (d.off < d.n) {
+    if (!rd_field(&d, &f, 0)) return 0;
+    if (f.kb == KB(1, 2)) { if (!once(&seen, 1) || !parse_node_id(f.d, id)) return 0; }
+    else if (f.kb == KB(2, 2)) { if (!once(&seen, 2)) return 0; }
   }
-  return have && !d.bad;
+  return (seen & 1) != 0;
 }
 static int deliver_one(osim* s, uint32_t node, const uint8_t* buf, size_t len, size_t* consumed, int relayed);
-/* QueryResponseMessage (types/query/response.rs: ltime 1, id 2, from 3, flags 4, payload 5) -> SIM_OP_QRESP at the origin */
+/* QueryResponseMessage (types/query/response.rs:100-243: ltime, id, from, flags required; payload optional) -> SIM_OP_QRESP at the origin */
 static int deliver_query_response(osim* s, uint32_t node, rdr body) {
   uint64_t qid = 0, flags = 0;
-  uint32_t from = 0, have_from = 0;
-  while (body.off < body.n && !body.bad) {
-    uint8_t fb = body.p[body.off++];
-    uint32_t wt = fb & 7, ft = fb >> 3;
-    if (wt == 1) { uint64_t v = rd_varint(&body); if (ft == 2) qid = v; else if (ft == 4) flags = v; }
-    else if (wt == 2) { rdr d = rd_ld(&body); if (ft == 3) have_from = (uint32_t)parse_node(d, &from); }
-    else if (wt == 0) body.off++;
-    else return SIM_EINVAL;
+  uint32_t from = 0, seen = 0;
+  fld f;
+  while (body.off < body.n) {
+    if (!rd_field(&body, &f, 0)) return SIM_EINVAL;
+    switch (f.kb) {
+      case KB(1, 1): if (!once(&seen, 1)) return SIM_EINVAL; break;
+      case KB(2, 1): if (!once(&seen, 2)) return SIM_EINVAL; qid = f.v; break;
+      case KB(3, 2): if (!once(&seen, 4) || !parse_node(f.d, &from)) return SIM_EINVAL; break;
+      case KB(4, 1): if (!once(&seen, 8)) return SIM_EINVAL; flags = f.v; break;
+      case KB(5, 2): if (!once(&seen, 16)) return SIM_EINVAL; break;
+      default: break;
+    }
   }
-  if (body.bad || !have_from || from >= s->N || !qid || qid > 0xFFFFFFFFull) return SIM_EINVAL;
+  if ((seen & 15u) != 15u || from >= s->N || !qid || qid > 0xFFFFFFFFull) return SIM_EINVAL;
   return inject_val(s, s->tick, SIM_OP_QRESP, node, (uint32_t)qid, from | ((flags & 1) ? 0x80000000u : 0u), 0);
 }
-/* PushPullMessage (types/push_pull.rs: ltime 1, status_ltimes 2 {id 1, ltime 2}, left_members 3, event_ltime 4, events 5
- * {ltime 1, events 2 {name 1, payload 2}}, query_ltime 6) -> what merge_remote_state (delegate.rs:427-554) does with it */
+/* PushPullMessage (types/push_pull.rs:150-320: ltime 1, status_ltimes 2 {id 1, ltime 2}, left_members 3, event_ltime 4, events 5
+ * {ltime 1, events 2 {name 1, payload 2}}, query_ltime 6; the three clocks required) -> what merge_remote_state
+ * (delegate.rs:427-554) does with it.  The whole message is decoded before anything is scheduled: a frame that is refused leaves
+ * nothing behind. */
+typedef struct { uint64_t lt; uint32_t key; rdr name, payload; } pp_event;
 static int deliver_push_pull(osim* s, uint32_t node, rdr body) {
   uint64_t clk[3] = {0, 0, 0};
-  uint32_t n_st = 0, n_left = 0, cap = 16;
-  uint32_t* ids = (uint32_t*)malloc(cap * sizeof(uint32_t));
-  uint64_t* lts = (uint64_t*)malloc(cap * sizeof(uint64_t));
-  uint32_t* left = (uint32_t*)malloc(cap * sizeof(uint32_t));
-  uint32_t cap_left = cap;
+  uint32_t n_st = 0, n_left = 0, n_ev = 0, cap_st = 16, cap_left = 16, cap_ev = 16, seen = 0;
+  uint32_t* ids = (uint32_t*)malloc(cap_st * sizeof(uint32_t));
+  uint64_t* lts = (uint64_t*)malloc(cap_st * sizeof(uint64_t));
+  uint32_t* left = (uint32_t*)malloc(cap_left * sizeof(uint32_t));
+  pp_event* evs = (pp_event*)malloc(cap_ev * sizeof(pp_event));
   int rc = SIM_OK;
-  rdr scan = body;
-  while (scan.off < scan.n && !scan.bad && rc == SIM_OK) { /* pass 1: clocks, the status map, the left list */
-    uint8_t fb = scan.p[scan.off++];
-    uint32_t wt = fb & 7, ft = fb >> 3;
-    if (wt == 1) { uint64_t v = rd_varint(&scan); if (ft == 1) clk[0] = v; else if (ft == 4) clk[1] = v; else if (ft == 6) clk[2] = v; }
-    else if (wt == 2) {
-      rdr d = rd_ld(&scan);
-      if (ft == 2) {
-        uint32_t id = 0, have = 0;
+  fld f;
+  while (body.off < body.n && rc == SIM_OK) {
+    if (!rd_field(&body, &f, 0)) { rc = SIM_EINVAL; break; }
+    switch (f.kb) {
+      case KB(1, 1): if (!once(&seen, 1)) rc = SIM_EINVAL; clk[0] = f.v; break;
+      case KB(4, 1): if (!once(&seen, 2)) rc = SIM_EINVAL; clk[1] = f.v; break;
+      case KB(6, 1): if (!once(&seen, 4)) rc = SIM_EINVAL; clk[2] = f.v; break;
+      case KB(2, 2): { /* one entry of the status map: {id, ltime} */
+        uint32_t id = 0, es = 0;
         uint64_t lt = 0;
-        while (d.off < d.n && !d.bad) {
-          uint8_t gb = d.p[d.off++];
-          if ((gb & 7) == 2) { rdr v = rd_ld(&d); if ((gb >> 3) == 1) have = (uint32_t)parse_node_id(v, &id); }
-          else if ((gb & 7) == 1) { uint64_t v = rd_varint(&d); if ((gb >> 3) == 2) lt = v; }
-          else { rc = SIM_EINVAL; break; }
+        fld g;
+        rdr d = f.d;
+        while (d.off < d.n && rc == SIM_OK) {
+          if (!rd_field(&d, &g, 0)) { rc = SIM_EINVAL; break; }
+          if (g.kb == KB(1, 2)) { if (!once(&es, 1) || !parse_node_id(g.d, &id)) rc = SIM_EINVAL; }
+          else if (g.kb == KB(2, 1)) { if (!once(&es, 2)) rc = SIM_EINVAL; lt = g.v; }
         }
-        if (d.bad || !have || id >= s->N) rc = SIM_EINVAL;
-        if (n_st == cap) { cap *= 2; ids = (uint32_t*)realloc(ids, cap * sizeof(uint32_t)); lts = (uint64_t*)realloc(lts, cap * sizeof(uint64_t)); }
+        if (rc == SIM_OK && (!(es & 1) || id >= s->N)) rc = SIM_EINVAL;
+        if (n_st == cap_st) { cap_st *= 2; ids = (uint32_t*)realloc(ids, cap_st * sizeof(uint32_t)); lts = (uint64_t*)realloc(lts, cap_st * sizeof(uint64_t)); }
         ids[n_st] = id; lts[n_st++] = lt;
-      } else if (ft == 3) {
+        break;
+      }
+      case KB(3, 2): { /* one left member */
         uint32_t id = 0;
-        if (!parse_node_id(d, &id) || id >= s->N) rc = SIM_EINVAL;
+        if (!parse_node_id(f.d, &id) || id >= s->N) rc = SIM_EINVAL;
         if (n_left == cap_left) { cap_left *= 2; left = (uint32_t*)realloc(left, cap_left * sizeof(uint32_t)); }
         left[n_left++] = id;
+        break;
       }
-    } else if (wt == 0) scan.off++;
-    else rc = SIM_EINVAL;
+      case KB(5, 2): { /* UserEvents{ltime 1, events 2 {name 1, payload 2}} (types/user_event.rs): one bucket of the event buffer */
+        uint64_t lt = 0;
+        uint32_t bs = 0, first = n_ev;
+        fld g;
+        rdr d = f.d;
+        while (d.off < d.n && rc == SIM_OK) {
+          if (!rd_field(&d, &g, 0)) { rc = SIM_EINVAL; break; }
+          if (g.kb == KB(1, 1)) { if (!once(&bs, 1)) rc = SIM_EINVAL; lt = g.v; }
+          else if (g.kb == KB(2, 2)) {
+            pp_event e;
+            memset(&e, 0, sizeof e);
+            uint32_t us = 0;
+            fld h;
+            rdr ev = g.d;
+            while (ev.off < ev.n && rc == SIM_OK) {
+              if (!rd_field(&ev, &h, 0)) { rc = SIM_EINVAL; break; }
+              if (h.kb == KB(1, 2)) { if (!once(&us, 1)) rc = SIM_EINVAL; e.name = h.d; }
+              else if (h.kb == KB(2, 2)) { if (!once(&us, 2)) rc = SIM_EINVAL; e.payload = h.d; }
+            }
+            if (n_ev == cap_ev) { cap_ev *= 2; evs = (pp_event*)realloc(evs, cap_ev * sizeof(pp_event)); }
+            evs[n_ev++] = e;
+          }
+        }
+        for (uint32_t i = first; i < n_ev; ++i) evs[i].lt = lt; /* (the bucket's ltime may come behind its events) */
+        break;
+      }
+      default: break;
+    }
   }
-  if (scan.bad) rc = SIM_EINVAL;
+  if (rc == SIM_OK && (seen & 7u) != 7u) rc = SIM_EINVAL;
   for (uint32_t i = 0; i < 3 && rc == SIM_OK; ++i) /* "we subtract 1 since no message with that clock has been sent yet" */
     if (clk[i] > 0) rc = inject_val(s, s->tick, SIM_OP_WITNESS, node, i, 0, clk[i] - 1);
   for (uint32_t i = 0; i < n_left && rc == SIM_OK; ++i) { /* the left members first, one past their status time */
@@ -2214,48 +2272,12 @@ static int deliver_push_pull(osim* s, uint32_t node, rdr body) {
     for (uint32_t i = 0; i < n_left; ++i) is_left |= left[i] == ids[j];
     if (!is_left) rc = inject_val(s, s->tick, SIM_OP_DELIVER, node, ids[j], wire_meta(SIM_K_JOIN, 0, 16) | SIM_DELIVER_MUTE, lts[j]);
   }
-  scan = body;
-  while (scan.off < scan.n && !scan.bad && rc == SIM_OK) { /* pass 2: the event buffer, replayed in order */
-    uint8_t fb = scan.p[scan.off++];
-    uint32_t wt = fb & 7, ft = fb >> 3;
-    if (wt == 1) (void)rd_varint(&scan);
-    else if (wt == 0) scan.off++;
-    else if (wt == 2) {
-      rdr d = rd_ld(&scan);
-      if (ft != 5) continue;
-      uint64_t lt = 0;
-      rdr d1 = d; /* the bucket's ltime may come behind its events: find it first */
-      while (d1.off < d1.n && !d1.bad) {
-        uint8_t gb = d1.p[d1.off++];
-        if ((gb & 7) == 1) { uint64_t v = rd_varint(&d1); if ((gb >> 3) == 1) lt = v; }
-        else if ((gb & 7) == 2) (void)rd_ld(&d1);
-        else break;
-      }
-      while (d.off < d.n && !d.bad && rc == SIM_OK) {
-        uint8_t gb = d.p[d.off++];
-        if ((gb & 7) == 1) (void)rd_varint(&d);
-        else if ((gb & 7) == 2) {
-          rdr ev = rd_ld(&d);
-          if ((gb >> 3) != 2) continue;
-          rdr name = {NULL, 0, 0, 0}, payload = {NULL, 0, 0, 0};
-          while (ev.off < ev.n && !ev.bad) {
-            uint8_t hb = ev.p[ev.off++];
-            if ((hb & 7) != 2) { rc = SIM_EINVAL; break; }
-            rdr v = rd_ld(&ev);
-            if ((hb >> 3) == 1) name = v; else if ((hb >> 3) == 2) payload = v;
-          }
-          if (ev.bad) rc = SIM_EINVAL;
-          if (rc == SIM_OK) {
-            uint32_t key = event_key_of(name.p, name.n, payload.p, payload.n);
-            rc = evreg_put(s, key, name.p, name.n, payload.p, payload.n);
-            if (rc == SIM_OK) rc = inject_val(s, s->tick, SIM_OP_DELIVER, node, key, wire_meta(SIM_K_EVENT, 0, 32) | SIM_DELIVER_MUTE, lt);
-          }
-        } else rc = SIM_EINVAL;
-      }
-      if (d.bad) rc = SIM_EINVAL;
-    } else rc = SIM_EINVAL;
+  for (uint32_t i = 0; i < n_ev && rc == SIM_OK; ++i) { /* the event buffer, replayed in order */
+    uint32_t key = event_key_of(evs[i].name.p, evs[i].name.n, evs[i].payload.p, evs[i].payload.n);
+    rc = evreg_put(s, key, evs[i].name.p, evs[i].name.n, evs[i].payload.p, evs[i].payload.n);
+    if (rc == SIM_OK) rc = inject_val(s, s->tick, SIM_OP_DELIVER, node, key, wire_meta(SIM_K_EVENT, 0, 32) | SIM_DELIVER_MUTE, evs[i].lt);
   }
-  free(ids); free(lts); free(left);
+  free(ids); free(lts); free(left); free(evs);
   return rc;
 }
 int API(deliver_message)(osim* s, uint32_t node, const uint8_t* buf, size_t len, size_t* consumed) {
@@ -2270,29 +2292,25 @@ static int deliver_one(osim* s, uint32_t node, const uint8_t* buf, size_t len, s
   if (tag == 8) { /* Relay (types/message.rs:431-470): NO length of its own — RELAY_NODE_BYTE <node>, RELAY_MSG_BYTE, then a framed message
                    * to the end of the buffer.  `node` forwards the wrapped message to the named node as it is (delegate.rs:262-313:
                    * memberlist.send) — if it is running; a process that is down forwards nothing */
-    uint32_t dest = 0, have = 0;
+    uint32_t dest = 0;
     if (relayed) return SIM_EINVAL; /* a relay inside a relay is not something serf sends */
-    while (r.off < r.n && !r.bad) {
-      uint8_t fb = r.p[r.off++];
-      if (fb == ((1u << 3) | 2u)) { rdr d = rd_ld(&r); have = (uint32_t)parse_node(d, &dest); }
-      else if (fb == ((2u << 3) | 2u)) {
-        if (!have || dest >= s->N || r.off >= r.n) return SIM_EINVAL;
-        uint32_t in_tag = r.p[r.off] >> 3;
-        if (in_tag == 3 || in_tag == 8) return SIM_EINVAL; /* a push-pull does not travel as a user message; no nesting */
-        size_t in_used = 0;
-        int rc = SIM_OK;
-        if (up_of(s, node)) rc = deliver_one(s, dest, r.p + r.off, r.n - r.off, &in_used, 1);
-        else { /* dropped with its relay: still walk the inner frame so that the caller learns its length */
-          rdr in = {r.p + r.off, r.n - r.off, 1, 0};
-          (void)rd_ld(&in);
-          if (in.bad) return SIM_EINVAL;
-          in_used = in.off;
-        }
-        if (rc == SIM_OK && consumed) *consumed = r.off + in_used;
-        return rc;
-      } else return SIM_EINVAL;
+    if (r.off >= r.n || r.p[r.off++] != KB(1, 2)) return SIM_EINVAL;
+    rdr d = rd_ld(&r);
+    if (r.bad || !parse_node(d, &dest) || dest >= s->N) return SIM_EINVAL;
+    if (r.off >= r.n || r.p[r.off++] != KB(2, 2) || r.off >= r.n) return SIM_EINVAL;
+    uint32_t in_tag = r.p[r.off] >> 3;
+    if ((r.p[r.off] & 7) != 2 || in_tag == 3 || in_tag == 8) return SIM_EINVAL; /* a push-pull does not travel as a user message; no nesting */
+    size_t in_used = 0;
+    int rc = SIM_OK;
+    if (up_of(s, node)) rc = deliver_one(s, dest, r.p + r.off, r.n - r.off, &in_used, 1);
+    else { /* dropped with its relay: still walk the inner frame so that the caller learns its length */
+      rdr in = {r.p + r.off, r.n - r.off, 1, 0};
+      (void)rd_ld(&in);
+      if (in.bad) return SIM_EINVAL;
+      in_used = in.off;
     }
-    return SIM_EINVAL;
+    if (rc == SIM_OK && consumed) *consumed = r.off + in_used;
+    return rc;
   }
   rdr body = rd_ld(&r);
   if (r.bad) return SIM_EINVAL;
@@ -2306,55 +2324,61 @@ static int deliver_one(osim* s, uint32_t node, const uint8_t* buf, size_t len, s
     if (rc == SIM_OK && consumed) *consumed = used;
     return rc;
   }
+  if (tag != 1 && tag != 2 && tag != 4 && tag != 5) return SIM_EINVAL; /* not a message of the simulated path */
   uint64_t ltime = 0, flags = 0, qid = 0;
-  uint32_t id = 0, have_id = 0, prune = 0, cc = 0, n_fid = 0, fids[SIM_QF_IDS];
+  uint32_t id = 0, prune = 0, cc = 0, n_fid = 0, fids[SIM_QF_IDS], seen = 0, from = 0;
+  const uint32_t need = tag == 2 ? 3u : tag == 1 ? 5u : tag == 4 ? 1u : (1u | 2u | 4u | 16u | 32u | 64u); /* the fields that must have come */
   rdr name = {NULL, 0, 0, 0}, payload = {NULL, 0, 0, 0};
-  while (body.off < body.n && !body.bad) {
-    uint8_t fb = body.p[body.off++];
-    uint32_t wt = fb & 7, ft = fb >> 3;
-    uint64_t v = 0;
-    rdr d = {NULL, 0, 0, 0};
-    if (tag == 5 && ft == 6) { if (body.off >= body.n) return SIM_EINVAL; v = body.p[body.off++]; } /* relay_factor: one raw byte (query.rs:484-490) */
-    else if (wt == 1) v = rd_varint(&body);
-    else if (wt == 0) { if (body.off >= body.n) return SIM_EINVAL; v = body.p[body.off++]; }
-    else if (wt == 2) d = rd_ld(&body);
-    else return SIM_EINVAL;
-    if (body.bad) return SIM_EINVAL;
-    switch (tag) {
-      case 2: /* JoinMessage: ltime 1, id 2 */
-        if (ft == 1) ltime = v; else if (ft == 2) have_id = parse_node_id(d, &id);
-        break;
-      case 1: /* LeaveMessage: ltime 1, prune 2, id 3 */
-        if (ft == 1) ltime = v; else if (ft == 2) prune = v != 0; else if (ft == 3) have_id = parse_node_id(d, &id);
-        break;
-      case 4: /* UserEventMessage: ltime 1, cc 2, name 3, payload 4 */
-        if (ft == 1) ltime = v; else if (ft == 2) cc = v != 0; else if (ft == 3) name = d; else if (ft == 4) payload = d;
-        break;
-      case 5: /* QueryMessage: ltime 1, id 2, from 3, filters 4, flags 5, relay_factor 6, timeout 7, name 8, payload 9 */
-        if (ft == 1) ltime = v; else if (ft == 2) qid = v; else if (ft == 5) flags = v;
-        else if (ft == 4) { /* Filter (types/filter.rs:176-262): Id = (id_byte <id, length-delimited>)*, Tag = tag_byte <TagFilter> */
-          rdr f = d;
-          while (f.off < f.n) {
-            uint8_t kb = f.p[f.off++];
-            if ((kb >> 3) != 1) return SIM_EINVAL; /* FILTER_TAG_TAG: a tag expression, evaluated by the host (sim_query_filtered) */
-            rdr one = rd_ld(&f);
+  fld f;
+  while (body.off < body.n) {
+    if (!rd_field(&body, &f, tag == 5 ? KB(6, 1) : 0)) return SIM_EINVAL;
+    int ok = 1;
+    if (tag == 2) { /* JoinMessage (types/join.rs:58-105): ltime, id — both required */
+      if (f.kb == KB(1, 1)) { ok = once(&seen, 1); ltime = f.v; }
+      else if (f.kb == KB(2, 2)) ok = once(&seen, 2) && parse_node_id(f.d, &id);
+    } else if (tag == 1) { /* LeaveMessage (types/leave.rs:60-118): ltime, prune (optional), id */
+      if (f.kb == KB(1, 1)) { ok = once(&seen, 1); ltime = f.v; }
+      else if (f.kb == KB(2, 0)) { ok = once(&seen, 2); prune = f.v != 0; }
+      else if (f.kb == KB(3, 2)) ok = once(&seen, 4) && parse_node_id(f.d, &id);
+    } else if (tag == 4) { /* UserEventMessage (types/user_event/message.rs:100-190): ltime required; cc, name, payload */
+      if (f.kb == KB(1, 1)) { ok = once(&seen, 1); ltime = f.v; }
+      else if (f.kb == KB(2, 0)) { ok = once(&seen, 2); cc = f.v != 0; }
+      else if (f.kb == KB(3, 2)) { ok = once(&seen, 4); name = f.d; }
+      else if (f.kb == KB(4, 2)) { ok = once(&seen, 8); payload = f.d; }
+    } else { /* QueryMessage (types/query.rs:200-370): ltime, id, from, flags, relay_factor, timeout required; filters (repeated), name, payload */
+      switch (f.kb) {
+        case KB(1, 1): ok = once(&seen, 1); ltime = f.v; break;
+        case KB(2, 1): ok = once(&seen, 2); qid = f.v; break;
+        case KB(3, 2): ok = once(&seen, 4) && parse_node(f.d, &from); break;
+        case KB(5, 1): ok = once(&seen, 16); flags = f.v; break;
+        case KB(6, 1): ok = once(&seen, 32); break;
+        case KB(7, 1): ok = once(&seen, 64); break;
+        case KB(8, 2): ok = once(&seen, 128); break;
+        case KB(9, 2): ok = once(&seen, 256); break;
+        case KB(4, 2): { /* Filter (types/filter.rs:176-262): Id = (id_byte <id, length-delimited>)*, Tag = tag_byte <TagFilter> */
+          rdr fl = f.d;
+          while (fl.off < fl.n) {
+            if ((fl.p[fl.off++] >> 3) != 1) return SIM_EINVAL; /* a tag expression: evaluated by the host (sim_query_filtered) */
+            rdr one = rd_ld(&fl);
             uint32_t g;
-            if (f.bad || !parse_node_id(one, &g) || g >= s->N || n_fid == SIM_QF_IDS) return SIM_EINVAL;
+            if (fl.bad || !parse_node_id(one, &g) || g >= s->N || n_fid == SIM_QF_IDS) return SIM_EINVAL;
             fids[n_fid++] = g;
           }
+          break;
         }
-        break;
-      default: return SIM_EINVAL; /* not a message of the simulated path */
+        default: break;
+      }
     }
+    if (!ok) return SIM_EINVAL;
   }
-  if (body.bad) return SIM_EINVAL;
+  if ((seen & need) != need) return SIM_EINVAL;
   sim_record rec;
   memset(&rec, 0, sizeof rec);
   rec.val = ltime;
   uint32_t wlen = (uint32_t)used;
   int rc = SIM_OK;
   if (tag == 2 || tag == 1) {
-    if (!have_id || id >= s->N) return SIM_EINVAL;
+    if (id >= s->N) return SIM_EINVAL;
     rec.key = id;
     rec.meta = wire_meta(tag == 2 ? SIM_K_JOIN : SIM_K_LEAVE, prune ? SIM_F_PRUNE : 0, wlen);
   } else if (tag == 4) {

@@ -93,16 +93,52 @@ inline Bytes encode_node(uint32_t gid) {
   put_ld(out, addr, 6);
   return out;
 }
-inline uint32_t decode_node(const Bytes& buf) {
+// ---- decoding, by the reference's rule (types/join.rs:58-105 and its siblings): a body is a run of fields, each opened by ONE key
+// byte (tag << 3 | wire type); a decoder knows the key bytes of its message — a known one that comes twice is an error
+// (DecodeError::duplicate_field), any other key byte is skipped by its wire type (Byte: one raw byte; Varint; LengthDelimited;
+// anything else cannot be skipped: error), and the fields the reference unwraps without a default must have come
+// (DecodeError::missing_field).
+constexpr uint8_t KB(unsigned tag, unsigned wt) { return (uint8_t)((tag << 3) | wt); }
+struct Field {
+  uint8_t kb = 0;  // the key byte
+  uint8_t tag = 0;
+  uint64_t v = 0;  // varint / byte fields
+  Bytes data;      // length-delimited fields
+};
+// raw1: a key byte whose value is ONE raw byte although its wire type says Varint (QueryMessage.relay_factor,
+// types/query.rs:484-490); 0: none
+inline std::vector<Field> fields(const Bytes& body, uint8_t raw1 = 0) {
+  std::vector<Field> out;
   size_t off = 0;
-  bool have = false;
-  uint32_t gid = 0;
-  while (off < buf.size()) {
-    uint8_t tag = split(buf[off++]).second;
-    Bytes data = read_ld(buf, off);
-    if (tag == 1) { gid = parse_node_id(data); have = true; }
+  while (off < body.size()) {
+    Field f;
+    f.kb = body[off++];
+    f.tag = (uint8_t)(f.kb >> 3);
+    const uint8_t ty = f.kb & 7;
+    if ((raw1 && f.kb == raw1) || ty == WIRE_BYTE) {
+      if (off >= body.size()) throw std::invalid_argument("truncated byte field");
+      f.v = body[off++];
+    } else if (ty == WIRE_VARINT) f.v = read_varint(body, off);
+    else if (ty == WIRE_LEN) f.data = read_ld(body, off);
+    else throw std::invalid_argument("a wire type that cannot be skipped");
+    out.push_back(std::move(f));
   }
-  if (!have) throw std::invalid_argument("node without id");
+  return out;
+}
+inline void once(uint32_t& seen, uint32_t bit) {
+  if (seen & bit) throw std::invalid_argument("duplicate field");
+  seen |= bit;
+}
+inline void need(uint32_t seen, uint32_t mask) {
+  if ((seen & mask) != mask) throw std::invalid_argument("missing field");
+}
+inline uint32_t decode_node(const Bytes& buf) {
+  uint32_t gid = 0, seen = 0;
+  for (const Field& f : fields(buf)) {
+    if (f.kb == KB(1, WIRE_LEN)) { once(seen, 1); gid = parse_node_id(f.data); }
+    else if (f.kb == KB(2, WIRE_LEN)) once(seen, 2);
+  }
+  need(seen, 1);
   return gid;
 }
 
@@ -183,28 +219,6 @@ inline size_t encoded_len(const M& m) {  // crate::types::encoded_message_len
   return 1 + varint_len(body) + body;
 }
 
-struct Field {
-  uint8_t tag;
-  uint64_t v = 0;  // varint / byte fields
-  Bytes data;      // length-delimited fields
-};
-inline std::vector<Field> fields(const Bytes& body, int raw_byte_tag = -1) {
-  std::vector<Field> out;
-  size_t off = 0;
-  while (off < body.size()) {
-    auto [ty, tag] = split(body[off++]);
-    Field f;
-    f.tag = tag;
-    if ((int)tag == raw_byte_tag || ty == WIRE_BYTE) {
-      if (off >= body.size()) throw std::invalid_argument("truncated byte field");
-      f.v = body[off++];
-    } else if (ty == WIRE_VARINT) f.v = read_varint(body, off);
-    else if (ty == WIRE_LEN) f.data = read_ld(body, off);
-    else throw std::invalid_argument("unknown wire type");
-    out.push_back(std::move(f));
-  }
-  return out;
-}
 // The framed message at the head of `buf`: its TAG and body; `consumed` = bytes used
 inline std::pair<uint8_t, Bytes> unframe(const Bytes& buf, size_t& consumed) {
   if (buf.empty()) throw std::invalid_argument("empty buffer");
@@ -215,49 +229,57 @@ inline std::pair<uint8_t, Bytes> unframe(const Bytes& buf, size_t& consumed) {
   consumed = off;
   return {tag, std::move(body)};
 }
-inline Join decode_join(const Bytes& body) {
+inline Join decode_join(const Bytes& body) {  // types/join.rs:58-105: ltime, id — both required
   Join m;
+  uint32_t seen = 0;
   for (const Field& f : fields(body)) {
-    if (f.tag == 1) m.ltime = f.v;
-    else if (f.tag == 2) m.id = parse_node_id(f.data);
+    if (f.kb == KB(1, WIRE_VARINT)) { once(seen, 1); m.ltime = f.v; }
+    else if (f.kb == KB(2, WIRE_LEN)) { once(seen, 2); m.id = parse_node_id(f.data); }
   }
+  need(seen, 3);
   return m;
 }
-inline Leave decode_leave(const Bytes& body) {
+inline Leave decode_leave(const Bytes& body) {  // types/leave.rs:60-118: ltime, prune (optional), id
   Leave m;
+  uint32_t seen = 0;
   for (const Field& f : fields(body)) {
-    if (f.tag == 1) m.ltime = f.v;
-    else if (f.tag == 2) m.prune = f.v != 0;
-    else if (f.tag == 3) m.id = parse_node_id(f.data);
+    if (f.kb == KB(1, WIRE_VARINT)) { once(seen, 1); m.ltime = f.v; }
+    else if (f.kb == KB(2, WIRE_BYTE)) { once(seen, 2); m.prune = f.v != 0; }
+    else if (f.kb == KB(3, WIRE_LEN)) { once(seen, 4); m.id = parse_node_id(f.data); }
   }
+  need(seen, 5);
   return m;
 }
-inline UserEvent decode_user_event(const Bytes& body) {
+inline UserEvent decode_user_event(const Bytes& body) {  // types/user_event/message.rs:100-190: ltime required; cc, name, payload
   UserEvent m;
+  uint32_t seen = 0;
   for (const Field& f : fields(body)) {
-    if (f.tag == 1) m.ltime = f.v;
-    else if (f.tag == 2) m.cc = f.v != 0;
-    else if (f.tag == 3) m.name = f.data;
-    else if (f.tag == 4) m.payload = f.data;
+    if (f.kb == KB(1, WIRE_VARINT)) { once(seen, 1); m.ltime = f.v; }
+    else if (f.kb == KB(2, WIRE_BYTE)) { once(seen, 2); m.cc = f.v != 0; }
+    else if (f.kb == KB(3, WIRE_LEN)) { once(seen, 4); m.name = f.data; }
+    else if (f.kb == KB(4, WIRE_LEN)) { once(seen, 8); m.payload = f.data; }
   }
+  need(seen, 1);
   return m;
 }
-inline Query decode_query(const Bytes& body) {
+inline Query decode_query(const Bytes& body) {  // types/query.rs:200-370: ltime, id, from, flags, relay_factor, timeout required
   Query m;
-  for (const Field& f : fields(body, 6)) {
-    switch (f.tag) {
-      case 1: m.ltime = f.v; break;
-      case 2: m.id = (uint32_t)f.v; break;
-      case 3: m.from_node = decode_node(f.data); break;
-      case 4: m.filters.push_back(f.data); break;
-      case 5: m.flags = (uint32_t)f.v; break;
-      case 6: m.relay_factor = (uint8_t)f.v; break;
-      case 7: m.timeout_ms = f.v; break;
-      case 8: m.name = f.data; break;
-      case 9: m.payload = f.data; break;
+  uint32_t seen = 0;
+  for (const Field& f : fields(body, KB(6, WIRE_VARINT))) {
+    switch (f.kb) {
+      case KB(1, WIRE_VARINT): once(seen, 1); m.ltime = f.v; break;
+      case KB(2, WIRE_VARINT): once(seen, 2); if (f.v > 0xFFFFFFFFull) throw std::invalid_argument("query id out of range"); m.id = (uint32_t)f.v; break;
+      case KB(3, WIRE_LEN): once(seen, 4); m.from_node = decode_node(f.data); break;
+      case KB(4, WIRE_LEN): m.filters.push_back(f.data); break;
+      case KB(5, WIRE_VARINT): once(seen, 16); m.flags = (uint32_t)f.v; break;
+      case KB(6, WIRE_VARINT): once(seen, 32); m.relay_factor = (uint8_t)f.v; break;
+      case KB(7, WIRE_VARINT): once(seen, 64); m.timeout_ms = f.v; break;
+      case KB(8, WIRE_LEN): once(seen, 128); m.name = f.data; break;
+      case KB(9, WIRE_LEN): once(seen, 256); m.payload = f.data; break;
       default: break;
     }
   }
+  need(seen, 1 | 2 | 4 | 16 | 32 | 64);
   return m;
 }
 
@@ -267,20 +289,20 @@ struct QueryResponse {
   uint32_t id = 0, from_node = 0, flags = 0;
   Bytes payload;
 };
-inline QueryResponse decode_query_response(const Bytes& body) {
+inline QueryResponse decode_query_response(const Bytes& body) {  // types/query/response.rs:100-243: ltime, id, from, flags required
   QueryResponse m;
-  bool have = false;
+  uint32_t seen = 0;
   for (const Field& f : fields(body)) {
-    switch (f.tag) {
-      case 1: m.ltime = f.v; break;
-      case 2: m.id = (uint32_t)f.v; break;
-      case 3: m.from_node = decode_node(f.data); have = true; break;
-      case 4: m.flags = (uint32_t)f.v; break;
-      case 5: m.payload = f.data; break;
+    switch (f.kb) {
+      case KB(1, WIRE_VARINT): once(seen, 1); m.ltime = f.v; break;
+      case KB(2, WIRE_VARINT): once(seen, 2); if (f.v > 0xFFFFFFFFull) throw std::invalid_argument("query id out of range"); m.id = (uint32_t)f.v; break;
+      case KB(3, WIRE_LEN): once(seen, 4); m.from_node = decode_node(f.data); break;
+      case KB(4, WIRE_VARINT): once(seen, 8); m.flags = (uint32_t)f.v; break;
+      case KB(5, WIRE_LEN): once(seen, 16); m.payload = f.data; break;
       default: break;
     }
   }
-  if (!have) throw std::invalid_argument("query response without a sender");
+  need(seen, 15);
   return m;
 }
 // A Relay (types/message.rs:431-470) at the head of `buf` — RELAY_MESSAGE_BYTE, RELAY_NODE_BYTE <node>, RELAY_MSG_BYTE, then the
@@ -301,35 +323,38 @@ struct PushPull {
   std::vector<uint32_t> left_members;
   std::vector<std::pair<uint64_t, std::vector<std::pair<Bytes, Bytes>>>> events;
 };
-inline PushPull decode_push_pull(const Bytes& body) {
+inline PushPull decode_push_pull(const Bytes& body) {  // types/push_pull.rs:150-320: the three clocks required
   PushPull m;
+  uint32_t seen = 0;
   for (const Field& f : fields(body)) {
-    switch (f.tag) {
-      case 1: m.ltime = f.v; break;
-      case 2: {
-        uint32_t id = 0;
+    switch (f.kb) {
+      case KB(1, WIRE_VARINT): once(seen, 1); m.ltime = f.v; break;
+      case KB(4, WIRE_VARINT): once(seen, 2); m.event_ltime = f.v; break;
+      case KB(6, WIRE_VARINT): once(seen, 4); m.query_ltime = f.v; break;
+      case KB(2, WIRE_LEN): {  // one entry of the status map: {id, ltime}
+        uint32_t id = 0, es = 0;
         uint64_t lt = 0;
-        bool have = false;
         for (const Field& g : fields(f.data)) {
-          if (g.tag == 1) { id = parse_node_id(g.data); have = true; }
-          else if (g.tag == 2) lt = g.v;
+          if (g.kb == KB(1, WIRE_LEN)) { once(es, 1); id = parse_node_id(g.data); }
+          else if (g.kb == KB(2, WIRE_VARINT)) { once(es, 2); lt = g.v; }
         }
-        if (!have) throw std::invalid_argument("status entry without a node");
+        need(es, 1);
         m.status_ltimes.emplace_back(id, lt);
         break;
       }
-      case 3: m.left_members.push_back(parse_node_id(f.data)); break;
-      case 4: m.event_ltime = f.v; break;
-      case 5: {
+      case KB(3, WIRE_LEN): m.left_members.push_back(parse_node_id(f.data)); break;
+      case KB(5, WIRE_LEN): {  // UserEvents{ltime, events {name, payload}} (types/user_event.rs): one bucket of the event buffer
         uint64_t lt = 0;
+        uint32_t bs = 0;
         std::vector<std::pair<Bytes, Bytes>> evs;
         for (const Field& g : fields(f.data)) {
-          if (g.tag == 1) lt = g.v;
-          else if (g.tag == 2) {
+          if (g.kb == KB(1, WIRE_VARINT)) { once(bs, 1); lt = g.v; }
+          else if (g.kb == KB(2, WIRE_LEN)) {
             Bytes name, payload;
+            uint32_t us = 0;
             for (const Field& e : fields(g.data)) {
-              if (e.tag == 1) name = e.data;
-              else if (e.tag == 2) payload = e.data;
+              if (e.kb == KB(1, WIRE_LEN)) { once(us, 1); name = e.data; }
+              else if (e.kb == KB(2, WIRE_LEN)) { once(us, 2); payload = e.data; }
             }
             evs.emplace_back(std::move(name), std::move(payload));
           }
@@ -337,10 +362,10 @@ inline PushPull decode_push_pull(const Bytes& body) {
         m.events.emplace_back(lt, std::move(evs));
         break;
       }
-      case 6: m.query_ltime = f.v; break;
       default: break;
     }
   }
+  need(seen, 7);
   return m;
 }
 

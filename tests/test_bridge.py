@@ -281,20 +281,36 @@ def test_byte_boundary_survives_mutated_frames(oracle):
     # Every message kind the boundary takes, cut short, with bytes flipped, lengths inflated and tails of noise: the decoder
     # returns SIM_OK or an error — it never reads past the buffer (run under ASan / UBSan by `make -C oracle sanitize-test`), and a
     # refused frame leaves no half-scheduled operation behind that would stop the simulation from stepping.
-    import random
-
     n = 64
     sim = _ffi.Sim(oracle, _ffi.make_config(n, **KW))
     sim.query(4, 77, _ffi.F_ACK)
     sim.step(2)
+    taken = refused = 0
+    for it, (node, buf) in enumerate(mutated_frames(n, 3000)):
+        try:
+            used = sim.deliver_message(node, buf)
+            assert 0 < used <= len(buf)
+            taken += 1
+        except _ffi.SimError as e:
+            assert e.code in (_ffi.EINVAL, _ffi.ENOSLOT, _ffi.ETOOBIG), e
+            refused += 1
+        if it % 200 == 199:
+            sim.step(1)   # what was taken is executed; the view may run out of slots (ops_dropped), nothing else may happen
+    assert taken > 300 and refused > 300
+    sim.step(3)
+
+
+def mutated_frames(n, count, seed=4):
+    """(node, bytes) pairs: valid frames of every kind the boundary takes, mutated"""
+    import random
+
     qr = wire.QueryResponse(5, 77, 9, 1, b"pong")
     seeds = [wire.encode_message(m) for m in (
         wire.Join(3, 5), wire.Leave(4, 6, True), wire.UserEvent(7, b"deploy", b"v1", True),
         wire.Query(3, 78, 5, flags=1, relay_factor=2, timeout_ms=1000, name=b"q", payload=b"x"), qr, wire.Relay(7, qr),
         wire.Relay(12, wire.UserEvent(5, b"a", b"b", False)), push_pull_message(), merge_kat_message())]
-    rnd = random.Random(4)
-    taken = refused = 0
-    for it in range(3000):
+    rnd = random.Random(seed)
+    for it in range(count):
         buf = bytearray(rnd.choice(seeds))
         for _ in range(rnd.randint(0, 3)):
             how = rnd.randint(0, 4)
@@ -309,16 +325,6 @@ def test_byte_boundary_survives_mutated_frames(oracle):
             elif how == 4 and len(buf) > 2:
                 i = rnd.randrange(len(buf) - 1)
                 buf[i:i + 1] = bytes([buf[i], buf[i]])                 # a doubled byte
-        if not buf:
-            continue
-        try:
-            used = sim.deliver_message(rnd.randrange(n), bytes(buf))
-            assert 0 < used <= len(buf)
-            taken += 1
-        except _ffi.SimError as e:
-            assert e.code in (_ffi.EINVAL, _ffi.ENOSLOT, _ffi.ETOOBIG), e
-            refused += 1
-        if it % 200 == 199:
-            sim.step(1)   # what was taken is executed; the view may run out of slots (ops_dropped), nothing else may happen
-    assert taken > 300 and refused > 300
-    sim.step(3)
+        node = rnd.randrange(n)
+        if buf:
+            yield node, bytes(buf)

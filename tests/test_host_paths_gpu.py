@@ -228,6 +228,35 @@ def test_query_response_relay_and_push_pull_on_the_gpu(oracle, hiplib, view_slot
                 s.inject(s.tick, op, 1, 1, 0)
 
 
+def test_two_decoders_agree_on_mutated_frames(oracle, hiplib):
+    # tests/test_bridge.py::test_byte_boundary_survives_mutated_frames on BOTH libraries: the C++ decoder of the HIP library
+    # (serf_amd/host/wire.hpp) and the oracle's C one take and refuse the same frames, with the same error and the same number
+    # of bytes used, and what they schedule leaves the two simulations digest-identical
+    from tests.test_bridge import KW, mutated_frames
+
+    n = 64
+    g, o = both(oracle, hiplib, n, **KW)
+    for s in (g, o):
+        s.query(4, 77, _ffi.F_ACK)
+        s.step(2)
+    taken = 0
+    frames = list(mutated_frames(n, 2500, seed=11)) + list(mutated_frames(n, 2500, seed=12))
+    for it, (node, buf) in enumerate(frames):
+        res = []
+        for s in (g, o):
+            try:
+                res.append(("ok", s.deliver_message(node, buf)))
+            except _ffi.SimError as e:
+                res.append(("err", e.code))
+        assert res[0] == res[1], f"frame {it} {buf.hex()}: HIP {res[0]} oracle {res[1]}"
+        taken += res[0][0] == "ok"
+        if it % 100 == 99:
+            g.step(1)
+            o.step(1)
+            assert g.digest() == o.digest(), f"after frame {it}"
+    assert taken > 500
+
+
 def test_reference_merge_remote_state_kat_on_the_gpu(hiplib):
     # delegate_merge_remote_state (serf/base/tests/serf/delegate.rs:117-180), the message in bytes, the HIP library alone
     from tests.test_bridge import check_merge_kat, merge_kat_message
