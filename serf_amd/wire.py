@@ -100,16 +100,19 @@ def encode_node(gid: int) -> bytes:
     return bytes([merge(WIRE_LEN, 1)]) + ld(node_id(gid)) + bytes([merge(WIRE_LEN, 2)]) + ld(addr)
 
 
+def parse_node_id(data: bytes) -> int:
+    """a simulated node's id: the decimal string of its number (digits only, at most 2^32 - 1)"""
+    if not data or not all(0x30 <= c <= 0x39 for c in data):
+        raise ValueError("node id is not a decimal number")
+    v = int(data)
+    if v > 0xFFFFFFFF:
+        raise ValueError("node id out of range")
+    return v
+
+
 def decode_node(buf: bytes) -> int:
-    off, gid = 0, None
-    while off < len(buf):
-        _, tag = split(buf[off])
-        data, off = read_ld(buf, off + 1)
-        if tag == 1:
-            gid = int(data.decode())
-    if gid is None:
-        raise ValueError("node without id")
-    return gid
+    d = _known(buf, {KB(1, WIRE_LEN): "id", KB(2, WIRE_LEN): "addr"}, required=("id",))
+    return parse_node_id(d["id"])
 
 
 def encode_duration(ms: int) -> bytes:
@@ -245,6 +248,12 @@ class Relay:
     msg: object        # the wrapped message (relay_response wraps a QueryResponse: query.rs:523-601)
 
 
+@dataclass
+class ConflictResponse:
+    """ConflictResponseMessage (types/conflict.rs): carried opaquely — SerfDelegate::notify_message has no arm for it (delegate.rs:286-288)"""
+    body: bytes = b""
+
+
 _TAG_OF = {Leave: LEAVE, Join: JOIN, PushPull: PUSH_PULL, UserEvent: USER_EVENT, Query: QUERY, QueryResponse: QUERY_RESPONSE}
 
 
@@ -262,24 +271,51 @@ def encoded_len(msg) -> int:
     return 1 + varint_len(body) + body
 
 
-def _fields(body: bytes, raw_byte_tags=()):
+def KB(tag: int, wt: int) -> int:
+    """a field's key byte"""
+    return (tag << 3) | wt
+
+
+def _fields(body: bytes, raw1: int = 0):
+    """(key byte, value) of every field of a body.  raw1: a key byte whose value is ONE raw byte although its wire type says
+    Varint (QueryMessage.relay_factor: types/query.rs:484-490 writes `buf[offset] = self.relay_factor`)."""
     off = 0
     while off < len(body):
-        ty, tag = split(body[off])
+        kb = body[off]
         off += 1
-        if tag in raw_byte_tags:
-            # QueryMessage.relay_factor: the tag byte says Varint, the value is ONE raw byte (types/query.rs:484-490
-            # writes `buf[offset] = self.relay_factor`), so values >= 128 are not a well-formed varint
+        ty = kb & 7
+        if (raw1 and kb == raw1) or ty == WIRE_BYTE:
+            if off >= len(body):
+                raise ValueError("truncated byte field")
             v, off = body[off], off + 1
         elif ty == WIRE_VARINT:
             v, off = read_varint(body, off)
-        elif ty == WIRE_BYTE:
-            v, off = body[off], off + 1
         elif ty == WIRE_LEN:
             v, off = read_ld(body, off)
         else:
-            raise ValueError(f"wire type {ty}")
-        yield tag, v
+            raise ValueError(f"wire type {ty} cannot be skipped")
+        yield kb, v
+
+
+def _known(body: bytes, table: dict, required=(), repeated=(), raw1: int = 0) -> dict:
+    """The decoders' rule — the reference's (types/join.rs:58-105 and its siblings): a field is opened by ONE key byte; a known key
+    byte that comes twice is an error (DecodeError::duplicate_field) unless the field repeats, any other key byte is skipped by
+    its wire type, and the fields the reference unwraps without a default must have come (DecodeError::missing_field)."""
+    out = {name: [] for name in repeated}
+    for kb, v in _fields(body, raw1):
+        name = table.get(kb)
+        if name is None:
+            continue
+        if name in repeated:
+            out[name].append(v)
+        elif name in out:
+            raise ValueError(f"duplicate field {name}")
+        else:
+            out[name] = v
+    for name in required:
+        if name not in out:
+            raise ValueError(f"missing field {name}")
+    return out
 
 
 def decode_message(buf: bytes):
@@ -290,7 +326,7 @@ def decode_message(buf: bytes):
     if ty != WIRE_LEN:
         raise ValueError("message type byte is not length-delimited")
     if tag == RELAY:   # no length of its own: node, then the wrapped message to the end of the buffer
-        if buf[1] != merge(WIRE_LEN, 1):
+        if len(buf) < 3 or buf[1] != merge(WIRE_LEN, 1):
             raise ValueError("relay message without a node")
         node, off = read_ld(buf, 2)
         if off >= len(buf) or buf[off] != merge(WIRE_LEN, 2):
@@ -298,45 +334,49 @@ def decode_message(buf: bytes):
         inner, used = decode_message(buf[off + 1:])
         return Relay(decode_node(node), inner), off + 1 + used
     body, end = read_ld(buf, 1)
-    f = list(_fields(body, raw_byte_tags=(6,) if tag == QUERY else ()))
+    V, L, B = WIRE_VARINT, WIRE_LEN, WIRE_BYTE
     if tag == JOIN:
-        d = dict(f)
-        msg = Join(d[1], int(d[2].decode()))
+        d = _known(body, {KB(1, V): "ltime", KB(2, L): "id"}, required=("ltime", "id"))
+        msg = Join(d["ltime"], parse_node_id(d["id"]))
     elif tag == LEAVE:
-        d = dict(f)
-        msg = Leave(d[1], int(d[3].decode()), bool(d.get(2, 0)))
+        d = _known(body, {KB(1, V): "ltime", KB(2, B): "prune", KB(3, L): "id"}, required=("ltime", "id"))
+        msg = Leave(d["ltime"], parse_node_id(d["id"]), bool(d.get("prune", 0)))
     elif tag == USER_EVENT:
-        d = dict(f)
-        msg = UserEvent(d[1], d.get(3, b""), d.get(4, b""), bool(d.get(2, 0)))
+        d = _known(body, {KB(1, V): "ltime", KB(2, B): "cc", KB(3, L): "name", KB(4, L): "payload"}, required=("ltime",))
+        msg = UserEvent(d["ltime"], d.get("name", b""), d.get("payload", b""), bool(d.get("cc", 0)))
     elif tag == QUERY:
-        d = {t: v for t, v in f if t != 4}
-        msg = Query(d[1], d[2], decode_node(d[3]), d[5], d[6], d[7], d.get(8, b""), d.get(9, b""), [v for t, v in f if t == 4])
+        d = _known(body, {KB(1, V): "ltime", KB(2, V): "id", KB(3, L): "from", KB(4, L): "filters", KB(5, V): "flags", KB(6, V): "relay_factor",
+                          KB(7, V): "timeout", KB(8, L): "name", KB(9, L): "payload"},
+                   required=("ltime", "id", "from", "flags", "relay_factor", "timeout"), repeated=("filters",), raw1=KB(6, V))
+        if d["id"] > 0xFFFFFFFF:
+            raise ValueError("query id out of range")
+        msg = Query(d["ltime"], d["id"], decode_node(d["from"]), d["flags"], d["relay_factor"], d["timeout"], d.get("name", b""),
+                    d.get("payload", b""), d["filters"])
     elif tag == QUERY_RESPONSE:
-        d = dict(f)
-        msg = QueryResponse(d[1], d[2], decode_node(d[3]), d.get(4, 0), d.get(5, b""))
+        d = _known(body, {KB(1, V): "ltime", KB(2, V): "id", KB(3, L): "from", KB(4, V): "flags", KB(5, L): "payload"},
+                   required=("ltime", "id", "from", "flags"))
+        if d["id"] > 0xFFFFFFFF:
+            raise ValueError("query id out of range")
+        msg = QueryResponse(d["ltime"], d["id"], decode_node(d["from"]), d["flags"], d.get("payload", b""))
     elif tag == PUSH_PULL:
-        msg = PushPull(0)
-        for t, v in f:
-            if t == 1:
-                msg.ltime = v
-            elif t == 2:
-                d = dict(_fields(v))
-                msg.status_ltimes[int(d[1].decode())] = d[2]
-            elif t == 3:
-                msg.left_members.append(int(v.decode()))
-            elif t == 4:
-                msg.event_ltime = v
-            elif t == 5:
-                lt, evs = 0, []
-                for t2, v2 in _fields(v):
-                    if t2 == 1:
-                        lt = v2
-                    else:
-                        d = dict(_fields(v2))
-                        evs.append((d.get(1, b""), d.get(2, b"")))
-                msg.events.append((lt, evs))
-            elif t == 6:
-                msg.query_ltime = v
+        d = _known(body, {KB(1, V): "ltime", KB(2, L): "status", KB(3, L): "left", KB(4, V): "event_ltime", KB(5, L): "events", KB(6, V): "query_ltime"},
+                   required=("ltime", "event_ltime", "query_ltime"), repeated=("status", "left", "events"))
+        msg = PushPull(d["ltime"], event_ltime=d["event_ltime"], query_ltime=d["query_ltime"])
+        msg.status_list = []   # in message order (a dict loses an id that comes twice)
+        for v in d["status"]:
+            e = _known(v, {KB(1, L): "id", KB(2, V): "ltime"}, required=("id",))
+            msg.status_list.append((parse_node_id(e["id"]), e.get("ltime", 0)))
+            msg.status_ltimes[msg.status_list[-1][0]] = msg.status_list[-1][1]
+        msg.left_members = [parse_node_id(v) for v in d["left"]]
+        for v in d["events"]:
+            e = _known(v, {KB(1, V): "ltime", KB(2, L): "events"}, repeated=("events",))
+            evs = []
+            for v2 in e["events"]:
+                u = _known(v2, {KB(1, L): "name", KB(2, L): "payload"})
+                evs.append((u.get("name", b""), u.get("payload", b"")))
+            msg.events.append((e.get("ltime", 0), evs))
+    elif tag == CONFLICT_RESPONSE:
+        msg = ConflictResponse(body)
     else:
         raise ValueError(f"message tag {tag} is not on the simulated path")
     return msg, end

@@ -328,3 +328,59 @@ def mutated_frames(n, count, seed=4):
         node = rnd.randrange(n)
         if buf:
             yield node, bytes(buf)
+
+
+def test_python_decoder_and_oracle_agree_on_mutated_frames(oracle):
+    # the third codec (serf_amd/wire.py, the Python host's) against the oracle's C decoder, frame by frame: what Python cannot
+    # decode the boundary refuses; what Python decodes the boundary takes — with the same byte count — unless the MEANING is out
+    # of the simulated cluster's range (a node id >= n, a query id of 0, a tag filter, a push-pull inside a relay ...), which is
+    # checked here on the decoded message
+    n = 64
+    sim = _ffi.Sim(oracle, _ffi.make_config(n, **dict(KW, view_slots=0)))
+
+    def in_range(m, relayed=False):
+        if isinstance(m, (wire.Join, wire.Leave)):
+            return m.id < n
+        if isinstance(m, wire.Query):
+            if not m.id:
+                return False
+            ids = 0
+            for f in m.filters:
+                off = 0
+                while off < len(f):
+                    if f[off] >> 3 != 1:
+                        return False
+                    try:
+                        one, off = wire.read_ld(f, off + 1)
+                        g = wire.parse_node_id(one)
+                    except ValueError:
+                        return False
+                    ids += 1
+                    if g >= n or ids > 12:   # SIM_QF_IDS
+                        return False
+            return True
+        if isinstance(m, wire.QueryResponse):
+            return m.from_node < n and m.id != 0
+        if isinstance(m, wire.Relay):
+            return not relayed and m.node < n and not isinstance(m.msg, (wire.PushPull, wire.Relay)) and in_range(m.msg, True)
+        if isinstance(m, wire.PushPull):
+            return not relayed and all(i < n for i, _ in m.status_list) and all(i < n for i in m.left_members)
+        return True
+
+    agree = 0
+    for node, buf in mutated_frames(n, 4000, seed=21):
+        try:
+            m, used = wire.decode_message(buf)
+        except (ValueError, IndexError, KeyError):
+            m = None
+        try:
+            got = sim.deliver_message(node, buf)
+        except _ffi.SimError as e:
+            assert e.code == _ffi.EINVAL, e
+            got = None
+        if m is None or not in_range(m):
+            assert got is None, f"{buf.hex()}: Python refuses ({m}), the boundary takes {got} bytes"
+        else:
+            assert got == used, f"{buf.hex()}: Python decodes {m} from {used} bytes, the boundary says {got}"
+            agree += 1
+    assert agree > 400
