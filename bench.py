@@ -5,8 +5,9 @@ A "step" is one gossip tick of every simulated node.  N=1: BASELINE.json configs
 (1 Mi nodes, fan-out 4, HBM-roofline report), measured on BOTH fan-out models in one run: the HEADLINE (`value`,
 `ms_per_step`, `roofline`) is memberlist's literal kRandomNodes peer selection — the reference's —,
 the per-tick bijection (every node receives exactly `fanout` packets) is reported next to it under `fanout_models`.
-N>1: one shard of 1 Mi nodes per GPU (weak scaling), the round's RCCL all-to-all issued chunk-wise and overlapped
-with compute (bijection: the random fan-out is not sharded yet).  Prints ONE JSON line on rank 0.
+N>1: one shard of 1 Mi nodes per GPU (weak scaling), the SAME two models, kRandomNodes the headline at every N: its packets
+are packed per destination shard behind the tick's launch and travel as one equal-split RCCL all-to-all per round (the
+bijection's all-to-all is issued chunk-wise and overlapped with compute).  Prints ONE JSON line on rank 0.
 
 `python bench.py --gpus N` without a launcher (WORLD_SIZE unset) starts its N ranks itself (one process per GPU,
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set for them, rendezvous on 127.0.0.1) and supervises them: a rank that dies
@@ -45,8 +46,10 @@ def b_tick_layout(f):
     return 2 * 64 + (2 * 16 * 4 + 4 * 16) + (48 + 4) + f * (48 + 4) + f * 4 * (4 + 16)
 
 
-PMC_TRAFFIC = {"krandomnodes": ("profiles/r04_pmc_traffic_krandomnodes.json",),  # newest first
-               "bijection": ("profiles/r04_pmc_traffic_bijection.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")}
+PMC_TRAFFIC = {"krandomnodes": ("profiles/r05_pmc_traffic_krandomnodes.json", "profiles/r04_pmc_traffic_krandomnodes.json"),  # newest first
+               "bijection": ("profiles/r05_pmc_traffic_bijection.json", "profiles/r04_pmc_traffic_bijection.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")}
+# ... and over the launches of the LONG window (its own PMC passes: the bytes a launch moves follow the load of the ticks it covers)
+PMC_TRAFFIC_LONG = {"krandomnodes": ("profiles/r05_pmc_traffic_krandomnodes_long.json",), "bijection": ("profiles/r05_pmc_traffic_bijection_long.json",)}
 LONG_WINDOW = 300  # ticks of the second timed window (with --steps < 300): long enough to hold a push-pull batch and recycling passes
 KERNEL_SOURCE = os.path.join("serf_amd", "csrc", "serf_sim.hip")
 # rounds-to-99 %: every user event the workload issues in CONV_WINDOW ticks starting CONV_OFFSET ticks after the
@@ -94,11 +97,11 @@ def kernel_source_sha16():
         return None
 
 
-def measured_traffic(model):
+def measured_traffic(model, long=False):
     """HBM bytes per tick-kernel launch from the newest committed PMC profile of that fan-out model — valid only for the
     kernel source it was measured on (the profile records the source's hash; a file without one is treated as stale)."""
     sha = kernel_source_sha16()
-    for rel in PMC_TRAFFIC[model]:
+    for rel in (PMC_TRAFFIC_LONG if long else PMC_TRAFFIC)[model]:
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
             continue
@@ -271,7 +274,7 @@ def parse_args(argv=None):
     if a.random_fanout:
         a.fanout_model = "krandomnodes"
     if a.force_sharded and a.fanout_model == "both":
-        a.fanout_model = "bijection"   # (one model per sharded run; --fanout-model krandomnodes: the random fan-out's all-gather path)
+        a.fanout_model = "bijection"   # (the one-rank rehearsal: one model per run; --fanout-model krandomnodes: the packed slabs)
     return a
 
 
@@ -368,11 +371,7 @@ def run(args, lib=None, dev=None, backend="nccl"):
     n_total = args.nodes_per_gpu * world
     if lib is None:
         lib = serf_amd.load()
-    # which fan-out models: both at N = 1 (the reference's first: it is the headline), the bijection alone when sharded
-    if world > 1:   # one model per sharded run: the bijection (its all-to-all moves f packets per node) unless asked otherwise —
-        # the random fan-out on shards exchanges every shard's cells with everybody (an all-gather: O(N) bytes per shard)
-        models = ["krandomnodes" if args.fanout_model == "krandomnodes" else "bijection"]
-    elif args.fanout_model == "both":
+    if args.fanout_model == "both":   # at every N: the reference's model first — the headline, ONE series from 1 to 8 GPUs —, the bijection next to it
         models = ["krandomnodes", "bijection"]
     else:
         models = [args.fanout_model]
@@ -606,6 +605,23 @@ def run(args, lib=None, dev=None, backend="nccl"):
                         f"issues in ticks [{conv_first}, {conv_first + CONV_WINDOW}) (a fixed window: independent of --steps / --warmup), "
                         "all outstanding events polled once per tick (sim_convergence_many)"}
 
+    def exchange_of(m):
+        """the `exchange` object of one measured sharded cluster"""
+        xb = m["exchange_bytes"]
+        packed = m["model"] == "krandomnodes"   # the random fan-out on shards: the slabs are packed from the packets the senders keep
+        return {"chunks": m["chunks"], "exchange_ms": m["exchange_ms"], "kernel_ms": m["timed"]["kern_s"] * 1e3,
+                           "collective": ("equal-split all-to-all of packed slabs (SIM_XCHG_PACKED: (target, sender, slot)-sorted 64-byte cells, "
+                                          "one count byte per target; mean + 12 sigma of room per slab)") if packed else "equal-split all-to-all per chunk",
+                           "serial_ms_per_step": m["serial_ms"], "overlapped_ms_per_step": m["timed"]["dt"] / args.steps * 1e3,
+                           "bytes_per_peer": xb // world, "bytes_per_gpu_per_tick": xb,
+                           "bytes_leaving_gpu_per_tick": xb // world * (world - 1),
+                           "bytes_arriving_per_gpu_per_tick": xb // world * (world - 1),
+                           "packet_bytes_per_gpu_per_tick": args.fanout * args.nodes_per_gpu * (64 if packed else 48) * max(1, args.pkt_records // 4),
+                           "what": f"the timed region runs each tick as {m['chunks']} chunk launches with the all-to-all of chunk c in flight "
+                                   "while chunk c + 1 computes (overlapped_ms_per_step = ms_per_step); exchange_ms and serial_ms_per_step come "
+                                   f"from {m['diag_ticks']} further ticks with the collectives run one after the other between events (rank 0): "
+                                   "exchange_ms = all-to-alls of one round, serial_ms_per_step = that round without overlap"}
+
     def summary_of(m):
         t, lw = m["timed"], m["long"]
         d = {"what": MODEL_WHAT[m["model"]], "value": n_total * args.steps / t["dt"], "unit": "member-ticks/s",
@@ -613,9 +629,23 @@ def run(args, lib=None, dev=None, backend="nccl"):
              "rounds_to_99": rounds_of(m), "model_bound_drops": m["load2"]["drops"],
              "records_per_packet": [round(m["load0"]["records_per_packet"], 3), round(m["load1"]["records_per_packet"], 3)],
              "deepest_queue": m["load1"]["max_queue"]}
+        if sharded:
+            d["exchange"] = exchange_of(m)
         if lw:
+            bt = b_tick_v0(args.fanout)
+            alg = args.nodes_per_gpu * bt / lw["kern_s"] / 1e9
+            tr, prov = measured_traffic(m["model"], long=True)
+            ok = bool(tr) and prov["matches_this_kernel"] and args.pkt_records == 4 and args.rate == 0.25 and args.nodes_per_gpu == 1 << 20 and world == 1 \
+                and prov["timed_ticks_of_the_profile"] == {"steps": long_window(args), "warmup": args.warmup + args.steps}
             d["long_window"] = {"steps": long_window(args), "value": n_total * long_window(args) / lw["dt"], "ms_per_step": lw["dt"] / long_window(args) * 1e3,
                                 "kernel_ms": lw["kern_s"] * 1e3, "kernel_ms_max": lw["kmax"],
+                                "roofline": {"bound": "hbm", "achieved": alg, "peak": 8000.0, "unit": "GB/s", "frac": alg / 8000.0,
+                                             "traffic": tr if ok else None, "frac_measured": (tr / lw["kern_s"] / 1e9 / 8000.0) if ok else None,
+                                             "traffic_provenance": prov,
+                                             "what": "the same two figures as `roofline`, over the long window's launches: the contract's formula, and the "
+                                                     "bytes the PMC counters saw on these very ticks over the kernel's time (null without a profile of this "
+                                                     "kernel source and these ticks)"},
+                                "timed_region_over_long_window_kernel_ms": t["kern_s"] / lw["kern_s"],
                                 "ticks": [m["parity_ticks"][1], m["parity_ticks"][1] + long_window(args) - 1],
                                 "what": "the ticks right behind the timed region, measured the same way: a push-pull batch (every 300 ticks at this "
                                         "size) and the recycling passes (every 75) fall inside"}
@@ -645,7 +675,9 @@ def run(args, lib=None, dev=None, backend="nccl"):
                                    f"{args.steps} ticks the driver asks for (not SURVEY §8d's 1 000)"
                                    + (f", the {long_window(args)} ticks behind it are measured as well (long_window)" if long_window(args) else ""),
                        "fanout_model": models[0],
-                       "parallelism": (f"node-id range shards x{world}, {args.chunks} chunk-wise all-to-all per tick, overlapped with compute"
+                       "parallelism": ((f"node-id range shards x{world}; " + ("kRandomNodes: packets packed per destination shard behind the tick's launch, one "
+                                                                               "equal-split all-to-all of the packed slabs per round" if models[0] == "krandomnodes" else
+                                                                               f"{args.chunks} chunk-wise all-to-all per tick, overlapped with compute"))
                                        if sharded else "single GPU"),
                        "preroll": args.preroll, "schedule_horizon": horizon(args),
                        "timed_ticks": [args.preroll + args.warmup, args.preroll + args.warmup + args.steps - 1],
@@ -664,19 +696,13 @@ def run(args, lib=None, dev=None, backend="nccl"):
         }
         if head["long"]:
             out["long_window"] = out["fanout_models"][models[0]]["long_window"]
+            # the driver's K steps are a SAMPLE of the run: the long window (the 300 ticks behind them, a push-pull batch and four
+            # recycling passes inside) is the representative figure — VERDICT r4 item 3
+            out["value_long_window"] = out["long_window"]["value"]
+            out["config"]["workload"] += (f"; kernel time of the timed region / of the long window = {out['long_window']['timed_region_over_long_window_kernel_ms']:.2f} "
+                                          "(value_long_window is the representative rate)")
         if sharded:
-            xb = head["exchange_bytes"]
-            gather = models[0] == "krandomnodes"   # the random fan-out on shards: an all-gather of the shards' cells (every peer gets all of xb)
-            out["exchange"] = {"chunks": head["chunks"], "exchange_ms": head["exchange_ms"], "kernel_ms": t["kern_s"] * 1e3,
-                               "collective": "all-gather of the shard's cells, plane by plane" if gather else "equal-split all-to-all per chunk",
-                               "serial_ms_per_step": head["serial_ms"], "overlapped_ms_per_step": t["dt"] / args.steps * 1e3,
-                               "bytes_per_peer": xb if gather else xb // world, "bytes_per_gpu_per_tick": xb,
-                               "bytes_leaving_gpu_per_tick": xb * (world - 1) if gather else xb // world * (world - 1),
-                               "bytes_arriving_per_gpu_per_tick": xb * (world - 1) if gather else xb // world * (world - 1),
-                               "what": f"the timed region runs each tick as {head['chunks']} chunk launches with the all-to-all of chunk c in flight "
-                                       "while chunk c + 1 computes (overlapped_ms_per_step = ms_per_step); exchange_ms and serial_ms_per_step come "
-                                       f"from {head['diag_ticks']} further ticks with the collectives run one after the other between events (rank 0): "
-                                       "exchange_ms = all-to-alls of one round, serial_ms_per_step = that round without overlap"}
+            out["exchange"] = exchange_of(head)
             out["distributed"] = {"backend": dist.get_backend() if world > 1 else None, "world_size": world,
                                   "collective_library": head["collectives"]}
         if world == 1 and on_gpu and not args.no_second_load and args.pkt_records == 4 and not sharded:

@@ -29,7 +29,7 @@ extern "C" {
 
 /* ------------------------------------------------------------------ constants */
 
-#define SIM_ABI_VERSION 12u
+#define SIM_ABI_VERSION 13u
 
 #define SIM_P 4u  /* piggyback records per packet PAGE (48-byte cell: 4 records x 12 wire bytes) */
 #define SIM_PKT_BYTES 1400u /* byte budget of a gossip packet: memberlist's UDP payload limit (lan() and wan()); a packet
@@ -287,10 +287,13 @@ typedef struct sim_config {
                                    * images): inbox[k * PG + pg][SENDER] — on a shard: its own senders.
                                    * (r4) The packets stay in their senders' cells and every receiver pulls what the tick's graph
                                    * (a CSR the HIP library builds two ticks ahead with its own two-level bucket sort) addresses
-                                   * to it.  On SHARDS (r4): every shard draws the whole cluster's targets and
-                                   * keeps its own nodes' rows; the round's exchange is an ALL-GATHER of the shards' cells
-                                   * (sim_exchange_layout) — O(N) bytes per shard and round where the bijection's all-to-all
-                                   * moves O(f N / V): correct and checkpointable, not the scalable form */
+                                   * to it.  On SHARDS (r5): every shard draws the targets of its OWN senders,
+                                   * sorts the (target, sender, slot) triples, and PACKS the packets bound for shard h into one
+                                   * dense slab in that order, with one count byte per target of h; the round's exchange is ONE
+                                   * equal-split all-to-all of those slabs (sim_exchange_layout: SIM_XCHG_PACKED) — f * 64 B *
+                                   * M * (V - 1) / V bytes leave a GPU per round (+ 2 % of room, + 1 byte per target) —, and the
+                                   * receiver's row is V sorted runs, one per source shard, in ascending source = ascending
+                                   * sender order.  No index and no count travels ahead; nobody draws anybody else's targets. */
 /* random fan-out only: broadcast requests one node can park in ONE tick beyond f * pkt_records + SIM_S + 1 (the bijection's
  * maximum; with a random in-degree there is none).  A counted model bound, the same in the oracle. */
 #define SIM_RF_PEND_EXTRA 32u
@@ -545,16 +548,35 @@ int sim_bind_exchange(sim_handle* h, void* send_dev, void* recv_dev);
  * sim_step_end  — and every exchange of tick t must have completed before sim_step_chunk of tick t + 1. */
 int sim_bind_exchange2(sim_handle* h, void* send_dev, void* recv0_dev, void* recv1_dev);
 int sim_exchange_chunks(const sim_handle* h, uint32_t* chunks, size_t* bytes_per_chunk);
-/* (r4) What the round's exchange of this handle IS.  SIM_XCHG_ALL_TO_ALL: the slabs above — one plane, receive buffer as big as
- * the send buffer.  SIM_XCHG_ALL_GATHER (SIM_CF_RANDOM_FANOUT on a shard): memberlist's kRandomNodes sends a packet to ANY node
- * of the cluster, so the packets stay in their senders' cells on a shard too — the send buffer is the shard's cells,
- * `planes` planes of send_plane_bytes each ([plane][local sender]) — and the exchange gathers plane j of every shard, in rank
- * order, into plane j of the receive buffer ([plane][global sender]: recv_bytes = shard count x the send buffer), from which
- * every node pulls what the tick's graph addresses to it.  The host moves plane j with one all-gather of send_plane_bytes per
- * rank (serf_amd/shard.py: all_gather_into_tensor; sim_exchange_chunk: ncclAllGather); both buffers are bound with
- * sim_bind_exchange2 as before (recv0 / recv1 of recv_bytes each). */
+/* (r5) The same with the sizes of the caller's buffers: SIM_EINVAL when `send_bytes` is less than sim_exchange_bytes() or
+ * `recv_bytes` (of recv0 and of recv1 each) less than sim_exchange_layout()'s recv_bytes — the unsized calls above trust the caller. */
+int sim_bind_exchange3(sim_handle* h, void* send_dev, size_t send_bytes, void* recv0_dev, void* recv1_dev, size_t recv_bytes);
+/* (r4, r5) What the round's exchange of this handle IS.  Every kind is an EQUAL-SPLIT all-to-all of the send buffer: V slabs of
+ * send_plane_bytes / V bytes, slab p to rank p, slab g of the receive buffer from rank g (torch.distributed.all_to_all_single,
+ * or sim_exchange_chunk); `planes` is 1 and recv_bytes = send_plane_bytes.
+ *   SIM_XCHG_ALL_TO_ALL  the bijection's slabs [C][V][fp][M / V / C], written by the tick kernel itself.
+ *   SIM_XCHG_PACKED      SIM_CF_RANDOM_FANOUT on a shard (r5).  memberlist's kRandomNodes sends a packet to ANY node, so there is no
+ *                        dense slab the tick kernel could write into: the packets stay in their senders' cells (as on one GPU) and
+ *                        sim_step_chunk PACKS, behind the tick's launch, the packets bound for shard h into slab h in (target,
+ *                        sender, slot) order — the order of a sort of the shard's own f * M (target, sender, slot) triples —
+ *                        together with one count byte per target of h.  A slab holds serf_rf_slab_cap(f, M, V) packets (mean + 12
+ *                        sigma of the binomial: a slab that would overflow makes the step fail with SIM_ERANGE).  sim_step_begin of
+ *                        the next tick turns the V slabs it received into the tick's rows.  The slab format is the
+ *                        implementation's own (HIP: 64-byte cells; oracle: 48-byte packets with explicit targets): ranks of one
+ *                        run use one implementation.  AFTER sim_restore the handle has packed the restored packets in flight into
+ *                        the send buffer again and the host has to run the exchange once more before the next tick.
+ * (SIM_XCHG_ALL_GATHER, ABI 12's O(N)-per-shard form of the random fan-out, is retired: no handle reports it.) */
 #define SIM_XCHG_ALL_TO_ALL 0u
 #define SIM_XCHG_ALL_GATHER 1u
+#define SIM_XCHG_PACKED 2u
+/* packets one (source shard, destination shard) slab of SIM_XCHG_PACKED holds: the mean f * M / V of the binomial, 12 sigma and
+ * some — or everything the source can send, if that is less (tiny clusters).  Integer arithmetic: the same on every side. */
+static inline uint32_t serf_rf_slab_cap(uint32_t fanout, uint32_t M, uint32_t V) {
+  uint64_t all = (uint64_t)fanout * M, mean = (all + V - 1) / V, r = 0;
+  while ((r + 1) * (r + 1) <= mean) ++r; /* floor(sqrt(mean)) */
+  uint64_t cap = mean + 12 * (r + 1) + 64;
+  return (uint32_t)(cap < all ? cap : all);
+}
 int sim_exchange_layout(const sim_handle* h, uint32_t* kind, uint32_t* planes, size_t* send_plane_bytes, size_t* recv_bytes);
 /* The round's all-to-all ISSUED BY THE LIBRARY over RCCL (grouped ncclSend / ncclRecv pairs over xGMI) — for a
  * host that has no collective library of its own (the north star's Rust host) and to take the per-chunk host cost out of the

@@ -317,6 +317,12 @@ struct sim_handle {
   uint32_t* rtgt;  /* [f][Nl] target of the packet in the same cell of the inbox being filled */
   uint32_t* rcsr;  /* [Nl + 1] */
   uint32_t* rsrc;  /* [f * Nl] cell indices (k * Nl + sender), grouped by target */
+  /* ... on a shard (SIM_XCHG_PACKED, include/serf_sim.h): the packets stay in the senders' cells here too (inbox[], like a handle
+   * that is not a shard); step_end packs the ones bound for shard h into slab h of the send buffer, (target, sender, slot) order,
+   * step_begin of the next tick makes the rows from the V slabs that arrived: rsrc = source shard * rf_cap + place in its slab */
+  uint32_t rf_cap;   /* packets a slab holds (serf_rf_slab_cap) */
+  uint32_t rf_rcap;  /* entries rsrc has room for */
+  int rf_err;        /* a slab overflowed (here or at a sender): the step reports SIM_ERANGE */
   /* content of the user events the library was told in bytes (sim_deliver_message, sim_user_event_bytes): key ->
    * name, payload — what sim_peek_packet encodes */
   /* probes of the running tick that failed on a target without a view slot: (prober, target) pairs, appended by
@@ -1445,6 +1451,13 @@ static uint32_t rf_draw(const osim* s, uint64_t tick, uint32_t gid, uint32_t fef
   }
   return nc;
 }
+/* ---- SIM_CF_RANDOM_FANOUT on a shard: the packed exchange (include/serf_sim.h SIM_XCHG_PACKED).  A slab = header, the
+ * (local target, sender * 4 + slot) of every packet in it, the packets (PG pages each), in (target, sender, slot) order ---- */
+typedef struct { uint32_t n, over, pad0, pad1; } rf_slab_hdr;
+static inline size_t rf_slab_bytes(const osim* s) { return sizeof(rf_slab_hdr) + (size_t)s->rf_cap * (8u + (size_t)s->PG * sizeof(sim_packet)); }
+static inline uint8_t* rf_slab(const osim* s, const void* buf, uint32_t g) { return (uint8_t*)buf + (size_t)g * rf_slab_bytes(s); }
+static inline uint32_t* rf_slab_idx(uint8_t* slab) { return (uint32_t*)(slab + sizeof(rf_slab_hdr)); }
+static inline sim_packet* rf_slab_pk(const osim* s, uint8_t* slab) { return (sim_packet*)(slab + sizeof(rf_slab_hdr) + (size_t)s->rf_cap * 8u); }
 static void tick_node(osim* s, const tickp* p, uint32_t l) {
   nctx c;
   nctx_init(&c, s, l);
@@ -1477,12 +1490,13 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
   if (up) {
     if (row->next_seq > 1023u - 64u) queue_renorm(row, q);
     if (s->tick > 0 && s->rfan) { /* variable in-degree: every packet addressed to this node, (sender, k) order */
-      const uint32_t NS = RF_SH(s) ? s->N : s->Nl; /* senders a cell plane spans: the shard's own, or — gathered — everybody's */
-      const sim_packet* cells = RF_SH(s) ? s->xrecv : s->inbox[s->tick & 1];
-      for (uint32_t i = s->rcsr[l]; i < s->rcsr[l + 1]; ++i) { /* rsrc: k * NS + sender */
+      const uint32_t NS = s->Nl;
+      const sim_packet* cells = s->inbox[s->tick & 1];
+      for (uint32_t i = s->rcsr[l]; i < s->rcsr[l + 1]; ++i) { /* rsrc: k * NS + sender — on a shard: source shard * rf_cap + place in its slab */
         uint32_t k = s->rsrc[i] / NS, snd = s->rsrc[i] % NS;
         for (uint32_t pg = 0; pg < PG; ++pg) {
-          const sim_packet* pk = &cells[((size_t)k * PG + pg) * NS + snd];
+          const sim_packet* pk = RF_SH(s) ? &rf_slab_pk(s, rf_slab(s, s->xrecv, s->rsrc[i] / s->rf_cap))[(size_t)(s->rsrc[i] % s->rf_cap) * PG + pg]
+                                          : &cells[((size_t)k * PG + pg) * NS + snd];
           for (uint32_t r = 0; r < SIM_P; ++r)
             if (pk_kind(pk, r) != SIM_K_EMPTY) { sim_record rec = pk_get(pk, r); dispatch_record(&c, &rec); }
         }
@@ -1510,7 +1524,7 @@ static void tick_node(osim* s, const tickp* p, uint32_t l) {
     for (uint32_t k = 0; k < p->feff; ++k) {
       size_t cell = (size_t)k * s->Nl + l;
       if (((skipm >> k) & 1u) || (up && pkt_lost(p, c.gid, k))) memset(out[k], 0, sizeof out[k]);
-      sim_packet* dst = RF_SH(s) ? s->xsend : s->inbox[(s->tick + 1) & 1];
+      sim_packet* dst = s->inbox[(s->tick + 1) & 1];
       for (uint32_t pg = 0; pg < PG; ++pg) dst[((size_t)k * PG + pg) * s->Nl + l] = out[k][pg];
       s->rtgt[cell] = k < nc ? chosen[k] : NOSLOT;
     }
@@ -1572,6 +1586,7 @@ static void rc_resolve(osim* s, const uint32_t* req, uint32_t n) {
     else rc_push(s, a, b);
   }
 }
+static void rf_unpack(osim* s);
 static void step_begin(osim* s) {
   /* every shard is here: the slot-less suspicions / reconnect attempts of the tick BEFORE the one that just ended are replayed
    * now — behind whatever the caller scheduled for this tick so far, which is where a sharded host (sim_suspect_import at
@@ -1584,6 +1599,7 @@ static void step_begin(osim* s) {
   tickp* p = &s->cur;
   tickp_make(p, &s->cfg, s->tick);
   if (SHARDED(s)) s->xrecv = s->rbuf[(s->tick + 1) & 1];
+  if (RF_SH(s) && s->tick > 0) rf_unpack(s); /* the rows of this tick, from the slabs the round's exchange delivered */
   if (recycle_due(s) && !SHARDED(s)) recycle_local(s);
   uint32_t* rreq = NULL; /* this tick's reconnect attempts, in schedule order */
   uint32_t n_rreq = 0, cap_rreq = 0;
@@ -1634,27 +1650,79 @@ static void step_chunk(osim* s, uint32_t chunk) {
   }
 }
 /* random fan-out: group the cells by target — counting sort, senders ascending within a target, then slots */
-/* ... on a shard: the rows of the shard's nodes over the senders of the WHOLE cluster — every shard draws everybody's targets of
- * tick `tick` (a function of seed, tick and node) and keeps the pairs that land in its range; entries k * N + sender */
-static void rf_group_sharded(osim* s, uint64_t tick, uint32_t feff) {
+/* ... on a shard, sending side: the packets the shard's own senders addressed (rtgt) to shard h, packed into slab h of the send
+ * buffer in (target, sender, slot) order — a counting sort of the shard's f * Nl pairs by global target, stable in (sender, slot).
+ * `cells` = the senders' cells of the tick that sent them ([k * PG + pg][sender]). */
+static void rf_pack(osim* s, const sim_packet* cells) {
+  const uint32_t PG = s->PG, M = s->M;
+  uint32_t* cnt = (uint32_t*)calloc((size_t)s->N + 1, sizeof(uint32_t));
+  uint32_t* order = (uint32_t*)malloc(((size_t)s->f * s->Nl + 1) * sizeof(uint32_t));
+  for (uint32_t k = 0; k < s->f; ++k)
+    for (uint32_t l = 0; l < s->Nl; ++l) {
+      uint32_t t = s->rtgt[(size_t)k * s->Nl + l];
+      if (t != NOSLOT) cnt[t + 1]++;
+    }
+  for (uint32_t t = 0; t < s->N; ++t) cnt[t + 1] += cnt[t];
+  uint32_t* fill = (uint32_t*)malloc((size_t)s->N * sizeof(uint32_t));
+  memcpy(fill, cnt, (size_t)s->N * sizeof(uint32_t));
+  for (uint32_t l = 0; l < s->Nl; ++l) /* (sender, slot) order within a target */
+    for (uint32_t k = 0; k < s->f; ++k) {
+      uint32_t t = s->rtgt[(size_t)k * s->Nl + l];
+      if (t != NOSLOT) order[fill[t]++] = l * 4u + k;
+    }
+  free(fill);
+  for (uint32_t h = 0; h < s->V; ++h) {
+    uint8_t* slab = rf_slab(s, s->xsend, h);
+    rf_slab_hdr* hd = (rf_slab_hdr*)slab;
+    uint32_t* idx = rf_slab_idx(slab);
+    sim_packet* pk = rf_slab_pk(s, slab);
+    uint32_t n = 0, over = 0;
+    for (uint32_t tl = 0; tl < M; ++tl)
+      for (uint32_t i = cnt[(size_t)h * M + tl]; i < cnt[(size_t)h * M + tl + 1]; ++i) {
+        if (n == s->rf_cap) { over = 1; continue; } /* never with uniform draws: mean + 12 sigma of room */
+        uint32_t l = order[i] >> 2, k = order[i] & 3u;
+        idx[2 * n] = tl; idx[2 * n + 1] = order[i];
+        for (uint32_t pg = 0; pg < PG; ++pg) pk[(size_t)n * PG + pg] = cells[((size_t)k * PG + pg) * s->Nl + l];
+        ++n;
+      }
+    hd->n = n; hd->over = over; hd->pad0 = hd->pad1 = 0;
+    if (over) s->rf_err = 1;
+  }
+  free(order);
+  free(cnt);
+}
+/* ... receiving side: the rows of this shard's nodes from the V slabs that arrived — source shards in ascending order, each
+ * slab sorted by (target, sender, slot): a node's row is in ascending (sender, slot) order, the order a handle that holds every
+ * node hands the packets over in */
+static void rf_unpack(osim* s) {
   memset(s->rcsr, 0, ((size_t)s->Nl + 1) * sizeof(uint32_t));
-  uint32_t cap = s->f * s->Nl, n = 0;
-  uint32_t (*pairs)[2] = (uint32_t (*)[2])malloc(((size_t)s->f * s->N + 1) * sizeof *pairs); /* (target, cell), (sender, k) order */
-  for (uint32_t g = 0; g < s->N; ++g) {
-    uint32_t chosen[SIM_MAX_FANOUT], nc = rf_draw(s, tick, g, feff, chosen);
-    for (uint32_t k = 0; k < nc && k < feff; ++k)
-      if (chosen[k] >= s->shard0 && chosen[k] < s->shard0 + s->Nl) { pairs[n][0] = chosen[k] - s->shard0; pairs[n][1] = k * s->N + g; ++n; }
+  size_t total = 0;
+  for (uint32_t g = 0; g < s->V; ++g) {
+    uint8_t* slab = rf_slab(s, s->xrecv, g);
+    const rf_slab_hdr* hd = (const rf_slab_hdr*)slab;
+    if (hd->over || hd->n > s->rf_cap) { s->rf_err = 1; continue; }
+    const uint32_t* idx = rf_slab_idx(slab);
+    for (uint32_t i = 0; i < hd->n; ++i) {
+      if (idx[2 * i] >= s->Nl) { s->rf_err = 1; break; }
+      s->rcsr[idx[2 * i] + 1]++;
+    }
+    total += hd->n;
   }
-  if (n > cap) { /* more packets for this shard than it has cells for rows: grow (uniform draws: the mean is f * Nl) */
-    s->rsrc = (uint32_t*)realloc(s->rsrc, (size_t)n * sizeof(uint32_t));
+  if (s->rf_err) { memset(s->rcsr, 0, ((size_t)s->Nl + 1) * sizeof(uint32_t)); return; }
+  if (total > s->rf_rcap) { /* more packets for this shard than f * Nl (uniform draws: that is the mean) */
+    s->rsrc = (uint32_t*)realloc(s->rsrc, total * sizeof(uint32_t));
+    s->rf_rcap = (uint32_t)total;
   }
-  for (uint32_t i = 0; i < n; ++i) s->rcsr[pairs[i][0] + 1]++;
   for (uint32_t l = 0; l < s->Nl; ++l) s->rcsr[l + 1] += s->rcsr[l];
   uint32_t* fill = (uint32_t*)malloc((size_t)s->Nl * sizeof(uint32_t));
   memcpy(fill, s->rcsr, (size_t)s->Nl * sizeof(uint32_t));
-  for (uint32_t i = 0; i < n; ++i) s->rsrc[fill[pairs[i][0]]++] = pairs[i][1];
+  for (uint32_t g = 0; g < s->V; ++g) {
+    uint8_t* slab = rf_slab(s, s->xrecv, g);
+    const rf_slab_hdr* hd = (const rf_slab_hdr*)slab;
+    const uint32_t* idx = rf_slab_idx(slab);
+    for (uint32_t i = 0; i < hd->n; ++i) s->rsrc[fill[idx[2 * i]]++] = g * s->rf_cap + i;
+  }
   free(fill);
-  free(pairs);
 }
 static void rf_group(osim* s) {
   memset(s->rcsr, 0, ((size_t)s->Nl + 1) * sizeof(uint32_t));
@@ -1673,7 +1741,7 @@ static void rf_group(osim* s) {
 }
 static void step_end(osim* s) {
   const tickp p = s->cur;
-  if (RF_SH(s)) rf_group_sharded(s, s->tick, p.feff);
+  if (RF_SH(s)) rf_pack(s, s->inbox[(s->tick + 1) & 1]); /* the slabs go out between this tick and the next (the host's all-to-all) */
   else if (s->rfan) rf_group(s);
   s->prev = p;
   s->tick++;
@@ -1777,13 +1845,16 @@ int API(create)(const sim_config* cfg, osim** out) {
   size_t Nl = s->Nl;
   s->rows = (sim_row*)calloc(Nl, sizeof(sim_row));
   s->queue = (sim_record*)malloc(Nl * SIM_Q * sizeof(sim_record));
+  s->rfan = (cfg->flags & SIM_CF_RANDOM_FANOUT) != 0;
+  s->rf_cap = serf_rf_slab_cap(s->f, s->M, s->V);
   if (CFG_SHARDED(cfg)) {
-    size_t cells = (size_t)s->fp * s->M;
-    s->xsend = (sim_packet*)calloc(cells, sizeof(sim_packet));
-    s->xrecv = (sim_packet*)calloc((cfg->flags & SIM_CF_RANDOM_FANOUT) ? (size_t)s->fp * s->N : cells, sizeof(sim_packet));
+    size_t bytes = s->rfan ? (size_t)s->V * rf_slab_bytes(s) : (size_t)s->fp * s->M * sizeof(sim_packet);
+    s->xsend = (sim_packet*)calloc(bytes, 1);
+    s->xrecv = (sim_packet*)calloc(bytes, 1);
     s->rbuf[0] = s->rbuf[1] = s->xrecv;
     s->own_x = 1;
-  } else {
+  }
+  if (!CFG_SHARDED(cfg) || s->rfan) { /* (random fan-out: the packets stay in their senders' cells, on a shard too) */
     s->inbox[0] = (sim_packet*)calloc((size_t)s->fp * Nl, sizeof(sim_packet));
     s->inbox[1] = (sim_packet*)calloc((size_t)s->fp * Nl, sizeof(sim_packet));
   }
@@ -1807,17 +1878,17 @@ int API(create)(const sim_config* cfg, osim** out) {
   s->q_timeout = 16u * digits10(s->N); /* query.rs:421-427 with query_timeout_mult = 16 (options.rs:518) */
   pp_params(cfg, &s->pp_step, &s->pp_groups);
   if (!s->qbits || !s->upmap || !s->rows || !s->queue || !s->view || !s->ering || !s->qring || !s->slot_of ||
-      !s->subject_of || !s->walk || !s->alloc_tick || !s->base || (CFG_SHARDED(cfg) ? (!s->xsend || !s->xrecv)
-                                                          : (!s->inbox[0] || !s->inbox[1]))) {
+      !s->subject_of || !s->walk || !s->alloc_tick || !s->base || (CFG_SHARDED(cfg) && (!s->xsend || !s->xrecv)) ||
+      ((!CFG_SHARDED(cfg) || s->rfan) && (!s->inbox[0] || !s->inbox[1]))) {
     API(destroy)(s);
     return SIM_ENOMEM;
   }
-  s->rfan = (cfg->flags & SIM_CF_RANDOM_FANOUT) != 0;
   if (s->rfan) {
     if (cfg->chunks > 1) { API(destroy)(s); return SIM_EINVAL; }
     s->rtgt = (uint32_t*)malloc((size_t)s->f * Nl * sizeof(uint32_t));
     s->rcsr = (uint32_t*)calloc((size_t)Nl + 1, sizeof(uint32_t));
     s->rsrc = (uint32_t*)malloc((size_t)s->f * Nl * sizeof(uint32_t));
+    s->rf_rcap = s->f * (uint32_t)Nl;
     if (!s->rtgt || !s->rcsr || !s->rsrc) { API(destroy)(s); return SIM_ENOMEM; }
   }
   int joined = (cfg->flags & SIM_CF_BASELINE_JOINED) != 0;
@@ -2412,8 +2483,7 @@ int API(peek_packet)(osim* s, uint32_t node, uint32_t k, uint8_t* buf, size_t ca
     uint32_t g = node / p->M, ll = node % p->M, h, lp;
     fan_target(p, g, ll, k, &h, &lp);
     for (uint32_t pg = 0; pg < s->PG; ++pg) {
-      const sim_packet* pk = RF_SH(s) ? &s->xsend[((size_t)k * s->PG + pg) * s->Nl + (node - s->shard0)]
-          : SHARDED(s) ? &s->xsend[xcell(p, s->fp, (ll % p->blk) / p->sub, h, k * s->PG + pg, lp)]
+      const sim_packet* pk = (SHARDED(s) && !s->rfan) ? &s->xsend[xcell(p, s->fp, (ll % p->blk) / p->sub, h, k * s->PG + pg, lp)]
           : s->rfan ? &s->inbox[s->tick & 1][((size_t)k * s->PG + pg) * s->Nl + (node - s->shard0)] /* random fan-out: the packets stay in their senders' cells */
           : &s->inbox[s->tick & 1][((size_t)k * s->PG + pg) * s->Nl + (size_t)h * p->M + lp];
       for (uint32_t r = 0; r < SIM_P; ++r) {
@@ -2602,7 +2672,7 @@ static uint64_t dig_words(const void* p, size_t n_words) {
   return acc;
 }
 static const sim_packet* cur_inbox(const osim* s) {
-  if (RF_SH(s)) return s->xsend; /* the packets in flight, canonical form: in their (local) senders' cells */
+  if (s->rfan) return s->inbox[s->tick & 1]; /* the packets in flight, canonical form: in their (local) senders' cells */
   return SHARDED(s) ? s->rbuf[(s->tick + 1) & 1] : s->inbox[s->tick & 1];
 }
 int API(state_digest)(osim* s, uint64_t out[8]) {
@@ -2751,14 +2821,15 @@ int API(restore)(osim* s, const void* buf, size_t bytes) {
     in += n;
   }
   if (s->tick > 0) tickp_make(&s->prev, &s->cfg, s->tick - 1); /* the parameters the packets in flight were sent with */
-  if (RF_SH(s) && s->tick > 0) rf_group_sharded(s, s->tick - 1, s->prev.feff); /* (the host gathers the cells again: sim_exchange_layout) */
-  else if (s->rfan && s->tick > 0) { /* the targets of the packets in flight: drawn again, grouped again */
+  if (s->rfan && s->tick > 0) { /* the targets of the packets in flight: drawn again, grouped again */
     for (uint32_t l = 0; l < s->Nl; ++l) {
       uint32_t chosen[SIM_MAX_FANOUT], nc = rf_draw(s, s->tick - 1, s->shard0 + l, s->prev.feff, chosen);
       for (uint32_t k = 0; k < s->f; ++k) s->rtgt[(size_t)k * s->Nl + l] = (k < s->prev.feff && k < nc) ? chosen[k] : NOSLOT;
     }
-    rf_group(s);
+    if (RF_SH(s)) rf_pack(s, s->inbox[s->tick & 1]); /* packed again: the host runs the exchange once more (SIM_XCHG_PACKED) */
+    else rf_group(s);
   }
+  s->rf_err = 0;
   s->n_watched = 0;
   for (uint32_t l = 0; l < s->Nl; ++l) s->n_watched += (s->rows[l].flags & SIM_RF_WATCHED) != 0;
   walk_rebuild(s);
@@ -2868,16 +2939,20 @@ int API(cluster_stats_get)(osim* s, sim_cluster_stats* o) {
   o->events_lost = 0; /* the log grows (emit_event) */
   return SIM_OK;
 }
+/* bytes of the send buffer (= of each receive buffer): the bijection's slabs [C][V][fp][M / V / C], or the random fan-out's V packed slabs */
+static size_t xbytes(const osim* s) {
+  if (!SHARDED(s)) return 0;
+  return RF_SH(s) ? (size_t)s->V * rf_slab_bytes(s) : (size_t)s->fp * s->M * sizeof(sim_packet);
+}
 int API(exchange_bytes)(const osim* s, size_t* bytes) {
   if (!s || !bytes) return SIM_EINVAL;
-  *bytes = SHARDED(s) ? (size_t)s->fp * s->M * sizeof(sim_packet) : 0;
+  *bytes = xbytes(s);
   return SIM_OK;
 }
 int API(exchange_layout)(const osim* s, uint32_t* kind, uint32_t* planes, size_t* send_plane_bytes, size_t* recv_bytes) {
   if (!s || !kind || !planes || !send_plane_bytes || !recv_bytes) return SIM_EINVAL;
-  size_t send = SHARDED(s) ? (size_t)s->fp * s->M * sizeof(sim_packet) : 0;
-  if (RF_SH(s)) { *kind = SIM_XCHG_ALL_GATHER; *planes = s->fp; *send_plane_bytes = (size_t)s->M * sizeof(sim_packet); *recv_bytes = send * s->V; }
-  else { *kind = SIM_XCHG_ALL_TO_ALL; *planes = 1; *send_plane_bytes = send; *recv_bytes = send; }
+  *kind = RF_SH(s) ? SIM_XCHG_PACKED : SIM_XCHG_ALL_TO_ALL;
+  *planes = 1; *send_plane_bytes = xbytes(s); *recv_bytes = xbytes(s);
   return SIM_OK;
 }
 int API(bind_exchange2)(osim* s, void* send, void* recv0, void* recv1) {
@@ -2887,18 +2962,22 @@ int API(bind_exchange2)(osim* s, void* send, void* recv0, void* recv1) {
   s->rbuf[0] = (sim_packet*)recv0;
   s->rbuf[1] = (sim_packet*)recv1;
   s->xrecv = s->rbuf[(s->tick + 1) & 1];
-  size_t nsend = (size_t)s->fp * s->M * sizeof(sim_packet), nrecv = RF_SH(s) ? nsend * s->V : nsend;
-  memset(send, 0, nsend);
-  memset(recv0, 0, nrecv);
-  memset(recv1, 0, nrecv);
+  size_t nb = xbytes(s);
+  memset(send, 0, nb);
+  memset(recv0, 0, nb);
+  memset(recv1, 0, nb);
   return SIM_OK;
 }
 int API(bind_exchange)(osim* s, void* send, void* recv) { return API(bind_exchange2)(s, send, recv, recv); }
+int API(bind_exchange3)(osim* s, void* send, size_t send_bytes, void* recv0, void* recv1, size_t recv_bytes) {
+  if (!s || !SHARDED(s) || send_bytes < xbytes(s) || recv_bytes < xbytes(s)) return SIM_EINVAL;
+  return API(bind_exchange2)(s, send, recv0, recv1);
+}
 int API(exchange_chunks)(const osim* s, uint32_t* chunks, size_t* bytes_per_chunk) {
   if (!s || !chunks || !bytes_per_chunk) return SIM_EINVAL;
   uint32_t C = s->cfg.chunks ? s->cfg.chunks : 1;
   *chunks = SHARDED(s) ? C : 1;
-  *bytes_per_chunk = SHARDED(s) ? (size_t)s->fp * s->M * sizeof(sim_packet) / C : 0;
+  *bytes_per_chunk = xbytes(s) / C;
   return SIM_OK;
 }
 /* ---- cross-shard push-pull, driven by the sharded host (include/serf_sim.h) ---- */
@@ -3035,7 +3114,7 @@ int API(step_begin)(osim* s) {
   if (SHARDED(s) && recycle_due(s)) return SIM_ESTATE; /* the host runs the pass first (it needs every shard) */
 
   step_begin(s);
-  return SIM_OK;
+  return s->rf_err ? SIM_ERANGE : SIM_OK; /* a slab of the round's exchange overflowed at its sender (serf_rf_slab_cap) */
 }
 int API(step_chunk)(osim* s, uint32_t chunk) {
   if (!s) return SIM_EINVAL;
@@ -3049,7 +3128,7 @@ int API(step_end)(osim* s) {
   if (!s) return SIM_EINVAL;
   if (!s->in_tick) return SIM_ESTATE;
   step_end(s);
-  return SIM_OK;
+  return s->rf_err ? SIM_ERANGE : SIM_OK; /* a slab this shard packed did not hold its packets */
 }
 
 /* =====================================================================================

@@ -36,7 +36,7 @@ ARR_ROWS, ARR_QUEUE, ARR_INBOX, ARR_VIEW, ARR_ERING, ARR_QRING, ARR_SLOTMAP = ra
 # enum sim_swim_state (memberlist node state)
 SWIM_ALIVE, SWIM_SUSPECT, SWIM_DEAD, SWIM_LEFT = 0, 1, 2, 3
 CF_BASELINE_JOINED, CF_RANDOM_FANOUT, CF_AWARENESS_PROBE, CF_JOIN_SYNC, CF_TCP_FALLBACK, CF_NACKS, CF_FORCE_SHARDED = 1, 2, 4, 8, 16, 32, 64
-XCHG_ALL_TO_ALL, XCHG_ALL_GATHER = 0, 1
+XCHG_ALL_TO_ALL, XCHG_ALL_GATHER, XCHG_PACKED = 0, 1, 2   # (ALL_GATHER: retired in ABI 13, never reported)
 EXCHANGE_ID_BYTES = 128
 F_NO_BROADCAST, F_ACK, F_RESPOND = 1, 2, 4
 
@@ -103,7 +103,7 @@ ABI_SYMBOLS = ("create", "destroy", "set_stream", "join", "leave", "force_leave"
                "query", "inject", "step", "sync", "tick", "members", "stats_get", "watch",
                "drain_events", "state_digest", "dump_state", "convergence", "convergence_many", "exchange_bytes",
                "bind_exchange", "snapshot", "restore", "query_status", "query_responders", "profile", "profile_read", "profile_read_stats", "cluster_stats_get",
-               "bind_exchange2", "exchange_chunks", "exchange_layout", "step_begin", "step_chunk", "step_end",
+               "bind_exchange2", "bind_exchange3", "exchange_chunks", "exchange_layout", "step_begin", "step_chunk", "step_end",
                "recycle_due", "recycle_scan", "recycle_apply", "pp_due", "pp_plan", "pp_export", "pp_merge",
                "query_filtered", "set_tags", "init_tags", "inject_record", "deliver_message", "user_event_bytes", "peek_packet", "suspect_requests", "suspect_export", "suspect_import",
                "exchange_unique_id", "exchange_init", "exchange_chunk", "exchange_wait", "exchange_library",
@@ -146,7 +146,7 @@ def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, vi
 class SimLib:
     """One loaded implementation of the ABI."""
 
-    def __init__(self, path, prefix="sim_"):
+    def __init__(self, path, prefix="sim_", optional=()):
         if not os.path.exists(path):
             raise FileNotFoundError(
                 f"{path} is missing — build it first (python -c 'import __graft_entry__ as g; g.build()')")
@@ -181,6 +181,7 @@ class SimLib:
             "exchange_bytes": (C.c_int, [H, C.POINTER(C.c_size_t)]),
             "bind_exchange": (C.c_int, [H, vp, vp]),
             "bind_exchange2": (C.c_int, [H, vp, vp, vp]),
+            "bind_exchange3": (C.c_int, [H, vp, C.c_size_t, vp, vp, C.c_size_t]),
             "exchange_chunks": (C.c_int, [H, C.POINTER(u32), C.POINTER(C.c_size_t)]),
             "exchange_layout": (C.c_int, [H, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
             "step_begin": (C.c_int, [H]),
@@ -217,6 +218,8 @@ class SimLib:
             "backend_name": (C.c_char_p, []),
         }
         for name, (res, args) in sig.items():
+            if name in optional and not hasattr(self.dll, prefix + name):
+                continue   # (tools/ab.py: a build of an older ABI next to the current one)
             fn = getattr(self.dll, prefix + name)  # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
             self.f[name] = fn
@@ -460,6 +463,10 @@ class Sim:
         self._ck(self.lib.f["exchange_bytes"](self.h, C.byref(n)), "sim_exchange_bytes")
         return n.value
 
+    def bind_exchange3(self, send_ptr, send_bytes, recv0_ptr, recv1_ptr, recv_bytes):
+        """sim_bind_exchange2 with the sizes of the caller's buffers (SIM_EINVAL when one is too small)"""
+        self._ck(self.lib.f["bind_exchange3"](self.h, C.c_void_p(send_ptr), send_bytes, C.c_void_p(recv0_ptr), C.c_void_p(recv1_ptr), recv_bytes), "sim_bind_exchange3")
+
     def bind_exchange2(self, send_ptr, recv0_ptr, recv1_ptr):
         self._ck(self.lib.f["bind_exchange2"](self.h, C.c_void_p(send_ptr), C.c_void_p(recv0_ptr), C.c_void_p(recv1_ptr)), "sim_bind_exchange2")
 
@@ -470,8 +477,9 @@ class Sim:
         return c.value, n.value
 
     def exchange_layout(self):
-        """(kind, planes, bytes of one plane of the send buffer, bytes of the receive buffer) — XCHG_ALL_TO_ALL: the slabs of the
-        bijection; XCHG_ALL_GATHER: the random fan-out on a shard (plane j of every shard gathered into plane j of the receiver)."""
+        """(kind, planes, bytes of the send buffer, bytes of the receive buffer) — every kind is an equal-split all-to-all;
+        XCHG_ALL_TO_ALL: the slabs of the bijection, written by the tick kernel; XCHG_PACKED: the random fan-out on a shard — the
+        slabs are packed from the packets the senders keep, and after a restore the exchange has to be run once more."""
         k, p, a, b = C.c_uint32(), C.c_uint32(), C.c_size_t(), C.c_size_t()
         self._ck(self.lib.f["exchange_layout"](self.h, C.byref(k), C.byref(p), C.byref(a), C.byref(b)), "sim_exchange_layout")
         return k.value, p.value, a.value, b.value

@@ -1318,6 +1318,24 @@ __device__ static __forceinline__ bool fast_retire(const Ctx& c, const Node& n, 
              (((kind - SIM_K_JOIN) < 2u) & (lt >= n.clock));
   return fast_noop(c, n, kind, r, has, e) & !adv;
 }
+// The second look of the random fan-out's classification: `t` = the TAIL of the entry whose head `e` could not settle the record
+// (ring bucket keys k2 .. k5; a view entry's confirmers).  True when the handler would change nothing, not even a clock:
+//   user event / query  the key is in the tail (bucket_add finds it: "seen"); a query only in a bucket of its own Lamport time
+//                       (quirk Q2: in a bucket of another time every copy is appended again)
+//   suspect             a suspicion is running and `from` is among the confirmers counted so far (swim_suspect: return)
+__device__ static __forceinline__ bool tail_retire(const Ctx& c, const Node& n, u32 kind, const uint4& r, const uint4& e, const uint4& t) {
+  const u64 lt = (u64)r.z | ((u64)r.w << 32);
+  const bool isev = kind == SIM_K_EVENT, isq = kind == SIM_K_QUERY;
+  const u64 clk = isev ? n.eclock : n.qclock, B = isev ? c.d.Bev : c.d.Bq;
+  const u64 cur = lt >= clk ? lt + 1 : clk;
+  const bool old = (cur > B) & ((isev & (lt < cur - B)) | (isq & (B < cur - B)));  // (retired by the first look already; kept so that the two agree)
+  const bool in_tail = (t.x == r.x) | (t.y == r.x) | (t.z == r.x) | (t.w == r.x);
+  const bool ring_ok = (isev | isq) & !(n.flags & SIM_RF_MINTIME) & (lt < clk) & (e.z != 0u) & (old | ((isev | (E_LTIME(e) == lt)) & in_tail));
+  const u32 k = SIM_VB_NCONF(e.w), from = r.w;
+  const bool conf = (t.x == from) | ((k >= 1u) & (t.y == from)) | ((k >= 2u) & (t.z == from)) | ((k >= 3u) & (t.w == from));
+  const bool susp_ok = (kind == SIM_K_SUSPECT) & ((e.w & SIM_VB_KNOWN) != 0u) & (SIM_VB_SWIM(e.w) == SIM_SWIM_SUSPECT) & (r.z >= e.z) & conf;
+  return ring_ok | susp_ok;
+}
 __device__ static __forceinline__ void dispatch(const Ctx& c, Node& n, const uint4& r, uint4* p, uint4& e, bool& dirty, Ins& ins) {
   u32 kind = SIM_META_KIND(r.y), flags = SIM_META_FLAGS(r.y);
   u64 val = (u64)r.z | ((u64)r.w << 32);
@@ -1362,7 +1380,9 @@ static u32 g_ablate = 0;
 // sim_packet: key, value bits 31..0, value bits 47..32 | len64 | kind | flags; SUSPECT / DEAD carry inc : 24 | from : 24)
 #define PK_U4 3u  // a packet cell is three uint4: the four keys, the four low words, the four high words
 #define RF_TMAX 512u   // random fan-out, balanced classification: incoming packets of one wave's 64 nodes the LDS tables hold (mean 256)
-#define RF_STASH 128u  // ... and records in need of a handler whose unpacked form and entry pointer are kept for it (mean 46)
+#define RF_STASH 208u  // ... and records in need of a handler whose unpacked form and entry pointer are kept for it (mean 75; a rumour's
+                       // wavefront brings 300 and more — profiles/r05_tick_series_before.json —: as many as 10 KiB of LDS per wave hold)
+#define RF_LDS_U4 ((4u * RF_TMAX + 2u * RF_TMAX + 8u * RF_STASH + 32u * TBLOCK + 16u * RF_STASH) / 16u)  // sum | own | sidx | st_p | nst | st_r
 #define RF_CELL_U4 4u  // random fan-out: a sender's cell is 64 bytes — the packet's 48 and, in cell 0, the sender's map word (slot -> cell): entry -> cell is ONE scattered line
 __device__ static inline uint4 wire_unpack(u32 key, u32 lo, u32 hm) {
   u32 meta = (((hm >> 8) & 0x3Fu) << 18) | (hm & 0xFFu), hi = hm >> 16;
@@ -1391,7 +1411,8 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   // (one allocation, carved: the RF one-page instantiation stages nothing per record — its tables fit lds_r and lds_e, 8 KiB per
   // wave = 20 waves per CU —, so for it lds_p is only a name for lds_r's memory that dead code refers to)
   constexpr bool kNoP = RF && !MP;
-  __shared__ uint4 lds_all[kNoP ? 2 * SIM_P * TBLOCK : 2 * SIM_P * TBLOCK + SIM_P * TBLOCK / 2];
+  __shared__ uint4 lds_all[kNoP ? RF_LDS_U4 : 2 * SIM_P * TBLOCK + SIM_P * TBLOCK / 2];
+  static_assert(RF_LDS_U4 * 16u <= 10240u && RF_LDS_U4 >= 3u * TBLOCK && RF_STASH < 255u && (6u * RF_TMAX + 8u * RF_STASH) % 16u == 0u, "RF tables: 10 KiB per wave (16 waves per CU), store_cell's three columns, 8-bit stash indices");
   uint4 (&lds_r)[SIM_P][TBLOCK] = *reinterpret_cast<uint4 (*)[SIM_P][TBLOCK]>(&lds_all[0]);
   uint4 (&lds_e)[SIM_P][TBLOCK] = *reinterpret_cast<uint4 (*)[SIM_P][TBLOCK]>(&lds_all[SIM_P * TBLOCK]);
   uint4* (&lds_p)[SIM_P][TBLOCK] = *reinterpret_cast<uint4* (*)[SIM_P][TBLOCK]>(&lds_all[kNoP ? 0 : 2 * SIM_P * TBLOCK]);  // where each record's entry lives (null: nothing to look at)
@@ -1558,15 +1579,15 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
   // (A wave that is not all here — the last one of a ragged shard — or whose packets do not fit the tables — clusters of a few
   // nodes — skips the classification: every record of every packet goes through the handlers, which is always right.)
   u64 rb_need = 0;  // records of this node's packets 0 .. 15 that need a handler: bit 4 k + q
+  u64 rb_dup = 0;   // ... of those, literal copies of an EARLIER record of this node's list (the same rumour in another packet of the tick)
   if (RF && !MP && !bal) rb_need = rcnt >= 16u ? ~0ull : (1ull << (4u * rcnt)) - 1ull;
   if (RF && !MP && bal) {
-    u32* const sum = reinterpret_cast<u32*>(&lds_r[0][0]);          // [RF_TMAX] slow mask | 4 x 6-bit subject hash (0: not a member record)
-    uint8_t* const own = reinterpret_cast<uint8_t*>(&lds_r[2][0]);  // [RF_TMAX] the lane a packet is for (the upper half of lds_r)
+    u32* const sum = reinterpret_cast<u32*>(&lds_all[0]);           // [RF_TMAX] slow mask | 4 x 6-bit subject hash (0: not a member record)
+    uint8_t* const own = reinterpret_cast<uint8_t*>(sum + RF_TMAX); // [RF_TMAX] the lane a packet is for
     uint8_t* const sidx = own + RF_TMAX;                            // [RF_TMAX] first stash entry of the packet's slow records (0xFF: none)
-    u64* const st_p = reinterpret_cast<u64*>(own + 2 * RF_TMAX);    // [RF_STASH] entry pointers
-    uint4* const nst = &lds_e[0][0];                                // [64][2] the nodes' clocks, flags, incarnation as the tick begins
-    uint4* const st_r = &lds_e[2][0];                               // [RF_STASH] unpacked records
-    static_assert(2 * RF_TMAX + 8 * RF_STASH <= 2 * TBLOCK * 16 && RF_TMAX * 4 <= 2 * TBLOCK * 16 && RF_STASH <= 2 * TBLOCK, "LDS overlay");
+    u64* const st_p = reinterpret_cast<u64*>(sidx + RF_TMAX);       // [RF_STASH] entry pointers
+    uint4* const nst = reinterpret_cast<uint4*>(st_p + RF_STASH);   // [64][2] the nodes' clocks, flags, incarnation as the tick begins
+    uint4* const st_r = nst + 2 * TBLOCK;                           // [RF_STASH] unpacked records
     const u32 rown = rin0 - rb_base;
 #pragma unroll 1
     for (u32 i = 0; i < rf_npk; ++i)
@@ -1627,8 +1648,43 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
       u32 m = (fast_retire(co, no, k0, r0, p0 != nullptr, e0) ? 0u : 1u) | (fast_retire(co, no, k1, r1, p1 != nullptr, e1) ? 0u : 2u) |
               (fast_retire(co, no, k2, r2, p2 != nullptr, e2) ? 0u : 4u) | (fast_retire(co, no, k3, r3, p3 != nullptr, e3) ? 0u : 8u);
       if (!live || !(no.flags & SIM_RF_UP)) m = 0;  // (packets for a process that is down are dropped)
-      auto hsh = [](u32 kind, u32 key) __attribute__((always_inline)) -> u32 { return member_kind(kind) ? ((key * 0x9E3779B1u) >> 27) + 1u : 0u; };
-      const u32 note = m | (hsh(k0, r0.x) << 4) | (hsh(k1, r1.x) << 10) | (hsh(k2, r2.x) << 16) | (hsh(k3, r3.x) << 22);
+      // Second look (r5): two kinds of records are no-ops that the 16-byte head cannot show — a user event / query whose key sits
+      // in the TAIL of its ring bucket (three and more rumours of one Lamport time share a bucket), and a suspect message from a
+      // confirmer the entry has already counted (the confirmers are in the tail).  Both circulate for the whole life of their
+      // rumour and reach every node in every packet: 250 of a wave's 256 record positions went to the handlers in such ticks, 20
+      // iterations, each of them a no-op (profiles/r05_tick_series_*.json: the 0.5 - 0.6 ms ticks), and the stash overflowed.
+      // One candidate per lane and turn, rolled, head (again: it sits in L2) and tail requested together: the four heads are
+      // dead by now, so the loop lives in their registers (looking at all four tails at once cost 115 spilled registers).
+      // A record retired here is judged like one the first look retires: against the state as the tick began — the walk below
+      // lists it again if an earlier listed record is about the same subject.
+      {
+        auto wants = [&](u32 kind, const uint4& e, u32 bit) __attribute__((always_inline)) -> u32 {
+          const bool ring = kind == SIM_K_EVENT || kind == SIM_K_QUERY;
+          return (bit != 0u && ((ring && e.z != 0u && e.w != 0u) ||
+                                (kind == SIM_K_SUSPECT && (e.w & SIM_VB_KNOWN) && SIM_VB_SWIM(e.w) == SIM_SWIM_SUSPECT))) ? bit : 0u;
+        };
+        u32 wm = wants(k0, e0, m & 1u) | wants(k1, e1, m & 2u) | wants(k2, e2, m & 4u) | wants(k3, e3, m & 8u);
+#pragma unroll 1
+        while (__any(wm != 0u)) {
+          const u32 q = wm ? (u32)__ffs((int)wm) - 1u : 0u;
+          const bool w = wm != 0u;
+          wm &= wm - 1u;
+          const u32 kq = SEL4(q, k0, k1, k2, k3);
+          const uint4 rq = sel4(q, r0, r1, r2, r3);
+          uint4* const pq = q == 0u ? p0 : q == 1u ? p1 : q == 2u ? p2 : p3;
+          const uint4* const tq = pq + (kq == SIM_K_QUERY ? d.qtail : kq == SIM_K_EVENT ? d.etail : d.vtail);
+          const uint4 eh = ld4(w ? pq : d.nullcell), et = ld4(w ? tq : d.nullcell);
+          if (w && tail_retire(co, no, kq, rq, eh, et)) m &= ~(1u << q);
+          TCNT(24, 1);  // turns of the second look
+        }
+      }
+      // per member record: a 4-bit hash of its subject (+ 1) and, bit 5, whether its handler can UNDO what made a later record
+      // about the same subject a no-op (see the walk below): an alive message, a leave intent with the prune flag
+      auto hsh = [](u32 kind, u32 key, u32 meta) __attribute__((always_inline)) -> u32 {
+        const u32 trig = (kind == SIM_K_ALIVE || (kind == SIM_K_LEAVE && (SIM_META_FLAGS(meta) & SIM_F_PRUNE))) ? 32u : 0u;
+        return member_kind(kind) ? (((key * 0x9E3779B1u) >> 28) + 1u) | trig : 0u;
+      };
+      const u32 note = m | (hsh(k0, r0.x, r0.y) << 4) | (hsh(k1, r1.x, r1.y) << 10) | (hsh(k2, r2.x, r2.y) << 16) | (hsh(k3, r3.x, r3.y) << 22);
       // stash entries for the slow records: a prefix sum of popcount(m) over the lanes, from three ballots
       const u32 pm = (u32)__popc(m);
       const u64 q0 = __ballot(pm & 1u), q1 = __ballot(pm & 2u), q2 = __ballot(pm & 4u);
@@ -1644,13 +1700,32 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
       }
       if (live) { sum[cc] = note; sidx[cc] = keep ? (uint8_t)first : (uint8_t)0xFFu; }
       TCNT(13, 1);  // rounds that looked anything up
+#ifdef TICK_TIMING
+#pragma unroll 1
+      for (u32 kd = 1; kd <= 7u; ++kd) {  // records left for the handlers, by kind (17 .. 23)
+        u32 w = ((m & 1u) && k0 == kd ? 1u : 0u) + ((m & 2u) && k1 == kd ? 1u : 0u) + ((m & 4u) && k2 == kd ? 1u : 0u) + ((m & 8u) && k3 == kd ? 1u : 0u);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) w += (u32)__shfl_xor((int)w, o, 64);
+        tacc[16 + kd] += w;
+      }
+#endif
     }
     __builtin_amdgcn_wave_barrier();
     TT(2);
     TCNT(14, nstash);  // records left for the handlers by the classification
-    // every node over the notes of its own packets, in arrival order: a member record about a subject that an earlier record
-    // in need of a handler is about needs one too
-    u64 hot = 0;
+    // every node over the notes of its own packets, in arrival order: a member record that was judged a no-op against the state
+    // as the tick began needs a handler all the same when an EARLIER listed record about the same subject can undo what made it
+    // one.  (r5) Which handlers can: a record is retired because its Lamport time / incarnation is not newer than the entry's
+    // (both only grow), because the subject is unknown, gone, or fully confirmed, or because its confirmer is counted.  An alive
+    // message (a new incarnation: unknown -> known, gone / suspect -> alive) and a leave intent with the prune flag (the entry is
+    // erased) undo such a verdict; a suspect, a dead, a join intent or a plain leave intent cannot — they raise the incarnation /
+    // the time, count a confirmer, or take the member from alive to suspect to gone, and every one of the verdicts above survives
+    // that.  (Until r5 every listed member record re-listed the later ones about its subject: at a suspicion's flood — every
+    // packet carries suspect / dead records about the same node — one new confirmation at a node with nine packets made a wave run
+    // 19 handler iterations for its one lane: profiles/r05_tick_series_2nd_look.json, ticks 376 - 382.)
+    u32 hot = 0;
+    u64 fl = 0;   // stash indices of the first copies seen so far (eight of them, a byte each)
+    u32 nf = 0;
     const u32 wmax = min(rf_npk, 16u);
 #pragma unroll 1
     for (u32 i = 0; i < wmax; ++i) {
@@ -1659,23 +1734,63 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
         u32 m = sn & 15u;
 #pragma unroll
         for (u32 q = 0; q < SIM_P; ++q) {
-          const u32 hq = (sn >> (4u + 6u * q)) & 63u;
-          if (hq && ((hot >> hq) & 1ull)) m |= 1u << q;
-          if (hq && ((m >> q) & 1u)) hot |= 1ull << hq;
+          const u32 hf = (sn >> (4u + 6u * q)) & 63u, hq = hf & 31u;
+          if (hq && ((hot >> hq) & 1u)) m |= 1u << q;
+          if ((hf & 32u) && ((m >> q) & 1u)) hot |= 1u << hq;
         }
         rb_need |= (u64)m << (4u * i);
+        // The same rumour arrives in several of a node's packets of one tick — at a rumour's wavefront every node hears it for the
+        // first time from two or three senders at once, and every copy was judged "new" against the state as the tick began
+        // (profiles/r05_tick_series_before.json: 300 records per wave and tick for the handlers, 20 iterations).  A literal copy
+        // of an earlier record of the node's own list changes nothing once that record's handler has run (the handlers below are
+        // idempotent for: user events and queries — the key is in the bucket by then —, join intents and leave intents about others
+        // without prune — the entry's Lamport time is the record's by then —, memberlist's alive / suspect / dead about others — the
+        // incarnation is the record's, the confirmer is counted, the member is gone by then), PROVIDED nothing of what `poison` watches for happens
+        // in between (handler loop below): noted here, skipped there.  Compared in the stash: only stashed records take part.
+        const u32 m0 = sn & 15u, si = (u32)sidx[rown + i];
+        if (m0 != 0u && si != 0xFFu) {
+          u32 mm = m0, j = si;
+#pragma unroll 1
+          while (mm) {
+            const u32 q = (u32)__ffs((int)mm) - 1u;
+            mm &= mm - 1u;
+            const uint4 r = st_r[j];
+            const u32 kd = SIM_META_KIND(r.y);
+            const bool elig = kd == SIM_K_EVENT || kd == SIM_K_QUERY || kd == SIM_K_JOIN || (kd >= SIM_K_ALIVE && r.x != gid) ||
+                              (kd == SIM_K_LEAVE && !(SIM_META_FLAGS(r.y) & SIM_F_PRUNE) && r.x != gid);
+            if (elig) {
+              bool isdup = false;
+#pragma unroll 1
+              for (u32 f = 0; f < nf; ++f) {
+                const uint4 a = st_r[(u32)(fl >> (8u * f)) & 0xFFu];
+                isdup |= a.x == r.x && a.y == r.y && a.z == r.z && a.w == r.w;
+              }
+              if (isdup) rb_dup |= 1ull << (4u * i + q);
+              else if (nf < 8u) { fl |= (u64)j << (8u * nf); ++nf; }
+            }
+            ++j;
+          }
+        }
       }
     }
+#ifdef TICK_TIMING
+    {
+      u32 w = (u32)__popcll(rb_dup);
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) w += (u32)__shfl_xor((int)w, o, 64);
+      TCNT(16, w);  // literal copies found, per wave
+    }
+#endif
     TT(3);
   }
   // ---- phase 1: deliver.  The queue is not touched: handlers park their broadcasts in d.pend.
   if (up && !ABL(2)) {
     if (RF && !MP) {
       // the records the balanced pass left for the handlers, in arrival order, one per lane and iteration
-      const u32* const sum = reinterpret_cast<const u32*>(&lds_r[0][0]);
-      const uint8_t* const sidx = reinterpret_cast<const uint8_t*>(&lds_r[2][0]) + RF_TMAX;
-      const u64* const st_p = reinterpret_cast<const u64*>(reinterpret_cast<const uint8_t*>(&lds_r[2][0]) + 2 * RF_TMAX);
-      const uint4* const st_r = &lds_e[2][0];
+      const u32* const sum = reinterpret_cast<const u32*>(&lds_all[0]);
+      const uint8_t* const sidx = reinterpret_cast<const uint8_t*>(sum + RF_TMAX) + RF_TMAX;
+      const u64* const st_p = reinterpret_cast<const u64*>(sidx + RF_TMAX);
+      const uint4* const st_r = reinterpret_cast<const uint4*>(st_p + RF_STASH) + 2 * TBLOCK;
       const u32 rown = rin0 - rb_base;
       // a record that was not stashed (a later record about a subject of an earlier one; a stash that ran full; a packet
       // beyond a node's sixteenth): entry -> cell -> slot map, on the spot
@@ -1694,6 +1809,12 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
       };
       // (tried: the head of the NEXT record requested while this record's handler runs — ten more live registers across the
       // handlers, 10 spilled VGPRs, + 6 %: profiles/r04_experiments.md)
+      // `poison`: from here on no copy is skipped any more (running a record whose handler changes nothing is always right; not
+      // running one is right only while the handlers are idempotent): a model bound was hit (a full ring bucket counts EVERY copy
+      // it turns away), a query met a bucket of another Lamport time (quirk Q2: the bucket keeps its time, so every copy is
+      // appended again), a leave intent pruned an entry or was about the node itself (erase / refute: not idempotent)
+      const u32 ovf0 = n.overflow;
+      bool poison = false;
       auto run = [&](const uint4& r, uint4* ptr) __attribute__((always_inline)) {
         uint4 e = ld4(ptr ? ptr : d.nullcell);
         Ins ins;
@@ -1701,17 +1822,27 @@ __device__ __forceinline__ void tick_block(const Dev& d, const TickP& tp, const 
         bool dirty = false;
         dispatch(c, n, r, ptr, e, dirty, ins);
         if (ins.has) pend_push(c, n, ins);
+        const u32 kd = SIM_META_KIND(r.y);
+        poison |= (n.overflow != ovf0) | ((kd == SIM_K_QUERY) & (E_LTIME(e) != ((u64)r.z | ((u64)r.w << 32)))) |
+                  ((kd == SIM_K_LEAVE) & (((SIM_META_FLAGS(r.y) & SIM_F_PRUNE) != 0u) | (r.x == gid)));
       };
       // (packets beyond a node's sixteenth — never at any realistic size — have no bits in rb_need: every record of theirs goes
       // through the handlers, after the others, by way of the cursor xcur = 4 k + q)
       u32 xcur = 64u;
       const u32 xend = rcnt > 16u ? 4u * rcnt : 0u;
 #pragma unroll 1
-      while (!ABL(32) && __any(rb_need != 0 || xcur < xend)) {
+      for (;;) {
+        // the next record of the list that is not a copy to be skipped; the copies in front of it are dropped with it (they were
+        // no-ops at their turn: nothing poisoned the list before them)
+        const u64 cand = poison ? rb_need : (rb_need & ~rb_dup);
+        if (ABL(32) || !__any(cand != 0 || xcur < xend)) break;
         TCNT(12, 1);
         u32 bit = NOSLOT;
-        if (rb_need) { bit = (u32)__ffsll((unsigned long long)rb_need) - 1u; rb_need &= rb_need - 1ull; }
-        else if (xcur < xend) bit = xcur++;
+        if (cand) { bit = (u32)__ffsll((unsigned long long)cand) - 1u; rb_need &= ~((2ull << bit) - 1ull); }
+        else {
+          rb_need = 0;
+          if (xcur < xend) bit = xcur++;
+        }
         if (bit != NOSLOT) {
           const u32 k = bit >> 2, q = bit & 3u;
           const bool noted = bal && k < 16u;
@@ -2465,10 +2596,12 @@ __global__ void ops_kernel(Dev d, OpBatch ob, u64 tick, u32 has_alive, u64 qbase
 struct RfP {
   u64 rb;       // rng_base(seed, STREAM_RFAN, tick)
   u32 N, Nl, shard0, feff, f;
-  u32 Ns;       // senders whose targets are drawn: Nl — or, on a shard, all N (every shard draws the whole cluster's targets and
-                // keeps the pairs that land on its own nodes [shard0, shard0 + Nl); pair ids p = 4 * sender + slot are global then)
+  u32 Ns;       // senders whose targets are drawn: the handle's own Nl (global id shard0 + l; pair ids p = 4 * l + slot are local)
   u32 rcap;     // entries rsrc holds
-  u32 LB, NB;   // level-1 buckets: NB = ceil(Nl / 2^LB) ranges of 2^LB consecutive (local) targets
+  u32 LB, NB;   // level-1 buckets: ranges of 2^LB consecutive targets — NB = ceil(Nl / 2^LB) of them; on a shard (r5: the sort is
+                // the SENDING side's, over the targets of the shard's own senders anywhere in the cluster) NBh = ceil(M / 2^LB) per
+                // destination shard, NB = V * NBh: a bucket never straddles two shards
+  u32 V, M, NBh;  // destination shards, their size, buckets per destination (one handle that holds every node: 1, N, NB)
   u32 PB;       // bits of a pair id p = 4 l + k; a scattered entry is (target - bucket start) << PB | p — 32 bits when they fit
   u32 NWG;      // workgroups of rf_scatter (RfSpw senders each)
   u32 cap;      // pairs rf_rows can rank in LDS (a multiple of RFR, at most RF_EPT * RFR)
@@ -2483,7 +2616,7 @@ template <typename E> struct RfSpw { static constexpr u32 v = sizeof(E) == 4 ? 4
 #ifndef RFR
 #define RFR 512           // threads of an rf_rows workgroup
 #endif
-#define RF_LB_MAX 11u     // at most 2048 rows per level-1 bucket
+#define RF_LB_MAX 13u     // at most 8192 rows per level-1 bucket (64 KiB of rf_rows' LDS; one handle that holds every node stays at 11 or below)
 #define RF_EPT 24u        // pairs one thread of rf_rows keeps in registers: cap <= RF_EPT * RFR
 // exclusive prefix over the 64 lanes of a wave (`total` = the sum)
 __device__ static inline u32 wave_excl_scan(u32 v, u32& total) {
@@ -2517,13 +2650,16 @@ __global__ __launch_bounds__(RFB) void rf_scatter_kernel(RfP r, u32* gcur, E* l1
   u32 tg[SPW / RFB][SIM_MAX_FANOUT], nc[SPW / RFB];
 #pragma unroll
   for (u32 j = 0; j < SPW / RFB; ++j) {
-    const u32 l = l0 + j * RFB + threadIdx.x;  // the sender (its global id: a handle that is not a shard has shard0 == 0)
-    nc[j] = l < r.Ns ? rf_draw(r.rb, l, r.N, r.feff, tg[j]) : 0u;
+    const u32 l = l0 + j * RFB + threadIdx.x;  // the sender, local index (global id shard0 + l)
+    nc[j] = l < r.Ns ? rf_draw(r.rb, r.shard0 + l, r.N, r.feff, tg[j]) : 0u;
 #pragma unroll
-    for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) {
-      if (k < nc[j] && tg[j][k] - r.shard0 >= r.Nl) tg[j][k] = NOSLOT;  // another shard's node
-      if (k < nc[j] && tg[j][k] != NOSLOT) atomicAdd(&cnt[(tg[j][k] - r.shard0) >> r.LB], 1u);
-    }
+    for (u32 k = 0; k < SIM_MAX_FANOUT; ++k)
+      if (k < nc[j]) {  // from here on a target is (bucket << 16 | offset in the bucket): the bucket never straddles two shards
+        const u32 t = tg[j][k], h = r.V == 1u ? 0u : t / r.M, tl = t - h * r.M;
+        const u32 b = h * r.NBh + (tl >> r.LB);
+        tg[j][k] = (b << 16) | (tl & ((1u << r.LB) - 1u));
+        atomicAdd(&cnt[b], 1u);
+      }
   }
   __syncthreads();
   {  // exclusive prefix of the counts (every thread a stretch of buckets), and the workgroup's share of every region
@@ -2548,9 +2684,9 @@ __global__ __launch_bounds__(RFB) void rf_scatter_kernel(RfP r, u32* gcur, E* l1
     const u32 l = l0 + j * RFB + threadIdx.x;
 #pragma unroll
     for (u32 k = 0; k < SIM_MAX_FANOUT; ++k) {
-      if (k < nc[j] && tg[j][k] != NOSLOT) {  // (a slot without a target — fewer other nodes than the fan-out — is in nobody's row)
-        const u32 t = tg[j][k] - r.shard0, b = t >> r.LB, at = lst[b] + atomicAdd(&cur[b], 1u);
-        stage[at] = ((E)(t - (b << r.LB)) << r.PB) | (E)(4u * l + k);
+      if (k < nc[j]) {  // (a slot without a target — fewer other nodes than the fan-out — is in nobody's row)
+        const u32 b = tg[j][k] >> 16, at = lst[b] + atomicAdd(&cur[b], 1u);
+        stage[at] = ((E)(tg[j][k] & 0xFFFFu) << r.PB) | (E)(4u * l + k);
         stb[at] = (uint16_t)b;
       }
     }
@@ -2571,13 +2707,15 @@ __global__ __launch_bounds__(RFB) void rf_scatter_kernel(RfP r, u32* gcur, E* l1
 // LDS of rf_rows (dynamic): cnt[R + 1] | cur[R] | rowp[cap]
 static inline size_t rf_rows_lds(const RfP& r) { return ((size_t)(2u << r.LB) + 1u + r.cap) * 4u + 16u; }
 template <typename E>
-__global__ __launch_bounds__(RFR) void rf_rows_kernel(RfP r, u32* gcur, u32* gcur_next, const E* l1, E* ovf, E* ovf_next, u32* rcsr, u32* rsrc) {
+__global__ __launch_bounds__(RFR) void rf_rows_kernel(RfP r, u32* gcur, u32* gcur_next, const E* l1, E* ovf, E* ovf_next, u32* rcsr, u32* rsrc, uint8_t* cntb, u32* btot, u32* xflag) {
+  // (cntb != null: the SENDING side's sort of a shard — instead of row starts, one count byte per target of every destination
+  // shard, cntb[h * M + t], and the bucket's total, btot[b]: what travels with the packets; rsrc = the sorted pair ids)
   extern __shared__ u32 rf_lds[];
   const u32 R = 1u << r.LB;
   u32 *cnt = rf_lds, *cur = cnt + R + 1u, *rowp = cur + R;
   __shared__ u32 wtot[RFR / 64u], s_base;
   const u32 b = blockIdx.x, n = gcur[(size_t)b * RF_GCS], nreg = min(n, r.bcap);
-  const u32 t0 = b << r.LB, nrows = min(R, r.Nl - t0);
+  const u32 hb = b / r.NBh, t0 = (b - hb * r.NBh) << r.LB, nrows = min(R, r.M - t0);
   const E pmask = ((E)1 << r.PB) - (E)1;
   // the bucket's place in the output: behind everything the buckets before it hold
   {
@@ -2638,8 +2776,17 @@ __global__ __launch_bounds__(RFR) void rf_rows_kernel(RfP r, u32* gcur, u32* gcu
     if (threadIdx.x == RFR - 1u) cnt[R] = run;
   }
   __syncthreads();
-  for (u32 i = threadIdx.x; i < nrows; i += RFR) rcsr[t0 + i] = base + cnt[i];
-  if (b == r.NB - 1u && threadIdx.x == 0) rcsr[r.Nl] = base + n;
+  if (cntb) {
+    for (u32 i = threadIdx.x; i < nrows; i += RFR) {
+      const u32 c = cnt[i + 1u] - cnt[i];
+      if (c > 255u) atomicOr(xflag, 1u);  // (a node drawn by more than 255 of one shard's senders in one tick)
+      cntb[(size_t)hb * r.M + t0 + i] = (uint8_t)min(c, 255u);
+    }
+    if (threadIdx.x == 0) btot[b] = n;
+  } else {
+    for (u32 i = threadIdx.x; i < nrows; i += RFR) rcsr[t0 + i] = base + cnt[i];
+    if (b == r.NB - 1u && threadIdx.x == 0) rcsr[r.Nl] = base + n;
+  }
   if (fits) {
 #pragma unroll
     for (u32 j = 0; j < RF_EPT; ++j)
@@ -2671,6 +2818,164 @@ __global__ __launch_bounds__(RFR) void rf_rows_kernel(RfP r, u32* gcur, u32* gcu
       }
       const u32 at = base + cnt[(u32)(e >> r.PB)] + rank;
       if (at < r.rcap) rsrc[at] = (u32)(e & pmask);
+    }
+  }
+}
+// ---- SIM_CF_RANDOM_FANOUT on a shard (r5): the packed exchange (include/serf_sim.h SIM_XCHG_PACKED) ----------------------------
+// A packet goes to ANY node of the cluster.  The packets stay in their senders' cells (as on one GPU); per tick every shard
+//   * sorts the (target, sender, slot) triples of its OWN senders by global target (rf_scatter / rf_rows above, two ticks ahead on
+//     the build stream): rsrc = the sorted pair ids p = 4 l + k, cntb = one count byte per target of every destination shard,
+//     btot = the buckets' totals, xoff = where every destination's pairs start (rfx_soff_kernel);
+//   * PACKS, behind the tick kernel, the packets bound for shard h into slab h of the send buffer in that order (rfx_pack_kernel:
+//     pair -> sender's cell 0 and its map word -> the packet's pages, one scattered 64-byte read per packet — the read the
+//     receiver does on one GPU), the count bytes and bucket totals of h next to them (rfx_meta_kernel);
+//   * after the round's all-to-all turns the V slabs it received into the tick's CSR (rfx_index_kernel): a node's row = V runs,
+//     source shards ascending = senders ascending; an entry of rsrc = the packet's cell in the receive buffer, so the tick
+//     kernel reads it exactly as it reads a sender's cell 0 (map word: "this cell, n pages"; pages adjacent: Dev::NC = 1).
+// A slab, in 64-byte units: header {packets, overflow flag, tick} | count bytes [M] | bucket totals [NBh] u32 | cells [cap * PG].
+struct RfxL {  // the layout of one slab (the same on every shard of a run)
+  u32 V, M, NBh, LB, PG, cap;
+  u32 cnt_u, tot_u, cell_u, slab_u;  // offsets of the three sections and the slab's size, in 64-byte units
+};
+static RfxL rfx_layout(u32 V, u32 M, u32 NBh, u32 LB, u32 PG, u32 f) {
+  RfxL x;
+  x.V = V; x.M = M; x.NBh = NBh; x.LB = LB; x.PG = PG;
+  x.cap = serf_rf_slab_cap(f, M, V);
+  x.cnt_u = 1u;
+  x.tot_u = x.cnt_u + (M + 63u) / 64u;
+  x.cell_u = x.tot_u + (NBh + 15u) / 16u;
+  x.slab_u = x.cell_u + x.cap * PG;
+  return x;
+}
+// where every destination's pairs start in the sorted list (xoff[0 .. V]); xoff[V + 1 + h] = 1 when slab h cannot hold them
+__global__ void rfx_soff_kernel(RfxL x, const u32* btot, u32* xoff, u32* xflag) {
+  __shared__ u32 part[64];
+  for (u32 h = threadIdx.x; h < x.V; h += blockDim.x) {
+    u32 sum = 0;
+    for (u32 j = 0; j < x.NBh; ++j) sum += btot[(size_t)h * x.NBh + j];
+    part[h] = sum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 run = 0;
+    for (u32 h = 0; h < x.V; ++h) {
+      xoff[h] = run;
+      run += part[h];
+      xoff[x.V + 1u + h] = part[h] > x.cap ? 1u : 0u;
+      if (part[h] > x.cap) atomicOr(xflag, 2u);
+    }
+    xoff[x.V] = run;
+  }
+}
+// the slabs' headers, count bytes and bucket totals (what the receiver makes its rows from)
+__global__ void rfx_meta_kernel(RfxL x, const uint8_t* cntb, const u32* btot, const u32* xoff, u32 tick, uint4* send) {
+  const size_t per = (size_t)x.M + (size_t)x.NBh * 4u + 64u;  // bytes of one slab's meta, header last
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per * x.V; i += (size_t)gridDim.x * blockDim.x) {
+    const u32 h = (u32)(i / per);
+    const size_t o = i - (size_t)h * per;
+    uint8_t* slab = reinterpret_cast<uint8_t*>(send + (size_t)h * x.slab_u * 4u);
+    if (o < x.M) slab[(size_t)x.cnt_u * 64u + o] = cntb[(size_t)h * x.M + o];
+    else if (o < (size_t)x.M + (size_t)x.NBh * 4u) {
+      const size_t w = o - x.M;
+      if ((w & 3u) == 0u) reinterpret_cast<u32*>(slab + (size_t)x.tot_u * 64u)[w >> 2] = btot[(size_t)h * x.NBh + (w >> 2)];
+    } else {
+      const size_t w = o - x.M - (size_t)x.NBh * 4u;
+      if ((w & 3u) == 0u) {
+        const u32 n = xoff[h + 1u] - xoff[h], over = xoff[x.V + 1u + h];
+        const u32 i4 = (u32)(w >> 2);
+        reinterpret_cast<u32*>(slab)[i4] = i4 == 0u ? min(n, x.cap) : i4 == 1u ? over : i4 == 2u ? tick : 0u;
+      }
+    }
+  }
+}
+// pair i of the sorted list -> its packet, copied into its place in the slab of its destination: four lanes per packet, one
+// 16-byte quarter each, consecutive pairs -> consecutive cells (dense 64-byte writes); the fourth quarter of a packet's first
+// cell is its map word ("this cell, n pages" — or all 0xFF: nothing was sent / the packet was lost)
+__global__ void rfx_pack_kernel(RfxL x, const u32* rsrc, const u32* xoff, const uint4* cells, u32 Nl, uint4* send) {
+  const u32 total = xoff[x.V];
+  const u32 q = threadIdx.x & 3u;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; i < total; i += ((size_t)gridDim.x * blockDim.x) >> 2) {
+    u32 h = 0;
+    while (h + 1u < x.V && xoff[h + 1u] <= (u32)i) ++h;
+    const u32 pos = (u32)i - xoff[h];
+    if (pos >= x.cap) continue;  // (the slab is full: its header says so and the step fails)
+    const u32 p = rsrc[i], l = p >> 2, k = p & 3u;
+    const u32 mw = cells[(size_t)l * RF_CELL_U4 + 3u].x, jb = (mw >> (8u * k)) & 0xFFu;
+    const u32 pages = jb == 0xFFu ? 0u : (jb & 3u) + 1u;
+    uint4* dst = send + ((size_t)h * x.slab_u + x.cell_u + (size_t)pos * x.PG) * 4u;
+    for (u32 pg = 0; pg < x.PG; ++pg) {
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (q == 3u) v.x = pg == 0u ? (pages ? (0xFFFFFF00u | (pages - 1u)) : 0xFFFFFFFFu) : 0xFFFFFFFFu;
+      else if (pg < pages) v = cells[((size_t)((jb >> 2) + pg) * Nl + l) * RF_CELL_U4 + q];
+      dst[(size_t)pg * 4u + q] = v;
+    }
+  }
+}
+// the receiving side: one workgroup per bucket of 2^LB targets — the bucket's place in every source's slab and in the rows is
+// the sum of the totals before it (they travelled with the packets); inside it, prefix sums over the count bytes
+#define RFX_T 256u
+__global__ __launch_bounds__(RFX_T) void rfx_index_kernel(RfxL x, const uint4* recv, u32 Nl, u32 rcap, u32* rcsr, u32* rsrc, u32* xflag) {
+  extern __shared__ u32 rfx_lds[];  // rs[R]: where the next entry of every row goes
+  __shared__ u32 wsum[RFX_T / 64u], s_base[2];
+  u32* rs = rfx_lds;
+  const u32 R = 1u << x.LB, b = blockIdx.x, t0 = b << x.LB, nrows = min(R, x.M - t0);
+  const u32 per = (R + RFX_T - 1u) / RFX_T, i0 = threadIdx.x * per, i1 = min(i0 + per, nrows);
+  auto slab = [&](u32 g) __attribute__((always_inline)) -> const uint8_t* { return reinterpret_cast<const uint8_t*>(recv + (size_t)g * x.slab_u * 4u); };
+  auto block_excl = [&](u32 v, u32& total) __attribute__((always_inline)) -> u32 {  // exclusive prefix over the workgroup's threads
+    u32 wt, run = wave_excl_scan(v, wt);
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) wsum[threadIdx.x >> 6] = wt;
+    __syncthreads();
+    total = 0;
+    for (u32 w = 0; w < RFX_T / 64u; ++w) { if (w < (threadIdx.x >> 6)) run += wsum[w]; total += wsum[w]; }
+    return run;
+  };
+  // the rows' starts: everything the buckets before this one hold, over all sources, then the prefix of the rows' lengths
+  u32 before = 0;
+  for (u32 g = 0; g < x.V; ++g) {
+    const u32* tot = reinterpret_cast<const u32*>(slab(g) + (size_t)x.tot_u * 64u);
+    for (u32 j = threadIdx.x; j < b; j += RFX_T) before += tot[j];
+    if (threadIdx.x == 0 && b == 0) {  // (one workgroup looks at the headers: a sender whose slab ran full says so here)
+      const u32* hd = reinterpret_cast<const u32*>(slab(g));
+      if (hd[1] != 0u || hd[0] > x.cap) atomicOr(xflag, 4u);
+    }
+  }
+  u32 mine = 0;
+  for (u32 i = i0; i < i1; ++i) {
+    u32 c = 0;
+    for (u32 g = 0; g < x.V; ++g) c += slab(g)[(size_t)x.cnt_u * 64u + t0 + i];
+    mine += c;
+  }
+  u32 tot_before, tot_rows;
+  (void)block_excl(before, tot_before);
+  u32 run = block_excl(mine, tot_rows) + tot_before;
+  for (u32 i = i0; i < i1; ++i) {
+    u32 c = 0;
+    for (u32 g = 0; g < x.V; ++g) c += slab(g)[(size_t)x.cnt_u * 64u + t0 + i];
+    rs[i] = run;
+    rcsr[t0 + i] = run;
+    run += c;
+  }
+  if (b == gridDim.x - 1u && threadIdx.x == RFX_T - 1u) rcsr[Nl] = tot_before + tot_rows;
+  if (threadIdx.x == 0 && tot_before + tot_rows > rcap) atomicOr(xflag, 8u);  // (more packets than rsrc has room for: mean + 12 sigma)
+  __syncthreads();
+  // source by source: the entries of a row's run from source g = the cells of g's slab from the row's offset on
+  for (u32 g = 0; g < x.V; ++g) {
+    const u32* tot = reinterpret_cast<const u32*>(slab(g) + (size_t)x.tot_u * 64u);
+    const uint8_t* cb = slab(g) + (size_t)x.cnt_u * 64u + t0;
+    u32 bef = 0, sum = 0;
+    for (u32 j = threadIdx.x; j < b; j += RFX_T) bef += tot[j];
+    for (u32 i = i0; i < i1; ++i) sum += cb[i];
+    u32 tb, ts;
+    (void)block_excl(bef, tb);
+    u32 off = block_excl(sum, ts) + tb;
+    const u32 cell0 = g * x.slab_u + x.cell_u;  // (64-byte units from the start of the receive buffer)
+    for (u32 i = i0; i < i1; ++i) {
+      const u32 c = cb[i];
+      u32 at = rs[i];
+      for (u32 k = 0; k < c; ++k, ++at, ++off)
+        if (at < rcap) rsrc[at] = (cell0 + off * x.PG) << 2;
+      rs[i] = at;
     }
   }
 }
@@ -3549,6 +3854,17 @@ struct sim_handle {
   // rf_q[i] = the tick whose graph buffer i holds or is getting (~0: none), rf_done[i] marks its build.
   u32* rf_rcsr[3];
   u32* rf_rsrc[3];
+  // ... on a shard (SIM_XCHG_PACKED): the graph of tick s is the SENDING side's — rf_rsrc[s % 3] = the shard's own (target, sender,
+  // slot) triples sorted, as pair ids; rf_cntb / rf_btot / rf_xoff [s % 3] = count bytes per target of every destination, bucket
+  // totals, where every destination's pairs start — needed when tick s has computed (the pack).  The receiving side's rows
+  // (rx_rcsr / rx_rsrc) are made at the start of a tick from the slabs the round's exchange delivered.
+  uint8_t* rf_cntb[3];
+  u32* rf_btot[3];
+  u32* rf_xoff[3];
+  u32 *rx_rcsr, *rx_rsrc;
+  u32 rx_cap;          // entries rx_rsrc holds (f * Nl, 12 sigma and some)
+  RfxL rfx;
+  u32* xflag;          // pinned host memory the rf / rfx kernels write to: a slab, a count byte or rsrc overflowed -> SIM_ERANGE
   hipStream_t rf_stream;
   hipEvent_t rf_done[3], rf_go[2];
   u64 rf_q[3];
@@ -3579,8 +3895,8 @@ static int cfg_check(const sim_config* c) {
   if ((c->flags & SIM_CF_FORCE_SHARDED) && c->shard_count != c->vshards) return SIM_EINVAL;  // one rank of the N > 1 path: V == 1
   if (c->fanout < 1 || c->fanout > SIM_MAX_FANOUT) return SIM_EINVAL;
   if (c->chunks > 1 && ((M / c->vshards) % c->chunks || (M / c->vshards) / c->chunks < 1)) return SIM_EINVAL;
-  // memberlist's literal kRandomNodes (variable in-degree, an explicit CSR per tick): one shard, one chunk
-  if ((c->flags & SIM_CF_RANDOM_FANOUT) && (c->chunks > 1 || c->n_nodes > (1u << 23))) return SIM_EINVAL;  // (shards: r4 — sim_exchange_layout)
+  // memberlist's literal kRandomNodes (variable in-degree, an explicit CSR per tick): one chunk per tick (shards: SIM_XCHG_PACKED)
+  if ((c->flags & SIM_CF_RANDOM_FANOUT) && c->chunks > 1) return SIM_EINVAL;
   if (c->event_ring < 1 || c->query_ring < 1) return SIM_EINVAL;
   if (c->pkt_records && (c->pkt_records % SIM_P || c->pkt_records > SIM_PKT_RECORDS_MAX)) return SIM_EINVAL;
   if (c->retransmit_mult * h_digits10(c->n_nodes) > 63u) return SIM_EINVAL;
@@ -3660,6 +3976,7 @@ int sim_destroy(sim_handle* h) {
     if (h->sreq_host[i]) (void)hipHostFree(h->sreq_host[i]);
     if (h->sreq_ev[i]) (void)hipEventDestroy(h->sreq_ev[i]);
   }
+  if (h->xflag) (void)hipHostFree(h->xflag);
   for (void* p : h->allocs) (void)hipFree(p);
   delete h;
   return SIM_OK;
@@ -3750,8 +4067,10 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
     DA(d.obox[0], (size_t)d.fp * Nl * cu4) DA(d.obox[1], (size_t)d.fp * Nl * cu4)
     if (!d.rfan) { DA(d.omap[0], Nl) DA(d.omap[1], Nl) }
     DA(h->inbox_mat, (size_t)d.fp * Nl * PK_U4)
-  } else if (d.rfan) {  // a shard with the random fan-out: its cells ARE the send buffer the host binds (sim_bind_exchange2)
-    d.obox[0] = d.obox[1] = nullptr;
+  } else if (d.rfan) {  // a shard with the random fan-out: the packets stay in their senders' cells here too (one buffer: nobody
+    // reads the cells of the tick before — the receivers read the slabs the exchange delivered)
+    DA(d.obox[0], (size_t)d.fp * Nl * RF_CELL_U4)
+    d.obox[1] = d.obox[0];
     DA(h->inbox_mat, (size_t)d.fp * Nl * PK_U4)
   }
   DA(d.view, (size_t)d.A * Nl * 2)
@@ -3766,34 +4085,44 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
   DA(h->d_mlt, d.N)
   DA(h->d_stats, 1)
   d.rcsr = d.rsrc = nullptr;
-  for (int i = 0; i < 3; ++i) h->rf_rcsr[i] = h->rf_rsrc[i] = nullptr;
+  for (int i = 0; i < 3; ++i) { h->rf_rcsr[i] = h->rf_rsrc[i] = nullptr; h->rf_cntb[i] = nullptr; h->rf_btot[i] = h->rf_xoff[i] = nullptr; }
+  h->rx_rcsr = h->rx_rsrc = nullptr; h->xflag = nullptr;
+  memset(&h->rfx, 0, sizeof h->rfx);
   h->rf_stream = nullptr; h->rf_go[0] = h->rf_go[1] = nullptr;
   for (int i = 0; i < 3; ++i) { h->rf_done[i] = nullptr; h->rf_q[i] = ~0ull; }
   h->rf_gcur[0] = h->rf_gcur[1] = nullptr; h->rf_ovf[0] = h->rf_ovf[1] = h->rf_l1 = nullptr; h->rf_par = 0; h->rf_wide = false;
   memset(&h->rfp, 0, sizeof h->rfp);
-  if (d.rfan) {  // the fan-out graph as a CSR, rebuilt every tick, and the packets pushed into it (SIM_CF_RANDOM_FANOUT)
+  if (d.rfan) {  // the fan-out graph as a CSR, rebuilt every tick (SIM_CF_RANDOM_FANOUT)
     RfP& r = h->rfp;
     r.N = d.N; r.Nl = d.Nl; r.shard0 = d.shard0; r.f = d.f;
-    r.Ns = d.sharded ? d.N : d.Nl;
-    // the packets for this handle's nodes: exactly f * Nl of them at most — on a shard f * Nl on average (room: 12 sigma and some)
-    const size_t np = (size_t)d.f * Nl + (d.sharded ? (size_t)(12.0 * std::sqrt((double)d.f * Nl)) + 4096u : 0u);
+    r.Ns = d.Nl;  // every handle sorts the pairs of its OWN senders: by (local) target — or, a shard, by target anywhere in the cluster
+    r.V = d.sharded ? d.V : 1u; r.M = d.sharded ? d.M : d.N;
+    if (d.sharded && d.V > 64u) { sim_destroy(h); return SIM_EINVAL; }
+    // the sorted list: every pair of the handle's senders, f * Nl at most.  The rows a shard RECEIVES (rx_rsrc): f * Nl on average
+    const size_t np = (size_t)d.f * Nl, nrx = (size_t)d.f * Nl + (size_t)(12.0 * std::sqrt((double)d.f * Nl)) + 4096u;
     r.rcap = (u32)np;
     // level-1 buckets of 2^LB targets.  A scattered entry carries the pair id (PB bits) and the target's offset in its bucket
-    // (LB bits) — rf_rows does not draw again —; 32-bit entries when both fit (1 Mi nodes: 22 + 10), 64-bit ones otherwise
+    // (LB bits) — rf_rows does not draw again —; 32-bit entries when both fit (1 Mi nodes: 22 + 10), 64-bit ones otherwise.
+    // A shard's buckets are per destination (V * ceil(M / 2^LB) of them): narrow entries while that keeps rf_scatter's three
+    // tables in 48 KiB of LDS, else wide ones and about 2048 buckets
     r.PB = 1;
     while ((1ull << r.PB) < 4ull * r.Ns) r.PB++;
+    auto nb_of = [&](u32 lb) { return (size_t)r.V * (((size_t)r.M + (1u << lb) - 1u) >> lb); };
     r.LB = std::min<u32>(11u, 32u - std::min<u32>(r.PB, 24u));
     if (const char* e = getenv("SERF_RF_LB")) r.LB = std::min<u32>(RF_LB_MAX, std::max<u32>(8u, (u32)strtoul(e, nullptr, 0)));
-    while (((size_t)Nl + (1u << r.LB) - 1u) >> r.LB > 4096u) r.LB++;  // rf_scatter's three tables: 48 KiB of LDS next to its staging area
-    if (r.LB > RF_LB_MAX) { sim_destroy(h); return SIM_EINVAL; }
+    while (nb_of(r.LB) > (r.V > 1u && r.PB + r.LB > 32u ? 2048u : 4096u) && r.LB < RF_LB_MAX) r.LB++;  // rf_scatter's three tables: 48 KiB of LDS next to its staging area
+    if (nb_of(r.LB) > 4096u) { sim_destroy(h); return SIM_EINVAL; }
     h->rf_wide = r.PB + r.LB > 32u || getenv("SERF_RF_WIDE") != nullptr;
-    r.NB = (u32)(((size_t)Nl + (1u << r.LB) - 1u) >> r.LB);
+    r.NBh = (u32)(nb_of(r.LB) / r.V);
+    r.NB = r.V * r.NBh;
     r.NWG = (u32)(((size_t)r.Ns + (h->rf_wide ? RfSpw<u64>::v : RfSpw<u32>::v) - 1u) / (h->rf_wide ? RfSpw<u64>::v : RfSpw<u32>::v));
-    r.cap = std::min<u32>(6u << r.LB, RF_EPT * RFR);  // mean 4 * 2^LB pairs, sigma 2 * 2^(LB/2): 32 sigma and more of room
+    // pairs of a bucket: f per row on one handle; a shard's f * M pairs spread over all V * NBh buckets
+    const double mean = (double)d.f * (double)(1u << r.LB) / (double)r.V;
+    r.cap = std::min<u32>(std::max<u32>(((u32)(mean + 16.0 * std::sqrt(mean)) + 64u + RFR - 1u) / RFR * RFR, RFR), RF_EPT * RFR);  // 16 sigma and more of room
+    if (r.V == 1u) r.cap = std::min<u32>(6u << r.LB, RF_EPT * RFR);
     if (const char* e = getenv("SERF_RF_CAP")) r.cap = std::max<u32>(RFR, std::min<u32>(r.cap, (u32)strtoul(e, nullptr, 0)) / RFR * RFR);  // tests: force rf_rows' slow path
-    // a bucket's region of l1: f pairs per row it can have at most when the shard is one bucket, else the mean and 12 sigma
+    // a bucket's region of l1: the mean and 12 sigma; what does not fit goes onto the overflow list
     {
-      const double mean = (double)d.f * (double)(1u << r.LB);
       r.bcap = (u32)(mean + 12.0 * std::sqrt(mean)) + 64u;
       if (const char* e = getenv("SERF_RF_BCAP")) r.bcap = std::max<u32>(1u, (u32)strtoul(e, nullptr, 0));  // tests: force the overflow list
       r.ocap = (u32)np;  // (every pair would fit: the list cannot run full)
@@ -3802,8 +4131,19 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
                       hipFuncSetAttribute(reinterpret_cast<const void*>(rf_scatter_kernel<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rf_scatter_lds<u64>(r)) != hipSuccess)
                    : (hipFuncSetAttribute(reinterpret_cast<const void*>(rf_rows_kernel<u32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rf_rows_lds(r)) != hipSuccess ||
                       hipFuncSetAttribute(reinterpret_cast<const void*>(rf_scatter_kernel<u32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rf_scatter_lds<u32>(r)) != hipSuccess)) { sim_destroy(h); return SIM_EDEVICE; }
+    if (hipHostMalloc((void**)&h->xflag, 64) != hipSuccess) { sim_destroy(h); return SIM_ENOMEM; }
+    *h->xflag = 0;
+    if (d.sharded) {
+      h->rfx = rfx_layout(d.V, d.M, r.NBh, r.LB, d.PG, d.f);
+      if ((size_t)d.V * h->rfx.slab_u >= ((size_t)1 << 30) ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(rfx_index_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4u << r.LB) + 16u)) != hipSuccess) { sim_destroy(h); return SIM_EINVAL; }
+      for (int i = 0; i < 3; ++i) { DA(h->rf_cntb[i], (size_t)d.N) DA(h->rf_btot[i], r.NB) DA(h->rf_xoff[i], 2 * (size_t)d.V + 2) }
+      DA(h->rx_rcsr, Nl + 1) DA(h->rx_rsrc, nrx)
+      if (hipMemset(h->rx_rcsr, 0, (Nl + 1) * 4) != hipSuccess) { sim_destroy(h); return SIM_EDEVICE; }  // tick 0 receives nothing
+    }
     h->rf_sync = getenv("SERF_RF_SYNC") != nullptr;  // measurements: build on the tick's own stream, nothing overlaps
     for (int i = 0; i < 3; ++i) { DA(h->rf_rcsr[i], Nl + 1) DA(h->rf_rsrc[i], np) }
+    h->rx_cap = (u32)nrx;
     {
       const size_t esz = h->rf_wide ? 2 : 1;  // (in u32 words)
       u32* p32 = nullptr;
@@ -3843,8 +4183,9 @@ int sim_create(const sim_config* cfg, sim_handle** out) {
     HCHECK(zero(d.obox[0], (size_t)d.fp * Nl * sizeof(sim_packet))); HCHECK(zero(d.obox[1], (size_t)d.fp * Nl * sizeof(sim_packet)));
     HCHECK(hipMemsetAsync(d.omap[0], 0xFF, Nl * 4, s)); HCHECK(hipMemsetAsync(d.omap[1], 0xFF, Nl * 4, s));
   }
-  if (d.rfan && !d.sharded) {  // (all 0xFF: every map word says "nothing sent"; a shard's cells: sim_bind_exchange2)
-    HCHECK(hipMemsetAsync(d.obox[0], 0xFF, (size_t)d.fp * Nl * RF_CELL_U4 * 16, s)); HCHECK(hipMemsetAsync(d.obox[1], 0xFF, (size_t)d.fp * Nl * RF_CELL_U4 * 16, s));
+  if (d.rfan) {  // (all 0xFF: every map word says "nothing sent")
+    HCHECK(hipMemsetAsync(d.obox[0], 0xFF, (size_t)d.fp * Nl * RF_CELL_U4 * 16, s));
+    if (d.obox[1] != d.obox[0]) HCHECK(hipMemsetAsync(d.obox[1], 0xFF, (size_t)d.fp * Nl * RF_CELL_U4 * 16, s));
   }
   HCHECK(zero(d.view, (size_t)d.A * Nl * 32));
   HCHECK(zero(d.ering, (size_t)d.Bev * Nl * 32));
@@ -4396,15 +4737,34 @@ static int rf_build(sim_handle* h, u64 tick, hipStream_t s) {
   r.rb = rng_base(h->cfg.seed, STREAM_RFAN, tick);
   r.feff = tp.feff;
   u32 *rcsr = h->rf_rcsr[tick % 3], *rsrc = h->rf_rsrc[tick % 3];
+  uint8_t* cntb = h->d.sharded ? h->rf_cntb[tick % 3] : nullptr;  // a shard: the sending side's sort (SIM_XCHG_PACKED)
+  u32* btot = h->d.sharded ? h->rf_btot[tick % 3] : nullptr;
   const u32 par = h->rf_par;
   h->rf_par ^= 1u;
   if (h->rf_wide) {
     rf_scatter_kernel<u64><<<r.NWG, RFB, rf_scatter_lds<u64>(r), s>>>(r, h->rf_gcur[par], (u64*)h->rf_l1, (u64*)h->rf_ovf[par]);
-    rf_rows_kernel<u64><<<r.NB, RFR, rf_rows_lds(r), s>>>(r, h->rf_gcur[par], h->rf_gcur[par ^ 1u], (const u64*)h->rf_l1, (u64*)h->rf_ovf[par], (u64*)h->rf_ovf[par ^ 1u], rcsr, rsrc);
+    rf_rows_kernel<u64><<<r.NB, RFR, rf_rows_lds(r), s>>>(r, h->rf_gcur[par], h->rf_gcur[par ^ 1u], (const u64*)h->rf_l1, (u64*)h->rf_ovf[par], (u64*)h->rf_ovf[par ^ 1u], rcsr, rsrc, cntb, btot, h->xflag);
   } else {
     rf_scatter_kernel<u32><<<r.NWG, RFB, rf_scatter_lds<u32>(r), s>>>(r, h->rf_gcur[par], (u32*)h->rf_l1, (u32*)h->rf_ovf[par]);
-    rf_rows_kernel<u32><<<r.NB, RFR, rf_rows_lds(r), s>>>(r, h->rf_gcur[par], h->rf_gcur[par ^ 1u], (const u32*)h->rf_l1, (u32*)h->rf_ovf[par], (u32*)h->rf_ovf[par ^ 1u], rcsr, rsrc);
+    rf_rows_kernel<u32><<<r.NB, RFR, rf_rows_lds(r), s>>>(r, h->rf_gcur[par], h->rf_gcur[par ^ 1u], (const u32*)h->rf_l1, (u32*)h->rf_ovf[par], (u32*)h->rf_ovf[par ^ 1u], rcsr, rsrc, cntb, btot, h->xflag);
   }
+  if (h->d.sharded) rfx_soff_kernel<<<1, 64, 0, s>>>(h->rfx, btot, h->rf_xoff[tick % 3], h->xflag);
+  HCHECK(hipGetLastError());
+  return SIM_OK;
+}
+// random fan-out on a shard: the packets sent during tick `t` (in their senders' cells) -> the V slabs of the send buffer, on the
+// handle's stream, behind the tick's launch (SIM_XCHG_PACKED).  The sort of tick t was enqueued on the build stream a tick ago
+// (right after a restore, or with SERF_RF_SYNC: it is built here and now).
+static int rfx_pack(sim_handle* h, u64 t) {
+  Dev& d = h->d;
+  if (h->rf_q[t % 3] != t) {
+    int rc = rf_build(h, t, h->stream);
+    if (rc) return rc;
+    h->rf_q[t % 3] = t;
+  } else HCHECK(hipStreamWaitEvent(h->stream, h->rf_done[t % 3], 0));
+  const RfxL& x = h->rfx;
+  rfx_meta_kernel<<<grid_for(((size_t)x.M + (size_t)x.NBh * 4u + 64u) * x.V), BLOCK, 0, h->stream>>>(x, h->rf_cntb[t % 3], h->rf_btot[t % 3], h->rf_xoff[t % 3], (u32)t, d.xsend);
+  rfx_pack_kernel<<<grid_for((size_t)d.f * d.Nl * 4u), BLOCK, 0, h->stream>>>(x, h->rf_rsrc[t % 3], h->rf_xoff[t % 3], d.obox[0], d.Nl, d.xsend);
   HCHECK(hipGetLastError());
   return SIM_OK;
 }
@@ -4412,6 +4772,7 @@ int sim_step_begin(sim_handle* h) {
   if (!h) return SIM_EINVAL;
   Dev& d = h->d;
   if (h->in_tick || (d.sharded && !h->bound)) return SIM_ESTATE;
+  if (h->xflag && *h->xflag) return SIM_ERANGE;  // a slab of the random fan-out's exchange (or a count byte, or the rows) overflowed
   if (h->xpending) { int rc = sim_exchange_wait(h); if (rc) return rc; }  // the packets of the round before have landed
   if (d.swim && !d.sharded) {
     // every shard is here: the slot-less suspicions / reconnect attempts of the tick BEFORE the one that just ended are
@@ -4530,19 +4891,29 @@ int sim_step_begin(sim_handle* h) {
     // reads it.  It was enqueued on the build stream two ticks ago (right after a restore, at tick 1, or with SERF_RF_SYNC: it
     // is built here and now); the graphs of THIS tick's packets and the next tick's are enqueued now if they are not yet — as
     // soon as everything enqueued so far has finished: they overwrite a buffer the tick before this one read.
-    if (h->tick > 0) {
-      const u64 s = h->tick - 1;
-      if (h->rf_q[s % 3] != s) {
-        int rc = rf_build(h, s, h->stream);
-        if (rc) return rc;
-        h->rf_q[s % 3] = s;
-      } else HCHECK(hipStreamWaitEvent(h->stream, h->rf_done[s % 3], 0));
+    if (d.sharded) {
+      // a shard: the rows of this tick come from the slabs the round's exchange delivered (sim_exchange_wait above / the host's
+      // collective has completed): one launch (rfx_index_kernel); an entry = a cell of the receive buffer
+      const uint4* rb = h->rbuf[(h->tick + 1) & 1];
+      if (h->tick > 0) rfx_index_kernel<<<h->rfx.NBh, RFX_T, (4u << h->rfx.LB) + 16u, h->stream>>>(h->rfx, rb, d.Nl, h->rx_cap, h->rx_rcsr, h->rx_rsrc, h->xflag);
+      d.rcsr = h->rx_rcsr;  // (tick 0: zeros — nothing has been sent)
+      d.rsrc = h->rx_rsrc;
+      d.rfrd = rb;
+      d.NC = 1u;            // the pages of a packet are adjacent cells of its slab
+    } else {
+      if (h->tick > 0) {
+        const u64 s = h->tick - 1;
+        if (h->rf_q[s % 3] != s) {
+          int rc = rf_build(h, s, h->stream);
+          if (rc) return rc;
+          h->rf_q[s % 3] = s;
+        } else HCHECK(hipStreamWaitEvent(h->stream, h->rf_done[s % 3], 0));
+      }
+      d.rcsr = h->rf_rcsr[(h->tick + 2) % 3];  // (tick 0: a buffer of zeros — nothing has been sent)
+      d.rsrc = h->rf_rsrc[(h->tick + 2) % 3];
+      d.rfrd = d.obox[h->tick & 1];  // ... and the cells those packets sit in: this handle's own of the tick before
+      d.NC = d.Nl;
     }
-    d.rcsr = h->rf_rcsr[(h->tick + 2) % 3];  // (tick 0: a buffer of zeros — nothing has been sent)
-    d.rsrc = h->rf_rsrc[(h->tick + 2) % 3];
-    // ... and the cells those packets sit in: this handle's own of the tick before, or what the shards' exchange gathered
-    d.rfrd = d.sharded ? h->rbuf[(h->tick + 1) & 1] : d.obox[h->tick & 1];
-    d.NC = d.sharded ? d.N : d.Nl;
     if (!h->rf_sync) {
       bool waited = false;
       for (u64 s = h->tick; s <= h->tick + 1; ++s) {
@@ -4641,7 +5012,9 @@ int sim_step_chunk(sim_handle* h, uint32_t chunk) {
   if (!h->in_tick) return SIM_ESTATE;
   if (!h->d.sharded || chunk >= h->cur_tp.C) return SIM_EINVAL;
   if (sim_pp_due(h) > 0) return SIM_ESTATE;  // the push-pull batch of this tick comes first (its pairs span shards: the host runs it)
-  return tick_launch(h, h->cur_tp.C == 1 ? 0xFFFFFFFFu : chunk);
+  int rc = tick_launch(h, h->cur_tp.C == 1 ? 0xFFFFFFFFu : chunk);
+  if (rc == SIM_OK && h->d.rfan) rc = rfx_pack(h, h->tick);  // the slabs of the round's exchange, from the cells the launch fills
+  return rc;
 }
 int sim_step_end(sim_handle* h) {
   if (!h) return SIM_EINVAL;
@@ -4745,6 +5118,7 @@ int sim_step(sim_handle* h, uint32_t n_ticks) {
       for (u32 c = 0; c < h->cur_tp.C && rc == SIM_OK; ++c) rc = tick_launch(h, c);
     } else {
       rc = tick_launch(h, 0xFFFFFFFFu);
+      if (rc == SIM_OK && d.sharded && d.rfan) rc = rfx_pack(h, h->tick);
     }
     int rc2 = sim_step_end(h);
     if (rc) return rc;
@@ -5192,6 +5566,14 @@ int sim_restore(sim_handle* h, const void* buf, size_t bytes) {
   h->op_cursor = 0;
   if (h->rf_stream) HCHECK(hipStreamSynchronize(h->rf_stream));  // a build of the run that is being replaced may still be writing the scratch
   for (int i = 0; i < 3; ++i) h->rf_q[i] = ~0ull;
+  if (h->xflag) *h->xflag = 0;
+  if (d.sharded && d.rfan && hd.tick > 0) {
+    // the packets in flight are back in their senders' cells: packed again — the host runs the round's exchange once more
+    // before the next tick (SIM_XCHG_PACKED)
+    int prc = rfx_pack(h, hd.tick - 1);
+    if (prc) return prc;
+    HCHECK(hipStreamSynchronize(h->stream));
+  }
   return SIM_OK;
 }
 int sim_query_status(sim_handle* h, uint32_t qid, uint64_t* acks, uint64_t* responses, int* open) {
@@ -5304,14 +5686,13 @@ int sim_cluster_stats_get(sim_handle* h, sim_cluster_stats* out) {
   out->events_lost = h->events_lost + (evc > d.ev_cap ? evc - d.ev_cap : 0);
   return SIM_OK;
 }
-// bytes of the handle's send buffer: the slabs [C][V dst][fp][M / V / C] of 48-byte packets — or, random fan-out on a shard, the
-// shard's own 64-byte cells [fp planes][M senders] (the packets stay with their senders: sim_exchange_layout)
+// bytes of the handle's send buffer (and of each receive buffer): the slabs [C][V dst][fp][M / V / C] of 48-byte packets — or,
+// random fan-out on a shard, the V packed slabs (RfxL: header, count bytes, bucket totals, 64-byte cells)
 static size_t xsend_bytes(const sim_handle* h) {
   const Dev& d = h->d;
   if (!d.sharded) return 0;
-  return d.rfan ? (size_t)d.fp * d.M * RF_CELL_U4 * 16 : (size_t)d.fp * d.M * sizeof(sim_packet);
+  return d.rfan ? (size_t)d.V * h->rfx.slab_u * 64u : (size_t)d.fp * d.M * sizeof(sim_packet);
 }
-static size_t xrecv_bytes(const sim_handle* h) { return (h->d.sharded && h->d.rfan) ? xsend_bytes(h) * h->d.V : xsend_bytes(h); }
 int sim_exchange_bytes(const sim_handle* h, size_t* bytes) {
   if (!h || !bytes) return SIM_EINVAL;
   *bytes = xsend_bytes(h);
@@ -5320,9 +5701,9 @@ int sim_exchange_bytes(const sim_handle* h, size_t* bytes) {
 int sim_exchange_layout(const sim_handle* h, uint32_t* kind, uint32_t* planes, size_t* send_plane_bytes, size_t* recv_bytes) {
   if (!h || !kind || !planes || !send_plane_bytes || !recv_bytes) return SIM_EINVAL;
   const Dev& d = h->d;
-  if (d.sharded && d.rfan) { *kind = SIM_XCHG_ALL_GATHER; *planes = d.fp; *send_plane_bytes = (size_t)d.M * RF_CELL_U4 * 16; }
-  else { *kind = SIM_XCHG_ALL_TO_ALL; *planes = 1; *send_plane_bytes = xsend_bytes(h); }
-  *recv_bytes = xrecv_bytes(h);
+  *kind = (d.sharded && d.rfan) ? SIM_XCHG_PACKED : SIM_XCHG_ALL_TO_ALL;
+  *planes = 1;
+  *send_plane_bytes = *recv_bytes = xsend_bytes(h);
   return SIM_OK;
 }
 int sim_bind_exchange2(sim_handle* h, void* send, void* recv0, void* recv1) {
@@ -5331,15 +5712,18 @@ int sim_bind_exchange2(sim_handle* h, void* send, void* recv0, void* recv1) {
   h->rbuf[0] = (uint4*)recv0;
   h->rbuf[1] = (uint4*)recv1;
   h->d.xrecv = h->rbuf[(h->tick + 1) & 1];
-  if (h->d.rfan) h->d.obox[0] = h->d.obox[1] = (uint4*)send;  // the shard's cells: written by its senders, gathered by the exchange
-  const int fill = h->d.rfan ? 0xFF : 0;  // (random fan-out: all 0xFF — every map word says "nothing sent")
-  HCHECK(hipMemsetAsync(send, fill, xsend_bytes(h), h->stream));
-  HCHECK(hipMemsetAsync(recv0, fill, xrecv_bytes(h), h->stream));
-  if (recv1 != recv0) HCHECK(hipMemsetAsync(recv1, fill, xrecv_bytes(h), h->stream));
+  // (all zero: no packets — the bijection's empty cells, the random fan-out's empty slabs)
+  HCHECK(hipMemsetAsync(send, 0, xsend_bytes(h), h->stream));
+  HCHECK(hipMemsetAsync(recv0, 0, xsend_bytes(h), h->stream));
+  if (recv1 != recv0) HCHECK(hipMemsetAsync(recv1, 0, xsend_bytes(h), h->stream));
   h->bound = true;
   return SIM_OK;
 }
 int sim_bind_exchange(sim_handle* h, void* send, void* recv) { return sim_bind_exchange2(h, send, recv, recv); }
+int sim_bind_exchange3(sim_handle* h, void* send, size_t send_bytes, void* recv0, void* recv1, size_t recv_bytes) {
+  if (!h || !h->d.sharded || send_bytes < xsend_bytes(h) || recv_bytes < xsend_bytes(h)) return SIM_EINVAL;
+  return sim_bind_exchange2(h, send, recv0, recv1);
+}
 int sim_exchange_chunks(const sim_handle* h, uint32_t* chunks, size_t* bytes_per_chunk) {
   if (!h || !chunks || !bytes_per_chunk) return SIM_EINVAL;
   u32 C = h->cfg.chunks ? h->cfg.chunks : 1;
@@ -5396,19 +5780,7 @@ int sim_exchange_chunk(sim_handle* h, uint32_t chunk) {
   if (chunk >= C) return SIM_EINVAL;
   // (called behind sim_step_chunk(chunk), before or after sim_step_end: the packets sent during tick t land in recv[t & 1])
   const u64 t = h->in_tick ? h->tick : h->tick - 1;
-  if (d.rfan) {  // SIM_XCHG_ALL_GATHER: plane j of every shard's cells, in rank order, into plane j of the receive buffer
-    const size_t pb = (size_t)d.M * RF_CELL_U4 * 16;
-    HCHECK(hipEventRecord(h->xev_go, h->stream));
-    HCHECK(hipStreamWaitEvent(h->xstream, h->xev_go, 0));
-    NCHECK(ncclGroupStart());
-    for (u32 j = 0; j < d.fp; ++j)
-      NCHECK(ncclAllGather(reinterpret_cast<const uint8_t*>(d.xsend) + (size_t)j * pb, reinterpret_cast<uint8_t*>(h->rbuf[t & 1]) + (size_t)j * pb * V, pb, ncclUint8,
-                           h->xcomm, h->xstream));
-    NCHECK(ncclGroupEnd());
-    h->xpending = true;
-    return SIM_OK;
-  }
-  const size_t chunk_bytes = (size_t)d.fp * d.M * sizeof(sim_packet) / C, slab = chunk_bytes / V;
+  const size_t chunk_bytes = xsend_bytes(h) / C, slab = chunk_bytes / V;  // (random fan-out: the V packed slabs, one chunk)
   const uint8_t* send = reinterpret_cast<const uint8_t*>(d.xsend) + (size_t)chunk * chunk_bytes;
   uint8_t* recv = reinterpret_cast<uint8_t*>(h->rbuf[t & 1]) + (size_t)chunk * chunk_bytes;
   // the exchange stream waits for what the handle's stream holds now — this chunk's launch —, not for the chunks after it

@@ -1,6 +1,6 @@
 """Sharded runs: one process per GPU, node-id range partition, the all-to-all of a gossip round overlapped with compute.
 
-Shard g owns nodes [g*M, (g+1)*M).  The tick kernel writes every outgoing packet into a send buffer laid out
+Shard g owns nodes [g*M, (g+1)*M).  The bijection's tick kernel writes every outgoing packet into a send buffer laid out
 [sender chunk][destination shard][fan-out slot][M/V/C packets]: the fan-out map (DESIGN.md SIMSPEC §2.3) sends the
 packets of one sender chunk for one (destination, slot) to exactly one dense slab, so
 
@@ -11,6 +11,12 @@ packets of one sender chunk for one (destination, slot) to exactly one dense sla
   slabs of chunk c travel while chunk c + 1 computes.  Only the last chunk's exchange is exposed.  Every exchange of
   round t has to be complete before round t + 1 reads it, and the later chunks of round t + 1 still read round t's
   packets while the first chunks of t + 1 arrive, so the receive side is double-buffered (recv[t & 1]).
+
+memberlist's literal kRandomNodes (SIM_CF_RANDOM_FANOUT) sends a packet to ANY node, so there is no dense slab a tick kernel could
+write into: the packets stay in their senders' cells, every shard sorts the (target, sender, slot) triples of its OWN senders and
+packs the packets bound for shard h into slab h in that order, one count byte per target next to them (sim_exchange_layout:
+XCHG_PACKED); the exchange is the same equal-split all-to-all — f * M * (V - 1) / V packets leave a GPU per round —, the receiver's
+row is V sorted runs.  One chunk per tick in this mode.
 
 The reference has no collective at all (its transport is UDP/TCP inside memberlist); this replaces
 `memberlist.send`-style delivery for the simulation.
@@ -43,15 +49,17 @@ class ShardedSim:
         self.sim = _ffi.Sim(lib, _ffi.make_config(n_nodes, **kw))
         nbytes = self.sim.exchange_bytes()
         self.chunks, self.chunk_bytes = self.sim.exchange_chunks()
-        # what the round's exchange is: the bijection's slabs (all-to-all) or — memberlist's kRandomNodes, whose packets stay in
-        # their senders' cells — an all-gather of the shards' cells, plane by plane (include/serf_sim.h sim_exchange_layout)
+        # what the round's exchange is (include/serf_sim.h sim_exchange_layout): always an equal-split all-to-all — of the slabs
+        # the bijection's tick kernel writes, or (memberlist's kRandomNodes: XCHG_PACKED) of the slabs the library packs, behind the
+        # tick's launch, from the packets the senders keep
         self.kind, self.planes, self.plane_bytes, recv_bytes = self.sim.exchange_layout()
+        assert self.kind in (_ffi.XCHG_ALL_TO_ALL, _ffi.XCHG_PACKED) and self.planes == 1 and recv_bytes == nbytes
         # plain byte tensors: torch only provides device memory + the collective
         self.send = torch.zeros(nbytes, dtype=torch.uint8, device=device)
         self.recv = [torch.zeros(recv_bytes, dtype=torch.uint8, device=device) for _ in range(2 if self.chunks > 1 else 1)]
         if device.type == "cuda":
             self.sim.set_stream(torch.cuda.current_stream(device).cuda_stream)
-        self.sim.bind_exchange2(self.send.data_ptr(), self.recv[0].data_ptr(), self.recv[-1].data_ptr())
+        self.sim.bind_exchange3(self.send.data_ptr(), nbytes, self.recv[0].data_ptr(), self.recv[-1].data_ptr(), recv_bytes)
         backend = dist.get_backend(group)
         self.use_lib = exchange == "rccl" or (exchange == "auto" and device.type == "cuda" and backend == "nccl" and lib.exchange_library() is not None)
         if self.use_lib:
@@ -117,13 +125,11 @@ class ShardedSim:
 
     def collective_library(self):
         """what moves the round's packets: "RCCL x.y.z (issued by the library: grouped ncclSend / ncclRecv)" or torch's backend"""
-        gather = self.kind == _ffi.XCHG_ALL_GATHER
         if self.use_lib:
-            return self.lib.exchange_library() + (" — issued by libserf_sim (sim_exchange_chunk: ncclAllGather per plane of cells)" if gather else
-                                                  " — issued by libserf_sim (sim_exchange_chunk: grouped ncclSend / ncclRecv per peer)")
+            return self.lib.exchange_library() + " — issued by libserf_sim (sim_exchange_chunk: grouped ncclSend / ncclRecv per peer)"
         backend = dist.get_backend(self.group)
         if backend == "nccl" and self.device.type == "cuda":
-            return "RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version()) + (" — torch.distributed.all_gather_into_tensor" if gather else " — torch.distributed.all_to_all_single")
+            return "RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version()) + " — torch.distributed.all_to_all_single"
         return backend
 
     def snapshot(self):
@@ -229,30 +235,17 @@ class ShardedSim:
             if self._poll_suspects:
                 self._suspicions_out()
 
-    def _gather(self, recv, send):
-        """SIM_XCHG_ALL_GATHER: plane j of every shard's cells, in rank order, into plane j of the receive buffer"""
-        pb = self.plane_bytes
-        for j in range(self.planes):
-            dist.all_gather_into_tensor(recv[j * pb * self.world:(j + 1) * pb * self.world], send[j * pb:(j + 1) * pb], group=self.group)
-
     def restore(self, image):
-        """sim_restore of this shard's image.  With the random fan-out the image holds the shard's OWN cells (the packets in
-        flight in their senders' cells): what the other shards sent has to be gathered again before the next tick."""
+        """sim_restore of this shard's image (collective: every rank restores its own).  With the random fan-out the image holds the
+        shard's OWN cells (the packets in flight in their senders' cells); the library has packed them into the send buffer
+        again (XCHG_PACKED) and the round's exchange is run once more before the next tick."""
+        self._drain()
         self.sim.restore(image)
-        if self.kind == _ffi.XCHG_ALL_GATHER:
-            self._exchange(0, self.recv[0], self.send, False)
+        if self.kind == _ffi.XCHG_PACKED and self.sim.tick > 0:
+            rbuf = self.recv[(self.sim.tick - 1) & 1] if self.chunks > 1 else self.recv[0]
+            self._exchange(0, rbuf, self.send, False)
 
     def _exchange(self, c, recv, send, asynchronous):
-        if self.kind == _ffi.XCHG_ALL_GATHER and not self.use_lib:
-            if self._xt is not None:
-                e0, e1 = self._event(), self._event()
-                e0.record()
-                self._gather(recv, send)
-                e1.record()
-                self._xt.append((e0, e1))
-            else:
-                self._gather(recv, send)
-            return
         if self._xt is not None:  # measurement mode: bracket the collective with events, no overlap
             e0, e1 = self._event(), self._event()
             e0.record()

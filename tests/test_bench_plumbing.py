@@ -58,7 +58,7 @@ def test_bench_control_flow(world):
 
 
 def test_bench_control_flow_random_fanout_on_two_ranks():
-    # (r4) the N > 1 line on memberlist's kRandomNodes: ShardedSim's all-gather of the shards' cells, the JSON's exchange section
+    # (r4, r5) the N > 1 line on memberlist's kRandomNodes: ShardedSim's all-to-all of the packed slabs, the JSON's exchange section
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
@@ -73,8 +73,12 @@ def test_bench_control_flow_random_fanout_on_two_ranks():
     assert not any(str(v).startswith("ERR") for v in res.values()), res
     out = json.loads(res[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["fanout_model"] == "krandomnodes"
-    assert out["exchange"]["collective"].startswith("all-gather") and out["exchange"]["chunks"] == 1
-    assert out["exchange"]["bytes_arriving_per_gpu_per_tick"] == out["exchange"]["bytes_per_gpu_per_tick"]
+    assert out["exchange"]["collective"].startswith("equal-split all-to-all of packed slabs") and out["exchange"]["chunks"] == 1
+    x = out["exchange"]
+    # what leaves a rank: (V - 1) / V of its slabs; the slabs are the packets (64-byte cells) plus a few per cent (12 sigma of room,
+    # a count byte per target, headers) — not the O(N) per shard of round 4's all-gather
+    assert x["bytes_arriving_per_gpu_per_tick"] == x["bytes_leaving_gpu_per_tick"] == x["bytes_per_gpu_per_tick"] // 2
+    assert x["bytes_per_gpu_per_tick"] < 1.4 * x["packet_bytes_per_gpu_per_tick"]   # (2 048 nodes per rank: 12 sigma is 9 % here; the oracle's slab carries 8 index bytes per packet)
     assert 1 <= out["rounds_to_99"]["median"] <= 60
 
 
@@ -95,7 +99,10 @@ def test_bench_launches_its_own_ranks(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and "error" not in out
     assert out["distributed"]["world_size"] == 2 and out["distributed"]["backend"] == "gloo"
-    assert out["exchange"]["chunks"] == 2
+    # (r5) at every N the headline is the reference's kRandomNodes (one exchange of packed slabs per round), the bijection — its
+    # all-to-all issued chunk-wise — next to it: the 1 -> 8 GPU series is ONE model
+    assert out["config"]["fanout_model"] == "krandomnodes" and out["exchange"]["chunks"] == 1
+    assert out["fanout_models"]["bijection"]["exchange"]["chunks"] == 2 and out["fanout_models"]["bijection"]["value"] > 0
 
 
 def test_bench_reports_a_dead_rank_instead_of_hanging():

@@ -1,0 +1,87 @@
+"""Parity at the sizes BASELINE.json names: the HIP library against the CPU oracle at 4 Mi nodes / 4 virtual
+shards on BOTH fan-out models (configs[3]'s cluster in one handle), at one rank's share of configs[4] (2 Mi nodes, 8 virtual
+shards, 2 sender chunks, churn + 1 % loss, packets of 16 records, 200 ticks), and on memberlist's kRandomNodes above 4 Mi nodes
+(64-bit entries in the graph build's sort).  `sim_state_digest` — all eight arrays: rows, queues, packets in flight, views, both
+rings, slot map + liveness, query tables — every 10th tick and at the end; views and rings are small (32 / 128 view slots) so that
+the oracle's arrays fit the host (the protocol does not depend on how many slots are spare: tests/test_oracle_unbounded.py).
+The oracle is the slow side: ~0.2 - 0.5 s per tick at these sizes on the box's host cores; runtimes are printed."""
+import time
+
+import numpy as np
+import pytest
+
+from serf_amd import _ffi
+from tests import _scenario as sc
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(oracle, hiplib, n, ops, ticks, every, what, **kw):
+    t0 = time.perf_counter()
+    g = _ffi.Sim(hiplib, _ffi.make_config(n, **kw))
+    o = _ffi.Sim(oracle, _ffi.make_config(n, **kw))
+    for x in (g, o):
+        for op in ops:
+            x.inject(*op)
+    done = 0
+    while done < ticks:
+        k = min(every, ticks - done)
+        g.step(k)
+        o.step(k)
+        done += k
+        dg, do = g.digest(), o.digest()
+        assert dg == do, f"{what}: digests differ after tick {done - 1}: arrays {[i for i in range(8) if dg[i] != do[i]]}"
+    cg, co = g.cluster_stats(), o.cluster_stats()
+    assert cg == co, f"{what}: load figures differ {cg} {co}"
+    print(f"{what}: {n} nodes x {ticks} ticks bit-exact ({ticks // every} digests), {time.perf_counter() - t0:.0f} s; "
+          f"drops {cg['overflow']}, slots in use {cg['slots_in_use']}, failed {cg['failed']}, left {cg['left']}")
+    g.close()
+    o.close()
+    return cg
+
+
+@pytest.mark.parametrize("model", ["krandomnodes", "bijection"])
+def test_4mi_nodes_4_vshards_both_models(oracle, hiplib, model):
+    # BASELINE configs[3]'s cluster (4 Mi nodes sharded 4-way) as ONE handle: 4 virtual shards — the bijection's map has the
+    # sharded shape (vblocks, rotations), kRandomNodes draws over all 4 Mi nodes (64-bit entries in the graph build: 24 + 10 bits)
+    n = 1 << 22
+    kw = dict(fanout=4, vshards=4, view_slots=32, event_ring=32, query_ring=16, probe_interval=5, loss=0.01, push_pull_interval=20,
+              leave_delay=6, reap_interval=15, queue_check_interval=30, recycle_interval=25)
+    if model == "krandomnodes":
+        kw["flags"] = _ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT
+    ops = sc.schedule(n, 45, rate=0.5, seed=41, max_member_subjects=14)
+    _run(oracle, hiplib, n, ops, 60, 10, f"4 Mi nodes, 4 vshards, {model}", **kw)
+
+
+def test_one_ranks_share_of_config4_2mi_8_vshards_2_chunks_churn_loss_16_records(oracle, hiplib):
+    # BASELINE configs[4] (16 Mi nodes sharded 8-way, 5 % churn + 1 % loss): one rank's share — 2 Mi nodes in the shape of an
+    # 8-way sharded cluster (8 virtual shards, 2 sender chunks), packets of 16 records, the failure detector with memberlist's
+    # stream-transport fallback ping and the join sync (what the configs[4] runs use), crash + re-join
+    # churn at the pace the view slots allow, 1 % loss on every packet and probe leg, view-slot recycling — 200 ticks
+    n = 1 << 21
+    kw = dict(fanout=4, vshards=8, chunks=2, view_slots=128, event_ring=32, query_ring=16, probe_interval=5, loss=0.01,
+              push_pull_interval=30, leave_delay=6, reap_interval=15, queue_check_interval=30, recycle_interval=25, pkt_records=16,
+              suspicion_mult=3, suspicion_max_mult=2, tcp_fallback=True, join_sync=True)
+    rng = np.random.default_rng(9)
+    churned = rng.choice(n, 60, replace=False).tolist()
+    ops = []
+    for i, node in enumerate(churned):       # one crash every 3 ticks, down 40 ticks (suspected, confirmed, declared failed: the
+        ops.append((5 + 3 * i, _ffi.OP_CRASH, node, 0, 0))   # suspicion timeout is 3 x 6 x 5 = 94 ticks at most here), then Serf::join
+        ops.append((5 + 3 * i + 40, _ffi.OP_JOIN, node, int(rng.integers(0, n)), 0))
+    for i in range(60):                      # rumours on top: user events and queries
+        ops.append((3 * i + 1, _ffi.OP_USER_EVENT, int(rng.integers(0, n)), 5000 + i, 40))
+        if i % 3 == 0:
+            ops.append((3 * i + 2, _ffi.OP_QUERY, int(rng.integers(0, n)), 300 + i, 0))
+    ops.sort(key=lambda o: o[0])
+    cs = _run(oracle, hiplib, n, ops, 200, 10, "2 Mi nodes, 8 vshards, 2 chunks, churn + 1 % loss, 16-record packets", **kw)
+    assert cs["failed"] > 0 or cs["left"] > 0 or cs["slots_in_use"] > 0   # the churn happened
+
+
+def test_krandomnodes_above_4mi_nodes(oracle, hiplib):
+    # memberlist's kRandomNodes at 6 Mi nodes: pair ids of 25 bits, 64-bit entries in rf_scatter / rf_rows, 2 048 senders per
+    # workgroup — the path profiles/r04_size_sweep.json timed and nothing checked
+    n = 6 << 20
+    kw = dict(fanout=4, view_slots=16, event_ring=16, query_ring=8, probe_interval=5, loss=0.01, push_pull_interval=20, leave_delay=6,
+              flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT)
+    ops = sc.schedule(n, 25, rate=0.5, seed=77, max_member_subjects=7)
+    _run(oracle, hiplib, n, ops, 30, 10, "6 Mi nodes, kRandomNodes (64-bit sort entries)", **kw)

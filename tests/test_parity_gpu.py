@@ -19,7 +19,7 @@ def pair(oracle, hiplib, n, **kw):
 
 def test_backend_is_hip(hiplib):
     assert hiplib.backend_name() == "hip-gfx950"
-    assert hiplib.abi_version() == 12
+    assert hiplib.abi_version() == 13
 
 
 @pytest.mark.parametrize("swim", [0, 5, 2])
@@ -595,31 +595,48 @@ def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim, chunks, pkt
     assert tuple(tot) == ref.convergence(_ffi.K_LEAVE, next(o for o in ops if o[1] == _ffi.OP_LEAVE)[2], 1)
 
 
-@pytest.mark.parametrize("swim,pkt,rc,n", [(0, 0, 0, 2048), (4, 0, 0, 2048), (4, 8, 0, 2048), (2, 0, 3, 2048), (4, 0, 0, 1 << 16)])
-def test_random_fanout_four_shards_on_one_gpu(oracle, hiplib, swim, pkt, rc, n):
-    # memberlist's kRandomNodes on shards (r4): 4 handles on ONE GPU, each drawing the whole cluster's
-    # targets and keeping the rows of its own nodes; the packets stay in their senders' cells and the round's exchange is
-    # an all-gather of the shards' cells (sim_exchange_layout: SIM_XCHG_ALL_GATHER), done here with device-to-device copies —
-    # plane j of shard g into plane j of every receive buffer, at g's place.  Every shard against the oracle's matching slice
-    # of ONE handle that holds every node; the cross-shard push-pull / suspicion hand-over as in the bijection's test.
+def _packed_exchange_on_one_gpu(send, recv):
+    """SIM_XCHG_PACKED / SIM_XCHG_ALL_TO_ALL with device-to-device copies: slab g of shard src's send buffer -> slab src of shard g's
+    receive buffer (equal split: what all_to_all_single, or the library's grouped ncclSend / ncclRecv, does)"""
+    V = len(send)
+    slab = send[0].numel() // V
+    for g in range(V):
+        for src in range(V):
+            recv[g][src * slab:(src + 1) * slab].copy_(send[src][g * slab:(g + 1) * slab])
+
+
+@pytest.mark.parametrize("V,swim,pkt,rc,n", [(4, 0, 0, 0, 2048), (4, 4, 0, 0, 2048), (4, 4, 8, 0, 2048), (4, 2, 0, 3, 2048), (4, 4, 0, 0, 1 << 16),
+                                             (8, 4, 16, 0, 4096), (2, 4, 0, 0, 1 << 17), (8, 0, 0, 0, 64)])
+def test_random_fanout_four_shards_on_one_gpu(oracle, hiplib, V, swim, pkt, rc, n):
+    # memberlist's kRandomNodes on shards (r5: the scalable form, VERDICT r4 item 1): V handles on ONE GPU, each sorting the
+    # (target, sender, slot) triples of its OWN senders and packing the packets bound for shard h into slab h (sim_exchange_layout:
+    # SIM_XCHG_PACKED); the round's exchange is an equal-split all-to-all of the slabs, done here with device-to-device copies.
+    # Every shard against the oracle's matching slice of ONE handle that holds every node; the cross-shard push-pull / suspicion
+    # hand-over as in the bijection's test.  (2 x 64 Ki: 64-bit sort entries; 8 x 8 nodes: slabs that hold everything.)
     import torch
 
-    V, ticks = 4, 50 if not rc else 90
+    ticks = 50 if not rc else 90
     m = n // V
-    kw = dict(fanout=4, view_slots=96, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=0.02,
+    kw = dict(fanout=4, view_slots=96 if n > 64 else 0, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=0.02,
               push_pull_interval=3 if swim else 0, pkt_records=pkt, reconnect_interval=rc, flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT,
               **(dict(suspicion_mult=3, suspicion_max_mult=2, gossip_to_the_dead=1) if rc else {}))
+    A = 96 if n > 64 else n
     ref = _ffi.Sim(oracle, _ffi.make_config(n, vshards=V, **kw))
     shards, send, recv = [], [], []
     for g in range(V):
         s = _ffi.Sim(hiplib, _ffi.make_config(n, vshards=V, shard_rank=g, shard_count=V, **kw))
         kind, planes, pb, rb = s.exchange_layout()
-        assert kind == _ffi.XCHG_ALL_GATHER and planes * pb == s.exchange_bytes() and rb == V * planes * pb
-        send.append(torch.zeros(planes * pb, dtype=torch.uint8, device="cuda"))
+        assert kind == _ffi.XCHG_PACKED and planes == 1 and pb == rb == s.exchange_bytes() and pb % (64 * V) == 0
+        # what leaves a GPU per tick: f packets of 64 bytes per node, (V - 1) / V of them, 2 % of room, a count byte per target
+        if n >= 1 << 16:   # (12 sigma of sqrt(m) = 16 Ki packets per slab is 9 %; at 1 Mi nodes per shard it is 2 %)
+            assert pb <= 1.13 * 4 * 64 * m, (pb, 4 * 64 * m)
+        send.append(torch.zeros(pb, dtype=torch.uint8, device="cuda"))
         recv.append(torch.zeros(rb, dtype=torch.uint8, device="cuda"))
-        s.bind_exchange2(send[-1].data_ptr(), recv[-1].data_ptr(), recv[-1].data_ptr())
+        with pytest.raises(_ffi.SimError):   # the sized bind refuses buffers that are too small (ADVICE r4)
+            s.bind_exchange3(send[-1].data_ptr(), pb - 64, recv[-1].data_ptr(), recv[-1].data_ptr(), rb)
+        s.bind_exchange3(send[-1].data_ptr(), pb, recv[-1].data_ptr(), recv[-1].data_ptr(), rb)
         shards.append(s)
-    ops = sc.schedule(n, ticks // 2, rate=0.8 if not pkt else 3.0, seed=5, max_member_subjects=60)
+    ops = sc.schedule(n, ticks // 2, rate=0.8 if not pkt else 3.0, seed=5, max_member_subjects=min(60, n // 2))
     for s in shards + [ref]:
         sc.apply_schedule(s, ops)
         for x in ((7, 300, 777, 1200, 1500, 2000) if rc else ()):
@@ -627,23 +644,24 @@ def test_random_fanout_four_shards_on_one_gpu(oracle, hiplib, swim, pkt, rc, n):
             if x > 500:
                 s.inject(50, _ffi.OP_REVIVE, x)
     fp = 4 * max(1, pkt // 4)
-    for t in range(ticks):
-        for s in shards:
+
+    def tick_all(hs):
+        for s in hs:
             s.step_begin()
-        if shards[0].pp_due():
-            _push_pull_on_one_gpu(shards)
-        for s in shards:
+        if hs[0].pp_due():
+            _push_pull_on_one_gpu(hs)
+        for s in hs:
             s.step_chunk(0)
-        for s in shards:
+        for s in hs:
             s.step_end()
             s.sync()
-        for g in range(V):              # the all-gather, plane by plane
-            for j in range(planes):
-                for src in range(V):
-                    recv[g][(j * V + src) * pb:(j * V + src + 1) * pb].copy_(send[src][j * pb:(j + 1) * pb])
-        _suspicions_on_one_gpu(shards)
+        _packed_exchange_on_one_gpu(send, recv)
+        _suspicions_on_one_gpu(hs)
         torch.cuda.synchronize()
         ref.step(1)
+
+    for t in range(ticks):
+        tick_all(shards)
         if t % 7 == 0 or t == ticks - 1:
             for g, s in enumerate(shards):
                 lo = g * m
@@ -652,18 +670,35 @@ def test_random_fanout_four_shards_on_one_gpu(oracle, hiplib, swim, pkt, rc, n):
                     per = len(b) // n
                     i = sc.first_diff(a, b[lo * per:(lo + m) * per])
                     assert i is None, f"shard {g} array {which} element {i} differs at tick {t}"
-                for which, rows in ((_ffi.ARR_VIEW, 96), (_ffi.ARR_ERING, 16), (_ffi.ARR_QRING, 8), (_ffi.ARR_INBOX, fp)):
+                for which, rows in ((_ffi.ARR_VIEW, A), (_ffi.ARR_ERING, 16), (_ffi.ARR_QRING, 8), (_ffi.ARR_INBOX, fp)):
                     a = s.dump(which).reshape(rows, m)
                     b = np.ascontiguousarray(ref.dump(which).reshape(rows, n)[:, lo:lo + m])
                     assert a.tobytes() == b.tobytes(), f"shard {g} array {which} differs at tick {t}"
     tot = [sum(x) for x in zip(*(s.convergence(_ffi.K_LEAVE, next(o for o in ops if o[1] == _ffi.OP_LEAVE)[2], 1) for s in shards))]
     assert tuple(tot) == ref.convergence(_ffi.K_LEAVE, next(o for o in ops if o[1] == _ffi.OP_LEAVE)[2], 1)
-    # a checkpoint of shard 1 into a fresh handle: its own cells come back, the others' are gathered again, the run goes on
-    img = shards[1].snapshot()
-    fresh = _ffi.Sim(hiplib, _ffi.make_config(n, vshards=V, shard_rank=1, shard_count=V, **kw))
-    fresh.bind_exchange2(send[1].data_ptr(), recv[1].data_ptr(), recv[1].data_ptr())
-    fresh.restore(img)
-    assert fresh.digest() == shards[1].digest()
+    # a checkpoint of EVERY shard into fresh handles: their own cells come back, the library packs them again, the exchange is
+    # run once more, and the restored run goes on in step with the oracle
+    pend = shards[0].__dict__.get("_sq_pending", [])
+    while pend:  # (the lists of slot-less suspicions still travelling live in the host's queue: imported first, like ShardedSim.snapshot)
+        of_tick, heads = pend.pop(0)
+        for s in shards:
+            s.suspect_import(of_tick, heads.data_ptr(), V)
+    imgs = [s.snapshot() for s in shards]
+    fresh = []
+    for g in range(V):
+        f2 = _ffi.Sim(hiplib, _ffi.make_config(n, vshards=V, shard_rank=g, shard_count=V, **kw))
+        f2.bind_exchange3(send[g].data_ptr(), send[g].numel(), recv[g].data_ptr(), recv[g].data_ptr(), recv[g].numel())
+        f2.restore(imgs[g])
+        assert f2.digest() == shards[g].digest()
+        fresh.append(f2)
+    torch.cuda.synchronize()
+    _packed_exchange_on_one_gpu(send, recv)
+    for t in range(6):
+        tick_all(fresh)
+        for g, s in enumerate(fresh):
+            a, b = s.dump(_ffi.ARR_ROWS), ref.dump(_ffi.ARR_ROWS)
+            per = len(b) // n
+            assert sc.first_diff(a, b[g * m * per:(g + 1) * m * per]) is None, f"restored shard {g} differs {t + 1} ticks on"
 
 
 def test_sharded_kernel_b64_four_shards_of_64k_on_one_gpu(oracle, hiplib):
@@ -1070,10 +1105,10 @@ def _one_rank_rccl_worker(port, q):
                 assert keep(sh.sim.digest()) == keep(plain.digest()) == keep(orc.digest()), f"chunks {chunks}: digests differ after tick {5 * t + 4}"
             out[chunks] = sh.collective_library()
             sh.close()
-        # the random fan-out as one rank of the N > 1 path: the round's all-gather of the cells as ncclAllGather issued by the library
+        # the random fan-out as one rank of the N > 1 path: the packed slabs (SIM_XCHG_PACKED) over the same grouped ncclSend / ncclRecv
         kw_rf = dict(kw, flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT, recycle_interval=0)
         sh = ShardedSim(lib, n, dev, chunks=1, exchange="rccl", **kw_rf)
-        assert sh.use_lib and sh.kind == _ffi.XCHG_ALL_GATHER
+        assert sh.use_lib and sh.kind == _ffi.XCHG_PACKED
         plain = _ffi.Sim(lib, _ffi.make_config(n, **kw_rf))
         orc = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw_rf))
         for x in (sh, plain, orc):
@@ -1083,7 +1118,7 @@ def _one_rank_rccl_worker(port, q):
             plain.step(5)
             orc.step(5)
             sh.sync()
-            assert sh.sim.digest() == plain.digest() == orc.digest(), f"random fan-out over ncclAllGather: digests differ after tick {5 * t + 4}"
+            assert sh.sim.digest() == plain.digest() == orc.digest(), f"random fan-out, packed slabs over RCCL: digests differ after tick {5 * t + 4}"
         sh.close()
         dist.destroy_process_group()
         q.put(("ok", out[1]))

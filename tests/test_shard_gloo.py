@@ -124,9 +124,10 @@ def _worker(rank, world, port, n, ticks, swim, chunks, q, jitter=0.0, pkt=0, los
 @pytest.mark.parametrize("world,swim,n,pkt,loss,rc", [(2, 0, 1024, 0, .02, 0), (2, 4, 1024, 0, .02, 0), (4, 2, 2048, 8, .12, 2), (4, 1, 1024, 16, .0, 3),
                                                       (1, 4, 1024, 0, .02, 0)])
 def test_shards_gloo_random_fanout_match_single_process(world, swim, n, pkt, loss, rc):
-    # memberlist's kRandomNodes on shards (r4): a packet goes to ANY node of the cluster, so the packets stay in their senders'
-    # cells and the round's exchange is an all-gather of the shards' cells (sim_exchange_layout: SIM_XCHG_ALL_GATHER); every
-    # shard draws the whole cluster's targets and keeps the rows of its own nodes.  Against ONE handle that holds every node.
+    # memberlist's kRandomNodes on shards (r5: the scalable form): a packet goes to ANY node of the cluster, so the packets stay
+    # in their senders' cells; every shard sorts the (target, sender, slot) triples of its OWN senders, packs the packets bound
+    # for shard h into slab h and the round's exchange is one equal-split all-to-all of those slabs (sim_exchange_layout:
+    # SIM_XCHG_PACKED); nobody draws anybody else's targets.  Against ONE handle that holds every node.
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")

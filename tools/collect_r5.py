@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Copy the summaries of tools/gpu/r5_measure.sh (gpurun_out/r5m) into profiles/ under their judged names and derive, for EACH
+fan-out model and EACH window (the driver's 20 timed launches; the 300 launches of the long window, ticks 345 .. 644),
+profiles/r05_pmc_traffic_<model>[_long].json — HBM bytes per tick-kernel launch with the calibration factors of
+profiles/r02_hbm_counter_calibration.json — stamped with the commit and the hash of the kernel source it was measured on
+(bench.py reports the figure as roofline.traffic / roofline.frac_measured only while that hash is the current one).
+
+usage: python tools/collect_r5.py [call_dir]"""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+call = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r5m")
+out = os.path.join(ROOT, "profiles")
+
+
+def last_json(path):
+    text = open(path).read().strip()
+    try:
+        return json.loads(text)
+    except json.JSONDecodeError:
+        return json.loads([ln for ln in text.splitlines() if ln.startswith("{")][-1])
+
+
+for src, dst in (("bench_20_5.json", "r05_bench_driver_args.json"), ("bench_one_rank_rccl.json", "r05_bench_one_rank_rccl.json"),
+                 ("bench_one_rank_rccl_krandomnodes.json", "r05_bench_one_rank_rccl_krandomnodes.json")):
+    if os.path.exists(os.path.join(call, src)) and os.path.getsize(os.path.join(call, src)):
+        json.dump(last_json(os.path.join(call, src)), open(os.path.join(out, dst), "w"), indent=1)
+sha = hashlib.sha256(open(os.path.join(ROOT, "serf_amd", "csrc", "serf_sim.hip"), "rb").read()).hexdigest()[:16]
+commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+n = 1 << 20
+for model in ("krandomnodes", "bijection"):
+    for window, steps, warmup, sfx in (("short", 20, 5, ""), ("long", 300, 25, "_long")):
+        d = os.path.join(call, f"{model}_{window}")
+        if not os.path.exists(os.path.join(d, "tick_kernel_pmc.json")):
+            continue
+        if os.path.getsize(os.path.join(d, "bench_traced.json")):
+            json.dump(last_json(os.path.join(d, "bench_traced.json")), open(os.path.join(out, f"r05_bench_under_rocprof_{model}{sfx}.json"), "w"), indent=1)
+        for f in (os.path.join(d, "trace", "t_kernel_stats.csv"),):
+            if os.path.exists(f):
+                shutil.copy(f, os.path.join(out, f"r05_kernel_stats_{model}{sfx}.csv"))
+        pmc = json.load(open(os.path.join(d, "tick_kernel_pmc.json")))
+        json.dump(pmc, open(os.path.join(out, f"r05_tick_kernel_pmc_{model}{sfx}.json"), "w"), indent=1)
+        c = pmc["counters"]
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            continue
+        read, write = 2.0 * c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024   # both counters are in KiB
+        traffic = {
+            "kernel": "tick_kernel", "fanout_model": model, "window": window, "launches_averaged": pmc["launches"], "kernel_us_mean_profiled": pmc["kernel_us_mean"],
+            "hbm_read_bytes": read, "hbm_write_bytes": write, "hbm_bytes_per_launch": read + write,
+            "hbm_gbps_over_the_profiled_launches": (read + write) / pmc["kernel_us_mean"] / 1e3,
+            "frac_of_8_tbps": (read + write) / pmc["kernel_us_mean"] / 1e3 / 8000.0,
+            "fetch_size_raw_kib": c["FETCH_SIZE"], "write_size_raw_kib": c["WRITE_SIZE"],
+            "commit": commit, "kernel_source_sha16": sha, "steps": steps, "warmup": warmup,
+            "workload": f"bench.py defaults, fan-out model {model}: 1 Mi nodes, fan-out 4, 0.25 API ops/tick, 4 records per packet, the {steps} timed "
+                        f"launches of --steps {steps} --warmup {warmup} (ticks {320 + warmup} .. {320 + warmup + steps - 1})",
+            "calibration": "reads = 2 x FETCH_SIZE, writes = WRITE_SIZE: tools/calib on this kernel's access shapes "
+                           "(profiles/r02_hbm_counter_calibration.json): TCC_EA0_RDREQ counts 128-byte requests, FETCH_SIZE prices "
+                           "them at 64 B (factor 0.500 for every read pattern); WRITE_SIZE exact (factor 1.000)",
+            "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python bench.py --fanout-model {model} "
+                      f"--no-cpu-baseline --no-convergence --no-second-load --no-long-window --steps {steps} --warmup {warmup}` (tools/gpu/r5_measure.sh), mean over "
+                      f"the {steps} timed launches",
+            "algorithmic_bytes_per_launch_v0": 1176 * n, "traffic_over_algorithmic": (read + write) / (1176 * n),
+        }
+        json.dump(traffic, open(os.path.join(out, f"r05_pmc_traffic_{model}{sfx}.json"), "w"), indent=1)
+        print(model, window, json.dumps({k: traffic[k] for k in ("kernel_us_mean_profiled", "hbm_bytes_per_launch", "frac_of_8_tbps", "traffic_over_algorithmic", "commit", "kernel_source_sha16")}))

@@ -5,7 +5,7 @@ single-process run of the CPU oracle (test infrastructure).  The multi-process t
 tests/test_parity_gpu.py::test_sharded_kernel_four_shards_on_one_gpu; run it on the GPU box under `timeout`.
 
 usage: python tools/shard_procs_check.py [world] [chunks] [swim] [nodes] [loss] [rf]
-(rf = 1: memberlist's kRandomNodes — the round's exchange is the all-gather of the shards' cells; chunks must be 1)
+(rf = 1: memberlist's kRandomNodes — the round's exchange is the all-to-all of the packed slabs, SIM_XCHG_PACKED; chunks must be 1)
 (loss >= 0.05: 256 view slots, and the run must have carried slot-less suspicions across the shards)"""
 import os
 import sys

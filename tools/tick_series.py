@@ -51,7 +51,7 @@ doc = {"nodes": n, "fanout_model": args.fanout_model, "first_tick": first, "tick
                "wave averages from the -DTICK_TIMING build on the same schedule (handler-loop iterations, classification rounds that looked "
                "anything up, records left for the handlers, of those fetched again); ops = operation codes the schedule applies in that tick"}
 # pass 1: the product library, one timed launch per tick
-sim = cluster(serf_amd.load())
+sim = cluster(serf_amd.load() if not os.environ.get("SERIES_LIB") else _ffi.SimLib(os.environ["SERIES_LIB"]))
 sim.profile(1)
 kms = []
 load = []
@@ -80,13 +80,14 @@ if os.path.exists(tlib_path):
         sim.sync()
         tlib.dll.sim_debug_timing(buf, 1)
         series.append({"iters": buf[12] / waves, "rounds": buf[13] / waves, "slow": buf[14] / waves, "refetched": buf[15] / waves,
+                       "copies": buf[16] / waves, "slow_by_kind": [round(buf[17 + i] / waves, 2) for i in range(7)],  # JOIN LEAVE EVENT QUERY ALIVE SUSPECT DEAD
                        "cyc_handlers": buf[5] / waves, "cyc_total": sum(buf[:12]) / waves})
     sim.close()
 rows = []
 for i in range(count):
     r = {"tick": first + i, "kernel_ms": round(kms[i], 5), "ops": by_tick.get(first + i, [])}
     if series:
-        r.update({k: round(v, 3) for k, v in series[i].items()})
+        r.update({k: (round(v, 3) if not isinstance(v, list) else v) for k, v in series[i].items()})
     rows.append(r)
 doc["series"] = rows
 doc["load_every_20_ticks"] = load
