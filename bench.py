@@ -51,7 +51,8 @@ PMC_TRAFFIC = {"krandomnodes": ("profiles/r05_pmc_traffic_krandomnodes.json", "p
 # ... and over the launches of the LONG window (its own PMC passes: the bytes a launch moves follow the load of the ticks it covers)
 PMC_TRAFFIC_LONG = {"krandomnodes": ("profiles/r05_pmc_traffic_krandomnodes_long.json",), "bijection": ("profiles/r05_pmc_traffic_bijection_long.json",)}
 LONG_WINDOW = 300  # ticks of the second timed window (with --steps < 300): long enough to hold a push-pull batch and recycling passes
-KERNEL_SOURCE = os.path.join("serf_amd", "csrc", "serf_sim.hip")
+# the DEVICE side of the tick kernel (state + queue, handlers + classification, the kernel itself): what a PMC profile is valid for
+KERNEL_SOURCES = [os.path.join("serf_amd", "csrc", f) for f in ("serf_sim_state.inc", "serf_sim_handlers.inc", "serf_sim_tick.inc")]
 # rounds-to-99 %: every user event the workload issues in CONV_WINDOW ticks starting CONV_OFFSET ticks after the
 # pre-roll (at most CONV_RUMOURS of them), each followed for at most CONV_MAX_ROUNDS rounds
 CONV_RUMOURS, CONV_MAX_ROUNDS, CONV_OFFSET, CONV_WINDOW = 64, 60, 400, 480
@@ -92,7 +93,7 @@ def workload(args, n_total, model=None):
 
 def kernel_source_sha16():
     try:
-        return hashlib.sha256(open(os.path.join(ROOT, KERNEL_SOURCE), "rb").read()).hexdigest()[:16]
+        return hashlib.sha256(b"".join(open(os.path.join(ROOT, f), "rb").read() for f in KERNEL_SOURCES)).hexdigest()[:16]
     except OSError:
         return None
 

@@ -28,7 +28,9 @@ def pytest_sessionstart(session):
     ex = os.path.join(ROOT, "serf_amd", "host", "serf_example")
     exsrc = os.path.join(ROOT, "serf_amd", "host", "serf_example.cpp")
     osrc = os.path.join(ROOT, "oracle", "serf_oracle.c")
-    stale = (_stale(so, hip, hdr) or _stale(ex, exsrc, os.path.join(ROOT, "serf_amd", "host", "serf.hpp"), hdr) or
+    import glob
+    parts = glob.glob(os.path.join(ROOT, "serf_amd", "csrc", "*.inc"))   # the translation unit's parts (serf_sim.hip includes them)
+    stale = (_stale(so, hip, hdr, *parts) or _stale(ex, exsrc, os.path.join(ROOT, "serf_amd", "host", "serf.hpp"), hdr) or
              _stale(os.path.join(ROOT, "oracle", "liboracle.so"), osrc, hdr))
     if stale:
         import shutil

@@ -6,7 +6,6 @@ profiles/r02_hbm_counter_calibration.json — stamped with the commit and the ha
 (bench.py reports the figure as roofline.traffic / roofline.frac_measured only while that hash is the current one).
 
 usage: python tools/collect_r5.py [call_dir]"""
-import hashlib
 import json
 import os
 import shutil
@@ -30,7 +29,9 @@ for src, dst in (("bench_20_5.json", "r05_bench_driver_args.json"), ("bench_one_
                  ("bench_one_rank_rccl_krandomnodes.json", "r05_bench_one_rank_rccl_krandomnodes.json")):
     if os.path.exists(os.path.join(call, src)) and os.path.getsize(os.path.join(call, src)):
         json.dump(last_json(os.path.join(call, src)), open(os.path.join(out, dst), "w"), indent=1)
-sha = hashlib.sha256(open(os.path.join(ROOT, "serf_amd", "csrc", "serf_sim.hip"), "rb").read()).hexdigest()[:16]
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+sha = bench.kernel_source_sha16()   # the device side of the tick kernel: serf_sim_state.inc + serf_sim_handlers.inc + serf_sim_tick.inc
 commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 n = 1 << 20
 for model in ("krandomnodes", "bijection"):
