@@ -2290,6 +2290,11 @@ static int deliver_push_pull(osim* s, uint32_t node, rdr body) {
           else if (g.kb == KB(2, 1)) { if (!once(&es, 2)) rc = SIM_EINVAL; lt = g.v; }
         }
         if (rc == SIM_OK && (!(es & 1) || id >= s->N)) rc = SIM_EINVAL;
+        { /* the reference's map is an IndexMap (types/push_pull.rs): a repeated id keeps its place and takes the LAST value */
+          uint32_t j = 0;
+          while (j < n_st && ids[j] != id) ++j;
+          if (j < n_st) { lts[j] = lt; break; }
+        }
         if (n_st == cap_st) { cap_st *= 2; ids = (uint32_t*)realloc(ids, cap_st * sizeof(uint32_t)); lts = (uint64_t*)realloc(lts, cap_st * sizeof(uint64_t)); }
         ids[n_st] = id; lts[n_st++] = lt;
         break;
@@ -2324,6 +2329,7 @@ static int deliver_push_pull(osim* s, uint32_t node, rdr body) {
             evs[n_ev++] = e;
           }
         }
+        if (rc == SIM_OK && !(bs & 1u)) rc = SIM_EINVAL; /* types/user_event/user_events.rs:102: missing_field("UserEvents", "ltime") */
         for (uint32_t i = first; i < n_ev; ++i) evs[i].lt = lt; /* (the bucket's ltime may come behind its events) */
         break;
       }

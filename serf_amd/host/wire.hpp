@@ -22,6 +22,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <algorithm>
 #include <vector>
 
 namespace serf {
@@ -339,7 +340,10 @@ inline PushPull decode_push_pull(const Bytes& body) {  // types/push_pull.rs:150
           else if (g.kb == KB(2, WIRE_VARINT)) { once(es, 2); lt = g.v; }
         }
         need(es, 1);
-        m.status_ltimes.emplace_back(id, lt);
+        {  // the reference's map is an IndexMap (types/push_pull.rs): a repeated id keeps its place and takes the LAST value
+          auto it = std::find_if(m.status_ltimes.begin(), m.status_ltimes.end(), [&](const std::pair<uint32_t, uint64_t>& e) { return e.first == id; });
+          if (it != m.status_ltimes.end()) it->second = lt; else m.status_ltimes.emplace_back(id, lt);
+        }
         break;
       }
       case KB(3, WIRE_LEN): m.left_members.push_back(parse_node_id(f.data)); break;
@@ -359,6 +363,7 @@ inline PushPull decode_push_pull(const Bytes& body) {  // types/push_pull.rs:150
             evs.emplace_back(std::move(name), std::move(payload));
           }
         }
+        need(bs, 1);  // types/user_event/user_events.rs:102: DecodeError::missing_field("UserEvents", "ltime")
         m.events.emplace_back(lt, std::move(evs));
         break;
       }

@@ -362,14 +362,15 @@ def decode_message(buf: bytes):
         d = _known(body, {KB(1, V): "ltime", KB(2, L): "status", KB(3, L): "left", KB(4, V): "event_ltime", KB(5, L): "events", KB(6, V): "query_ltime"},
                    required=("ltime", "event_ltime", "query_ltime"), repeated=("status", "left", "events"))
         msg = PushPull(d["ltime"], event_ltime=d["event_ltime"], query_ltime=d["query_ltime"])
-        msg.status_list = []   # in message order (a dict loses an id that comes twice)
+        msg.status_list = []   # in first-insertion order; a repeated id keeps its place and takes the LAST value (the reference's IndexMap)
         for v in d["status"]:
             e = _known(v, {KB(1, L): "id", KB(2, V): "ltime"}, required=("id",))
-            msg.status_list.append((parse_node_id(e["id"]), e.get("ltime", 0)))
-            msg.status_ltimes[msg.status_list[-1][0]] = msg.status_list[-1][1]
+            nid, lt = parse_node_id(e["id"]), e.get("ltime", 0)
+            msg.status_ltimes[nid] = lt
+        msg.status_list = list(msg.status_ltimes.items())
         msg.left_members = [parse_node_id(v) for v in d["left"]]
         for v in d["events"]:
-            e = _known(v, {KB(1, V): "ltime", KB(2, L): "events"}, repeated=("events",))
+            e = _known(v, {KB(1, V): "ltime", KB(2, L): "events"}, required=("ltime",), repeated=("events",))   # user_events.rs:102: missing_field
             evs = []
             for v2 in e["events"]:
                 u = _known(v2, {KB(1, L): "name", KB(2, L): "payload"})

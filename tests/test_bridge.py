@@ -277,6 +277,54 @@ def test_reference_merge_remote_state_kat_in_byte_form(oracle):
     check_merge_kat(sim, n)
 
 
+def _varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _ld(tag, body):   # one length-delimited field
+    return bytes([wire.merge(wire.WIRE_LEN, tag)]) + _varint(len(body)) + body
+
+
+def _vi(tag, v):      # one varint field
+    return bytes([wire.merge(wire.WIRE_VARINT, tag)]) + _varint(v)
+
+
+def test_push_pull_requires_a_buckets_ltime_and_takes_the_last_of_a_repeated_status_id(oracle):
+    # the reference refuses a UserEvents bucket without its Lamport time (types/user_event/user_events.rs:102:
+    # DecodeError::missing_field("UserEvents", "ltime")); its status map is an IndexMap — a repeated id keeps its place and takes
+    # the LAST value.  Python decoder and oracle (the HIP library's C++ decoder: tests/test_host_paths_gpu.py) follow both rules.
+    n = 8
+    clocks = _vi(1, 40) + _vi(4, 30) + _vi(6, 20)
+    ev = _ld(2, _ld(1, b"deploy") + _ld(2, b"x"))
+    no_ltime = _ld(wire.PUSH_PULL, clocks + _ld(5, ev))
+    with_ltime = _ld(wire.PUSH_PULL, clocks + _ld(5, _vi(1, 7) + ev))
+    with pytest.raises(ValueError):
+        wire.decode_message(no_ltime)
+    m, used = wire.decode_message(with_ltime)
+    assert used == len(with_ltime) and m.events == [(7, [(b"deploy", b"x")])]
+    sim = _ffi.Sim(oracle, _ffi.make_config(n, flags=0, view_slots=0, event_ring=512))
+    with pytest.raises(_ffi.SimError) as ei:
+        sim.deliver_message(0, no_ltime)
+    assert ei.value.code == _ffi.EINVAL
+    assert sim.deliver_message(0, with_ltime) == len(with_ltime)
+    # a status id that comes twice: one join intent, at the LAST ltime
+    st = lambda nid, lt: _ld(2, _ld(1, str(nid).encode()) + _vi(2, lt))
+    twice = _ld(wire.PUSH_PULL, clocks + st(3, 5) + st(4, 6) + st(3, 9))
+    m, _ = wire.decode_message(twice)
+    assert m.status_list == [(3, 9), (4, 6)]
+    sim2 = _ffi.Sim(oracle, _ffi.make_config(n, flags=0, view_slots=0, event_ring=512))
+    assert sim2.deliver_message(0, twice) == len(twice)
+    sim2.step(1)
+    view = sim2.dump(_ffi.ARR_VIEW).reshape(n, n)
+    assert int(view[3, 0]["ltime"]) == 9 and int(view[4, 0]["ltime"]) == 6   # buffered join intents of node 0 about 3 and 4
+
+
 def test_byte_boundary_survives_mutated_frames(oracle):
     # Every message kind the boundary takes, cut short, with bytes flipped, lengths inflated and tails of noise: the decoder
     # returns SIM_OK or an error — it never reads past the buffer (run under ASan / UBSan by `make -C oracle sanitize-test`), and a

@@ -257,6 +257,29 @@ def test_two_decoders_agree_on_mutated_frames(oracle, hiplib):
     assert taken > 500
 
 
+def test_push_pull_decoder_rules_on_the_gpu(oracle, hiplib):
+    # a UserEvents bucket without its Lamport time is refused (types/user_event/user_events.rs:102); a status id that
+    # comes twice keeps its place and takes the last value (the reference's IndexMap) — the library's C++ decoder and the oracle's
+    # C one take and refuse the same frames and leave identical simulations
+    from tests.test_bridge import _ld, _vi
+    n = 8
+    clocks = _vi(1, 40) + _vi(4, 30) + _vi(6, 20)
+    ev = _ld(2, _ld(1, b"deploy") + _ld(2, b"x"))
+    st = lambda nid, lt: _ld(2, _ld(1, str(nid).encode()) + _vi(2, lt))   # noqa: E731
+    no_ltime = _ld(wire.PUSH_PULL, clocks + _ld(5, ev))
+    good = _ld(wire.PUSH_PULL, clocks + st(3, 5) + st(4, 6) + st(3, 9) + _ld(5, _vi(1, 7) + ev))
+    sims = [_ffi.Sim(lib, _ffi.make_config(n, flags=0, view_slots=0, event_ring=512)) for lib in (hiplib, oracle)]
+    for sim in sims:
+        with pytest.raises(_ffi.SimError) as ei:
+            sim.deliver_message(0, no_ltime)
+        assert ei.value.code == _ffi.EINVAL
+        assert sim.deliver_message(0, good) == len(good)
+        sim.step(2)
+    assert sims[0].digest() == sims[1].digest()
+    view = sims[0].dump(_ffi.ARR_VIEW).reshape(n, n)
+    assert int(view[3, 0]["ltime"]) == 9 and int(view[4, 0]["ltime"]) == 6
+
+
 def test_reference_merge_remote_state_kat_on_the_gpu(hiplib):
     # delegate_merge_remote_state (serf/base/tests/serf/delegate.rs:117-180), the message in bytes, the HIP library alone
     from tests.test_bridge import check_merge_kat, merge_kat_message

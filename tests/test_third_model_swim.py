@@ -1,0 +1,157 @@
+"""The oracle (CPU) and the HIP library (GPU) against the memberlist half of the THIRD model (tests/third_model_swim.py: pure Python,
+dictionary state, unbounded, written from SURVEY.md Appendix B and the SIMSPEC — VERDICT r4 item 6).  Closed loop: the model makes its
+own packets out of its own TransmitLimitedQueue, delivers them by memberlist's kRandomNodes, loses them by the specified draw, runs its
+own suspicion timers and probes; after EVERY tick the implementation under test must show the same packets in flight, the same queues
+in drain order (class, transmits, length, kind, flags, key, value), clocks, SerfState, member tables, memberlist states, incarnations,
+confirmers, awareness and de-dup rings.  SWIM on, packet loss on, crashes, graceful leaves, re-joins, refutations.  Model bounds never
+bite in these runs (overflow == 0 is asserted).  memberlist-core's source is absent, so rows a13 / a16 stay parity-unpinned; what this
+removes is the common mode of two restatements by one author."""
+import numpy as np
+import pytest
+
+from serf_amd import _ffi
+from tests import third_model as tm
+from tests import third_model_swim as tms
+from tests._oracle import load_oracle
+
+RING_EV, RING_Q, PG = 64, 32, 4
+
+
+def _packets(sim, n, fanout):
+    """the packets in flight, sender-indexed (the canonical form with memberlist's kRandomNodes): [sender][slot] -> records"""
+    inbox = sim.dump(_ffi.ARR_INBOX).reshape(fanout * PG, n)
+    out = []
+    for snd in range(n):
+        per = []
+        for k in range(fanout):
+            recs = []
+            for pg in range(PG):
+                pk = inbox[k * PG + pg, snd]
+                for r in range(4):
+                    hm = int(pk["hi_meta"][r])
+                    kind = (hm >> 4) & 15
+                    if kind == 0:
+                        continue
+                    v48 = int(pk["val_lo"][r]) | ((hm >> 16) << 32)
+                    val = (v48 & 0xFFFFFF) | ((v48 >> 24) << 32) if kind in (tms.K_SUSPECT, tms.K_DEAD) else v48
+                    recs.append((kind, hm & 15, 63 - ((hm >> 8) & 63), int(pk["key"][r]), val))
+            per.append(recs)
+        out.append(per)
+    return out
+
+
+def run(sim, n, ops, ticks, joined, **kw):
+    fanout = kw["fanout"]
+    par = tms.Params(n, fanout, kw["probe_interval"], kw.get("suspicion_mult", 4), kw.get("suspicion_max_mult", 6), kw.get("indirect_checks", 3),
+                     kw.get("retransmit_mult", 4), kw.get("loss", 0.0), 4 * PG, kw.get("leave_delay", 30))
+    model = tms.Cluster(par, RING_EV, RING_Q, joined)
+    by_tick = {}
+    for o in ops:
+        by_tick.setdefault(o[0], []).append(o[1:])
+        sim.inject(*o)
+    seen_kinds = set()
+    for t in range(ticks):
+        model.step(by_tick.get(t, ()))
+        sim.step(1)
+        rows = sim.dump(_ffi.ARR_ROWS)
+        view = sim.dump(_ffi.ARR_VIEW).reshape(n, n)        # dense view: [subject][observer]
+        er = sim.dump(_ffi.ARR_ERING).reshape(RING_EV, n)
+        qr = sim.dump(_ffi.ARR_QRING).reshape(RING_Q, n)
+        queue = sim.dump(_ffi.ARR_QUEUE).reshape(n, 16)
+        assert int(rows["overflow"].sum()) == 0, f"tick {t}: a model bound was hit"
+        # ---- the packets sent this tick
+        got = _packets(sim, n, fanout)
+        for i in range(n):
+            for k in range(fanout):
+                want = [(kd, fl, ln, key, val) for kd, fl, ln, key, val in (model.flight[i][k] or ())]
+                assert got[i][k] == want, f"tick {t} sender {i} slot {k}: packet {got[i][k]} != {want}"
+                seen_kinds.update(r[0] for r in want)
+        for i, x in enumerate(model.nodes):
+            w = f"tick {t} node {i}"
+            assert (int(rows["clock"][i]), int(rows["event_clock"][i]), int(rows["query_clock"][i])) == \
+                   (x.clock.time(), x.event_clock.time(), x.query_clock.time()), w
+            assert bool(rows["flags"][i] & 1) == x.up and ((int(rows["flags"][i]) >> 1) & 3) == x.state, w
+            assert (int(rows["inc"][i]), int(rows["awareness"][i])) == (x.inc, x.awareness), w
+            st = [m[0] for m in x.members.values()]
+            assert (int(rows["n_known"][i]), int(rows["n_failed"][i]), int(rows["n_left"][i])) == (len(st), st.count(tm.FAILED), st.count(tm.LEFT)), w
+            # ---- the queue in drain order
+            live = [(int(r["meta"]) >> 30, (int(r["meta"]) >> 24) & 63, 63 - ((int(r["meta"]) >> 18) & 63), (int(r["meta"]) >> 4) & 15,
+                     int(r["meta"]) & 15, int(r["key"]), int(r["val"])) for r in queue[i] if r["meta"] != 0xFFFFFFFF]
+            want = [(e[0], e[1], e[2], e[4], e[5], e[6], e[7]) for e in x.drain_order()]
+            assert live == want, f"{w}: queue {live} != {want}"
+            # ---- member table, memberlist state, suspicions
+            for s in range(n):
+                e = view[s, i]
+                bits = int(e["bits"])
+                if s in x.members:
+                    assert bits & 1 and ((bits >> 1) & 7, int(e["ltime"])) == tuple(x.members[s]), f"{w} subject {s}"
+                    ml = x.ml[s]
+                    assert ((bits >> 4) & 3, int(e["inc"])) == (ml[0], ml[1]), f"{w} subject {s}: memberlist state"
+                    if ml[0] == tms.ML_SUSPECT:
+                        conf = x.susp[s][1]
+                        assert (bits >> 8) & 7 == len(conf) - 1 and [int(c) for c in e["conf"][:len(conf)]] == conf, f"{w} subject {s}: confirmers"
+                        assert (bits >> 11) == x.susp[s][0], f"{w} subject {s}: suspicion start"
+                else:
+                    it = x.intents.get(s)
+                    assert not (bits & 1) and s not in x.ml, f"{w} subject {s}"
+                    assert ((bits >> 6) & 3, int(e["ltime"])) == ((it[0], it[1]) if it else (0, 0)), f"{w} subject {s} intent"
+            for ring, buf, name in ((er, x.event_buf, "event"), (qr, x.query_buf, "query")):
+                for j, want in enumerate(buf):
+                    b = ring[j, i]
+                    got_k = [int(v) for v in b["keys"] if v]
+                    if want is None:
+                        assert not got_k, f"{w} {name} bucket {j}"
+                    else:
+                        assert (int(b["ltime"]), got_k) == (want[0], want[1]), f"{w} {name} bucket {j}"
+    return seen_kinds, model
+
+
+def _schedule(n, ticks, seed):
+    """user events, queries, graceful leaves (leave intent, memberlist.leave after the leave delay, shutdown), crashes, re-joins"""
+    rng = np.random.default_rng(seed)
+    ops, key = [], 100
+    busy = {}
+    for t in range(2, ticks - 30):
+        if rng.random() < 0.45:
+            node = int(rng.integers(0, n))
+            if busy.get(node, 0) > t:
+                continue
+            r = rng.random()
+            key += 1
+            if r < 0.4:
+                ops.append((t, _ffi.OP_USER_EVENT, node, key, 40))
+            elif r < 0.6:
+                ops.append((t, _ffi.OP_QUERY, node, key, 0))
+            elif r < 0.8:   # crash, suspected / declared dead by the others, back with a refuting incarnation
+                ops.append((t, _ffi.OP_CRASH, node, 0, 0))
+                back = t + int(rng.integers(12, 40))
+                ops.append((back, _ffi.OP_JOIN, node, 0, 0))
+                busy[node] = back + 10
+            else:           # Serf::leave
+                ops.append((t, _ffi.OP_LEAVE, node, 0, 0))
+                ops.append((t + 4, _ffi.OP_LEAVE_FINISH, node, 0, 0))
+                ops.append((t + 8, _ffi.OP_CRASH, node, 0, 0))
+                busy[node] = ticks
+    ops.sort(key=lambda o: o[0])
+    return ops
+
+
+CASES = [(11, 48, 3, 0.03, 2), (12, 64, 4, 0.0, 3), (13, 33, 3, 0.08, 1), (14, 24, 2, 0.02, 2)]
+KW = dict(view_slots=0, event_ring=RING_EV, query_ring=RING_Q, leave_delay=4, pkt_records=4 * PG, suspicion_mult=3, suspicion_max_mult=2,
+          flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT)
+
+
+@pytest.mark.parametrize("seed,n,fanout,loss,pi", CASES)
+def test_oracle_matches_the_third_model_with_the_memberlist_layer_on(seed, n, fanout, loss, pi):
+    kw = dict(KW, fanout=fanout, loss=loss, probe_interval=pi)
+    sim = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw))
+    kinds, model = run(sim, n, _schedule(n, 110, seed), 110, True, **kw)
+    assert {tms.K_ALIVE, tms.K_SUSPECT, tms.K_DEAD} <= kinds, kinds   # the scenario did exercise refutations, suspicions and declarations
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,fanout,loss,pi", CASES[:3])
+def test_hip_matches_the_third_model_with_the_memberlist_layer_on(hiplib, seed, n, fanout, loss, pi):
+    kw = dict(KW, fanout=fanout, loss=loss, probe_interval=pi)
+    sim = _ffi.Sim(hiplib, _ffi.make_config(n, **kw))
+    run(sim, n, _schedule(n, 110, seed), 110, True, **kw)

@@ -1,0 +1,376 @@
+"""The memberlist half of the THIRD model — test infrastructure, pure Python, dictionary state, no capacity
+bounds — written from SURVEY.md Appendix B (B.1 TransmitLimitedQueue, B.3 probe, B.4 alive / suspect / dead, B.5 suspicion timer) and
+the simulator's SIMSPEC (DESIGN.md §2.1 tick order, §2.2 PRNG streams, §2.4 record lengths, §2.5 queue pooling, §2.7 probe phases,
+§2.8 operations), NOT from oracle/serf_oracle.c's swim_* / queue functions and not from the HIP kernel.  memberlist-core's source is
+not in /root/reference, so this cannot pin rows a13 / a16 to memberlist itself; what it removes is the single-author common mode:
+the oracle and the kernel share one reading of Appendix B, this is a second one, and it runs CLOSED LOOP — it makes its own packets
+out of its own queues (get_broadcasts: drain order, byte budget, retransmit limit), delivers them by memberlist's kRandomNodes
+(third_model.k_random_nodes), loses them by the specified loss draw, runs its own suspicion timers and probes — and is compared with
+the implementation under test after EVERY tick: the packets in flight, every queue in drain order (class, transmits, length, kind,
+flags, key, value), clocks, SerfState, member tables, memberlist states, incarnations, confirmers, awareness, both de-dup rings.
+
+The serf handlers are third_model.Node's (written from the Rust sources); handle_node_join / handle_node_leave below are restated
+from serf/base.rs:1206-1334 and 1375-1440."""
+import math
+
+from tests import third_model as tm
+from tests.third_model import mix64, M64, JOIN, LEAVE, EVENT, QUERY, NONE, ALIVE, LEAVING, LEFT, FAILED, S_ALIVE, S_LEAVING, S_LEFT
+
+K_ALIVE, K_SUSPECT, K_DEAD = 5, 6, 7                        # memberlist's own broadcasts as the simulated packets carry them
+ML_ALIVE, ML_SUSPECT, ML_DEAD, ML_LEFT = 0, 1, 2, 3         # memberlist node states (B.4)
+PKT_UNITS = 1400 // 16                                      # the UDP payload budget in 16-byte units (SIMSPEC §2.4)
+MAX_AWARENESS = 8                                           # awareness_max_multiplier (App. B defaults)
+STREAM_LOSS, STREAM_PROBE = 4, 5                            # PRNG streams (SIMSPEC §2.2)
+F_PRUNE = 1
+
+
+def units(nbytes):
+    return min(63, (nbytes + 15) // 16)
+
+
+def rng_base(seed, stream, a):
+    return mix64(mix64(seed ^ ((stream * 0xD6E8FEB86659FD93) & M64)) ^ a)
+
+
+def digits10(n):
+    return len(str(n)) if n > 0 else 0
+
+
+class Params:
+    """what Appendix B derives from the configuration"""
+
+    def __init__(self, n, fanout, probe_interval, suspicion_mult=4, suspicion_max_mult=6, indirect_checks=3, retransmit_mult=4,
+                 loss=0.0, pkt_records=4, leave_delay=30, seed=None):
+        from serf_amd import _ffi
+        self.n, self.fanout, self.pi, self.ic, self.rmult = n, fanout, probe_interval, indirect_checks, retransmit_mult
+        self.loss_u32 = min(0xFFFFFFFF, int(round(loss * 2 ** 32)))
+        self.P, self.leave_delay = pkt_records, leave_delay
+        self.seed = _ffi.DEFAULT_SEED if seed is None else seed
+        # B.5: k confirmations shrink the timeout from max to min
+        k = max(0, suspicion_mult - 2)
+        self.k = 0 if n < 2 or n - 2 < k else min(k, 3)
+        scale = max(1.0, math.log10(max(1, n)))
+        mn = max(1, suspicion_mult * math.floor(scale * 1000.0) * probe_interval // 1000)
+        mx = max(mn, suspicion_max_mult * mn)
+        self.T = []
+        for c in range(4):
+            t = float(mn)
+            if self.k >= 1 and c <= self.k:
+                t = max(float(mn), math.floor(mx - math.log(c + 1.0) / math.log(self.k + 1.0) * (mx - mn)))
+            self.T.append(int(t))
+
+
+class SwimNode(tm.Node):
+    def __init__(self, me, par: Params, ring_ev, ring_q, joined):
+        super().__init__(me, par.n, ring_ev, ring_q, joined)
+        self.par = par
+        self.inc, self.awareness = 0, 0
+        # memberlist's node map: subject -> [state, incarnation]; a suspicion: subject -> [start tick, confirmers (who started it first)]
+        self.ml = {s: [ML_ALIVE, 0] for s in range(par.n)} if joined else {me: [ML_ALIVE, 0]}
+        self.susp = {}
+        self.slots = []                                     # the timers in the order they are looked at: first free place (SIMSPEC §2.7)
+        self.queue, self.next_id = [], 0                    # TransmitLimitedQueue: [class, transmits, length, id, kind, flags, key, val]
+        self.tick = 0
+
+    # ---- B.1 TransmitLimitedQueue, pooled (SIMSPEC §2.5: memberlist's queue < intents < queries < events) --------------------
+    @staticmethod
+    def _cls(kind):
+        return 1 if kind in (JOIN, LEAVE) else 2 if kind == QUERY else 3 if kind == EVENT else 0
+
+    def queue_broadcast(self, kind, flags, nbytes, key, val):
+        cls = self._cls(kind)
+        if cls == 0:                                        # a memberlist broadcast invalidates the queued one about the same node
+            self.queue = [e for e in self.queue if not (e[0] == 0 and e[6] == key)]
+        self.queue.append([cls, 0, units(nbytes), self.next_id, kind, flags, key, val])
+        self.next_id += 1
+
+    def drain_order(self):
+        return sorted(self.queue, key=lambda e: (e[0], e[1], -e[2], -e[3]))
+
+    def get_broadcasts(self):
+        """one packet: walk the queue in drain order, take what still fits the byte budget, at most P records; transmits + 1,
+        finished at the retransmit limit"""
+        limit = self.par.rmult * digits10(len(self.members))
+        free, out = PKT_UNITS, []
+        for e in self.drain_order():
+            if len(out) == self.par.P:
+                break
+            if e[2] > free:
+                continue
+            free -= e[2]
+            out.append((e[4], e[5], e[2], e[6], e[7]))
+            e[1] += 1
+            if e[1] >= limit:
+                self.queue.remove(e)
+        return out
+
+    # ---- serf's side of memberlist's notifications -----------------------------------------------------------------------------
+    def handle_node_join(self, s):                          # serf/base.rs:1206-1334
+        m = self.members.get(s)
+        if m is not None:
+            m[0] = ALIVE                                    # status_time stays
+            return
+        status, lt = ALIVE, 0
+        it = self.intents.get(s)
+        if it is not None and it[0] == JOIN:
+            lt = it[1]
+        if it is not None and it[0] == LEAVE:
+            status, lt = LEAVING, it[1]
+        self.members[s] = [status, lt]
+        self.intents.pop(s, None)                           # (one entry per subject in the simulator: a member has no buffered intent)
+
+    def handle_node_leave(self, s):                         # serf/base.rs:1375-1440
+        m = self.members.get(s)
+        if m is None:
+            return
+        if m[0] == LEAVING:
+            m[0] = LEFT
+        elif m[0] == ALIVE:
+            m[0] = FAILED
+
+    # ---- B.4 ------------------------------------------------------------------------------------------------------------------
+    def refute(self, accused_inc, flags=0):
+        self.inc = max(self.inc + 1, accused_inc + 1)
+        if self.me in self.ml:
+            self.ml[self.me][1] = self.inc
+        self.awareness = min(MAX_AWARENESS, self.awareness + 1)
+        self.queue_broadcast(K_ALIVE, flags, 64, self.me, self.inc)
+
+    def _cancel(self, s):
+        if s in self.susp:
+            del self.susp[s]
+            self.slots[self.slots.index(s)] = None
+
+    def alive(self, s, inc, rec):
+        if s == self.me:
+            if inc > self.inc:
+                self.refute(inc)
+            return
+        cur = self.ml.get(s)
+        if cur is None:
+            self.ml[s] = [ML_ALIVE, inc]
+            self.handle_node_join(s)
+            self.queue_broadcast(*rec)
+            return
+        if inc <= cur[1]:
+            return
+        old = cur[0]
+        self._cancel(s)
+        cur[0], cur[1] = ML_ALIVE, inc
+        self.queue_broadcast(*rec)
+        if old in (ML_DEAD, ML_LEFT):
+            self.handle_node_join(s)
+
+    def suspect(self, s, inc, frm, rec):
+        cur = self.ml.get(s)
+        if cur is None or inc < cur[1]:
+            return
+        if cur[0] == ML_SUSPECT:                            # a timer exists: confirm(from); rebroadcast iff it was a new confirmation
+            t = self.susp[s]
+            if len(t[1]) - 1 >= self.par.k or frm in t[1]:
+                return
+            t[1].append(frm)
+            self.queue_broadcast(*rec)
+            return
+        if cur[0] != ML_ALIVE:
+            return
+        if s == self.me:
+            self.refute(inc)
+            return
+        self.queue_broadcast(*rec)
+        cur[0], cur[1] = ML_SUSPECT, inc
+        self.susp[s] = [self.tick, [frm]]
+        if None in self.slots:
+            self.slots[self.slots.index(None)] = s
+        else:
+            self.slots.append(s)
+
+    def dead(self, s, inc, frm, rec):
+        cur = self.ml.get(s)
+        if cur is None or inc < cur[1]:
+            return
+        self._cancel(s)
+        if cur[0] in (ML_DEAD, ML_LEFT):
+            return
+        if cur[0] == ML_SUSPECT:
+            cur[0] = ML_ALIVE                               # (the timer is gone; what follows decides the state)
+        if s == self.me and self.state not in (S_LEAVING, S_LEFT):
+            self.refute(inc)
+            return
+        self.queue_broadcast(*rec)
+        cur[0], cur[1] = (ML_LEFT if frm == s else ML_DEAD), inc
+        self.handle_node_leave(s)
+
+    # ---- B.5: the timers, in slot order; a timer that has run out declares the node dead, from = self -------------------------------
+    def run_timers(self):
+        for s in list(self.slots):
+            if s is None or s not in self.susp:
+                continue
+            start, conf = self.susp[s]
+            if self.tick - start >= self.par.T[len(conf) - 1]:
+                self.dead(s, self.ml[s][1], self.me, (K_DEAD, 0, 32, s, self.ml[s][1] | (self.me << 32)))
+
+    # ---- B.3: one probe per probe interval, the 64 nodes of an id-aligned group in the same phase (SIMSPEC §2.7) ---------------
+    def probe(self, up):
+        par = self.par
+        if par.n < 2 or (self.tick + (self.me >> 6)) % par.pi:
+            return
+        base = rng_base(par.seed, STREAM_PROBE, self.tick)
+
+        def draw(j):
+            return mix64(base ^ ((self.me * 32 + j) & M64))
+
+        def below(d, n):
+            return ((d >> 32) * n) >> 32
+
+        def lost(j):
+            return bool(par.loss_u32) and (draw(j) >> 32) < par.loss_u32
+
+        t = below(draw(0), par.n - 1)
+        if t >= self.me:
+            t += 1
+        cur = self.ml.get(t)
+        if cur is None or cur[0] in (ML_DEAD, ML_LEFT):
+            return
+        ok = False
+        if up[t]:
+            ok = not lost(1) and not lost(2)
+            for j in range(min(par.ic, 4)):
+                if ok:
+                    break
+                r = below(draw(3 + 5 * j), par.n)
+                if r == self.me or r == t or not up[r]:
+                    continue
+                ok = not lost(3 + 5 * j + 1) and not lost(3 + 5 * j + 2) and not lost(3 + 5 * j + 3) and not lost(3 + 5 * j + 4)
+        if ok:
+            self.awareness = max(0, self.awareness - 1)
+            return
+        self.awareness = min(MAX_AWARENESS, self.awareness + 1)
+        self.suspect(t, cur[1], self.me, (K_SUSPECT, 0, 32, t, cur[1] | (self.me << 32)))
+
+    # ---- SerfDelegate::notify_message with the original message re-queued unchanged (delegate.rs:294-300) ----------------------------
+    def receive(self, kind, flags, length, key, val):
+        rec = (kind, flags, length * 16, key, val)
+        if kind == K_ALIVE:
+            self.alive(key, val & 0xFFFFFFFF, rec)
+        elif kind == K_SUSPECT:
+            self.suspect(key, val & 0xFFFFFFFF, val >> 32, rec)
+        elif kind == K_DEAD:
+            self.dead(key, val & 0xFFFFFFFF, val >> 32, rec)
+        else:
+            self.rebroadcast = []
+            self.notify(kind, key, val, flags)              # third_model.Node: the serf handlers
+            self._flush(default=rec)
+
+    def _flush(self, default=None, lens=None):
+        """what the serf handlers asked to (re)broadcast, into the queue: the received message as it came, or a message of this
+        node's own making with the length the codec gives it (SIMSPEC §2.4)"""
+        for kind, key, lt in self.rebroadcast:
+            if default is not None and (kind, key, lt) == (default[0], default[3], default[4]):
+                self.queue_broadcast(*default)
+            else:                                           # a refutation (broadcast_join) the handler queued on the way
+                fl, nb = (lens or {}).get(kind, (0, 16))
+                self.queue_broadcast(kind, fl, nb, key, lt)
+        self.rebroadcast = []
+
+    def prune_sync(self):
+        """erase_node! also forgets memberlist's node state in the simulator (waived / simplified)"""
+        for s in list(self.ml):
+            if s != self.me and s not in self.members:
+                self._cancel(s)
+                del self.ml[s]
+
+
+class Cluster:
+    """the tick of SIMSPEC §2.1 over SwimNodes: operations, deliveries, timers, probe, drain"""
+
+    def __init__(self, par: Params, ring_ev, ring_q, joined):
+        self.par = par
+        self.nodes = [SwimNode(i, par, ring_ev, ring_q, joined) for i in range(par.n)]
+        self.up = [True] * par.n
+        self.tick = 0
+        self.flight = None                                  # packets sent during the last tick: [sender][slot] -> list of records (None: not sent)
+
+    def apply(self, op, node, a, b):
+        from serf_amd import _ffi
+        x = self.nodes[node]
+        if op == _ffi.OP_CRASH:
+            x.up = self.up[node] = False
+        elif op == _ffi.OP_REVIVE:
+            x.up = self.up[node] = True
+        elif op == _ffi.OP_JOIN:                            # memberlist.join + Serf::join (api.rs:318-364): a fresh incarnation, then broadcast_join
+            self.up[node] = True
+            x.up, x.state = True, S_ALIVE
+            me = x.ml.get(node)
+            old = me[0] if me else ML_ALIVE
+            if me:
+                x._cancel(node)
+                me[0] = ML_ALIVE
+            x.refute(me[1] if me else x.inc)
+            x.awareness = max(0, x.awareness - 1)           # not an accusation
+            if old in (ML_DEAD, ML_LEFT):
+                x.handle_node_join(node)
+            x.rebroadcast = []
+            x.broadcast_join(x.clock.time())
+            x._flush()
+        elif op == _ffi.OP_LEAVE_FINISH:                    # memberlist.leave: dead{self, from = self}, then SerfState::Left (api.rs:474-497)
+            if x.up and x.state == S_LEAVING:
+                x.dead(node, x.inc, node, (K_DEAD, 0, 32, node, x.inc | (node << 32)))
+                x.state = S_LEFT
+        elif not x.up:
+            return
+        elif op == _ffi.OP_USER_EVENT:
+            x.rebroadcast = []
+            x.user_event(a)
+            x._flush(lens={EVENT: (0, b & 0x7FFFFFFF)})
+        elif op == _ffi.OP_QUERY:
+            x.rebroadcast = []
+            x.query(a, b & 15)
+            x._flush(lens={QUERY: (b & 15, 48)})
+        elif op == _ffi.OP_LEAVE:
+            x.rebroadcast = []
+            x.leave(others_alive=self.par.n > 1)
+            x._flush()
+        elif op == _ffi.OP_FORCE_LEAVE:
+            x.rebroadcast = []
+            x.force_leave(a, bool(b), others_alive=self.par.n > 1)
+            x._flush(lens={LEAVE: (F_PRUNE if b else 0, 16)})
+            x.prune_sync()
+
+    def step(self, ops):
+        par, t = self.par, self.tick
+        for x in self.nodes:
+            x.tick = t
+        for op, node, a, b in ops:
+            self.apply(op, node, a, b)
+        # (1) deliveries: every packet addressed to the node, (sender, slot) order, records in packet order
+        if self.flight is not None:
+            rows = [[] for _ in range(par.n)]
+            for snd in range(par.n):
+                for k, tgt in enumerate(tm.k_random_nodes(par.seed, t - 1, snd, par.n, min(par.fanout, par.n - 1))):
+                    rows[tgt].append((snd, k))
+            for i, x in enumerate(self.nodes):
+                if not x.up:
+                    continue
+                for snd, k in rows[i]:
+                    for rec in self.flight[snd][k] or ():
+                        x.receive(*rec)
+                        x.prune_sync()
+        # (2) timers, (3) probe, (5) drain
+        loss_base = rng_base(par.seed, STREAM_LOSS, t)
+        flight = []
+        for i, x in enumerate(self.nodes):
+            pk = [None] * par.fanout
+            if x.up:
+                if par.pi:
+                    x.run_timers()
+                    x.probe(self.up)
+                targets = tm.k_random_nodes(par.seed, t, i, par.n, min(par.fanout, par.n - 1))
+                for k in range(min(par.fanout, par.n - 1)):
+                    recs = x.get_broadcasts()
+                    lost = bool(par.loss_u32) and (mix64(loss_base ^ ((i * 4 + k) & M64)) >> 32) < par.loss_u32
+                    if k < len(targets) and not lost:
+                        pk[k] = recs
+            flight.append(pk)
+        self.flight = flight
+        self.tick += 1
