@@ -409,7 +409,7 @@ def run(args, lib=None, dev=None, backend="nccl"):
         kw, ops = workload(args, n_total, model)
         progress(f"create ({model})")
         if sharded:
-            sim = ShardedSim(lib, n_total, dev, chunks=1 if model == "krandomnodes" else args.chunks, exchange=args.exchange, **kw)
+            sim = ShardedSim(lib, n_total, dev, chunks=args.chunks, exchange=args.exchange, **kw)
         else:
             sim = _ffi.Sim(lib, _ffi.make_config(n_total, **kw))
             if on_gpu:
@@ -676,8 +676,8 @@ def run(args, lib=None, dev=None, backend="nccl"):
                                    f"{args.steps} ticks the driver asks for (not SURVEY §8d's 1 000)"
                                    + (f", the {long_window(args)} ticks behind it are measured as well (long_window)" if long_window(args) else ""),
                        "fanout_model": models[0],
-                       "parallelism": ((f"node-id range shards x{world}; " + ("kRandomNodes: packets packed per destination shard behind the tick's launch, one "
-                                                                               "equal-split all-to-all of the packed slabs per round" if models[0] == "krandomnodes" else
+                       "parallelism": ((f"node-id range shards x{world}; " + (f"kRandomNodes: packets packed per destination shard behind each of the {args.chunks} sender-chunk launches, an "
+                                                                               "equal-split all-to-all of the packed slabs per chunk, overlapped with compute" if models[0] == "krandomnodes" else
                                                                                f"{args.chunks} chunk-wise all-to-all per tick, overlapped with compute"))
                                        if sharded else "single GPU"),
                        "preroll": args.preroll, "schedule_horizon": horizon(args),

@@ -280,8 +280,9 @@ typedef struct sim_config {
 #define SIM_CF_BASELINE_JOINED 1u /* all nodes known+Alive at status_time 1, clock 2 (config 2-5) */
 #define SIM_CF_RANDOM_FANOUT 2u   /* gossip targets are memberlist's literal kRandomNodes (uniform over the other nodes, no
                                    * replacement, skip self — App. B.2) instead of the per-tick bijection; in-degree is then
-                                   * Poisson-like and a node's packets are handed over in (sender, slot) order.  One chunk
-                                   * (SIM_EINVAL otherwise); packets of 1 - 4 pages; checkpoints like every other run
+                                   * Poisson-like and a node's packets are handed over in (sender, slot) order.  Sender chunks
+                                   * (sim_config.chunks > 1) only on a shard, where they are the exchange's schedule (SIM_EINVAL
+                                   * on a handle that holds every node); packets of 1 - 4 pages; checkpoints like every other run
                                    * (the targets of the packets in flight are a function of (seed, tick, sender): drawn again
                                    * on restore).  Canonical form of the packets in flight in this mode (SIM_ARR_INBOX, digests,
                                    * images): inbox[k * PG + pg][SENDER] — on a shard: its own senders.
@@ -293,7 +294,10 @@ typedef struct sim_config {
                                    * equal-split all-to-all of those slabs (sim_exchange_layout: SIM_XCHG_PACKED) — f * 64 B *
                                    * M * (V - 1) / V bytes leave a GPU per round (+ 2 % of room, + 1 byte per target) —, and the
                                    * receiver's row is V sorted runs, one per source shard, in ascending source = ascending
-                                   * sender order.  No index and no count travels ahead; nobody draws anybody else's targets. */
+                                   * sender order.  No index and no count travels ahead; nobody draws anybody else's targets.
+                                   * With sim_config.chunks = C the senders are cut into C ranges, each sorted, packed and
+                                   * exchanged behind its own launch (slab (c, h) of the send buffer; a row is V * C runs): chunk
+                                   * c travels while chunk c + 1 computes, like the bijection's chunks. */
 /* random fan-out only: broadcast requests one node can park in ONE tick beyond f * pkt_records + SIM_S + 1 (the bijection's
  * maximum; with a random in-degree there is none).  A counted model bound, the same in the oracle. */
 #define SIM_RF_PEND_EXTRA 32u
@@ -559,7 +563,9 @@ int sim_bind_exchange3(sim_handle* h, void* send_dev, size_t send_bytes, void* r
  *                        dense slab the tick kernel could write into: the packets stay in their senders' cells (as on one GPU) and
  *                        sim_step_chunk PACKS, behind the tick's launch, the packets bound for shard h into slab h in (target,
  *                        sender, slot) order — the order of a sort of the shard's own f * M (target, sender, slot) triples —
- *                        together with one count byte per target of h.  A slab holds serf_rf_slab_cap(f, M, V) packets (mean + 12
+ *                        together with one count byte per target of h (with C sender chunks: C x V slabs, chunk-major, each
+ *                        chunk's V slabs one region of sim_exchange_chunks' bytes_per_chunk, exchanged on its own).  A slab holds
+ *                        serf_rf_slab_cap(f, M / C, V) packets (mean + 12
  *                        sigma of the binomial: a slab that would overflow makes the step fail with SIM_ERANGE).  sim_step_begin of
  *                        the next tick turns the V slabs it received into the tick's rows.  The slab format is the
  *                        implementation's own (HIP: 64-byte cells; oracle: 48-byte packets with explicit targets): ranks of one

@@ -320,7 +320,10 @@ struct sim_handle {
   /* ... on a shard (SIM_XCHG_PACKED, include/serf_sim.h): the packets stay in the senders' cells here too (inbox[], like a handle
    * that is not a shard); step_end packs the ones bound for shard h into slab h of the send buffer, (target, sender, slot) order,
    * step_begin of the next tick makes the rows from the V slabs that arrived: rsrc = source shard * rf_cap + place in its slab */
-  uint32_t rf_cap;   /* packets a slab holds (serf_rf_slab_cap) */
+  uint32_t rf_cap;   /* packets a slab holds (serf_rf_slab_cap of one sender chunk's share) */
+  uint32_t rf_C;     /* sender chunks per tick (sim_config.chunks): chunk c = the senders [c * M / C, (c + 1) * M / C), packed and
+                      * exchanged on their own — slab (c, h) of the send buffer; a row is then V * C runs: source shards ascending,
+                      * their chunks ascending = senders ascending */
   uint32_t rf_rcap;  /* entries rsrc has room for */
   int rf_err;        /* a slab overflowed (here or at a sender): the step reports SIM_ERANGE */
   /* content of the user events the library was told in bytes (sim_deliver_message, sim_user_event_bytes): key ->
@@ -1636,43 +1639,49 @@ static void step_begin(osim* s) {
   s->in_tick = 1;
 }
 /* the nodes of sender chunk c (all of them for c == NOSLOT): V ranges of `sub` consecutive nodes */
+static void rf_pack(osim* s, const sim_packet* cells, uint32_t chunk);
 static void step_chunk(osim* s, uint32_t chunk) {
   const tickp* p = &s->cur;
   uint32_t cnt = chunk == NOSLOT ? s->Nl : p->V * p->sub;
+  const int rfs = RF_SH(s); /* random fan-out on a shard: a sender chunk is a RANGE of nodes (there is no vblock structure to keep) */
   if (s->n_watched) {
     for (uint32_t i = 0; i < cnt; ++i)
-      tick_node(s, p, chunk == NOSLOT ? i : (i / p->sub) * p->blk + chunk * p->sub + i % p->sub);
+      tick_node(s, p, chunk == NOSLOT ? i : rfs ? chunk * cnt + i : (i / p->sub) * p->blk + chunk * p->sub + i % p->sub);
   } else {
     int nt = oracle_threads();
 #pragma omp parallel for schedule(static) num_threads(nt) if (cnt >= 4096)
     for (uint32_t i = 0; i < cnt; ++i)
-      tick_node(s, p, chunk == NOSLOT ? i : (i / p->sub) * p->blk + chunk * p->sub + i % p->sub);
+      tick_node(s, p, chunk == NOSLOT ? i : rfs ? chunk * cnt + i : (i / p->sub) * p->blk + chunk * p->sub + i % p->sub);
+  }
+  if (rfs) { /* the slabs of the chunk(s) that just computed: they go out between this launch and the next tick (the host's all-to-all) */
+    if (chunk == NOSLOT) for (uint32_t c = 0; c < s->rf_C; ++c) rf_pack(s, s->inbox[(s->tick + 1) & 1], c);
+    else rf_pack(s, s->inbox[(s->tick + 1) & 1], chunk);
   }
 }
 /* random fan-out: group the cells by target — counting sort, senders ascending within a target, then slots */
 /* ... on a shard, sending side: the packets the shard's own senders addressed (rtgt) to shard h, packed into slab h of the send
  * buffer in (target, sender, slot) order — a counting sort of the shard's f * Nl pairs by global target, stable in (sender, slot).
  * `cells` = the senders' cells of the tick that sent them ([k * PG + pg][sender]). */
-static void rf_pack(osim* s, const sim_packet* cells) {
-  const uint32_t PG = s->PG, M = s->M;
+static void rf_pack(osim* s, const sim_packet* cells, uint32_t chunk) {
+  const uint32_t PG = s->PG, M = s->M, per = s->Nl / s->rf_C, l0 = chunk * per, l1 = l0 + per; /* the senders of this chunk */
   uint32_t* cnt = (uint32_t*)calloc((size_t)s->N + 1, sizeof(uint32_t));
-  uint32_t* order = (uint32_t*)malloc(((size_t)s->f * s->Nl + 1) * sizeof(uint32_t));
+  uint32_t* order = (uint32_t*)malloc(((size_t)s->f * per + 1) * sizeof(uint32_t));
   for (uint32_t k = 0; k < s->f; ++k)
-    for (uint32_t l = 0; l < s->Nl; ++l) {
+    for (uint32_t l = l0; l < l1; ++l) {
       uint32_t t = s->rtgt[(size_t)k * s->Nl + l];
       if (t != NOSLOT) cnt[t + 1]++;
     }
   for (uint32_t t = 0; t < s->N; ++t) cnt[t + 1] += cnt[t];
   uint32_t* fill = (uint32_t*)malloc((size_t)s->N * sizeof(uint32_t));
   memcpy(fill, cnt, (size_t)s->N * sizeof(uint32_t));
-  for (uint32_t l = 0; l < s->Nl; ++l) /* (sender, slot) order within a target */
+  for (uint32_t l = l0; l < l1; ++l) /* (sender, slot) order within a target */
     for (uint32_t k = 0; k < s->f; ++k) {
       uint32_t t = s->rtgt[(size_t)k * s->Nl + l];
       if (t != NOSLOT) order[fill[t]++] = l * 4u + k;
     }
   free(fill);
   for (uint32_t h = 0; h < s->V; ++h) {
-    uint8_t* slab = rf_slab(s, s->xsend, h);
+    uint8_t* slab = rf_slab(s, s->xsend, chunk * s->V + h);
     rf_slab_hdr* hd = (rf_slab_hdr*)slab;
     uint32_t* idx = rf_slab_idx(slab);
     sim_packet* pk = rf_slab_pk(s, slab);
@@ -1697,7 +1706,9 @@ static void rf_pack(osim* s, const sim_packet* cells) {
 static void rf_unpack(osim* s) {
   memset(s->rcsr, 0, ((size_t)s->Nl + 1) * sizeof(uint32_t));
   size_t total = 0;
-  for (uint32_t g = 0; g < s->V; ++g) {
+  const uint32_t NS = s->V * s->rf_C; /* sources in the order of their senders: shard g's chunks 0 .. C - 1, then shard g + 1's; slab (c, g) */
+  for (uint32_t q = 0; q < NS; ++q) {
+    uint32_t g = (q % s->rf_C) * s->V + q / s->rf_C;
     uint8_t* slab = rf_slab(s, s->xrecv, g);
     const rf_slab_hdr* hd = (const rf_slab_hdr*)slab;
     if (hd->over || hd->n > s->rf_cap) { s->rf_err = 1; continue; }
@@ -1716,7 +1727,8 @@ static void rf_unpack(osim* s) {
   for (uint32_t l = 0; l < s->Nl; ++l) s->rcsr[l + 1] += s->rcsr[l];
   uint32_t* fill = (uint32_t*)malloc((size_t)s->Nl * sizeof(uint32_t));
   memcpy(fill, s->rcsr, (size_t)s->Nl * sizeof(uint32_t));
-  for (uint32_t g = 0; g < s->V; ++g) {
+  for (uint32_t q = 0; q < NS; ++q) {
+    uint32_t g = (q % s->rf_C) * s->V + q / s->rf_C;
     uint8_t* slab = rf_slab(s, s->xrecv, g);
     const rf_slab_hdr* hd = (const rf_slab_hdr*)slab;
     const uint32_t* idx = rf_slab_idx(slab);
@@ -1741,8 +1753,7 @@ static void rf_group(osim* s) {
 }
 static void step_end(osim* s) {
   const tickp p = s->cur;
-  if (RF_SH(s)) rf_pack(s, s->inbox[(s->tick + 1) & 1]); /* the slabs go out between this tick and the next (the host's all-to-all) */
-  else if (s->rfan) rf_group(s);
+  if (s->rfan && !RF_SH(s)) rf_group(s);
   s->prev = p;
   s->tick++;
   s->in_tick = 0;
@@ -1846,9 +1857,10 @@ int API(create)(const sim_config* cfg, osim** out) {
   s->rows = (sim_row*)calloc(Nl, sizeof(sim_row));
   s->queue = (sim_record*)malloc(Nl * SIM_Q * sizeof(sim_record));
   s->rfan = (cfg->flags & SIM_CF_RANDOM_FANOUT) != 0;
-  s->rf_cap = serf_rf_slab_cap(s->f, s->M, s->V);
+  s->rf_C = (s->rfan && CFG_SHARDED(cfg) && cfg->chunks > 1) ? cfg->chunks : 1;
+  s->rf_cap = serf_rf_slab_cap(s->f, s->M / s->rf_C, s->V);
   if (CFG_SHARDED(cfg)) {
-    size_t bytes = s->rfan ? (size_t)s->V * rf_slab_bytes(s) : (size_t)s->fp * s->M * sizeof(sim_packet);
+    size_t bytes = s->rfan ? (size_t)s->rf_C * s->V * rf_slab_bytes(s) : (size_t)s->fp * s->M * sizeof(sim_packet);
     s->xsend = (sim_packet*)calloc(bytes, 1);
     s->xrecv = (sim_packet*)calloc(bytes, 1);
     s->rbuf[0] = s->rbuf[1] = s->xrecv;
@@ -1884,7 +1896,7 @@ int API(create)(const sim_config* cfg, osim** out) {
     return SIM_ENOMEM;
   }
   if (s->rfan) {
-    if (cfg->chunks > 1) { API(destroy)(s); return SIM_EINVAL; }
+    if (cfg->chunks > 1 && !CFG_SHARDED(cfg)) { API(destroy)(s); return SIM_EINVAL; } /* sender chunks: a shard's exchange schedule */
     s->rtgt = (uint32_t*)malloc((size_t)s->f * Nl * sizeof(uint32_t));
     s->rcsr = (uint32_t*)calloc((size_t)Nl + 1, sizeof(uint32_t));
     s->rsrc = (uint32_t*)malloc((size_t)s->f * Nl * sizeof(uint32_t));
@@ -2832,7 +2844,7 @@ int API(restore)(osim* s, const void* buf, size_t bytes) {
       uint32_t chosen[SIM_MAX_FANOUT], nc = rf_draw(s, s->tick - 1, s->shard0 + l, s->prev.feff, chosen);
       for (uint32_t k = 0; k < s->f; ++k) s->rtgt[(size_t)k * s->Nl + l] = (k < s->prev.feff && k < nc) ? chosen[k] : NOSLOT;
     }
-    if (RF_SH(s)) rf_pack(s, s->inbox[s->tick & 1]); /* packed again: the host runs the exchange once more (SIM_XCHG_PACKED) */
+    if (RF_SH(s)) for (uint32_t c = 0; c < s->rf_C; ++c) rf_pack(s, s->inbox[s->tick & 1], c); /* packed again: the host runs the exchange once more (SIM_XCHG_PACKED) */
     else rf_group(s);
   }
   s->rf_err = 0;
@@ -2948,7 +2960,7 @@ int API(cluster_stats_get)(osim* s, sim_cluster_stats* o) {
 /* bytes of the send buffer (= of each receive buffer): the bijection's slabs [C][V][fp][M / V / C], or the random fan-out's V packed slabs */
 static size_t xbytes(const osim* s) {
   if (!SHARDED(s)) return 0;
-  return RF_SH(s) ? (size_t)s->V * rf_slab_bytes(s) : (size_t)s->fp * s->M * sizeof(sim_packet);
+  return RF_SH(s) ? (size_t)s->rf_C * s->V * rf_slab_bytes(s) : (size_t)s->fp * s->M * sizeof(sim_packet);
 }
 int API(exchange_bytes)(const osim* s, size_t* bytes) {
   if (!s || !bytes) return SIM_EINVAL;

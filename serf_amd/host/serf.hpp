@@ -121,12 +121,13 @@ class Serf {
     void on_respond(std::function<std::vector<uint8_t>(uint32_t)> f) { payload_of_ = std::move(f); }
    private:
     friend class Serf;
-    QueryResponse(Cluster* c, uint32_t id) : c_(c), id_(id) {}
+    QueryResponse(Cluster* c, uint32_t id);   // (below Cluster: it notes the tick the query's deadline cannot outlast)
     std::vector<uint32_t> fresh(int which, std::vector<uint32_t>& seen);
     Cluster* c_;
     uint32_t id_;
     bool closed_ = false;
     mutable bool started_ = false;  // the tracker has been seen under this id (the tick that executes the query has run)
+    uint64_t give_up_ = 0;          // a tick by which the query has certainly run out: its tick + 16 * digits10(N) (query.rs:421-427) and some
     std::vector<uint32_t> seen_acks_, seen_resp_;                             // ascending (QueryResponseCore.acks / .responses)
     std::function<std::vector<uint8_t>(uint32_t)> payload_of_;
   };
@@ -242,10 +243,18 @@ inline bool Serf::QueryResponse::finished() const {
   uint64_t a, r;
   int open = 0;
   const int rc = sim_query_status(c_->raw(), id_, &a, &r, &open);
-  if (rc == SIM_EINVAL) return started_;  // not started yet: still open; evicted: finished
+  // not started yet: still open; evicted: finished — and an id that never gets to own its tracker entry (taken over by a newer query
+  // of the same residue before this object ever saw it; an id that was never valid) is finished once its deadline is past, so that
+  // `while (!r.finished()) step()` ends
+  if (rc == SIM_EINVAL) return started_ || c_->tick() > give_up_;
   check(rc, "sim_query_status");
   started_ = true;
   return !open;
+}
+inline Serf::QueryResponse::QueryResponse(Cluster* c, uint32_t id) : c_(c), id_(id) {
+  uint32_t n = c->size(), digits = 0;
+  while (n) { ++digits; n /= 10; }
+  give_up_ = c->tick() + 2u + 16u * digits;
 }
 inline std::vector<uint32_t> Serf::QueryResponse::fresh(int which, std::vector<uint32_t>& seen) {
   std::vector<uint32_t> out;

@@ -16,7 +16,8 @@ memberlist's literal kRandomNodes (SIM_CF_RANDOM_FANOUT) sends a packet to ANY n
 write into: the packets stay in their senders' cells, every shard sorts the (target, sender, slot) triples of its OWN senders and
 packs the packets bound for shard h into slab h in that order, one count byte per target next to them (sim_exchange_layout:
 XCHG_PACKED); the exchange is the same equal-split all-to-all — f * M * (V - 1) / V packets leave a GPU per round —, the receiver's
-row is V sorted runs.  One chunk per tick in this mode.
+row is V sorted runs.  With ``chunks = C`` the senders are cut into C ranges, each packed and exchanged behind its own launch (a row
+is then V * C runs) — the same overlap as the bijection's.
 
 The reference has no collective at all (its transport is UDP/TCP inside memberlist); this replaces
 `memberlist.send`-style delivery for the simulation.
@@ -243,7 +244,9 @@ class ShardedSim:
         self.sim.restore(image)
         if self.kind == _ffi.XCHG_PACKED and self.sim.tick > 0:
             rbuf = self.recv[(self.sim.tick - 1) & 1] if self.chunks > 1 else self.recv[0]
-            self._exchange(0, rbuf, self.send, False)
+            for c in range(self.chunks):
+                lo = c * self.chunk_bytes
+                self._exchange(c, rbuf[lo:lo + self.chunk_bytes], self.send[lo:lo + self.chunk_bytes], False)
 
     def _exchange(self, c, recv, send, asynchronous):
         if self._xt is not None:  # measurement mode: bracket the collective with events, no overlap

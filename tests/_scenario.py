@@ -24,3 +24,12 @@ def assert_same_state(x, y, what=""):
         assert a.shape == b.shape, f"{what}: {name} shape {a.shape} vs {b.shape}"
         i = first_diff(a, b)
         assert i is None, f"{what}: {name}[{i}] differs: {a[i]} vs {b[i]}"
+
+
+def free_port():
+    """a TCP port nobody listens on right now (the rendezvous of a multi-process test: a port derived from the pid collided now and
+    then when pytest-xdist ran two such tests side by side — one of them then waited for its 240 s join)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]

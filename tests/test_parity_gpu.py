@@ -605,9 +605,21 @@ def _packed_exchange_on_one_gpu(send, recv):
             recv[g][src * slab:(src + 1) * slab].copy_(send[src][g * slab:(g + 1) * slab])
 
 
-@pytest.mark.parametrize("V,swim,pkt,rc,n", [(4, 0, 0, 0, 2048), (4, 4, 0, 0, 2048), (4, 4, 8, 0, 2048), (4, 2, 0, 3, 2048), (4, 4, 0, 0, 1 << 16),
-                                             (8, 4, 16, 0, 4096), (2, 4, 0, 0, 1 << 17), (8, 0, 0, 0, 64)])
-def test_random_fanout_four_shards_on_one_gpu(oracle, hiplib, V, swim, pkt, rc, n):
+def _packed_exchange_chunk_on_one_gpu(send, recv, c, C):
+    """chunk c of a chunk-wise exchange: region c of every send buffer, equal split, into region c of the receive buffers"""
+    V = len(send)
+    reg = send[0].numel() // C
+    slab = reg // V
+    for g in range(V):
+        for src in range(V):
+            recv[g][c * reg + src * slab:c * reg + (src + 1) * slab].copy_(send[src][c * reg + g * slab:c * reg + (g + 1) * slab])
+
+
+@pytest.mark.parametrize("V,swim,pkt,rc,n,C", [(4, 0, 0, 0, 2048, 1), (4, 4, 0, 0, 2048, 1), (4, 4, 8, 0, 2048, 1), (4, 2, 0, 3, 2048, 1), (4, 4, 0, 0, 1 << 16, 1),
+                                               (8, 4, 16, 0, 4096, 1), (2, 4, 0, 0, 1 << 17, 1), (8, 0, 0, 0, 64, 1),
+                                               # sender chunks (r5): chunk c's slabs are packed behind chunk c's launch; a row is V * C runs
+                                               (4, 4, 0, 0, 2048, 2), (4, 4, 8, 0, 1 << 16, 4), (2, 2, 0, 3, 2048, 2)])
+def test_random_fanout_four_shards_on_one_gpu(oracle, hiplib, V, swim, pkt, rc, n, C):
     # memberlist's kRandomNodes on shards (r5: the scalable form, VERDICT r4 item 1): V handles on ONE GPU, each sorting the
     # (target, sender, slot) triples of its OWN senders and packing the packets bound for shard h into slab h (sim_exchange_layout:
     # SIM_XCHG_PACKED); the round's exchange is an equal-split all-to-all of the slabs, done here with device-to-device copies.
@@ -622,19 +634,22 @@ def test_random_fanout_four_shards_on_one_gpu(oracle, hiplib, V, swim, pkt, rc, 
               **(dict(suspicion_mult=3, suspicion_max_mult=2, gossip_to_the_dead=1) if rc else {}))
     A = 96 if n > 64 else n
     ref = _ffi.Sim(oracle, _ffi.make_config(n, vshards=V, **kw))
+    kw = dict(kw, chunks=C if C > 1 else 0)   # (sender chunks are the shards' exchange schedule: the handle that holds every node has none)
     shards, send, recv = [], [], []
     for g in range(V):
         s = _ffi.Sim(hiplib, _ffi.make_config(n, vshards=V, shard_rank=g, shard_count=V, **kw))
         kind, planes, pb, rb = s.exchange_layout()
-        assert kind == _ffi.XCHG_PACKED and planes == 1 and pb == rb == s.exchange_bytes() and pb % (64 * V) == 0
+        assert kind == _ffi.XCHG_PACKED and planes == 1 and pb == rb == s.exchange_bytes() and pb % (64 * V * C) == 0
+        assert s.exchange_chunks() == (C, pb // C)
         # what leaves a GPU per tick: f packets of 64 bytes per node, (V - 1) / V of them, 2 % of room, a count byte per target
-        if n >= 1 << 16:   # (12 sigma of sqrt(m) = 16 Ki packets per slab is 9 %; at 1 Mi nodes per shard it is 2 %)
+        if n >= 1 << 16 and C == 1:   # (12 sigma of sqrt(m) = 16 Ki packets per slab is 9 %; at 1 Mi nodes per shard it is 2 %)
             assert pb <= 1.13 * 4 * 64 * m, (pb, 4 * 64 * m)
         send.append(torch.zeros(pb, dtype=torch.uint8, device="cuda"))
-        recv.append(torch.zeros(rb, dtype=torch.uint8, device="cuda"))
+        # (packets sent during tick t land in recv[t & 1]: with sender chunks the late chunks of tick t + 1 still read tick t's)
+        recv.append([torch.zeros(rb, dtype=torch.uint8, device="cuda") for _ in range(2 if C > 1 else 1)])
         with pytest.raises(_ffi.SimError):   # the sized bind refuses buffers that are too small
-            s.bind_exchange3(send[-1].data_ptr(), pb - 64, recv[-1].data_ptr(), recv[-1].data_ptr(), rb)
-        s.bind_exchange3(send[-1].data_ptr(), pb, recv[-1].data_ptr(), recv[-1].data_ptr(), rb)
+            s.bind_exchange3(send[-1].data_ptr(), pb - 64, recv[-1][0].data_ptr(), recv[-1][-1].data_ptr(), rb)
+        s.bind_exchange3(send[-1].data_ptr(), pb, recv[-1][0].data_ptr(), recv[-1][-1].data_ptr(), rb)
         shards.append(s)
     ops = sc.schedule(n, ticks // 2, rate=0.8 if not pkt else 3.0, seed=5, max_member_subjects=min(60, n // 2))
     for s in shards + [ref]:
@@ -650,12 +665,15 @@ def test_random_fanout_four_shards_on_one_gpu(oracle, hiplib, V, swim, pkt, rc, 
             s.step_begin()
         if hs[0].pp_due():
             _push_pull_on_one_gpu(hs)
-        for s in hs:
-            s.step_chunk(0)
+        into = [r[hs[0].tick & 1] if C > 1 else r[0] for r in recv]
+        for c in range(C):
+            for s in hs:
+                s.step_chunk(c)
+                s.sync()
+            _packed_exchange_chunk_on_one_gpu(send, into, c, C)
         for s in hs:
             s.step_end()
             s.sync()
-        _packed_exchange_on_one_gpu(send, recv)
         _suspicions_on_one_gpu(hs)
         torch.cuda.synchronize()
         ref.step(1)
@@ -687,12 +705,14 @@ def test_random_fanout_four_shards_on_one_gpu(oracle, hiplib, V, swim, pkt, rc, 
     fresh = []
     for g in range(V):
         f2 = _ffi.Sim(hiplib, _ffi.make_config(n, vshards=V, shard_rank=g, shard_count=V, **kw))
-        f2.bind_exchange3(send[g].data_ptr(), send[g].numel(), recv[g].data_ptr(), recv[g].data_ptr(), recv[g].numel())
+        f2.bind_exchange3(send[g].data_ptr(), send[g].numel(), recv[g][0].data_ptr(), recv[g][-1].data_ptr(), recv[g][0].numel())
         f2.restore(imgs[g])
         assert f2.digest() == shards[g].digest()
         fresh.append(f2)
     torch.cuda.synchronize()
-    _packed_exchange_on_one_gpu(send, recv)
+    into = [r[(fresh[0].tick - 1) & 1] if C > 1 else r[0] for r in recv]   # the packets in flight were sent during tick - 1
+    for c in range(C):
+        _packed_exchange_chunk_on_one_gpu(send, into, c, C)
     for t in range(6):
         tick_all(fresh)
         for g, s in enumerate(fresh):
@@ -1107,19 +1127,20 @@ def _one_rank_rccl_worker(port, q):
             sh.close()
         # the random fan-out as one rank of the N > 1 path: the packed slabs (SIM_XCHG_PACKED) over the same grouped ncclSend / ncclRecv
         kw_rf = dict(kw, flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT, recycle_interval=0)
-        sh = ShardedSim(lib, n, dev, chunks=1, exchange="rccl", **kw_rf)
-        assert sh.use_lib and sh.kind == _ffi.XCHG_PACKED
-        plain = _ffi.Sim(lib, _ffi.make_config(n, **kw_rf))
-        orc = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw_rf))
-        for x in (sh, plain, orc):
-            sc.apply_schedule(x, ops)
-        for t in range(12):
-            sh.step(5)
-            plain.step(5)
-            orc.step(5)
-            sh.sync()
-            assert sh.sim.digest() == plain.digest() == orc.digest(), f"random fan-out, packed slabs over RCCL: digests differ after tick {5 * t + 4}"
-        sh.close()
+        for chunks in (1, 2, 4):   # (sender chunks: chunk c's slabs are packed and travel while chunk c + 1 computes)
+            sh = ShardedSim(lib, n, dev, chunks=chunks, exchange="rccl", **kw_rf)
+            assert sh.use_lib and sh.kind == _ffi.XCHG_PACKED and sh.chunks == chunks
+            plain = _ffi.Sim(lib, _ffi.make_config(n, **kw_rf))
+            orc = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw_rf))
+            for x in (sh, plain, orc):
+                sc.apply_schedule(x, ops)
+            for t in range(12):
+                sh.step(5)
+                plain.step(5)
+                orc.step(5)
+                sh.sync()
+                assert sh.sim.digest() == plain.digest() == orc.digest(), f"random fan-out, packed slabs over RCCL, {chunks} chunk(s): digests differ after tick {5 * t + 4}"
+            sh.close()
         dist.destroy_process_group()
         q.put(("ok", out[1]))
     except BaseException as e:  # noqa: BLE001

@@ -137,7 +137,8 @@ def test_sharded_recycling_matches_single_process():
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29450 + (os.getpid() % 300)
+    from tests._scenario import free_port
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

@@ -54,7 +54,8 @@ def _worker(rank, world, port, n, ticks, swim, chunks, q, jitter=0.0, pkt=0, los
                   **(dict(suspicion_mult=3, suspicion_max_mult=2, gossip_to_the_dead=1) if rc else {}),
                   **(dict(flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT) if rf else {}))
         sh = ShardedSim(lib, n, torch.device("cpu"), chunks=chunks, **kw)
-        ref = _ffi.Sim(lib, _ffi.make_config(n, vshards=world, chunks=chunks if chunks > 1 else 0, **kw))  # all shards in one process
+        # all shards in one process (memberlist's kRandomNodes: sender chunks are a shard's exchange schedule, nothing a single handle has)
+        ref = _ffi.Sim(lib, _ffi.make_config(n, vshards=world, chunks=chunks if chunks > 1 and not rf else 0, **kw))
         ops = sc.schedule(n, ticks // 2, rate=0.7 if not pkt else 3.0, seed=17, max_member_subjects=40)
         # query filters and tag classes are replicated tables: every shard applies the same operations
         ops, classes = sc.with_filters(ops, n, tag_changes=6 if swim else 0)
@@ -121,9 +122,11 @@ def _worker(rank, world, port, n, ticks, swim, chunks, q, jitter=0.0, pkt=0, los
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,swim,n,pkt,loss,rc", [(2, 0, 1024, 0, .02, 0), (2, 4, 1024, 0, .02, 0), (4, 2, 2048, 8, .12, 2), (4, 1, 1024, 16, .0, 3),
-                                                      (1, 4, 1024, 0, .02, 0)])
-def test_shards_gloo_random_fanout_match_single_process(world, swim, n, pkt, loss, rc):
+@pytest.mark.parametrize("world,swim,n,pkt,loss,rc,chunks", [(2, 0, 1024, 0, .02, 0, 1), (2, 4, 1024, 0, .02, 0, 1), (4, 2, 2048, 8, .12, 2, 1), (4, 1, 1024, 16, .0, 3, 1),
+                                                             (1, 4, 1024, 0, .02, 0, 1),
+                                                             # sender chunks (r5): chunk c's slabs are packed and travel while chunk c + 1 computes
+                                                             (2, 4, 1024, 0, .02, 0, 2), (4, 2, 2048, 8, .12, 2, 4), (1, 4, 1024, 0, .02, 0, 2)])
+def test_shards_gloo_random_fanout_match_single_process(world, swim, n, pkt, loss, rc, chunks):
     # memberlist's kRandomNodes on shards (r5: the scalable form): a packet goes to ANY node of the cluster, so the packets stay
     # in their senders' cells; every shard sorts the (target, sender, slot) triples of its OWN senders, packs the packets bound
     # for shard h into slab h and the round's exchange is one equal-split all-to-all of those slabs (sim_exchange_layout:
@@ -132,8 +135,9 @@ def test_shards_gloo_random_fanout_match_single_process(world, swim, n, pkt, los
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29950 + (os.getpid() % 300) + swim + 7 * world + 11 * rc
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, 60 if not rc else 100, swim, 1, q, 0.0, pkt, loss, rc, 1)) for r in range(world)]
+    from tests._scenario import free_port
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, 60 if not rc else 100, swim, chunks, q, 0.0, pkt, loss, rc, 1)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -155,7 +159,8 @@ def test_shards_gloo_match_single_process(world, chunks, swim, n, jitter, pkt, l
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 300) + swim + 7 * world + chunks + (40 if loss > .05 else 0) + 11 * rc
+    from tests._scenario import free_port
+    port = free_port()
     # (the last case is the configuration that stalled on one GPU in round 2 — world 4, 4 chunks, SWIM and push-pull
     # batches, 4 096 nodes — here with CPU tensors and every collective randomly delayed)
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, 60 if not rc else 100, swim, chunks, q, jitter, pkt, loss, rc)) for r in range(world)]
