@@ -2349,6 +2349,11 @@ static int deliver_push_pull(osim* s, uint32_t node, rdr body) {
     }
   }
   if (rc == SIM_OK && (seen & 7u) != 7u) rc = SIM_EINVAL;
+  if (rc == SIM_OK) { /* a frame that is refused leaves NOTHING behind: the view slots its members need (they execute in this tick) are counted first */
+    uint32_t need = 0;
+    for (uint32_t j = 0; j < n_st; ++j) need += s->slot_of[ids[j]] == NOSLOT; /* (ids are distinct: the status map is a map) */
+    if (need > s->A - s->n_alloc) rc = SIM_ENOSLOT;
+  }
   for (uint32_t i = 0; i < 3 && rc == SIM_OK; ++i) /* "we subtract 1 since no message with that clock has been sent yet" */
     if (clk[i] > 0) rc = inject_val(s, s->tick, SIM_OP_WITNESS, node, i, 0, clk[i] - 1);
   for (uint32_t i = 0; i < n_left && rc == SIM_OK; ++i) { /* the left members first, one past their status time */

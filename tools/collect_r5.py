@@ -5,7 +5,7 @@ profiles/r05_pmc_traffic_<model>[_long].json — HBM bytes per tick-kernel launc
 profiles/r02_hbm_counter_calibration.json — stamped with the commit and the hash of the kernel source it was measured on
 (bench.py reports the figure as roofline.traffic / roofline.frac_measured only while that hash is the current one).
 
-usage: python tools/collect_r5.py [call_dir]"""
+usage: python tools/collect_r5.py [call_dir [git-rev-that-was-measured]]"""
 import json
 import os
 import shutil
@@ -32,7 +32,11 @@ for src, dst in (("bench_20_5.json", "r05_bench_driver_args.json"), ("bench_one_
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 sha = bench.kernel_source_sha16()   # the device side of the tick kernel: serf_sim_state.inc + serf_sim_handlers.inc + serf_sim_tick.inc
-commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+if len(sys.argv) > 2:               # ... as it stood at the commit the call measured (the working tree has moved on since)
+    import hashlib
+    rev = sys.argv[2]
+    sha = hashlib.sha256(b"".join(subprocess.run(["git", "-C", ROOT, "show", f"{rev}:{f}"], capture_output=True, check=True).stdout for f in bench.KERNEL_SOURCES)).hexdigest()[:16]
+commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", sys.argv[2] if len(sys.argv) > 2 else "HEAD"], capture_output=True, text=True).stdout.strip()
 n = 1 << 20
 for model in ("krandomnodes", "bijection"):
     for window, steps, warmup, sfx in (("short", 20, 5, ""), ("long", 300, 25, "_long")):

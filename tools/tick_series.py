@@ -80,7 +80,7 @@ if os.path.exists(tlib_path):
         sim.sync()
         tlib.dll.sim_debug_timing(buf, 1)
         series.append({"iters": buf[12] / waves, "rounds": buf[13] / waves, "slow": buf[14] / waves, "refetched": buf[15] / waves,
-                       "copies": buf[16] / waves, "slow_by_kind": [round(buf[17 + i] / waves, 2) for i in range(7)],  # JOIN LEAVE EVENT QUERY ALIVE SUSPECT DEAD
+                       "slow_by_kind": [round(buf[17 + i] / waves, 2) for i in range(7)],  # JOIN LEAVE EVENT QUERY ALIVE SUSPECT DEAD
                        "cyc_handlers": buf[5] / waves, "cyc_total": sum(buf[:12]) / waves})
     sim.close()
 rows = []
