@@ -127,7 +127,7 @@ def main():
                 "crash / re-join churn + packet loss with the failure detector on; rounds until >= 99 % of the running nodes have applied a user event",
         "config": {k: v for k, v in vars(args).items() if k != "out"}, "backend": lib.backend_name(),
         "ticks": int(shards[0].tick), "churn_events": int(n_churn), "churn_frac_of_nodes": n_churn / n,
-        "churn_note": "configs[4] asks for 5 % churn: at one crash per %d ticks (the pace the view slots and suspicion timers allow) that is %.1e ticks; this run shows the "
+        "churn_note": "configs[4] asks for 5 %% churn: at one crash per %d ticks (the pace the view slots and suspicion timers allow) that is %.1e ticks; this run shows the "
                       "mechanism at the full size, not the full dose (the full dose on one rank's share: profiles/r04_config4_shard_size_2m_v8.json)" % (args.churn_every, 0.05 * n * args.churn_every),
         "rumors": int(len(rounds)),
         "rounds_to_99": {"median": float(np.median(r)), "p90": float(np.percentile(r, 90)), "max": int(r.max()), "min": int(r.min()), "not_converged": int((r > args.max_rounds).sum()),
