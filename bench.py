@@ -543,7 +543,21 @@ def run(args, lib=None, dev=None, backend="nccl"):
             conv_first, conv_last = c0, raw.tick
         m["rounds"], m["conv"] = rounds, (conv_first, conv_last)
         m["load2"] = load_now()
-        raw.close()  # two clusters need not sit next to each other (66 GB each at 1 Mi nodes)
+        # what the cluster holds at the end of the run: the planes of the view / the rings that ever got memory (sim_resident_planes:
+        # slots handed out, Lamport times admitted) and what the device reports in use (everything on it: HIP context, torch, RCCL)
+        fp = {}
+        if "resident_planes" in raw.lib.f:
+            rp = raw.resident_planes()
+            fp = {"view_planes": list(rp["view"]), "event_ring_planes": list(rp["event_ring"]), "query_ring_planes": list(rp["query_ring"]),
+                  "bytes_per_plane": rp["bytes_per_plane"],
+                  "view_and_rings_resident_bytes": (rp["view"][0] + rp["event_ring"][0] + rp["query_ring"][0]) * rp["bytes_per_plane"],
+                  "view_and_rings_whole_bytes": (rp["view"][1] + rp["event_ring"][1] + rp["query_ring"][1]) * rp["bytes_per_plane"]}
+        if on_gpu:
+            free, tot = torch.cuda.mem_get_info(dev)
+            fp["device_bytes_in_use"] = int(tot - free)
+            fp["device_GiB_in_use_per_Mi_nodes"] = round((tot - free) / 2 ** 30 / (args.nodes_per_gpu / 2 ** 20), 2)
+        m["footprint"] = fp
+        raw.close()  # two clusters need not sit next to each other
         return m
 
     def roofline_of(m):
@@ -629,7 +643,7 @@ def run(args, lib=None, dev=None, backend="nccl"):
              "ms_per_step": t["dt"] / args.steps * 1e3, "kernel_ms": t["kern_s"] * 1e3, "roofline": roofline_of(m),
              "rounds_to_99": rounds_of(m), "model_bound_drops": m["load2"]["drops"],
              "records_per_packet": [round(m["load0"]["records_per_packet"], 3), round(m["load1"]["records_per_packet"], 3)],
-             "deepest_queue": m["load1"]["max_queue"]}
+             "deepest_queue": m["load1"]["max_queue"], "footprint": m["footprint"]}
         if sharded:
             d["exchange"] = exchange_of(m)
         if lw:
@@ -690,7 +704,8 @@ def run(args, lib=None, dev=None, backend="nccl"):
                                 "deepest_queue": head["load1"]["max_queue"],
                                 "records_per_packet_preroll_every_40_ticks": head["trace"],
                                 "nodes_up": head["load1"]["up"], "view_slots_in_use": head["load2"]["slots_in_use"],
-                                "view_slots_recycled": head["load2"]["slots_recycled"]}},
+                                "view_slots_recycled": head["load2"]["slots_recycled"]},
+                       "footprint": head["footprint"]},
             "rounds_to_99": rounds_of(head),
             "roofline": roofline_of(head),
             "fanout_models": {mo: summary_of(res[mo]) for mo in models},

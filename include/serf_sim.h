@@ -696,6 +696,15 @@ int sim_profile_read(sim_handle* h, double* tick_kernel_ms, uint64_t* launches);
 int sim_profile_read_stats(sim_handle* h, double out_ms[3], uint64_t* launches);
 /* Sums over the local shard's nodes (one reduction kernel; see sim_cluster_stats). */
 int sim_cluster_stats_get(sim_handle* h, sim_cluster_stats* out);
+/* How much of the handle's big arrays has memory behind it.  A view entry of slot a lives in plane a of the view array, a ring
+ * bucket of Lamport time t in plane t mod ring size; the HIP library reserves the address range of all planes and gives a plane
+ * physical memory when the host first hands out its slot / admits a Lamport time that reaches it (HIP virtual-memory API; a
+ * plane must be a multiple of the mapping granularity — 128 Ki nodes per shard —, the view must be sparse; the rings of a
+ * shard are whole; SERF_SIM_EAGER=1 in the environment turns it off).  Digests, dumps and images do not change: a plane without
+ * memory is the zeros it stands for.  out = { view planes with memory, view planes, event-ring planes with memory, event-ring
+ * planes, query-ring planes with memory, query-ring planes }; bytes_per_plane = 32 x the shard's nodes.  (The oracle keeps
+ * whole arrays: resident == total.)  No reference counterpart. */
+int sim_resident_planes(const sim_handle* h, uint32_t out[6], uint64_t* bytes_per_plane);
 
 uint32_t sim_abi_version(void);
 const char* sim_backend_name(void);

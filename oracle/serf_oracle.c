@@ -2941,6 +2941,12 @@ int API(profile_read_stats)(osim* s, double out_ms[3], uint64_t* launches) {
   *launches = 0;
   return SIM_OK;
 }
+int API(resident_planes)(const osim* s, uint32_t out[6], uint64_t* bytes_per_plane) { /* whole arrays: resident == total */
+  if (!s || !out) return SIM_EINVAL;
+  out[0] = out[1] = s->A; out[2] = out[3] = s->Bev; out[4] = out[5] = s->Bq;
+  if (bytes_per_plane) *bytes_per_plane = (uint64_t)s->Nl * 32;
+  return SIM_OK;
+}
 int API(cluster_stats_get)(osim* s, sim_cluster_stats* o) {
   if (!s || !o) return SIM_EINVAL;
   memset(o, 0, sizeof *o);

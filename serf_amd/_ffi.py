@@ -102,7 +102,7 @@ _ARR_DTYPE = {ARR_ROWS: ROW_DTYPE, ARR_QUEUE: REC_DTYPE, ARR_INBOX: PACKET_DTYPE
 ABI_SYMBOLS = ("create", "destroy", "set_stream", "join", "leave", "force_leave", "user_event",
                "query", "inject", "step", "sync", "tick", "members", "stats_get", "watch",
                "drain_events", "state_digest", "dump_state", "convergence", "convergence_many", "exchange_bytes",
-               "bind_exchange", "snapshot", "restore", "query_status", "query_responders", "profile", "profile_read", "profile_read_stats", "cluster_stats_get",
+               "bind_exchange", "snapshot", "restore", "query_status", "query_responders", "profile", "profile_read", "profile_read_stats", "cluster_stats_get", "resident_planes",
                "bind_exchange2", "bind_exchange3", "exchange_chunks", "exchange_layout", "step_begin", "step_chunk", "step_end",
                "recycle_due", "recycle_scan", "recycle_apply", "pp_due", "pp_plan", "pp_export", "pp_merge",
                "query_filtered", "set_tags", "init_tags", "inject_record", "deliver_message", "user_event_bytes", "peek_packet", "suspect_requests", "suspect_export", "suspect_import",
@@ -184,6 +184,7 @@ class SimLib:
             "bind_exchange3": (C.c_int, [H, vp, C.c_size_t, vp, vp, C.c_size_t]),
             "exchange_chunks": (C.c_int, [H, C.POINTER(u32), C.POINTER(C.c_size_t)]),
             "exchange_layout": (C.c_int, [H, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+            "resident_planes": (C.c_int, [H, C.POINTER(u32), C.POINTER(C.c_uint64)]),
             "step_begin": (C.c_int, [H]),
             "step_chunk": (C.c_int, [H, u32]),
             "step_end": (C.c_int, [H]),
@@ -448,6 +449,13 @@ class Sim:
         ms, n = (C.c_double * 3)(), C.c_uint64()
         self._ck(self.lib.f["profile_read_stats"](self.h, C.byref(ms), C.byref(n)), "sim_profile_read_stats")
         return (ms[0], ms[1], ms[2]), n.value
+
+    def resident_planes(self):
+        """{array: (planes with memory, planes)} for view / event ring / query ring, and the bytes of one plane"""
+        out = (C.c_uint32 * 6)()
+        bpp = C.c_uint64()
+        self._ck(self.lib.f["resident_planes"](self.h, out, C.byref(bpp)), "sim_resident_planes")
+        return {"view": (out[0], out[1]), "event_ring": (out[2], out[3]), "query_ring": (out[4], out[5]), "bytes_per_plane": bpp.value}
 
     def cluster_stats(self):
         """Load figures summed over the local shard's nodes (queue depths by class, model-bound drops, ...)."""

@@ -22,7 +22,7 @@ from serf_amd import _ffi  # noqa: E402
 
 
 def run_one(path, args, ticks):
-    lib = _ffi.SimLib(path, optional=("bind_exchange3",))   # (a build of the previous ABI may be one of the candidates)
+    lib = _ffi.SimLib(path, optional=("bind_exchange3", "resident_planes"))   # (a build of the previous ABI may be one of the candidates)
     n = args.nodes_per_gpu
     kw, ops = bench.workload(args, n)
     sim = _ffi.Sim(lib, _ffi.make_config(n, **kw))
