@@ -2132,7 +2132,15 @@ static int inject_val(osim* s, uint64_t tick, uint32_t op, uint32_t node, uint32
   }
   /* stable insertion by tick (ops already consumed stay in front) */
   size_t pos = s->n_ops;
-  while (pos > s->op_cursor && s->ops[pos - 1].tick > tick) { s->ops[pos] = s->ops[pos - 1]; --pos; }
+  /* order within a tick: the caller's operations in the order they were scheduled, then the replayed suspicions / reconnect
+   * attempts (SIM_OP_SUSPECT / SIM_OP_RECONNECT) in theirs — whenever the lists reached the schedule (step_begin, a checkpoint,
+   * the sharded host's hand-over) */
+#define OP_LATE(o) ((o) == SIM_OP_SUSPECT || (o) == SIM_OP_RECONNECT)
+  while (pos > s->op_cursor && (s->ops[pos - 1].tick > tick || (s->ops[pos - 1].tick == tick && OP_LATE(s->ops[pos - 1].op) && !OP_LATE(op)))) {
+    s->ops[pos] = s->ops[pos - 1];
+    --pos;
+  }
+#undef OP_LATE
   s->ops[pos].tick = tick; s->ops[pos].op = op; s->ops[pos].node = node; s->ops[pos].a = a; s->ops[pos].b = b;
   s->ops[pos].val = val;
   s->n_ops++;
