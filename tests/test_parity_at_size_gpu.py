@@ -88,3 +88,70 @@ def test_krandomnodes_above_4mi_nodes(oracle, hiplib, mi, ticks):
               flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT)
     ops = sc.schedule(n, ticks - 5, rate=0.5, seed=77, max_member_subjects=7)
     _run(oracle, hiplib, n, ops, ticks, 10, f"{mi} Mi nodes, kRandomNodes (64-bit sort entries)", **kw)
+
+
+def test_config3_as_four_shard_handles_through_the_packed_exchange(oracle, hiplib):
+    # BASELINE configs[3] in its SHARDED form on the headline model: 4 Mi nodes as the four shard handles of four ranks (1 Mi nodes each,
+    # memberlist's kRandomNodes, 2 sender chunks), on one GPU — every shard sorts its own senders' (target, sender, slot) triples, packs
+    # the packets per destination behind the chunk's launch, the round's equal-split all-to-all of the packed slabs (SIM_XCHG_PACKED) is
+    # done with device copies, the cross-shard push-pull batch and the suspicions' hand-over as a sharded host does them — against ONE
+    # oracle handle that holds all 4 Mi nodes: every shard's rows and queues at tick 19, every array at tick 39, slice by slice.
+    import torch
+
+    from tests.test_parity_gpu import _packed_exchange_chunk_on_one_gpu, _push_pull_on_one_gpu, _suspicions_on_one_gpu
+
+    n, V, C, A, BE, BQ, ticks = 1 << 22, 4, 2, 16, 16, 8, 40
+    m = n // V
+    kw = dict(fanout=4, view_slots=A, event_ring=BE, query_ring=BQ, leave_delay=6, probe_interval=5, loss=0.01, push_pull_interval=20,
+              flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT)
+    t0 = time.perf_counter()
+    ref = _ffi.Sim(oracle, _ffi.make_config(n, vshards=V, **kw))
+    shards, send, recv = [], [], []
+    for g in range(V):
+        s = _ffi.Sim(hiplib, _ffi.make_config(n, vshards=V, shard_rank=g, shard_count=V, chunks=C, **kw))
+        kind, planes, pb, rb = s.exchange_layout()
+        assert kind == _ffi.XCHG_PACKED and pb <= 1.06 * 4 * 64 * m       # what a shard sends per tick: f x 64 B per node + 5 % (room of 12 sigma per slab and chunk, a count byte per target)
+        send.append(torch.zeros(pb, dtype=torch.uint8, device="cuda"))
+        recv.append([torch.zeros(rb, dtype=torch.uint8, device="cuda") for _ in range(2)])
+        s.bind_exchange3(send[-1].data_ptr(), pb, recv[-1][0].data_ptr(), recv[-1][1].data_ptr(), rb)
+        shards.append(s)
+    ops = sc.schedule(n, 30, rate=0.6, seed=23, max_member_subjects=7)
+    for s in shards + [ref]:
+        sc.apply_schedule(s, ops)
+    for t in range(ticks):
+        for s in shards:
+            s.step_begin()
+        if shards[0].pp_due():
+            _push_pull_on_one_gpu(shards)
+        into = [r[shards[0].tick & 1] for r in recv]
+        for c in range(C):
+            for s in shards:
+                s.step_chunk(c)
+                s.sync()
+            _packed_exchange_chunk_on_one_gpu(send, into, c, C)
+        for s in shards:
+            s.step_end()
+            s.sync()
+        _suspicions_on_one_gpu(shards)
+        torch.cuda.synchronize()
+        ref.step(1)
+        if t in (19, ticks - 1):
+            arrays = [(_ffi.ARR_ROWS, None), (_ffi.ARR_QUEUE, None)]
+            if t == ticks - 1:
+                arrays += [(_ffi.ARR_VIEW, A), (_ffi.ARR_ERING, BE), (_ffi.ARR_QRING, BQ), (_ffi.ARR_INBOX, 4)]
+            for which, rows in arrays:
+                b = ref.dump(which)
+                for g, s in enumerate(shards):
+                    a, lo = s.dump(which), g * m
+                    if rows is None:
+                        per = len(b) // n
+                        i = sc.first_diff(a, b[lo * per:(lo + m) * per])
+                        assert i is None, f"shard {g} array {which} element {i} differs at tick {t}"
+                    else:
+                        assert a.reshape(rows, m).tobytes() == np.ascontiguousarray(b.reshape(rows, n)[:, lo:lo + m]).tobytes(), f"shard {g} array {which} differs at tick {t}"
+                del b
+    cs = [s.cluster_stats() for s in shards]
+    print(f"4 Mi nodes as 4 shard handles of 1 Mi, kRandomNodes, packed exchange, 2 chunks: {ticks} ticks bit-exact against one oracle handle, "
+          f"{time.perf_counter() - t0:.0f} s; slab bytes per shard and tick {send[0].numel()}; drops {sum(c['overflow'] for c in cs)}")
+    for s in shards + [ref]:
+        s.close()
