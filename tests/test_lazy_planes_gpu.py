@@ -79,3 +79,25 @@ def test_lazy_planes_equal_whole_arrays_and_the_oracle(oracle, hiplib, model):
     assert lazy.digest() == fresh.digest() == fresh_whole.digest() == fo.digest()
     for x in (lazy, whole, o, fresh, fresh_whole, fo):
         x.close()
+
+
+def test_restore_gives_memory_to_every_slot_that_was_handed_out(oracle, hiplib):
+    # a slot that was handed out may hold nothing but zeros (a cluster nobody has joined yet: the baseline entry is empty) — the image's
+    # view section is all zeros then, and the restored handle must give the slot's plane memory all the same: the tick kernel walks it
+    kw = dict(KW, flags=0)
+    a, o = _create(hiplib, False, **kw), _ffi.Sim(oracle, _ffi.make_config(N, **kw))
+    if a.resident_planes()["view"][1] == a.resident_planes()["view"][0]:
+        pytest.skip("nothing is lazy on this device")
+    for x in (a, o):
+        x.leave(9)              # executes in tick 0: subject 9 gets slot 0 now
+        x.inject(3, _ffi.OP_CRASH, 11)
+    img = a.snapshot()
+    assert bytes(img) == bytes(o.snapshot())
+    b = _create(hiplib, False, **kw)
+    b.restore(img)
+    assert b.resident_planes()["view"][0] >= 1
+    for x in (a, b, o):
+        x.step(12)
+    assert a.digest() == b.digest() == o.digest()
+    for x in (a, b, o):
+        x.close()
