@@ -145,12 +145,15 @@ def main():
         "max_view_slots_in_use_seen": stats["max_slots_in_use"], "deepest_queue_seen": stats["max_queue"],
         "nodes_up_at_end": int(sum(int(c["up"]) for c in cs)),
         "create_s": t_create, "wall_s": dt, "ms_per_cluster_tick_8_shards_taking_turns_incl_host": dt / max(1, int(shards[0].tick)) * 1e3,
-        "device_memory": {"in_use_bytes_after_create": int(tot - free), "total_bytes": int(tot), "per_Mi_nodes_GiB": (tot - free) / (n / 2 ** 20) / 2 ** 30},
+        "device_memory": {"in_use_bytes_after_create": int(tot - free), "in_use_bytes_at_the_end": int(tot - torch.cuda.mem_get_info()[0]), "total_bytes": int(tot),
+                          "per_Mi_nodes_GiB_after_create": (tot - free) / (n / 2 ** 20) / 2 ** 30,
+                          "resident_planes_shard_0": shards[0].resident_planes() if "resident_planes" in lib.f else None,
+                          "note": "view planes get their memory as slots are handed out (every shard maps the same planes: the slot bookkeeping is replicated); a shard's rings are whole"},
     }
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     json.dump(out, open(args.out, "w"), indent=1)
     print(json.dumps({k: out[k] for k in ("ticks", "churn_events", "rumors", "rounds_to_99", "histogram", "model_bound_drops", "ops_dropped_no_slot", "wall_s",
-                                          "ms_per_cluster_tick_8_shards_taking_turns_incl_host", "device_memory", "exchange")}))
+                                          "ms_per_cluster_tick_8_shards_taking_turns_incl_host", "device_memory", "exchange", "failure_detector")}))
     for s in shards:
         s.close()
 
