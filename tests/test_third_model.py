@@ -16,7 +16,7 @@ from tests import _scenario as sc
 RING_EV, RING_Q, PG = 64, 32, 4   # packets of 4 pages = 16 records: they carry a node's whole queue, nothing waits for a turn
 
 
-def run_against_third_model(sim, n, fanout, ops, ticks, joined, rf=False):
+def run_against_third_model(sim, n, fanout, ops, ticks, joined, rf=False, pp_interval=0):
     nodes = [tm.Node(i, n, RING_EV, RING_Q, joined) for i in range(n)]
     by_tick = {}
     for o in ops:
@@ -54,6 +54,11 @@ def run_against_third_model(sim, n, fanout, ops, ticks, joined, rf=False):
                 x.leave()
             elif op == _ffi.OP_FORCE_LEAVE:
                 x.force_leave(a, bool(b))
+        # (0b) the tick's push-pull batch (SIMSPEC §2.10): both processes must be running; `a` merges first, then `b` merges a's updated state
+        for a, b in tm.push_pull_pairs(_ffi.DEFAULT_SEED, t, n, pp_interval):
+            if nodes[a].up and nodes[b].up:
+                nodes[a].merge_remote_state(nodes[b].local_state())
+                nodes[b].merge_remote_state(nodes[a].local_state())
         # (1) deliveries: slot 0 first, records in packet order
         for i, x in enumerate(nodes):
             if not x.up:
@@ -125,6 +130,30 @@ def test_oracle_matches_the_third_model(seed, n, fanout, joined, rf):
               flags=(_ffi.CF_BASELINE_JOINED if joined else 0) | (_ffi.CF_RANDOM_FANOUT if rf else 0))
     sim = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw))
     run_against_third_model(sim, n, fanout, _schedule(n, 70, seed, joined), 70, joined, rf)
+
+
+# push-pull anti-entropy (delegate.rs:386-554) in the third model: the batches' pairs drawn from the specification, local_state /
+# merge_remote_state written from the Rust source; packet loss on, so that there is something for a push-pull to repair
+PP_CASES = [(11, 48, 3, True, False, 12), (12, 64, 4, True, True, 8), (13, 33, 2, True, False, 16), (14, 40, 3, False, False, 8)]
+
+
+def _pp_kw(fanout, joined, rf, ppi):
+    return dict(fanout=fanout, view_slots=0, event_ring=RING_EV, query_ring=RING_Q, leave_delay=4, pkt_records=4 * PG, push_pull_interval=ppi, loss=0.15,
+                flags=(_ffi.CF_BASELINE_JOINED if joined else 0) | (_ffi.CF_RANDOM_FANOUT if rf else 0))
+
+
+@pytest.mark.parametrize("seed,n,fanout,joined,rf,ppi", PP_CASES)
+def test_oracle_matches_the_third_model_with_push_pull(seed, n, fanout, joined, rf, ppi):
+    sim = _ffi.Sim(load_oracle(), _ffi.make_config(n, **_pp_kw(fanout, joined, rf, ppi)))
+    assert any(tm.push_pull_pairs(_ffi.DEFAULT_SEED, t, n, ppi) for t in range(1, 70)), "the run must contain push-pull batches"
+    run_against_third_model(sim, n, fanout, _schedule(n, 70, seed, joined), 70, joined, rf, pp_interval=ppi)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,fanout,joined,rf,ppi", PP_CASES[:3])
+def test_hip_matches_the_third_model_with_push_pull(hiplib, seed, n, fanout, joined, rf, ppi):
+    sim = _ffi.Sim(hiplib, _ffi.make_config(n, **_pp_kw(fanout, joined, rf, ppi)))
+    run_against_third_model(sim, n, fanout, _schedule(n, 70, seed, joined), 70, joined, rf, pp_interval=ppi)
 
 
 @pytest.mark.gpu

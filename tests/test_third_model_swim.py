@@ -43,7 +43,7 @@ def _packets(sim, n, fanout):
 def run(sim, n, ops, ticks, joined, **kw):
     fanout = kw["fanout"]
     par = tms.Params(n, fanout, kw["probe_interval"], kw.get("suspicion_mult", 4), kw.get("suspicion_max_mult", 6), kw.get("indirect_checks", 3),
-                     kw.get("retransmit_mult", 4), kw.get("loss", 0.0), 4 * PG, kw.get("leave_delay", 30))
+                     kw.get("retransmit_mult", 4), kw.get("loss", 0.0), 4 * PG, kw.get("leave_delay", 30), push_pull_interval=kw.get("push_pull_interval", 0))
     model = tms.Cluster(par, RING_EV, RING_Q, joined)
     by_tick = {}
     for o in ops:
@@ -147,6 +147,27 @@ def test_oracle_matches_the_third_model_with_the_memberlist_layer_on(seed, n, fa
     sim = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw))
     kinds, model = run(sim, n, _schedule(n, 110, seed), 110, True, **kw)
     assert {tms.K_ALIVE, tms.K_SUSPECT, tms.K_DEAD} <= kinds, kinds   # the scenario did exercise refutations, suspicions and declarations
+
+
+# with memberlist's push-pull (B.6) and the serf delegate's merge_remote_state (delegate.rs:427-554) in the third model: a batch every few
+# ticks (the interval is scaled by log2 n and cut into eight classes), under loss — left members, suspects and dead nodes cross in the merges
+PP_CASES = [(21, 48, 3, 0.05, 2, 12), (22, 64, 4, 0.02, 3, 8), (23, 33, 3, 0.1, 1, 16)]
+
+
+@pytest.mark.parametrize("seed,n,fanout,loss,pi,ppi", PP_CASES)
+def test_oracle_matches_the_third_model_with_push_pull(seed, n, fanout, loss, pi, ppi):
+    kw = dict(KW, fanout=fanout, loss=loss, probe_interval=pi, push_pull_interval=ppi)
+    sim = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw))
+    kinds, model = run(sim, n, _schedule(n, 110, seed), 110, True, **kw)
+    assert {tms.K_ALIVE, tms.K_SUSPECT, tms.K_DEAD} <= kinds, kinds
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,fanout,loss,pi,ppi", PP_CASES[:2])
+def test_hip_matches_the_third_model_with_push_pull(hiplib, seed, n, fanout, loss, pi, ppi):
+    kw = dict(KW, fanout=fanout, loss=loss, probe_interval=pi, push_pull_interval=ppi)
+    sim = _ffi.Sim(hiplib, _ffi.make_config(n, **kw))
+    run(sim, n, _schedule(n, 110, seed), 110, True, **kw)
 
 
 @pytest.mark.gpu

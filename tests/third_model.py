@@ -47,6 +47,48 @@ def k_random_nodes(seed, tick, node, n, fanout):
     return chosen
 
 
+def push_pull_pairs(seed, tick, n, interval, groups=8):
+    """The pairs of the tick's push-pull batch as the simulator specifies them (DESIGN.md SIMSPEC §2.10; memberlist's pushPull picks
+    any peer, App. B.6): the interval is scaled by memberlist's pushPullScale (x (ceil(log2 n - 5) + 1) above 32 nodes) and cut into
+    `groups` classes; every step = interval / groups ticks one class of the tick's perfect matching {sigma^-1(2 p), sigma^-1(2 p + 1)}
+    synchronises, p = class, class + groups ... — sigma the tick's cycle-walking three-round multiply-xorshift bijection of the node ids,
+    its multipliers and offsets drawn from stream 1 of (seed, tick).  `a` merges first, then `b` merges a's updated state.
+    Written from the specification, not from the oracle's pp_pair_at."""
+    if not interval:
+        return []
+    mult = 1
+    if n > 32:
+        import math
+        mult = math.ceil(math.log2(n) - 5.0) + 1
+    step = max(1, interval * mult // groups)
+    if tick == 0 or tick % step:
+        return []
+    cls = (tick // step) % groups
+    bits = max(1, (n - 1).bit_length())
+    mask, shift = (1 << bits) - 1, (bits + 1) // 2
+    base = mix64(mix64(seed ^ ((1 * 0xD6E8FEB86659FD93) & M64)) ^ tick)
+    w = [mix64(base ^ r) for r in range(3)]
+    mul = [(x & 0xFFFFFFFF) | 1 for x in w]
+    add = [x >> 32 for x in w]
+    imul = [pow(m, -1, 1 << 32) for m in mul]
+
+    def inv(y):
+        while True:
+            y = (((y - add[2]) & 0xFFFFFFFF) * imul[2]) & mask
+            y ^= y >> shift
+            y = (((y - add[1]) & 0xFFFFFFFF) * imul[1]) & mask
+            y ^= y >> shift
+            y = (((y - add[0]) & 0xFFFFFFFF) * imul[0]) & mask
+            if y < n:
+                return y
+
+    pairs, p = [], cls
+    while 2 * p + 1 < n:
+        pairs.append((inv(2 * p), inv(2 * p + 1)))
+        p += groups
+    return pairs
+
+
 class Clock:
     """types/clock.rs:125-172"""
 
@@ -194,6 +236,29 @@ class Node:
             return
         if rb:
             self.rebroadcast.append((kind, key, ltime))
+
+    # ---- SerfDelegate::local_state, serf/delegate.rs:386-425: what a push-pull ships
+    def local_state(self):
+        return {"ltime": self.clock.time(), "event_ltime": self.event_clock.time(), "query_ltime": self.query_clock.time(),
+                "status_ltimes": {m: st[1] for m, st in self.members.items()},
+                "left_members": [m for m, st in self.members.items() if st[0] == LEFT],
+                "events": [None if b is None else (b[0], list(b[1])) for b in self.event_buf]}
+
+    # ---- SerfDelegate::merge_remote_state(is_join = false), serf/delegate.rs:427-554
+    def merge_remote_state(self, pp):
+        for clock, t in ((self.clock, pp["ltime"]), (self.event_clock, pp["event_ltime"]), (self.query_clock, pp["query_ltime"])):
+            if t > 0:
+                clock.witness(t - 1)                        # "no message with that clock has been sent yet"
+        for node in pp["left_members"]:                     # the left nodes first, one past their status time (:488-512)
+            if node in pp["status_ltimes"]:
+                self.handle_node_leave_intent(node, pp["status_ltimes"][node] + 1)
+        for node, ltime in pp["status_ltimes"].items():     # every other status time as a join intent (:515-526)
+            if node not in pp["left_members"]:
+                self.handle_node_join_intent(node, ltime)
+        for bucket in pp["events"]:                         # the event buffer, replayed (:540-552); nothing of this is rebroadcast
+            if bucket is not None:
+                for key in bucket[1]:
+                    self.handle_user_event(key, bucket[0])
 
     # ---- the user-facing calls
     def user_event(self, key):                              # serf/api.rs:241-299

@@ -40,8 +40,9 @@ class Params:
     """what Appendix B derives from the configuration"""
 
     def __init__(self, n, fanout, probe_interval, suspicion_mult=4, suspicion_max_mult=6, indirect_checks=3, retransmit_mult=4,
-                 loss=0.0, pkt_records=4, leave_delay=30, seed=None):
+                 loss=0.0, pkt_records=4, leave_delay=30, seed=None, push_pull_interval=0):
         from serf_amd import _ffi
+        self.pp_interval = push_pull_interval
         self.n, self.fanout, self.pi, self.ic, self.rmult = n, fanout, probe_interval, indirect_checks, retransmit_mult
         self.loss_u32 = min(0xFFFFFFFF, int(round(loss * 2 ** 32)))
         self.P, self.leave_delay = pkt_records, leave_delay
@@ -273,6 +274,24 @@ class SwimNode(tm.Node):
                 self.queue_broadcast(kind, fl, nb, key, lt)
         self.rebroadcast = []
 
+    # ---- B.6 push-pull: memberlist's mergeState, then SerfDelegate::merge_remote_state (third_model.Node) ----------------------------------
+    def push_pull_merge(self, remote):
+        """local <- remote.  memberlist hands every node state of the remote to the state machine (SIMSPEC §2.10): an alive node as an
+        alive message, a node that left as dead{from = the node}, a suspect or dead one as a suspicion raised by the merging node itself;
+        then the serf delegate merges the remote's local_state.  What the handlers queue is queued (a merge tells the cluster what it
+        learnt); of the serf half only a refutation is."""
+        for subj in sorted(remote.members):
+            st, inc = remote.ml[subj]
+            if st == ML_ALIVE:
+                self.alive(subj, inc, (K_ALIVE, 0, 64, subj, inc))
+            elif st == ML_LEFT:
+                self.dead(subj, inc, subj, (K_DEAD, 0, 32, subj, inc | (subj << 32)))
+            else:
+                self.suspect(subj, inc, self.me, (K_SUSPECT, 0, 32, subj, inc | (self.me << 32)))
+        self.rebroadcast = []
+        self.merge_remote_state(remote.local_state())
+        self._flush()
+
     def prune_sync(self):
         """erase_node! also forgets memberlist's node state in the simulator (waived / simplified)"""
         for s in list(self.ml):
@@ -343,6 +362,11 @@ class Cluster:
             x.tick = t
         for op, node, a, b in ops:
             self.apply(op, node, a, b)
+        # (0b) the tick's push-pull batch: both processes running; `a` merges first, then `b` merges a's updated state
+        for a, b in tm.push_pull_pairs(par.seed, t, par.n, par.pp_interval):
+            if self.up[a] and self.up[b]:
+                self.nodes[a].push_pull_merge(self.nodes[b])
+                self.nodes[b].push_pull_merge(self.nodes[a])
         # (1) deliveries: every packet addressed to the node, (sender, slot) order, records in packet order
         if self.flight is not None:
             rows = [[] for _ in range(par.n)]
