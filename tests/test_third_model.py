@@ -16,8 +16,14 @@ from tests import _scenario as sc
 RING_EV, RING_Q, PG = 64, 32, 4   # packets of 4 pages = 16 records: they carry a node's whole queue, nothing waits for a turn
 
 
-def run_against_third_model(sim, n, fanout, ops, ticks, joined, rf=False, pp_interval=0):
+def run_against_third_model(sim, n, fanout, ops, ticks, joined, rf=False, pp_interval=0, loss=0.0):
     nodes = [tm.Node(i, n, RING_EV, RING_Q, joined) for i in range(n)]
+    # the query path end to end: the origin's trackers and the responders' acks / responses, relays and loss included
+    trackers = tm.QueryTrackers(_ffi.DEFAULT_SEED, n, loss)
+    now = [0]
+    for x in nodes:
+        x.on_query = lambda me, qid, flags: trackers.respond(me, qid, flags, now[0], [y.up for y in nodes])
+    counted = 0
     by_tick = {}
     for o in ops:
         by_tick.setdefault(o[0], []).append(o)
@@ -33,8 +39,11 @@ def run_against_third_model(sim, n, fanout, ops, ticks, joined, rf=False, pp_int
                 for k, tgt in enumerate(tm.k_random_nodes(_ffi.DEFAULT_SEED, t - 1, snd, n, fanout)):
                     rows[tgt].append((snd, k))
         # (0) the tick's operations, in call order (SIMSPEC §2.1)
+        now[0] = t
         for _, op, node, a, b in by_tick.get(t, ()):
             x = nodes[node]
+            if op == _ffi.OP_QUERY:                         # base.rs:905-930: the QueryResponse is registered before the query is handled / sent
+                trackers.register(a, node, b, t)
             if op == _ffi.OP_CRASH:
                 x.up = False
             elif op == _ffi.OP_REVIVE:
@@ -81,6 +90,10 @@ def run_against_third_model(sim, n, fanout, ops, ticks, joined, rf=False, pp_int
         qr = sim.dump(_ffi.ARR_QRING).reshape(RING_Q, n)
         queue = sim.dump(_ffi.ARR_QUEUE).reshape(n, 16)
         assert int(rows["overflow"].sum()) == 0, f"tick {t}: a model bound was hit"
+        for qid in trackers.running:                        # what every running query's origin has counted so far, and whether it still listens
+            got = sim.query_status(qid)
+            assert (got[0], got[1], bool(got[2])) == trackers.status(qid, t + 1), f"tick {t} query {qid}: {got} != {trackers.status(qid, t + 1)}"
+            counted = max(counted, got[0] + got[1])
 
         for i, x in enumerate(nodes):
             w = f"tick {t} node {i}"
@@ -113,6 +126,7 @@ def run_against_third_model(sim, n, fanout, ops, ticks, joined, rf=False, pp_int
                 assert set(x.rebroadcast) <= live, f"{w}: asked for {set(x.rebroadcast) - live} and it is not queued"
             assert live <= approved[i], f"{w}: queued without the delegate's say: {live - approved[i]}"
             x.rebroadcast = []
+    return counted
 
 
 def _schedule(n, ticks, seed, joined):
@@ -146,14 +160,45 @@ def _pp_kw(fanout, joined, rf, ppi):
 def test_oracle_matches_the_third_model_with_push_pull(seed, n, fanout, joined, rf, ppi):
     sim = _ffi.Sim(load_oracle(), _ffi.make_config(n, **_pp_kw(fanout, joined, rf, ppi)))
     assert any(tm.push_pull_pairs(_ffi.DEFAULT_SEED, t, n, ppi) for t in range(1, 70)), "the run must contain push-pull batches"
-    run_against_third_model(sim, n, fanout, _schedule(n, 70, seed, joined), 70, joined, rf, pp_interval=ppi)
+    counted = run_against_third_model(sim, n, fanout, _schedule(n, 70, seed, joined), 70, joined, rf, pp_interval=ppi, loss=0.15)
+    assert counted > n // 2, "the runs must contain queries whose acks / responses reach the origin"
+
+
+def _origin_goes_down_schedule(n):
+    """queries whose origin crashes while the query is still spreading (what comes back after that is dropped: the origin is not
+    running), one of them back up before the spread is over, and one query issued by a node that is down (registered, never sent)"""
+    ops = []
+    for i, (origin, t0) in enumerate(((5, 2), (9, 6), (17, 11), (21, 15))):
+        ops.append((t0, _ffi.OP_QUERY, origin, 700 + i, _ffi.F_ACK | _ffi.F_RESPOND | ((i % 3) << 8)))
+        ops.append((t0 + 1 + i % 2, _ffi.OP_CRASH, origin, 0, 0))
+        if i == 1:
+            ops.append((t0 + 3, _ffi.OP_REVIVE, origin, 0, 0))
+    ops.append((20, _ffi.OP_QUERY, 5, 750, _ffi.F_ACK))          # node 5 is down
+    ops.append((22, _ffi.OP_USER_EVENT, 30, 760, 40))
+    ops.sort(key=lambda o: o[0])
+    return ops
+
+
+def test_oracle_matches_the_third_model_when_a_query_origin_goes_down():
+    n, fanout = 64, 2
+    kw = dict(_pp_kw(fanout, True, False, 0), loss=0.1)
+    sim = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw))
+    counted = run_against_third_model(sim, n, fanout, _origin_goes_down_schedule(n), 45, True, False, loss=0.1)
+    assert counted > 0
+
+
+@pytest.mark.gpu
+def test_hip_matches_the_third_model_when_a_query_origin_goes_down(hiplib):
+    n, fanout = 64, 2
+    sim = _ffi.Sim(hiplib, _ffi.make_config(n, **dict(_pp_kw(fanout, True, False, 0), loss=0.1)))
+    run_against_third_model(sim, n, fanout, _origin_goes_down_schedule(n), 45, True, False, loss=0.1)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,n,fanout,joined,rf,ppi", PP_CASES[:3])
 def test_hip_matches_the_third_model_with_push_pull(hiplib, seed, n, fanout, joined, rf, ppi):
     sim = _ffi.Sim(hiplib, _ffi.make_config(n, **_pp_kw(fanout, joined, rf, ppi)))
-    run_against_third_model(sim, n, fanout, _schedule(n, 70, seed, joined), 70, joined, rf, pp_interval=ppi)
+    run_against_third_model(sim, n, fanout, _schedule(n, 70, seed, joined), 70, joined, rf, pp_interval=ppi, loss=0.15)
 
 
 @pytest.mark.gpu

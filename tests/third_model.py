@@ -89,6 +89,60 @@ def push_pull_pairs(seed, tick, n, interval, groups=8):
     return pairs
 
 
+class QueryTrackers:
+    """The origin's side of a query (serf/base.rs:875-942 registers the QueryResponse before the query is sent; handle_query_response
+    base.rs:1158-1204 and QueryResponse::handle_query_response query.rs:240-303 count what comes back: nothing after the deadline or
+    when the origin is not running, one ack and one response per sender) and the responder's (base.rs:1075-1154: an ack when the query
+    asks for one, the response when the user code calls respond(); both straight to the origin over memberlist.send, subject to packet
+    loss; relay_response query.rs:523-601: up to relay_factor more tries through a random live member, two more legs each) — as the
+    simulator specifies the draws (DESIGN.md SIMSPEC: stream 6 of (seed, tick), keyed by the query id; lane = node x 64 + 32 for the
+    response; draw 0 = the direct leg, 1 + 3 r = relay r's choice, 2 + 3 r and 3 + 3 r = its two legs).  Written from the Rust sources and
+    the specification, not from the oracle's query_respond."""
+    ACK, RESPOND = 2, 4
+
+    def __init__(self, seed, n, loss):
+        self.seed, self.n = seed, n
+        self.loss_u32 = min(0xFFFFFFFF, int(round(loss * 2 ** 32)))
+        self.timeout = 16 * len(str(n))                      # query.rs:421-427: gossip_interval x query_timeout_mult (16) x ceil(log10(n + 1)) ticks
+        self.running = {}                                   # query id -> [origin, deadline, flags, ackers, responders]
+
+    def register(self, qid, origin, flags, tick):
+        self.running[qid] = [origin, tick + self.timeout, flags, set(), set()]
+
+    def respond(self, node, qid, flags, tick, up):
+        tr = self.running.get(qid)
+        if tr is None or not flags & (self.ACK | self.RESPOND):
+            return
+        origin, deadline, qflags = tr[0], tr[1], tr[2]
+        if tick > deadline or not up[origin]:
+            return
+        base = mix64(mix64(mix64(self.seed ^ ((6 * 0xD6E8FEB86659FD93) & M64)) ^ tick) ^ ((qid << 32) & M64))
+        relay = (qflags >> 8) & 7
+        if self.n < relay + 1:                              # "members.states.len() < relay_factor + 1": no relays
+            relay = 0
+        for which, bit in ((0, self.ACK), (1, self.RESPOND)):
+            if not flags & bit:
+                continue
+            lane = node * 64 + which * 32
+
+            def lost(i):
+                return bool(self.loss_u32) and (mix64(base ^ (lane + i)) >> 32) < self.loss_u32
+
+            ok = not lost(0)
+            for r in range(relay):
+                if ok:
+                    break
+                via = ((mix64(base ^ (lane + 1 + 3 * r)) >> 32) * self.n) >> 32
+                if via != node and up[via]:
+                    ok = not lost(2 + 3 * r) and not lost(3 + 3 * r)
+            if ok:
+                tr[3 + which].add(node)
+
+    def status(self, qid, tick_now):
+        tr = self.running[qid]
+        return len(tr[3]), len(tr[4]), tick_now <= tr[1]
+
+
 class Clock:
     """types/clock.rs:125-172"""
 
@@ -120,6 +174,7 @@ class Node:
         self.query_buf = [None] * ring_q                    # QueryCore.buffer: Option<Queries{ltime, query_ids}>
         self.event_min = self.query_min = 0
         self.rebroadcast = []                               # (kind, key, ltime) the delegate re-queues, in order
+        self.on_query = None                                # the responder's half (QueryTrackers.respond), when the harness models it
         if everybody_joined:                                # the simulator's pre-joined baseline: every member Alive at status_time 1,
             for s in range(n):                              # the own join at ltime 1 witnessed
                 self.members[s] = [ALIVE, 1]
@@ -220,6 +275,8 @@ class Node:
             seen[1].append(qid)                             # (the bucket keeps its old ltime: base.rs:1035)
         else:
             self.query_buf[idx] = [ltime, [qid]]
+        if self.on_query is not None:                       # base.rs:1075-1154: ack / respond (no filters in this model: every node processes)
+            self.on_query(self.me, qid, flags)
         return not (flags & NO_BROADCAST)
 
     # ---- SerfDelegate::notify_message, serf/delegate.rs:183-300: dispatch, re-queue the original message when told to
