@@ -43,7 +43,9 @@ def _packets(sim, n, fanout):
 def run(sim, n, ops, ticks, joined, **kw):
     fanout = kw["fanout"]
     par = tms.Params(n, fanout, kw["probe_interval"], kw.get("suspicion_mult", 4), kw.get("suspicion_max_mult", 6), kw.get("indirect_checks", 3),
-                     kw.get("retransmit_mult", 4), kw.get("loss", 0.0), 4 * PG, kw.get("leave_delay", 30), push_pull_interval=kw.get("push_pull_interval", 0))
+                     kw.get("retransmit_mult", 4), kw.get("loss", 0.0), 4 * PG, kw.get("leave_delay", 30), push_pull_interval=kw.get("push_pull_interval", 0),
+                     reap_interval=kw.get("reap_interval", 0), reconnect_timeout=kw.get("reconnect_timeout", 432000),
+                     tombstone_timeout=kw.get("tombstone_timeout", 432000), intent_timeout=kw.get("intent_timeout", 0))
     model = tms.Cluster(par, RING_EV, RING_Q, joined)
     by_tick = {}
     for o in ops:
@@ -160,6 +162,31 @@ def test_oracle_matches_the_third_model_with_push_pull(seed, n, fanout, loss, pi
     sim = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw))
     kinds, model = run(sim, n, _schedule(n, 110, seed), 110, True, **kw)
     assert {tms.K_ALIVE, tms.K_SUSPECT, tms.K_DEAD} <= kinds, kinds
+
+
+# with the Reaper (base.rs:483-610): failed members erased after the reconnect timeout, left ones after the tombstone timeout, buffered intents
+# after the intent timeout — short ones, so that members are reaped and come back inside the run
+REAP_CASES = [(31, 48, 3, 0.03, 2, 0), (32, 64, 4, 0.0, 3, 12), (33, 40, 3, 0.06, 1, 0)]
+REAP_KW = dict(reap_interval=4, reconnect_timeout=14, tombstone_timeout=22, intent_timeout=10)
+
+
+@pytest.mark.parametrize("seed,n,fanout,loss,pi,ppi", REAP_CASES)
+def test_oracle_matches_the_third_model_with_the_reaper(seed, n, fanout, loss, pi, ppi):
+    kw = dict(KW, fanout=fanout, loss=loss, probe_interval=pi, push_pull_interval=ppi, **REAP_KW)
+    sim = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw))
+    ev0 = len(sim.drain_events())
+    for w in range(0, n, 7):
+        sim.watch(w)
+    kinds, model = run(sim, n, _schedule(n, 110, seed), 110, True, **kw)
+    assert any(e[2] == _ffi.EV_REAP for e in sim.drain_events()), "the run must reap somebody"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,fanout,loss,pi,ppi", REAP_CASES[:2])
+def test_hip_matches_the_third_model_with_the_reaper(hiplib, seed, n, fanout, loss, pi, ppi):
+    kw = dict(KW, fanout=fanout, loss=loss, probe_interval=pi, push_pull_interval=ppi, **REAP_KW)
+    sim = _ffi.Sim(hiplib, _ffi.make_config(n, **kw))
+    run(sim, n, _schedule(n, 110, seed), 110, True, **kw)
 
 
 @pytest.mark.gpu

@@ -40,9 +40,11 @@ class Params:
     """what Appendix B derives from the configuration"""
 
     def __init__(self, n, fanout, probe_interval, suspicion_mult=4, suspicion_max_mult=6, indirect_checks=3, retransmit_mult=4,
-                 loss=0.0, pkt_records=4, leave_delay=30, seed=None, push_pull_interval=0):
+                 loss=0.0, pkt_records=4, leave_delay=30, seed=None, push_pull_interval=0, reap_interval=0, reconnect_timeout=432000,
+                 tombstone_timeout=432000, intent_timeout=0):
         from serf_amd import _ffi
         self.pp_interval = push_pull_interval
+        self.reap_interval, self.reconnect_timeout, self.tombstone_timeout, self.intent_timeout = reap_interval, reconnect_timeout, tombstone_timeout, intent_timeout
         self.n, self.fanout, self.pi, self.ic, self.rmult = n, fanout, probe_interval, indirect_checks, retransmit_mult
         self.loss_u32 = min(0xFFFFFFFF, int(round(loss * 2 ** 32)))
         self.P, self.leave_delay = pkt_records, leave_delay
@@ -72,6 +74,7 @@ class SwimNode(tm.Node):
         self.slots = []                                     # the timers in the order they are looked at: first free place (SIMSPEC §2.7)
         self.queue, self.next_id = [], 0                    # TransmitLimitedQueue: [class, transmits, length, id, kind, flags, key, val]
         self.tick = 0
+        self.left_at, self.intent_at = {}, {}               # MemberState.leave_time of the failed / left members, NodeIntent.wall_time (ticks)
 
     # ---- B.1 TransmitLimitedQueue, pooled (SIMSPEC §2.5: memberlist's queue < intents < queries < events) --------------------
     @staticmethod
@@ -106,10 +109,17 @@ class SwimNode(tm.Node):
         return out
 
     # ---- serf's side of memberlist's notifications -----------------------------------------------------------------------------
+    def upsert_intent(self, node, ty, ltime):               # serf/base.rs:1835-1866: a new or a newer intent is stamped with the time it came
+        changed = super().upsert_intent(node, ty, ltime)
+        if changed:
+            self.intent_at[node] = self.tick
+        return changed
+
     def handle_node_join(self, s):                          # serf/base.rs:1206-1334
         m = self.members.get(s)
         if m is not None:
             m[0] = ALIVE                                    # status_time stays
+            self.left_at.pop(s, None)                       # (out of failed_members / left_members)
             return
         status, lt = ALIVE, 0
         it = self.intents.get(s)
@@ -119,6 +129,7 @@ class SwimNode(tm.Node):
             status, lt = LEAVING, it[1]
         self.members[s] = [status, lt]
         self.intents.pop(s, None)                           # (one entry per subject in the simulator: a member has no buffered intent)
+        self.intent_at.pop(s, None)
 
     def handle_node_leave(self, s):                         # serf/base.rs:1375-1440
         m = self.members.get(s)
@@ -126,8 +137,30 @@ class SwimNode(tm.Node):
             return
         if m[0] == LEAVING:
             m[0] = LEFT
+            self.left_at[s] = self.tick                     # leave_time (base.rs:1384-1402): what the Reaper measures against
         elif m[0] == ALIVE:
             m[0] = FAILED
+            self.left_at[s] = self.tick
+
+    # ---- Reaper::run, serf/base.rs:483-610 (reap! 521-553; reap_intents 1817-1822): every reap_interval ticks ----------------------------
+    def reap(self):
+        par = self.par
+        for s in sorted(self.members):
+            st = self.members[s][0]
+            if st == FAILED:                                # a failed member (a leave intent may have made it LEFT since: then the tombstone timeout counts, from the same leave_time)
+                timeout = par.reconnect_timeout
+            elif st == LEFT:
+                timeout = par.tombstone_timeout
+            else:
+                continue
+            if self.tick - self.left_at[s] > timeout:       # erase_node!: out of the member table altogether
+                del self.members[s]
+                del self.left_at[s]
+        if par.intent_timeout:
+            for s in [s for s, at in self.intent_at.items() if s in self.intents and self.tick - at > par.intent_timeout]:
+                del self.intents[s]
+                del self.intent_at[s]
+        self.prune_sync()
 
     # ---- B.4 ------------------------------------------------------------------------------------------------------------------
     def refute(self, accused_inc, flags=0):
@@ -389,6 +422,8 @@ class Cluster:
                 if par.pi:
                     x.run_timers()
                     x.probe(self.up)
+                if par.reap_interval and (t + (i >> 6)) % par.reap_interval == 0:   # (the phase is shared by a group of 64 nodes, like the probe's)
+                    x.reap()
                 targets = tm.k_random_nodes(par.seed, t, i, par.n, min(par.fanout, par.n - 1))
                 for k in range(min(par.fanout, par.n - 1)):
                     recs = x.get_broadcasts()
