@@ -45,7 +45,8 @@ def run(sim, n, ops, ticks, joined, **kw):
     par = tms.Params(n, fanout, kw["probe_interval"], kw.get("suspicion_mult", 4), kw.get("suspicion_max_mult", 6), kw.get("indirect_checks", 3),
                      kw.get("retransmit_mult", 4), kw.get("loss", 0.0), 4 * PG, kw.get("leave_delay", 30), push_pull_interval=kw.get("push_pull_interval", 0),
                      reap_interval=kw.get("reap_interval", 0), reconnect_timeout=kw.get("reconnect_timeout", 432000),
-                     tombstone_timeout=kw.get("tombstone_timeout", 432000), intent_timeout=kw.get("intent_timeout", 0))
+                     tombstone_timeout=kw.get("tombstone_timeout", 432000), intent_timeout=kw.get("intent_timeout", 0),
+                     queue_check_interval=kw.get("queue_check_interval", 0), max_queue_depth=kw.get("max_queue_depth", 4096))
     model = tms.Cluster(par, RING_EV, RING_Q, joined)
     by_tick = {}
     for o in ops:
@@ -138,6 +139,19 @@ def _schedule(n, ticks, seed):
     return ops
 
 
+def _burst_schedule(n, ticks, seed):
+    """the schedule above plus bursts of user events and queries from different nodes in one tick: queues that hold four and more of serf's messages"""
+    ops = _schedule(n, ticks, seed)
+    rng = np.random.default_rng(seed + 1000)
+    key = 5000
+    for t in range(6, ticks - 30, 9):
+        for _ in range(5):
+            key += 1
+            ops.append((t, _ffi.OP_USER_EVENT if key % 3 else _ffi.OP_QUERY, int(rng.integers(0, n)), key, 40 if key % 3 else 0))
+    ops.sort(key=lambda o: o[0])
+    return ops
+
+
 CASES = [(11, 48, 3, 0.03, 2), (12, 64, 4, 0.0, 3), (13, 33, 3, 0.08, 1), (14, 24, 2, 0.02, 2)]
 KW = dict(view_slots=0, event_ring=RING_EV, query_ring=RING_Q, leave_delay=4, pkt_records=4 * PG, suspicion_mult=3, suspicion_max_mult=2,
           flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT)
@@ -179,6 +193,38 @@ def test_oracle_matches_the_third_model_with_the_reaper(seed, n, fanout, loss, p
         sim.watch(w)
     kinds, model = run(sim, n, _schedule(n, 110, seed), 110, True, **kw)
     assert any(e[2] == _ffi.EV_REAP for e in sim.drain_events()), "the run must reap somebody"
+
+
+# with the QueueChecker (base.rs:683-740) at a depth that bites: a queue of serf's that holds more than two messages is pruned to the two that drain first
+QC_KW = dict(queue_check_interval=3, max_queue_depth=2, min_queue_depth=0)
+
+
+@pytest.mark.parametrize("seed,n,fanout,loss,pi,ppi", [(41, 48, 3, 0.02, 2, 0), (42, 64, 2, 0.0, 3, 0)])
+def test_oracle_matches_the_third_model_with_the_queue_checker(seed, n, fanout, loss, pi, ppi):
+    kw = dict(KW, fanout=fanout, loss=loss, probe_interval=pi, push_pull_interval=ppi, **QC_KW, **REAP_KW)
+    sim = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw))
+    pruned = [0]
+    orig = tms.SwimNode.queue_check
+
+    def counting(self):
+        before = len(self.queue)
+        orig(self)
+        pruned[0] += before - len(self.queue)
+
+    tms.SwimNode.queue_check = counting
+    try:
+        run(sim, n, _burst_schedule(n, 110, seed), 110, True, **kw)
+    finally:
+        tms.SwimNode.queue_check = orig
+    assert pruned[0] > 0, "the checker must have pruned something"
+
+
+@pytest.mark.gpu
+def test_hip_matches_the_third_model_with_the_queue_checker(hiplib):
+    seed, n, fanout, loss, pi = 41, 48, 3, 0.02, 2
+    kw = dict(KW, fanout=fanout, loss=loss, probe_interval=pi, **QC_KW, **REAP_KW)
+    sim = _ffi.Sim(hiplib, _ffi.make_config(n, **kw))
+    run(sim, n, _burst_schedule(n, 110, seed), 110, True, **kw)
 
 
 @pytest.mark.gpu

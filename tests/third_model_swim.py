@@ -41,10 +41,11 @@ class Params:
 
     def __init__(self, n, fanout, probe_interval, suspicion_mult=4, suspicion_max_mult=6, indirect_checks=3, retransmit_mult=4,
                  loss=0.0, pkt_records=4, leave_delay=30, seed=None, push_pull_interval=0, reap_interval=0, reconnect_timeout=432000,
-                 tombstone_timeout=432000, intent_timeout=0):
+                 tombstone_timeout=432000, intent_timeout=0, queue_check_interval=0, max_queue_depth=4096):
         from serf_amd import _ffi
         self.pp_interval = push_pull_interval
         self.reap_interval, self.reconnect_timeout, self.tombstone_timeout, self.intent_timeout = reap_interval, reconnect_timeout, tombstone_timeout, intent_timeout
+        self.queue_check_interval, self.max_queue_depth = queue_check_interval, max_queue_depth
         self.n, self.fanout, self.pi, self.ic, self.rmult = n, fanout, probe_interval, indirect_checks, retransmit_mult
         self.loss_u32 = min(0xFFFFFFFF, int(round(loss * 2 ** 32)))
         self.P, self.leave_delay = pkt_records, leave_delay
@@ -141,6 +142,14 @@ class SwimNode(tm.Node):
         elif m[0] == ALIVE:
             m[0] = FAILED
             self.left_at[s] = self.tick
+
+    # ---- QueueChecker::run, serf/base.rs:683-740: `if numq >= max { queue.prune(max) }` for each of serf's three queues (intents, queries,
+    # events: classes 1 - 3 of the pooled queue); memberlist's TransmitLimitedQueue::prune keeps the `max` entries that drain first
+    def queue_check(self):
+        for cls in (1, 2, 3):
+            mine = [e for e in self.drain_order() if e[0] == cls]
+            for e in mine[self.par.max_queue_depth:]:
+                self.queue.remove(e)
 
     # ---- Reaper::run, serf/base.rs:483-610 (reap! 521-553; reap_intents 1817-1822): every reap_interval ticks ----------------------------
     def reap(self):
@@ -424,6 +433,8 @@ class Cluster:
                     x.probe(self.up)
                 if par.reap_interval and (t + (i >> 6)) % par.reap_interval == 0:   # (the phase is shared by a group of 64 nodes, like the probe's)
                     x.reap()
+                if par.queue_check_interval and (t + (i >> 6)) % par.queue_check_interval == 0:
+                    x.queue_check()
                 targets = tm.k_random_nodes(par.seed, t, i, par.n, min(par.fanout, par.n - 1))
                 for k in range(min(par.fanout, par.n - 1)):
                     recs = x.get_broadcasts()
