@@ -46,7 +46,8 @@ def run(sim, n, ops, ticks, joined, **kw):
                      kw.get("retransmit_mult", 4), kw.get("loss", 0.0), 4 * PG, kw.get("leave_delay", 30), push_pull_interval=kw.get("push_pull_interval", 0),
                      reap_interval=kw.get("reap_interval", 0), reconnect_timeout=kw.get("reconnect_timeout", 432000),
                      tombstone_timeout=kw.get("tombstone_timeout", 432000), intent_timeout=kw.get("intent_timeout", 0),
-                     queue_check_interval=kw.get("queue_check_interval", 0), max_queue_depth=kw.get("max_queue_depth", 4096))
+                     queue_check_interval=kw.get("queue_check_interval", 0), max_queue_depth=kw.get("max_queue_depth", 4096),
+                     reconnect_interval=kw.get("reconnect_interval", 0))
     model = tms.Cluster(par, RING_EV, RING_Q, joined)
     by_tick = {}
     for o in ops:
@@ -193,6 +194,53 @@ def test_oracle_matches_the_third_model_with_the_reaper(seed, n, fanout, loss, p
         sim.watch(w)
     kinds, model = run(sim, n, _schedule(n, 110, seed), 110, True, **kw)
     assert any(e[2] == _ffi.EV_REAP for e in sim.drain_events()), "the run must reap somebody"
+
+
+# with the Reconnector (base.rs:612-681): nodes that crash and silently resume stay failed in the others' tables until somebody's reconnect attempt
+# (a push-pull pair of its own, two ticks after the draw) or a push-pull batch reaches them
+def _resume_schedule(n, ticks, seed):
+    rng = np.random.default_rng(seed)
+    ops, key = [], 100
+    for i, x in enumerate(rng.choice(n, 6, replace=False).tolist()):
+        ops.append((1 + i, _ffi.OP_CRASH, x, 0, 0))
+        if i % 3 != 2:
+            ops.append((40 + 5 * i, _ffi.OP_REVIVE, x, 0, 0))
+    for t in range(3, ticks - 25, 4):
+        key += 1
+        ops.append((t, _ffi.OP_USER_EVENT, int(rng.integers(0, n)), key, 40))
+    ops.sort(key=lambda o: o[0])
+    return ops
+
+
+RC_KW = dict(reconnect_interval=3, suspicion_mult=3, suspicion_max_mult=2)
+
+
+@pytest.mark.parametrize("seed,n,fanout,loss,pi,ppi", [(51, 48, 3, 0.02, 2, 0), (52, 64, 4, 0.0, 2, 16)])
+def test_oracle_matches_the_third_model_with_the_reconnector(seed, n, fanout, loss, pi, ppi):
+    kw = dict(KW, fanout=fanout, loss=loss, probe_interval=pi, push_pull_interval=ppi, **RC_KW)
+    sim = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw))
+    made = [0]
+    orig = tms.SwimNode.reconnect
+
+    def counting(self):
+        tgt = orig(self)
+        made[0] += tgt is not None
+        return tgt
+
+    tms.SwimNode.reconnect = counting
+    try:
+        run(sim, n, _resume_schedule(n, 120, seed), 120, True, **kw)
+    finally:
+        tms.SwimNode.reconnect = orig
+    assert made[0] > 3, "the run must contain reconnect attempts"
+
+
+@pytest.mark.gpu
+def test_hip_matches_the_third_model_with_the_reconnector(hiplib):
+    seed, n, fanout, loss, pi, ppi = 51, 48, 3, 0.02, 2, 0
+    kw = dict(KW, fanout=fanout, loss=loss, probe_interval=pi, push_pull_interval=ppi, **RC_KW)
+    sim = _ffi.Sim(hiplib, _ffi.make_config(n, **kw))
+    run(sim, n, _resume_schedule(n, 120, seed), 120, True, **kw)
 
 
 # with the QueueChecker (base.rs:683-740) at a depth that bites: a queue of serf's that holds more than two messages is pruned to the two that drain first

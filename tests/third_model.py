@@ -47,6 +47,18 @@ def k_random_nodes(seed, tick, node, n, fanout):
     return chosen
 
 
+def push_pull_batch_tick(tick, n, interval, groups=8):
+    """is `tick` one of the ticks a class of the push-pull matching synchronises in (see push_pull_pairs)"""
+    if not interval:
+        return False
+    mult = 1
+    if n > 32:
+        import math
+        mult = math.ceil(math.log2(n) - 5.0) + 1
+    step = max(1, interval * mult // groups)
+    return tick > 0 and tick % step == 0
+
+
 def push_pull_pairs(seed, tick, n, interval, groups=8):
     """The pairs of the tick's push-pull batch as the simulator specifies them (DESIGN.md SIMSPEC §2.10; memberlist's pushPull picks
     any peer, App. B.6): the interval is scaled by memberlist's pushPullScale (x (ceil(log2 n - 5) + 1) above 32 nodes) and cut into

@@ -41,11 +41,12 @@ class Params:
 
     def __init__(self, n, fanout, probe_interval, suspicion_mult=4, suspicion_max_mult=6, indirect_checks=3, retransmit_mult=4,
                  loss=0.0, pkt_records=4, leave_delay=30, seed=None, push_pull_interval=0, reap_interval=0, reconnect_timeout=432000,
-                 tombstone_timeout=432000, intent_timeout=0, queue_check_interval=0, max_queue_depth=4096):
+                 tombstone_timeout=432000, intent_timeout=0, queue_check_interval=0, max_queue_depth=4096, reconnect_interval=0):
         from serf_amd import _ffi
         self.pp_interval = push_pull_interval
         self.reap_interval, self.reconnect_timeout, self.tombstone_timeout, self.intent_timeout = reap_interval, reconnect_timeout, tombstone_timeout, intent_timeout
         self.queue_check_interval, self.max_queue_depth = queue_check_interval, max_queue_depth
+        self.reconnect_interval = reconnect_interval if probe_interval else 0
         self.n, self.fanout, self.pi, self.ic, self.rmult = n, fanout, probe_interval, indirect_checks, retransmit_mult
         self.loss_u32 = min(0xFFFFFFFF, int(round(loss * 2 ** 32)))
         self.P, self.leave_delay = pkt_records, leave_delay
@@ -142,6 +143,25 @@ class SwimNode(tm.Node):
         elif m[0] == ALIVE:
             m[0] = FAILED
             self.left_at[s] = self.tick
+
+    # ---- Reconnector::run, serf/base.rs:612-681: every reconnect_interval, when there are failed members: with probability failed / alive
+    # pick one of them uniformly and memberlist.join it — a push-pull with that node, if it answers.  The simulator (SIMSPEC §2.8): the draws
+    # are numbers 30 and 31 of the node's probe stream; the attempt goes on the tick's request list and runs two ticks later as a push-pull pair
+    def reconnect(self):
+        par = self.par
+        if not par.reconnect_interval or (self.tick + (self.me >> 6)) % par.reconnect_interval:
+            return None
+        failed = [s for s in sorted(self.members) if self.members[s][0] == FAILED]
+        if not failed:
+            return None                                     # base.rs:640-642
+        n_left = sum(1 for m in self.members.values() if m[0] == LEFT)
+        alive = max(1, len(self.members) - len(failed) - n_left)   # base.rs:645-651
+        base = rng_base(par.seed, STREAM_PROBE, self.tick)
+        r = mix64(base ^ ((self.me * 32 + 30) & M64)) >> 32
+        if r * alive > (len(failed) << 32):                 # "forgoing reconnect for random throttling"
+            return None
+        target = failed[((mix64(base ^ ((self.me * 32 + 31) & M64)) >> 32) * len(failed)) >> 32]
+        return None if target == self.me else target
 
     # ---- QueueChecker::run, serf/base.rs:683-740: `if numq >= max { queue.prune(max) }` for each of serf's three queues (intents, queries,
     # events: classes 1 - 3 of the pooled queue); memberlist's TransmitLimitedQueue::prune keeps the `max` entries that drain first
@@ -351,6 +371,8 @@ class Cluster:
         self.up = [True] * par.n
         self.tick = 0
         self.flight = None                                  # packets sent during the last tick: [sender][slot] -> list of records (None: not sent)
+        self.rc_made = {}                                   # tick -> the reconnect attempts (initiator, target) made in it, by initiator
+        self.rc_postponed = []                              # attempts that found a partner busy (or a batch tick): next tick, first
 
     def apply(self, op, node, a, b):
         from serf_amd import _ffi
@@ -404,6 +426,23 @@ class Cluster:
             x.tick = t
         for op, node, a, b in ops:
             self.apply(op, node, a, b)
+        # (0a) the reconnect attempts due now — postponed ones first, then the ones made two ticks ago — run as push-pull pairs of their own,
+        # the initiator merging first; on a batch tick, or when one of the two is already in a pair of this tick, an attempt waits a tick
+        due = self.rc_postponed + sorted(self.rc_made.pop(t - 2, []))
+        self.rc_postponed = []
+        batch = bool(par.pp_interval) and tm.push_pull_batch_tick(t, par.n, par.pp_interval)
+        taken, pairs = set(), []
+        for a, b in due:
+            if a == b or not self.up[a] or not self.up[b]:
+                continue
+            if batch or a in taken or b in taken:
+                self.rc_postponed.append((a, b))
+                continue
+            taken.update((a, b))
+            pairs.append((a, b))
+        for a, b in pairs:
+            self.nodes[a].push_pull_merge(self.nodes[b])
+            self.nodes[b].push_pull_merge(self.nodes[a])
         # (0b) the tick's push-pull batch: both processes running; `a` merges first, then `b` merges a's updated state
         for a, b in tm.push_pull_pairs(par.seed, t, par.n, par.pp_interval):
             if self.up[a] and self.up[b]:
@@ -433,6 +472,9 @@ class Cluster:
                     x.probe(self.up)
                 if par.reap_interval and (t + (i >> 6)) % par.reap_interval == 0:   # (the phase is shared by a group of 64 nodes, like the probe's)
                     x.reap()
+                target = x.reconnect()
+                if target is not None:
+                    self.rc_made.setdefault(t, []).append((i, target))
                 if par.queue_check_interval and (t + (i >> 6)) % par.queue_check_interval == 0:
                     x.queue_check()
                 targets = tm.k_random_nodes(par.seed, t, i, par.n, min(par.fanout, par.n - 1))
