@@ -47,7 +47,8 @@ def run(sim, n, ops, ticks, joined, **kw):
                      reap_interval=kw.get("reap_interval", 0), reconnect_timeout=kw.get("reconnect_timeout", 432000),
                      tombstone_timeout=kw.get("tombstone_timeout", 432000), intent_timeout=kw.get("intent_timeout", 0),
                      queue_check_interval=kw.get("queue_check_interval", 0), max_queue_depth=kw.get("max_queue_depth", 4096),
-                     reconnect_interval=kw.get("reconnect_interval", 0))
+                     reconnect_interval=kw.get("reconnect_interval", 0), awareness_probe=kw.get("awareness_probe", False),
+                     tcp_fallback=kw.get("tcp_fallback", False), nacks=kw.get("nacks", False), gossip_to_the_dead=kw.get("gossip_to_the_dead", 0))
     model = tms.Cluster(par, RING_EV, RING_Q, joined)
     by_tick = {}
     for o in ops:
@@ -241,6 +242,26 @@ def test_hip_matches_the_third_model_with_the_reconnector(hiplib):
     kw = dict(KW, fanout=fanout, loss=loss, probe_interval=pi, push_pull_interval=ppi, **RC_KW)
     sim = _ffi.Sim(hiplib, _ffi.make_config(n, **kw))
     run(sim, n, _resume_schedule(n, 120, seed), 120, True, **kw)
+
+
+# memberlist's behaviours behind switches: awareness-scaled probing, the stream-transport fallback ping, nacks, gossip_to_the_dead_time
+SWITCH_CASES = [(61, 48, 3, 0.05, 2, dict(awareness_probe=True)), (62, 48, 3, 0.06, 2, dict(nacks=True)), (63, 64, 4, 0.1, 2, dict(tcp_fallback=True, nacks=True)),
+                (64, 48, 3, 0.03, 2, dict(gossip_to_the_dead=6, **RC_KW)), (65, 40, 2, 0.05, 2, dict(awareness_probe=True, tcp_fallback=True, nacks=True, gossip_to_the_dead=10))]
+
+
+@pytest.mark.parametrize("seed,n,fanout,loss,pi,sw", SWITCH_CASES)
+def test_oracle_matches_the_third_model_with_the_memberlist_switches(seed, n, fanout, loss, pi, sw):
+    kw = dict(KW, fanout=fanout, loss=loss, probe_interval=pi, **sw)
+    sim = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw))
+    run(sim, n, _resume_schedule(n, 110, seed) if "gossip_to_the_dead" in sw else _schedule(n, 110, seed), 110, True, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,fanout,loss,pi,sw", [SWITCH_CASES[2], SWITCH_CASES[4]])
+def test_hip_matches_the_third_model_with_the_memberlist_switches(hiplib, seed, n, fanout, loss, pi, sw):
+    kw = dict(KW, fanout=fanout, loss=loss, probe_interval=pi, **sw)
+    sim = _ffi.Sim(hiplib, _ffi.make_config(n, **kw))
+    run(sim, n, _resume_schedule(n, 110, seed) if "gossip_to_the_dead" in sw else _schedule(n, 110, seed), 110, True, **kw)
 
 
 # with the QueueChecker (base.rs:683-740) at a depth that bites: a queue of serf's that holds more than two messages is pruned to the two that drain first

@@ -41,12 +41,16 @@ class Params:
 
     def __init__(self, n, fanout, probe_interval, suspicion_mult=4, suspicion_max_mult=6, indirect_checks=3, retransmit_mult=4,
                  loss=0.0, pkt_records=4, leave_delay=30, seed=None, push_pull_interval=0, reap_interval=0, reconnect_timeout=432000,
-                 tombstone_timeout=432000, intent_timeout=0, queue_check_interval=0, max_queue_depth=4096, reconnect_interval=0):
+                 tombstone_timeout=432000, intent_timeout=0, queue_check_interval=0, max_queue_depth=4096, reconnect_interval=0,
+                 awareness_probe=False, tcp_fallback=False, nacks=False, gossip_to_the_dead=0):
         from serf_amd import _ffi
         self.pp_interval = push_pull_interval
         self.reap_interval, self.reconnect_timeout, self.tombstone_timeout, self.intent_timeout = reap_interval, reconnect_timeout, tombstone_timeout, intent_timeout
         self.queue_check_interval, self.max_queue_depth = queue_check_interval, max_queue_depth
         self.reconnect_interval = reconnect_interval if probe_interval else 0
+        # memberlist behaviours behind switches (App. B.3, UPSTREAM-RECALL of state.go): the probe interval scaled by the health score, the fallback
+        # ping over the stream transport, nacks from the relays, gossip_to_the_dead_time
+        self.awareness_probe, self.tcp_fallback, self.nacks, self.gttd = awareness_probe, tcp_fallback, nacks, gossip_to_the_dead
         self.n, self.fanout, self.pi, self.ic, self.rmult = n, fanout, probe_interval, indirect_checks, retransmit_mult
         self.loss_u32 = min(0xFFFFFFFF, int(round(loss * 2 ** 32)))
         self.P, self.leave_delay = pkt_records, leave_delay
@@ -278,6 +282,8 @@ class SwimNode(tm.Node):
         par = self.par
         if par.n < 2 or (self.tick + (self.me >> 6)) % par.pi:
             return
+        if par.awareness_probe and ((self.tick + (self.me >> 6)) // par.pi) % (self.awareness + 1):
+            return                                          # probeNode: the interval is (score + 1) x the configured one
         base = rng_base(par.seed, STREAM_PROBE, self.tick)
 
         def draw(j):
@@ -305,10 +311,23 @@ class SwimNode(tm.Node):
                 if r == self.me or r == t or not up[r]:
                     continue
                 ok = not lost(3 + 5 * j + 1) and not lost(3 + 5 * j + 2) and not lost(3 + 5 * j + 3) and not lost(3 + 5 * j + 4)
+            if not ok and par.tcp_fallback:                 # the fallback ping over the stream transport reaches a running node: "didContact"
+                ok = True
         if ok:
             self.awareness = max(0, self.awareness - 1)
             return
-        self.awareness = min(MAX_AWARENESS, self.awareness + 1)
+        delta = 1
+        if par.nacks:                                       # awarenessDelta = nacks expected - nacks received (no relay asked: + 1)
+            expected = got = 0
+            for j in range(min(par.ic, 4)):
+                r = below(draw(3 + 5 * j), par.n)
+                if r == self.me or r == t:
+                    continue
+                expected += 1
+                if up[r] and not lost(3 + 5 * j + 1) and not lost(3 + 5 * j + 4):
+                    got += 1
+            delta = expected - got if expected else 1
+        self.awareness = max(0, min(MAX_AWARENESS, self.awareness + delta))
         self.suspect(t, cur[1], self.me, (K_SUSPECT, 0, 32, t, cur[1] | (self.me << 32)))
 
     # ---- SerfDelegate::notify_message with the original message re-queued unchanged (delegate.rs:294-300) ----------------------------
@@ -448,6 +467,17 @@ class Cluster:
             if self.up[a] and self.up[b]:
                 self.nodes[a].push_pull_merge(self.nodes[b])
                 self.nodes[b].push_pull_merge(self.nodes[a])
+        # gossip_to_the_dead_time: whom a node does not gossip to this tick — a member it has believed dead (or gone) for longer than that,
+        # by its view as the tick's deliveries begin
+        skip = []
+        for i, x in enumerate(self.nodes):
+            sk = set()
+            if par.gttd:
+                for k, tgt in enumerate(tm.k_random_nodes(par.seed, t, i, par.n, min(par.fanout, par.n - 1))):
+                    st = x.ml.get(tgt)
+                    if tgt in x.members and st is not None and st[0] in (ML_DEAD, ML_LEFT) and t - x.left_at.get(tgt, t) > par.gttd:
+                        sk.add(k)
+            skip.append(sk)
         # (1) deliveries: every packet addressed to the node, (sender, slot) order, records in packet order
         if self.flight is not None:
             rows = [[] for _ in range(par.n)]
@@ -481,7 +511,7 @@ class Cluster:
                 for k in range(min(par.fanout, par.n - 1)):
                     recs = x.get_broadcasts()
                     lost = bool(par.loss_u32) and (mix64(loss_base ^ ((i * 4 + k) & M64)) >> 32) < par.loss_u32
-                    if k < len(targets) and not lost:
+                    if k < len(targets) and not lost and k not in skip[i]:
                         pk[k] = recs
             flight.append(pk)
         self.flight = flight
