@@ -245,6 +245,34 @@ def test_hip_matches_the_third_model_with_the_reconnector(hiplib):
     run(sim, n, _resume_schedule(n, 120, seed), 120, True, **kw)
 
 
+def _tags_schedule(n, ticks, seed):
+    """Serf::set_tags calls next to the usual churn: a node's tags change while it is alive, while it is suspected, right before it crashes"""
+    ops = _schedule(n, ticks, seed)
+    rng = np.random.default_rng(seed + 7)
+    for t in range(4, ticks - 30, 6):
+        ops.append((t, _ffi.OP_SET_TAGS, int(rng.integers(0, n)), int(rng.integers(0, 4)), 0))
+    ops.sort(key=lambda o: o[0])
+    return ops
+
+
+@pytest.mark.parametrize("seed,n,fanout,loss,pi", [(81, 48, 3, 0.03, 2), (82, 64, 4, 0.0, 3)])
+def test_oracle_matches_the_third_model_with_set_tags(seed, n, fanout, loss, pi):
+    kw = dict(KW, fanout=fanout, loss=loss, probe_interval=pi)
+    sim = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw))
+    for w in range(0, n, 5):
+        sim.watch(w)
+    run(sim, n, _tags_schedule(n, 110, seed), 110, True, **kw)
+    assert any(e[2] == _ffi.EV_UPDATE for e in sim.drain_events()), "somebody must have seen a member update"
+
+
+@pytest.mark.gpu
+def test_hip_matches_the_third_model_with_set_tags(hiplib):
+    seed, n, fanout, loss, pi = 81, 48, 3, 0.03, 2
+    kw = dict(KW, fanout=fanout, loss=loss, probe_interval=pi)
+    sim = _ffi.Sim(hiplib, _ffi.make_config(n, **kw))
+    run(sim, n, _tags_schedule(n, 110, seed), 110, True, **kw)
+
+
 def _light_schedule(n, ticks, seed):
     """a load the 16-slot queue carries with packets of 4 records: a rumour every few ticks, two crashes (one re-joins), one graceful leave"""
     rng = np.random.default_rng(seed)

@@ -22,6 +22,7 @@ PKT_UNITS = 1400 // 16                                      # the UDP payload bu
 MAX_AWARENESS = 8                                           # awareness_max_multiplier (App. B defaults)
 STREAM_LOSS, STREAM_PROBE = 4, 5                            # PRNG streams (SIMSPEC §2.2)
 F_PRUNE = 1
+F_META = 1                                                  # ALIVE: the node's tags changed with this incarnation
 
 
 def units(nbytes):
@@ -421,6 +422,10 @@ class Cluster:
                 x.state = S_LEFT
         elif not x.up:
             return
+        elif op == _ffi.OP_SET_TAGS:                        # Serf::set_tags (api.rs:219-235): memberlist.update_node — the next incarnation and an
+            if self.par.pi:                                 # alive broadcast whose meta differs (the receivers' notify_update, base.rs:1574-1625)
+                x.refute(x.inc, F_META)
+                x.awareness = max(0, x.awareness - 1)       # not an accusation
         elif op == _ffi.OP_USER_EVENT:
             x.rebroadcast = []
             x.user_event(a)
