@@ -273,6 +273,31 @@ def test_hip_matches_the_third_model_with_set_tags(hiplib):
     run(sim, n, _tags_schedule(n, 110, seed), 110, True, **kw)
 
 
+# THE BENCHMARK'S configuration tuple (bench.workload: fan-out 4, memberlist's kRandomNodes, probe interval 5, push-pull 150 x the log2 scaling,
+# Reaper every 75, QueueChecker every 150, packets of 4 records, every other knob at its default) and its own schedule generator (the same mix, evenly
+# spaced), on clusters the third model can follow: 64 and 100 nodes, 220 ticks.  (Dense views and rings of 64 / 32: the model is unbounded.)
+@pytest.mark.parametrize("n,rate", [(64, 0.25), (100, 0.3)])
+def test_oracle_matches_the_third_model_on_the_benchmarks_configuration(n, rate):
+    from serf_amd import workload as wl
+    kw = dict(fanout=4, view_slots=0, event_ring=RING_EV, query_ring=RING_Q, probe_interval=5, push_pull_interval=150, reap_interval=75, queue_check_interval=150,
+              flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT)
+    ops = wl.schedule(n, 190, rate=rate, seed=3, mix=wl.BENCH_MIX, max_member_subjects=n // 2, even=True)
+    sim = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw))
+    kinds, model = run(sim, n, ops, 220, True, **dict(kw, pkt_records=4))
+    assert any(tm.push_pull_pairs(_ffi.DEFAULT_SEED, t, n, 150) for t in range(1, 220))
+
+
+@pytest.mark.gpu
+def test_hip_matches_the_third_model_on_the_benchmarks_configuration(hiplib):
+    from serf_amd import workload as wl
+    n = 64
+    kw = dict(fanout=4, view_slots=0, event_ring=RING_EV, query_ring=RING_Q, probe_interval=5, push_pull_interval=150, reap_interval=75, queue_check_interval=150,
+              flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT)
+    ops = wl.schedule(n, 190, rate=0.25, seed=3, mix=wl.BENCH_MIX, max_member_subjects=n // 2, even=True)
+    sim = _ffi.Sim(hiplib, _ffi.make_config(n, **kw))
+    run(sim, n, ops, 220, True, **dict(kw, pkt_records=4))
+
+
 def _light_schedule(n, ticks, seed):
     """a load the 16-slot queue carries with packets of 4 records: a rumour every few ticks, two crashes (one re-joins), one graceful leave"""
     rng = np.random.default_rng(seed)
