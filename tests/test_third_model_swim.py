@@ -49,7 +49,8 @@ def run(sim, n, ops, ticks, joined, **kw):
                      tombstone_timeout=kw.get("tombstone_timeout", 432000), intent_timeout=kw.get("intent_timeout", 0),
                      queue_check_interval=kw.get("queue_check_interval", 0), max_queue_depth=kw.get("max_queue_depth", 4096),
                      reconnect_interval=kw.get("reconnect_interval", 0), awareness_probe=kw.get("awareness_probe", False),
-                     tcp_fallback=kw.get("tcp_fallback", False), nacks=kw.get("nacks", False), gossip_to_the_dead=kw.get("gossip_to_the_dead", 0))
+                     tcp_fallback=kw.get("tcp_fallback", False), nacks=kw.get("nacks", False), gossip_to_the_dead=kw.get("gossip_to_the_dead", 0),
+                     join_sync=kw.get("join_sync", False))
     model = tms.Cluster(par, RING_EV, RING_Q, joined)
     by_tick = {}
     for o in ops:
@@ -296,6 +297,36 @@ def test_hip_matches_the_third_model_on_the_benchmarks_configuration(hiplib):
     ops = wl.schedule(n, 190, rate=0.25, seed=3, mix=wl.BENCH_MIX, max_member_subjects=n // 2, even=True)
     sim = _ffi.Sim(hiplib, _ffi.make_config(n, **kw))
     run(sim, n, ops, 220, True, **dict(kw, pkt_records=4))
+
+
+def _rejoin_schedule(n, ticks, seed):
+    """crash / re-join cycles with a named peer (what the configs[4] runs do): the joiner adopts the peer's view when SIM_CF_JOIN_SYNC is set"""
+    rng = np.random.default_rng(seed)
+    ops, key = [], 100
+    for i, x in enumerate(rng.choice(n, 8, replace=False).tolist()):
+        t0 = 2 + 5 * i
+        ops.append((t0, _ffi.OP_CRASH, x, 0, 0))
+        ops.append((t0 + int(rng.integers(18, 45)), _ffi.OP_JOIN, x, int(rng.integers(0, n)), 0))
+    for t in range(3, ticks - 25, 4):
+        key += 1
+        ops.append((t, _ffi.OP_USER_EVENT, int(rng.integers(0, n)), key, 40))
+    ops.sort(key=lambda o: o[0])
+    return ops
+
+
+@pytest.mark.parametrize("seed,n,fanout,loss,pi", [(91, 48, 3, 0.03, 2), (92, 64, 4, 0.05, 1)])
+def test_oracle_matches_the_third_model_with_join_sync(seed, n, fanout, loss, pi):
+    kw = dict(KW, fanout=fanout, loss=loss, probe_interval=pi, join_sync=True, tcp_fallback=True)
+    sim = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw))
+    run(sim, n, _rejoin_schedule(n, 110, seed), 110, True, **kw)
+
+
+@pytest.mark.gpu
+def test_hip_matches_the_third_model_with_join_sync(hiplib):
+    seed, n, fanout, loss, pi = 91, 48, 3, 0.03, 2
+    kw = dict(KW, fanout=fanout, loss=loss, probe_interval=pi, join_sync=True, tcp_fallback=True)
+    sim = _ffi.Sim(hiplib, _ffi.make_config(n, **kw))
+    run(sim, n, _rejoin_schedule(n, 110, seed), 110, True, **kw)
 
 
 def _light_schedule(n, ticks, seed):

@@ -43,7 +43,7 @@ class Params:
     def __init__(self, n, fanout, probe_interval, suspicion_mult=4, suspicion_max_mult=6, indirect_checks=3, retransmit_mult=4,
                  loss=0.0, pkt_records=4, leave_delay=30, seed=None, push_pull_interval=0, reap_interval=0, reconnect_timeout=432000,
                  tombstone_timeout=432000, intent_timeout=0, queue_check_interval=0, max_queue_depth=4096, reconnect_interval=0,
-                 awareness_probe=False, tcp_fallback=False, nacks=False, gossip_to_the_dead=0):
+                 awareness_probe=False, tcp_fallback=False, nacks=False, gossip_to_the_dead=0, join_sync=False):
         from serf_amd import _ffi
         self.pp_interval = push_pull_interval
         self.reap_interval, self.reconnect_timeout, self.tombstone_timeout, self.intent_timeout = reap_interval, reconnect_timeout, tombstone_timeout, intent_timeout
@@ -52,6 +52,7 @@ class Params:
         # memberlist behaviours behind switches (App. B.3, UPSTREAM-RECALL of state.go): the probe interval scaled by the health score, the fallback
         # ping over the stream transport, nacks from the relays, gossip_to_the_dead_time
         self.awareness_probe, self.tcp_fallback, self.nacks, self.gttd = awareness_probe, tcp_fallback, nacks, gossip_to_the_dead
+        self.join_sync = join_sync                          # memberlist.join = a push-pull with the peer: the simulator lets the joiner ADOPT a running node's view (SIMSPEC §2.8)
         self.n, self.fanout, self.pi, self.ic, self.rmult = n, fanout, probe_interval, indirect_checks, retransmit_mult
         self.loss_u32 = min(0xFFFFFFFF, int(round(loss * 2 ** 32)))
         self.P, self.leave_delay = pkt_records, leave_delay
@@ -403,6 +404,8 @@ class Cluster:
             x.up = self.up[node] = True
         elif op == _ffi.OP_JOIN:                            # memberlist.join + Serf::join (api.rs:318-364): a fresh incarnation, then broadcast_join
             self.up[node] = True
+            if self.par.join_sync:
+                self._adopt(x, a)
             x.up, x.state = True, S_ALIVE
             me = x.ml.get(node)
             old = me[0] if me else ML_ALIVE
@@ -443,6 +446,33 @@ class Cluster:
             x.force_leave(a, bool(b), others_alive=self.par.n > 1)
             x._flush(lens={LEAVE: (F_PRUNE if b else 0, 16)})
             x.prune_sync()
+
+    def _adopt(self, x, peer):
+        """SIM_CF_JOIN_SYNC: the joining node takes over the view of the first running node at or after `peer` that is not itself — every
+        entry but its own (of that it keeps the higher incarnation), the suspicions with their timers, the buffered intents —, and witnesses
+        the partner's clocks one below their value (delegate.rs:466-480)"""
+        n = self.par.n
+        partner = next((c for c in ((peer % n + i) % n for i in range(n)) if c != x.me and self.up[c]), None)
+        if partner is None:
+            return
+        p = self.nodes[partner]
+        own = {"m": x.members.get(x.me), "ml": x.ml.get(x.me), "left": x.left_at.get(x.me), "it": x.intents.get(x.me), "ia": x.intent_at.get(x.me)}
+        seen_inc = p.ml[x.me][1] if x.me in p.ml else None
+        x.members = {s: list(v) for s, v in p.members.items() if s != x.me}
+        x.ml = {s: list(v) for s, v in p.ml.items() if s != x.me}
+        x.left_at = {s: v for s, v in p.left_at.items() if s != x.me}
+        x.intents = {s: list(v) for s, v in p.intents.items() if s != x.me}
+        x.intent_at = {s: v for s, v in p.intent_at.items() if s != x.me}
+        x.susp = {s: [v[0], list(v[1])] for s, v in p.susp.items() if s != x.me}
+        for key, d in (("m", x.members), ("ml", x.ml), ("left", x.left_at), ("it", x.intents), ("ia", x.intent_at)):
+            if own[key] is not None:
+                d[x.me] = own[key]
+        if seen_inc is not None and x.me in x.ml and seen_inc > x.ml[x.me][1]:
+            x.ml[x.me][1] = seen_inc
+        x.slots = sorted(x.susp)                            # the adopted suspicions keep running, looked at in subject order
+        for mine, theirs in ((x.clock, p.clock), (x.event_clock, p.event_clock), (x.query_clock, p.query_clock)):
+            if theirs.time() > 0:
+                mine.witness(theirs.time() - 1)
 
     def step(self, ops):
         par, t = self.par, self.tick
