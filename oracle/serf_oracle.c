@@ -1144,9 +1144,13 @@ static void join_sync(osim* s, nctx* c, uint32_t peer) {
   }
   row->susp_next = next;
   row->reap_next = prow->reap_next;
-  row->n_known = prow->n_known;
-  uint32_t pst = (pme && (pme->bits & SIM_VB_KNOWN)) ? SIM_VB_STATUS(pme->bits) : SIM_STATUS_NONE;
-  uint32_t mst = (me && (me->bits & SIM_VB_KNOWN)) ? SIM_VB_STATUS(me->bits) : SIM_STATUS_NONE;
+  /* the partner's counters, corrected for the one entry that is not adopted — the joiner's own: the partner may not know the joiner
+   * at all (it has reaped it): until the end of r5 n_known was copied as it stood and came out one short then (found by the third
+   * model's sweep over combinations, tests/test_third_model_swim.py: join sync + Reaper) */
+  const int pknown = pme && (pme->bits & SIM_VB_KNOWN), mknown = me && (me->bits & SIM_VB_KNOWN);
+  row->n_known = prow->n_known - (pknown ? 1u : 0u) + (mknown ? 1u : 0u);
+  uint32_t pst = pknown ? SIM_VB_STATUS(pme->bits) : SIM_STATUS_NONE;
+  uint32_t mst = mknown ? SIM_VB_STATUS(me->bits) : SIM_STATUS_NONE;
   row->n_failed = prow->n_failed - (pst == SIM_STATUS_FAILED) + (mst == SIM_STATUS_FAILED);
   row->n_left = prow->n_left - (pst == SIM_STATUS_LEFT) + (mst == SIM_STATUS_LEFT);
   if (prow->clock > 0) lc_witness(&row->clock, prow->clock - 1); /* delegate.rs:466-480 */

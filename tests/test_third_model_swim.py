@@ -329,6 +329,68 @@ def test_hip_matches_the_third_model_with_join_sync(hiplib):
     run(sim, n, _rejoin_schedule(n, 110, seed), 110, True, **kw)
 
 
+# a sweep over COMBINATIONS: every knob drawn at random per case — cluster size, fan-out, loss, probe interval, packet size, push-pull, Reaper with
+# short timeouts, QueueChecker, Reconnector, the four memberlist switches, join sync — over a schedule with crashes, silent resumes, re-joins with a
+# peer, graceful leaves, tag changes, events and queries.  (A case whose load hits the 16-slot queue is skipped: the model has no bounds.)
+def _sweep_case(i):
+    rng = np.random.default_rng(9000 + i)
+    n = int(rng.choice([24, 33, 40, 48, 64, 80]))
+    kw = dict(KW, fanout=int(rng.integers(2, 5)), loss=float(rng.choice([0.0, 0.02, 0.05])), probe_interval=int(rng.integers(1, 4)),
+              pkt_records=int(rng.choice([4, 8, 16, 16])), push_pull_interval=int(rng.choice([0, 8, 16])),
+              awareness_probe=bool(rng.integers(0, 2)), tcp_fallback=bool(rng.integers(0, 2)), nacks=bool(rng.integers(0, 2)),
+              gossip_to_the_dead=int(rng.choice([0, 0, 8])), join_sync=bool(rng.integers(0, 2)), reconnect_interval=int(rng.choice([0, 3])))
+    if rng.integers(0, 2):
+        kw.update(REAP_KW)
+    if rng.integers(0, 2):
+        kw.update(queue_check_interval=5, max_queue_depth=3, min_queue_depth=0)
+    ops, key = [], 300
+    busy = {}
+    for t in range(2, 80):
+        if rng.random() < (0.25 if kw["pkt_records"] == 4 else 0.4):
+            node = int(rng.integers(0, n))
+            if busy.get(node, 0) > t:
+                continue
+            r, key = rng.random(), key + 1
+            if r < 0.35:
+                ops.append((t, _ffi.OP_USER_EVENT, node, key, 40))
+            elif r < 0.5:
+                ops.append((t, _ffi.OP_QUERY, node, key, int(rng.choice([0, _ffi.F_ACK, _ffi.F_ACK | _ffi.F_RESPOND | (2 << 8)]))))
+            elif r < 0.6:
+                ops.append((t, _ffi.OP_SET_TAGS, node, int(rng.integers(0, 4)), 0))
+            elif r < 0.8:
+                back = t + int(rng.integers(10, 35))
+                ops.append((t, _ffi.OP_CRASH, node, 0, 0))
+                ops.append((back, _ffi.OP_JOIN, node, int(rng.integers(0, n)), 0) if rng.random() < 0.6 else (back, _ffi.OP_REVIVE, node, 0, 0))
+                busy[node] = back + 8
+            else:
+                ops += [(t, _ffi.OP_LEAVE, node, 0, 0), (t + 4, _ffi.OP_LEAVE_FINISH, node, 0, 0), (t + 8, _ffi.OP_CRASH, node, 0, 0)]
+                busy[node] = 10 ** 6
+    ops.sort(key=lambda o: o[0])
+    return n, kw, ops
+
+
+def _run_sweep_case(lib, i):
+    n, kw, ops = _sweep_case(i)
+    sim = _ffi.Sim(lib, _ffi.make_config(n, **kw))
+    try:
+        run(sim, n, ops, 110, True, **kw)
+    except AssertionError as e:
+        if "a model bound was hit" in str(e):
+            pytest.skip(f"case {i}: the load hit the bounded queue ({e})")
+        raise
+
+
+@pytest.mark.parametrize("i", range(16))
+def test_oracle_matches_the_third_model_over_random_combinations(i):
+    _run_sweep_case(load_oracle(), i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", [1, 4, 7, 10])
+def test_hip_matches_the_third_model_over_random_combinations(hiplib, i):
+    _run_sweep_case(hiplib, i)
+
+
 def _light_schedule(n, ticks, seed):
     """a load the 16-slot queue carries with packets of 4 records: a rumour every few ticks, two crashes (one re-joins), one graceful leave"""
     rng = np.random.default_rng(seed)
