@@ -164,6 +164,24 @@ def test_oracle_matches_the_third_model_with_push_pull(seed, n, fanout, joined, 
     assert counted > n // 2, "the runs must contain queries whose acks / responses reach the origin"
 
 
+def _sweep(i):
+    """a random combination: size, fan-out, pre-joined or not, fan-out model, push-pull interval, loss (a cluster nobody has joined keeps its
+    retransmit limit at 4: a fan-out below that keeps a record queued past its first tick, which the rebroadcast check relies on)"""
+    rng = np.random.default_rng(5000 + i)
+    n = int(rng.choice([20, 33, 48, 64, 90]))
+    joined = bool(rng.random() < 0.8)
+    fanout = int(rng.integers(2, 5)) if joined else int(rng.integers(2, 4))
+    rf, ppi, loss = bool(rng.integers(0, 2)), int(rng.choice([0, 8, 16])), float(rng.choice([0.0, 0.1, 0.2]))
+    return n, fanout, joined, rf, ppi, loss
+
+
+@pytest.mark.parametrize("i", range(14))
+def test_oracle_matches_the_third_model_over_random_combinations(i):
+    n, fanout, joined, rf, ppi, loss = _sweep(i)
+    sim = _ffi.Sim(load_oracle(), _ffi.make_config(n, **dict(_pp_kw(fanout, joined, rf, ppi), loss=loss)))
+    run_against_third_model(sim, n, fanout, _schedule(n, 70, 100 + i, joined), 70, joined, rf, pp_interval=ppi, loss=loss)
+
+
 def _origin_goes_down_schedule(n):
     """queries whose origin crashes while the query is still spreading (what comes back after that is dropped: the origin is not
     running), one of them back up before the spread is over, and one query issued by a node that is down (registered, never sent)"""
