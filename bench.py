@@ -184,8 +184,22 @@ def cpu_baseline(args, model, parity_ticks, timed=True, seconds_budget=300.0):
         dt1 = time.perf_counter() - t2
         lib.dll.osim_t_set_threads(0)
         drops = sim.cluster_stats()["overflow"]
-        res = {"value": n * done / dt, "unit": "member-ticks/s", "cores": cores, "kind": "port",
+        curve = {}
+        host_cores = os.cpu_count()
+        if getattr(args, "cpu_thread_curve", True):   # SURVEY.md §8d (ii) "all cores": what more threads than the cgroup quota buy (nothing)
+            for nt in (2 * cores, 4 * cores, host_cores):
+                if nt and nt > cores and nt <= (host_cores or 0) and nt not in curve:
+                    lib.dll.osim_t_set_threads(nt)
+                    t3 = time.perf_counter()
+                    sim.step(2)
+                    curve[nt] = n * 2 / (time.perf_counter() - t3)
+            lib.dll.osim_t_set_threads(0)
+        best = max([n * done / dt] + list(curve.values()))
+        res = {"value": best, "unit": "member-ticks/s", "cores": cores if best == n * done / dt else max(curve, key=curve.get), "kind": "port",
+               "host_cores": host_cores, "cpu_quota_threads": cores, "value_quota_threads": n * done / dt,
+               "threads_curve": {str(k): v for k, v in sorted(curve.items())},
                "single_thread_value": n * done1 / dt1, "fanout_model": model,
+               "sample_short": f"{n} nodes, same config+schedule; ticks {first}..{first + done - 1} on {cores} threads (cgroup quota; host shows {host_cores} CPUs: curve in detail), {done1} ticks on 1",
                "sample": f"same configuration, fan-out model ({model}) and schedule as the GPU run{note}: {n} nodes, view_slots {args.view_slots}, "
                          f"rings {args.ring}, fan-out {args.fanout}; {first} untimed pre-roll ticks ({t_roll:.1f} s), then ticks {first}..{first + done - 1} "
                          f"timed on {cores} threads (OpenMP over nodes), on to tick {last} for the second parity digest, and {done1} more on one "
@@ -260,6 +274,7 @@ def parse_args(argv=None):
                     help="sharded runs: who issues the round's all-to-all — the library itself over RCCL (sim_exchange_*), or torch.distributed")
     ap.add_argument("--no-second-load", action="store_true", help="skip the second measured load (N = 1: 16 records per packet at --second-rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-all", action="store_true", help="roll the CPU oracle for the second fan-out model's parity digests too (default: the headline model only)")
     ap.add_argument("--no-long-window", action="store_true", help="skip the second timed window (profiling runs: the LAST launches are then the timed ones)")
     ap.add_argument("--no-convergence", action="store_true", help="skip the rounds-to-99 %% measurement (profiling runs)")
     ap.add_argument("--allow-drops", action="store_true", help="do not fail when the run hit a model bound (overflow > 0)")
@@ -297,6 +312,91 @@ def claim_stdout():
 
 def emit(obj):
     print(json.dumps(obj), file=_OUT if _OUT is not None else sys.stdout, flush=True)
+
+
+LINE_LIMIT = 4000      # bytes of the ONE JSON line (the driver keeps a tail of ~8 KB of stdout: a longer line loses its head)
+DETAIL_FILE = "bench_detail.json"
+
+
+def _r(x, nd=4):
+    """a number rounded to `nd` significant digits (the line is a summary; bench_detail.json keeps full precision)"""
+    if isinstance(x, float):
+        return float(f"{x:.{nd}g}")
+    return x
+
+
+def compact(out):
+    """The ONE line: the contract's keys + roofline + cpu_baseline + what a reader needs to judge the run, every text short.
+    Everything else (prose, per-model blocks, digests, provenance, load traces) is `out` itself, written to DETAIL_FILE."""
+    def roof(r):
+        if not r:
+            return None
+        d = {k: _r(r.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_measured", "traffic", "kernel", "kernel_ms")}
+        return {k: v for k, v in d.items() if v is not None or k in ("traffic", "frac_measured")}
+
+    def rounds(r):
+        return None if not r else {"median": r["median"], "p90": r["p90"], "max": r["max"], "n": r["n"]}
+
+    cfg = out["config"]
+    line = {k: _r(out[k], 6) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                       "vs_baseline", "dtype", "data") if k in out}
+    line["config"] = {"workload": cfg["workload_short"], "fanout_model": cfg["fanout_model"], "parallelism": cfg["parallelism_short"],
+                      "timed_ticks": cfg["timed_ticks"], "model_bound_drops": cfg["model_bound_drops"]}
+    line["roofline"] = roof(out.get("roofline"))
+    if out.get("cpu_baseline"):
+        cb = out["cpu_baseline"]
+        line["cpu_baseline"] = {k: _r(cb.get(k)) for k in ("value", "unit", "cores", "host_cores", "kind", "single_thread_value", "value_16_threads") if cb.get(k) is not None}
+        line["cpu_baseline"]["sample"] = cb["sample_short"]
+    if out.get("long_window"):
+        lw = out["long_window"]
+        line["value_long_window"] = _r(out["value_long_window"], 6)
+        line["long_window"] = {"steps": lw["steps"], "ms_per_step": _r(lw["ms_per_step"]), "roofline": roof(lw["roofline"])}
+    if out.get("parity"):
+        line["parity"] = {"digest_match": out["parity"].get("digest_match"), "ticks": out["parity"].get("ticks"),
+                          "models": [k for k, v in out["parity"].items() if isinstance(v, dict)]}
+    line["rounds_to_99"] = rounds(out.get("rounds_to_99"))
+    fm = {}
+    for mo, d in out.get("fanout_models", {}).items():
+        if mo == cfg["fanout_model"]:
+            continue
+        fm[mo] = {"value": _r(d["value"], 6), "ms_per_step": _r(d["ms_per_step"]), "kernel_ms": _r(d["kernel_ms"]),
+                  "frac": _r(d["roofline"]["frac"]), "frac_measured": _r(d["roofline"]["frac_measured"]), "rounds_to_99": rounds(d["rounds_to_99"])}
+        if "exchange" in d:
+            fm[mo]["exchange"] = {"chunks": d["exchange"]["chunks"], "exchange_ms": _r(d["exchange"]["exchange_ms"])}
+    if fm:
+        line["fanout_models"] = fm
+    if out.get("second_load"):
+        sl = out["second_load"]
+        line["second_load"] = {k: _r(sl.get(k)) for k in ("rate", "pkt_records", "live_rumours", "value", "ms_per_step", "kernel_ms", "frac", "frac_measured",
+                                                          "model_bound_drops", "records_per_packet", "deepest_queue", "digest_match") if sl.get(k) is not None}
+    if out.get("exchange"):
+        x = out["exchange"]
+        line["exchange"] = {k: _r(x.get(k)) for k in ("chunks", "exchange_ms", "kernel_ms", "serial_ms_per_step", "overlapped_ms_per_step",
+                                                      "bytes_leaving_gpu_per_tick")}
+    if out.get("distributed"):
+        line["distributed"] = {k: out["distributed"].get(k) for k in ("backend", "world_size")}
+    line["detail_file"] = DETAIL_FILE
+    s = json.dumps(line)
+    if len(s) > LINE_LIMIT:   # never again a line the driver cannot parse: shed the optional blocks, largest first
+        for k in ("fanout_models", "second_load", "exchange", "long_window", "distributed"):
+            line.pop(k, None)
+            if len(json.dumps(line)) <= LINE_LIMIT:
+                break
+    return line
+
+
+def emit_result(out):
+    """full result -> DETAIL_FILE (next to bench.py; also under gpurun_out/ when that exists) and stderr; the compact line -> stdout"""
+    txt = json.dumps(out, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, DETAIL_FILE), "w") as f:
+                    f.write(txt)
+            except OSError:
+                pass
+    sys.stderr.write("bench.py detail: " + json.dumps(out) + "\n")
+    emit(compact(out))
 
 
 class Progress:
@@ -484,7 +584,7 @@ def run(args, lib=None, dev=None, backend="nccl"):
         # parity block: the state the timed region starts from and the state it ends in, digested (all 8 arrays); rank 0's
         # cpu_baseline() rolls the oracle through the same schedule to the same ticks and compares
         m["parity_ticks"] = [args.preroll + args.warmup, args.preroll + args.warmup + args.steps]
-        want_parity = world == 1 and not args.no_cpu_baseline
+        want_parity = world == 1 and not args.no_cpu_baseline and (model == models[0] or args.parity_all)
         m["digests"] = {}
         if want_parity:
             m["digests"][m["parity_ticks"][0]] = raw.digest()
@@ -689,6 +789,10 @@ def run(args, lib=None, dev=None, backend="nccl"):
                                    f"{args.preroll} untimed pre-roll ticks under the same load before the warm-up (steady state); the timed region is the "
                                    f"{args.steps} ticks the driver asks for (not SURVEY §8d's 1 000)"
                                    + (f", the {long_window(args)} ticks behind it are measured as well (long_window)" if long_window(args) else ""),
+                       "workload_short": f"BASELINE configs[2]: {n_total} nodes ({args.nodes_per_gpu}/GPU), fan-out {args.fanout}, {models[0]}, {args.rate} API ops/tick, "
+                                         f"{args.pkt_records} records/packet, view_slots {args.view_slots}, rings {args.ring}, probe {args.probe_interval}, push-pull {args.push_pull_interval}, "
+                                         f"{args.preroll} pre-roll ticks",
+                       "parallelism_short": f"node-id range shards x{world}, {args.chunks} chunks, one all-to-all per round" if sharded else "single GPU",
                        "fanout_model": models[0],
                        "parallelism": ((f"node-id range shards x{world}; " + (f"kRandomNodes: packets packed per destination shard behind each of the {args.chunks} sender-chunk launches, an "
                                                                                "equal-split all-to-all of the packed slabs per chunk, overlapped with compute" if models[0] == "krandomnodes" else
@@ -727,6 +831,8 @@ def run(args, lib=None, dev=None, backend="nccl"):
         if world == 1 and not args.no_cpu_baseline:
             out["parity"] = {}
             for i, mo in enumerate(models):
+                if i > 0 and not args.parity_all:   # one oracle roll per run by default: the lease is for the GPU
+                    continue
                 progress(f"cpu_baseline ({mo})")
                 m = res[mo]
                 cb, cpu_dig = cpu_baseline(args, mo, m["parity_ticks"], timed=(i == 0))
@@ -746,7 +852,7 @@ def run(args, lib=None, dev=None, backend="nccl"):
                                          "oracle": {str(tk): [f"{x:016x}" for x in cpu_dig[tk]] for tk in pt}}
             out["parity"]["digest_match"] = all(v.get("digest_match") is not False for v in out["parity"].values() if isinstance(v, dict))
             out["parity"]["ticks"] = head["parity_ticks"]
-        emit(out)
+        emit_result(out)
     progress.done = True
     if world > 1 or args.force_sharded:
         dist.destroy_process_group()

@@ -56,6 +56,17 @@ def test_bench_control_flow(world):
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     if world > 1:
         assert all(res[r] == "null" for r in range(1, world))
+    # the ONE line the driver parses: short enough that an 8 KB tail holds all of it (round 5's 21 KB line lost its head)
+    sys.path.insert(0, ROOT)
+    import bench
+    line = bench.compact(out)
+    txt = json.dumps(line)
+    assert len(txt) < bench.LINE_LIMIT < 6000, len(txt)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "rounds_to_99", "detail_file"):
+        assert key in line, key
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and len(line["config"]["workload"]) <= 300
+    assert line["value"] == pytest.approx(out["value"], rel=1e-4)
 
 
 def test_bench_control_flow_random_fanout_on_two_ranks():
