@@ -29,7 +29,7 @@ extern "C" {
 
 /* ------------------------------------------------------------------ constants */
 
-#define SIM_ABI_VERSION 13u
+#define SIM_ABI_VERSION 14u
 
 #define SIM_P 4u  /* piggyback records per packet PAGE (48-byte cell: 4 records x 12 wire bytes) */
 #define SIM_PKT_BYTES 1400u /* byte budget of a gossip packet: memberlist's UDP payload limit (lan() and wan()); a packet
@@ -38,16 +38,21 @@ extern "C" {
 #define SIM_PKT_UNITS (SIM_PKT_BYTES / 16u)
 #define SIM_PAGES_MAX 4u        /* pages of SIM_P records in one packet                            */
 #define SIM_PKT_RECORDS_MAX (SIM_P * SIM_PAGES_MAX)
-/* The three capacity bounds of the model.  The product is built with exactly these values; the oracle can ALSO be
+/* The capacity bounds of the model.  The product is built with exactly these values; the oracle can ALSO be
  * built with far larger ones (oracle/Makefile: liboracle_unbounded.so) so that a test can show that a bounded run
  * which never hit a bound (overflow == 0) is identical to the run without the bounds
  * (tests/test_oracle_unbounded.py; reference: queues of up to 4096 entries options.rs:513, a Vec per ring bucket
- * base.rs:783-813, one suspicion timer per suspected member). */
+ * base.rs:783-813, one suspicion timer per suspected member).
+ * (ABI 14) SIM_Q went from 16 to 64 and a ring bucket that holds SIM_C keys continues in the ring's OVERFLOW ROWS
+ * (sim_config.ring_overflow, below) instead of treating a seventh key as seen. */
 #ifndef SIM_Q
-#define SIM_Q 16u /* retransmit-queue slots per node (all four queues share the pool) */
+#define SIM_Q 64u /* retransmit-queue slots per node (all four queues share the pool).  The HIP library keeps the SIM_Q_HOT
+                   * entries that drain first in registers inside the tick kernel; a node whose queue is (or would get)
+                   * deeper is finished by a second kernel behind it (deep_queue_kernel) — same results */
 #endif
+#define SIM_Q_HOT 16u
 #ifndef SIM_C
-#define SIM_C 6u  /* keys per de-dup ring bucket (32-byte bucket)                     */
+#define SIM_C 6u  /* keys per de-dup ring bucket (32-byte bucket); further keys: the ring's overflow rows */
 #endif
 #define SIM_MAX_FANOUT 4u
 #define SIM_MAX_CONF 4u /* conf[0] = node that started the suspicion, conf[1..3] = confirmers (k <= 3) */
@@ -197,7 +202,13 @@ typedef struct sim_view {
 #define SIM_VB_STAMP(b) ((b) >> 11)
 
 /* 32-byte de-dup ring bucket (event ring: base.rs:783-813, query ring: base.rs:1025-1042).
- * keys[0] == 0 means "bucket absent" (None). */
+ * keys[0] == 0 means "bucket absent" (None).
+ * (ABI 14) A ring array is [X + B][Nl] buckets, X = sim_config.ring_overflow: rows 0 .. X-1 are the node's OVERFLOW ROWS,
+ * the bucket of Lamport time t is row X + t mod B.  The reference keeps a Vec per bucket (base.rs:801-813 push, 1027-1042);
+ * here the keys beyond SIM_C of bucket i continue in overflow rows whose `ltime` field holds i + 1 (0: the row is free) —
+ * rows are handed out in ascending order, one owner each, never given back (the reference never shrinks the Vec
+ * either); a bucket's keys in push order = its own SIM_C, then its overflow rows in ascending row order.  A key that
+ * finds every row taken is treated as seen and counted in sim_row.overflow (the model bound that is left). */
 typedef struct sim_bucket {
   uint64_t ltime;
   uint32_t keys[SIM_C];
@@ -274,6 +285,10 @@ typedef struct sim_config {
                                * with failed members attempts, with probability failed / alive, a memberlist.join — a
                                * push-pull — with one of them (base.rs:612-681; SIMSPEC §2.9).  Needs the SWIM layer
                                * (members only fail there).  (ABI <= 9: this word was reserved, 0)                   */
+  uint32_t ring_overflow;     /* X: overflow rows per de-dup ring and node (sim_bucket above), each SIM_C further keys
+                               * for ONE bucket that ran full; 0 = none (a full bucket then treats a new key as seen,
+                               * counted — the behaviour of ABI <= 13).  (ABI 14)                                     */
+  uint32_t reserved0;         /* 0                                                                                    */
   uint64_t seed;              /* master seed; default 0x5EEDC0DE5E4F0001                        */
 } sim_config;
 
@@ -571,6 +586,10 @@ int sim_bind_exchange3(sim_handle* h, void* send_dev, size_t send_bytes, void* r
  *                        implementation's own (HIP: 64-byte cells; oracle: 48-byte packets with explicit targets): ranks of one
  *                        run use one implementation.  AFTER sim_restore the handle has packed the restored packets in flight into
  *                        the send buffer again and the host has to run the exchange once more before the next tick.
+ *                        Limits of the HIP library in this mode (sim_create returns SIM_EINVAL beyond them; the oracle, whose slabs
+ *                        are plain arrays, has none): at most 64 shards (V <= 64: one partial sum per destination in a 64-entry
+ *                        table), a receive buffer of fewer than 2^30 16-byte units (C * V slabs), and (4 + V * C) << LB bytes of
+ *                        LDS for the receiver's index pass, LB = the graph build's bucket width (11 at 1 Mi nodes per shard): V * C <= 28.
  * (SIM_XCHG_ALL_GATHER, ABI 12's O(N)-per-shard form of the random fan-out, is retired: no handle reports it.) */
 #define SIM_XCHG_ALL_TO_ALL 0u
 #define SIM_XCHG_ALL_GATHER 1u

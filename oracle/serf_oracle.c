@@ -260,6 +260,7 @@ typedef struct sim_opent {
 struct sim_handle {
   sim_config cfg;
   uint32_t N, V, M, Nl, A, Bev, Bq, f, dense, shard0; /* Nl local nodes; shard0 = first global id */
+  uint32_t X; /* overflow rows per ring (sim_config.ring_overflow): a ring array is [X + B][Nl], bucket i = row X + i */
   uint32_t P, PG, fp; /* records a packet can carry (sim_config.pkt_records), its pages of SIM_P records, fp = f * PG cells per node */
   uint64_t tick;
   tickp prev; /* parameters of the tick that produced the current inbox (sharded reads) */
@@ -271,8 +272,8 @@ struct sim_handle {
   tickp cur; int in_tick;    /* between step_begin and step_end */
   int own_x;
   sim_view* view;       /* [A][Nl]   */
-  sim_bucket* ering;    /* [Bev][Nl] */
-  sim_bucket* qring;    /* [Bq][Nl]  */
+  sim_bucket* ering;    /* [X + Bev][Nl] */
+  sim_bucket* qring;    /* [X + Bq][Nl]  */
   uint32_t* slot_of;    /* [N] global subject -> slot */
   uint32_t* subject_of; /* [A] */
   uint32_t n_slots;
@@ -682,6 +683,32 @@ static inline sim_bucket* ring_at(sim_bucket* ring, uint32_t Nl, uint32_t idx, u
   return &ring[(size_t)idx * Nl + l];
 }
 
+/* One key into a ring bucket (the Vec push of base.rs:801-813 / 1027-1042).  `b` = the bucket (present: keys[0] != 0), `idx` its
+ * index in the ring, `match` = a stored key equal to `key` counts as seen (user events: always, quirk U1; queries: only in a
+ * bucket of the query's own Lamport time, quirk Q2).  The bucket's keys are its own SIM_C, then its overflow rows (rows
+ * 0 .. X-1 of the ring array, `ltime` = owner index + 1, handed out in ascending order — include/serf_sim.h sim_bucket).
+ * Returns 1 when the key was appended, 0 when it was seen — or when nothing is left to append it to (model bound, counted). */
+static int bucket_push(nctx* c, sim_bucket* ring, sim_bucket* b, uint32_t idx, uint32_t key, int match) {
+  osim* s = c->s;
+  uint32_t n = 0;
+  for (; n < SIM_C && b->keys[n]; ++n)
+    if (match && b->keys[n] == key) return 0;
+  if (n < SIM_C) { b->keys[n] = key; return 1; }
+  for (uint32_t j = 0; j < s->X; ++j) {
+    sim_bucket* o = ring_at(ring, s->Nl, j, c->l);
+    if (o->ltime == 0) { /* a free row: the bucket's next one */
+      o->ltime = (uint64_t)idx + 1;
+      o->keys[0] = key;
+      return 1;
+    }
+    if (o->ltime != (uint64_t)idx + 1) continue;
+    for (n = 0; n < SIM_C && o->keys[n]; ++n)
+      if (match && o->keys[n] == key) return 0;
+    if (n < SIM_C) { o->keys[n] = key; return 1; }
+  }
+  c->row->overflow++; /* model bound: every overflow row taken => treated as seen */
+  return 0;
+}
 /* handle_user_event: base.rs:750-837.  (name,payload) identity is the 32-bit event key.
  * Quirk U1 is reproduced: an existing bucket's ltime is not compared (base.rs:801-807). */
 static int handle_user_event(nctx* c, uint32_t key, uint64_t ltime) {
@@ -691,16 +718,9 @@ static int handle_user_event(nctx* c, uint32_t key, uint64_t ltime) {
   uint64_t B = s->Bev, cur = c->row->event_clock; /* base.rs:770-771 */
   if (cur > B && ltime < cur - B) return 0;     /* base.rs:772 */
   uint32_t idx = (uint32_t)(ltime % B);         /* base.rs:783 */
-  sim_bucket* b = ring_at(s->ering, s->Nl, idx, c->l);
+  sim_bucket* b = ring_at(s->ering, s->Nl, s->X + idx, c->l);
   if (b->keys[0]) { /* Some(seen)  base.rs:801-807 */
-    uint32_t n = 0;
-    for (; n < SIM_C && b->keys[n]; ++n)
-      if (b->keys[n] == key) return 0;
-    if (n == SIM_C) { /* model bound: bucket full => treated as seen */
-      c->row->overflow++;
-      return 0;
-    }
-    b->keys[n] = key;
+    if (!bucket_push(c, s->ering, b, idx, key, 1)) return 0;
   } else { /* base.rs:808-813 */
     b->ltime = ltime;
     b->keys[0] = key;
@@ -716,7 +736,8 @@ static inline int up_of_early(const osim* s, uint32_t gid) { return (s->upmap[gi
  * straight to the query's origin (memberlist.send, base.rs:1097) and are subject to packet loss.
  * The origin half (handle_query_response base.rs:1158-1204, QueryResponse::handle_query_response
  * query.rs:240-303): dropped after the deadline or when the origin is not running, duplicates from
- * the same node are dropped — a bit per (query, node).  Relays (relay_factor) are not modelled. */
+ * the same node are dropped — a bit per (query, node).  A response whose direct leg is lost takes the relays (relay_factor,
+ * query.rs:523-601): the loop below. */
 static void query_respond(nctx* c, uint32_t id, uint32_t flags) {
   osim* s = c->s;
   if (!(flags & (SIM_F_ACK | SIM_F_RESPOND))) return;
@@ -768,16 +789,9 @@ static int handle_query(nctx* c, uint32_t id, uint64_t ltime, uint32_t flags) {
   uint64_t cur = c->row->query_clock, qt = s->Bq; /* base.rs:1012-1013 */
   if (cur > qt && qt < cur - qt) return 0;   /* base.rs:1014 (sic) */
   uint32_t idx = (uint32_t)(ltime % qt);     /* base.rs:1025 */
-  sim_bucket* b = ring_at(s->qring, s->Nl, idx, c->l);
+  sim_bucket* b = ring_at(s->qring, s->Nl, s->X + idx, c->l);
   if (b->keys[0]) {
-    uint32_t n = 0;
-    for (; n < SIM_C && b->keys[n]; ++n)
-      if (b->ltime == ltime && b->keys[n] == id) return 0; /* base.rs:1028-1035 */
-    if (n == SIM_C) {
-      c->row->overflow++;
-      return 0;
-    }
-    b->keys[n] = id; /* base.rs:1036 */
+    if (!bucket_push(c, s->qring, b, idx, id, b->ltime == ltime)) return 0; /* base.rs:1028-1036 */
   } else {           /* base.rs:1038-1042 */
     b->ltime = ltime;
     b->keys[0] = id;
@@ -1305,7 +1319,7 @@ static void pp_params(const sim_config* c, uint32_t* step, uint32_t* groups) {
  * shard (sim_pp_export / sim_pp_merge): 32-byte header {clock, event_clock, query_clock, 0}, the 16-byte heads
  * {ltime, inc, bits} of the view entries in walk (subject) order, the event ring's buckets. */
 typedef struct pp_head { uint64_t ltime; uint32_t inc, bits; } pp_head;
-static size_t pp_record_bytes(const osim* s) { return 32 + (size_t)s->n_walk * sizeof(pp_head) + (size_t)s->Bev * sizeof(sim_bucket); }
+static size_t pp_record_bytes(const osim* s) { return 32 + (size_t)s->n_walk * sizeof(pp_head) + (size_t)(s->X + s->Bev) * sizeof(sim_bucket); }
 static void pp_pack(const osim* s, uint32_t l, uint8_t* rec) {
   const sim_row* r = &s->rows[l];
   uint64_t hdr[4] = {r->clock, r->event_clock, r->query_clock, 0};
@@ -1316,7 +1330,7 @@ static void pp_pack(const osim* s, uint32_t l, uint8_t* rec) {
     h[wi].ltime = e->ltime; h[wi].inc = e->inc; h[wi].bits = e->bits;
   }
   sim_bucket* b = (sim_bucket*)(rec + 32 + (size_t)s->n_walk * sizeof(pp_head));
-  for (uint32_t idx = 0; idx < s->Bev; ++idx) b[idx] = s->ering[(size_t)idx * s->Nl + l];
+  for (uint32_t row = 0; row < s->X + s->Bev; ++row) b[row] = s->ering[(size_t)row * s->Nl + l]; /* overflow rows first, like the array */
 }
 /* local <- remote record: memberlist mergeState, then SerfDelegate::merge_remote_state(is_join = false) */
 static void pp_merge(osim* s, uint32_t ll, const uint8_t* rec) {
@@ -1357,8 +1371,14 @@ static void pp_merge(osim* s, uint32_t ll, const uint8_t* rec) {
       handle_join_intent(&c, s->subject_of[s->walk[wi]], re->ltime);
   }
   for (uint32_t idx = 0; idx < s->Bev; ++idx) { /* replay the remote event buffer: delegate.rs:540-552 */
-    const sim_bucket* rb = &rbk[idx];
-    for (uint32_t k = 0; k < SIM_C && rb->keys[k]; ++k) handle_user_event(&c, rb->keys[k], rb->ltime);
+    const sim_bucket* rb = &rbk[s->X + idx];
+    if (!rb->keys[0]) continue;
+    uint32_t k = 0;
+    for (; k < SIM_C && rb->keys[k]; ++k) handle_user_event(&c, rb->keys[k], rb->ltime);
+    if (k == SIM_C) /* a full bucket continues in its overflow rows, in row order (= push order) */
+      for (uint32_t j = 0; j < s->X && rbk[j].ltime; ++j)
+        if (rbk[j].ltime == (uint64_t)idx + 1)
+          for (k = 0; k < SIM_C && rbk[j].keys[k]; ++k) handle_user_event(&c, rbk[j].keys[k], rb->ltime);
   }
 #undef PP_GUARD
 }
@@ -1819,6 +1839,7 @@ static int cfg_check(const sim_config* c) {
   if (c->fanout < 1 || c->fanout > SIM_MAX_FANOUT) return SIM_EINVAL;
   if (c->chunks > 1 && ((M / c->vshards) % c->chunks || (M / c->vshards) / c->chunks < 1)) return SIM_EINVAL;
   if (c->event_ring < 1 || c->query_ring < 1) return SIM_EINVAL;
+  if (c->ring_overflow > 4096u || c->reserved0) return SIM_EINVAL;
   if (c->pkt_records && (c->pkt_records % SIM_P || c->pkt_records > SIM_PKT_RECORDS_MAX)) return SIM_EINVAL;
   if (c->retransmit_mult * digits10(c->n_nodes) > 63u) return SIM_EINVAL;
   if (c->n_nodes > (1u << 24)) return SIM_EINVAL; /* SUSPECT / DEAD carry the accuser's id in 24 bits on the wire (sim_packet) */
@@ -1854,6 +1875,7 @@ int API(create)(const sim_config* cfg, osim** out) {
   s->dense = (cfg->view_slots == 0 || cfg->view_slots >= s->N);
   s->A = s->dense ? s->N : cfg->view_slots;
   s->Bev = cfg->event_ring; s->Bq = cfg->query_ring; s->f = cfg->fanout;
+  s->X = cfg->ring_overflow;
   s->P = cfg->pkt_records ? cfg->pkt_records : SIM_P;
   s->PG = s->P / SIM_P;
   s->fp = s->f * s->PG;
@@ -1875,8 +1897,8 @@ int API(create)(const sim_config* cfg, osim** out) {
     s->inbox[1] = (sim_packet*)calloc((size_t)s->fp * Nl, sizeof(sim_packet));
   }
   s->view = (sim_view*)calloc((size_t)s->A * Nl, sizeof(sim_view));
-  s->ering = (sim_bucket*)calloc((size_t)s->Bev * Nl, sizeof(sim_bucket));
-  s->qring = (sim_bucket*)calloc((size_t)s->Bq * Nl, sizeof(sim_bucket));
+  s->ering = (sim_bucket*)calloc((size_t)(s->X + s->Bev) * Nl, sizeof(sim_bucket));
+  s->qring = (sim_bucket*)calloc((size_t)(s->X + s->Bq) * Nl, sizeof(sim_bucket));
   s->slot_of = (uint32_t*)malloc((size_t)s->N * sizeof(uint32_t));
   s->subject_of = (uint32_t*)malloc((size_t)s->A * sizeof(uint32_t));
   s->walk = (uint32_t*)malloc((size_t)s->A * sizeof(uint32_t));
@@ -2717,8 +2739,8 @@ int API(state_digest)(osim* s, uint64_t out[8]) {
   out[1] = dig_words(s->queue, (size_t)s->Nl * SIM_Q * 2);
   out[2] = dig_words(cur_inbox(s), (size_t)s->fp * s->Nl * (sizeof(sim_packet) / 8));
   out[3] = dig_words(s->view, (size_t)s->A * s->Nl * 4);
-  out[4] = dig_words(s->ering, (size_t)s->Bev * s->Nl * 4);
-  out[5] = dig_words(s->qring, (size_t)s->Bq * s->Nl * 4);
+  out[4] = dig_words(s->ering, (size_t)(s->X + s->Bev) * s->Nl * (sizeof(sim_bucket) / 8));
+  out[5] = dig_words(s->qring, (size_t)(s->X + s->Bq) * s->Nl * (sizeof(sim_bucket) / 8));
   {
     uint64_t acc = 0;
     for (uint32_t i = 0; i < s->N; ++i) acc += dig((uint64_t)s->slot_of[i], (uint64_t)i);
@@ -2754,8 +2776,8 @@ int API(dump_state)(osim* s, uint32_t which, void* buf, size_t cap, size_t* byte
     case SIM_ARR_QUEUE: src = s->queue; n = (size_t)s->Nl * SIM_Q * sizeof(sim_record); break;
     case SIM_ARR_INBOX: src = cur_inbox(s); n = (size_t)s->fp * s->Nl * sizeof(sim_packet); break;
     case SIM_ARR_VIEW: src = s->view; n = (size_t)s->A * s->Nl * sizeof(sim_view); break;
-    case SIM_ARR_ERING: src = s->ering; n = (size_t)s->Bev * s->Nl * sizeof(sim_bucket); break;
-    case SIM_ARR_QRING: src = s->qring; n = (size_t)s->Bq * s->Nl * sizeof(sim_bucket); break;
+    case SIM_ARR_ERING: src = s->ering; n = (size_t)(s->X + s->Bev) * s->Nl * sizeof(sim_bucket); break;
+    case SIM_ARR_QRING: src = s->qring; n = (size_t)(s->X + s->Bq) * s->Nl * sizeof(sim_bucket); break;
     case SIM_ARR_SLOTMAP: src = s->slot_of; n = (size_t)s->N * sizeof(uint32_t); break;
     default: return SIM_EINVAL;
   }
@@ -2788,7 +2810,7 @@ static void snap_sections(osim* s, const void* ptr[SNAP_SECTIONS], size_t len[SN
                                   s->qfilt, s->tagclass};
   size_t n[SNAP_SECTIONS] = {(size_t)s->Nl * sizeof(sim_row), (size_t)s->Nl * SIM_Q * sizeof(sim_record),
                              (size_t)s->fp * s->Nl * sizeof(sim_packet), (size_t)s->A * s->Nl * sizeof(sim_view),
-                             (size_t)s->Bev * s->Nl * sizeof(sim_bucket), (size_t)s->Bq * s->Nl * sizeof(sim_bucket),
+                             (size_t)(s->X + s->Bev) * s->Nl * sizeof(sim_bucket), (size_t)(s->X + s->Bq) * s->Nl * sizeof(sim_bucket),
                              (size_t)s->N * 4, (size_t)s->A * 4, (size_t)s->N * sizeof(sim_view), nup * 4,
                              sizeof s->qtab, (size_t)SIM_QT * 2 * nup * 4, (s->n_ops - s->op_cursor) * sizeof(sim_opent),
                              (size_t)s->A * 4, sizeof s->qfilt, (size_t)s->N};
@@ -2890,9 +2912,16 @@ int API(convergence)(osim* s, uint32_t kind, uint32_t key, uint64_t ltime, uint6
       case SIM_K_EVENT: case SIM_K_QUERY: {
         const sim_bucket* ring = kind == SIM_K_EVENT ? s->ering : s->qring;
         uint32_t B = kind == SIM_K_EVENT ? s->Bev : s->Bq;
-        const sim_bucket* b = &ring[(size_t)(ltime % B) * s->Nl + l];
+        const uint32_t idx = (uint32_t)(ltime % B);
+        const sim_bucket* b = &ring[(size_t)(s->X + idx) * s->Nl + l];
         int hit = 0;
         for (uint32_t i = 0; i < SIM_C; ++i) hit |= (b->keys[i] == key && key != 0);
+        for (uint32_t j = 0; j < s->X && !hit; ++j) { /* ... or among the keys the bucket keeps in its overflow rows */
+          const sim_bucket* o = &ring[(size_t)j * s->Nl + l];
+          if (!o->ltime) break;
+          if (o->ltime == (uint64_t)idx + 1)
+            for (uint32_t i = 0; i < SIM_C; ++i) hit |= (o->keys[i] == key && key != 0);
+        }
         ns += hit;
         break;
       }
@@ -2955,7 +2984,7 @@ int API(profile_read_stats)(osim* s, double out_ms[3], uint64_t* launches) {
 }
 int API(resident_planes)(const osim* s, uint32_t out[6], uint64_t* bytes_per_plane) { /* whole arrays: resident == total */
   if (!s || !out) return SIM_EINVAL;
-  out[0] = out[1] = s->A; out[2] = out[3] = s->Bev; out[4] = out[5] = s->Bq;
+  out[0] = out[1] = s->A; out[2] = out[3] = s->X + s->Bev; out[4] = out[5] = s->X + s->Bq;
   if (bytes_per_plane) *bytes_per_plane = (uint64_t)s->Nl * 32;
   return SIM_OK;
 }

@@ -12,7 +12,8 @@ import os
 
 import numpy as np
 
-P, Q, CKEYS, MAX_FANOUT = 4, 16, 6, 4
+P, Q, CKEYS, MAX_FANOUT = 4, 64, 6, 4
+Q_HOT = 16  # SIM_Q_HOT: the entries the HIP tick kernel keeps in registers
 DEFAULT_SEED = 0x5EEDC0DE5E4F0001
 
 OK, EINVAL, ENOMEM, EDEVICE, ENOSLOT, ESTATE, ERANGE, ETOOBIG = 0, -1, -2, -3, -4, -5, -6, -7
@@ -53,7 +54,8 @@ class Config(C.Structure):
         "event_ring", "query_ring", "retransmit_mult", "probe_interval", "suspicion_mult",
         "suspicion_max_mult", "indirect_checks", "loss_u32", "intent_timeout", "leave_delay",
         "reap_interval", "reconnect_timeout", "tombstone_timeout", "queue_check_interval", "max_queue_depth",
-        "min_queue_depth", "push_pull_interval", "chunks", "recycle_interval", "pkt_records", "flags", "gossip_to_the_dead", "reconnect_interval")] + [("seed", C.c_uint64)]
+        "min_queue_depth", "push_pull_interval", "chunks", "recycle_interval", "pkt_records", "flags", "gossip_to_the_dead", "reconnect_interval",
+        "ring_overflow", "reserved0")] + [("seed", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -115,7 +117,7 @@ def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, vi
                 suspicion_mult=4, suspicion_max_mult=6, indirect_checks=3, loss=0.0,
                 intent_timeout=0, leave_delay=30, reap_interval=0, reconnect_timeout=432000, tombstone_timeout=432000,
                 queue_check_interval=0, max_queue_depth=4096, min_queue_depth=0, push_pull_interval=0, chunks=0, recycle_interval=0,
-                pkt_records=0, gossip_to_the_dead=0, reconnect_interval=0, tcp_fallback=False, nacks=False, awareness_probe=False, join_sync=False, force_sharded=False, flags=CF_BASELINE_JOINED, seed=DEFAULT_SEED):
+                pkt_records=0, gossip_to_the_dead=0, reconnect_interval=0, ring_overflow=0, tcp_fallback=False, nacks=False, awareness_probe=False, join_sync=False, force_sharded=False, flags=CF_BASELINE_JOINED, seed=DEFAULT_SEED):
     cfg = Config()
     cfg.struct_size = C.sizeof(Config)
     cfg.n_nodes, cfg.vshards, cfg.shard_rank, cfg.shard_count = n_nodes, vshards, shard_rank, shard_count
@@ -130,6 +132,7 @@ def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, vi
     cfg.pkt_records = pkt_records  # 0 = 4 records (one page) per packet; 8 / 12 / 16 = more pages
     cfg.gossip_to_the_dead = gossip_to_the_dead
     cfg.reconnect_interval = reconnect_interval  # Reconnector (base.rs:612-681): 0 = off
+    cfg.ring_overflow = ring_overflow  # overflow rows per de-dup ring and node (a full bucket's further keys); 0 = none
     if awareness_probe:
         cfg.flags |= CF_AWARENESS_PROBE
     if join_sync:

@@ -88,7 +88,7 @@ def run_against_third_model(sim, n, fanout, ops, ticks, joined, rf=False, pp_int
         view = sim.dump(_ffi.ARR_VIEW).reshape(n, n)        # dense view: [subject][observer]
         er = sim.dump(_ffi.ARR_ERING).reshape(RING_EV, n)
         qr = sim.dump(_ffi.ARR_QRING).reshape(RING_Q, n)
-        queue = sim.dump(_ffi.ARR_QUEUE).reshape(n, 16)
+        queue = sim.dump(_ffi.ARR_QUEUE).reshape(n, _ffi.Q)
         assert int(rows["overflow"].sum()) == 0, f"tick {t}: a model bound was hit"
         for qid in trackers.running:                        # what every running query's origin has counted so far, and whether it still listens
             got = sim.query_status(qid)

@@ -64,7 +64,7 @@ def run(sim, n, ops, ticks, joined, **kw):
         view = sim.dump(_ffi.ARR_VIEW).reshape(n, n)        # dense view: [subject][observer]
         er = sim.dump(_ffi.ARR_ERING).reshape(RING_EV, n)
         qr = sim.dump(_ffi.ARR_QRING).reshape(RING_Q, n)
-        queue = sim.dump(_ffi.ARR_QUEUE).reshape(n, 16)
+        queue = sim.dump(_ffi.ARR_QUEUE).reshape(n, _ffi.Q)
         assert int(rows["overflow"].sum()) == 0, f"tick {t}: a model bound was hit"
         # ---- the packets sent this tick
         got = _packets(sim, n, fanout, PG)
