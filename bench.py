@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 # SURVEY.md §8d algorithmic bytes per member-tick (v0 layout): 2R + 2QE + 2fPE + 4(f+2)
 def b_tick_v0(f, p=4):
-    return 2 * 64 + 2 * 16 * 16 + 2 * f * p * 16 + 4 * (f + 2)
+    return 2 * 64 + 2 * 16 * 16 + 2 * f * p * 16 + 4 * (f + 2)   # (Q stays the survey's 16: the bytes a deeper queue moves are not priced)
 
 
 # the same accounting for the frozen layout
@@ -50,6 +50,7 @@ PMC_TRAFFIC = {"krandomnodes": ("profiles/r05_pmc_traffic_krandomnodes.json", "p
                "bijection": ("profiles/r05_pmc_traffic_bijection.json", "profiles/r04_pmc_traffic_bijection.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")}
 # ... and over the launches of the LONG window (its own PMC passes: the bytes a launch moves follow the load of the ticks it covers)
 PMC_TRAFFIC_LONG = {"krandomnodes": ("profiles/r05_pmc_traffic_krandomnodes_long.json",), "bijection": ("profiles/r05_pmc_traffic_bijection_long.json",)}
+PMC_TRAFFIC_SECOND = ("profiles/r06_pmc_traffic_second_load.json",)
 LONG_WINDOW = 300  # ticks of the second timed window (with --steps < 300): long enough to hold a push-pull batch and recycling passes
 # the DEVICE side of the tick kernel (state + queue, handlers + classification, the kernel itself): what a PMC profile is valid for
 KERNEL_SOURCES = [os.path.join("serf_amd", "csrc", f) for f in ("serf_sim_state.inc", "serf_sim_handlers.inc", "serf_sim_tick.inc")]
@@ -83,6 +84,8 @@ def workload(args, n_total, model=None):
               recycle_interval=args.recycle_interval)
     if getattr(args, "pkt_records", 4) != 4:
         kw["pkt_records"] = args.pkt_records
+    if getattr(args, "ring_overflow", 0):
+        kw["ring_overflow"] = args.ring_overflow
     if model == "krandomnodes":  # memberlist's literal kRandomNodes instead of the per-tick bijection (one GPU)
         from serf_amd import _ffi
         kw["flags"] = _ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT
@@ -209,39 +212,87 @@ def cpu_baseline(args, model, parity_ticks, timed=True, seconds_budget=300.0):
 
 
 def second_load(args, lib, dev, torch):
-    """N = 1 only, after the headline run: the same cluster with packets of 16 records (= SIM_Q: a packet carries the
-    whole queue, only the 1 400-byte budget is left) under a heavier evenly spaced load that still stays inside the model
-    bounds (0.35 operations per tick: 1.4 x the headline load; at 0.4 the first seventh key shows up in a ring bucket) — measured the same way (pre-roll, warm-up, HIP events around the launches), reported next to the
-    headline ("report both loads")."""
+    """N = 1 only, after the headline run: SURVEY.md §8d config 3 read the way the reference's packets allow — the same cluster under as
+    many concurrently active rumours as the 1 400-byte packet budget carries (r6: the queue holds 64 entries, a full ring bucket
+    continues in overflow rows — the old bounds of 16 / 6 stopped this load at 0.35 operations per tick).  The benchmark mix's user
+    events average 264 bytes: a rumour has to be sent `retransmit_mult * ceil(log10(N + 1))` = 28 times by every node, a node sends
+    4 packets x 87 sixteen-byte units per tick, so ~1 operation per tick saturates the REFERENCE's own packets at 1 Mi nodes —
+    --second-rate (default 0.8) stays just below.  Packets of 16 records (4 pages): only the byte budget binds.  Measured like the
+    headline (pre-roll, warm-up, HIP events on the launches); `live_rumours` = distinct (kind, subject / key) pairs in the queues
+    at the end of the timed window (one dump of the queue array), `live_records` = distinct records (a suspicion counts once per
+    accuser).  With --second-parity the CPU oracle is rolled through the same ticks and the digests are compared (minutes)."""
     import copy
+
+    import numpy as np
 
     from serf_amd import _ffi
 
     a2 = copy.copy(args)
-    a2.pkt_records, a2.rate, a2.warmup, a2.steps = 16, args.second_rate, 20, 100
-    kw, ops = workload(a2, args.nodes_per_gpu)
+    a2.pkt_records, a2.rate, a2.preroll, a2.warmup, a2.steps = 16, args.second_rate, args.second_preroll, 20, args.second_steps
+    a2.ring_overflow = args.second_ring_overflow
+    model = "bijection" if args.fanout_model == "bijection" else "krandomnodes"   # the headline model
+    kw, ops = workload(a2, args.nodes_per_gpu, model)
     sim = _ffi.Sim(lib, _ffi.make_config(args.nodes_per_gpu, **kw))
     sim.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     for o in ops:
         sim.inject(*o)
     sim.step(a2.preroll + a2.warmup)
     sim.sync()
+    d0 = sim.digest() if args.second_parity else None
     sim.profile(1)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev0.record()
     sim.step(a2.steps)
+    ev1.record()
     sim.sync()
     dt = time.perf_counter() - t0
     (ms, mn, mx), cnt = sim.profile_read_stats()
     sim.profile(0)
+    d1 = sim.digest() if args.second_parity else None
     cs = sim.cluster_stats()
-    out = {"pkt_records": 16, "rate": a2.rate, "steps": a2.steps, "value": args.nodes_per_gpu * a2.steps / dt, "unit": "member-ticks/s",
-           "ms_per_step": dt / a2.steps * 1e3, "kernel_ms": ms / max(1, cnt), "kernel_ms_min": mn, "kernel_ms_max": mx,
+    kern_s = ms / 1e3 / max(1, cnt)
+    # the load, from the queues themselves
+    q = sim.dump(_ffi.ARR_QUEUE)
+    live = q[q["meta"] != 0xFFFFFFFF]
+    kinds = ((live["meta"] >> 4) & 15).astype(np.uint64)
+    live_rumours = int(len(np.unique(live["key"].astype(np.uint64) | (kinds << 32))))
+    live_records = int(len(np.unique(np.stack([live["key"].astype(np.uint64) | (kinds << 32), live["val"]], 1), axis=0)))
+    del q, live
+    f, P = args.fanout, 16
+    bt = b_tick_v0(f, P)
+    alg = args.nodes_per_gpu * bt / kern_s / 1e9
+    tr = None
+    for rel in PMC_TRAFFIC_SECOND:
+        path = os.path.join(ROOT, rel)
+        if os.path.exists(path):
+            try:
+                doc = json.load(open(path))
+                if doc.get("kernel_source_sha16") == kernel_source_sha16() and doc.get("rate") == a2.rate and doc.get("steps") == a2.steps:
+                    tr = doc.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+            break
+    out = {"pkt_records": 16, "fanout_model": model, "rate": a2.rate, "steps": a2.steps, "preroll": a2.preroll, "ring_overflow": a2.ring_overflow,
+           "value": args.nodes_per_gpu * a2.steps / dt, "unit": "member-ticks/s",
+           "ms_per_step": dt / a2.steps * 1e3, "stream_ms_per_step": ev0.elapsed_time(ev1) / a2.steps,
+           "kernel_ms": kern_s * 1e3, "kernel_ms_min": mn, "kernel_ms_max": mx,
+           "b_tick_bytes": bt, "achieved": alg, "frac": alg / 8000.0, "traffic": tr, "frac_measured": (tr / kern_s / 1e9 / 8000.0) if tr else None,
            "model_bound_drops": int(cs["overflow"]) + int(cs["ops_dropped"]),
+           "live_rumours": live_rumours, "live_records": live_records,
            "records_per_packet": round(cs["inbox_records"] / (args.fanout * args.nodes_per_gpu), 3),
            "queued_per_node": round(sum(cs["queued"]) / args.nodes_per_gpu, 3), "deepest_queue": int(cs["max_queue"]),
-           "what": f"same cluster and mix, {a2.rate} API ops/tick, 16 records per packet (the whole 16-slot queue per packet: the byte budget of "
-                   "1 400 B is the only packet bound left); above this rate the 6-key ring buckets and the 16-slot pooled queue — model "
-                   "bounds, counted — start to drop (DESIGN.md §7)"}
+           "what": f"SURVEY §8d config 3 at the packet budget: same cluster and mix, {a2.rate} API ops/tick (~1 saturates the reference's 1 400-byte "
+                   "packets at this size and mix), 16 records per packet, queue of 64 (16 hot + deep_queue_kernel), ring buckets with "
+                   f"{a2.ring_overflow} overflow rows; frac = B_tick(f, P = 16) x nodes / tick-kernel time (the deep kernel's time is in ms_per_step)"}
+    if args.second_parity:
+        progress_ticks = [a2.preroll + a2.warmup, a2.preroll + a2.warmup + a2.steps]
+        _, dig = cpu_baseline(a2, model, progress_ticks, timed=False, seconds_budget=3600.0)
+        ok = [tuple(dig[t]) == tuple(d) for t, d in zip(progress_ticks, (d0, d1))]
+        out["digest_match"] = all(ok)
+        out["parity"] = {"ticks": progress_ticks, "digest_match_per_tick": ok, "gpu": [[f"{x:016x}" for x in d] for d in (d0, d1)],
+                         "oracle": [[f"{x:016x}" for x in dig[t]] for t in progress_ticks]}
     sim.close()
     return out
 
@@ -262,7 +313,12 @@ def parse_args(argv=None):
     ap.add_argument("--probe-interval", type=int, default=5, help="memberlist probe interval in ticks (0 = SWIM layer off)")
     ap.add_argument("--push-pull-interval", type=int, default=150, help="memberlist push_pull_interval in ticks before log2(N) scaling (0 = off)")
     ap.add_argument("--recycle-interval", type=int, default=75, help="view-slot recycling pass every this many ticks (0 = never)")
-    ap.add_argument("--second-rate", type=float, default=0.35, help="API operations per tick of the second measured load (16 records per packet)")
+    ap.add_argument("--second-rate", type=float, default=0.8, help="API operations per tick of the second measured load (16 records per packet; ~1 saturates the 1 400-byte packets at 1 Mi nodes)")
+    ap.add_argument("--second-preroll", type=int, default=160, help="untimed ticks of the second load before its 20 warm-up ticks")
+    ap.add_argument("--second-steps", type=int, default=60, help="timed ticks of the second load")
+    ap.add_argument("--second-ring-overflow", type=int, default=8, help="overflow rows per de-dup ring of the second load's cluster")
+    ap.add_argument("--second-parity", action="store_true", help="roll the CPU oracle through the second load's ticks as well and compare digests (minutes of CPU)")
+    ap.add_argument("--ring-overflow", type=int, default=0, help="overflow rows per de-dup ring and node of the headline cluster (sim_config.ring_overflow)")
     ap.add_argument("--fanout-model", choices=["both", "krandomnodes", "bijection"], default="both",
                     help="N = 1: which fan-out model(s) to measure.  both (default): memberlist's literal kRandomNodes — the reference's peer "
                          "selection, the HEADLINE — and the per-tick bijection next to it (fanout_models)")

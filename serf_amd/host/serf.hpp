@@ -61,6 +61,7 @@ struct Options {
     c.queue_check_interval = 150; c.max_queue_depth = 4096; c.min_queue_depth = 0;  // options.rs:512-514
     c.push_pull_interval = 150;                    // lan(): 30 s
     c.reconnect_interval = 150;                    // options.rs:507 reconnect_interval 30 s (Reconnector, base.rs:612-681)
+    c.ring_overflow = 8;                           // a de-dup bucket is a Vec in the reference (base.rs:801-813): 6 keys + 8 rows of 6 per ring here
     c.flags = SIM_CF_BASELINE_JOINED | SIM_CF_TCP_FALLBACK | SIM_CF_NACKS;  // memberlist lan(): disable_tcp_pings = false, nacks (protocol >= 4)
     c.seed = SIM_DEFAULT_SEED;
   }
@@ -77,6 +78,7 @@ struct Options {
   Options& with_packet_loss(double p) { c.loss_u32 = p >= 1.0 ? 0xFFFFFFFFu : (uint32_t)(p * 4294967296.0); return *this; }
   Options& with_disable_tcp_pings(bool off) { c.flags = off ? (c.flags & ~SIM_CF_TCP_FALLBACK) : (c.flags | SIM_CF_TCP_FALLBACK); return *this; }  // memberlist Options::disable_tcp_pings
   Options& with_reconnect_interval(uint32_t ticks) { c.reconnect_interval = ticks; return *this; }  // options.rs:162 (0 = no Reconnector)
+  Options& with_ring_overflow(uint32_t rows) { c.ring_overflow = rows; return *this; }  // overflow rows per de-dup ring and node (0: a full bucket treats new keys as seen)
   Options& with_seed(uint64_t s) { c.seed = s; return *this; }
 };
 

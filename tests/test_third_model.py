@@ -16,7 +16,7 @@ from tests import _scenario as sc
 RING_EV, RING_Q, PG = 64, 32, 4   # packets of 4 pages = 16 records: they carry a node's whole queue, nothing waits for a turn
 
 
-def run_against_third_model(sim, n, fanout, ops, ticks, joined, rf=False, pp_interval=0, loss=0.0):
+def run_against_third_model(sim, n, fanout, ops, ticks, joined, rf=False, pp_interval=0, loss=0.0, X=0):
     nodes = [tm.Node(i, n, RING_EV, RING_Q, joined) for i in range(n)]
     # the query path end to end: the origin's trackers and the responders' acks / responses, relays and loss included
     trackers = tm.QueryTrackers(_ffi.DEFAULT_SEED, n, loss)
@@ -86,8 +86,8 @@ def run_against_third_model(sim, n, fanout, ops, ticks, joined, rf=False, pp_int
         # ---- compare
         rows = sim.dump(_ffi.ARR_ROWS)
         view = sim.dump(_ffi.ARR_VIEW).reshape(n, n)        # dense view: [subject][observer]
-        er = sim.dump(_ffi.ARR_ERING).reshape(RING_EV, n)
-        qr = sim.dump(_ffi.ARR_QRING).reshape(RING_Q, n)
+        er = sim.dump(_ffi.ARR_ERING).reshape(X + RING_EV, n)   # (X = sim_config.ring_overflow: the rings' overflow rows come first)
+        qr = sim.dump(_ffi.ARR_QRING).reshape(X + RING_Q, n)
         queue = sim.dump(_ffi.ARR_QUEUE).reshape(n, _ffi.Q)
         assert int(rows["overflow"].sum()) == 0, f"tick {t}: a model bound was hit"
         for qid in trackers.running:                        # what every running query's origin has counted so far, and whether it still listens
@@ -112,8 +112,14 @@ def run_against_third_model(sim, n, fanout, ops, ticks, joined, rf=False, pp_int
                     assert ((bits >> 6) & 3, int(e["ltime"])) == ((it[0], it[1]) if it else (0, 0)), f"{w} subject {s} intent"
             for ring, buf, name in ((er, x.event_buf, "event"), (qr, x.query_buf, "query")):
                 for j, want in enumerate(buf):
-                    b = ring[j, i]
+                    b = ring[X + j, i]
                     got = [int(v) for v in b["keys"] if v]
+                    if len(got) == len(b["keys"]):      # a full bucket continues in its overflow rows, in row order (include/serf_sim.h sim_bucket)
+                        for o in ring[:X, i]:
+                            if o["ltime"] == 0:
+                                break
+                            if o["ltime"] == j + 1:
+                                got += [int(v) for v in o["keys"] if v]
                     if want is None:
                         assert not got, f"{w} {name} bucket {j}"
                     else:
@@ -226,3 +232,21 @@ def test_hip_matches_the_third_model(hiplib, seed, n, fanout, joined, rf):
               flags=(_ffi.CF_BASELINE_JOINED if joined else 0) | (_ffi.CF_RANDOM_FANOUT if rf else 0))
     sim = _ffi.Sim(hiplib, _ffi.make_config(n, **kw))
     run_against_third_model(sim, n, fanout, _schedule(n, 70, seed, joined), 70, joined, rf)
+
+
+@pytest.mark.parametrize("seed,n,fanout,rf", [(31, 48, 3, False), (32, 64, 4, True)])
+def test_beyond_the_old_bounds_against_the_third_model(seed, n, fanout, rf):
+    # (r6) the third model's Vec-per-bucket and unbounded queues against the oracle's overflow rows and 64-slot queue: a burst of user
+    # events and queries of ONE Lamport time (20 + 12 of them in one tick: one bucket each, 6 keys in place, the rest in overflow rows)
+    # on top of a load that takes queues past the old bound of 16
+    X = 4
+    kw = dict(fanout=fanout, view_slots=0, event_ring=RING_EV, query_ring=RING_Q, leave_delay=4, pkt_records=4 * PG, ring_overflow=X,
+              flags=_ffi.CF_BASELINE_JOINED | (_ffi.CF_RANDOM_FANOUT if rf else 0))
+    sim = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw))
+    ops = sc.schedule(n, 40, rate=1.2, seed=seed, mix=(0.6, 0.25, 0.15, 0.0, 0.0), max_member_subjects=n // 3)
+    ops += [(5, _ffi.OP_USER_EVENT, (7 * i + 1) % n, 9000 + i, 32 + i) for i in range(20)]
+    ops += [(9, _ffi.OP_QUERY, (5 * i + 2) % n, 10340 + i, _ffi.F_ACK) for i in range(12)]
+    ops.sort(key=lambda o: o[0])
+    run_against_third_model(sim, n, fanout, ops, 60, True, rf, X=X)
+    er = sim.dump(_ffi.ARR_ERING).reshape(X + RING_EV, n)
+    assert (er[:X]["ltime"] != 0).any(), "the burst was meant to spill into the overflow rows"

@@ -31,13 +31,17 @@ def run_one(path, args, ticks):
     sim.step(args.preroll)
     sim.sync()
     sim.profile(1)
+    import time
+    t0 = time.perf_counter()
     sim.step(ticks)
+    sim.sync()
+    step_us = (time.perf_counter() - t0) / ticks * 1e6   # the whole step: graph build, deep-queue kernel, launch gaps
     (tot, mn, mx), cnt = sim.profile_read_stats()
     sim.profile(0)
     dig = sim.digest()
     drops = sim.cluster_stats()["overflow"]
     sim.close()
-    return tot / cnt * 1e3, mn * 1e3, mx * 1e3, dig, drops
+    return tot / cnt * 1e3, mn * 1e3, mx * 1e3, dig, drops, step_us
 
 
 def main():
@@ -46,22 +50,36 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--nodes", type=int, default=1 << 20)
     ap.add_argument("--fanout-model", default="bijection", choices=["bijection", "krandomnodes"])
+    ap.add_argument("--rate", type=float, default=None, help="API operations per tick (default: the bench's)")
+    ap.add_argument("--pkt-records", type=int, default=None)
+    ap.add_argument("--ring-overflow", type=int, default=None)
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
-    args = bench.parse_args(["--nodes-per-gpu", str(a.nodes), "--fanout-model", a.fanout_model])
+    extra = []
+    if a.rate is not None:
+        extra += ["--rate", str(a.rate)]
+    if a.pkt_records is not None:
+        extra += ["--pkt-records", str(a.pkt_records)]
+    if a.ring_overflow is not None:
+        extra += ["--ring-overflow", str(a.ring_overflow)]
+    args = bench.parse_args(["--nodes-per-gpu", str(a.nodes), "--fanout-model", a.fanout_model] + extra)
     res = {p: [] for p in a.libs}
+    steps = {p: [] for p in a.libs}
     digs = {}
     for r in range(a.rounds):
         for p in a.libs:
-            mean, mn, mx, dig, drops = run_one(os.path.join(ROOT, p) if not os.path.isabs(p) else p, args, a.ticks)
+            mean, mn, mx, dig, drops, step_us = run_one(os.path.join(ROOT, p) if not os.path.isabs(p) else p, args, a.ticks)
             res[p].append(mean)
+            steps[p].append(step_us)
             digs[p] = dig
-            print(f"round {r} {p}: {mean:.1f} us/tick (min {mn:.1f} max {mx:.1f}) drops {drops}", flush=True)
+            print(f"round {r} {p}: kernel {mean:.1f} us/tick (min {mn:.1f} max {mx:.1f}), step {step_us:.1f} us, drops {drops}", flush=True)
     ref = digs[a.libs[0]]
     out = {"ticks": a.ticks, "nodes": a.nodes, "results": {}}
     for p in a.libs:
         v = sorted(res[p])
-        out["results"][p] = {"us_per_tick_median": v[len(v) // 2], "us_per_tick_all": res[p], "same_digest_as_first": digs[p] == ref}
+        sv = sorted(steps[p])
+        out["results"][p] = {"us_per_tick_median": v[len(v) // 2], "us_per_tick_all": res[p], "step_us_median": sv[len(sv) // 2], "step_us_all": steps[p],
+                             "same_digest_as_first": digs[p] == ref}
     print(json.dumps(out))
 
 
