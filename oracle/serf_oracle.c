@@ -437,6 +437,23 @@ static inline void rec_clear(sim_record* r) {
   r->meta = SIM_META_EMPTY;
   r->val = 0;
 }
+/* entries in a node's queue (sorted: the empty slots come last) — the sorts below touch these only: with SIM_Q = 64 a qsort of
+ * the whole pool on every packet was most of the oracle's time */
+static inline uint32_t q_live(const sim_record* q) {
+  uint32_t n = 0;
+  while (n < SIM_Q && q[n].meta != SIM_META_EMPTY) ++n;
+  return n;
+}
+/* restore the order of the first n slots (some were re-keyed or emptied in place: nearly sorted — an insertion sort; meta values
+ * are distinct, so the result is the one qsort gave) */
+static inline void q_resort(sim_record* q, uint32_t n) {
+  for (uint32_t i = 1; i < n; ++i) {
+    sim_record x = q[i];
+    uint32_t j = i;
+    while (j > 0 && q[j - 1].meta > x.meta) { q[j] = q[j - 1]; --j; }
+    q[j] = x;
+  }
+}
 static void queue_renorm(sim_row* row, sim_record* q) {
   /* seq := rank by age (older = smaller); next_seq := count */
   uint32_t seqs[SIM_Q], n = 0;
@@ -449,7 +466,7 @@ static void queue_renorm(sim_row* row, sim_record* q) {
     q[i].meta = (q[i].meta & ~(0x3FFu << 8)) | ((1023u - rank) << 8);
   }
   row->next_seq = n;
-  qsort(q, SIM_Q, sizeof(sim_record), rec_cmp);
+  q_resort(q, q_live(q)); /* (order-preserving: nothing moves) */
 }
 /* queue_broadcast (B.1), one record at a time in arrival order: the record gets the next id; a
  * memberlist (class 0) broadcast first invalidates queued class-0 broadcasts about the same node;
@@ -467,17 +484,19 @@ static void q_push(nctx* c, uint32_t key, uint32_t wmeta, uint64_t val) {
   r.key = key;
   r.meta = (cls << 30) | (wmeta & SIM_META_WIRE_MASK) | ((1023u - seq) << 8);
   r.val = val;
+  uint32_t n = q_live(q);
   if (cls == 0) {
     int hit = 0;
-    for (uint32_t i = 0; i < SIM_Q; ++i)
-      if (q[i].meta != SIM_META_EMPTY && (q[i].meta >> 30) == 0 && q[i].key == key) { rec_clear(&q[i]); hit = 1; }
-    if (hit) qsort(q, SIM_Q, sizeof(sim_record), rec_cmp);
+    for (uint32_t i = 0; i < n && (q[i].meta >> 30) == 0; ++i) /* class 0 drains first: its entries lead the queue */
+      if (q[i].key == key) { rec_clear(&q[i]); hit = 1; }
+    if (hit) { q_resort(q, n); n = q_live(q); }
   }
-  if (q[SIM_Q - 1].meta != SIM_META_EMPTY) { /* full */
+  if (n == SIM_Q) { /* full */
     row->overflow++;
     if (r.meta > q[SIM_Q - 1].meta) return; /* the newcomer drains last: it is the one dropped */
+    n = SIM_Q - 1;
   }
-  uint32_t i = SIM_Q - 1;
+  uint32_t i = n;
   while (i > 0 && q[i - 1].meta > r.meta) { q[i] = q[i - 1]; --i; }
   q[i] = r;
 }
@@ -508,9 +527,9 @@ static void queue_emit(sim_row* row, sim_record* q, uint32_t limit, uint32_t P, 
   (void)row;
   memset(out, 0, (size_t)((P + SIM_P - 1) / SIM_P) * sizeof *out);
   uint32_t free_u = SIM_PKT_UNITS, cnt = 0;
-  for (uint32_t i = 0; i < SIM_Q && cnt < P; ++i) {
+  const uint32_t n = q_live(q);
+  for (uint32_t i = 0; i < n && cnt < P; ++i) {
     sim_record* r = &q[i];
-    if (r->meta == SIM_META_EMPTY) break;
     uint32_t len = SIM_META_LEN64(r->meta);
     if (len > free_u) continue;
     free_u -= len;
@@ -520,7 +539,7 @@ static void queue_emit(sim_row* row, sim_record* q, uint32_t limit, uint32_t P, 
     if (t >= limit) rec_clear(r);
     else r->meta = (r->meta & ~(0x3Fu << 24)) | (t << 24);
   }
-  qsort(q, SIM_Q, sizeof(sim_record), rec_cmp);
+  if (cnt) q_resort(q, n);
 }
 
 /* Reaper bookkeeping: row->reap_next is the earliest tick at which some entry of this node has
@@ -1081,13 +1100,14 @@ static void queue_check(nctx* c) {
     if (max < s->cfg.min_queue_depth) max = s->cfg.min_queue_depth;
   }
   int changed = 0;
+  const uint32_t n = q_live(c->q);
   for (uint32_t cls = 1; cls <= 3; ++cls) {
     uint32_t cnt = 0;
-    for (uint32_t i = 0; i < SIM_Q; ++i) cnt += c->q[i].meta != SIM_META_EMPTY && (c->q[i].meta >> 30) == cls;
-    for (uint32_t i = SIM_Q; i-- > 0 && cnt > max;)
+    for (uint32_t i = 0; i < n; ++i) cnt += c->q[i].meta != SIM_META_EMPTY && (c->q[i].meta >> 30) == cls;
+    for (uint32_t i = n; i-- > 0 && cnt > max;)
       if (c->q[i].meta != SIM_META_EMPTY && (c->q[i].meta >> 30) == cls) { rec_clear(&c->q[i]); --cnt; changed = 1; }
   }
-  if (changed) qsort(c->q, SIM_Q, sizeof(sim_record), rec_cmp);
+  if (changed) q_resort(c->q, n);
 }
 
 /* SerfDelegate::notify_message dispatch: delegate.rs:183-300 */
