@@ -46,10 +46,11 @@ def b_tick_layout(f):
     return 2 * 64 + (2 * 16 * 4 + 4 * 16) + (48 + 4) + f * (48 + 4) + f * 4 * (4 + 16)
 
 
-PMC_TRAFFIC = {"krandomnodes": ("profiles/r05_pmc_traffic_krandomnodes.json", "profiles/r04_pmc_traffic_krandomnodes.json"),  # newest first
-               "bijection": ("profiles/r05_pmc_traffic_bijection.json", "profiles/r04_pmc_traffic_bijection.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")}
+PMC_TRAFFIC = {"krandomnodes": ("profiles/r06_pmc_traffic_krandomnodes.json", "profiles/r05_pmc_traffic_krandomnodes.json", "profiles/r04_pmc_traffic_krandomnodes.json"),  # newest first
+               "bijection": ("profiles/r06_pmc_traffic_bijection.json", "profiles/r05_pmc_traffic_bijection.json", "profiles/r04_pmc_traffic_bijection.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")}
 # ... and over the launches of the LONG window (its own PMC passes: the bytes a launch moves follow the load of the ticks it covers)
-PMC_TRAFFIC_LONG = {"krandomnodes": ("profiles/r05_pmc_traffic_krandomnodes_long.json",), "bijection": ("profiles/r05_pmc_traffic_bijection_long.json",)}
+PMC_TRAFFIC_LONG = {"krandomnodes": ("profiles/r06_pmc_traffic_krandomnodes_long.json", "profiles/r05_pmc_traffic_krandomnodes_long.json"),
+                    "bijection": ("profiles/r06_pmc_traffic_bijection_long.json", "profiles/r05_pmc_traffic_bijection_long.json")}
 PMC_TRAFFIC_SECOND = ("profiles/r06_pmc_traffic_second_load.json",)
 LONG_WINDOW = 300  # ticks of the second timed window (with --steps < 300): long enough to hold a push-pull batch and recycling passes
 # the DEVICE side of the tick kernel (state + queue, handlers + classification, the kernel itself): what a PMC profile is valid for

@@ -8,7 +8,7 @@ probability `--loss`.  Probes that fail on live nodes (0.26 per tick at 1 Mi nod
 are refuted.  `--rumors` user events are injected at regular intervals from random running nodes; for each the number of
 gossip rounds until >= 99 % of the running nodes have applied it is recorded.  The run is valid only if no model bound was
 hit (`model_bound_drops` == 0).  The pace of the churn is set by the model's per-node capacity: SIM_S = 16 suspicion timers
-(a crashed node is a running suspicion at every node for ~125 ticks), SIM_Q = 16 queue slots.
+(a crashed node is a running suspicion at every node for ~125 ticks); the queue holds 64 entries (r6).
 
 Needs an MI355X.  Writes one JSON (default profiles/r03_config4_churn5_loss1_swim.json)."""
 import argparse
@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--nacks", action="store_true", help="memberlist's nack accounting for the health score")
     ap.add_argument("--reconnect-interval", type=int, default=0, help="Reconnector period in ticks (reference: 30 s = 150; 0 = off)")
     ap.add_argument("--gossip-to-the-dead", type=int, default=0, help="memberlist gossip_to_the_dead_time in ticks (lan: 30 s = 150; 0 = off)")
+    ap.add_argument("--ring-overflow", type=int, default=8, help="overflow rows per de-dup ring and node (sim_config.ring_overflow)")
     ap.add_argument("--vshards", type=int, default=1, help="virtual shards of the fan-out map (the shape of one rank's share of a V-way sharded cluster)")
     ap.add_argument("--chunks", type=int, default=0, help="sender chunks per shard (the chunk-wise exchange's layout)")
     ap.add_argument("--lib", default=None, help="oracle: run the CPU oracle instead (small sizes; for checking the tool)")
@@ -62,7 +63,7 @@ def main():
               probe_interval=args.probe_interval, push_pull_interval=args.push_pull_interval, loss=args.loss,
               reap_interval=75, queue_check_interval=150, recycle_interval=args.recycle_interval, pkt_records=args.pkt_records,
               reconnect_interval=args.reconnect_interval, gossip_to_the_dead=args.gossip_to_the_dead,
-              tcp_fallback=args.tcp_fallback, nacks=args.nacks, vshards=args.vshards, chunks=args.chunks,
+              tcp_fallback=args.tcp_fallback, nacks=args.nacks, vshards=args.vshards, chunks=args.chunks, ring_overflow=args.ring_overflow,
               **({"flags": _ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT} if args.random_fanout else {}),
               join_sync=True)   # Serf::join = memberlist.join: the re-joining node syncs with a peer (SIM_CF_JOIN_SYNC)
     sim = _ffi.Sim(lib, _ffi.make_config(n, **kw))
