@@ -127,3 +127,63 @@ def test_checkpoint_with_deep_queues(oracle, hiplib):
     sc.assert_same_state(g2, o, "restored")
     for s in (g, o, g2, o2):
         s.close()
+
+
+@pytest.mark.parametrize("V,C,n", [(4, 1, 2048), (4, 2, 4096), (8, 1, 4096)])
+def test_a_shard_packs_its_own_slab_in_place(oracle, hiplib, V, C, n):
+    # (r6) When the library issues the round's exchange itself (sim_exchange_init), the slab a shard addresses to ITSELF is packed straight
+    # into its place in the receive buffer and left out of the group of sends / receives.  RCCL refuses several ranks on one device, so the
+    # V > 1 form is driven here through the test hook that switches the same code on without a communicator: V shard handles on one
+    # GPU, device copies for every slab but the diagonal, against the oracle's slices.
+    import ctypes as C_
+    import torch
+
+    from tests.test_parity_gpu import _push_pull_on_one_gpu, _suspicions_on_one_gpu
+
+    m = n // V
+    kw = dict(fanout=4, view_slots=96, event_ring=16, query_ring=8, leave_delay=6, probe_interval=4, loss=0.02, push_pull_interval=3,
+              pkt_records=8, ring_overflow=4, flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT)
+    ref = _ffi.Sim(oracle, _ffi.make_config(n, vshards=V, **kw))
+    shards, send, recv = [], [], []
+    for g in range(V):
+        s = _ffi.Sim(hiplib, _ffi.make_config(n, vshards=V, shard_rank=g, shard_count=V, chunks=C if C > 1 else 0, **kw))
+        kind, planes, pb, rb = s.exchange_layout()
+        send.append(torch.zeros(pb, dtype=torch.uint8, device="cuda"))
+        recv.append([torch.zeros(rb, dtype=torch.uint8, device="cuda") for _ in range(2 if C > 1 else 1)])
+        s.bind_exchange3(send[-1].data_ptr(), pb, recv[-1][0].data_ptr(), recv[-1][-1].data_ptr(), rb)
+        assert hiplib.dll.sim_t_self_direct(s.h, C_.c_int(1)) == 0
+        shards.append(s)
+    ops = sc.schedule(n, 25, rate=2.5, seed=9, max_member_subjects=40)
+    for s in shards + [ref]:
+        sc.apply_schedule(s, ops)
+    reg = send[0].numel() // C
+    slab = reg // V
+    for t in range(50):
+        for s in shards:
+            s.step_begin()
+        if shards[0].pp_due():
+            _push_pull_on_one_gpu(shards)
+        into = [r[shards[0].tick & 1] if C > 1 else r[0] for r in recv]
+        for c in range(C):
+            for s in shards:
+                s.step_chunk(c)
+                s.sync()
+            for g in range(V):
+                for src in range(V):
+                    if src != g:   # the diagonal never travels: shard g packed it into `into[g]` itself
+                        into[g][c * reg + src * slab:c * reg + (src + 1) * slab].copy_(send[src][c * reg + g * slab:c * reg + (g + 1) * slab])
+        for s in shards:
+            s.step_end()
+            s.sync()
+        _suspicions_on_one_gpu(shards)
+        torch.cuda.synchronize()
+        ref.step(1)
+        if t % 7 == 0 or t == 49:
+            for g, s in enumerate(shards):
+                for which in (_ffi.ARR_ROWS, _ffi.ARR_QUEUE):
+                    a, b = s.dump(which), ref.dump(which)
+                    per = len(b) // n
+                    i = sc.first_diff(a, b[g * m * per:(g + 1) * m * per])
+                    assert i is None, f"shard {g} array {which} element {i} differs at tick {t}"
+    for s in shards + [ref]:
+        s.close()

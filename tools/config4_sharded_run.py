@@ -9,7 +9,11 @@ f * 64 * M * (V - 1) / V bytes per shard and round (+ 2 %), and rumours converge
 (eight shards take turns on one GPU).  The churn runs at the pace the view slots allow (one crash per `--churn-every` ticks, each node
 down `--down` ticks, then Serf::join): a fraction of configs[4]'s 5 % in a run of this length — said in the JSON.
 
-Needs an MI355X.  Writes one JSON (default profiles/r05_config4_16m_8shards_krandomnodes.json)."""
+(r6) The pace of the churn is set by SIM_S = 16 suspicion timers per node (a crashed node is a running suspicion at every node for ~125
+ticks), not by batching: 5 % of 16 Mi nodes at one crash per 12 ticks would be 1.0e7 cluster ticks of 25 ms — the full dose is run on the
+headline model at 2 Mi nodes (tools/config4_run.py, profiles/r06_config4_2m_krandomnodes_churn5_loss1.json).
+
+Needs an MI355X.  Writes one JSON (default profiles/r06_config4_16m_8shards_krandomnodes.json)."""
 import argparse
 import json
 import os
@@ -31,7 +35,7 @@ def main():
     ap.add_argument("--loss", type=float, default=0.01)
     ap.add_argument("--view-slots", type=int, default=128)
     ap.add_argument("--max-rounds", type=int, default=60)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_config4_16m_8shards_krandomnodes.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_config4_16m_8shards_krandomnodes.json"))
     args = ap.parse_args()
 
     import numpy as np
@@ -45,7 +49,7 @@ def main():
     n, V = args.nodes, args.shards
     m = n // V
     kw = dict(fanout=4, view_slots=args.view_slots, event_ring=64, query_ring=32, probe_interval=5, push_pull_interval=150, loss=args.loss,
-              reap_interval=75, queue_check_interval=150, pkt_records=16, tcp_fallback=True, nacks=True, join_sync=True,
+              reap_interval=75, queue_check_interval=150, pkt_records=16, tcp_fallback=True, nacks=True, join_sync=True, ring_overflow=8,
               flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT)
     t0 = time.perf_counter()
     shards, send, recv = [], [], []
