@@ -429,7 +429,7 @@ def compact(out):
     if out.get("exchange"):
         x = out["exchange"]
         line["exchange"] = {k: _r(x.get(k)) for k in ("chunks", "exchange_ms", "kernel_ms", "serial_ms_per_step", "overlapped_ms_per_step",
-                                                      "bytes_leaving_gpu_per_tick")}
+                                                      "host_ms_per_step", "bytes_leaving_gpu_per_tick")}
     if out.get("distributed"):
         line["distributed"] = {k: out["distributed"].get(k) for k in ("backend", "world_size")}
     line["detail_file"] = DETAIL_FILE
@@ -611,7 +611,14 @@ def run(args, lib=None, dev=None, backend="nccl"):
             t0 = time.perf_counter()
             ev0, ev1 = Event(enable_timing=True), Event(enable_timing=True)
             ev0.record()
-            sim.step(k)
+            if os.environ.get("SERF_BENCH_CPROFILE"):  # where the host's share goes (measurements: tools/gpu/r6_onerank_ab.sh)
+                import cProfile, pstats
+                pr = cProfile.Profile()
+                pr.runcall(sim.step, k)
+                pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(30)
+            else:
+                sim.step(k)
+            host = time.perf_counter() - t0  # the host's share: every launch of the k steps has been enqueued (nothing waited for)
             ev1.record()
             barrier()
             dt = time.perf_counter() - t0
@@ -623,7 +630,7 @@ def run(args, lib=None, dev=None, backend="nccl"):
             (ms, mn, mx), cnt = raw.profile_read_stats()
             raw.profile(False)
             kern_s = ms / 1e3 / max(1, cnt) if ms > 0 else ev_ms / 1e3 / k  # (the oracle behind a CPU test has no kernel)
-            return {"dt": dt, "ev_ms": ev_ms, "kern_s": kern_s, "kmin": mn, "kmax": mx, "kn": int(cnt), "every": profile_every}
+            return {"dt": dt, "ev_ms": ev_ms, "kern_s": kern_s, "kmin": mn, "kmax": mx, "kn": int(cnt), "every": profile_every, "host_s": host}
 
         m = {"model": model, "ops": ops}
         # ---- untimed: pre-roll to the stationary load, then the contract's warm-up ----
@@ -750,7 +757,7 @@ def run(args, lib=None, dev=None, backend="nccl"):
                "kernel_launches": t["kn"],
                "kernel_timing": f"HIP event pair on every {every}{'th' if every > 1 else 'st'} tick_kernel dispatch of the timed region "
                                 "(hipExtLaunchKernelGGL start/stop events, on the launch stream)",
-               "stream_ms_per_step": t["ev_ms"] / args.steps,
+               "stream_ms_per_step": t["ev_ms"] / args.steps, "host_ms_per_step": t["host_s"] / args.steps * 1e3,
                "algorithmic": {"b_tick_bytes": bt, "achieved": algorithmic, "frac": algorithmic / 8000.0,
                                "what": "SURVEY.md §8d B_tick(f) = 2R + 2QE + 2fPE + 4(f+2) x nodes / kernel time"},
                "traffic_over_algorithmic": (traffic / (args.nodes_per_gpu * bt)) if traffic else None,
@@ -785,6 +792,7 @@ def run(args, lib=None, dev=None, backend="nccl"):
                            "collective": ("equal-split all-to-all of packed slabs (SIM_XCHG_PACKED: (target, sender, slot)-sorted 64-byte cells, "
                                           "one count byte per target; mean + 12 sigma of room per slab)") if packed else "equal-split all-to-all per chunk",
                            "serial_ms_per_step": m["serial_ms"], "overlapped_ms_per_step": m["timed"]["dt"] / args.steps * 1e3,
+                           "host_ms_per_step": m["timed"]["host_s"] / args.steps * 1e3,  # the host's enqueue time per tick (sharded: the Python loop of serf_amd/shard.py)
                            "bytes_per_peer": xb // world, "bytes_per_gpu_per_tick": xb,
                            "bytes_leaving_gpu_per_tick": xb // world * (world - 1),
                            "bytes_arriving_per_gpu_per_tick": xb // world * (world - 1),
