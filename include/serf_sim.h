@@ -614,8 +614,12 @@ int sim_exchange_layout(const sim_handle* h, uint32_t* kind, uint32_t* planes, s
  *                                         bytes_per_chunk / V — go out and come in as ONE group of V ncclSend + V ncclRecv on the
  *                                         library's exchange stream, which waits for that chunk's launch only: chunk c travels
  *                                         while chunk c + 1 computes.  Packets sent during tick t land in recv[t & 1].
+ *                                         (r6) With ONE chunk per tick there is no later launch to travel beside: the group is issued
+ *                                         on the handle's own stream, behind the pack — nothing hops between two streams.  The
+ *                                         slab a shard addresses to itself never travels (it is packed in place).
  *   sim_exchange_wait(h)                  the handle's stream waits (on the device, no host wait) for every exchange issued so
- *                                         far; sim_step_begin does it by itself before the next tick reads the packets.
+ *                                         far; sim_step_begin, sim_sync and every call that reads the packets in flight (digest,
+ *                                         dump, checkpoint, recycling scan) do it by themselves.
  *   sim_exchange_library(buf, cap)        "RCCL <major>.<minor>.<patch>" of the library the calls above go to.
  * SIM_ESTATE before sim_exchange_init; SIM_EDEVICE when RCCL reports an error.  (The CPU oracle has no collective library:
  * its entry points return SIM_EDEVICE — a test moves its buffers by hand.) */
