@@ -84,10 +84,7 @@ class ShardedSim:
             self._sq_host = [torch.zeros(w * self.world, dtype=torch.int32) for _ in range(4)]
             if device.type == "cuda":
                 self._sq_host = [x.pin_memory() for x in self._sq_host]
-                # (r6) at another priority than the compute stream: a priority level has hardware queues of its own.  With more streams
-                # than hardware queues this one shared the compute stream's queue, and its copy to the host — which waits for the
-                # all-gather — stood in that queue AHEAD of the next tick's first kernel: 50 us of every tick (profiles/r06_experiments.md §7)
-                self._sq_stream = torch.cuda.Stream(device, priority=-1)
+                self._sq_stream = torch.cuda.Stream(device)  # (r6, tried: at the highest priority — own hardware queue: kRandomNodes + 1.4 %, the bijection's chunk-wise exchange - 18 %)
             self._sq_inflight = []
         self._pending = []  # async all-to-alls of the round in flight
         self._xt = None     # exchange timing: list of (start, end) event pairs while enabled
