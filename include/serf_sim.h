@@ -29,7 +29,7 @@ extern "C" {
 
 /* ------------------------------------------------------------------ constants */
 
-#define SIM_ABI_VERSION 14u
+#define SIM_ABI_VERSION 15u
 
 #define SIM_P 4u  /* piggyback records per packet PAGE (48-byte cell: 4 records x 12 wire bytes) */
 #define SIM_PKT_BYTES 1400u /* byte budget of a gossip packet: memberlist's UDP payload limit (lan() and wan()); a packet
@@ -340,6 +340,17 @@ typedef struct sim_config {
                                    * buffers, the sharded instantiation of the tick kernel, the host-driven push-pull / recycling /
                                    * suspicion hand-over — the N > 1 path with a single rank, so that it (and its collective) can be
                                    * rehearsed on one GPU.  State and digests are those of the plain single-handle run.            */
+#define SIM_CF_PRUNE_DELAY 128u      /* (ABI 15) handle_prune's wait (serf/base.rs:1628-1653): a pruning leave intent about a member that is — or
+                                   * thereby becomes — Leaving erases it `leave_delay` ticks (broadcast_timeout + leave_propagate_delay) AFTER the
+                                   * intent was handled, not in the same tick: the node notes (node, subject) on the tick's request list (the list
+                                   * of the slot-less suspicions and the reconnect attempts), the library replays it as SIM_OP_PRUNE at tick
+                                   * t + max(2, leave_delay) — the list is read two ticks after it was written — and the member is erased then,
+                                   * whatever it has become, with its Reap event (erase_node!).  Left and Failed members are erased at once, as the
+                                   * reference does.  Needs the SWIM layer (probe_interval > 0: the request lists are its machinery); sim_create
+                                   * returns SIM_EINVAL otherwise.  Model bound: the request list's (SIM_SUSPECT_REQ_MAX per tick; a shard hands over
+                                   * SIM_SREQ_HEAD_PAIRS) — a tick that overflows it loses its requests, counted in ops_dropped.  NOT modelled: the
+                                   * reference sleeps with the member lock held, so every member handler of that node stalls for the duration; here
+                                   * the node keeps handling messages.  Off (the default): the erase happens in the tick of the intent. */
 #define SIM_DEFAULT_SEED 0x5EEDC0DE5E4F0001ull
 
 /* Stats — mirrors serf-core/src/serf/api.rs:586-602 (`Stats`) for one simulated node. */
@@ -427,8 +438,10 @@ enum sim_op {
                                    node b & 0xFFFFFF — counted when the query is still inside its deadline and names `node`
                                    as its origin (handle_query_response base.rs:1158-1204, query.rs:240-303; one entry per
                                    responder), exactly like one that arrived over the simulated network                      */
-  SIM_OP_WITNESS = 16           /* internal (a PushPull message's clocks, delegate.rs:466-480): `node` witnesses Lamport time
+  SIM_OP_WITNESS = 16,          /* internal (a PushPull message's clocks, delegate.rs:466-480): `node` witnesses Lamport time
                                    `val` on clock a (0 member, 1 event, 2 query) — the caller passes remote - 1              */
+  SIM_OP_PRUNE = 17             /* internal (SIM_CF_PRUNE_DELAY): `node` erases member a — the end of handle_prune's wait (base.rs:1636-1652);
+                                   scheduled by the library from the tick's request list, like SIM_OP_SUSPECT: an entry (node, a | 1 << 30)  */
 };
 #define SIM_DELIVER_MUTE 0x80000000u
 

@@ -608,9 +608,21 @@ static void broadcast_join(nctx* c, uint64_t ltime) {
   q_push(c, c->gid, wire_meta(SIM_K_JOIN, 0, 16), ltime); /* base.rs:389-391 */
 }
 
-/* handle_prune: base.rs:1628-1653.  The Leaving-state sleep (broadcast_timeout +
- * leave_propagate_delay) is not modelled: the erase happens in the same tick. */
-static void handle_prune(nctx* c, sim_view* e, uint32_t subject) { erase_member(c, e, subject); }
+/* handle_prune: base.rs:1628-1653.  A Leaving member is erased after a sleep of broadcast_timeout + leave_propagate_delay
+ * (base.rs:1634-1639) — with SIM_CF_PRUNE_DELAY: the node notes (node, subject | SREQ_PRUNE) on the tick's request list and
+ * step_begin replays it as SIM_OP_PRUNE leave_delay ticks after this one (include/serf_sim.h); without the flag, and for
+ * Left / Failed members, the erase happens here and now (base.rs:1641-1652).  The lock the reference holds while it sleeps
+ * (every member handler of the node stalls) is not modelled. */
+#define SREQ_PRUNE 0x40000000u
+static void handle_prune(nctx* c, sim_view* e, uint32_t subject) {
+  osim* s = c->s;
+  if ((s->cfg.flags & SIM_CF_PRUNE_DELAY) && SIM_VB_STATUS(e->bits) == SIM_STATUS_LEAVING) {
+    uint32_t i = __atomic_fetch_add(&s->sreq_n, 1u, __ATOMIC_RELAXED);
+    if (i < SIM_SUSPECT_REQ_MAX) { s->sreq[2 * i] = c->gid; s->sreq[2 * i + 1] = subject | SREQ_PRUNE; }
+    return;
+  }
+  erase_member(c, e, subject);
+}
 
 /* handle_node_leave_intent: base.rs:1442-1572 */
 static int handle_leave_intent(nctx* c, uint32_t subject, uint64_t ltime, int prune) {
@@ -1285,6 +1297,12 @@ static void apply_op(osim* s, const sim_opent* op) {
     }
     case SIM_OP_CRASH: row->flags &= ~SIM_RF_UP; break;
     case SIM_OP_REVIVE: row->flags |= SIM_RF_UP; break;
+    case SIM_OP_PRUNE: /* the end of handle_prune's wait (base.rs:1636-1652): the member goes, whatever it has become */
+      if (row->flags & SIM_RF_UP) {
+        sim_view* e = view_at(s, l, op->a);
+        if (e && (e->bits & SIM_VB_KNOWN)) erase_member(&c, e, op->a);
+      }
+      break;
     case SIM_OP_SUSPECT: /* the suspicion of a probe that failed last tick on a then slot-less target (swim_probe) */
       if ((row->flags & SIM_RF_UP) && s->swim) {
         sim_view* e = view_at(s, l, op->a);
@@ -1863,6 +1881,7 @@ static int cfg_check(const sim_config* c) {
   if (c->pkt_records && (c->pkt_records % SIM_P || c->pkt_records > SIM_PKT_RECORDS_MAX)) return SIM_EINVAL;
   if (c->retransmit_mult * digits10(c->n_nodes) > 63u) return SIM_EINVAL;
   if (c->n_nodes > (1u << 24)) return SIM_EINVAL; /* SUSPECT / DEAD carry the accuser's id in 24 bits on the wire (sim_packet) */
+  if ((c->flags & SIM_CF_PRUNE_DELAY) && !c->probe_interval) return SIM_EINVAL; /* the request lists are the SWIM layer's machinery */
   if (c->probe_interval) { /* suspicion timers name view slots with 16 bits */
     uint32_t A = (c->view_slots == 0 || c->view_slots >= c->n_nodes) ? c->n_nodes : c->view_slots;
     if (A > 65534u) return SIM_EINVAL;
@@ -2017,7 +2036,7 @@ static int ensure_slot(osim* s, uint32_t subject) {
 static uint32_t op_subject(const osim* s, uint32_t op, uint32_t node, uint32_t a, uint32_t b) {
   switch (op) {
     case SIM_OP_LEAVE: case SIM_OP_JOIN: case SIM_OP_LEAVE_FINISH: return node;
-    case SIM_OP_FORCE_LEAVE: return a;
+    case SIM_OP_FORCE_LEAVE: case SIM_OP_PRUNE: return a;
     case SIM_OP_CRASH: case SIM_OP_REVIVE: case SIM_OP_SET_TAGS: return s->swim ? node : NOSLOT;
     case SIM_OP_SUSPECT: return s->swim ? a : NOSLOT;
     case SIM_OP_DELIVER: { /* a member record from outside is about subject `a` */
@@ -2144,8 +2163,12 @@ static int inject_val(osim* s, uint64_t tick, uint32_t op, uint32_t node, uint32
   if (tick < s->tick) tick = s->tick;
   int rc = SIM_OK;
   if (op == SIM_OP_SUSPECT && (a & SREQ_RECONNECT)) { op = SIM_OP_RECONNECT; a &= ~SREQ_RECONNECT; } /* an entry of the request list, as it stands there */
+  else if (op == SIM_OP_SUSPECT && (a & SREQ_PRUNE)) { /* ... of a pruning leave intent: due leave_delay ticks after the tick it was noted in — the list is read two ticks after */
+    op = SIM_OP_PRUNE; a &= ~SREQ_PRUNE;
+    if (s->cfg.leave_delay > 2) tick += s->cfg.leave_delay - 2;
+  }
   switch (op) {
-    case SIM_OP_SUSPECT: case SIM_OP_RECONNECT: if (a >= s->N) return SIM_EINVAL; break;
+    case SIM_OP_SUSPECT: case SIM_OP_RECONNECT: case SIM_OP_PRUNE: if (a >= s->N) return SIM_EINVAL; break;
     case SIM_OP_DELIVER: {
       uint32_t kind = SIM_META_KIND(b);
       if (kind < SIM_K_JOIN || kind > SIM_K_DEAD || (b & ~(SIM_META_WIRE_MASK | SIM_DELIVER_MUTE))) return SIM_EINVAL;
@@ -2181,7 +2204,7 @@ static int inject_val(osim* s, uint64_t tick, uint32_t op, uint32_t node, uint32
   /* order within a tick: the caller's operations in the order they were scheduled, then the replayed suspicions / reconnect
    * attempts (SIM_OP_SUSPECT / SIM_OP_RECONNECT) in theirs — whenever the lists reached the schedule (step_begin, a checkpoint,
    * the sharded host's hand-over) */
-#define OP_LATE(o) ((o) == SIM_OP_SUSPECT || (o) == SIM_OP_RECONNECT)
+#define OP_LATE(o) ((o) == SIM_OP_SUSPECT || (o) == SIM_OP_RECONNECT || (o) == SIM_OP_PRUNE)
   while (pos > s->op_cursor && (s->ops[pos - 1].tick > tick || (s->ops[pos - 1].tick == tick && OP_LATE(s->ops[pos - 1].op) && !OP_LATE(op)))) {
     s->ops[pos] = s->ops[pos - 1];
     --pos;
@@ -3348,6 +3371,7 @@ uint32_t osim_t_scheduled(const osim* s, uint32_t op, uint64_t tick, uint32_t* o
   if (!SHARDED(s) && tick == s->tick && (op == SIM_OP_SUSPECT || op == SIM_OP_RECONNECT))
     for (uint32_t i = 0; i < s->sreq_prev_n; ++i) {
       uint32_t a = s->sreq_prev[2 * i + 1];
+      if (a & SREQ_PRUNE) continue; /* (a pruning leave intent's note: due leave_delay ticks on, not at `tick`) */
       if (((a & SREQ_RECONNECT) != 0) != (op == SIM_OP_RECONNECT)) continue;
       if (out_pairs && n < cap) { out_pairs[2 * n] = s->sreq_prev[2 * i]; out_pairs[2 * n + 1] = a & ~SREQ_RECONNECT; }
       ++n;

@@ -29,6 +29,7 @@ EV_JOIN, EV_LEAVE, EV_FAILED, EV_UPDATE, EV_REAP, EV_USER, EV_QUERY = range(7)
 # enum sim_op
 OP_USER_EVENT, OP_QUERY, OP_LEAVE, OP_JOIN, OP_FORCE_LEAVE, OP_CRASH, OP_REVIVE, OP_LEAVE_FINISH = 1, 2, 3, 4, 5, 6, 7, 8
 OP_SET_TAGS, OP_QUERY_FILTER_ID, OP_QUERY_FILTER_TAGS, OP_DELIVER, OP_SUSPECT, OP_RECONNECT = 9, 10, 11, 12, 13, 14
+OP_PRUNE = 17   # internal: the end of handle_prune's wait (CF_PRUNE_DELAY), scheduled by the library from the tick's request list
 OP_QRESP, OP_WITNESS = 15, 16   # internal: scheduled by sim_deliver_message (a QueryResponse / a PushPull's clocks), refused by sim_inject
 SUSPECT_REQ_MAX, SREQ_HEAD_WORDS = 4096, 512
 QF_IDS, TAG_CLASSES, NO_TAG_FILTER = 12, 32, 0xFFFFFFFF
@@ -36,7 +37,7 @@ QF_IDS, TAG_CLASSES, NO_TAG_FILTER = 12, 32, 0xFFFFFFFF
 ARR_ROWS, ARR_QUEUE, ARR_INBOX, ARR_VIEW, ARR_ERING, ARR_QRING, ARR_SLOTMAP = range(7)
 # enum sim_swim_state (memberlist node state)
 SWIM_ALIVE, SWIM_SUSPECT, SWIM_DEAD, SWIM_LEFT = 0, 1, 2, 3
-CF_BASELINE_JOINED, CF_RANDOM_FANOUT, CF_AWARENESS_PROBE, CF_JOIN_SYNC, CF_TCP_FALLBACK, CF_NACKS, CF_FORCE_SHARDED = 1, 2, 4, 8, 16, 32, 64
+CF_BASELINE_JOINED, CF_RANDOM_FANOUT, CF_AWARENESS_PROBE, CF_JOIN_SYNC, CF_TCP_FALLBACK, CF_NACKS, CF_FORCE_SHARDED, CF_PRUNE_DELAY = 1, 2, 4, 8, 16, 32, 64, 128
 XCHG_ALL_TO_ALL, XCHG_ALL_GATHER, XCHG_PACKED = 0, 1, 2   # (ALL_GATHER: retired in ABI 13, never reported)
 EXCHANGE_ID_BYTES = 128
 F_NO_BROADCAST, F_ACK, F_RESPOND = 1, 2, 4
@@ -117,7 +118,7 @@ def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, vi
                 suspicion_mult=4, suspicion_max_mult=6, indirect_checks=3, loss=0.0,
                 intent_timeout=0, leave_delay=30, reap_interval=0, reconnect_timeout=432000, tombstone_timeout=432000,
                 queue_check_interval=0, max_queue_depth=4096, min_queue_depth=0, push_pull_interval=0, chunks=0, recycle_interval=0,
-                pkt_records=0, gossip_to_the_dead=0, reconnect_interval=0, ring_overflow=0, tcp_fallback=False, nacks=False, awareness_probe=False, join_sync=False, force_sharded=False, flags=CF_BASELINE_JOINED, seed=DEFAULT_SEED):
+                pkt_records=0, gossip_to_the_dead=0, reconnect_interval=0, ring_overflow=0, tcp_fallback=False, nacks=False, awareness_probe=False, join_sync=False, force_sharded=False, prune_delay=False, flags=CF_BASELINE_JOINED, seed=DEFAULT_SEED):
     cfg = Config()
     cfg.struct_size = C.sizeof(Config)
     cfg.n_nodes, cfg.vshards, cfg.shard_rank, cfg.shard_count = n_nodes, vshards, shard_rank, shard_count
@@ -143,6 +144,8 @@ def make_config(n_nodes, *, fanout=3, vshards=1, shard_rank=0, shard_count=1, vi
         cfg.flags |= CF_NACKS          # awareness += relays that were asked and did not nack
     if force_sharded:
         cfg.flags |= CF_FORCE_SHARDED  # one rank of the N > 1 path: exchange buffers, the sharded kernel, host-driven push-pull
+    if prune_delay:
+        cfg.flags |= CF_PRUNE_DELAY    # handle_prune's wait (base.rs:1628-1653): a Leaving member's forced erase comes leave_delay ticks later
     return cfg
 
 

@@ -30,14 +30,14 @@ def test_hip_library_exports_every_declared_symbol():
     dll = C.CDLL(lib.path)
     for sym in declared_symbols():
         assert hasattr(dll, sym), f"{sym} missing from {lib.path}"
-    assert lib.backend_name() == "hip-gfx950" and lib.abi_version() == 14
+    assert lib.backend_name() == "hip-gfx950" and lib.abi_version() == 15
 
 
 def test_oracle_exports_the_same_interface(oracle):
     dll = C.CDLL(oracle.path)
     for sym in declared_symbols():
         assert hasattr(dll, "o" + sym), f"o{sym} missing from the oracle"
-    assert oracle.backend_name() == "cpu-oracle" and oracle.abi_version() == 14
+    assert oracle.backend_name() == "cpu-oracle" and oracle.abi_version() == 15
 
 
 def test_struct_layouts_match_the_header(tmp_path):

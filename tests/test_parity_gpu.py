@@ -19,7 +19,7 @@ def pair(oracle, hiplib, n, **kw):
 
 def test_backend_is_hip(hiplib):
     assert hiplib.backend_name() == "hip-gfx950"
-    assert hiplib.abi_version() == 14
+    assert hiplib.abi_version() == 15
 
 
 @pytest.mark.parametrize("swim", [0, 5, 2])

@@ -50,7 +50,7 @@ def run(sim, n, ops, ticks, joined, **kw):
                      queue_check_interval=kw.get("queue_check_interval", 0), max_queue_depth=kw.get("max_queue_depth", 4096),
                      reconnect_interval=kw.get("reconnect_interval", 0), awareness_probe=kw.get("awareness_probe", False),
                      tcp_fallback=kw.get("tcp_fallback", False), nacks=kw.get("nacks", False), gossip_to_the_dead=kw.get("gossip_to_the_dead", 0),
-                     join_sync=kw.get("join_sync", False))
+                     join_sync=kw.get("join_sync", False), prune_delay=kw.get("prune_delay", False))
     model = tms.Cluster(par, RING_EV, RING_Q, joined)
     by_tick = {}
     for o in ops:
@@ -197,6 +197,73 @@ def test_oracle_matches_the_third_model_with_the_reaper(seed, n, fanout, loss, p
         sim.watch(w)
     kinds, model = run(sim, n, _schedule(n, 110, seed), 110, True, **kw)
     assert any(e[2] == _ffi.EV_REAP for e in sim.drain_events()), "the run must reap somebody"
+
+
+# handle_prune's wait (base.rs:1628-1653, SIM_CF_PRUNE_DELAY): a pruning leave intent about a member that is Alive or Leaving erases it leave_delay ticks
+# after the node handled it; a Failed or Left member goes at once.  Forced removals of running members (they refute: the join intent races the erase), of
+# members that are leaving by themselves, of crashed members before and after they were declared failed
+def _prune_schedule(n, ticks, seed):
+    rng = np.random.default_rng(seed)
+    ops, key = [], 300
+    who = rng.choice(n, 10, replace=False).tolist()
+    t = 3
+    for i, x in enumerate(who):
+        by = int(rng.integers(0, n))
+        by = by if by != x else (x + 1) % n
+        if i % 4 == 0:      # a running member
+            ops.append((t, _ffi.OP_FORCE_LEAVE, by, x, 1))
+        elif i % 4 == 1:    # a member on its way out (its process dies before the removal reaches it: a leaving node that erased ITSELF would
+            ops.append((t, _ffi.OP_LEAVE, x, 0, 0))         # keep its memberlist state in the third model and lose it in the simulator — §2.7's merged entry)
+            ops.append((t + 1, _ffi.OP_CRASH, x, 0, 0))
+            ops.append((t + 3, _ffi.OP_FORCE_LEAVE, by, x, 1))
+        elif i % 4 == 2:    # a crashed member, at once
+            ops.append((t, _ffi.OP_CRASH, x, 0, 0))
+            ops.append((t + 1, _ffi.OP_FORCE_LEAVE, by, x, 1))
+        else:               # a crashed member, once it has been declared failed
+            ops.append((t, _ffi.OP_CRASH, x, 0, 0))
+            ops.append((t + 22, _ffi.OP_FORCE_LEAVE, by, x, 1))
+            ops.append((t + 23, _ffi.OP_FORCE_LEAVE, (by + 2) % n, x, 0))
+        t += 7
+    for tt in range(2, ticks - 25, 5):
+        key += 1
+        ops.append((tt, _ffi.OP_USER_EVENT, int(rng.integers(0, n)), key, 40))
+    ops = [o for o in ops if o[0] < ticks - 12]
+    ops.sort(key=lambda o: o[0])
+    return ops
+
+
+PRUNE_CASES = [(61, 48, 3, 0.02, 2, 5), (62, 64, 4, 0.0, 3, 2), (63, 40, 3, 0.05, 2, 9)]
+
+
+def _prune_run(lib, seed, n, fanout, loss, pi, delay):
+    kw = dict(KW, fanout=fanout, loss=loss, probe_interval=pi, leave_delay=delay, prune_delay=True, reap_interval=6, reconnect_timeout=60, tombstone_timeout=60)
+    sim = _ffi.Sim(lib, _ffi.make_config(n, **kw))
+    sim.drain_events()
+    for w in range(0, n, 3):
+        sim.watch(w)
+    ticks = 120
+    ops = _prune_schedule(n, ticks, seed)
+    run(sim, n, ops, ticks, True, **kw)
+    reaps = [e for e in sim.drain_events() if e[2] == _ffi.EV_REAP]
+    assert reaps, "somebody must have been erased"
+    # the same schedule without the wait erases earlier: the two runs must differ (the flag does something)
+    return sim.digest()
+
+
+@pytest.mark.parametrize("seed,n,fanout,loss,pi,delay", PRUNE_CASES)
+def test_oracle_matches_the_third_model_with_handle_prunes_wait(seed, n, fanout, loss, pi, delay):
+    _prune_run(load_oracle(), seed, n, fanout, loss, pi, delay)
+
+
+def test_create_refuses_the_prune_wait_without_the_memberlist_layer():
+    with pytest.raises(Exception):
+        _ffi.Sim(load_oracle(), _ffi.make_config(16, fanout=3, prune_delay=True))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,fanout,loss,pi,delay", PRUNE_CASES[:2])
+def test_hip_matches_the_third_model_with_handle_prunes_wait(hiplib, seed, n, fanout, loss, pi, delay):
+    assert _prune_run(hiplib, seed, n, fanout, loss, pi, delay) == _prune_run(load_oracle(), seed, n, fanout, loss, pi, delay)
 
 
 # with the Reconnector (base.rs:612-681): nodes that crash and silently resume stay failed in the others' tables until somebody's reconnect attempt

@@ -186,6 +186,7 @@ class Node:
         self.query_buf = [None] * ring_q                    # QueryCore.buffer: Option<Queries{ltime, query_ids}>
         self.event_min = self.query_min = 0
         self.rebroadcast = []                               # (kind, key, ltime) the delegate re-queues, in order
+        self.prune_wait = None                              # a list: handle_prune's sleep is modelled (SIM_CF_PRUNE_DELAY) — the subjects whose erase waits, in order
         self.on_query = None                                # the responder's half (QueryTrackers.respond), when the harness models it
         if everybody_joined:                                # the simulator's pre-joined baseline: every member Alive at status_time 1,
             for s in range(n):                              # the own join at ltime 1 witnessed
@@ -246,9 +247,12 @@ class Node:
             member[0] = LEFT
         elif st not in (LEAVING, LEFT):
             member[0] = LEAVING
-        if prune:                                           # handle_prune: the member is erased (serf/base.rs:1628-1653)
-            del self.members[node]
-            self.intents.pop(node, None)
+        if prune:                                           # handle_prune (serf/base.rs:1628-1653): a Leaving member after a sleep of broadcast_timeout + leave_propagate_delay,
+            if self.prune_wait is not None and member[0] == LEAVING:    # anybody else at once
+                self.prune_wait.append(node)
+            else:
+                del self.members[node]
+                self.intents.pop(node, None)
         return True
 
     # ---- serf/base.rs:750-837

@@ -43,8 +43,9 @@ class Params:
     def __init__(self, n, fanout, probe_interval, suspicion_mult=4, suspicion_max_mult=6, indirect_checks=3, retransmit_mult=4,
                  loss=0.0, pkt_records=4, leave_delay=30, seed=None, push_pull_interval=0, reap_interval=0, reconnect_timeout=432000,
                  tombstone_timeout=432000, intent_timeout=0, queue_check_interval=0, max_queue_depth=4096, reconnect_interval=0,
-                 awareness_probe=False, tcp_fallback=False, nacks=False, gossip_to_the_dead=0, join_sync=False):
+                 awareness_probe=False, tcp_fallback=False, nacks=False, gossip_to_the_dead=0, join_sync=False, prune_delay=False):
         from serf_amd import _ffi
+        self.prune_delay = prune_delay                      # handle_prune's sleep while the member is Leaving (serf/base.rs:1634-1639), leave_delay ticks
         self.pp_interval = push_pull_interval
         self.reap_interval, self.reconnect_timeout, self.tombstone_timeout, self.intent_timeout = reap_interval, reconnect_timeout, tombstone_timeout, intent_timeout
         self.queue_check_interval, self.max_queue_depth = queue_check_interval, max_queue_depth
@@ -394,6 +395,10 @@ class Cluster:
         self.flight = None                                  # packets sent during the last tick: [sender][slot] -> list of records (None: not sent)
         self.rc_made = {}                                   # tick -> the reconnect attempts (initiator, target) made in it, by initiator
         self.rc_postponed = []                              # attempts that found a partner busy (or a batch tick): next tick, first
+        self.prune_due = {}                                 # tick -> the (node, subject) whose forced erase ends its wait then
+        if par.prune_delay:
+            for x in self.nodes:
+                x.prune_wait = []
 
     def apply(self, op, node, a, b):
         from serf_amd import _ffi
@@ -480,6 +485,16 @@ class Cluster:
             x.tick = t
         for op, node, a, b in ops:
             self.apply(op, node, a, b)
+        # (0') the forced erases whose wait ends now (handle_prune, serf/base.rs:1636-1652: the member goes, whatever it has become), behind the tick's
+        # operations, by (node, subject); the sleeps begun during this tick's operations are noted for their tick
+        for node, subject in sorted(self.prune_due.pop(t, [])):
+            x = self.nodes[node]
+            if x.up and subject in x.members:
+                del x.members[subject]
+                x.left_at.pop(subject, None)
+                x.intents.pop(subject, None)
+                x.intent_at.pop(subject, None)
+                x.prune_sync()
         # (0a) the reconnect attempts due now — postponed ones first, then the ones made two ticks ago — run as push-pull pairs of their own,
         # the initiator merging first; on a batch tick, or when one of the two is already in a pair of this tick, an attempt waits a tick
         due = self.rc_postponed + sorted(self.rc_made.pop(t - 2, []))
@@ -550,4 +565,9 @@ class Cluster:
                         pk[k] = recs
             flight.append(pk)
         self.flight = flight
+        if par.prune_delay:                                 # the sleeps begun in this tick (its operations and deliveries) end max(2, leave_delay) ticks from it
+            for i, x in enumerate(self.nodes):
+                for subject in x.prune_wait:
+                    self.prune_due.setdefault(t + max(2, par.leave_delay), []).append((i, subject))
+                x.prune_wait = []
         self.tick += 1
