@@ -347,8 +347,8 @@ typedef struct sim_config {
                                    * t + max(2, leave_delay) — the list is read two ticks after it was written — and the member is erased then,
                                    * whatever it has become, with its Reap event (erase_node!).  Left and Failed members are erased at once, as the
                                    * reference does.  Needs the SWIM layer (probe_interval > 0: the request lists are its machinery); sim_create
-                                   * returns SIM_EINVAL otherwise.  Model bound: the request list's (SIM_SUSPECT_REQ_MAX per tick; a shard hands over
-                                   * SIM_SREQ_HEAD_PAIRS) — a tick that overflows it loses its requests, counted in ops_dropped.  NOT modelled: the
+                                   * returns SIM_EINVAL otherwise.  Model bound: the request list's (SIM_SUSPECT_REQ_MAX per tick; cluster-wide,
+                                   * sharded or not) — a tick that overflows it loses its requests, counted in ops_dropped.  NOT modelled: the
                                    * reference sleeps with the member lock held, so every member handler of that node stalls for the duration; here
                                    * the node keeps handling messages.  Off (the default): the erase happens in the tick of the intent. */
 #define SIM_DEFAULT_SEED 0x5EEDC0DE5E4F0001ull
@@ -685,10 +685,10 @@ int sim_suspect_requests(sim_handle* h, uint32_t* out, uint32_t cap_pairs, uint3
  * all-gathers the heads of all shards with an asynchronous device-side collective, copies the result to host memory behind
  * it, and any time before sim_step_begin of tick t + 2 hands it to sim_suspect_import(h, t, heads, world) on every shard,
  * which merges the lists in ascending prober order and schedules them as SIM_OP_SUSPECT for tick t + 2 — the tick a
- * single-process handle replays them in.  A shard whose list of one tick is longer than the head: that list is dropped
- * and counted in ops_dropped on every shard (model bound). */
-#define SIM_SREQ_HEAD_PAIRS 255u
-#define SIM_SREQ_HEAD_WORDS 512u
+ * single-process handle replays them in.  (ABI 15) The bound is the single-process handle's: more than SIM_SUSPECT_REQ_MAX
+ * requests in one tick over ALL shards together and every one of them is dropped and counted in ops_dropped, on every shard. */
+#define SIM_SREQ_HEAD_PAIRS 4096u   /* (ABI 15: = SIM_SUSPECT_REQ_MAX, was 255 — the notes of SIM_CF_PRUNE_DELAY come a node a tick in a rumour's wavefront) */
+#define SIM_SREQ_HEAD_WORDS 8193u
 int sim_suspect_export(sim_handle* h, void* out);
 int sim_suspect_import(sim_handle* h, uint64_t of_tick, const uint32_t* heads, uint32_t world);
 int sim_recycle_due(const sim_handle* h);

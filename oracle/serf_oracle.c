@@ -3194,9 +3194,11 @@ int API(suspect_import)(osim* s, uint64_t of_tick, const uint32_t* heads, uint32
   if (!s || !heads || !world || s->in_tick || of_tick + 2 < s->tick) return SIM_EINVAL;
   uint32_t* all = (uint32_t*)malloc((size_t)world * SIM_SREQ_HEAD_PAIRS * 2 * sizeof(uint32_t));
   uint32_t n = 0;
+  uint64_t total = 0;
+  for (uint32_t w = 0; w < world; ++w) total += heads[(size_t)w * SIM_SREQ_HEAD_WORDS];
+  if (total > SIM_SUSPECT_REQ_MAX) { s->ops_dropped += (uint32_t)total; free(all); return SIM_OK; } /* model bound, the single-process handle's: the whole tick's list is dropped */
   for (uint32_t w = 0; w < world; ++w) {
     const uint32_t* hd = heads + (size_t)w * SIM_SREQ_HEAD_WORDS;
-    if (hd[0] > SIM_SREQ_HEAD_PAIRS) { s->ops_dropped += hd[0]; continue; } /* model bound: that shard's list is dropped */
     memcpy(all + 2 * n, hd + 1, (size_t)hd[0] * 2 * sizeof(uint32_t));
     n += hd[0];
   }

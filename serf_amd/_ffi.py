@@ -31,7 +31,7 @@ OP_USER_EVENT, OP_QUERY, OP_LEAVE, OP_JOIN, OP_FORCE_LEAVE, OP_CRASH, OP_REVIVE,
 OP_SET_TAGS, OP_QUERY_FILTER_ID, OP_QUERY_FILTER_TAGS, OP_DELIVER, OP_SUSPECT, OP_RECONNECT = 9, 10, 11, 12, 13, 14
 OP_PRUNE = 17   # internal: the end of handle_prune's wait (CF_PRUNE_DELAY), scheduled by the library from the tick's request list
 OP_QRESP, OP_WITNESS = 15, 16   # internal: scheduled by sim_deliver_message (a QueryResponse / a PushPull's clocks), refused by sim_inject
-SUSPECT_REQ_MAX, SREQ_HEAD_WORDS = 4096, 512
+SUSPECT_REQ_MAX, SREQ_HEAD_WORDS = 4096, 8193
 QF_IDS, TAG_CLASSES, NO_TAG_FILTER = 12, 32, 0xFFFFFFFF
 # enum sim_array
 ARR_ROWS, ARR_QUEUE, ARR_INBOX, ARR_VIEW, ARR_ERING, ARR_QRING, ARR_SLOTMAP = range(7)

@@ -47,6 +47,35 @@ def test_full_state_every_tick_small(oracle, hiplib, n, fanout, dense, swim):
     sc.assert_same_state(g, o, f"n={n} final")
 
 
+@pytest.mark.parametrize("rf", [False, True])
+@pytest.mark.parametrize("n,slots,delay", [(1024, 64, 5), (300, 0, 2), (4096, 96, 11)])
+def test_handle_prunes_wait_parity(oracle, hiplib, n, slots, delay, rf):
+    # SIM_CF_PRUNE_DELAY (serf/base.rs:1628-1653): pruning leave intents about Alive / Leaving members erase leave_delay ticks later — notes on the
+    # tick's request list, SIM_OP_PRUNE operations on the schedule; a load with many forced removals (a third of them pruning), sparse and dense views,
+    # recycling, push-pull, loss; checkpoints in the middle carry the lists in flight and the pending erases (HIP image -> both, oracle image -> both)
+    kw = dict(fanout=4, view_slots=slots, event_ring=16, query_ring=8, leave_delay=delay, probe_interval=3, loss=0.02, push_pull_interval=8,
+              reap_interval=7, reconnect_timeout=30, tombstone_timeout=45, intent_timeout=20, recycle_interval=10 if slots else 0, prune_delay=True,
+              flags=_ffi.CF_BASELINE_JOINED | (_ffi.CF_RANDOM_FANOUT if rf else 0))
+    g, o = pair(oracle, hiplib, n, **kw)
+    ops = sc.schedule(n, 70, rate=0.9, seed=n + delay, mix=(0.3, 0.1, 0.15, 0.35, 0.1), max_member_subjects=min(n // 3, 40))
+    sc.apply_schedule(g, ops)
+    sc.apply_schedule(o, ops)
+    for t in range(120):
+        g.step(1)
+        o.step(1)
+        assert g.digest() == o.digest(), f"digest differs after tick {t}"
+        if t % 13 == 0:
+            sc.assert_same_state(g, o, f"tick {t}")
+        if t in (31, 58):  # resume both from one image: the HIP library's, then the oracle's
+            img = (g if t == 31 else o).snapshot()
+            g.close(); o.close()
+            g = _ffi.Sim(hiplib, _ffi.make_config(n, **kw)); o = _ffi.Sim(oracle, _ffi.make_config(n, **kw))
+            g.restore(img); o.restore(img)
+            assert g.digest() == o.digest(), f"restored images differ at tick {t}"
+    sc.assert_same_state(g, o, "final")
+    assert g.cluster_stats()["ops_dropped"] == o.cluster_stats()["ops_dropped"]
+
+
 @pytest.mark.parametrize("n,vshards,chunks,fanout", [(4096, 4, 2, 4), (2048, 4, 0, 4), (4096, 1, 0, 3), (640, 2, 0, 2), (8192, 2, 2, 4)])
 def test_packets_kept_at_the_sender_virtual_shards_and_chunks(oracle, hiplib, n, vshards, chunks, fanout):
     # One handle, every shape of the fan-out map (virtual shards, sender chunks, 64-node blocks and the B = 1
@@ -528,6 +557,7 @@ def test_sharded_kernel_four_shards_on_one_gpu(oracle, hiplib, swim, chunks, pkt
     m = n // V
     kw = dict(fanout=4, view_slots=96, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=0.02,
               push_pull_interval=3 if swim else 0, chunks=chunks if chunks > 1 else 0, pkt_records=pkt,   # pkt: paged packets in the exchange buffers
+              prune_delay=bool(swim),   # handle_prune's wait: its notes go over the shards' request-list hand-over
               reconnect_interval=rc, **(dict(suspicion_mult=3, suspicion_max_mult=2, gossip_to_the_dead=1) if rc else {}))
     ref = _ffi.Sim(oracle, _ffi.make_config(n, vshards=V, **kw))
     shards, send, recv = [], [], []

@@ -51,6 +51,7 @@ def _worker(rank, world, port, n, ticks, swim, chunks, q, jitter=0.0, pkt=0, los
         lib = load_oracle()
         kw = dict(fanout=3, view_slots=64 if loss < 0.05 else 256, event_ring=16, query_ring=8, leave_delay=6, probe_interval=swim, loss=loss,
                   push_pull_interval=4 if swim else 0, pkt_records=pkt, reconnect_interval=rc,
+                  prune_delay=bool(swim),   # handle_prune's wait: the notes cross the shards on the request list, like the slot-less suspicions
                   **(dict(suspicion_mult=3, suspicion_max_mult=2, gossip_to_the_dead=1) if rc else {}),
                   **(dict(flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT) if rf else {}))
         sh = ShardedSim(lib, n, torch.device("cpu"), chunks=chunks, **kw)
