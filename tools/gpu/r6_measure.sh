@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/r6m
 mkdir -p $OUT
 cd $ROOT
 timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_20_5.json 2> $OUT/bench_20_5.err; echo "bench (driver args) rc=$?"; cp bench_detail.json $OUT/bench_20_5_detail.json; wc -c $OUT/bench_20_5.json
-timeout 400 python bench.py --gpus 1 --force-sharded --fanout-model krandomnodes --exchange rccl --steps 20 --warmup 5 --no-cpu-baseline --no-second-load > $OUT/bench_one_rank_rccl_krandomnodes.json 2> $OUT/bench_one_rank_rccl_krandomnodes.err; echo "bench one rank, kRandomNodes packed slabs, over RCCL rc=$?"; cp bench_detail.json $OUT/bench_one_rank_rccl_krandomnodes_detail.json
+timeout 400 python bench.py --gpus 1 --force-sharded --fanout-model krandomnodes --exchange rccl --chunks 1 --steps 20 --warmup 5 --no-cpu-baseline --no-second-load > $OUT/bench_one_rank_rccl_krandomnodes.json 2> $OUT/bench_one_rank_rccl_krandomnodes.err; echo "bench one rank, kRandomNodes packed slabs, over RCCL rc=$?"; cp bench_detail.json $OUT/bench_one_rank_rccl_krandomnodes_detail.json
 timeout 400 python bench.py --gpus 1 --force-sharded --exchange rccl --chunks 2 --steps 20 --warmup 5 --no-cpu-baseline --no-second-load > $OUT/bench_one_rank_rccl.json 2> $OUT/bench_one_rank_rccl.err; echo "bench one rank, bijection, over RCCL rc=$?"; cp bench_detail.json $OUT/bench_one_rank_rccl_detail.json
 cd /tmp && export TMPDIR=/tmp
 for M in ${MODELS:-krandomnodes bijection}; do
