@@ -79,6 +79,9 @@ struct Options {
   Options& with_disable_tcp_pings(bool off) { c.flags = off ? (c.flags & ~SIM_CF_TCP_FALLBACK) : (c.flags | SIM_CF_TCP_FALLBACK); return *this; }  // memberlist Options::disable_tcp_pings
   Options& with_reconnect_interval(uint32_t ticks) { c.reconnect_interval = ticks; return *this; }  // options.rs:162 (0 = no Reconnector)
   Options& with_ring_overflow(uint32_t rows) { c.ring_overflow = rows; return *this; }  // overflow rows per de-dup ring and node (0: a full bucket treats new keys as seen)
+  // handle_prune's wait (serf/base.rs:1628-1653): a pruning leave intent about a Leaving member erases it leave_delay ticks later — the reference's
+  // behaviour; off by default (the erase in the tick of the intent), needs the SWIM layer (probe_interval > 0)
+  Options& with_prune_wait(bool on) { c.flags = on ? (c.flags | SIM_CF_PRUNE_DELAY) : (c.flags & ~SIM_CF_PRUNE_DELAY); return *this; }
   Options& with_seed(uint64_t s) { c.seed = s; return *this; }
 };
 

@@ -317,6 +317,49 @@ def test_memberlist_flags_on_the_gpu(oracle, hiplib):
         assert g.digest() == o.digest(), f"awareness probe: tick {t}"
 
 
+def test_handle_prunes_wait_on_the_gpu(oracle, hiplib):
+    # tests/test_oracle_swim.py::test_handle_prune_waits_while_the_member_is_leaving and ::test_remove_failed_node_prune (serf/base.rs:1628-1653,
+    # remove.rs:96-153) on the HIP library, the oracle beside it tick by tick: the member table of node 0 keeps the pruned member for leave_delay
+    # ticks and loses it then, with a Reap event of that tick; a Failed member goes at once
+    n, victim, delay = 4096, 40, 9
+    kw = dict(fanout=3, view_slots=32, event_ring=16, query_ring=8, probe_interval=5, leave_delay=delay, prune_delay=True)
+    g, o = both(oracle, hiplib, n, **kw)
+    for s in (g, o):
+        s.watch(0)
+        s.inject(2, _ffi.OP_CRASH, victim)
+        s.inject(3, _ffi.OP_FORCE_LEAVE, 0, victim, 1)
+    for t in range(3 + delay + 30):
+        g.step(1)
+        o.step(1)
+        assert g.digest() == o.digest(), f"tick {t}"
+        if 3 <= t < 3 + delay:
+            assert g.stats(0).members == n and int(g.members(0)[0][victim]) == _ffi.STATUS_LEAVING, f"tick {t}: the erase must wait"
+        if t == 3 + delay:
+            assert g.stats(0).members == n - 1
+    ev_g, ev_o = g.drain_events(), o.drain_events()
+    assert [tuple(e) for e in ev_g] == [tuple(e) for e in ev_o]
+    reap = [e for e in ev_g if e[2] == _ffi.EV_REAP and e[3] == victim]
+    assert reap and reap[0][0] == 3 + delay
+    assert all(g.stats(x).members == n - 1 for x in (0, 7, 4000)), "everybody has erased the member by now"
+    g.close(); o.close()
+    g, o = both(oracle, hiplib, 3, fanout=2, probe_interval=5, leave_delay=6, prune_delay=True)   # remove.rs:96-153
+    for s in (g, o):
+        s.inject(1, _ffi.OP_CRASH, 1)
+    for t in range(400):
+        g.step(1)
+        o.step(1)
+        if int(g.members(0)[0][1]) == _ffi.STATUS_FAILED and int(g.members(2)[0][1]) == _ffi.STATUS_FAILED:
+            break
+    assert g.digest() == o.digest()
+    for s in (g, o):
+        s.remove_failed_node(0, 1, prune=True)
+    for t in range(6):
+        g.step(1)
+        o.step(1)
+        assert g.digest() == o.digest()
+    assert [g.stats(x).members for x in (0, 2)] == [2, 2]
+
+
 def test_reconnector_on_the_gpu(oracle, hiplib):
     # tests/test_oracle_reconnect.py on the HIP library, the oracle beside it tick by tick: a node that resumes after it was
     # declared failed, with nobody gossiping to it any more, is reached by a peer's Reconnector (base.rs:612-681), refutes,

@@ -593,3 +593,49 @@ def test_nacks_keep_a_healthy_prober_healthy(oracle):
             tot += int(sim.dump(_ffi.ARR_ROWS)["awareness"].astype(np.int64).sum())
         score[nk] = tot
     assert score[False] > 50 and score[True] * 10 < score[False], score   # (a relay that is itself one of the dead nodes: no nack)
+
+
+# ------------------------------------------------------------------------------------------------
+# remove_failed_node_prune and handle_prune's wait (serf/base.rs:452-480, 1628-1653)
+# ------------------------------------------------------------------------------------------------
+def known_by(sim, subject, observers):
+    return [bool(sim.dump(_ffi.ARR_VIEW).reshape(-1, sim.n)[subject, o]["bits"] & 1) for o in observers]
+
+
+@pytest.mark.parametrize("wait", [False, True])
+def test_remove_failed_node_prune(oracle, wait):
+    # serf/base/tests/serf/remove.rs:96-153 (serf_remove_failed_node_prune): three nodes, one is shut down and declared Failed, the first calls
+    # remove_failed_node_prune — the member table of the two that are left drops to 2.  A Failed member does not wait (base.rs:1634: only
+    # Leaving sleeps), so the flag changes nothing here.
+    n, victim = 3, 1
+    sim, _ = cluster(oracle, n, fanout=2, leave_delay=6, prune_delay=wait)
+    sim.inject(1, _ffi.OP_CRASH, victim)
+    others = [0, 2]
+    assert run_until(sim, lambda: all(s == FAILED for s in statuses_of(sim, victim, others)), 400) is not None, "never declared failed"
+    assert [sim.stats(o).members for o in others] == [3, 3]
+    t0 = sim.tick
+    sim.remove_failed_node(0, victim, prune=True)
+    t = run_until(sim, lambda: [sim.stats(o).members for o in others] == [2, 2], 40)
+    assert t is not None and t - t0 <= 4, "a failed member is erased when the intent is handled: no wait"
+
+
+def test_handle_prune_waits_while_the_member_is_leaving(oracle):
+    # base.rs:1628-1653: a pruning leave intent about a member that is Alive (it becomes Leaving) or Leaving is erased broadcast_timeout +
+    # leave_propagate_delay after the node handled it; here leave_delay = 9 ticks, in a cluster where the subject has crashed but is not yet suspected
+    n, victim, delay = 64, 40, 9
+    sim, _ = cluster(oracle, n, fanout=3, leave_delay=delay, prune_delay=True, probe_interval=5)
+    sim.watch(0)
+    sim.inject(2, _ffi.OP_CRASH, victim)
+    sim.inject(3, _ffi.OP_FORCE_LEAVE, 0, victim, 1)
+    others = [o for o in range(n) if o != victim]
+    sim.step(4)     # tick 3 has run: node 0 handled its own intent
+    assert statuses_of(sim, victim, [0]) == [LEAVING] and sim.stats(0).members == n, "the erase must wait"
+    sim.step(delay - 1)   # ticks 4 .. 3 + delay - 1: still there at node 0, Leaving wherever the intent has arrived
+    assert sim.stats(0).members == n
+    sim.step(1)     # tick 3 + delay: node 0's wait is over
+    assert sim.stats(0).members == n - 1 and not known_by(sim, victim, [0])[0]
+    ev = [e for e in sim.drain_events() if e[3] == victim]
+    assert [e[2] for e in ev][-1] == _ffi.EV_REAP and ev[-1][0] == 3 + delay, "Reap at the end of the wait"
+    # everybody handles the intent within a few rounds and erases `delay` ticks after that
+    assert run_until(sim, lambda: not any(known_by(sim, victim, others)), 40) is not None
+    assert all(sim.stats(o).members == n - 1 for o in (0, 7, 63))
