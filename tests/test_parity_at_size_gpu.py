@@ -77,6 +77,20 @@ def test_one_ranks_share_of_config4_2mi_8_vshards_2_chunks_churn_loss_16_records
     assert cs["failed"] > 0 or cs["left"] > 0 or cs["slots_in_use"] > 0   # the churn happened
 
 
+def test_prune_wait_at_1mi_nodes_the_request_list_bound_bites_the_same_way(oracle, hiplib):
+    # SIM_CF_PRUNE_DELAY at BASELINE configs[2]'s size: three pruning removals of running and of crashed members.  Every node notes its wait on
+    # the tick's request list as the intent's wavefront passes — far more than SIM_SUSPECT_REQ_MAX a tick at this size: those ticks' lists are
+    # dropped and counted, the ticks at the wavefront's head and tail are replayed — and the library and the oracle must drop and replay the
+    # very same ones (ops_dropped is part of the load figures compared below)
+    n = 1 << 20
+    kw = dict(fanout=4, view_slots=32, event_ring=32, query_ring=16, probe_interval=5, loss=0.01, push_pull_interval=20, leave_delay=7,
+              reap_interval=15, recycle_interval=25, prune_delay=True, flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT)
+    ops = [(2, _ffi.OP_FORCE_LEAVE, 11, 500000, 1), (4, _ffi.OP_CRASH, 777, 0, 0), (5, _ffi.OP_FORCE_LEAVE, 90000, 777, 1),
+           (9, _ffi.OP_USER_EVENT, 3, 4242, 40), (12, _ffi.OP_FORCE_LEAVE, 1000000, 31, 1), (14, _ffi.OP_QUERY, 5, 77, 0)]
+    cs = _run(oracle, hiplib, n, ops, 50, 5, "1 Mi nodes, handle_prune's wait, kRandomNodes", **kw)
+    assert cs["ops_dropped"] > 0, "the request list's bound was meant to bite"
+
+
 @pytest.mark.parametrize("mi,ticks", [(6, 30), (8, 20)])
 def test_krandomnodes_above_4mi_nodes(oracle, hiplib, mi, ticks):
     # memberlist's kRandomNodes at 6 Mi nodes: pair ids of 25 bits, 64-bit entries in rf_scatter / rf_rows, 2 048 senders per
