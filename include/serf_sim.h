@@ -630,6 +630,8 @@ int sim_exchange_layout(const sim_handle* h, uint32_t* kind, uint32_t* planes, s
  *                                         (r6) With ONE chunk per tick there is no later launch to travel beside: the group is issued
  *                                         on the handle's own stream, behind the pack — nothing hops between two streams.  The
  *                                         slab a shard addresses to itself never travels (it is packed in place).
+ *                                         With the SWIM layer on, the LAST chunk's group also carries the head of the tick's list of
+ *                                         slot-less suspicions to every peer (sim_suspect_import with heads == NULL reads them).
  *   sim_exchange_wait(h)                  the handle's stream waits (on the device, no host wait) for every exchange issued so
  *                                         far; sim_step_begin, sim_sync and every call that reads the packets in flight (digest,
  *                                         dump, checkpoint, recycling scan) do it by themselves.
@@ -686,7 +688,12 @@ int sim_suspect_requests(sim_handle* h, uint32_t* out, uint32_t cap_pairs, uint3
  * it, and any time before sim_step_begin of tick t + 2 hands it to sim_suspect_import(h, t, heads, world) on every shard,
  * which merges the lists in ascending prober order and schedules them as SIM_OP_SUSPECT for tick t + 2 — the tick a
  * single-process handle replays them in.  (ABI 15) The bound is the single-process handle's: more than SIM_SUSPECT_REQ_MAX
- * requests in one tick over ALL shards together and every one of them is dropped and counted in ops_dropped, on every shard. */
+ * requests in one tick over ALL shards together and every one of them is dropped and counted in ops_dropped, on every shard.
+ * (r6) A handle whose round's exchange the LIBRARY issues (sim_exchange_init) needs neither the export nor a collective of the
+ * host's: sim_exchange_chunk of a tick's last chunk sends the head to every peer in the same group as the slabs and writes what
+ * the V heads hold into pinned host memory behind it (an event marks it); sim_suspect_import(h, t, NULL, world) — heads == NULL —
+ * waits for that event and imports them.  SIM_EINVAL without sim_exchange_init (and in the CPU oracle, which has no collective
+ * library), SIM_ESTATE when no exchange of tick t was issued or its heads were imported already. */
 #define SIM_SREQ_HEAD_PAIRS 4096u   /* (ABI 15: = SIM_SUSPECT_REQ_MAX, was 255 — the notes of SIM_CF_PRUNE_DELAY come a node a tick in a rumour's wavefront) */
 #define SIM_SREQ_HEAD_WORDS 8193u
 int sim_suspect_export(sim_handle* h, void* out);

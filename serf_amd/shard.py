@@ -77,7 +77,12 @@ class ShardedSim:
         self.lo = self.rank * self.m
         # slot-less failed probes (SWIM layer on): every tick's lists are gathered on the device and read two ticks later
         self._poll_suspects = bool(kw.get("probe_interval", 0))
-        if self._poll_suspects:
+        # (r6) the library's own exchange carries the lists' heads to every peer and on into pinned host memory (sim_exchange_chunk;
+        # sim_suspect_import(h, t, NULL, world) reads them): no second collective, no side stream, no copies between two ticks
+        self._lib_heads = self.use_lib and self._poll_suspects
+        if self._lib_heads:
+            self._sq_inflight = []
+        elif self._poll_suspects:
             w = _ffi.SREQ_HEAD_WORDS
             self._sq_send = [torch.zeros(w, dtype=torch.int32, device=device) for _ in range(4)]
             self._sq_gath = [torch.zeros(w * self.world, dtype=torch.int32, device=device) for _ in range(4)] if device.type == "cuda" else None
@@ -139,9 +144,7 @@ class ShardedSim:
         self._drain()
         if self._poll_suspects:
             while self._sq_inflight:
-                t, i, done = self._sq_inflight.pop(0)
-                done.synchronize() if self.device.type == "cuda" else done.wait()
-                self.sim.suspect_import(t, self._sq_host[i].data_ptr(), self.world)
+                self._suspicions_take()
         return self.sim.snapshot()
 
     def _recycle(self):
@@ -208,9 +211,15 @@ class ShardedSim:
         """Before tick T begins: the gathered lists of tick T - 2 become SIM_OP_SUSPECT operations of tick T on EVERY shard
         (the schedule and the slot map are replicated) — the rule of a single-process run."""
         while self._sq_inflight and self._sq_inflight[0][0] + 2 <= self.sim.tick:
-            t, i, done = self._sq_inflight.pop(0)
-            done.synchronize() if self.device.type == "cuda" else done.wait()  # issued two ticks ago
-            self.sim.suspect_import(t, self._sq_host[i].data_ptr(), self.world)
+            self._suspicions_take()
+
+    def _suspicions_take(self):
+        t, i, done = self._sq_inflight.pop(0)
+        if self._lib_heads:
+            self.sim.suspect_import(t, 0, self.world)  # waits for the event behind the exchange of tick t (issued two ticks ago)
+            return
+        done.synchronize() if self.device.type == "cuda" else done.wait()  # issued two ticks ago
+        self.sim.suspect_import(t, self._sq_host[i].data_ptr(), self.world)
 
     def step(self, n_ticks=1):
         for _ in range(n_ticks):
@@ -233,7 +242,9 @@ class ShardedSim:
                     lo = c * self.chunk_bytes
                     self._exchange(c, rbuf[lo:lo + self.chunk_bytes], self.send[lo:lo + self.chunk_bytes], True)
                 self.sim.step_end()
-            if self._poll_suspects:
+            if self._lib_heads:
+                self._sq_inflight.append((self.sim.tick - 1, None, None))  # (travelled with the last chunk's exchange)
+            elif self._poll_suspects:
                 self._suspicions_out()
 
     def restore(self, image):
@@ -323,5 +334,7 @@ class ShardedSim:
     def close(self):
         self._drain()
         for _, _, done in getattr(self, "_sq_inflight", []):  # gathers still writing into our buffers
+            if done is None:
+                continue  # (heads that travelled with the library's exchange: its buffers go with the handle)
             done.synchronize() if self.device.type == "cuda" else done.wait()
         self.sim.close()
