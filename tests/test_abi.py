@@ -87,3 +87,6 @@ def test_api_argument_errors(oracle):
     with pytest.raises(_ffi.SimError) as ei:
         s.leave(3)                          # third active subject, two view slots
     assert ei.value.code == _ffi.ENOSLOT
+    with pytest.raises(_ffi.SimError) as ei:
+        s.suspect_import(0, 0, 1)           # heads == NULL = "the ones the library's exchange carried": the oracle has no exchange
+    assert ei.value.code == _ffi.EINVAL

@@ -1139,6 +1139,7 @@ def _one_rank_rccl_worker(port, q):
         for chunks in (1, 2, 4):
             sh = ShardedSim(lib, n, dev, chunks=chunks, exchange="rccl", **kw)
             assert sh.use_lib and sh.collective_library().startswith("RCCL "), sh.collective_library()
+            assert sh._lib_heads  # the lists of slot-less suspicions travel with the library's exchange (sim_suspect_import, heads == NULL)
             plain = _ffi.Sim(lib, _ffi.make_config(n, chunks=chunks if chunks > 1 else 0, **kw))
             orc = _ffi.Sim(load_oracle(), _ffi.make_config(n, chunks=chunks if chunks > 1 else 0, **kw))
             ops = sc.schedule(n, 40, rate=0.8, seed=23, max_member_subjects=20)
@@ -1159,7 +1160,7 @@ def _one_rank_rccl_worker(port, q):
         kw_rf = dict(kw, flags=_ffi.CF_BASELINE_JOINED | _ffi.CF_RANDOM_FANOUT, recycle_interval=0)
         for chunks in (1, 2, 4):   # (sender chunks: chunk c's slabs are packed and travel while chunk c + 1 computes)
             sh = ShardedSim(lib, n, dev, chunks=chunks, exchange="rccl", **kw_rf)
-            assert sh.use_lib and sh.kind == _ffi.XCHG_PACKED and sh.chunks == chunks
+            assert sh.use_lib and sh._lib_heads and sh.kind == _ffi.XCHG_PACKED and sh.chunks == chunks
             plain = _ffi.Sim(lib, _ffi.make_config(n, **kw_rf))
             orc = _ffi.Sim(load_oracle(), _ffi.make_config(n, **kw_rf))
             for x in (sh, plain, orc):
