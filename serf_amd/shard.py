@@ -24,6 +24,8 @@ The reference has no collective at all (its transport is UDP/TCP inside memberli
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -79,7 +81,7 @@ class ShardedSim:
         self._poll_suspects = bool(kw.get("probe_interval", 0))
         # (r6) the library's own exchange carries the lists' heads to every peer and on into pinned host memory (sim_exchange_chunk;
         # sim_suspect_import(h, t, NULL, world) reads them): no second collective, no side stream, no copies between two ticks
-        self._lib_heads = self.use_lib and self._poll_suspects
+        self._lib_heads = self.use_lib and self._poll_suspects and os.environ.get("SERF_SIM_XHEADS", "1") != "0"  # (= 0: the host's own hand-over below)
         if self._lib_heads:
             self._sq_inflight = []
         elif self._poll_suspects:
