@@ -391,3 +391,15 @@ def test_reconnector_on_the_gpu(oracle, hiplib):
         o.step(1)
         assert g.digest() == o.digest(), f"hand-placed attempts: tick {t}"
     sc.assert_same_state(g, o, "reconnector final")
+
+
+def test_suspect_import_without_an_exchange_of_the_librarys(oracle, hiplib):
+    # (r6) heads == NULL means "the lists the library's own exchange carried" (sim_exchange_chunk): a handle that never called
+    # sim_exchange_init has none — SIM_EINVAL on the product, as on the oracle (which has no collective library at all)
+    for lib in (hiplib, oracle):
+        s = _ffi.Sim(lib, _ffi.make_config(256, fanout=3, view_slots=16, probe_interval=2))
+        s.step(3)
+        with pytest.raises(_ffi.SimError) as ei:
+            s.suspect_import(1, 0, 1)
+        assert ei.value.code == _ffi.EINVAL
+        s.close()
