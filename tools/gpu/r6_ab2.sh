@@ -20,4 +20,6 @@ except Exception as e:
     print('$T', 'no line', e)
 PY
 done
-timeout 900 python tools/ab.py --fanout-model krandomnodes --ticks 120 --rounds 3 serf_amd/csrc/libserf_sim.so gpurun_tmp/libserf_sim_p2.so gpurun_tmp/libserf_sim_hsh.so gpurun_tmp/libserf_sim_p2hsh.so 2>&1 | tail -30
+# (the variant builds are made by hand into gpurun_tmp/ — e.g. hipcc ... -DHSH_LOW -o gpurun_tmp/libserf_sim_hsh.so — and are not kept)
+LIBS=$(ls gpurun_tmp/libserf_sim_*.so 2>/dev/null)
+[ -n "$LIBS" ] && timeout 900 python tools/ab.py --fanout-model krandomnodes --ticks 120 --rounds 3 serf_amd/csrc/libserf_sim.so $LIBS 2>&1 | tail -30
